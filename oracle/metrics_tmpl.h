@@ -1,0 +1,71 @@
+/*
+ * metrics_tmpl.h -- ORACLE (test infrastructure only; see gradus_oracle.h).
+ *
+ * metric_components of the reference written once over an abstract number type so the
+ * oracle can evaluate it on forward-mode dual numbers exactly as the reference does with
+ * ForwardDiff (src/tracing/method-implementations/auto-diff.jl:206-211).
+ *
+ * Include with these macros defined:
+ *   NUM                 number type
+ *   FN(name)            name mangler
+ *   N_CONST(x)          lift a double
+ *   N_ADD N_SUB N_MUL N_DIV (NUM,NUM)->NUM ; N_SCALE(double,NUM) ; N_NEG(NUM)
+ *   N_SIN(NUM) N_COS(NUM)
+ */
+
+/* __BoyerLindquistAD.metric_components, src/metrics/kerr-metric.jl:11-28 */
+static void FN(kerr_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1];
+    const double R = 2.0 * M;
+    NUM s = N_SIN(th);
+    NUM sin2 = N_MUL(s, s);                                /* sinθ2 = sin(θ)^2      :14 */
+    NUM cos2 = N_SUB(N_CONST(1.0), sin2);                  /* cosθ2 = 1 - sinθ2     :15 */
+    NUM r2 = N_MUL(r, r);
+    NUM Sig = N_ADD(r2, N_SCALE(a * a, cos2));             /* Σ₀                    :17 */
+    NUM iSig = N_DIV(N_CONST(1.0), Sig);                   /* Σ₀⁻¹                  :18 */
+    NUM gam = N_SCALE(a, N_MUL(N_SCALE(R, sin2), r));      /* γ = sinθ2*R*r*a       :19 */
+    NUM Rr = N_SCALE(R, r);
+    NUM Delta = N_SUB(N_ADD(r2, N_CONST(a * a)), Rr);      /* Δ(r,R,a)              :7  */
+
+    g[0] = N_NEG(N_SUB(N_CONST(1.0), N_MUL(Rr, iSig)));    /* tt                    :21 */
+    g[1] = N_DIV(Sig, Delta);                              /* rr                    :22 */
+    g[2] = Sig;                                            /* θθ                    :23 */
+    g[3] = N_MUL(sin2, N_ADD(N_ADD(r2, N_CONST(a * a)),
+                             N_MUL(N_SCALE(a, gam), iSig))); /* ϕϕ                  :24 */
+    g[4] = N_NEG(N_MUL(gam, iSig));                        /* tϕ                    :26 */
+}
+
+/* __JohannsenAD.metric_components, src/metrics/johannsen-ad.jl:4-34 */
+static void FN(johannsen_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1], a13 = p[2], a22 = p[3], a52 = p[4], e3 = p[5];
+    NUM Mr = N_DIV(N_CONST(M), r);
+    NUM Mr2 = N_MUL(Mr, Mr);
+    NUM Mr3 = N_MUL(Mr2, Mr);
+    NUM A1 = N_ADD(N_CONST(1.0), N_SCALE(a13, Mr3));       /* A₁ :8  */
+    NUM A2 = N_ADD(N_CONST(1.0), N_SCALE(a22, Mr2));       /* A₂ :9  */
+    NUM A5 = N_ADD(N_CONST(1.0), N_SCALE(a52, Mr2));       /* A₅ :10 */
+    NUM c = N_COS(th);
+    NUM r2 = N_MUL(r, r);
+    NUM f = N_DIV(N_CONST(e3 * M * M * M), r);             /* f  :4  */
+    NUM Sig = N_ADD(N_ADD(r2, N_SCALE(a * a, N_MUL(c, c))), f);   /* Σ :5 */
+    NUM Delta = N_ADD(N_SUB(r2, N_SCALE(2.0 * M, r)), N_CONST(a * a)); /* Δ :6 */
+    NUM r2a2 = N_ADD(r2, N_CONST(a * a));
+    NUM s = N_SIN(th);
+    NUM s2 = N_MUL(s, s);
+    NUM dn = N_SUB(N_MUL(r2a2, A1), N_SCALE(a * a, N_MUL(A2, s2)));
+    NUM denom = N_MUL(dn, dn);                             /* :25 */
+    NUM tt = N_NEG(N_MUL(Sig, N_SUB(Delta, N_SCALE(a * a, N_MUL(N_MUL(A2, A2), s2)))));   /* :27 */
+    NUM rr = N_DIV(Sig, N_MUL(Delta, A5));                 /* :28 */
+    NUM pp = N_MUL(N_MUL(Sig, s2),
+                   N_SUB(N_MUL(N_MUL(r2a2, r2a2), N_MUL(A1, A1)),
+                         N_SCALE(a * a, N_MUL(Delta, s2))));                               /* :30 */
+    NUM tp = N_NEG(N_SCALE(a, N_MUL(N_MUL(Sig, s2),
+                                    N_SUB(N_MUL(N_MUL(r2a2, A1), A2), Delta))));           /* :32 */
+    g[0] = N_DIV(tt, denom);
+    g[1] = rr;
+    g[2] = Sig;
+    g[3] = N_DIV(pp, denom);
+    g[4] = N_DIV(tp, denom);
+}

@@ -1,0 +1,300 @@
+"""ctypes binding of the CPU ORACLE (oracle/gradus_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (gradus.jl_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgradus_oracle.so")
+
+OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 1, 2, 3
+METRIC_KERR, METRIC_JOHANNSEN = 0, 1
+DISC_NONE, DISC_THIN = 0, 1
+PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
+FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("metric_id", C.c_int32),
+        ("disc_id", C.c_int32),
+        ("params", C.c_double * 8),
+        ("r_inner", C.c_double),
+        ("r_outer", C.c_double),
+        ("disc_r_in", C.c_double),
+        ("disc_r_out", C.c_double),
+        ("gtol", C.c_double),
+        ("lambda0", C.c_double),
+        ("lambda1", C.c_double),
+        ("abstol", C.c_double),
+        ("reltol", C.c_double),
+        ("mu", C.c_double),
+        ("maxiters", C.c_int64),
+        ("upper_hemisphere", C.c_int32),
+        ("_pad", C.c_int32),
+        ("hemi_delta", C.c_double),
+    ]
+
+
+POINT_DTYPE = np.dtype(
+    [
+        ("status", np.int32),
+        ("flags", np.int32),
+        ("lambda_min", np.float64),
+        ("lambda_max", np.float64),
+        ("x_init", np.float64, (4,)),
+        ("x", np.float64, (4,)),
+        ("v_init", np.float64, (4,)),
+        ("v", np.float64, (4,)),
+    ],
+    align=True,
+)
+assert POINT_DTYPE.itemsize == 152
+
+STATS_DTYPE = np.dtype(
+    [("accepted", np.int32), ("rejected", np.int32), ("rhs_evals", np.int32), ("cond_evals", np.int32)]
+)
+
+
+class PF(C.Structure):
+    _fields_ = [
+        ("pf_id", C.c_int32),
+        ("filter_id", C.c_int32),
+        ("fill", C.c_double),
+        ("r_isco", C.c_double),
+        ("n_plunge", C.c_int64),
+        ("plunge_r", C.POINTER(C.c_double)),
+        ("plunge_vt", C.POINTER(C.c_double)),
+        ("plunge_vr", C.POINTER(C.c_double)),
+        ("plunge_vphi", C.POINTER(C.c_double)),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("gradus_oracle.c", "gradus_oracle.h", "metrics_tmpl.h")
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        cp = C.POINTER(Config)
+        L.orc_metric_jacobian.argtypes = [cp, C.c_double, C.c_double, dp, dp, dp]
+        L.orc_geodesic_equation.argtypes = [cp, dp, dp, dp]
+        L.orc_constrain_time.argtypes = [cp, dp, dp]
+        L.orc_constrain_time.restype = C.c_double
+        L.orc_lnrbasis.argtypes = [cp, dp, dp]
+        L.orc_lnrframe.argtypes = [cp, dp, dp]
+        L.orc_lnr_transform.argtypes = [cp, dp, dp]
+        L.orc_map_impact_parameters.argtypes = [cp, dp, C.c_double, C.c_double, dp]
+        L.orc_render_velocities.argtypes = [cp, dp] + [C.c_double] * 4 + [C.c_int64] * 4 + [dp]
+        L.orc_trace.argtypes = [cp, dp, C.c_int64, dp, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_trace.restype = C.c_int
+        L.orc_isco.argtypes = [cp]
+        L.orc_isco.restype = C.c_double
+        L.orc_circular_fourvelocity.argtypes = [cp, C.c_double, dp]
+        L.orc_apply_pf.argtypes = [cp, C.POINTER(PF), C.c_void_p, C.c_int64, C.c_double, dp, C.c_int]
+        L.orc_plunging_table.argtypes = [cp, C.c_double, dp, dp, dp, dp, C.c_int64]
+        L.orc_plunging_table.restype = C.c_int64
+        L.orc_tsit5_tableau.argtypes = [dp, dp, dp, dp]
+        L.orc_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def inner_radius(M, a):
+    # inner_radius(m::KerrMetric) = M + sqrt(M^2 - a^2), kerr-metric.jl:72 (same for Johannsen)
+    return M + math.sqrt(M * M - a * a)
+
+
+def make_config(
+    metric="kerr",
+    params=(1.0, 0.0),
+    disc=None,
+    lambda_max=2000.0,
+    lambda_min=0.0,
+    abstol=1e-9,
+    reltol=1e-9,
+    gtol=1e-2,
+    closest_approach=1.01,
+    outer_radius=12000.0,
+    mu=0.0,
+    upper_hemisphere=False,
+    hemi_delta=1e-4,
+    maxiters=1_000_000,
+) -> Config:
+    c = Config()
+    c.metric_id = METRIC_KERR if metric == "kerr" else METRIC_JOHANNSEN
+    for i, p in enumerate(params):
+        c.params[i] = float(p)
+    c.r_inner = inner_radius(params[0], params[1]) * closest_approach
+    c.r_outer = outer_radius
+    if disc is None:
+        c.disc_id = DISC_NONE
+    else:
+        c.disc_id = DISC_THIN
+        c.disc_r_in, c.disc_r_out = float(disc[0]), float(disc[1])
+    c.gtol = gtol
+    c.lambda0, c.lambda1 = lambda_min, lambda_max
+    c.abstol, c.reltol = abstol, reltol
+    c.mu = mu
+    c.maxiters = maxiters
+    c.upper_hemisphere = int(bool(upper_hemisphere))
+    c.hemi_delta = hemi_delta
+    return c
+
+
+def metric_jacobian(cfg, r, th):
+    g, dr, dth = (np.zeros(5) for _ in range(3))
+    lib().orc_metric_jacobian(C.byref(cfg), r, th, _dp(g), _dp(dr), _dp(dth))
+    return g, dr, dth
+
+
+def geodesic_equation(cfg, x, v):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    acc = np.zeros(4)
+    lib().orc_geodesic_equation(C.byref(cfg), _dp(x), _dp(v), _dp(acc))
+    return acc
+
+
+def constrain_time(cfg, x, v):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    return lib().orc_constrain_time(C.byref(cfg), _dp(x), _dp(v))
+
+
+def lnrbasis(cfg, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    T = np.zeros((4, 4))
+    lib().orc_lnrbasis(C.byref(cfg), _dp(x), _dp(T))
+    return T
+
+
+def lnrframe(cfg, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    T = np.zeros((4, 4))
+    lib().orc_lnrframe(C.byref(cfg), _dp(x), _dp(T))
+    return T
+
+
+def lnr_transform(cfg, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    T = np.zeros((4, 4))
+    lib().orc_lnr_transform(C.byref(cfg), _dp(x), _dp(T))
+    return T
+
+
+def map_impact_parameters(cfg, x, alphas, betas):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    alphas = np.atleast_1d(np.asarray(alphas, dtype=np.float64))
+    betas = np.atleast_1d(np.asarray(betas, dtype=np.float64))
+    out = np.zeros((alphas.size, 4))
+    v = np.zeros(4)
+    for i, (a, b) in enumerate(zip(alphas, betas)):
+        lib().orc_map_impact_parameters(C.byref(cfg), _dp(x), float(a), float(b), _dp(v))
+        out[i] = v
+    return out
+
+
+def render_velocities(cfg, x, alims, blims, W, H, i0=0, n=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = W * H - i0 if n is None else n
+    v = np.zeros((n, 4))
+    lib().orc_render_velocities(
+        C.byref(cfg), _dp(x), float(alims[0]), float(alims[1]), float(blims[0]), float(blims[1]), W, H, i0, n, _dp(v)
+    )
+    return v
+
+
+def trace(cfg, x, vs, nthreads=0, stats=False):
+    """tracegeodesics(m, x, vs, ...; ensemble=EnsembleEndpointThreads()) -> GeodesicPoint array."""
+    vs = np.ascontiguousarray(vs, dtype=np.float64).reshape(-1, 4)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    N = vs.shape[0]
+    stride = 0 if x.ndim == 1 else 4
+    out = np.zeros(N, dtype=POINT_DTYPE)
+    st = np.zeros(N, dtype=STATS_DTYPE) if stats else None
+    rc = lib().orc_trace(
+        C.byref(cfg), _dp(x), stride, _dp(vs), N, out.ctypes.data, st.ctypes.data if stats else None, nthreads
+    )
+    if rc != 0:
+        raise RuntimeError(f"orc_trace failed: {rc}")
+    return (out, st) if stats else out
+
+
+def isco(cfg):
+    return lib().orc_isco(C.byref(cfg))
+
+
+def circular_fourvelocity(cfg, r):
+    v = np.zeros(4)
+    lib().orc_circular_fourvelocity(C.byref(cfg), float(r), _dp(v))
+    return v
+
+
+def plunging_table(cfg, r_isco, cap=100000):
+    """PlungingInterpolation (orbit-solving.jl:99-131): returns (r, vt, vr, vphi) sorted by r with
+    the smallest-r row dropped (`sortperm(sol[2, :])[2:end]`)."""
+    r, vt, vr, vp = (np.zeros(cap) for _ in range(4))
+    n = lib().orc_plunging_table(C.byref(cfg), r_isco, _dp(r), _dp(vt), _dp(vr), _dp(vp), cap)
+    idx = np.argsort(r[:n], kind="stable")[1:]
+    return tuple(np.ascontiguousarray(a[:n][idx]) for a in (r, vt, vr, vp))
+
+
+def apply_pf(cfg, points, max_time, pf_id=PF_AFFINE_TIME, filter_id=FILTER_NONE, fill=float("nan"), r_isco=0.0,
+             plunge=None, nthreads=0):
+    pf = PF()
+    pf.pf_id, pf.filter_id, pf.fill, pf.r_isco = pf_id, filter_id, fill, r_isco
+    keep = None
+    if plunge is not None:
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in plunge]
+        pf.n_plunge = keep[0].size
+        pf.plunge_r, pf.plunge_vt, pf.plunge_vr, pf.plunge_vphi = (_dp(a) for a in keep)
+    out = np.zeros(points.shape[0])
+    lib().orc_apply_pf(C.byref(cfg), C.byref(pf), points.ctypes.data, points.shape[0], max_time, _dp(out), nthreads)
+    return out
+
+
+def rendergeodesics(cfg, x, alims, blims, W, H, pf_id=PF_AFFINE_TIME, filter_id=FILTER_EARLY_TERM,
+                    nthreads=0, return_points=False, **pfkw):
+    """rendergeodesics(m, x, [d], λmax; image_width=W, image_height=H, αlims, βlims, pf)
+    (rendering.jl:28-54).  Returns the H x W image (image[y, x]; Julia's column-major H×W)."""
+    v = render_velocities(cfg, x, alims, blims, W, H)
+    pts = trace(cfg, x, v, nthreads=nthreads)
+    img = apply_pf(cfg, pts, cfg.lambda1, pf_id=pf_id, filter_id=filter_id, nthreads=nthreads, **pfkw)
+    img = img.reshape(W, H).T
+    return (img, pts) if return_points else img
+
+
+def tsit5_tableau():
+    c = np.zeros(7)
+    a = np.zeros((7, 7))
+    bt = np.zeros(7)
+    r = np.zeros((7, 4))
+    lib().orc_tsit5_tableau(_dp(c), _dp(a), _dp(bt), _dp(r))
+    return c, a, bt, r
