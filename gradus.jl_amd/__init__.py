@@ -1,0 +1,22 @@
+"""gradus.jl_amd -- MI355X-native backend for Gradus.jl's image-plane render path.
+
+Host-side mirror of the reference API (rendergeodesics / tracegeodesics / PointFunction /
+AbstractMetric) over the C ABI of libgradus_mi355x.so (include/gradus_mi355x.h).  All per-ray
+work runs in hand-written HIP kernels for gfx950; there is no CPU fallback.
+"""
+from . import _lib
+from ._lib import Context, GradusMI355XError, POINT_DTYPE
+from .geometry import ThinDisc
+from .metrics import JohannsenMetric, KerrMetric, inner_radius, isco
+from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix
+from .planes import (CartesianPlane, GeometricGrid, InverseGrid, LinearGrid, PolarPlane, image_plane,
+                     impact_parameters, trajectory_count, unnormalized_areas)
+from .pointfunctions import ConstPointFunctions, FilterPointFunction, FilterStatusCode, PointFunction
+from .rendering import (EndpointRenderCache, apply, impact_axes, prerendergeodesics, render_configuration,
+                        render_into_image, rendergeodesics)
+from .status import StatusCodes
+from .tracing import (EnsembleMI355X, PolarChart, TracingConfiguration, chart_for_metric, domain_upper_hemisphere,
+                      ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
+                      map_impact_parameters, tracegeodesics, tracing_configuration)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

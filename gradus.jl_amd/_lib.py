@@ -1,0 +1,206 @@
+"""ctypes binding of libgradus_mi355x.so (the C ABI declared in include/gradus_mi355x.h).
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950 device is
+present when a context is created, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgradus_mi355x.so")
+
+GR_OK = 0
+ERROR_NAMES = {
+    -1: "GR_ERR_INVALID_ARGUMENT",
+    -2: "GR_ERR_UNSUPPORTED",
+    -3: "GR_ERR_NO_DEVICE",
+    -4: "GR_ERR_HIP",
+    -5: "GR_ERR_OUT_OF_MEMORY",
+}
+
+
+class GradusMI355XError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class gr_config(C.Structure):
+    _fields_ = [
+        ("metric_id", C.c_int32),
+        ("disc_id", C.c_int32),
+        ("params", C.c_double * 8),
+        ("r_inner", C.c_double),
+        ("r_outer", C.c_double),
+        ("disc_r_in", C.c_double),
+        ("disc_r_out", C.c_double),
+        ("gtol", C.c_double),
+        ("lambda0", C.c_double),
+        ("lambda1", C.c_double),
+        ("abstol", C.c_double),
+        ("reltol", C.c_double),
+        ("mu", C.c_double),
+        ("maxiters", C.c_int64),
+        ("upper_hemisphere", C.c_int32),
+        ("_pad", C.c_int32),
+        ("hemi_delta", C.c_double),
+    ]
+
+
+class gr_plane(C.Structure):
+    _fields_ = [
+        ("x_obs", C.c_double * 4),
+        ("Mx", C.c_double * 16),
+        ("alpha0", C.c_double),
+        ("alpha1", C.c_double),
+        ("beta0", C.c_double),
+        ("beta1", C.c_double),
+        ("width", C.c_int64),
+        ("height", C.c_int64),
+        ("offset", C.c_double),
+    ]
+
+
+class gr_range(C.Structure):
+    _fields_ = [("first", C.c_int64), ("count", C.c_int64), ("block", C.c_int64), ("stride_blocks", C.c_int64)]
+
+
+class gr_pointfunction(C.Structure):
+    _fields_ = [
+        ("pf_id", C.c_int32),
+        ("filter_id", C.c_int32),
+        ("fill", C.c_double),
+        ("r_isco", C.c_double),
+        ("n_plunge", C.c_int64),
+        ("plunge_r", C.POINTER(C.c_double)),
+        ("plunge_vt", C.POINTER(C.c_double)),
+        ("plunge_vr", C.POINTER(C.c_double)),
+        ("plunge_vphi", C.POINTER(C.c_double)),
+    ]
+
+
+class gr_stats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_int64),
+        ("accepted_steps", C.c_int64),
+        ("rejected_steps", C.c_int64),
+        ("rhs_evals", C.c_int64),
+        ("flagged_rays", C.c_int64),
+        ("status_count", C.c_int64 * 4),
+        ("kernel_ms", C.c_double),
+    ]
+
+    def asdict(self):
+        return {
+            "rays": self.rays,
+            "accepted_steps": self.accepted_steps,
+            "rejected_steps": self.rejected_steps,
+            "rhs_evals": self.rhs_evals,
+            "flagged_rays": self.flagged_rays,
+            "status_count": list(self.status_count),
+            "kernel_ms": self.kernel_ms,
+        }
+
+
+# GeodesicPoint{Float64,Nothing}: 152 bytes (src/solution-processing.jl:15-32)
+POINT_DTYPE = np.dtype(
+    [
+        ("status", np.int32),
+        ("flags", np.int32),
+        ("lambda_min", np.float64),
+        ("lambda_max", np.float64),
+        ("x_init", np.float64, (4,)),
+        ("x", np.float64, (4,)),
+        ("v_init", np.float64, (4,)),
+        ("v", np.float64, (4,)),
+    ],
+    align=True,
+)
+assert POINT_DTYPE.itemsize == 152
+
+# every symbol include/gradus_mi355x.h declares
+EXPORTS = [
+    "gr_abi_version",
+    "gr_last_error",
+    "gr_ctx_create",
+    "gr_ctx_destroy",
+    "gr_ctx_set",
+    "gr_render_device",
+    "gr_render",
+    "gr_render_endpoints_device",
+    "gr_render_endpoints",
+    "gr_trace_endpoints_device",
+    "gr_trace_endpoints",
+    "gr_apply_pointfunction_device",
+    "gr_apply_pointfunction",
+]
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GradusMI355XError(
+            -3, f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.gr_abi_version.restype = i32
+    L.gr_last_error.restype = C.c_char_p
+    L.gr_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.gr_ctx_destroy.argtypes = [vp]
+    L.gr_ctx_set.argtypes = [vp, C.c_char_p, i64]
+    cfgp, plp, pfp, rgp, stp = (C.POINTER(t) for t in (gr_config, gr_plane, gr_pointfunction, gr_range, gr_stats))
+    L.gr_render_device.argtypes = [vp, cfgp, plp, pfp, rgp, vp, vp, vp]
+    L.gr_render.argtypes = [vp, cfgp, plp, pfp, rgp, vp, stp]
+    L.gr_render_endpoints_device.argtypes = [vp, cfgp, plp, rgp, vp, vp, vp]
+    L.gr_render_endpoints.argtypes = [vp, cfgp, plp, rgp, vp, stp]
+    L.gr_trace_endpoints_device.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, vp, vp]
+    L.gr_trace_endpoints.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, stp]
+    L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]
+    L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
+    for name in EXPORTS:
+        if name not in ("gr_last_error",):
+            getattr(L, name).restype = i32
+    L.gr_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != GR_OK:
+        raise GradusMI355XError(code, load().gr_last_error().decode("utf-8", "replace"))
+
+
+class Context:
+    """Owns one gr_ctx (one HIP device)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        check(self._lib.gr_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def set(self, key: str, value: int):
+        check(self._lib.gr_ctx_set(self.handle, key.encode(), int(value)))
+        return self
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.gr_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

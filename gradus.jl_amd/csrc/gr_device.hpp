@@ -1,0 +1,868 @@
+// gr_device.hpp -- device-side physics and the per-lane Tsit5 ray integrator (gfx950).
+//
+// One null geodesic per work-item, the whole ODE state in VGPRs.  What this replaces in the
+// reference (Gradus.jl, citations into /root/reference):
+//   metric_components + ForwardDiff Jacobian   src/metrics/kerr-metric.jl:11-28,
+//                                              src/metrics/johannsen-ad.jl:12-34,
+//                                              src/tracing/method-implementations/auto-diff.jl:206-211
+//   inverse_metric_components                  auto-diff.jl:59-76
+//   compute_geodesic_equation                  auto-diff.jl:115-141
+//   constrain_time                             auto-diff.jl:161-179
+//   Tsit5 / PI controller / initial dt / callbacks  (OrdinaryDiffEq, DiffEqBase)
+//   chart callback                             src/tracing/charts.jl:9-23
+//   ThinDisc distance_to_disc                  src/geometry/discs/thin-disc.jl:20-26
+//   unpack_solution -> GeodesicPoint           src/solution-processing.jl:86-112
+//   PointFunctions / redshift                  src/const-point-functions.jl:26-79, src/redshift.jl:93-220
+//
+// Design notes (MI355X): fp64 VALU-bound.  Everything is fully unrolled with compile-time
+// tableau constants so no array is runtime-indexed (no scratch); divisions go through one
+// shared v_rcp_f64 + Newton per RHS; sin/cos use a branch-free Cody-Waite + minimax kernel
+// instead of the library's Payne-Hanek-capable sincos; the error norm is kept squared so the
+// step controller needs one log2 and one exp2 per step and no sqrt.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gradus_mi355x.h"
+
+namespace gr {
+
+#define GR_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------------
+GR_DEV double rcp_full(double x)
+{
+    // v_rcp_f64 seed + two Newton steps: <= 1 ulp for normal, finite x
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+GR_DEV double rcp_fast(double x)
+{
+    // one Newton step: ~1e-14 relative or better; used where the consumer is a tolerance test
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+GR_DEV int sgn(double x) { return (x > 0.0) - (x < 0.0); }
+
+// sin and cos of x for moderate |x| (|x| < ~1e5): two-term Cody-Waite reduction by pi/2 with
+// exact-product FMAs, then the fdlibm minimax kernels on [-pi/4, pi/4].  < 1 ulp each.
+GR_DEV void sincos_fast(double x, double& s_out, double& c_out)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632679489655800e+00;
+    const double PIO2_LO = 6.12323399573676603587e-17;
+    const double kf = __builtin_rint(x * TWO_OVER_PI);
+    double y = __builtin_fma(-kf, PIO2_HI, x);
+    y = __builtin_fma(-kf, PIO2_LO, y);
+    const int q = (int)kf;
+    const double z = y * y;
+    // __kernel_sin
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double ps = __builtin_fma(z, S6, S5);
+    ps = __builtin_fma(z, ps, S4);
+    ps = __builtin_fma(z, ps, S3);
+    ps = __builtin_fma(z, ps, S2);
+    ps = __builtin_fma(z, ps, S1);
+    const double sn = __builtin_fma(y * z, ps, y);
+    // __kernel_cos
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double pc = __builtin_fma(z, C6, C5);
+    pc = __builtin_fma(z, pc, C4);
+    pc = __builtin_fma(z, pc, C3);
+    pc = __builtin_fma(z, pc, C2);
+    pc = __builtin_fma(z, pc, C1);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + z * (z * pc));
+    // quadrant
+    const double s0 = (q & 1) ? cs : sn;
+    const double c0 = (q & 1) ? sn : cs;
+    s_out = (q & 2) ? -s0 : s0;
+    c_out = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward-mode dual number with two partials, for metrics without hand-written derivatives
+// (the reference differentiates every metric this way, auto-diff.jl:206-211).
+// ---------------------------------------------------------------------------------------
+struct Dual2 {
+    double v, a, b;
+};
+GR_DEV Dual2 dconst(double x) { return { x, 0.0, 0.0 }; }
+GR_DEV Dual2 operator+(Dual2 x, Dual2 y) { return { x.v + y.v, x.a + y.a, x.b + y.b }; }
+GR_DEV Dual2 operator-(Dual2 x, Dual2 y) { return { x.v - y.v, x.a - y.a, x.b - y.b }; }
+GR_DEV Dual2 operator-(Dual2 x) { return { -x.v, -x.a, -x.b }; }
+GR_DEV Dual2 operator+(Dual2 x, double y) { return { x.v + y, x.a, x.b }; }
+GR_DEV Dual2 operator+(double y, Dual2 x) { return { x.v + y, x.a, x.b }; }
+GR_DEV Dual2 operator-(Dual2 x, double y) { return { x.v - y, x.a, x.b }; }
+GR_DEV Dual2 operator-(double y, Dual2 x) { return { y - x.v, -x.a, -x.b }; }
+GR_DEV Dual2 operator*(double s, Dual2 x) { return { s * x.v, s * x.a, s * x.b }; }
+GR_DEV Dual2 operator*(Dual2 x, double s) { return { s * x.v, s * x.a, s * x.b }; }
+GR_DEV Dual2 operator*(Dual2 x, Dual2 y)
+{
+    return { x.v * y.v, __builtin_fma(x.a, y.v, x.v * y.a), __builtin_fma(x.b, y.v, x.v * y.b) };
+}
+GR_DEV Dual2 dinv(Dual2 y)
+{
+    const double i = rcp_full(y.v);
+    const double m = -i * i;
+    return { i, m * y.a, m * y.b };
+}
+GR_DEV Dual2 operator/(Dual2 x, Dual2 y) { return x * dinv(y); }
+
+// ---------------------------------------------------------------------------------------
+// Metrics.  eval() returns, for the block form (tt, rr, θθ, ϕϕ, tϕ):
+//   g[5], gr[5] = ∂_r g, gt[5] = ∂_θ g, gi[5] = inverse components (tt, rr, θθ, ϕϕ, tϕ)
+// given r and (sinθ, cosθ).
+// ---------------------------------------------------------------------------------------
+GR_DEV void inverse_generic(const double g[5], double gi[5])
+{
+    // inverse_metric_components, auto-diff.jl:59-76, with a single reciprocal
+    const double D = __builtin_fma(g[0], g[3], -g[4] * g[4]);
+    const double rt = g[1] * g[2];
+    const double P = rcp_full(D * rt);
+    const double iD = P * rt;
+    gi[0] = g[3] * iD;
+    gi[1] = P * D * g[2];
+    gi[2] = P * D * g[1];
+    gi[3] = g[0] * iD;
+    gi[4] = -g[4] * iD;
+}
+
+struct KerrMetric {
+    double M, a;
+    GR_DEV void load(const double* p) { M = p[0]; a = p[1]; }
+
+    // values only (constraint, redshift)
+    GR_DEV void comps(double r, double s, double c, double g[5]) const
+    {
+        const double r2 = r * r, a2 = a * a, s2 = s * s;
+        const double Sig = __builtin_fma(a2, c * c, r2);
+        const double Del = __builtin_fma(-2.0 * M, r, r2) + a2;
+        const double iSig = rcp_full(Sig);
+        const double w = 2.0 * M * r * iSig;
+        g[0] = w - 1.0;
+        g[1] = Sig * rcp_full(Del);
+        g[2] = Sig;
+        g[4] = -a * s2 * w;
+        g[3] = s2 * (r2 + a2 - a * g[4]);
+    }
+
+    // hand-differentiated kerr-metric.jl:11-28; one reciprocal for everything
+    GR_DEV void eval(double r, double s, double c, double g[5], double gr[5], double gt[5], double gi[5]) const
+    {
+        const double r2 = r * r, a2 = a * a, s2 = s * s, sc = s * c;
+        const double Sig = __builtin_fma(a2, c * c, r2);
+        const double Del = __builtin_fma(-2.0 * M, r, r2) + a2;
+        const double P = rcp_full(Sig * Del * s2);
+        const double Ds2 = Del * s2;
+        const double iSig = P * Ds2;           // 1/Σ
+        const double iDel = P * Sig * s2;      // 1/Δ
+        const double iDs = P * Sig;            // 1/(Δ sin²θ)
+        const double tM = 2.0 * M;
+        const double w = tM * r * iSig;        // 2Mr/Σ
+        const double iSig2 = iSig * iSig;
+        const double w_r = tM * (Sig - 2.0 * r2) * iSig2;
+        const double Sig_t = -2.0 * a2 * sc;
+        const double w_t = -w * Sig_t * iSig;
+        const double as2 = a * s2;
+        const double tr = 2.0 * r;
+
+        g[0] = w - 1.0;
+        g[1] = Sig * iDel;
+        g[2] = Sig;
+        g[4] = -as2 * w;
+        const double B = r2 + a2 - a * g[4];
+        g[3] = s2 * B;
+
+        gr[0] = w_r;
+        gr[1] = (tr - g[1] * (tr - tM)) * iDel;
+        gr[2] = tr;
+        gr[4] = -as2 * w_r;
+        gr[3] = s2 * (tr - a * gr[4]);
+
+        gt[0] = w_t;
+        gt[1] = Sig_t * iDel;
+        gt[2] = Sig_t;
+        gt[4] = -a * (2.0 * sc * w + s2 * w_t);
+        gt[3] = 2.0 * sc * B - as2 * gt[4];
+
+        // g_tt g_ϕϕ - g_tϕ² = -Δ sin²θ for Kerr
+        gi[0] = -B * iDel;
+        gi[1] = Del * iSig;
+        gi[2] = iSig;
+        gi[3] = -g[0] * iDs;
+        gi[4] = g[4] * iDs;
+    }
+};
+
+struct JohannsenMetric {
+    double M, a, a13, a22, a52, e3;
+    GR_DEV void load(const double* p) { M = p[0]; a = p[1]; a13 = p[2]; a22 = p[3]; a52 = p[4]; e3 = p[5]; }
+
+    // johannsen-ad.jl:12-34 on an arbitrary number type
+    template <class T>
+    GR_DEV void components(T r, T s, T c, T g[5]) const
+    {
+        const double a2 = a * a;
+        T Mr = M * inv_(r);
+        T Mr2 = Mr * Mr;
+        T A1 = 1.0 + a13 * (Mr2 * Mr);
+        T A2 = 1.0 + a22 * Mr2;
+        T A5 = 1.0 + a52 * Mr2;
+        T r2 = r * r;
+        T Sig = r2 + a2 * (c * c) + (e3 * M * M * M) * inv_(r);
+        T Del = r2 - (2.0 * M) * r + a2;
+        T r2a2 = r2 + a2;
+        T s2 = s * s;
+        T dn = r2a2 * A1 - a2 * (A2 * s2);
+        T idenom = inv_(dn * dn);
+        T tt = -(Sig * (Del - a2 * (A2 * A2 * s2)));
+        T pp = (Sig * s2) * ((r2a2 * r2a2) * (A1 * A1) - a2 * (Del * s2));
+        T tp = -(a * ((Sig * s2) * (r2a2 * A1 * A2 - Del)));
+        g[0] = tt * idenom;
+        g[1] = Sig * inv_(Del * A5);
+        g[2] = Sig;
+        g[3] = pp * idenom;
+        g[4] = tp * idenom;
+    }
+    static GR_DEV double inv_(double x) { return rcp_full(x); }
+    static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
+
+    GR_DEV void comps(double r, double s, double c, double g[5]) const { components<double>(r, s, c, g); }
+
+    GR_DEV void eval(double r, double s, double c, double g[5], double gr[5], double gt[5], double gi[5]) const
+    {
+        Dual2 gd[5];
+        // seeds: r = (r;1,0), sinθ = (s;0,c), cosθ = (c;0,-s)
+        components<Dual2>(Dual2{ r, 1.0, 0.0 }, Dual2{ s, 0.0, c }, Dual2{ c, 0.0, -s }, gd);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            g[i] = gd[i].v;
+            gr[i] = gd[i].a;
+            gt[i] = gd[i].b;
+        }
+        inverse_generic(g, gi);
+    }
+};
+
+// geodesic_equation (auto-diff.jl:213-226) with the sparse contraction of SURVEY App. B.1.
+// Also returns sinθ, cosθ of the evaluation point (re-used by the disc condition).
+template <class Metric>
+GR_DEV void geodesic_rhs(const Metric& m, double r, double th, double vt, double vr, double vh, double vp,
+                         double& at, double& ar, double& ah, double& ap, double& s, double& c)
+{
+    double g[5], j1[5], j2[5], gi[5];
+    sincos_fast(th, s, c);
+    m.eval(r, s, c, g, j1, j2, gi);
+    double gd[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) gd[k] = __builtin_fma(j1[k], vr, j2[k] * vh);
+    const double vt2 = vt * vt, vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp, vtp = 2.0 * vt * vp;
+    const double Dr = j1[0] * vt2 + j1[1] * vr2 + j1[2] * vh2 + j1[3] * vp2 + j1[4] * vtp;
+    const double Dh = j2[0] * vt2 + j2[1] * vr2 + j2[2] * vh2 + j2[3] * vp2 + j2[4] * vtp;
+    const double St = 2.0 * (gd[0] * vt + gd[4] * vp);
+    const double Sr = 2.0 * gd[1] * vr - Dr;
+    const double Sh = 2.0 * gd[2] * vh - Dh;
+    const double Sp = 2.0 * (gd[4] * vt + gd[3] * vp);
+    at = -0.5 * (gi[0] * St + gi[4] * Sp);
+    ar = -0.5 * (gi[1] * Sr);
+    ah = -0.5 * (gi[2] * Sh);
+    ap = -0.5 * (gi[4] * St + gi[3] * Sp);
+}
+
+// constrain_time, auto-diff.jl:161-179
+GR_DEV double constrain_time(const double g[5], double vr, double vh, double vp, double mu)
+{
+    const double disc = -g[0] * g[1] * vr * vr - g[0] * g[2] * vh * vh - g[0] * mu * mu
+                        - (g[0] * g[3] - g[4] * g[4]) * vp * vp;
+    return -(g[4] * vp + ::sqrt(disc)) / g[0];
+}
+
+// ---------------------------------------------------------------------------------------
+// Tsit5 tableau, dense output
+// ---------------------------------------------------------------------------------------
+struct Ts {
+    static constexpr double A[7][6] = {
+        { 0, 0, 0, 0, 0, 0 },
+        { 0.161, 0, 0, 0, 0, 0 },
+        { -0.008480655492356989, 0.335480655492357, 0, 0, 0, 0 },
+        { 2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0 },
+        { 5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0 },
+        { 5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0 },
+        { 0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774 },
+    };
+    static constexpr double BT[7] = { -0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+                                      -0.1447110071732629,     0.5823571654525552,     -0.45808210592918697,
+                                      0.015151515151515152 };
+    // b_i(Θ) = Σ_m R[i][m] Θ^(m+1)
+    static constexpr double R[7][4] = {
+        { 1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216 },
+        { 0.0, 0.13169999999999998, -0.2234, 0.1017 },
+        { 0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253 },
+        { 0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902 },
+        { 0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928 },
+        { 0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661 },
+        { 0.0, 1.5, -4.0, 2.5 },
+    };
+};
+
+// PI controller constants (App. A.3)
+constexpr double PI_BETA1 = 7.0 / 50.0;
+constexpr double PI_BETA2 = 2.0 / 25.0;
+constexpr double PI_GAMMA = 0.9;
+constexpr double PI_QMIN = 0.2;
+constexpr double PI_QMAX = 10.0;
+constexpr double LOG2_QOLDINIT = -13.287712379549449;  // log2(1e-4)
+
+// ---------------------------------------------------------------------------------------
+// kernel parameter block (uniform, lives in the kernarg segment / SGPRs)
+// ---------------------------------------------------------------------------------------
+struct PfDev {
+    int32_t pf_id, filter_id;
+    double fill, r_isco;
+    int64_t n_plunge;
+    const double* plunge_r;   // device
+    const double* plunge_vt;
+    const double* plunge_vr;
+    const double* plunge_vphi;
+};
+
+struct Params {
+    gr_config cfg;
+    int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays
+    int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records
+    gr_plane plane;
+    gr_range range;
+    const double* x;          // device
+    int64_t x_stride;
+    const double* v;          // device
+    int64_t n;                // rays in this call
+    double* image;            // device
+    gr_point* points;         // device
+    PfDev pf;
+    unsigned long long* stats;  // device: 9 counters (see gr_stats order), may be null
+    unsigned long long* queue;  // device: persistent-kernel work counter
+    int32_t refill_threshold;
+    int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
+};
+
+// local ray index -> swizzled local index so that 64 consecutive work items cover an 8x8 tile
+GR_DEV int64_t tile_swizzle(const Params& p, int64_t j)
+{
+    if (!p.swizzle) return j;
+    const int64_t H = p.plane.height;
+    const int64_t tile = j >> 6;
+    const int lane = (int)(j & 63);
+    const int64_t tiles_per_col = H >> 3;
+    const int64_t tx = tile / tiles_per_col, ty = tile - tx * tiles_per_col;
+    return ((tx << 3) + (lane >> 3)) * H + (ty << 3) + (lane & 7);
+}
+
+GR_DEV int64_t range_map(const gr_range& rg, int64_t j)
+{
+    const int64_t b = j / rg.block;
+    return rg.first + b * rg.stride_blocks * rg.block + (j - b * rg.block);
+}
+
+GR_DEV double range_at(double a, double b, int64_t n, int64_t k)
+{
+    if (n <= 1) return a;
+    const double t = (double)k / (double)(n - 1);
+    return (1.0 - t) * a + t * b;
+}
+
+// ---------------------------------------------------------------------------------------
+// point functions on a finished ray
+// ---------------------------------------------------------------------------------------
+GR_DEV double kerr_plunge_Le(double M, double rms, double a)
+{
+    // Lₑ, redshift.jl:93
+    return ::sqrt(M) * (rms * rms - 2.0 * a * ::sqrt(M * rms) + a * a)
+           / (rms * ::sqrt(rms) - 2.0 * M * ::sqrt(rms) + a * ::sqrt(M));
+}
+
+GR_DEV double nan_linear_interp(const double* t, const double* y, int64_t n, double x)
+{
+    // NaNLinearInterpolator, interpolations.jl:7-29
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (t[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    int64_t idx = lo < 1 ? 1 : lo;
+    if (idx > n - 1) idx = n - 1;
+    const double x1 = t[idx - 1], x2 = t[idx], y1 = y[idx - 1], y2 = y[idx];
+    const double w = (x - x1) / (x2 - x1);
+    const double v = (1.0 - w) * y1 + w * y2;
+    if (!(v == v)) {
+        if (w < 0.5) return (y1 == y1) ? y1 : 0.0;
+        return (y2 == y2) ? y2 : 0.0;
+    }
+    return v;
+}
+
+// CircularOrbits.fourvelocity(m, ρ) at θ = π/2, circular-orbits.jl:11-37,58-61,114-121
+template <class Metric>
+GR_DEV void circular_fourvelocity(const Metric& m, double rho, double& vt, double& vp)
+{
+    double g[5], j1[5], j2[5], gi[5];
+    m.eval(rho, 1.0, 0.0, g, j1, j2, gi);
+    const double Dl = ::sqrt(j1[4] * j1[4] - j1[0] * j1[3]);
+    const double Om = -(j1[4] - Dl) / j1[3];
+    const double A = -(Om * gi[0] - gi[4]);
+    const double B = (Om * gi[4] - gi[3]);
+    const double den = B * B * gi[0] + 2.0 * A * B * gi[4] + A * A * gi[3];
+    const double d = -(double)sgn(den) * ::sqrt(1.0 / ::fabs(den));
+    const double ut = B * d, up = A * d;
+    vt = gi[0] * ut + gi[4] * up;
+    vp = gi[4] * ut + gi[3] * up;
+}
+
+// redshift_function(m, gp) / interpolate_redshift closure; redshift.jl:192-220,246-276
+template <class Metric>
+GR_DEV double redshift_pf(const Metric& m, const Params& p, const double x0[4], const double v0[4],
+                          const double x[4], const double v[4])
+{
+    double s, c;
+    sincos_fast(x[2], s, c);
+    const double rho = x[1] * ::fabs(s);
+    double dt_, dr_, dp_;
+    const bool kerr_analytic = (p.cfg.metric_id == GR_METRIC_KERR) && (p.pf.n_plunge == 0);
+    const double isco = p.pf.r_isco;
+    if (rho < isco) {
+        if (kerr_analytic) {
+            const double M = p.cfg.params[0], a = p.cfg.params[1];
+            const double Le = kerr_plunge_Le(M, isco, a);
+            const double H = (2.0 * M * rho - a * Le) / (rho * rho - 2.0 * M * rho + a * a);
+            const double ge = ::sqrt(1.0 - (2.0 * M) / (3.0 * isco));
+            const double q = isco / rho - 1.0;
+            const double ur = -::sqrt((2.0 * M) / (3.0 * isco)) * q * ::sqrt(q);
+            dt_ = ge * (1.0 + 2.0 * M * (1.0 + H) / rho);
+            dr_ = -ur;
+            dp_ = ge / (rho * rho) * (Le + a * H);
+        } else {
+            double rb = rho;
+            const int64_t n = p.pf.n_plunge;
+            if (rb < p.pf.plunge_r[0]) rb = p.pf.plunge_r[0];
+            if (rb > p.pf.plunge_r[n - 1]) rb = p.pf.plunge_r[n - 1];
+            dt_ = nan_linear_interp(p.pf.plunge_r, p.pf.plunge_vt, n, rb);
+            dr_ = -nan_linear_interp(p.pf.plunge_r, p.pf.plunge_vr, n, rb);
+            dp_ = nan_linear_interp(p.pf.plunge_r, p.pf.plunge_vphi, n, rb);
+        }
+    } else {
+        circular_fourvelocity(m, rho, dt_, dp_);
+        dr_ = 0.0;
+    }
+    // _redshift_dotproduct: E_obs / E_disc with v_obs = (1,0,0,0)
+    double g[5];
+    m.comps(x[1], s, c, g);
+    const double E_disc = (g[0] * v[0] + g[4] * v[3]) * dt_ + g[1] * v[1] * dr_ + (g[4] * v[0] + g[3] * v[3]) * dp_;
+    double s0, c0, g0[5];
+    sincos_fast(x0[2], s0, c0);
+    m.comps(x0[1], s0, c0, g0);
+    const double E_obs = g0[0] * v0[0] + g0[4] * v0[3];
+    return E_obs / E_disc;
+}
+
+// ---------------------------------------------------------------------------------------
+// The per-lane integrator.
+// ---------------------------------------------------------------------------------------
+template <class Metric, int DISC>
+struct Ray {
+    double u[8];        // (t, r, θ, ϕ, v^t, v^r, v^θ, v^ϕ) at the start of the current step
+    double k[7][8];     // Tsit5 stages; k[0] is FSAL
+    double t, dt, h;    // affine time, proposed step, last used step
+    double lq_old;      // log2(qold)
+    double cprev;       // disc condition at u
+    double ev_top;      // Θ of the upper bracket when an event is pending
+    int64_t j;          // local (swizzled) ray index
+    int32_t status, flags, event;
+    int32_t nacc, nrej;
+    int64_t iters;
+
+    // distance_to_disc(::ThinDisc), thin-disc.jl:20-26
+    static GR_DEV double disc_cond(const Params& p, double r, double s, double c)
+    {
+        const double rho = r * ::fabs(s);
+        if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
+        return r * ::fabs(c) - p.cfg.gtol * ::fabs(r);
+    }
+
+    // DiscreteCallbacks in CallbackSet order: domain_upper_hemisphere, then the chart
+    static GR_DEV bool discrete_cb(const Params& p, double r, double c, int32_t& st)
+    {
+        bool term = false;
+        if (p.cfg.upper_hemisphere && r * c < p.cfg.hemi_delta) { st = GR_STATUS_OUT_OF_DOMAIN; term = true; }
+        if (r <= p.cfg.r_inner || r > p.cfg.r_outer) {
+            st = (r <= p.cfg.r_inner) ? GR_STATUS_WITHIN_INNER_BOUNDARY : GR_STATUS_OUT_OF_DOMAIN;
+            term = true;
+        }
+        return term;
+    }
+
+    // initial position / unconstrained velocity of local ray jl
+    static GR_DEV void initial_conditions(const Params& p, int64_t jl, double x[4], double v[4])
+    {
+        if (p.src_mode == 0) {
+            // _render_velocity_function, rendering.jl:140-163 ; local_momentum, utility.jl:13-20
+            const int64_t i = range_map(p.range, jl);
+            const int64_t H = p.plane.height;
+            const int64_t xi = i / H, yi = i - xi * H;
+            const double alpha = range_at(p.plane.alpha0, p.plane.alpha1, p.plane.width, xi) + p.plane.offset;
+            const double beta = range_at(p.plane.beta0, p.plane.beta1, H, yi) + p.plane.offset;
+            const double ro = p.plane.x_obs[1];
+            const double b = beta / ro, a = alpha / ro;
+            const double pr = -1.0 / ::sqrt(1.0 + a * a + b * b);
+            const double pb[4] = { 1.0, pr, b * pr, a * pr };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x[q] = p.plane.x_obs[q];
+                v[q] = p.plane.Mx[q * 4 + 0] * pb[0] + p.plane.Mx[q * 4 + 1] * pb[1] + p.plane.Mx[q * 4 + 2] * pb[2]
+                       + p.plane.Mx[q * 4 + 3] * pb[3];
+            }
+        } else {
+            const double* xs = p.x + jl * p.x_stride;
+            const double* vs = p.v + jl * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { x[q] = xs[q]; v[q] = vs[q]; }
+        }
+    }
+
+    // constrain_all (constraints.jl:14-15): v^t from the null/mass-shell condition
+    static GR_DEV void constrained_u0(const Metric& m, const Params& p, int64_t jl, double u0[8])
+    {
+        double x[4], v[4];
+        initial_conditions(p, jl, x, v);
+        double s, c, g[5];
+        sincos_fast(x[2], s, c);
+        m.comps(x[1], s, c, g);
+        v[0] = constrain_time(g, v[1], v[2], v[3], p.cfg.mu);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { u0[q] = x[q]; u0[4 + q] = v[q]; }
+    }
+
+    GR_DEV void rhs_at(const Metric& m, const double y[8], double kk[8], double& s, double& c) const
+    {
+        kk[0] = y[4]; kk[1] = y[5]; kk[2] = y[6]; kk[3] = y[7];
+        geodesic_rhs(m, y[1], y[2], y[4], y[5], y[6], y[7], kk[4], kk[5], kk[6], kk[7], s, c);
+    }
+
+    // reinit! + auto_dt_reset! (tracing.jl:234-243; App. A.4)
+    GR_DEV void init(const Metric& m, const Params& p, int64_t jl)
+    {
+        j = jl;
+        status = GR_STATUS_NO_STATUS;
+        flags = 0; event = 0; nacc = 0; nrej = 0; iters = 0;
+        constrained_u0(m, p, jl, u);
+        t = p.cfg.lambda0;
+        h = 0.0; ev_top = 0.0;
+        lq_old = LOG2_QOLDINIT;
+        double s, c;
+        rhs_at(m, u, k[0], s, c);
+        cprev = DISC ? disc_cond(p, u[1], s, c) : 1.0;
+
+        const double abstol = p.cfg.abstol, reltol = p.cfg.reltol;
+        const double dtmax = ::fabs(p.cfg.lambda1 - p.cfg.lambda0);
+        double isk[8], d0s = 0.0, d1s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            isk[i] = rcp_full(abstol + ::fabs(u[i]) * reltol);
+            const double a0 = u[i] * isk[i], a1 = k[0][i] * isk[i];
+            d0s = __builtin_fma(a0, a0, d0s);
+            d1s = __builtin_fma(a1, a1, d1s);
+        }
+        const double d0 = ::sqrt(d0s * 0.125), d1 = ::sqrt(d1s * 0.125);
+        double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+        dt0 = ::fmin(dt0, dtmax);
+        if (dt0 < 10.0 * 2.220446049250313e-16) {
+            dt = 1e-6;
+        } else {
+            double y[8], f1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = __builtin_fma(dt0, k[0][i], u[i]);
+            rhs_at(m, y, f1, s, c);
+            double d2s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double a2 = (f1[i] - k[0][i]) * isk[i];
+                d2s = __builtin_fma(a2, a2, d2s);
+            }
+            const double d2 = ::sqrt(d2s * 0.125) / dt0;
+            const double dm = ::fmax(d1, d2);
+            const double dt1 = (dm <= 1e-15) ? ::fmax(1e-6, dt0 * 1e-3) : ::exp10(-(2.0 + ::log10(dm)) / 5.0);
+            dt = ::fmin(::fmin(100.0 * dt0, dt1), dtmax);
+        }
+    }
+
+    // One attempted Tsit5 step.  Returns true when the ray has finished (terminated by a
+    // callback, reached λ1, or hit an anomaly).
+    GR_DEV bool step(const Metric& m, const Params& p)
+    {
+        const double tend = p.cfg.lambda1;
+        const double dtmax = ::fabs(tend - p.cfg.lambda0);
+        if (++iters > p.cfg.maxiters) { flags |= GR_FLAG_MAXITERS; return true; }
+        double hh = ::fmin(dt, dtmax);
+        if (!(hh == hh)) { flags |= GR_FLAG_NAN; return true; }
+        if (hh < 4.0 * 2.220446049250313e-16 * ::fmax(::fabs(t), 1.0)) { flags |= GR_FLAG_DTMIN; return true; }
+        hh = ::fmin(hh, tend - t);
+        h = hh;
+
+        double y[8], s, c;
+        // stages 2..6 (arguments need r, θ and the four velocities only: the RHS does not
+        // depend on t or ϕ)
+#define GR_STAGE(S)                                                                               \
+    {                                                                                             \
+        _Pragma("unroll") for (int i = 1; i < 8; ++i)                                             \
+        {                                                                                         \
+            if (i == 3) continue;                                                                 \
+            double acc = Ts::A[S][0] * k[0][i];                                                   \
+            _Pragma("unroll") for (int q = 1; q < S; ++q) acc = __builtin_fma(Ts::A[S][q], k[q][i], acc); \
+            y[i] = __builtin_fma(hh, acc, u[i]);                                                  \
+        }                                                                                         \
+        rhs_at(m, y, k[S], s, c);                                                                 \
+    }
+        GR_STAGE(1)
+        GR_STAGE(2)
+        GR_STAGE(3)
+        GR_STAGE(4)
+        GR_STAGE(5)
+#undef GR_STAGE
+        // stage 7 argument = the new state (all eight components)
+        double un[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double acc = Ts::A[6][0] * k[0][i];
+#pragma unroll
+            for (int q = 1; q < 6; ++q) acc = __builtin_fma(Ts::A[6][q], k[q][i], acc);
+            un[i] = __builtin_fma(hh, acc, u[i]);
+        }
+        double sn, cn;
+        rhs_at(m, un, k[6], sn, cn);
+
+        // error estimate, squared RMS norm
+        const double abstol = p.cfg.abstol, reltol = p.cfg.reltol;
+        double e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double acc = Ts::BT[0] * k[0][i];
+#pragma unroll
+            for (int q = 1; q < 7; ++q) acc = __builtin_fma(Ts::BT[q], k[q][i], acc);
+            const double sk = __builtin_fma(::fmax(::fabs(u[i]), ::fabs(un[i])), reltol, abstol);
+            const double a = hh * acc * rcp_fast(sk);
+            e2 = __builtin_fma(a, a, e2);
+        }
+        e2 *= 0.125;   // EEst² ; accept iff EEst <= 1
+
+        // PI controller in log2 space: q = EEst^β1 / qold^β2 / γ
+        const double lE = 0.5 * ::log2(e2);                  // log2(EEst); -inf when EEst == 0
+        const double q11_l = PI_BETA1 * lE;
+        if (e2 <= 1.0) {
+            double q;
+            if (e2 == 0.0) q = 1.0 / PI_QMAX;
+            else {
+                q = ::exp2(q11_l - PI_BETA2 * lq_old) * (1.0 / PI_GAMMA);
+                q = ::fmax(1.0 / PI_QMAX, ::fmin(1.0 / PI_QMIN, q));
+            }
+            nacc++;
+            lq_old = ::fmax(lE, LOG2_QOLDINIT);
+            const double dtnew = hh * rcp_full(q);
+            double tnew = t + hh;
+            if (::fabs(tnew - tend) < 100.0 * 2.220446049250313e-16 * ::fmax(::fabs(tnew), ::fabs(tend))) tnew = tend;
+
+            if (DISC) {
+                const double cnext = disc_cond(p, un[1], sn, cn);
+                const int ps = sgn(cprev);
+                bool ev = false;
+                double top = 1.0;
+                if (ps != 0) {
+                    if (ps * sgn(cnext) <= 0) {
+                        ev = true;
+                    } else {
+                        ev = sample_event(p, ps, hh, top);
+                    }
+                }
+                if (ev) {
+                    // leave (u, k, h) in place; finalize() root-finds on the dense output
+                    event = 1;
+                    ev_top = top;
+                    status = GR_STATUS_INTERSECTED_WITH_GEOMETRY;
+                    return true;
+                }
+                cprev = cnext;
+            }
+            const bool term = discrete_cb(p, un[1], cn, status);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { u[i] = un[i]; k[0][i] = k[6][i]; }
+            t = tnew;
+            dt = ::fmin(dtmax, dtnew);
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bad |= !(u[i] == u[i]);
+            if (bad) { flags |= GR_FLAG_NAN; return true; }
+            return term || !(t < tend);
+        } else {
+            nrej++;
+            const double q11 = ::exp2(q11_l);
+            dt = hh / ::fmin(1.0 / PI_QMIN, q11 * (1.0 / PI_GAMMA));
+            return false;
+        }
+    }
+
+    // dense-output polynomial coefficients of component `comp`: y(Θ) = u + h Σ_m C[m] Θ^(m+1)
+    GR_DEV void dense_coeffs(int comp, double C[4]) const
+    {
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                if (Ts::R[i][mm] != 0.0) acc = __builtin_fma(Ts::R[i][mm], k[i][comp], acc);
+            C[mm] = acc;
+        }
+    }
+    static GR_DEV double dense_eval(double u0, double hh, const double C[4], double th)
+    {
+        const double poly = th * (C[0] + th * (C[1] + th * (C[2] + th * C[3])));
+        return __builtin_fma(hh, poly, u0);
+    }
+
+    // ContinuousCallback safety sampling at Θ = j/7, j = 1..6 (Θ = 1 was tested by the caller).
+    // A sample can only change sign if it lies inside the |cosθ| < gtol wedge, so θ alone is
+    // evaluated first and the full condition only for samples near the equatorial plane.
+    GR_DEV bool sample_event(const Params& p, int ps, double hh, double& top) const
+    {
+        double Ct[4];
+        dense_coeffs(2, Ct);
+        const double wedge = ::asin(::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+        bool any = (ps < 0);
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            double d = dense_eval(u[2], hh, Ct, (double)(jj + 1) / 7.0) - 1.5707963267948966;
+            d -= 3.141592653589793 * __builtin_rint(d * 0.3183098861837907);
+            any |= (::fabs(d) < wedge);
+        }
+        if (!any) return false;
+        double Cr[4];
+        dense_coeffs(1, Cr);
+        for (int jj = 0; jj < 6; ++jj) {
+            const double th = (double)(jj + 1) / 7.0;
+            const double thv = dense_eval(u[2], hh, Ct, th);
+            const double rv = dense_eval(u[1], hh, Cr, th);
+            double s, c;
+            sincos_fast(thv, s, c);
+            const double cj = disc_cond(p, rv, s, c);
+            if ((double)ps * cj < 0.0) { top = th; return true; }
+        }
+        return false;
+    }
+
+    // Root-find the event on the dense output (left-biased), move the state there, run the
+    // discrete callbacks on it.  Result: final (t, u).
+    GR_DEV void resolve_event(const Params& p)
+    {
+        double Cr[4], Ct[4];
+        dense_coeffs(1, Cr);
+        dense_coeffs(2, Ct);
+        const int ps = sgn(cprev);
+        double lo = 0.0, hi = ev_top;
+        double flo = cprev, fhi;
+        {
+            double s, c;
+            sincos_fast(dense_eval(u[2], h, Ct, hi), s, c);
+            fhi = disc_cond(p, dense_eval(u[1], h, Cr, hi), s, c);
+        }
+        double theta = hi;
+        if (fhi != 0.0) {
+            // bracketing hybrid: false position with forced bisection; keeps sign(f(lo)) == ps
+            for (int it = 0; it < 80; ++it) {
+                const double w = hi - lo;
+                if (w <= 4.0e-16 * ::fmax(hi, 1e-300) || w < 1e-17) break;
+                double mid;
+                if ((it % 3) == 2 || !(flo * fhi < 0.0)) mid = lo + 0.5 * w;
+                else {
+                    mid = lo - flo * w / (fhi - flo);
+                    const double guard = 1e-3 * w;
+                    if (!(mid > lo + guard)) mid = lo + guard;
+                    if (!(mid < hi - guard)) mid = hi - guard;
+                }
+                if (!(mid > lo && mid < hi)) break;
+                double s, c;
+                sincos_fast(dense_eval(u[2], h, Ct, mid), s, c);
+                const double fm = disc_cond(p, dense_eval(u[1], h, Cr, mid), s, c);
+                if (sgn(fm) == ps) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+            }
+            theta = lo;
+        }
+        // change_t_via_interpolation!: every component from the interpolant
+        double un[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double C[4];
+            dense_coeffs(i, C);
+            un[i] = dense_eval(u[i], h, C, theta);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = un[i];
+        t = t + theta * h;
+        double s, c;
+        sincos_fast(u[2], s, c);
+        discrete_cb(p, u[1], c, status);
+    }
+
+    // unpack_solution + apply_to_image!
+    GR_DEV void finalize(const Metric& m, const Params& p)
+    {
+        if (DISC && event) resolve_event(p);
+        if (flags) status = GR_STATUS_NO_STATUS;
+        if (p.out_mode == 1) {
+            double u0[8];
+            constrained_u0(m, p, j, u0);
+            gr_point* o = p.points + j;
+            o->status = status;
+            o->flags = flags;
+            o->lambda_min = p.cfg.lambda0;
+            o->lambda_max = t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o->x_init[q] = u0[q];
+                o->v_init[q] = u0[4 + q];
+                o->x[q] = u[q];
+                o->v[q] = u[4 + q];
+            }
+        } else {
+            bool pass = true;
+            if (p.pf.filter_id == GR_FILTER_EARLY_TERM) pass = t < p.cfg.lambda1;
+            else if (p.pf.filter_id == GR_FILTER_INTERSECTED) pass = status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
+            double val = p.pf.fill;
+            if (pass) {
+                if (p.pf.pf_id == GR_PF_AFFINE_TIME) val = t;
+                else if (p.pf.pf_id == GR_PF_STATUS) val = (double)status;
+                else if (p.pf.pf_id == GR_PF_RADIUS) {
+                    double s, c;
+                    sincos_fast(u[2], s, c);
+                    val = u[1] * ::fabs(s);
+                } else {
+                    double u0[8];
+                    constrained_u0(m, p, j, u0);
+                    val = redshift_pf(m, p, u0, u0 + 4, u, u + 4);
+                }
+            }
+            p.image[j] = val;
+        }
+    }
+};
+
+}  // namespace gr

@@ -1,0 +1,604 @@
+// gradus_mi355x.hip -- kernels and the C ABI of libgradus_mi355x.so (see include/gradus_mi355x.h).
+//
+// Two launch shapes for the same per-lane integrator (gr_device.hpp):
+//   kernel 0  "lane"        one ray per work-item, 8x8-pixel tiles per wave; a wave lives as
+//                           long as its slowest ray.
+//   kernel 1  "persistent"  a resident grid pulls rays from a global counter; when enough lanes
+//                           of a wave have finished (wave ballot), their results are written and
+//                           they are refilled with new rays, so lanes stay busy although step
+//                           counts differ ~4x between rays.
+// Output is one double per ray (fused PointFunction) or one 152-byte GeodesicPoint per ray.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "gr_device.hpp"
+
+using namespace gr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define GR_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? GR_ERR_OUT_OF_MEMORY : GR_ERR_HIP,            \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+constexpr int N_STAT = 9;   // rays, accepted, rejected, rhs, flagged, status[4]
+
+template <class Metric, int DISC>
+struct LaneStats {
+    unsigned long long rays = 0, acc = 0, rej = 0, flagged = 0, st[4] = { 0, 0, 0, 0 };
+    GR_DEV void add(const Ray<Metric, DISC>& r)
+    {
+        rays += 1;
+        acc += (unsigned)r.nacc;
+        rej += (unsigned)r.nrej;
+        flagged += r.flags ? 1 : 0;
+        const int s = r.flags ? GR_STATUS_NO_STATUS : r.status;
+        st[0] += (s == 0); st[1] += (s == 1); st[2] += (s == 2); st[3] += (s == 3);
+    }
+    GR_DEV void flush(unsigned long long* out) const
+    {
+        if (!out) return;
+        unsigned long long v[N_STAT] = { rays, acc, rej, 2 * rays + 6 * (acc + rej), flagged, st[0], st[1], st[2], st[3] };
+#pragma unroll
+        for (int i = 0; i < N_STAT; ++i) {
+            unsigned long long x = v[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(out + i, x);
+        }
+    }
+};
+
+// ---- kernel 0: one ray per work-item ----
+template <class Metric, int DISC>
+__global__ void __launch_bounds__(256) k_trace_lane(const Params p)
+{
+    Metric m;
+    m.load(p.cfg.params);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    LaneStats<Metric, DISC> ls;
+    if (gid < p.n) {
+        Ray<Metric, DISC> ray;
+        ray.init(m, p, tile_swizzle(p, gid));
+        while (!ray.step(m, p)) {}
+        ray.finalize(m, p);
+        ls.add(ray);
+    }
+    ls.flush(p.stats);
+}
+
+// ---- kernel 1: persistent grid with wave-ballot refill ----
+template <class Metric, int DISC>
+__global__ void __launch_bounds__(256) k_trace_persistent(const Params p)
+{
+    Metric m;
+    m.load(p.cfg.params);
+    Ray<Metric, DISC> ray;
+    LaneStats<Metric, DISC> ls;
+    bool active = false, pending = false, queue_empty = false;
+    const int lane = threadIdx.x & 63;
+    const int threshold = p.refill_threshold;
+
+    for (;;) {
+        const unsigned long long act = __ballot(active);
+        const int n_idle = 64 - __popcll(act);
+        if (n_idle >= threshold || act == 0ull) {
+            if (__ballot(pending)) {
+                if (pending) {
+                    ray.finalize(m, p);
+                    ls.add(ray);
+                    pending = false;
+                }
+            }
+            if (!queue_empty) {
+                const unsigned long long idle = __ballot(!active);
+                const int n = __popcll(idle);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(p.queue, (unsigned long long)n);
+                base = __shfl(base, 0, 64);
+                const int64_t mine = (int64_t)base + __popcll(idle & ((1ull << lane) - 1ull));
+                if (!active && mine < p.n) {
+                    ray.init(m, p, tile_swizzle(p, mine));
+                    active = true;
+                }
+                if ((int64_t)base + n >= p.n) queue_empty = true;
+            }
+            if (__ballot(active) == 0ull) break;
+        }
+        if (active) {
+            if (ray.step(m, p)) {
+                active = false;
+                pending = true;
+            }
+        }
+    }
+    ls.flush(p.stats);
+}
+
+// ---- apply(pf, points) ----
+template <class Metric>
+__global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point* pts, double max_time, double* out)
+{
+    Metric m;
+    m.load(p.cfg.params);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const gr_point gp = pts[i];
+    bool pass = true;
+    if (p.pf.filter_id == GR_FILTER_EARLY_TERM) pass = gp.lambda_max < max_time;
+    else if (p.pf.filter_id == GR_FILTER_INTERSECTED) pass = gp.status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
+    double val = p.pf.fill;
+    if (pass) {
+        if (p.pf.pf_id == GR_PF_AFFINE_TIME) val = gp.lambda_max;
+        else if (p.pf.pf_id == GR_PF_STATUS) val = (double)gp.status;
+        else if (p.pf.pf_id == GR_PF_RADIUS) val = gp.x[1] * ::fabs(::sin(gp.x[2]));
+        else val = redshift_pf(m, p, gp.x_init, gp.v_init, gp.x, gp.v);
+    }
+    out[i] = val;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+struct gr_ctx {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;          // used by the host-buffer entry points
+    unsigned long long* d_queue = nullptr; // ring of work counters (one per in-flight launch)
+    int queue_slots = 64, queue_next = 0;
+    unsigned long long* d_stats = nullptr; // for host-buffer entry points
+    double* d_plunge = nullptr;            // 4 x n_plunge
+    int64_t plunge_cap = 0;
+    void* d_scratch = nullptr;             // staging for host-buffer entry points
+    size_t scratch_bytes = 0;
+    void* d_in = nullptr;
+    size_t in_bytes = 0;
+    // knobs
+    int64_t kernel = 1;
+    int64_t block = 256;
+    int64_t refill_threshold = 8;
+    int64_t waves_per_simd = 0;            // 0 = from occupancy query
+    int64_t swizzle = 1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int32_t ensure(void** buf, size_t* cap, size_t need)
+{
+    if (*cap >= need) return GR_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    GR_HIP(hipMalloc(buf, need));
+    *cap = need;
+    return GR_OK;
+}
+
+int32_t validate_cfg(const gr_config* cfg)
+{
+    if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
+    if (cfg->metric_id != GR_METRIC_KERR && cfg->metric_id != GR_METRIC_JOHANNSEN)
+        return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
+    if (cfg->disc_id != GR_DISC_NONE && cfg->disc_id != GR_DISC_THIN)
+        return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
+    if (!(cfg->abstol > 0.0) || !(cfg->reltol > 0.0))
+        return fail(GR_ERR_INVALID_ARGUMENT, "abstol and reltol must be positive");
+    if (!(cfg->lambda1 > cfg->lambda0))
+        return fail(GR_ERR_INVALID_ARGUMENT, "λ domain must be increasing");
+    if (cfg->maxiters <= 0) return fail(GR_ERR_INVALID_ARGUMENT, "maxiters must be positive");
+    if (cfg->disc_id == GR_DISC_THIN && !(cfg->disc_r_out >= cfg->disc_r_in))
+        return fail(GR_ERR_INVALID_ARGUMENT, "disc outer radius below inner radius");
+    return GR_OK;
+}
+
+int32_t validate_plane(const gr_plane* pl, const gr_range* rg)
+{
+    if (!pl || !rg) return fail(GR_ERR_INVALID_ARGUMENT, "plane/range is null");
+    if (pl->width <= 0 || pl->height <= 0) return fail(GR_ERR_INVALID_ARGUMENT, "image dimensions must be positive");
+    // @assert issorted(αlims), rendering.jl:148-149
+    if (pl->alpha0 > pl->alpha1) return fail(GR_ERR_INVALID_ARGUMENT, "α limits must be sorted");
+    if (pl->beta0 > pl->beta1) return fail(GR_ERR_INVALID_ARGUMENT, "β limits must be sorted");
+    if (rg->count < 0 || rg->first < 0 || rg->block <= 0 || rg->stride_blocks <= 0)
+        return fail(GR_ERR_INVALID_ARGUMENT, "bad ray range");
+    if (rg->count > 0) {
+        const int64_t last = rg->count - 1;
+        const int64_t b = last / rg->block;
+        const int64_t i = rg->first + b * rg->stride_blocks * rg->block + (last - b * rg->block);
+        if (i >= pl->width * pl->height) return fail(GR_ERR_INVALID_ARGUMENT, "ray range exceeds the image");
+    }
+    return GR_OK;
+}
+
+template <class Metric, int DISC>
+int32_t launch_tmpl(gr_ctx* ctx, Params& p, hipStream_t stream)
+{
+    const int block = (int)ctx->block;
+    if (ctx->kernel == 0) {
+        const int64_t grid = (p.n + block - 1) / block;
+        hipLaunchKernelGGL((k_trace_lane<Metric, DISC>), dim3((unsigned)grid), dim3(block), 0, stream, p);
+    } else {
+        int per_cu = 0;
+        GR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persistent<Metric, DISC>, block, 0));
+        if (per_cu < 1) per_cu = 1;
+        if (ctx->waves_per_simd > 0) {
+            const int want = (int)(ctx->waves_per_simd * 256 / block);
+            if (want >= 1 && want < per_cu) per_cu = want;
+        }
+        int64_t grid = (int64_t)ctx->n_cu * per_cu;
+        const int64_t need = (p.n + block - 1) / block;
+        if (grid > need) grid = need;
+        if (grid < 1) grid = 1;
+        p.queue = ctx->d_queue + ctx->queue_next;
+        ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
+        GR_HIP(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL((k_trace_persistent<Metric, DISC>), dim3((unsigned)grid), dim3(block), 0, stream, p);
+    }
+    GR_HIP(hipGetLastError());
+    return GR_OK;
+}
+
+int32_t launch_trace(gr_ctx* ctx, Params& p, hipStream_t stream)
+{
+    if (p.n == 0) return GR_OK;
+    p.refill_threshold = (int32_t)ctx->refill_threshold;
+    const bool disc = p.cfg.disc_id == GR_DISC_THIN;
+    if (p.cfg.metric_id == GR_METRIC_KERR)
+        return disc ? launch_tmpl<KerrMetric, 1>(ctx, p, stream) : launch_tmpl<KerrMetric, 0>(ctx, p, stream);
+    return disc ? launch_tmpl<JohannsenMetric, 1>(ctx, p, stream) : launch_tmpl<JohannsenMetric, 0>(ctx, p, stream);
+}
+
+// copy the plunging table (host pointers) into the context and fill the device-side pf
+int32_t stage_pf(gr_ctx* ctx, const gr_pointfunction* pf, PfDev& out, hipStream_t stream)
+{
+    if (!pf) return fail(GR_ERR_INVALID_ARGUMENT, "point function is null");
+    if (pf->pf_id < GR_PF_AFFINE_TIME || pf->pf_id > GR_PF_RADIUS)
+        return fail(GR_ERR_UNSUPPORTED, "unknown pf_id " + std::to_string(pf->pf_id));
+    if (pf->filter_id < GR_FILTER_NONE || pf->filter_id > GR_FILTER_INTERSECTED)
+        return fail(GR_ERR_UNSUPPORTED, "unknown filter_id " + std::to_string(pf->filter_id));
+    out.pf_id = pf->pf_id;
+    out.filter_id = pf->filter_id;
+    out.fill = pf->fill;
+    out.r_isco = pf->r_isco;
+    out.n_plunge = 0;
+    out.plunge_r = out.plunge_vt = out.plunge_vr = out.plunge_vphi = nullptr;
+    if (pf->pf_id == GR_PF_REDSHIFT && pf->n_plunge > 0) {
+        if (pf->n_plunge < 2 || !pf->plunge_r || !pf->plunge_vt || !pf->plunge_vr || !pf->plunge_vphi)
+            return fail(GR_ERR_INVALID_ARGUMENT, "plunging table needs >= 2 rows and four arrays");
+        const int64_t n = pf->n_plunge;
+        if (ctx->plunge_cap < n) {
+            if (ctx->d_plunge) (void)hipFree(ctx->d_plunge);
+            ctx->d_plunge = nullptr;
+            ctx->plunge_cap = 0;
+            GR_HIP(hipMalloc((void**)&ctx->d_plunge, sizeof(double) * 4 * n));
+            ctx->plunge_cap = n;
+        }
+        const double* src[4] = { pf->plunge_r, pf->plunge_vt, pf->plunge_vr, pf->plunge_vphi };
+        for (int q = 0; q < 4; ++q)
+            GR_HIP(hipMemcpyAsync(ctx->d_plunge + q * ctx->plunge_cap, src[q], sizeof(double) * n, hipMemcpyHostToDevice, stream));
+        out.n_plunge = n;
+        out.plunge_r = ctx->d_plunge;
+        out.plunge_vt = ctx->d_plunge + ctx->plunge_cap;
+        out.plunge_vr = ctx->d_plunge + 2 * ctx->plunge_cap;
+        out.plunge_vphi = ctx->d_plunge + 3 * ctx->plunge_cap;
+    }
+    if (pf->pf_id == GR_PF_REDSHIFT && !(pf->r_isco > 0.0))
+        return fail(GR_ERR_INVALID_ARGUMENT, "redshift needs r_isco > 0");
+    return GR_OK;
+}
+
+void plane_params(gr_ctx* ctx, Params& p, const gr_config* cfg, const gr_plane* plane, const gr_range* range)
+{
+    std::memset(&p, 0, sizeof p);
+    p.cfg = *cfg;
+    p.src_mode = 0;
+    p.plane = *plane;
+    p.range = *range;
+    p.n = range->count;
+    // 8x8 tiles need whole, column-aligned groups of 8 columns in the local index space
+    const int64_t H = plane->height;
+    const bool cols_ok = (H % 8 == 0) && (range->first % H == 0) && (range->block % (8 * H) == 0)
+                         && (range->count % (8 * H) == 0);
+    p.swizzle = (ctx->swizzle && cols_ok) ? 1 : 0;
+}
+
+void stats_to_host(const unsigned long long* h, gr_stats* s)
+{
+    s->rays = (int64_t)h[0];
+    s->accepted_steps = (int64_t)h[1];
+    s->rejected_steps = (int64_t)h[2];
+    s->rhs_evals = (int64_t)h[3];
+    s->flagged_rays = (int64_t)h[4];
+    for (int i = 0; i < 4; ++i) s->status_count[i] = (int64_t)h[5 + i];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t gr_abi_version(void) { return GR_ABI_VERSION; }
+
+const char* gr_last_error(void) { return g_last_error.c_str(); }
+
+int32_t gr_ctx_create(int32_t device, gr_ctx** out)
+{
+    if (!out) return fail(GR_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(GR_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= count)
+        return fail(GR_ERR_INVALID_ARGUMENT, "device index out of range");
+    GR_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GR_HIP(hipGetDeviceProperties(&prop, device));
+    gr_ctx* c = new gr_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    int32_t rc = GR_OK;
+    do {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipStreamCreate failed"); break; }
+        if (hipMalloc((void**)&c->d_queue, sizeof(unsigned long long) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"); break; }
+        if (hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * N_STAT) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(stats) failed"); break; }
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipEventCreate failed"); break; }
+    } while (0);
+    if (rc != GR_OK) {
+        gr_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return GR_OK;
+}
+
+int32_t gr_ctx_destroy(gr_ctx* c)
+{
+    if (!c) return GR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_plunge) (void)hipFree(c->d_plunge);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GR_OK;
+}
+
+int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
+{
+    if (!c || !key) return fail(GR_ERR_INVALID_ARGUMENT, "ctx/key is null");
+    const std::string k(key);
+    if (k == "kernel") {
+        if (value != 0 && value != 1) return fail(GR_ERR_INVALID_ARGUMENT, "kernel must be 0 or 1");
+        c->kernel = value;
+    } else if (k == "block") {
+        if (value < 64 || value > 1024 || value % 64) return fail(GR_ERR_INVALID_ARGUMENT, "block must be a multiple of 64 in [64, 1024]");
+        c->block = value;
+    } else if (k == "refill_threshold") {
+        if (value < 1 || value > 64) return fail(GR_ERR_INVALID_ARGUMENT, "refill_threshold must be in [1, 64]");
+        c->refill_threshold = value;
+    } else if (k == "waves_per_simd") {
+        if (value < 0 || value > 8) return fail(GR_ERR_INVALID_ARGUMENT, "waves_per_simd must be in [0, 8]");
+        c->waves_per_simd = value;
+    } else if (k == "swizzle") {
+        c->swizzle = value ? 1 : 0;
+    } else {
+        return fail(GR_ERR_INVALID_ARGUMENT, "unknown knob '" + k + "'");
+    }
+    return GR_OK;
+}
+
+int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,
+                         const gr_range* range, double* d_image, gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if ((rc = validate_plane(plane, range)) != GR_OK) return rc;
+    if (!d_image && range->count > 0) return fail(GR_ERR_INVALID_ARGUMENT, "image is null");
+    GR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params p;
+    plane_params(ctx, p, cfg, plane, range);
+    if ((rc = stage_pf(ctx, pf, p.pf, stream)) != GR_OK) return rc;
+    p.out_mode = 0;
+    p.image = d_image;
+    p.stats = (unsigned long long*)d_stats;   // same layout: 9 x 64-bit counters then kernel_ms
+    return launch_trace(ctx, p, stream);
+}
+
+int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
+                                   gr_point* d_points, gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if ((rc = validate_plane(plane, range)) != GR_OK) return rc;
+    if (!d_points && range->count > 0) return fail(GR_ERR_INVALID_ARGUMENT, "points is null");
+    GR_HIP(hipSetDevice(ctx->device));
+    Params p;
+    plane_params(ctx, p, cfg, plane, range);
+    p.out_mode = 1;
+    p.points = d_points;
+    p.stats = (unsigned long long*)d_stats;
+    return launch_trace(ctx, p, (hipStream_t)hip_stream);
+}
+
+int32_t gr_trace_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const double* d_x, int64_t x_stride,
+                                  const double* d_v, int64_t n, gr_point* d_points, gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if (n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (x_stride != 0 && x_stride != 4) return fail(GR_ERR_INVALID_ARGUMENT, "x_stride must be 0 or 4");
+    if (n > 0 && (!d_x || !d_v || !d_points)) return fail(GR_ERR_INVALID_ARGUMENT, "x/v/points is null");
+    GR_HIP(hipSetDevice(ctx->device));
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.cfg = *cfg;
+    p.src_mode = 1;
+    p.out_mode = 1;
+    p.x = d_x;
+    p.x_stride = x_stride;
+    p.v = d_v;
+    p.n = n;
+    p.points = d_points;
+    p.stats = (unsigned long long*)d_stats;
+    p.range = gr_range{ 0, n, n > 0 ? n : 1, 1 };
+    p.swizzle = 0;
+    return launch_trace(ctx, p, (hipStream_t)hip_stream);
+}
+
+int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,
+                                      const gr_point* d_points, int64_t n, double max_time, double* d_out, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if (n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (n > 0 && (!d_points || !d_out)) return fail(GR_ERR_INVALID_ARGUMENT, "points/out is null");
+    GR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.cfg = *cfg;
+    p.n = n;
+    if ((rc = stage_pf(ctx, pf, p.pf, stream)) != GR_OK) return rc;
+    if (n == 0) return GR_OK;
+    const int block = 256;
+    const int64_t grid = (n + block - 1) / block;
+    if (cfg->metric_id == GR_METRIC_KERR)
+        hipLaunchKernelGGL((k_apply_pf<KerrMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
+    else
+        hipLaunchKernelGGL((k_apply_pf<JohannsenMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
+    GR_HIP(hipGetLastError());
+    return GR_OK;
+}
+
+// ---- host-buffer variants: stage through the context, block until done ----
+static int32_t begin_host_call(gr_ctx* ctx, gr_stats* stats)
+{
+    GR_HIP(hipSetDevice(ctx->device));
+    if (stats) GR_HIP(hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * N_STAT, ctx->stream));
+    GR_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return GR_OK;
+}
+
+static int32_t end_host_call(gr_ctx* ctx, gr_stats* stats)
+{
+    GR_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    unsigned long long h[N_STAT];
+    if (stats) GR_HIP(hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    GR_HIP(hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        stats_to_host(h, stats);
+        float ms = 0.f;
+        GR_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        stats->kernel_ms = ms;
+    }
+    return GR_OK;
+}
+
+int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,
+                  const gr_range* range, double* image, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!range) return fail(GR_ERR_INVALID_ARGUMENT, "range is null");
+    if (!image && range->count > 0) return fail(GR_ERR_INVALID_ARGUMENT, "image is null");
+    int32_t rc;
+    const size_t bytes = sizeof(double) * (size_t)(range->count > 0 ? range->count : 0);
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = gr_render_device(ctx, cfg, plane, pf, range, (double*)ctx->d_scratch,
+                               stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    if (bytes) GR_HIP(hipMemcpyAsync(image, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
+}
+
+int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
+                            gr_point* points, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!range) return fail(GR_ERR_INVALID_ARGUMENT, "range is null");
+    if (!points && range->count > 0) return fail(GR_ERR_INVALID_ARGUMENT, "points is null");
+    int32_t rc;
+    const size_t bytes = sizeof(gr_point) * (size_t)(range->count > 0 ? range->count : 0);
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = gr_render_endpoints_device(ctx, cfg, plane, range, (gr_point*)ctx->d_scratch,
+                                         stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
+}
+
+int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, int64_t x_stride, const double* v,
+                           int64_t n, gr_point* points, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (x_stride != 0 && x_stride != 4) return fail(GR_ERR_INVALID_ARGUMENT, "x_stride must be 0 or 4");
+    if (n > 0 && (!x || !v || !points)) return fail(GR_ERR_INVALID_ARGUMENT, "x/v/points is null");
+    int32_t rc;
+    const size_t nx = (size_t)(x_stride == 0 ? 4 : 4 * n), nv = (size_t)(4 * n);
+    const size_t out_bytes = sizeof(gr_point) * (size_t)n;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, out_bytes ? out_bytes : 8)) != GR_OK) return rc;
+    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * (nx + nv) + 8)) != GR_OK) return rc;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    double* d_x = (double*)ctx->d_in;
+    double* d_v = d_x + nx;
+    if (n > 0) {
+        GR_HIP(hipMemcpyAsync(d_x, x, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
+        GR_HIP(hipMemcpyAsync(d_v, v, sizeof(double) * nv, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = gr_trace_endpoints_device(ctx, cfg, d_x, x_stride, d_v, n, (gr_point*)ctx->d_scratch,
+                                        stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    if (out_bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
+}
+
+int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf, const gr_point* points,
+                               int64_t n, double max_time, double* out)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (n > 0 && (!points || !out)) return fail(GR_ERR_INVALID_ARGUMENT, "points/out is null");
+    int32_t rc;
+    const size_t in_bytes = sizeof(gr_point) * (size_t)n, out_bytes = sizeof(double) * (size_t)n;
+    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, in_bytes ? in_bytes : 8)) != GR_OK) return rc;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, out_bytes ? out_bytes : 8)) != GR_OK) return rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    if (n > 0) GR_HIP(hipMemcpyAsync(ctx->d_in, points, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = gr_apply_pointfunction_device(ctx, cfg, pf, (const gr_point*)ctx->d_in, n, max_time,
+                                            (double*)ctx->d_scratch, ctx->stream)) != GR_OK) return rc;
+    if (n > 0) GR_HIP(hipMemcpyAsync(out, ctx->d_scratch, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GR_HIP(hipStreamSynchronize(ctx->stream));
+    return GR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+"""Tracing front-end: configuration, charts, initial conditions and the ensemble boundary.
+
+Mirrors src/tracing/{tracing,configuration,charts,callbacks,utility,constraints}.jl of the
+reference.  Everything below `ensemble_solve_tracing_problem` runs in the HIP library; this
+module only flattens the configuration into the C-ABI structs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import _lib
+from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, ThinDisc
+from .metrics import AbstractMetric
+from .orthonormalization import lnrbasis
+
+DEFAULT_TOLERANCE = 1e-9  # configuration.jl:1
+
+
+# ---- charts.jl:3-6,51-58 ----
+@dataclass(frozen=True)
+class PolarChart:
+    inner_radius: float
+    outer_radius: float
+
+
+def chart_for_metric(m: AbstractMetric, outer_radius: float = 12000.0, *, closest_approach: float = 1.01):
+    return PolarChart(m.inner_radius() * closest_approach, outer_radius)
+
+
+# ---- callbacks.jl:31-40 ----
+@dataclass(frozen=True)
+class DomainUpperHemisphere:
+    delta: float = 1e-4
+
+
+def domain_upper_hemisphere(δ: float = 1e-4):
+    return DomainUpperHemisphere(δ)
+
+
+# ---- utility.jl:13-20 ----
+def local_momentum(r_obs, α, β):
+    b = β / r_obs
+    a = α / r_obs
+    pr = -1.0 / math.sqrt(1.0 + a * a + b * b)
+    return np.array([1.0, pr, b * pr, a * pr])
+
+
+# ---- utility.jl:32-40 ----
+def lnr_momentum_to_global_velocity_matrix(m: AbstractMetric, x):
+    """The constant 4x4 matrix of `lnr_momentum_to_global_velocity_transform`: p̄ ↦ g⁻¹ (Tx p̄)."""
+    g = m.metric(x)
+    Tx = np.column_stack(lnrbasis(g))
+    return np.linalg.inv(g) @ Tx
+
+
+def lnr_momentum_to_global_velocity_transform(m: AbstractMetric, x):
+    Mx = lnr_momentum_to_global_velocity_matrix(m, x)
+    return lambda pbar: Mx @ pbar
+
+
+# ---- utility.jl:66-87 ----
+def map_impact_parameters(m: AbstractMetric, x, α, β):
+    """Unconstrained initial velocity (or an (n, 4) array of them) for impact parameters."""
+    Mx = lnr_momentum_to_global_velocity_matrix(m, x)
+    if np.ndim(α) == 0 and np.ndim(β) == 0:
+        return Mx @ local_momentum(x[1], float(α), float(β))
+    αs, βs = np.broadcast_arrays(np.asarray(α, dtype=np.float64), np.asarray(β, dtype=np.float64))
+    return np.stack([Mx @ local_momentum(x[1], a, b) for a, b in zip(αs.ravel(), βs.ravel())])
+
+
+# ---- Gradus.jl:412 / ext/GradusDiffEqGPUExt: the ensemble type selects the backend ----
+class EnsembleMI355X:
+    """Ensemble algorithm that runs the trace on one MI355X through libgradus_mi355x.so.
+
+    Passing it as `ensemble=` is the drop-in point (dispatch of
+    `ensemble_solve_tracing_problem`, src/tracing/tracing.jl:113-196).
+    """
+
+    def __init__(self, device: int = 0, **knobs):
+        self.device = device
+        self.knobs = dict(knobs)
+        self._ctx: Optional[_lib.Context] = None
+
+    @property
+    def ctx(self) -> _lib.Context:
+        if self._ctx is None:
+            self._ctx = _lib.Context(self.device)
+            for k, v in self.knobs.items():
+                self._ctx.set(k, v)
+        return self._ctx
+
+    def set(self, key, value):
+        self.knobs[key] = value
+        if self._ctx is not None:
+            self._ctx.set(key, value)
+        return self
+
+
+@dataclass(frozen=True)
+class RenderVelocity:
+    """`_render_velocity_function` (rendering.jl:140-163) as data: evaluated per pixel on device."""
+
+    alpha_lims: tuple
+    beta_lims: tuple
+    image_width: int
+    image_height: int
+    offset: float = 1e-6
+
+
+@dataclass
+class TracingConfiguration:
+    """configuration.jl:3-88 flattened; `μ` from TraceGeodesic (tracing.jl:1-7), `gtol` from
+    geometry/bootstrap.jl:8."""
+
+    metric: AbstractMetric
+    position: np.ndarray
+    velocity: object                # (n,4) array | RenderVelocity
+    geometry: Optional[AbstractAccretionGeometry]
+    chart: PolarChart
+    callback: object
+    ensemble: EnsembleMI355X
+    trajectories: Optional[int]
+    λ_domain: tuple
+    abstol: float = DEFAULT_TOLERANCE
+    reltol: float = DEFAULT_TOLERANCE
+    gtol: float = 1e-2
+    μ: float = 0.0
+    maxiters: int = 1_000_000
+
+    def abi_config(self) -> _lib.gr_config:
+        c = _lib.gr_config()
+        m = self.metric
+        if m.metric_id < 0:
+            raise NotImplementedError(f"metric {type(m).__name__} has no device implementation")
+        c.metric_id = m.metric_id
+        for i, p in enumerate(m.abi_params()):
+            c.params[i] = float(p)
+        c.r_inner, c.r_outer = float(self.chart.inner_radius), float(self.chart.outer_radius)
+        if self.geometry is None:
+            c.disc_id = GR_DISC_NONE
+        elif isinstance(self.geometry, ThinDisc):
+            c.disc_id = self.geometry.disc_id
+            c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float(self.geometry.outer_radius)
+        else:
+            raise NotImplementedError(f"geometry {type(self.geometry).__name__} has no device implementation")
+        c.gtol = float(self.gtol)
+        c.lambda0, c.lambda1 = float(self.λ_domain[0]), float(self.λ_domain[1])
+        c.abstol, c.reltol = float(self.abstol), float(self.reltol)
+        c.mu = float(self.μ)
+        c.maxiters = int(self.maxiters)
+        if self.callback is None:
+            c.upper_hemisphere = 0
+        elif isinstance(self.callback, DomainUpperHemisphere):
+            c.upper_hemisphere = 1
+            c.hemi_delta = float(self.callback.delta)
+        else:
+            raise NotImplementedError("only `domain_upper_hemisphere()` callbacks can run on the device")
+        return c
+
+    def abi_plane(self) -> _lib.gr_plane:
+        rv = self.velocity
+        assert isinstance(rv, RenderVelocity)
+        pl = _lib.gr_plane()
+        for i in range(4):
+            pl.x_obs[i] = float(self.position[i])
+        Mx = lnr_momentum_to_global_velocity_matrix(self.metric, self.position)
+        for i in range(4):
+            for k in range(4):
+                pl.Mx[4 * i + k] = float(Mx[i, k])
+        pl.alpha0, pl.alpha1 = float(rv.alpha_lims[0]), float(rv.alpha_lims[1])
+        pl.beta0, pl.beta1 = float(rv.beta_lims[0]), float(rv.beta_lims[1])
+        pl.width, pl.height = int(rv.image_width), int(rv.image_height)
+        pl.offset = float(rv.offset)
+        return pl
+
+
+def _as_lambda_domain(λs):
+    if np.ndim(λs) == 0:
+        return (0.0, float(λs))
+    return (float(λs[0]), float(λs[1]))
+
+
+def tracing_configuration(
+    m,
+    position,
+    velocity,
+    geometry,
+    λs,
+    *,
+    chart=None,
+    callback=None,
+    ensemble=None,
+    trajectories=None,
+    abstol=DEFAULT_TOLERANCE,
+    reltol=DEFAULT_TOLERANCE,
+    gtol=1e-2,
+    μ=0.0,
+    maxiters=1_000_000,
+    solver="Tsit5",
+    save_on=False,
+):
+    if solver != "Tsit5":
+        raise NotImplementedError("the device integrator is Tsit5 (configuration.jl:99)")
+    if save_on:
+        raise ValueError("Cannot use `EnsembleMI355X` with `save_on` (cf. tracing.jl:159-161)")
+    if ensemble is None:
+        ensemble = EnsembleMI355X()
+    if not isinstance(ensemble, EnsembleMI355X):
+        raise TypeError("this package only provides the `EnsembleMI355X` ensemble (no CPU fallback)")
+    from .planes import AbstractImagePlane, impact_parameters
+
+    position = np.asarray(position, dtype=np.float64)
+    if isinstance(velocity, AbstractImagePlane):
+        # promote_velfunc, image-planes/planes.jl:180-184
+        αs, βs = impact_parameters(velocity, position)
+        velocity = map_impact_parameters(m, position, αs, βs)
+        trajectories = velocity.shape[0]
+    elif callable(velocity):
+        # velocity function i -> SVector (1-based index, configuration.jl:47-49)
+        if trajectories is None:
+            raise ValueError("When velocity is a function, trajectories must be defined.")
+        velocity = np.stack([np.asarray(velocity(i + 1), dtype=np.float64) for i in range(trajectories)])
+    elif isinstance(velocity, RenderVelocity):
+        pass
+    else:
+        velocity = np.ascontiguousarray(velocity, dtype=np.float64)
+        if velocity.ndim == 1:
+            if trajectories is not None:
+                raise ValueError("Trajectories should be `nothing` when solving only a single geodesic problem.")
+            velocity = velocity.reshape(1, 4)
+        trajectories = velocity.shape[0]
+    if chart is None:
+        chart = chart_for_metric(m)
+    return TracingConfiguration(
+        m, position, velocity, geometry, chart, callback, ensemble, trajectories, _as_lambda_domain(λs),
+        abstol, reltol, gtol, μ, maxiters,
+    )
+
+
+def ensemble_solve_tracing_problem(ensemble: EnsembleMI355X, config: TracingConfiguration, *, stats: bool = False):
+    """THE DROP-IN BOUNDARY (src/tracing/tracing.jl:151-196): returns the GeodesicPoint records
+    (numpy structured array, 152-byte layout of src/solution-processing.jl:15-32)."""
+    L = _lib.load()
+    cfg = config.abi_config()
+    st = _lib.gr_stats()
+    if isinstance(config.velocity, RenderVelocity):
+        pl = config.abi_plane()
+        n = pl.width * pl.height
+        rg = _lib.gr_range(0, n, max(n, 1), 1)
+        out = np.zeros(n, dtype=_lib.POINT_DTYPE)
+        _lib.check(L.gr_render_endpoints(ensemble.ctx.handle, C.byref(cfg), C.byref(pl), C.byref(rg),
+                                         out.ctypes.data, C.byref(st)))
+    else:
+        v = np.ascontiguousarray(config.velocity, dtype=np.float64)
+        x = np.ascontiguousarray(config.position, dtype=np.float64)
+        n = v.shape[0]
+        stride = 0 if x.ndim == 1 else 4
+        if stride == 4 and x.shape[0] != n:
+            raise ValueError("positions and velocities must have the same length")
+        out = np.zeros(n, dtype=_lib.POINT_DTYPE)
+        _lib.check(L.gr_trace_endpoints(ensemble.ctx.handle, C.byref(cfg), x.ctypes.data, stride, v.ctypes.data, n,
+                                        out.ctypes.data, C.byref(st)))
+    return (out, st.asdict()) if stats else out
+
+
+def tracegeodesics(m, x, v, *args, stats=False, **kwargs):
+    """tracegeodesics(m, x, v, [disc], λ_domain; kwargs...) -- src/tracing/tracing.jl:66-80.
+
+    `v` may be an (n, 4) array of unconstrained velocities (with `x` one position or an (n, 4)
+    array), an `AbstractImagePlane`, or a function `i -> velocity` with `trajectories=`.
+    Returns an array of GeodesicPoint records (the reference's `EnsembleEndpointThreads` result).
+    """
+    if len(args) == 2:
+        geometry, λs = args
+    elif len(args) == 1:
+        geometry, λs = None, args[0]
+    else:
+        raise TypeError("tracegeodesics(m, x, v, [disc], λ_domain; ...)")
+    config = tracing_configuration(m, x, v, geometry, λs, **kwargs)
+    return ensemble_solve_tracing_problem(config.ensemble, config, stats=stats)

@@ -1,0 +1,210 @@
+/*
+ * gradus_mi355x.h -- C ABI of libgradus_mi355x.so, the MI355X (gfx950) backend for the
+ * image-plane render path of Gradus.jl.
+ *
+ * Drop-in boundary: Gradus.ensemble_solve_tracing_problem(ensemble, problem, config)
+ * (reference: src/tracing/tracing.jl:113-196; the DiffEqGPU extension overloads the same
+ * method at ext/GradusDiffEqGPUExt/GradusDiffEqGPUExt.jl:10-31).  A Julia method for a new
+ * ensemble type `EnsembleMI355X` ccall's the entry points below (binding shown in
+ * INTEGRATION.md); everything under the boundary -- constrain_all, the Tsit5 integration
+ * of the second-order geodesic ODE with chart / disc callbacks, unpack_solution and the
+ * built-in PointFunctions -- runs in hand-written HIP kernels.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative gr_status; nothing throws;
+ *     gr_last_error() returns a thread-local message for the last failure.
+ *   - "_device" entry points take DEVICE pointers and a hipStream_t (as void*) and are
+ *     asynchronous on that stream; the host variants take HOST pointers, stage through
+ *     the context and block until the result is in the caller's buffer.
+ *   - the caller owns every buffer passed in; pointers are only used during the call
+ *     (host variants) or until the stream work completes (device variants).
+ *   - one gr_ctx is bound to one HIP device; a ctx is not thread-safe, distinct ctxs are
+ *     independent.  There is NO CPU fallback: without a gfx950 device gr_ctx_create fails.
+ */
+#ifndef GRADUS_MI355X_H
+#define GRADUS_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR_ABI_VERSION 1
+
+typedef enum {
+    GR_OK = 0,
+    GR_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad size, unsorted limits ...           */
+    GR_ERR_UNSUPPORTED = -2,      /* unknown metric / disc / point-function id             */
+    GR_ERR_NO_DEVICE = -3,        /* no usable HIP device (this library has no CPU path)   */
+    GR_ERR_HIP = -4,              /* a HIP runtime call failed; see gr_last_error()        */
+    GR_ERR_OUT_OF_MEMORY = -5
+} gr_status;
+
+/* StatusCodes -- src/Gradus.jl:59-64 (EnumX, declaration order) */
+enum {
+    GR_STATUS_OUT_OF_DOMAIN = 0,
+    GR_STATUS_WITHIN_INNER_BOUNDARY = 1,
+    GR_STATUS_INTERSECTED_WITH_GEOMETRY = 2,
+    GR_STATUS_NO_STATUS = 3
+};
+
+/* AbstractStaticAxisSymmetric metrics available on the device.
+ *   KERR       src/metrics/kerr-metric.jl:11-28,62-72        params = {M, a}
+ *   JOHANNSEN  src/metrics/johannsen-ad.jl:12-34,49-67       params = {M, a, α13, α22, α52, ϵ3} */
+enum { GR_METRIC_KERR = 0, GR_METRIC_JOHANNSEN = 1 };
+
+/* accretion geometry: ThinDisc -- src/geometry/discs/thin-disc.jl:9-26 */
+enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1 };
+
+/* per-ray anomaly bits written next to the status (SciML retcodes MaxIters /
+ * DtLessThanMin / Unstable, which EnsembleEndpointThreads discards, tracing.jl:250) */
+enum { GR_FLAG_MAXITERS = 1, GR_FLAG_DTMIN = 2, GR_FLAG_NAN = 4 };
+
+/* TracingConfiguration (src/tracing/configuration.jl:3-29) + TraceGeodesic.μ
+ * (src/tracing/tracing.jl:1-7) + the geometry callback's gtol (src/geometry/bootstrap.jl:8)
+ * flattened to plain data. */
+typedef struct gr_config {
+    int32_t metric_id;        /* GR_METRIC_*                                             */
+    int32_t disc_id;          /* GR_DISC_*                                               */
+    double params[8];         /* metric parameters, see GR_METRIC_*                      */
+    double r_inner;           /* PolarChart.inner_radius (charts.jl:3-6), already scaled */
+    double r_outer;           /* PolarChart.outer_radius                                 */
+    double disc_r_in;         /* ThinDisc.inner_radius                                   */
+    double disc_r_out;        /* ThinDisc.outer_radius                                   */
+    double gtol;              /* geometry tolerance, default 1e-2                        */
+    double lambda0, lambda1;  /* λ_domain                                                */
+    double abstol, reltol;    /* default 1e-9 (configuration.jl:1)                       */
+    double mu;                /* geodesic mass μ (0 = null)                              */
+    int64_t maxiters;         /* OrdinaryDiffEq default 1_000_000                        */
+    int32_t upper_hemisphere; /* 1 = domain_upper_hemisphere callback (callbacks.jl:31)  */
+    int32_t _pad;
+    double hemi_delta;        /* its δ, default 1e-4                                     */
+} gr_config;
+
+/* GeodesicPoint{Float64,Nothing} -- src/solution-processing.jl:15-32.  152 bytes, same
+ * field order and padding as the Julia isbits struct (status::Int32 enum + 4 pad bytes,
+ * which carry the anomaly flags here). */
+typedef struct gr_point {
+    int32_t status;
+    int32_t flags;
+    double lambda_min, lambda_max;
+    double x_init[4], x[4], v_init[4], v[4];
+} gr_point;
+
+/* The pixel -> initial-velocity closure of _render_velocity_function
+ * (src/rendering/rendering.jl:140-163) as data. */
+typedef struct gr_plane {
+    double x_obs[4];          /* observer four-position                                   */
+    double Mx[16];            /* row-major 4x4: ginv * hcat(lnrbasis(g)...) of
+                                 lnr_momentum_to_global_velocity_transform
+                                 (src/tracing/utility.jl:32-40), computed by the caller   */
+    double alpha0, alpha1;    /* αlims                                                    */
+    double beta0, beta1;      /* βlims                                                    */
+    int64_t width, height;    /* image_width, image_height                                */
+    double offset;            /* the +1e-6 of rendering.jl:158-159                        */
+} gr_plane;
+
+/* Which rays of the W*H image (0-based linear index i = x*H + y, Julia's column-major
+ * H x W matrix) a call processes: local ray j in [0, count) is image ray
+ *     i = first + ((j / block) * stride_blocks + 0) * block + (j % block)
+ * i.e. blocks of `block` consecutive rays, every `stride_blocks`-th block.  A contiguous
+ * range is {first, count, count, 1}.  Used to shard an image over GPUs. */
+typedef struct gr_range {
+    int64_t first;
+    int64_t count;
+    int64_t block;
+    int64_t stride_blocks;
+} gr_range;
+
+/* Built-in point functions -- src/const-point-functions.jl:26-79, src/redshift.jl:192-276 */
+enum {
+    GR_PF_AFFINE_TIME = 0,    /* gp.λ_max                                                */
+    GR_PF_REDSHIFT = 1,       /* ConstPointFunctions.redshift(m, x)                      */
+    GR_PF_STATUS = 2,         /* Float64(gp.status)                                      */
+    GR_PF_RADIUS = 3          /* _equatorial_project(gp.x)                               */
+};
+enum {
+    GR_FILTER_NONE = 0,
+    GR_FILTER_EARLY_TERM = 1, /* filter_early_term: gp.λ_max < max_time                  */
+    GR_FILTER_INTERSECTED = 2 /* filter_intersected: status == IntersectedWithGeometry   */
+};
+typedef struct gr_pointfunction {
+    int32_t pf_id;
+    int32_t filter_id;
+    double fill;              /* FilterPointFunction.default (NaN)                       */
+    double r_isco;            /* isco(m), host-computed                                  */
+    /* PlungingInterpolation table for non-Kerr redshift (src/orbits/orbit-solving.jl:99-131,
+     * src/interpolations.jl:1-45); n_plunge = 0 selects the analytic Kerr branch.  HOST
+     * pointers in every entry point (the table is copied into the context). */
+    int64_t n_plunge;
+    const double* plunge_r;
+    const double* plunge_vt;
+    const double* plunge_vr;
+    const double* plunge_vphi;
+} gr_pointfunction;
+
+/* aggregate counters of one call (device-side reductions) */
+typedef struct gr_stats {
+    int64_t rays;
+    int64_t accepted_steps;
+    int64_t rejected_steps;
+    int64_t rhs_evals;
+    int64_t flagged_rays;     /* rays with a GR_FLAG_* bit set                           */
+    int64_t status_count[4];  /* histogram over StatusCodes                              */
+    double kernel_ms;         /* host variants only: device time of the trace kernel     */
+} gr_stats;
+
+typedef struct gr_ctx gr_ctx;
+
+int32_t gr_abi_version(void);
+const char* gr_last_error(void);
+
+/* Create / destroy a context on HIP device `device`. */
+int32_t gr_ctx_create(int32_t device, gr_ctx** out);
+int32_t gr_ctx_destroy(gr_ctx* ctx);
+/* Tuning knobs: key/value, e.g. ("kernel", 0 = one-ray-per-lane, 1 = persistent with
+ * wave-ballot refill), ("block", threads per workgroup), ("refill_threshold", lanes). */
+int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
+
+/* ---- fused render: rendergeodesics / render_into_image! (rendering.jl:28-54,89-107) ----
+ * image[j] (j local, see gr_range) = pf(m, trace(ray i), λ_max). */
+int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane,
+                         const gr_pointfunction* pf, const gr_range* range,
+                         double* d_image /* device, range->count doubles */,
+                         gr_stats* d_stats /* device, may be NULL */, void* hip_stream);
+int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane,
+                  const gr_pointfunction* pf, const gr_range* range,
+                  double* image /* host, range->count doubles */, gr_stats* stats /* host, may be NULL */);
+
+/* ---- endpoints of an image plane: prerendergeodesics / EndpointRenderCache
+ * (rendering.jl:56-87,121-138) ---- */
+int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane,
+                                   const gr_range* range, gr_point* d_points, gr_stats* d_stats,
+                                   void* hip_stream);
+int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane,
+                            const gr_range* range, gr_point* points, gr_stats* stats);
+
+/* ---- tracegeodesics(m, xs, vs, ...; ensemble) -> Vector{GeodesicPoint}
+ * (tracing.jl:151-196; input shapes of geodesic-problem.jl:121-150).
+ * x: n x 4 positions, or a single position when x_stride == 0 (else x_stride == 4);
+ * v: n x 4 UNCONSTRAINED velocities -- constrain_all (constraints.jl:14-15) is applied on
+ * the device. */
+int32_t gr_trace_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const double* d_x,
+                                  int64_t x_stride, const double* d_v, int64_t n,
+                                  gr_point* d_points, gr_stats* d_stats, void* hip_stream);
+int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, int64_t x_stride,
+                           const double* v, int64_t n, gr_point* points, gr_stats* stats);
+
+/* ---- apply(pf, cache): evaluate a built-in point function on endpoint records
+ * (point-functions.jl:98-101, rendering.jl:103-107) ---- */
+int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,
+                                      const gr_point* d_points, int64_t n, double max_time,
+                                      double* d_out, void* hip_stream);
+int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,
+                               const gr_point* points, int64_t n, double max_time, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRADUS_MI355X_H */

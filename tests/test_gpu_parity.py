@@ -1,0 +1,208 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Needs an MI355X."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+X_SMOKE = np.array([0.0, 100.0, math.radians(85), 0.0])
+X_FAR = np.array([0.0, 1000.0, math.radians(75), 0.0])
+ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
+
+# fp64 tolerance of the north star: redshift map rtol 1e-6 (integration tolerance 1e-9)
+RTOL = 1e-6
+
+
+def _metric(G, name, params):
+    return G.KerrMetric(*params) if name == "kerr" else G.JohannsenMetric(*params)
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize(
+    "name,params,disc,expected",
+    [
+        ("kerr", (1.0, 0.0), None, 9009.452876609641),
+        ("johannsen", (1.0, 0.0, 0.0, 0.0, 0.0, 0.0), None, 9009.448935932085),
+        ("kerr", (1.0, 0.0), (0.0, 40.0), 38412.08347901267),
+        ("johannsen", (1.0, 0.0, 0.0, 0.0, 0.0, 0.0), (0.0, 40.0), 38412.08386562321),
+    ],
+)
+def test_reference_fingerprints_on_device(G, ens, kernel, name, params, disc, expected):
+    """test/smoke-tests/rendergeodesics.jl:43-67 run through the HIP path."""
+    ens.set("kernel", kernel)
+    m = _metric(G, name, params)
+    args = (G.ThinDisc(*disc), 200.0) if disc else (200.0,)
+    _, _, img = G.rendergeodesics(m, X_SMOKE, *args, image_width=20, image_height=20, alpha_lims=(-9.5, 9.5),
+                                  beta_lims=(-9.5, 9.5), ensemble=ens)
+    assert float(np.nansum(img)) == pytest.approx(expected, rel=1e-6)
+
+
+def _compare_points(G, O, got, ref, rtol=RTOL):
+    mism = got["status"] != ref["status"]
+    assert mism.sum() <= max(2, got.size // 2000), f"{mism.sum()} status mismatches"
+    ok = ~mism
+    np.testing.assert_array_equal(got["flags"][ok], 0)
+    np.testing.assert_allclose(got["x_init"][ok], ref["x_init"][ok], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(got["v_init"][ok], ref["v_init"][ok], rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(got["lambda_max"][ok], ref["lambda_max"][ok], rtol=rtol)
+    # positions/velocities at the end point; ϕ and t are compared absolutely scaled by their size
+    for f in ("x", "v"):
+        scale = np.maximum(np.abs(ref[f][ok]), 1.0)
+        assert np.max(np.abs(got[f][ok] - ref[f][ok]) / scale) < 20 * rtol
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("disc", [None, "isco"])
+def test_endpoints_match_oracle_64(G, oracle, ens, kernel, disc):
+    ens.set("kernel", kernel)
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0) if disc else None
+    args = (d, 2000.0) if d else (2000.0,)
+    W = H = 64
+    _, _, cache = G.prerendergeodesics(m, X_FAR, *args, image_width=W, image_height=H, alpha_lims=ALIMS,
+                                       beta_lims=BLIMS, ensemble=ens)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    cfg = oracle.make_config("kerr", (1.0, 0.998), disc=(m.isco(), 50.0) if disc else None, lambda_max=2000.0)
+    ref = oracle.trace(cfg, X_FAR, oracle.render_velocities(cfg, X_FAR, ALIMS, BLIMS, W, H))
+    _compare_points(G, oracle, got, ref)
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_redshift_image_matches_oracle_128(G, oracle, ens, kernel):
+    """BASELINE config C2 geometry at 128x128: fused redshift ∘ filter_intersected."""
+    ens.set("kernel", kernel)
+    m = G.KerrMetric(1.0, 0.998)
+    isco = m.isco()
+    W = H = 128
+    pf = G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    _, _, img, st = G.rendergeodesics(m, X_FAR, G.ThinDisc(isco, 50.0), 2000.0, image_width=W, image_height=H,
+                                      alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens, stats=True)
+    cfg = oracle.make_config("kerr", (1.0, 0.998), disc=(isco, 50.0), lambda_max=2000.0)
+    ref = oracle.rendergeodesics(cfg, X_FAR, ALIMS, BLIMS, W, H, pf_id=oracle.PF_REDSHIFT,
+                                 filter_id=oracle.FILTER_INTERSECTED, r_isco=isco)
+    assert st["rays"] == W * H and st["flagged_rays"] == 0
+    nan_mismatch = np.isnan(img) != np.isnan(ref)
+    assert nan_mismatch.sum() <= 8
+    both = ~np.isnan(img) & ~np.isnan(ref)
+    assert both.sum() > 1000
+    np.testing.assert_allclose(img[both], ref[both], rtol=RTOL)
+
+
+def test_fused_image_equals_endpoints_plus_apply(G, ens):
+    """rendergeodesics(pf) == apply(pf, prerendergeodesics(...)) (test/smoke-tests/prerendergeodesics.jl:33-42)."""
+    ens.set("kernel", 1)
+    m = G.KerrMetric(1.0, 0.9)
+    d = G.ThinDisc(0.0, 40.0)
+    kw = dict(image_width=48, image_height=40, alpha_lims=(-20, 20), beta_lims=(-15, 15), ensemble=ens)
+    for pf in (G.ConstPointFunctions.shadow(),
+               G.ConstPointFunctions.redshift(m, X_SMOKE) @ G.ConstPointFunctions.filter_intersected()):
+        _, _, img = G.rendergeodesics(m, X_SMOKE, d, 200.0, pf=pf, **kw)
+        _, _, cache = G.prerendergeodesics(m, X_SMOKE, d, 200.0, **kw)
+        img2 = G.apply(pf, cache)
+        np.testing.assert_array_equal(np.isnan(img), np.isnan(img2))
+        ok = ~np.isnan(img)
+        np.testing.assert_allclose(img[ok], img2[ok], rtol=1e-12)
+
+
+def test_kernels_agree_bitwise(G, ens):
+    """Wave-ballot refill must not change any ray: persistent == one-ray-per-lane, bit for bit."""
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    out = []
+    for kernel, thr in ((0, 8), (1, 1), (1, 8), (1, 64)):
+        ens.set("kernel", kernel).set("refill_threshold", thr)
+        _, _, cache = G.prerendergeodesics(m, X_FAR, d, 2000.0, image_width=96, image_height=72, alpha_lims=ALIMS,
+                                           beta_lims=BLIMS, ensemble=ens)
+        out.append(cache.points.copy())
+    ens.set("refill_threshold", 8)
+    for o in out[1:]:
+        assert o.tobytes() == out[0].tobytes()
+
+
+def test_tracegeodesics_arrays_and_polar_counts(G, oracle, ens):
+    """tracegeodesics(m, x, plane, λ) on the device reproduces the reference's exact
+    WithinInnerBoundary counts (test/image-planes/test-polar-grids.jl:13-21)."""
+    ens.set("kernel", 1)
+    m = G.KerrMetric()
+    u = np.array([1.0, 1e3, math.pi / 2, 0.0])
+    for grid, n in ((G.LinearGrid(), 10), (G.GeometricGrid(), 30), (G.InverseGrid(), 80)):
+        pts = G.tracegeodesics(m, u, G.PolarPlane(grid, Nr=10, Nθ=10), (0.0, 2000.0), ensemble=ens)
+        assert int(np.sum(pts["status"] == G.StatusCodes.WithinInnerBoundary)) == n
+    kw = dict(x_min=0.1, y_min=0.1, Nx=12, Ny=12)
+    for grid, n in ((G.LinearGrid(), 1), (G.GeometricGrid(), 25), (G.InverseGrid(), 81)):
+        pts = G.tracegeodesics(m, u, G.CartesianPlane(grid, **kw), (0.0, 2000.0), ensemble=ens)
+        assert int(np.sum(pts["status"] == G.StatusCodes.WithinInnerBoundary)) == n
+
+
+def test_tracegeodesics_per_ray_positions(G, oracle, ens):
+    """(xs, vs) array input shape of geodesic-problem.jl:141-150, ragged size (not a multiple of 64)."""
+    m = G.KerrMetric(1.0, 0.5)
+    rng = np.random.default_rng(7)
+    n = 333
+    xs = np.column_stack([np.zeros(n), rng.uniform(20, 60, n), rng.uniform(0.4, 2.7, n), rng.uniform(0, 6, n)])
+    vs = np.stack([G.map_impact_parameters(m, x, a, b) for x, a, b in
+                   zip(xs, rng.uniform(-8, 8, n), rng.uniform(-8, 8, n))])
+    got = G.tracegeodesics(m, xs, vs, G.ThinDisc(2.0, 30.0), (0.0, 300.0), ensemble=ens)
+    cfg = oracle.make_config("kerr", (1.0, 0.5), disc=(2.0, 30.0), lambda_max=300.0)
+    ref = oracle.trace(cfg, xs, vs)
+    _compare_points(G, oracle, got, ref)
+
+
+def test_empty_and_single(G, ens):
+    m = G.KerrMetric()
+    x = X_SMOKE
+    pts = G.tracegeodesics(m, x, np.zeros((0, 4)), 200.0, ensemble=ens)
+    assert pts.shape == (0,)
+    v = G.map_impact_parameters(m, x, 1.0, 1.0)
+    pts = G.tracegeodesics(m, x, v, 200.0, ensemble=ens)
+    assert pts.shape == (1,) and pts["status"][0] == G.StatusCodes.WithinInnerBoundary
+    _, _, img = G.rendergeodesics(m, x, 200.0, image_width=1, image_height=1, alpha_lims=(0, 0), beta_lims=(0, 0),
+                                  ensemble=ens)
+    assert img.shape == (1, 1)
+
+
+def test_invalid_arguments_return_errors(G, ens):
+    with pytest.raises(G.GradusMI355XError, match="INVALID_ARGUMENT"):
+        G.tracegeodesics(G.KerrMetric(), X_SMOKE, np.zeros((2, 4)), 200.0, abstol=-1.0, ensemble=ens)
+    with pytest.raises(G.GradusMI355XError, match="INVALID_ARGUMENT"):
+        ens.set("kernel", 7)
+    ens.set("kernel", 1)
+
+
+def test_full_size_properties_1024(G, oracle, ens):
+    """BASELINE config C2 at full size: conservation laws on every ray and oracle parity on a
+    strided subset of the same pixels."""
+    ens.set("kernel", 1)
+    m = G.KerrMetric(1.0, 0.998)
+    isco = m.isco()
+    W = H = 1024
+    _, _, cache = G.prerendergeodesics(m, X_FAR, G.ThinDisc(isco, 50.0), 2000.0, image_width=W, image_height=H,
+                                       alpha_lims=ALIMS, beta_lims=BLIMS, ensemble=ens)
+    pts = np.ascontiguousarray(cache.points.T).ravel()
+    assert pts.size == W * H and np.all(pts["flags"] == 0)
+    assert np.all(pts["status"] != G.StatusCodes.NoStatus) or np.all(pts["lambda_max"][pts["status"] == 3] == 2000.0)
+
+    def EL(x, v):
+        s2 = np.sin(x[:, 2]) ** 2
+        Sig = x[:, 1] ** 2 + 0.998 ** 2 * (1 - s2)
+        w = 2 * x[:, 1] / Sig
+        gtt, gtp = w - 1, -0.998 * s2 * w
+        gpp = s2 * (x[:, 1] ** 2 + 0.998 ** 2 - 0.998 * gtp)
+        return -(gtt * v[:, 0] + gtp * v[:, 3]), gtp * v[:, 0] + gpp * v[:, 3]
+
+    E0, L0 = EL(pts["x_init"], pts["v_init"])
+    E1, L1 = EL(pts["x"], pts["v"])
+    fin = pts["status"] != G.StatusCodes.WithinInnerBoundary   # near the horizon Δ→0 amplifies rounding
+    assert np.max(np.abs(E1[fin] / E0[fin] - 1)) < 1e-6
+    assert np.max(np.abs(L1[fin] - L0[fin]) / np.maximum(np.abs(L0[fin]), 1.0)) < 1e-6
+    hit = pts["status"] == G.StatusCodes.IntersectedWithGeometry
+    assert hit.sum() > 50_000
+    assert np.all(np.abs(np.cos(pts["x"][hit, 2])) <= 0.01 + 1e-9)
+
+    # oracle parity on every 16th pixel in both directions (4096 rays)
+    idx = (np.arange(0, W, 16)[:, None] * H + np.arange(0, H, 16)[None, :]).ravel()
+    cfg = oracle.make_config("kerr", (1.0, 0.998), disc=(isco, 50.0), lambda_max=2000.0)
+    v_all = np.concatenate([oracle.render_velocities(cfg, X_FAR, ALIMS, BLIMS, W, H, i0=int(i), n=1) for i in idx])
+    ref = oracle.trace(cfg, X_FAR, v_all)
+    _compare_points(G, oracle, pts[idx], ref)

@@ -1,0 +1,111 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, struct layouts
+match the header, and the host-side mirror of the reference API agrees with the oracle."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(G):
+    hdr = open(os.path.join(ROOT, "include", "gradus_mi355x.h")).read()
+    declared = set(re.findall(r"\b(gr_[a-z_]+)\s*\(", hdr))
+    declared -= {"gr_ctx"}
+    lib = C.CDLL(G._lib.LIB_PATH)
+    assert declared == set(G._lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.gr_abi_version.restype = C.c_int32
+    assert lib.gr_abi_version() == 1
+
+
+def test_struct_layouts(G):
+    L = G._lib
+    assert L.POINT_DTYPE.itemsize == 152            # GeodesicPoint{Float64,Nothing}
+    assert C.sizeof(L.gr_config) == 8 + 64 + 8 * 10 + 8 + 8 + 8
+    assert C.sizeof(L.gr_plane) == 8 * (4 + 16 + 4) + 16 + 8
+    assert C.sizeof(L.gr_range) == 32
+    assert C.sizeof(L.gr_stats) == 80
+    assert C.sizeof(L.gr_pointfunction) == 8 + 16 + 8 + 32
+
+
+def test_no_device_means_loud_failure(G):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(G.GradusMI355XError) as ei:
+        G.Context(0)
+    assert ei.value.code == -3   # GR_ERR_NO_DEVICE: there is no CPU fallback
+    with pytest.raises(G.GradusMI355XError):
+        G.rendergeodesics(G.KerrMetric(), np.array([0.0, 100.0, 1.4, 0.0]), 200.0, image_width=4, image_height=4)
+
+
+def test_status_codes(G):
+    assert [int(s) for s in G.StatusCodes] == [0, 1, 2, 3]
+    assert G.StatusCodes.IntersectedWithGeometry == 2
+
+
+def test_host_observer_setup_matches_oracle(G, oracle):
+    x = np.array([0.0, 1000.0, math.radians(75), 0.0])
+    for m, (name, params) in (
+        (G.KerrMetric(1.0, 0.998), ("kerr", (1.0, 0.998))),
+        (G.KerrMetric(1.0, 0.0), ("kerr", (1.0, 0.0))),
+        (G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0), ("johannsen", (1.0, 0.7, 2.0, 0.0, 0.0, 1.0))),
+    ):
+        cfg = oracle.make_config(name, params)
+        np.testing.assert_allclose(G.lnrbasis_matrix(m, x), oracle.lnrbasis(cfg, x), rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(G.lnrframe_matrix(m, x), oracle.lnrframe(cfg, x), rtol=1e-12, atol=1e-15)
+        v = G.map_impact_parameters(m, x, np.array([1.0, -3.0]), np.array([2.0, 0.5]))
+        np.testing.assert_allclose(v, oracle.map_impact_parameters(cfg, x, [1.0, -3.0], [2.0, 0.5]), rtol=1e-12)
+        g, _, _ = oracle.metric_jacobian(cfg, x[1], x[2])
+        np.testing.assert_allclose(m.metric_components(x[1], x[2]), g, rtol=1e-13)
+        assert m.inner_radius() == pytest.approx(oracle.inner_radius(params[0], params[1]))
+
+
+def test_kerr_isco_matches_reference_table(G):
+    assert G.KerrMetric(1.0, 0.0).isco() == 6.0
+    assert G.KerrMetric(1.0, 1.0).isco() == 1.0
+    assert G.KerrMetric(1.0, 0.998).isco() == pytest.approx(1.2369706551751847, abs=1e-12)
+    assert G.KerrMetric(1.0, -0.998).isco() == pytest.approx(8.99437445480357, abs=1e-12)
+
+
+def test_planes(G):
+    assert G.trajectory_count(G.PolarPlane(G.LinearGrid(), Nr=10, Nθ=10)) == 100
+    pl = G.CartesianPlane(G.LinearGrid(), x_min=0.1, y_min=0.1, Nx=12, Ny=12)
+    a, b = G.impact_parameters(pl)
+    assert a.size == G.trajectory_count(pl) == 121
+    assert a.min() == -150.0 and a.max() == 150.0 and (a == 0.1).sum() == 11
+    g = G.GeometricGrid()(1.0, 250.0, 5)
+    assert g[0] == 1.0 and g[-1] == pytest.approx(250.0)
+
+
+def test_configuration_errors_mirror_reference(G):
+    m = G.KerrMetric()
+    x = np.array([0.0, 100.0, 1.4, 0.0])
+    with pytest.raises(ValueError, match="trajectories must be defined"):
+        G.tracing_configuration(m, x, lambda i: np.zeros(4), None, 200.0)
+    with pytest.raises(ValueError, match="save_on"):
+        G.tracing_configuration(m, x, np.zeros((2, 4)), None, 200.0, save_on=True)
+    with pytest.raises(AssertionError, match="α limits must be sorted"):
+        G.render_configuration(m, x, 200.0, image_width=4, image_height=4, alpha_lims=(1, -1), beta_lims=(-1, 1))
+    cfg = G.tracing_configuration(m, x, np.zeros((3, 4)), G.ThinDisc(0.0, 40.0), (0.0, 200.0)).abi_config()
+    assert cfg.disc_id == 1 and cfg.disc_r_out == 40.0 and cfg.gtol == 1e-2 and cfg.abstol == 1e-9
+    assert cfg.r_inner == pytest.approx(2.02) and cfg.r_outer == 12000.0 and cfg.maxiters == 1_000_000
+
+
+def test_pointfunction_composition(G):
+    CPF = G.ConstPointFunctions
+    pf = CPF.affine_time() @ CPF.filter_early_term()
+    assert pf.fusable and pf.device_pf == 0 and pf.device_filter == 1
+    gp = np.zeros(1, dtype=G.POINT_DTYPE)[0]
+    gp["lambda_max"] = 5.0
+    assert pf(None, gp, 10.0) == 5.0
+    assert math.isnan(pf(None, gp, 5.0))
+    custom = G.PointFunction(lambda m, gp, t, **kw: gp["x"][1]) @ CPF.filter_intersected()
+    assert not custom.fusable
+    assert math.isnan(custom(None, gp, 10.0))
