@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: null geodesics / second on a 2048 x 2048 Kerr image plane (BASELINE.json).
+
+One "step" = one complete render of the image plane: every rank traces its share of the
+2048² = 4 194 304 rays (KerrMetric a = 0.998, observer r = 1000, θ = 75°, ThinDisc(r_isco, 50),
+redshift ∘ filter_intersected, Tsit5 abstol = reltol = 1e-9) with the HIP kernels, results stay
+in HBM, then ONE RCCL gather assembles the image on rank 0.  Total work is fixed as N grows
+("scaling": "strong").
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md chip table): FP32 vector 157.3 TFLOP/s
+# => FP64 vector = half rate; HBM3E 8.0 TB/s spec.
+PEAK_FP64_VALU_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+
+# Algorithmic flops of the reference formulation, counted by the oracle compiled on a counting
+# scalar (oracle/flopcount.cpp, `make -C oracle count`): per attempted Tsit5 step
+# and per ray outside the step loop, for the bench workload.
+FLOPS_JSON = os.path.join(ROOT, "oracle", "flopcount.json")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=2048, help="image is size x size")
+    ap.add_argument("--kernel", type=int, default=1, help="0 = one ray per lane, 1 = persistent")
+    ap.add_argument("--refill-threshold", type=int, default=None)
+    ap.add_argument("--waves-per-simd", type=int, default=None)
+    ap.add_argument("--block-cols", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def workload(G, size, ens):
+    m = G.KerrMetric(M=1.0, a=0.998)
+    x = np.array([0.0, 1000.0, math.radians(75.0), 0.0])
+    d = G.ThinDisc(m.isco(), 50.0)
+    pf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+    cfg = G.render_configuration(m, x, d, 2000.0, image_width=size, image_height=size, alpha_lims=(-60.0, 60.0),
+                                 beta_lims=(-35.0, 35.0), ensemble=ens)
+    return m, x, d, pf, cfg
+
+
+def cpu_baseline(size, seconds):
+    """The oracle (OpenMP port of the reference algorithm -- NOT the Julia package) timed on this
+    host's cores on a strided sub-grid of the same image plane."""
+    from oracle import oracle as O
+
+    isco = 1.2369706551751847
+    cfg = O.make_config("kerr", (1.0, 0.998), disc=(isco, 50.0), lambda_max=2000.0)
+    x = np.array([0.0, 1000.0, math.radians(75.0), 0.0])
+    threads = O.lib().orc_max_threads()
+
+    def run(S):
+        # S x S pixels spread evenly over the same α/β window => same mix of ray lengths
+        v = O.render_velocities(cfg, x, (-60.0, 60.0), (-35.0, 35.0), S, S)
+        t0 = time.perf_counter()
+        pts = O.trace(cfg, x, v)
+        img = O.apply_pf(cfg, pts, 2000.0, pf_id=O.PF_REDSHIFT, filter_id=O.FILTER_INTERSECTED, r_isco=isco)
+        return S * S / (time.perf_counter() - t0), img
+
+    rate, _ = run(48)
+    S = int(min(512, max(48, math.sqrt(rate * seconds))))
+    rate, _ = run(S)
+    return {
+        "value": rate, "unit": "geodesics/s", "cores": threads, "kind": "port",
+        "sample": f"{S}x{S} pixels spanning the same image plane, C oracle with OpenMP on {threads} threads "
+                  f"(restatement of the reference algorithm; Julia is not available on this box)",
+    }
+
+
+def flop_model():
+    if os.path.exists(FLOPS_JSON):
+        with open(FLOPS_JSON) as f:
+            return json.load(f)
+    return None
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import gradus_jl_amd as G
+    from gradus_jl_amd import device as gdev
+
+    ens = G.EnsembleMI355X(local_rank, kernel=args.kernel)
+    if args.refill_threshold is not None:
+        ens.set("refill_threshold", args.refill_threshold)
+    if args.waves_per_simd is not None:
+        ens.set("waves_per_simd", args.waves_per_simd)
+    m, x, d, pf, cfg = workload(G, args.size, ens)
+    plan = G.shard_plan(args.size, args.size, world, rank, args.block_cols)
+    rg = plan.ray_range()
+    local = torch.empty(plan.count, dtype=torch.float64, device=dev)
+    stats = gdev.new_stats(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        gdev.render_device(cfg, pf, local, rg, stats if i is not None else None)
+        if i is not None:
+            ev[i][1].record()
+        return G.gather_image(local, plan)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    image = None
+    for i in range(args.steps):
+        image = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    st = gdev.stats_dict(stats)
+    total_rays = args.size * args.size
+    rays_per_s = total_rays * args.steps / elapsed
+
+    if rank == 0:
+        # sanity: the image is a real render (hits exist, values finite and O(1))
+        img = image.cpu().numpy()
+        hits = np.isfinite(img)
+        assert hits.sum() > 0.05 * total_rays and 0.0 < np.nanmin(img) and np.nanmax(img) < 2.0
+
+        rays_launch = st["rays"] / args.steps
+        steps_launch = (st["accepted_steps"] + st["rejected_steps"]) / args.steps
+        fm = flop_model()
+        if fm:
+            flops_launch = rays_launch * fm["flops_per_ray_fixed"] + steps_launch * fm["flops_per_step"]
+            flops_per_ray = flops_launch / rays_launch
+        else:
+            flops_per_ray = 3.0e5          # SURVEY §8(d) estimate until oracle/flopcount.json exists
+            flops_launch = rays_launch * flops_per_ray
+        achieved_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
+        bytes_launch = rays_launch * 8.0   # fused render: 8 B written per ray, 0 B read
+        achieved_gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "geodesics/sec, 2048^2 Kerr image plane (fp64 null geodesics, redshift image)",
+            "value": rays_per_s,
+            "unit": "geodesics/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"KerrMetric(a=0.998) {args.size}x{args.size} image plane, r_obs=1000, theta=75deg, "
+                            "ThinDisc(r_isco,50), redshift∘filter_intersected, Tsit5 tol 1e-9, lambda_max=2000",
+                "sharding": f"{world} rank(s), block-cyclic by {plan.block_cols} columns, one RCCL gather",
+                "kernel": "persistent+wave-ballot-refill" if args.kernel == 1 else "one-ray-per-lane",
+                "rays_per_gpu": plan.count,
+                "steps_per_ray": steps_launch / rays_launch,
+                "rejected_steps_per_ray": st["rejected_steps"] / max(st["rays"], 1),
+                "status_count_rank0": st["status_count"],
+            },
+            "roofline": {
+                "bound": "fp64-valu",
+                "note": "neither HBM nor MFMA binds this path (SURVEY §8d): the ODE state lives in registers; "
+                        "peak = FP64 vector ALU. HBM fraction reported beside it.",
+                "achieved": achieved_tflops,
+                "peak": PEAK_FP64_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_FP64_VALU_TFLOPS,
+                "flops_per_ray": flops_per_ray,
+                "flop_model": "oracle counting-scalar build" if fm else "SURVEY §8(d) estimate",
+                "kernel_ms": kernel_ms,
+                "traffic": None,
+                "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_ray": 8},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,8 @@ work runs in hand-written HIP kernels for gfx950; there is no CPU fallback.
 """
 from . import _lib
 from ._lib import Context, GradusMI355XError, POINT_DTYPE
+from . import device, distributed
+from .distributed import gather_image, shard_plan
 from .geometry import ThinDisc
 from .metrics import JohannsenMetric, KerrMetric, inner_radius, isco
 from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix

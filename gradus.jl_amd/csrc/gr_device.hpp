@@ -21,14 +21,23 @@
 // step controller needs one log2 and one exp2 per step and no sqrt.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/gradus_mi355x.h"
 
-namespace gr {
-
+#ifdef GR_HOST_HARNESS
+// tests/host_harness.cpp compiles this header with g++ to trace single rays on the CPU next to
+// the oracle.  Test infrastructure only: the shipped library never defines GR_HOST_HARNESS.
+#include <cmath>
+#define GR_DEV inline
+#define GR_RCP_SEED(x) (1.0 / (x))
+#else
+#include <hip/hip_runtime.h>
 #define GR_DEV __device__ __forceinline__
+#define GR_RCP_SEED(x) __builtin_amdgcn_rcp(x)
+#endif
+
+namespace gr {
 
 // ---------------------------------------------------------------------------------------
 // scalar helpers
@@ -36,7 +45,7 @@ namespace gr {
 GR_DEV double rcp_full(double x)
 {
     // v_rcp_f64 seed + two Newton steps: <= 1 ulp for normal, finite x
-    double r = __builtin_amdgcn_rcp(x);
+    double r = GR_RCP_SEED(x);
     double e = __builtin_fma(-x, r, 1.0);
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-x, r, 1.0);
@@ -46,7 +55,7 @@ GR_DEV double rcp_full(double x)
 GR_DEV double rcp_fast(double x)
 {
     // one Newton step: ~1e-14 relative or better; used where the consumer is a tolerance test
-    double r = __builtin_amdgcn_rcp(x);
+    double r = GR_RCP_SEED(x);
     double e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
 }
@@ -492,6 +501,9 @@ struct Ray {
     int32_t status, flags, event;
     int32_t nacc, nrej;
     int64_t iters;
+#ifdef GR_HOST_HARNESS
+    double dbg_e2;
+#endif
 
     // distance_to_disc(::ThinDisc), thin-disc.jl:20-26
     static GR_DEV double disc_cond(const Params& p, double r, double s, double c)
@@ -665,6 +677,9 @@ struct Ray {
             e2 = __builtin_fma(a, a, e2);
         }
         e2 *= 0.125;   // EEst² ; accept iff EEst <= 1
+#ifdef GR_HOST_HARNESS
+        dbg_e2 = e2;
+#endif
 
         // PI controller in log2 space: q = EEst^β1 / qold^β2 / γ
         const double lE = 0.5 * ::log2(e2);                  // log2(EEst); -inf when EEst == 0

@@ -1,0 +1,70 @@
+"""Sharding the image plane over the GPUs of one node (one process per GPU).
+
+Rays are independent (the reference fans them out over threads, src/tracing/tracing.jl:186), so
+each rank traces its own rays with no exchange; one RCCL gather over xGMI at the end assembles
+the H x W image on rank 0.  Rays are dealt block-cyclically in groups of `block_cols` image
+columns so every rank gets a similar mix of short (captured / disc-hit) and long (escaping) rays.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    width: int
+    height: int
+    world: int
+    rank: int
+    block_cols: int
+
+    @property
+    def block(self) -> int:          # rays per block
+        return self.block_cols * self.height
+
+    @property
+    def n_blocks(self) -> int:       # blocks per rank
+        return self.width // (self.block_cols * self.world)
+
+    @property
+    def count(self) -> int:          # rays of this rank
+        return self.n_blocks * self.block
+
+    def ray_range(self) -> _lib.gr_range:
+        return _lib.gr_range(self.rank * self.block, self.count, self.block, self.world)
+
+    def global_index(self, j):
+        """image ray index of local ray j (same formula as gr_range in the C ABI)."""
+        b = j // self.block
+        return self.rank * self.block + b * self.world * self.block + (j - b * self.block)
+
+
+def shard_plan(width: int, height: int, world: int, rank: int, block_cols: int = 8) -> ShardPlan:
+    bc = block_cols
+    while bc > 1 and width % (bc * world) != 0:
+        bc //= 2
+    if width % (bc * world) != 0:
+        raise ValueError(f"image width {width} cannot be dealt in column blocks over {world} ranks")
+    return ShardPlan(width, height, world, rank, bc)
+
+
+def gather_image(local, plan: ShardPlan, group=None, dst: int = 0):
+    """One collective: gather every rank's compact slab on `dst` and undo the block-cyclic deal.
+    `local` is a 1-D tensor of plan.count values in local ray order.  Returns the (H, W) image on
+    `dst` (None elsewhere).  Works with RCCL ("nccl") on GPUs and gloo on CPU tensors."""
+    import torch
+    import torch.distributed as dist
+
+    if plan.world == 1:
+        full = local
+    else:
+        bufs = [torch.empty_like(local) for _ in range(plan.world)] if plan.rank == dst else None
+        dist.gather(local, bufs, dst=dst, group=group)
+        if plan.rank != dst:
+            return None
+        full = torch.stack(bufs)                                   # [world, n_blocks * block]
+        full = full.view(plan.world, plan.n_blocks, plan.block).permute(1, 0, 2).reshape(-1)
+    # linear index i = x*H + y  ->  Julia's (H, W) column-major matrix
+    return full.view(plan.width, plan.height).t()

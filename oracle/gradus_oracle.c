@@ -489,12 +489,14 @@ static int discrete_callbacks(const orc_config* c, const double u[8], int* statu
 typedef struct {
     double *r, *vt, *vr, *vphi;
     int64_t cap, n;
+    double *t;      /* optional: affine time of every saved state */
 } save_t;
 
-static void save_state(save_t* s, const double u[8])
+static void save_state(save_t* s, const double u[8], double t)
 {
     if (!s || s->n >= s->cap) return;
     s->r[s->n] = u[1]; s->vt[s->n] = u[4]; s->vr[s->n] = u[5]; s->vphi[s->n] = u[7];
+    if (s->t) s->t[s->n] = t;
     s->n++;
 }
 
@@ -511,7 +513,7 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
     int status = ORC_NO_STATUS, flags = 0;
     int n_acc = 0, n_rej = 0, n_rhs = 0, n_cond = 0;
     double t = t0;
-    save_state(save, u);
+    save_state(save, u, t);
 
     /* ---- initial dt: ode_determine_initdt (App. A.4) ---- */
     double f0[8], sk[8];
@@ -653,7 +655,7 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
             memcpy(k[0], k[6], sizeof k[0]);   /* FSAL */
             t = tnew;
             dt = dtpropose;
-            save_state(save, u);
+            save_state(save, u, t);
             /* check_error!: unstable_check = any(isnan, u) */
             int bad = 0;
             for (int i = 0; i < 8; ++i) if (!(u[i] == u[i])) bad = 1;
@@ -967,8 +969,23 @@ int64_t orc_plunging_table(const orc_config* c, double r_isco, double* r, double
     const double den = -g[1];
     double u0[8] = { 0.0, r_isco - dr, M_PI / 2.0, 0.0, vtt, -sqrt(fabs(nom / den)), 0.0, vpp };
     u0[4] = orc_constrain_time(&cc, u0, u0 + 4);
-    save_t sv = { r, vt, vr, vphi, cap, 0 };
+    save_t sv = { r, vt, vr, vphi, cap, 0, NULL };
     orc_point pt;
     integrate(&cc, u0, &pt, NULL, &sv);
+    return sv.n;
+}
+
+/* debugging aid for the tests: every accepted step (t, r) of one ray */
+int64_t orc_trace_steps(const orc_config* c, const double x[4], const double v[4], orc_point* out,
+                        double* t, double* r, int64_t cap)
+{
+    double u0[8];
+    memcpy(u0, x, 4 * sizeof(double));
+    memcpy(u0 + 4, v, 4 * sizeof(double));
+    u0[4] = orc_constrain_time(c, x, v);
+    double* scratch = (double*)malloc(sizeof(double) * 3 * (size_t)cap);
+    save_t sv = { r, scratch, scratch + cap, scratch + 2 * cap, cap, 0, t };
+    integrate(c, u0, out, NULL, &sv);
+    free(scratch);
     return sv.n;
 }

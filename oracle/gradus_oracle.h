@@ -129,6 +129,9 @@ void orc_apply_pf(const orc_config* c, const orc_pf* pf, const orc_point* pts, i
 int64_t orc_plunging_table(const orc_config* c, double r_isco, double* r, double* vt, double* vr,
                            double* vphi, int64_t cap);
 
+int64_t orc_trace_steps(const orc_config* c, const double x[4], const double v[4], orc_point* out,
+                        double* t, double* r, int64_t cap);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -118,6 +118,8 @@ def lib():
         L.orc_plunging_table.restype = C.c_int64
         L.orc_tsit5_tableau.argtypes = [dp, dp, dp, dp]
         L.orc_max_threads.restype = C.c_int
+        L.orc_trace_steps.argtypes = [cp, dp, dp, C.c_void_p, dp, dp, C.c_int64]
+        L.orc_trace_steps.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -298,3 +300,13 @@ def tsit5_tableau():
     r = np.zeros((7, 4))
     lib().orc_tsit5_tableau(_dp(c), _dp(a), _dp(bt), _dp(r))
     return c, a, bt, r
+
+
+def trace_steps(cfg, x, v, cap=100000):
+    """(point, t[], r[]) of every accepted step of one ray (debugging aid)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.zeros(1, dtype=POINT_DTYPE)
+    t, r = np.zeros(cap), np.zeros(cap)
+    n = lib().orc_trace_steps(C.byref(cfg), _dp(x), _dp(v), out.ctypes.data, _dp(t), _dp(r), cap)
+    return out[0], t[:n], r[:n]

@@ -1,0 +1,84 @@
+// host_harness.cpp -- TEST INFRASTRUCTURE.  Compiles the device integrator (gr_device.hpp) for
+// the host with g++ so that tests can run the exact kernel logic ray by ray on a CPU, next to the
+// oracle, and log its steps.  Never linked into libgradus_mi355x.so.
+#define GR_HOST_HARNESS 1
+#include <cstring>
+
+#include "../gradus.jl_amd/csrc/gr_device.hpp"
+
+using namespace gr;
+
+template <class Metric, int DISC>
+static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
+{
+    Metric m;
+    m.load(p.cfg.params);
+    for (int64_t j = 0; j < n; ++j) {
+        Ray<Metric, DISC> ray;
+        ray.init(m, p, j);
+        int64_t k = 0;
+        if (tlog && k < cap) { tlog[k] = ray.t; hlog[k] = ray.dt; ++k; }
+        for (;;) {
+            const bool fin = ray.step(m, p);
+            if (tlog && k < cap) { tlog[k] = ray.t; hlog[k] = ray.dbg_e2; ++k; }
+            if (fin) break;
+        }
+        if (nlog) *nlog = k;
+        ray.finalize(m, p);
+    }
+}
+
+static void dispatch(const Params& p, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
+{
+    const bool disc = p.cfg.disc_id == GR_DISC_THIN;
+    if (p.cfg.metric_id == GR_METRIC_KERR) {
+        if (disc) run<KerrMetric, 1>(p, p.n, tlog, hlog, cap, nlog); else run<KerrMetric, 0>(p, p.n, tlog, hlog, cap, nlog);
+    } else {
+        if (disc) run<JohannsenMetric, 1>(p, p.n, tlog, hlog, cap, nlog); else run<JohannsenMetric, 0>(p, p.n, tlog, hlog, cap, nlog);
+    }
+}
+
+extern "C" {
+
+int hh_render_endpoints(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, gr_point* out)
+{
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.cfg = *cfg; p.src_mode = 0; p.out_mode = 1; p.plane = *plane; p.range = *rg; p.n = rg->count; p.points = out;
+    dispatch(p, nullptr, nullptr, 0, nullptr);
+    return 0;
+}
+
+int hh_render(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, const gr_pointfunction* pf, double* image)
+{
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.cfg = *cfg; p.src_mode = 0; p.out_mode = 0; p.plane = *plane; p.range = *rg; p.n = rg->count; p.image = image;
+    p.pf.pf_id = pf->pf_id; p.pf.filter_id = pf->filter_id; p.pf.fill = pf->fill; p.pf.r_isco = pf->r_isco;
+    p.pf.n_plunge = pf->n_plunge; p.pf.plunge_r = pf->plunge_r; p.pf.plunge_vt = pf->plunge_vt;
+    p.pf.plunge_vr = pf->plunge_vr; p.pf.plunge_vphi = pf->plunge_vphi;
+    dispatch(p, nullptr, nullptr, 0, nullptr);
+    return 0;
+}
+
+int hh_trace_endpoints(const gr_config* cfg, const double* x, int64_t x_stride, const double* v, int64_t n, gr_point* out)
+{
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.cfg = *cfg; p.src_mode = 1; p.out_mode = 1; p.x = x; p.x_stride = x_stride; p.v = v; p.n = n; p.points = out;
+    p.range = gr_range{ 0, n, n > 0 ? n : 1, 1 };
+    dispatch(p, nullptr, nullptr, 0, nullptr);
+    return 0;
+}
+
+// one ray of a plane with a log of (t, h) after every attempted step
+int64_t hh_step_log(const gr_config* cfg, const gr_plane* plane, int64_t i, gr_point* out, double* tlog, double* hlog, int64_t cap)
+{
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.cfg = *cfg; p.src_mode = 0; p.out_mode = 1; p.plane = *plane; p.range = gr_range{ i, 1, 1, 1 }; p.n = 1; p.points = out;
+    int64_t n = 0;
+    dispatch(p, tlog, hlog, cap, &n);
+    return n;
+}
+}

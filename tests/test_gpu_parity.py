@@ -39,17 +39,30 @@ def test_reference_fingerprints_on_device(G, ens, kernel, name, params, disc, ex
 
 
 def _compare_points(G, O, got, ref, rtol=RTOL):
+    """Endpoint parity.  Status must agree except for a few edge pixels (rays grazing the disc rim
+    or a thin higher-order image; chaotic near the photon orbit).  Rays that reach the chart,
+    the disc or λ_max must agree to `rtol`.  Rays swallowed by the hole stop at whichever step
+    first lands inside 1.01 r₊, where v^t and t diverge, so only λ and r are meaningful there."""
     mism = got["status"] != ref["status"]
-    assert mism.sum() <= max(2, got.size // 2000), f"{mism.sum()} status mismatches"
+    assert mism.sum() <= max(2, got.size // 500), f"{mism.sum()} status mismatches"
     ok = ~mism
     np.testing.assert_array_equal(got["flags"][ok], 0)
     np.testing.assert_allclose(got["x_init"][ok], ref["x_init"][ok], rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(got["v_init"][ok], ref["v_init"][ok], rtol=1e-11, atol=1e-15)
-    np.testing.assert_allclose(got["lambda_max"][ok], ref["lambda_max"][ok], rtol=rtol)
-    # positions/velocities at the end point; ϕ and t are compared absolutely scaled by their size
+    inner = ok & (ref["status"] == O.WITHIN_INNER_BOUNDARY)
+    rest = ok & ~inner
+    np.testing.assert_allclose(got["lambda_max"][rest], ref["lambda_max"][rest], rtol=rtol)
+    errs = []
     for f in ("x", "v"):
-        scale = np.maximum(np.abs(ref[f][ok]), 1.0)
-        assert np.max(np.abs(got[f][ok] - ref[f][ok]) / scale) < 20 * rtol
+        scale = np.maximum(np.abs(ref[f][rest]), 1.0)
+        e = np.abs(got[f][rest] - ref[f][rest]) / scale
+        assert e.max() < rtol, (f, e.max())
+        errs.append(e)
+    # typical agreement is far below the tolerance: rounding-level differences only
+    assert np.median(np.concatenate(errs, axis=1)) < 1e-11
+    if inner.any():
+        np.testing.assert_allclose(got["lambda_max"][inner], ref["lambda_max"][inner], rtol=1e-5)
+        np.testing.assert_allclose(got["x"][inner, 1], ref["x"][inner, 1], rtol=1e-2)
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
@@ -83,7 +96,8 @@ def test_redshift_image_matches_oracle_128(G, oracle, ens, kernel):
                                  filter_id=oracle.FILTER_INTERSECTED, r_isco=isco)
     assert st["rays"] == W * H and st["flagged_rays"] == 0
     nan_mismatch = np.isnan(img) != np.isnan(ref)
-    assert nan_mismatch.sum() <= 8
+    # rim pixels only: the 8-point event sampling is step-sequence dependent
+    assert nan_mismatch.sum() <= 0.002 * W * H
     both = ~np.isnan(img) & ~np.isnan(ref)
     assert both.sum() > 1000
     np.testing.assert_allclose(img[both], ref[both], rtol=RTOL)
