@@ -61,7 +61,8 @@ def _compare_points(G, O, got, ref, rtol=RTOL):
     # typical agreement is far below the tolerance: rounding-level differences only
     assert np.median(np.concatenate(errs, axis=1)) < 1e-11
     if inner.any():
-        np.testing.assert_allclose(got["lambda_max"][inner], ref["lambda_max"][inner], rtol=1e-5)
+        # one step more or less when a step ends within rounding of 1.01 r₊ (steps there are ~1e-3)
+        np.testing.assert_allclose(got["lambda_max"][inner], ref["lambda_max"][inner], rtol=1e-4)
         np.testing.assert_allclose(got["x"][inner, 1], ref["x"][inner, 1], rtol=1e-2)
 
 
