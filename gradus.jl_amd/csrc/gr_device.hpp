@@ -31,10 +31,14 @@
 #include <cmath>
 #define GR_DEV inline
 #define GR_RCP_SEED(x) (1.0 / (x))
+#define GR_LOG2F(x) std::log2((float)(x))
+#define GR_EXP2F(x) std::exp2((float)(x))
 #else
 #include <hip/hip_runtime.h>
 #define GR_DEV __device__ __forceinline__
 #define GR_RCP_SEED(x) __builtin_amdgcn_rcp(x)
+#define GR_LOG2F(x) __builtin_amdgcn_logf(x)     // v_log_f32
+#define GR_EXP2F(x) __builtin_amdgcn_exp2f(x)    // v_exp_f32
 #endif
 
 namespace gr {
@@ -60,6 +64,8 @@ GR_DEV double rcp_fast(double x)
     return __builtin_fma(r, e, r);
 }
 GR_DEV int sgn(double x) { return (x > 0.0) - (x < 0.0); }
+GR_DEV float fast_log2f(float x) { return GR_LOG2F(x); }
+GR_DEV float fast_exp2f(float x) { return GR_EXP2F(x); }
 
 // sin and cos of x for moderate |x| (|x| < ~1e5): two-term Cody-Waite reduction by pi/2 with
 // exact-product FMAs, then the fdlibm minimax kernels on [-pi/4, pi/4].  < 1 ulp each.
@@ -328,6 +334,69 @@ struct Ts {
     };
 };
 
+
+// Derived tables for the second-order (x' = v, v' = a) structure of the geodesic ODE.  Stage
+// velocities are v_j = v + h Σ_{i<j} a_ji A_i, so every Σ_j w_j v_j that Tsit5 needs for the
+// position half of the state collapses to (Σ_j w_j) v + h Σ_i (Σ_{j>i} w_j a_ji) A_i.  Only the
+// stage ACCELERATIONS A_i are stored (28 doubles instead of 56); results differ from the
+// first-order bookkeeping by rounding only.
+struct TsX {
+    double C[7];       // c_s = Σ_j a_sj
+    double AX[7][7];   // ā_si = Σ_{i<j<s} a_sj a_ji
+    double SBT;        // Σ_j b̃_j (zero up to rounding of the published coefficients)
+    double BTX[7];     // Σ_{j>i} b̃_j a_ji
+    double SR[4];      // Σ_j R[j][m]  (1, ~0, ~0, ~0)
+    double RX[7][4];   // Σ_{j>i} R[j][m] a_ji
+    double K2;         // max_j Σ_i |Σ_m RX[i][m] Θ_j^(m+1)| over the sample points Θ_j = j/7
+};
+constexpr TsX make_tsx()
+{
+    TsX t{};
+    for (int s = 0; s < 7; ++s) {
+        double c = 0.0;
+        for (int j = 0; j < s && j < 6; ++j) c += Ts::A[s][j];
+        t.C[s] = c;
+        for (int i = 0; i < 7; ++i) {
+            double a = 0.0;
+            for (int j = i + 1; j < s && j < 6; ++j) a += Ts::A[s][j] * Ts::A[j][i];
+            t.AX[s][i] = a;
+        }
+    }
+    double sb = 0.0;
+    for (int j = 0; j < 7; ++j) sb += Ts::BT[j];
+    t.SBT = sb;
+    for (int i = 0; i < 7; ++i) {
+        double a = 0.0;
+        for (int j = i + 1; j < 7; ++j) a += Ts::BT[j] * (i < 6 ? Ts::A[j][i] : 0.0);
+        t.BTX[i] = a;
+    }
+    for (int m = 0; m < 4; ++m) {
+        double sr = 0.0;
+        for (int j = 0; j < 7; ++j) sr += Ts::R[j][m];
+        t.SR[m] = sr;
+        for (int i = 0; i < 7; ++i) {
+            double a = 0.0;
+            for (int j = i + 1; j < 7; ++j) a += Ts::R[j][m] * (i < 6 ? Ts::A[j][i] : 0.0);
+            t.RX[i][m] = a;
+        }
+    }
+    double k2 = 0.0;
+    for (int jj = 1; jj <= 6; ++jj) {
+        const double th = (double)jj / 7.0;
+        double sum = 0.0;
+        for (int i = 0; i < 7; ++i) {
+            const double b = th * (t.RX[i][0] + th * (t.RX[i][1] + th * (t.RX[i][2] + th * t.RX[i][3])));
+            sum += b < 0.0 ? -b : b;
+        }
+        if (sum > k2) k2 = sum;
+    }
+    t.K2 = k2;
+    return t;
+}
+struct TsD {
+    static constexpr TsX X = make_tsx();
+};
+
 // PI controller constants (App. A.3)
 constexpr double PI_BETA1 = 7.0 / 50.0;
 constexpr double PI_BETA2 = 2.0 / 25.0;
@@ -335,6 +404,9 @@ constexpr double PI_GAMMA = 0.9;
 constexpr double PI_QMIN = 0.2;
 constexpr double PI_QMAX = 10.0;
 constexpr double LOG2_QOLDINIT = -13.287712379549449;  // log2(1e-4)
+// bounds used to skip the event sampling (see Ray::sample_event); 1e-6 of slack for rounding
+constexpr double DENSE_K1 = 1.000001;
+constexpr double DENSE_K2 = TsD::X.K2 * 1.000001;
 
 // ---------------------------------------------------------------------------------------
 // kernel parameter block (uniform, lives in the kernarg segment / SGPRs)
@@ -349,27 +421,47 @@ struct PfDev {
     const double* plunge_vphi;
 };
 
-struct Params {
-    gr_config cfg;
+// Per-launch data that only init()/finalize() touch.  It lives in device memory behind a pointer
+// (not in the kernarg segment) and is re-read at each use, so that its ~60 scalars are not kept
+// live in SGPRs across the hot step loop.
+struct Cold {
     int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays
     int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records
+    int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
+    int32_t _pad;
     gr_plane plane;
     gr_range range;
     const double* x;          // device
     int64_t x_stride;
     const double* v;          // device
-    int64_t n;                // rays in this call
     double* image;            // device
     gr_point* points;         // device
     PfDev pf;
+};
+
+struct Params {
+    gr_config cfg;
+    const Cold* cold;         // device
+    int64_t n;                // rays in this call
     unsigned long long* stats;  // device: 9 counters (see gr_stats order), may be null
     unsigned long long* queue;  // device: persistent-kernel work counter
     int32_t refill_threshold;
-    int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
+    int32_t _pad;
+    double wedge;             // asin(gtol) with a hair of slack: |θ - π/2| beyond it cannot hit the disc
 };
 
+// read the cold block through a pointer the optimiser cannot hoist loads from
+GR_DEV const Cold& cold_of(const Params& p)
+{
+    const Cold* c = p.cold;
+#ifndef GR_HOST_HARNESS
+    asm volatile("" : "+s"(c));
+#endif
+    return *c;
+}
+
 // local ray index -> swizzled local index so that 64 consecutive work items cover an 8x8 tile
-GR_DEV int64_t tile_swizzle(const Params& p, int64_t j)
+GR_DEV int64_t tile_swizzle(const Cold& p, int64_t j)
 {
     if (!p.swizzle) return j;
     const int64_t H = p.plane.height;
@@ -442,18 +534,18 @@ GR_DEV void circular_fourvelocity(const Metric& m, double rho, double& vt, doubl
 
 // redshift_function(m, gp) / interpolate_redshift closure; redshift.jl:192-220,246-276
 template <class Metric>
-GR_DEV double redshift_pf(const Metric& m, const Params& p, const double x0[4], const double v0[4],
+GR_DEV double redshift_pf(const Metric& m, const Params& pp, const Cold& p, const double x0[4], const double v0[4],
                           const double x[4], const double v[4])
 {
     double s, c;
     sincos_fast(x[2], s, c);
     const double rho = x[1] * ::fabs(s);
     double dt_, dr_, dp_;
-    const bool kerr_analytic = (p.cfg.metric_id == GR_METRIC_KERR) && (p.pf.n_plunge == 0);
+    const bool kerr_analytic = (pp.cfg.metric_id == GR_METRIC_KERR) && (p.pf.n_plunge == 0);
     const double isco = p.pf.r_isco;
     if (rho < isco) {
         if (kerr_analytic) {
-            const double M = p.cfg.params[0], a = p.cfg.params[1];
+            const double M = pp.cfg.params[0], a = pp.cfg.params[1];
             const double Le = kerr_plunge_Le(M, isco, a);
             const double H = (2.0 * M * rho - a * Le) / (rho * rho - 2.0 * M * rho + a * a);
             const double ge = ::sqrt(1.0 - (2.0 * M) / (3.0 * isco));
@@ -489,18 +581,20 @@ GR_DEV double redshift_pf(const Metric& m, const Params& p, const double x0[4], 
 // ---------------------------------------------------------------------------------------
 // The per-lane integrator.
 // ---------------------------------------------------------------------------------------
+enum : int32_t { RAY_EVENT = 0x100 };   // bit in Ray::flags while a disc event awaits its root find
+
 template <class Metric, int DISC>
 struct Ray {
-    double u[8];        // (t, r, θ, ϕ, v^t, v^r, v^θ, v^ϕ) at the start of the current step
-    double k[7][8];     // Tsit5 stages; k[0] is FSAL
+    double x[4];        // (t, r, θ, ϕ) at the start of the current step
+    double v[4];        // (v^t, v^r, v^θ, v^ϕ)
+    double A[7][4];     // stage accelerations; A[0] is FSAL
     double t, dt, h;    // affine time, proposed step, last used step
-    double lq_old;      // log2(qold)
-    double cprev;       // disc condition at u
-    double ev_top;      // Θ of the upper bracket when an event is pending
+    double cprev;       // disc condition at x
+    float lq_old;       // log2(qold)
+    int32_t ev_top;     // upper bracket j of Θ = j/7 when an event is pending
     int64_t j;          // local (swizzled) ray index
-    int32_t status, flags, event;
+    int32_t status, flags;
     int32_t nacc, nrej;
-    int64_t iters;
 #ifdef GR_HOST_HARNESS
     double dbg_e2;
 #endif
@@ -526,8 +620,9 @@ struct Ray {
     }
 
     // initial position / unconstrained velocity of local ray jl
-    static GR_DEV void initial_conditions(const Params& p, int64_t jl, double x[4], double v[4])
+    static GR_DEV void initial_conditions(const Params& pp, int64_t jl, double x0[4], double v0[4])
     {
+        const Cold& p = cold_of(pp);
         if (p.src_mode == 0) {
             // _render_velocity_function, rendering.jl:140-163 ; local_momentum, utility.jl:13-20
             const int64_t i = range_map(p.range, jl);
@@ -541,35 +636,31 @@ struct Ray {
             const double pb[4] = { 1.0, pr, b * pr, a * pr };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                x[q] = p.plane.x_obs[q];
-                v[q] = p.plane.Mx[q * 4 + 0] * pb[0] + p.plane.Mx[q * 4 + 1] * pb[1] + p.plane.Mx[q * 4 + 2] * pb[2]
-                       + p.plane.Mx[q * 4 + 3] * pb[3];
+                x0[q] = p.plane.x_obs[q];
+                v0[q] = p.plane.Mx[q * 4 + 0] * pb[0] + p.plane.Mx[q * 4 + 1] * pb[1] + p.plane.Mx[q * 4 + 2] * pb[2]
+                        + p.plane.Mx[q * 4 + 3] * pb[3];
             }
         } else {
             const double* xs = p.x + jl * p.x_stride;
             const double* vs = p.v + jl * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { x[q] = xs[q]; v[q] = vs[q]; }
+            for (int q = 0; q < 4; ++q) { x0[q] = xs[q]; v0[q] = vs[q]; }
         }
     }
 
     // constrain_all (constraints.jl:14-15): v^t from the null/mass-shell condition
-    static GR_DEV void constrained_u0(const Metric& m, const Params& p, int64_t jl, double u0[8])
+    static GR_DEV void constrained_u0(const Metric& m, const Params& p, int64_t jl, double x0[4], double v0[4])
     {
-        double x[4], v[4];
-        initial_conditions(p, jl, x, v);
+        initial_conditions(p, jl, x0, v0);
         double s, c, g[5];
-        sincos_fast(x[2], s, c);
-        m.comps(x[1], s, c, g);
-        v[0] = constrain_time(g, v[1], v[2], v[3], p.cfg.mu);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { u0[q] = x[q]; u0[4 + q] = v[q]; }
+        sincos_fast(x0[2], s, c);
+        m.comps(x0[1], s, c, g);
+        v0[0] = constrain_time(g, v0[1], v0[2], v0[3], p.cfg.mu);
     }
 
-    GR_DEV void rhs_at(const Metric& m, const double y[8], double kk[8], double& s, double& c) const
+    static GR_DEV void accel(const Metric& m, double r, double th, const double vv[4], double a[4], double& s, double& c)
     {
-        kk[0] = y[4]; kk[1] = y[5]; kk[2] = y[6]; kk[3] = y[7];
-        geodesic_rhs(m, y[1], y[2], y[4], y[5], y[6], y[7], kk[4], kk[5], kk[6], kk[7], s, c);
+        geodesic_rhs(m, r, th, vv[0], vv[1], vv[2], vv[3], a[0], a[1], a[2], a[3], s, c);
     }
 
     // reinit! + auto_dt_reset! (tracing.jl:234-243; App. A.4)
@@ -577,24 +668,28 @@ struct Ray {
     {
         j = jl;
         status = GR_STATUS_NO_STATUS;
-        flags = 0; event = 0; nacc = 0; nrej = 0; iters = 0;
-        constrained_u0(m, p, jl, u);
+        flags = 0; nacc = 0; nrej = 0; ev_top = 0;
+        constrained_u0(m, p, jl, x, v);
         t = p.cfg.lambda0;
-        h = 0.0; ev_top = 0.0;
-        lq_old = LOG2_QOLDINIT;
+        h = 0.0;
+        lq_old = (float)LOG2_QOLDINIT;
         double s, c;
-        rhs_at(m, u, k[0], s, c);
-        cprev = DISC ? disc_cond(p, u[1], s, c) : 1.0;
+        accel(m, x[1], x[2], v, A[0], s, c);
+        cprev = DISC ? disc_cond(p, x[1], s, c) : 1.0;
 
         const double abstol = p.cfg.abstol, reltol = p.cfg.reltol;
         const double dtmax = ::fabs(p.cfg.lambda1 - p.cfg.lambda0);
-        double isk[8], d0s = 0.0, d1s = 0.0;
+        double iskx[4], iskv[4], d0s = 0.0, d1s = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            isk[i] = rcp_full(abstol + ::fabs(u[i]) * reltol);
-            const double a0 = u[i] * isk[i], a1 = k[0][i] * isk[i];
+        for (int i = 0; i < 4; ++i) {
+            iskx[i] = rcp_full(abstol + ::fabs(x[i]) * reltol);
+            iskv[i] = rcp_full(abstol + ::fabs(v[i]) * reltol);
+            const double a0 = x[i] * iskx[i], b0 = v[i] * iskv[i];
+            const double a1 = v[i] * iskx[i], b1 = A[0][i] * iskv[i];
             d0s = __builtin_fma(a0, a0, d0s);
+            d0s = __builtin_fma(b0, b0, d0s);
             d1s = __builtin_fma(a1, a1, d1s);
+            d1s = __builtin_fma(b1, b1, d1s);
         }
         const double d0 = ::sqrt(d0s * 0.125), d1 = ::sqrt(d1s * 0.125);
         double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
@@ -602,15 +697,17 @@ struct Ray {
         if (dt0 < 10.0 * 2.220446049250313e-16) {
             dt = 1e-6;
         } else {
-            double y[8], f1[8];
+            double v1[4], a1[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) y[i] = __builtin_fma(dt0, k[0][i], u[i]);
-            rhs_at(m, y, f1, s, c);
+            for (int i = 0; i < 4; ++i) v1[i] = __builtin_fma(dt0, A[0][i], v[i]);
+            accel(m, __builtin_fma(dt0, v[1], x[1]), __builtin_fma(dt0, v[2], x[2]), v1, a1, s, c);
             double d2s = 0.0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const double a2 = (f1[i] - k[0][i]) * isk[i];
-                d2s = __builtin_fma(a2, a2, d2s);
+            for (int i = 0; i < 4; ++i) {
+                const double ex = (v1[i] - v[i]) * iskx[i];
+                const double ev = (a1[i] - A[0][i]) * iskv[i];
+                d2s = __builtin_fma(ex, ex, d2s);
+                d2s = __builtin_fma(ev, ev, d2s);
             }
             const double d2 = ::sqrt(d2s * 0.125) / dt0;
             const double dm = ::fmax(d1, d2);
@@ -619,32 +716,56 @@ struct Ray {
         }
     }
 
+    // Σ_{i<n} W[i] A[i][comp], compile-time weights
+    template <int N, class W>
+    GR_DEV double asum(const W& w, int comp) const
+    {
+        double acc = w(0) * A[0][comp];
+#pragma unroll
+        for (int i = 1; i < N; ++i) acc = __builtin_fma(w(i), A[i][comp], acc);
+        return acc;
+    }
+
     // One attempted Tsit5 step.  Returns true when the ray has finished (terminated by a
     // callback, reached λ1, or hit an anomaly).
     GR_DEV bool step(const Metric& m, const Params& p)
     {
         const double tend = p.cfg.lambda1;
         const double dtmax = ::fabs(tend - p.cfg.lambda0);
-        if (++iters > p.cfg.maxiters) { flags |= GR_FLAG_MAXITERS; return true; }
+        if (nacc + nrej >= p.cfg.maxiters) { flags |= GR_FLAG_MAXITERS; return true; }
         double hh = ::fmin(dt, dtmax);
         if (!(hh == hh)) { flags |= GR_FLAG_NAN; return true; }
         if (hh < 4.0 * 2.220446049250313e-16 * ::fmax(::fabs(t), 1.0)) { flags |= GR_FLAG_DTMIN; return true; }
         hh = ::fmin(hh, tend - t);
         h = hh;
+        const double h2 = hh * hh;
+        constexpr const TsX& X = TsD::X;
 
-        double y[8], s, c;
-        // stages 2..6 (arguments need r, θ and the four velocities only: the RHS does not
+        double s, c;
+        // stages 2..6: arguments need r, θ and the four velocities only (the RHS does not
         // depend on t or ϕ)
-#define GR_STAGE(S)                                                                               \
-    {                                                                                             \
-        _Pragma("unroll") for (int i = 1; i < 8; ++i)                                             \
-        {                                                                                         \
-            if (i == 3) continue;                                                                 \
-            double acc = Ts::A[S][0] * k[0][i];                                                   \
-            _Pragma("unroll") for (int q = 1; q < S; ++q) acc = __builtin_fma(Ts::A[S][q], k[q][i], acc); \
-            y[i] = __builtin_fma(hh, acc, u[i]);                                                  \
-        }                                                                                         \
-        rhs_at(m, y, k[S], s, c);                                                                 \
+#define GR_STAGE(S)                                                                                   \
+    {                                                                                                 \
+        double vs[4];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+        {                                                                                             \
+            double acc = Ts::A[S][0] * A[0][i];                                                       \
+            _Pragma("unroll") for (int q = 1; q < S; ++q) acc = __builtin_fma(Ts::A[S][q], A[q][i], acc); \
+            vs[i] = __builtin_fma(hh, acc, v[i]);                                                     \
+        }                                                                                             \
+        double rs = __builtin_fma(X.C[S] * hh, v[1], x[1]);                                           \
+        double ts = __builtin_fma(X.C[S] * hh, v[2], x[2]);                                           \
+        if (S > 1) {                                                                                  \
+            double ar = X.AX[S][0] * A[0][1], at = X.AX[S][0] * A[0][2];                              \
+            _Pragma("unroll") for (int q = 1; q < S - 1; ++q)                                         \
+            {                                                                                         \
+                ar = __builtin_fma(X.AX[S][q], A[q][1], ar);                                          \
+                at = __builtin_fma(X.AX[S][q], A[q][2], at);                                          \
+            }                                                                                         \
+            rs = __builtin_fma(h2, ar, rs);                                                           \
+            ts = __builtin_fma(h2, at, ts);                                                           \
+        }                                                                                             \
+        accel(m, rs, ts, vs, A[S], s, c);                                                             \
     }
         GR_STAGE(1)
         GR_STAGE(2)
@@ -652,100 +773,116 @@ struct Ray {
         GR_STAGE(4)
         GR_STAGE(5)
 #undef GR_STAGE
-        // stage 7 argument = the new state (all eight components)
-        double un[8];
+        // stage 7 argument = the new state
+        double xn[4], vn[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            double acc = Ts::A[6][0] * k[0][i];
+        for (int i = 0; i < 4; ++i) {
+            double acc = Ts::A[6][0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 6; ++q) acc = __builtin_fma(Ts::A[6][q], k[q][i], acc);
-            un[i] = __builtin_fma(hh, acc, u[i]);
+            for (int q = 1; q < 6; ++q) acc = __builtin_fma(Ts::A[6][q], A[q][i], acc);
+            vn[i] = __builtin_fma(hh, acc, v[i]);
+            double ax = X.AX[6][0] * A[0][i];
+#pragma unroll
+            for (int q = 1; q < 5; ++q) ax = __builtin_fma(X.AX[6][q], A[q][i], ax);
+            xn[i] = __builtin_fma(h2, ax, __builtin_fma(X.C[6] * hh, v[i], x[i]));
         }
         double sn, cn;
-        rhs_at(m, un, k[6], sn, cn);
+        accel(m, xn[1], xn[2], vn, A[6], sn, cn);
 
-        // error estimate, squared RMS norm
+        // error estimate, squared RMS norm over all eight components
         const double abstol = p.cfg.abstol, reltol = p.cfg.reltol;
         double e2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            double acc = Ts::BT[0] * k[0][i];
+        for (int i = 0; i < 4; ++i) {
+            double ev = Ts::BT[0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 7; ++q) acc = __builtin_fma(Ts::BT[q], k[q][i], acc);
-            const double sk = __builtin_fma(::fmax(::fabs(u[i]), ::fabs(un[i])), reltol, abstol);
-            const double a = hh * acc * rcp_fast(sk);
-            e2 = __builtin_fma(a, a, e2);
+            for (int q = 1; q < 7; ++q) ev = __builtin_fma(Ts::BT[q], A[q][i], ev);
+            double ex = X.BTX[0] * A[0][i];
+#pragma unroll
+            for (int q = 1; q < 6; ++q) ex = __builtin_fma(X.BTX[q], A[q][i], ex);
+            ex = __builtin_fma(hh, ex, X.SBT * v[i]);
+            const double skv = __builtin_fma(::fmax(::fabs(v[i]), ::fabs(vn[i])), reltol, abstol);
+            const double skx = __builtin_fma(::fmax(::fabs(x[i]), ::fabs(xn[i])), reltol, abstol);
+            const double av = hh * ev * rcp_fast(skv);
+            const double ax = hh * ex * rcp_fast(skx);
+            e2 = __builtin_fma(av, av, e2);
+            e2 = __builtin_fma(ax, ax, e2);
         }
         e2 *= 0.125;   // EEst² ; accept iff EEst <= 1
 #ifdef GR_HOST_HARNESS
         dbg_e2 = e2;
 #endif
 
-        // PI controller in log2 space: q = EEst^β1 / qold^β2 / γ
-        const double lE = 0.5 * ::log2(e2);                  // log2(EEst); -inf when EEst == 0
-        const double q11_l = PI_BETA1 * lE;
+        // PI controller in log2 space: q = EEst^β1 / qold^β2 / γ.  The step factor is formed with
+        // single-precision hardware log2/exp2 (relative error ~1e-6 in dt, far below anything the
+        // 1e-9 tolerance can see; the reference's DiffEqBase.fastpow is itself Float32-based).
+        const float lE = 0.5f * fast_log2f((float)e2);       // log2(EEst); -inf when e2 underflows
         if (e2 <= 1.0) {
-            double q;
-            if (e2 == 0.0) q = 1.0 / PI_QMAX;
-            else {
-                q = ::exp2(q11_l - PI_BETA2 * lq_old) * (1.0 / PI_GAMMA);
-                q = ::fmax(1.0 / PI_QMAX, ::fmin(1.0 / PI_QMIN, q));
-            }
+            float qf = fast_exp2f((float)PI_BETA1 * lE - (float)PI_BETA2 * lq_old) * (float)(1.0 / PI_GAMMA);
+            qf = ::fmaxf((float)(1.0 / PI_QMAX), ::fminf((float)(1.0 / PI_QMIN), qf));   // e2 == 0 -> 1/qmax
             nacc++;
-            lq_old = ::fmax(lE, LOG2_QOLDINIT);
-            const double dtnew = hh * rcp_full(q);
+            lq_old = ::fmaxf(lE, (float)LOG2_QOLDINIT);
+            const double dtnew = hh * rcp_full((double)qf);
             double tnew = t + hh;
             if (::fabs(tnew - tend) < 100.0 * 2.220446049250313e-16 * ::fmax(::fabs(tnew), ::fabs(tend))) tnew = tend;
 
             if (DISC) {
-                const double cnext = disc_cond(p, un[1], sn, cn);
+                const double cnext = disc_cond(p, xn[1], sn, cn);
                 const int ps = sgn(cprev);
-                bool ev = false;
-                double top = 1.0;
+                int top = 0;
                 if (ps != 0) {
-                    if (ps * sgn(cnext) <= 0) {
-                        ev = true;
-                    } else {
-                        ev = sample_event(p, ps, hh, top);
-                    }
+                    if (ps * sgn(cnext) <= 0) top = 7;
+                    else top = sample_event(p, ps, hh);
                 }
-                if (ev) {
-                    // leave (u, k, h) in place; finalize() root-finds on the dense output
-                    event = 1;
+                if (top) {
+                    // leave (x, v, A, h) in place; finalize() root-finds on the dense output
+                    flags |= RAY_EVENT;
                     ev_top = top;
                     status = GR_STATUS_INTERSECTED_WITH_GEOMETRY;
                     return true;
                 }
                 cprev = cnext;
             }
-            const bool term = discrete_cb(p, un[1], cn, status);
+            const bool term = discrete_cb(p, xn[1], cn, status);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { u[i] = un[i]; k[0][i] = k[6][i]; }
+            for (int i = 0; i < 4; ++i) { x[i] = xn[i]; v[i] = vn[i]; A[0][i] = A[6][i]; }
             t = tnew;
             dt = ::fmin(dtmax, dtnew);
-            bool bad = false;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bad |= !(u[i] == u[i]);
-            if (bad) { flags |= GR_FLAG_NAN; return true; }
             return term || !(t < tend);
         } else {
+            // step_reject_controller!; a NaN state lands here too (e2 is NaN) and is flagged at
+            // the top of the next attempt through the NaN step size
             nrej++;
-            const double q11 = ::exp2(q11_l);
-            dt = hh / ::fmin(1.0 / PI_QMIN, q11 * (1.0 / PI_GAMMA));
+            const float q11 = fast_exp2f((float)PI_BETA1 * lE);
+            dt = hh / (double)::fminf((float)(1.0 / PI_QMIN), q11 * (float)(1.0 / PI_GAMMA));
             return false;
         }
     }
 
-    // dense-output polynomial coefficients of component `comp`: y(Θ) = u + h Σ_m C[m] Θ^(m+1)
-    GR_DEV void dense_coeffs(int comp, double C[4]) const
+    // dense-output polynomial coefficients of component `comp` (0..3 position, 4..7 velocity):
+    // y(Θ) = y0 + h Σ_m C[m] Θ^(m+1)
+    GR_DEV void dense_coeffs(int comp, double hh, double C[4]) const
     {
+        constexpr const TsX& X = TsD::X;
+        if (comp >= 4) {
+            const int q = comp - 4;
 #pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
-            double acc = 0.0;
+            for (int mm = 0; mm < 4; ++mm) {
+                double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < 7; ++i)
-                if (Ts::R[i][mm] != 0.0) acc = __builtin_fma(Ts::R[i][mm], k[i][comp], acc);
-            C[mm] = acc;
+                for (int i = 0; i < 7; ++i)
+                    if (Ts::R[i][mm] != 0.0) acc = __builtin_fma(Ts::R[i][mm], A[i][q], acc);
+                C[mm] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (X.RX[i][mm] != 0.0) acc = __builtin_fma(X.RX[i][mm], A[i][comp], acc);
+                C[mm] = __builtin_fma(hh, acc, X.SR[mm] * v[comp]);
+            }
         }
     }
     static GR_DEV double dense_eval(double u0, double hh, const double C[4], double th)
@@ -755,49 +892,59 @@ struct Ray {
     }
 
     // ContinuousCallback safety sampling at Θ = j/7, j = 1..6 (Θ = 1 was tested by the caller).
-    // A sample can only change sign if it lies inside the |cosθ| < gtol wedge, so θ alone is
-    // evaluated first and the full condition only for samples near the equatorial plane.
-    GR_DEV bool sample_event(const Params& p, int ps, double hh, double& top) const
+    // Returns the first j whose condition has the opposite sign of `ps`, or 0.
+    // A sample can only change sign if it lies inside the |cosθ| < gtol wedge.  Cheap exits first:
+    // (1) a bound on how far θ can move inside the step, (2) θ alone at the six samples; the full
+    // condition is evaluated only for steps that come near the equatorial plane.
+    GR_DEV int sample_event(const Params& p, int ps, double hh) const
     {
+        const double wedge = p.wedge;
+        if (ps > 0) {
+            // |θ(Θ_j) - θ_0| <= h (Θ_j |v^θ| + h Σ_i |RXΣ_i(Θ_j)| |A_i^θ|) <= h (|v^θ| + K h max_i |A_i^θ|)
+            double amax = ::fabs(A[0][2]);
+#pragma unroll
+            for (int i = 1; i < 6; ++i) amax = ::fmax(amax, ::fabs(A[i][2]));
+            const double reach = hh * (::fabs(v[2]) * DENSE_K1 + DENSE_K2 * hh * amax);
+            double d0 = x[2] - 1.5707963267948966;
+            d0 -= 3.141592653589793 * __builtin_rint(d0 * 0.3183098861837907);
+            if (::fabs(d0) - reach > wedge) return 0;
+        }
         double Ct[4];
-        dense_coeffs(2, Ct);
-        const double wedge = ::asin(::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+        dense_coeffs(2, hh, Ct);
         bool any = (ps < 0);
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj) {
-            double d = dense_eval(u[2], hh, Ct, (double)(jj + 1) / 7.0) - 1.5707963267948966;
+            double d = dense_eval(x[2], hh, Ct, (double)(jj + 1) / 7.0) - 1.5707963267948966;
             d -= 3.141592653589793 * __builtin_rint(d * 0.3183098861837907);
             any |= (::fabs(d) < wedge);
         }
-        if (!any) return false;
+        if (!any) return 0;
         double Cr[4];
-        dense_coeffs(1, Cr);
-        for (int jj = 0; jj < 6; ++jj) {
-            const double th = (double)(jj + 1) / 7.0;
-            const double thv = dense_eval(u[2], hh, Ct, th);
-            const double rv = dense_eval(u[1], hh, Cr, th);
+        dense_coeffs(1, hh, Cr);
+        for (int jj = 1; jj <= 6; ++jj) {
+            const double th = (double)jj / 7.0;
             double s, c;
-            sincos_fast(thv, s, c);
-            const double cj = disc_cond(p, rv, s, c);
-            if ((double)ps * cj < 0.0) { top = th; return true; }
+            sincos_fast(dense_eval(x[2], hh, Ct, th), s, c);
+            const double cj = disc_cond(p, dense_eval(x[1], hh, Cr, th), s, c);
+            if ((double)ps * cj < 0.0) return jj;
         }
-        return false;
+        return 0;
     }
 
     // Root-find the event on the dense output (left-biased), move the state there, run the
-    // discrete callbacks on it.  Result: final (t, u).
+    // discrete callbacks on it.  Result: final (t, x, v).
     GR_DEV void resolve_event(const Params& p)
     {
         double Cr[4], Ct[4];
-        dense_coeffs(1, Cr);
-        dense_coeffs(2, Ct);
+        dense_coeffs(1, h, Cr);
+        dense_coeffs(2, h, Ct);
         const int ps = sgn(cprev);
-        double lo = 0.0, hi = ev_top;
+        double lo = 0.0, hi = (ev_top >= 7) ? 1.0 : (double)ev_top / 7.0;
         double flo = cprev, fhi;
         {
             double s, c;
-            sincos_fast(dense_eval(u[2], h, Ct, hi), s, c);
-            fhi = disc_cond(p, dense_eval(u[1], h, Cr, hi), s, c);
+            sincos_fast(dense_eval(x[2], h, Ct, hi), s, c);
+            fhi = disc_cond(p, dense_eval(x[1], h, Cr, hi), s, c);
         }
         double theta = hi;
         if (fhi != 0.0) {
@@ -815,67 +962,73 @@ struct Ray {
                 }
                 if (!(mid > lo && mid < hi)) break;
                 double s, c;
-                sincos_fast(dense_eval(u[2], h, Ct, mid), s, c);
-                const double fm = disc_cond(p, dense_eval(u[1], h, Cr, mid), s, c);
+                sincos_fast(dense_eval(x[2], h, Ct, mid), s, c);
+                const double fm = disc_cond(p, dense_eval(x[1], h, Cr, mid), s, c);
                 if (sgn(fm) == ps) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
             }
             theta = lo;
         }
         // change_t_via_interpolation!: every component from the interpolant
-        double un[8];
+        double xe[4], ve[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             double C[4];
-            dense_coeffs(i, C);
-            un[i] = dense_eval(u[i], h, C, theta);
+            dense_coeffs(i, h, C);
+            xe[i] = dense_eval(x[i], h, C, theta);
+            dense_coeffs(4 + i, h, C);
+            ve[i] = dense_eval(v[i], h, C, theta);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = un[i];
+        for (int i = 0; i < 4; ++i) { x[i] = xe[i]; v[i] = ve[i]; }
         t = t + theta * h;
         double s, c;
-        sincos_fast(u[2], s, c);
-        discrete_cb(p, u[1], c, status);
+        sincos_fast(x[2], s, c);
+        discrete_cb(p, x[1], c, status);
     }
 
     // unpack_solution + apply_to_image!
     GR_DEV void finalize(const Metric& m, const Params& p)
     {
-        if (DISC && event) resolve_event(p);
+        if (DISC && (flags & RAY_EVENT)) {
+            resolve_event(p);
+            flags &= ~RAY_EVENT;
+        }
         if (flags) status = GR_STATUS_NO_STATUS;
-        if (p.out_mode == 1) {
-            double u0[8];
-            constrained_u0(m, p, j, u0);
-            gr_point* o = p.points + j;
+        const Cold& cd = cold_of(p);
+        if (cd.out_mode == 1) {
+            double x0[4], v0[4];
+            constrained_u0(m, p, j, x0, v0);
+            gr_point* o = cd.points + j;
             o->status = status;
             o->flags = flags;
             o->lambda_min = p.cfg.lambda0;
             o->lambda_max = t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                o->x_init[q] = u0[q];
-                o->v_init[q] = u0[4 + q];
-                o->x[q] = u[q];
-                o->v[q] = u[4 + q];
+                o->x_init[q] = x0[q];
+                o->v_init[q] = v0[q];
+                o->x[q] = x[q];
+                o->v[q] = v[q];
             }
         } else {
             bool pass = true;
-            if (p.pf.filter_id == GR_FILTER_EARLY_TERM) pass = t < p.cfg.lambda1;
-            else if (p.pf.filter_id == GR_FILTER_INTERSECTED) pass = status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
-            double val = p.pf.fill;
+            if (cd.pf.filter_id == GR_FILTER_EARLY_TERM) pass = t < p.cfg.lambda1;
+            else if (cd.pf.filter_id == GR_FILTER_INTERSECTED) pass = status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
+            double val = cd.pf.fill;
             if (pass) {
-                if (p.pf.pf_id == GR_PF_AFFINE_TIME) val = t;
-                else if (p.pf.pf_id == GR_PF_STATUS) val = (double)status;
-                else if (p.pf.pf_id == GR_PF_RADIUS) {
+                if (cd.pf.pf_id == GR_PF_AFFINE_TIME) val = t;
+                else if (cd.pf.pf_id == GR_PF_STATUS) val = (double)status;
+                else if (cd.pf.pf_id == GR_PF_RADIUS) {
                     double s, c;
-                    sincos_fast(u[2], s, c);
-                    val = u[1] * ::fabs(s);
+                    sincos_fast(x[2], s, c);
+                    val = x[1] * ::fabs(s);
                 } else {
-                    double u0[8];
-                    constrained_u0(m, p, j, u0);
-                    val = redshift_pf(m, p, u0, u0 + 4, u, u + 4);
+                    double x0[4], v0[4];
+                    constrained_u0(m, p, j, x0, v0);
+                    val = redshift_pf(m, p, cd, x0, v0, x, v);
                 }
             }
-            p.image[j] = val;
+            cd.image[j] = val;
         }
     }
 };

@@ -42,7 +42,8 @@ constexpr int N_STAT = 9;   // rays, accepted, rejected, rhs, flagged, status[4]
 
 template <class Metric, int DISC>
 struct LaneStats {
-    unsigned long long rays = 0, acc = 0, rej = 0, flagged = 0, st[4] = { 0, 0, 0, 0 };
+    // per-lane 32-bit counters (a lane handles far fewer than 2^32 steps per launch)
+    unsigned rays = 0, acc = 0, rej = 0, flagged = 0, st[4] = { 0, 0, 0, 0 };
     GR_DEV void add(const Ray<Metric, DISC>& r)
     {
         rays += 1;
@@ -55,7 +56,7 @@ struct LaneStats {
     GR_DEV void flush(unsigned long long* out) const
     {
         if (!out) return;
-        unsigned long long v[N_STAT] = { rays, acc, rej, 2 * rays + 6 * (acc + rej), flagged, st[0], st[1], st[2], st[3] };
+        unsigned long long v[N_STAT] = { rays, acc, rej, 2ull * rays + 6ull * ((unsigned long long)acc + rej), flagged, st[0], st[1], st[2], st[3] };
 #pragma unroll
         for (int i = 0; i < N_STAT; ++i) {
             unsigned long long x = v[i];
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256) k_trace_lane(const Params p)
     LaneStats<Metric, DISC> ls;
     if (gid < p.n) {
         Ray<Metric, DISC> ray;
-        ray.init(m, p, tile_swizzle(p, gid));
+        ray.init(m, p, tile_swizzle(cold_of(p), gid));
         while (!ray.step(m, p)) {}
         ray.finalize(m, p);
         ls.add(ray);
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(256) k_trace_persistent(const Params p)
                 base = __shfl(base, 0, 64);
                 const int64_t mine = (int64_t)base + __popcll(idle & ((1ull << lane) - 1ull));
                 if (!active && mine < p.n) {
-                    ray.init(m, p, tile_swizzle(p, mine));
+                    ray.init(m, p, tile_swizzle(cold_of(p), mine));
                     active = true;
                 }
                 if ((int64_t)base + n >= p.n) queue_empty = true;
@@ -141,15 +142,16 @@ __global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     const gr_point gp = pts[i];
+    const Cold& cd = *p.cold;
     bool pass = true;
-    if (p.pf.filter_id == GR_FILTER_EARLY_TERM) pass = gp.lambda_max < max_time;
-    else if (p.pf.filter_id == GR_FILTER_INTERSECTED) pass = gp.status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
-    double val = p.pf.fill;
+    if (cd.pf.filter_id == GR_FILTER_EARLY_TERM) pass = gp.lambda_max < max_time;
+    else if (cd.pf.filter_id == GR_FILTER_INTERSECTED) pass = gp.status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
+    double val = cd.pf.fill;
     if (pass) {
-        if (p.pf.pf_id == GR_PF_AFFINE_TIME) val = gp.lambda_max;
-        else if (p.pf.pf_id == GR_PF_STATUS) val = (double)gp.status;
-        else if (p.pf.pf_id == GR_PF_RADIUS) val = gp.x[1] * ::fabs(::sin(gp.x[2]));
-        else val = redshift_pf(m, p, gp.x_init, gp.v_init, gp.x, gp.v);
+        if (cd.pf.pf_id == GR_PF_AFFINE_TIME) val = gp.lambda_max;
+        else if (cd.pf.pf_id == GR_PF_STATUS) val = (double)gp.status;
+        else if (cd.pf.pf_id == GR_PF_RADIUS) val = gp.x[1] * ::fabs(::sin(gp.x[2]));
+        else val = redshift_pf(m, p, cd, gp.x_init, gp.v_init, gp.x, gp.v);
     }
     out[i] = val;
 }
@@ -166,6 +168,8 @@ struct gr_ctx {
     unsigned long long* d_queue = nullptr; // ring of work counters (one per in-flight launch)
     int queue_slots = 64, queue_next = 0;
     unsigned long long* d_stats = nullptr; // for host-buffer entry points
+    Cold* d_cold = nullptr;                // ring of per-launch cold blocks
+    int cold_next = 0;
     double* d_plunge = nullptr;            // 4 x n_plunge
     int64_t plunge_cap = 0;
     void* d_scratch = nullptr;             // staging for host-buffer entry points
@@ -257,10 +261,16 @@ int32_t launch_tmpl(gr_ctx* ctx, Params& p, hipStream_t stream)
     return GR_OK;
 }
 
-int32_t launch_trace(gr_ctx* ctx, Params& p, hipStream_t stream)
+int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold, hipStream_t stream)
 {
     if (p.n == 0) return GR_OK;
+    // stage the cold block into the next ring slot (stream-ordered before the kernel)
+    Cold* slot = ctx->d_cold + ctx->cold_next;
+    ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
+    GR_HIP(hipMemcpyAsync(slot, &cold, sizeof(Cold), hipMemcpyHostToDevice, stream));
+    p.cold = slot;
     p.refill_threshold = (int32_t)ctx->refill_threshold;
+    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     const bool disc = p.cfg.disc_id == GR_DISC_THIN;
     if (p.cfg.metric_id == GR_METRIC_KERR)
         return disc ? launch_tmpl<KerrMetric, 1>(ctx, p, stream) : launch_tmpl<KerrMetric, 0>(ctx, p, stream);
@@ -306,14 +316,15 @@ int32_t stage_pf(gr_ctx* ctx, const gr_pointfunction* pf, PfDev& out, hipStream_
     return GR_OK;
 }
 
-void plane_params(gr_ctx* ctx, Params& p, const gr_config* cfg, const gr_plane* plane, const gr_range* range)
+void plane_params(gr_ctx* ctx, Params& pp, Cold& p, const gr_config* cfg, const gr_plane* plane, const gr_range* range)
 {
+    std::memset(&pp, 0, sizeof pp);
     std::memset(&p, 0, sizeof p);
-    p.cfg = *cfg;
+    pp.cfg = *cfg;
+    pp.n = range->count;
     p.src_mode = 0;
     p.plane = *plane;
     p.range = *range;
-    p.n = range->count;
     // 8x8 tiles need whole, column-aligned groups of 8 columns in the local index space
     const int64_t H = plane->height;
     const bool cols_ok = (H % 8 == 0) && (range->first % H == 0) && (range->block % (8 * H) == 0)
@@ -362,6 +373,7 @@ int32_t gr_ctx_create(int32_t device, gr_ctx** out)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipStreamCreate failed"); break; }
         if (hipMalloc((void**)&c->d_queue, sizeof(unsigned long long) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"); break; }
         if (hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * N_STAT) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(stats) failed"); break; }
+        if (hipMalloc((void**)&c->d_cold, sizeof(Cold) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(cold) failed"); break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipEventCreate failed"); break; }
     } while (0);
     if (rc != GR_OK) {
@@ -379,6 +391,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_plunge) (void)hipFree(c->d_plunge);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -424,12 +437,13 @@ int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plan
     GR_HIP(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)hip_stream;
     Params p;
-    plane_params(ctx, p, cfg, plane, range);
-    if ((rc = stage_pf(ctx, pf, p.pf, stream)) != GR_OK) return rc;
-    p.out_mode = 0;
-    p.image = d_image;
+    Cold cd;
+    plane_params(ctx, p, cd, cfg, plane, range);
+    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    cd.out_mode = 0;
+    cd.image = d_image;
     p.stats = (unsigned long long*)d_stats;   // same layout: 9 x 64-bit counters then kernel_ms
-    return launch_trace(ctx, p, stream);
+    return launch_trace(ctx, p, cd, stream);
 }
 
 int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
@@ -442,11 +456,12 @@ int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_p
     if (!d_points && range->count > 0) return fail(GR_ERR_INVALID_ARGUMENT, "points is null");
     GR_HIP(hipSetDevice(ctx->device));
     Params p;
-    plane_params(ctx, p, cfg, plane, range);
-    p.out_mode = 1;
-    p.points = d_points;
+    Cold cd;
+    plane_params(ctx, p, cd, cfg, plane, range);
+    cd.out_mode = 1;
+    cd.points = d_points;
     p.stats = (unsigned long long*)d_stats;
-    return launch_trace(ctx, p, (hipStream_t)hip_stream);
+    return launch_trace(ctx, p, cd, (hipStream_t)hip_stream);
 }
 
 int32_t gr_trace_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const double* d_x, int64_t x_stride,
@@ -460,19 +475,21 @@ int32_t gr_trace_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const doubl
     if (n > 0 && (!d_x || !d_v || !d_points)) return fail(GR_ERR_INVALID_ARGUMENT, "x/v/points is null");
     GR_HIP(hipSetDevice(ctx->device));
     Params p;
+    Cold cd;
     std::memset(&p, 0, sizeof p);
+    std::memset(&cd, 0, sizeof cd);
     p.cfg = *cfg;
-    p.src_mode = 1;
-    p.out_mode = 1;
-    p.x = d_x;
-    p.x_stride = x_stride;
-    p.v = d_v;
     p.n = n;
-    p.points = d_points;
     p.stats = (unsigned long long*)d_stats;
-    p.range = gr_range{ 0, n, n > 0 ? n : 1, 1 };
-    p.swizzle = 0;
-    return launch_trace(ctx, p, (hipStream_t)hip_stream);
+    cd.src_mode = 1;
+    cd.out_mode = 1;
+    cd.x = d_x;
+    cd.x_stride = x_stride;
+    cd.v = d_v;
+    cd.points = d_points;
+    cd.range = gr_range{ 0, n, n > 0 ? n : 1, 1 };
+    cd.swizzle = 0;
+    return launch_trace(ctx, p, cd, (hipStream_t)hip_stream);
 }
 
 int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,
@@ -486,11 +503,17 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     GR_HIP(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)hip_stream;
     Params p;
+    Cold cd;
     std::memset(&p, 0, sizeof p);
+    std::memset(&cd, 0, sizeof cd);
     p.cfg = *cfg;
     p.n = n;
-    if ((rc = stage_pf(ctx, pf, p.pf, stream)) != GR_OK) return rc;
+    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
     if (n == 0) return GR_OK;
+    Cold* slot = ctx->d_cold + ctx->cold_next;
+    ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
+    GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, stream));
+    p.cold = slot;
     const int block = 256;
     const int64_t grid = (n + block - 1) / block;
     if (cfg->metric_id == GR_METRIC_KERR)

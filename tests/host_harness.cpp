@@ -28,8 +28,9 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
     }
 }
 
-static void dispatch(const Params& p, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
+static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
 {
+    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     const bool disc = p.cfg.disc_id == GR_DISC_THIN;
     if (p.cfg.metric_id == GR_METRIC_KERR) {
         if (disc) run<KerrMetric, 1>(p, p.n, tlog, hlog, cap, nlog); else run<KerrMetric, 0>(p, p.n, tlog, hlog, cap, nlog);
@@ -42,41 +43,45 @@ extern "C" {
 
 int hh_render_endpoints(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, gr_point* out)
 {
-    Params p;
-    std::memset(&p, 0, sizeof p);
-    p.cfg = *cfg; p.src_mode = 0; p.out_mode = 1; p.plane = *plane; p.range = *rg; p.n = rg->count; p.points = out;
+    Params p; Cold c;
+    std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
+    p.cfg = *cfg; p.n = rg->count; p.cold = &c;
+    c.src_mode = 0; c.out_mode = 1; c.plane = *plane; c.range = *rg; c.points = out;
     dispatch(p, nullptr, nullptr, 0, nullptr);
     return 0;
 }
 
 int hh_render(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, const gr_pointfunction* pf, double* image)
 {
-    Params p;
-    std::memset(&p, 0, sizeof p);
-    p.cfg = *cfg; p.src_mode = 0; p.out_mode = 0; p.plane = *plane; p.range = *rg; p.n = rg->count; p.image = image;
-    p.pf.pf_id = pf->pf_id; p.pf.filter_id = pf->filter_id; p.pf.fill = pf->fill; p.pf.r_isco = pf->r_isco;
-    p.pf.n_plunge = pf->n_plunge; p.pf.plunge_r = pf->plunge_r; p.pf.plunge_vt = pf->plunge_vt;
-    p.pf.plunge_vr = pf->plunge_vr; p.pf.plunge_vphi = pf->plunge_vphi;
+    Params p; Cold c;
+    std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
+    p.cfg = *cfg; p.n = rg->count; p.cold = &c;
+    c.src_mode = 0; c.out_mode = 0; c.plane = *plane; c.range = *rg; c.image = image;
+    c.pf.pf_id = pf->pf_id; c.pf.filter_id = pf->filter_id; c.pf.fill = pf->fill; c.pf.r_isco = pf->r_isco;
+    c.pf.n_plunge = pf->n_plunge; c.pf.plunge_r = pf->plunge_r; c.pf.plunge_vt = pf->plunge_vt;
+    c.pf.plunge_vr = pf->plunge_vr; c.pf.plunge_vphi = pf->plunge_vphi;
     dispatch(p, nullptr, nullptr, 0, nullptr);
     return 0;
 }
 
 int hh_trace_endpoints(const gr_config* cfg, const double* x, int64_t x_stride, const double* v, int64_t n, gr_point* out)
 {
-    Params p;
-    std::memset(&p, 0, sizeof p);
-    p.cfg = *cfg; p.src_mode = 1; p.out_mode = 1; p.x = x; p.x_stride = x_stride; p.v = v; p.n = n; p.points = out;
-    p.range = gr_range{ 0, n, n > 0 ? n : 1, 1 };
+    Params p; Cold c;
+    std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
+    p.cfg = *cfg; p.n = n; p.cold = &c;
+    c.src_mode = 1; c.out_mode = 1; c.x = x; c.x_stride = x_stride; c.v = v; c.points = out;
+    c.range = gr_range{ 0, n, n > 0 ? n : 1, 1 };
     dispatch(p, nullptr, nullptr, 0, nullptr);
     return 0;
 }
 
-// one ray of a plane with a log of (t, h) after every attempted step
+// one ray of a plane with a log of (t, EEst^2) after every attempted step
 int64_t hh_step_log(const gr_config* cfg, const gr_plane* plane, int64_t i, gr_point* out, double* tlog, double* hlog, int64_t cap)
 {
-    Params p;
-    std::memset(&p, 0, sizeof p);
-    p.cfg = *cfg; p.src_mode = 0; p.out_mode = 1; p.plane = *plane; p.range = gr_range{ i, 1, 1, 1 }; p.n = 1; p.points = out;
+    Params p; Cold c;
+    std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
+    p.cfg = *cfg; p.n = 1; p.cold = &c;
+    c.src_mode = 0; c.out_mode = 1; c.plane = *plane; c.range = gr_range{ i, 1, 1, 1 }; c.points = out;
     int64_t n = 0;
     dispatch(p, tlog, hlog, cap, &n);
     return n;
