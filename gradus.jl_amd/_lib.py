@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgradus_mi355x.so")
+# GRADUS_MI355X_LIB selects another build of the same library (A/B timing of compiler flags)
+LIB_PATH = os.environ.get("GRADUS_MI355X_LIB") or os.path.join(_HERE, "csrc", "libgradus_mi355x.so")
 
 GR_OK = 0
 ERROR_NAMES = {

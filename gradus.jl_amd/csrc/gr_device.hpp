@@ -31,12 +31,14 @@
 #include <cmath>
 #define GR_DEV inline
 #define GR_RCP_SEED(x) (1.0 / (x))
+#define GR_RSQ_SEED(x) (1.0 / std::sqrt(x))
 #define GR_LOG2F(x) std::log2((float)(x))
 #define GR_EXP2F(x) std::exp2((float)(x))
 #else
 #include <hip/hip_runtime.h>
 #define GR_DEV __device__ __forceinline__
 #define GR_RCP_SEED(x) __builtin_amdgcn_rcp(x)
+#define GR_RSQ_SEED(x) __builtin_amdgcn_rsq(x)
 #define GR_LOG2F(x) __builtin_amdgcn_logf(x)     // v_log_f32
 #define GR_EXP2F(x) __builtin_amdgcn_exp2f(x)    // v_exp_f32
 #endif
@@ -62,6 +64,21 @@ GR_DEV double rcp_fast(double x)
     double r = GR_RCP_SEED(x);
     double e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
+}
+GR_DEV double sqrt_fast(double x)
+{
+    // x > 0, normal range.  rsq seed + two coupled Newton steps (Goldschmidt): <= 1 ulp
+    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : ::sqrt(x);
+    double y = GR_RSQ_SEED(x);
+    double g = x * y, hh = 0.5 * y;
+    double r = __builtin_fma(-hh, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    hh = __builtin_fma(hh, r, hh);
+    r = __builtin_fma(-hh, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    hh = __builtin_fma(hh, r, hh);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, hh, g);
 }
 GR_DEV int sgn(double x) { return (x > 0.0) - (x < 0.0); }
 GR_DEV float fast_log2f(float x) { return GR_LOG2F(x); }
@@ -303,7 +320,7 @@ GR_DEV double constrain_time(const double g[5], double vr, double vh, double vp,
 {
     const double disc = -g[0] * g[1] * vr * vr - g[0] * g[2] * vh * vh - g[0] * mu * mu
                         - (g[0] * g[3] - g[4] * g[4]) * vp * vp;
-    return -(g[4] * vp + ::sqrt(disc)) / g[0];
+    return -(g[4] * vp + sqrt_fast(disc)) * rcp_full(g[0]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -521,12 +538,12 @@ GR_DEV void circular_fourvelocity(const Metric& m, double rho, double& vt, doubl
 {
     double g[5], j1[5], j2[5], gi[5];
     m.eval(rho, 1.0, 0.0, g, j1, j2, gi);
-    const double Dl = ::sqrt(j1[4] * j1[4] - j1[0] * j1[3]);
-    const double Om = -(j1[4] - Dl) / j1[3];
+    const double Dl = sqrt_fast(j1[4] * j1[4] - j1[0] * j1[3]);
+    const double Om = -(j1[4] - Dl) * rcp_full(j1[3]);
     const double A = -(Om * gi[0] - gi[4]);
     const double B = (Om * gi[4] - gi[3]);
     const double den = B * B * gi[0] + 2.0 * A * B * gi[4] + A * A * gi[3];
-    const double d = -(double)sgn(den) * ::sqrt(1.0 / ::fabs(den));
+    const double d = -(double)sgn(den) * sqrt_fast(rcp_full(::fabs(den)));
     const double ut = B * d, up = A * d;
     vt = gi[0] * ut + gi[4] * up;
     vp = gi[4] * ut + gi[3] * up;
@@ -575,7 +592,7 @@ GR_DEV double redshift_pf(const Metric& m, const Params& pp, const Cold& p, cons
     sincos_fast(x0[2], s0, c0);
     m.comps(x0[1], s0, c0, g0);
     const double E_obs = g0[0] * v0[0] + g0[4] * v0[3];
-    return E_obs / E_disc;
+    return E_obs * rcp_full(E_disc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -631,8 +648,9 @@ struct Ray {
             const double alpha = range_at(p.plane.alpha0, p.plane.alpha1, p.plane.width, xi) + p.plane.offset;
             const double beta = range_at(p.plane.beta0, p.plane.beta1, H, yi) + p.plane.offset;
             const double ro = p.plane.x_obs[1];
-            const double b = beta / ro, a = alpha / ro;
-            const double pr = -1.0 / ::sqrt(1.0 + a * a + b * b);
+            const double iro = rcp_full(ro);
+            const double b = beta * iro, a = alpha * iro;
+            const double pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
             const double pb[4] = { 1.0, pr, b * pr, a * pr };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -691,8 +709,8 @@ struct Ray {
             d1s = __builtin_fma(a1, a1, d1s);
             d1s = __builtin_fma(b1, b1, d1s);
         }
-        const double d0 = ::sqrt(d0s * 0.125), d1 = ::sqrt(d1s * 0.125);
-        double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+        const double d0 = sqrt_fast(d0s * 0.125), d1 = sqrt_fast(d1s * 0.125);
+        double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 * rcp_full(d1));
         dt0 = ::fmin(dt0, dtmax);
         if (dt0 < 10.0 * 2.220446049250313e-16) {
             dt = 1e-6;
@@ -709,9 +727,12 @@ struct Ray {
                 d2s = __builtin_fma(ex, ex, d2s);
                 d2s = __builtin_fma(ev, ev, d2s);
             }
-            const double d2 = ::sqrt(d2s * 0.125) / dt0;
+            const double d2 = sqrt_fast(d2s * 0.125) * rcp_full(dt0);
             const double dm = ::fmax(d1, d2);
-            const double dt1 = (dm <= 1e-15) ? ::fmax(1e-6, dt0 * 1e-3) : ::exp10(-(2.0 + ::log10(dm)) / 5.0);
+            // 10^(-(2 + log10 dm)/5) = 10^-0.4 dm^-0.2 ; single-precision hardware log2/exp2 is ample
+            // for a starting step size
+            const double dt1 = (dm <= 1e-15) ? ::fmax(1e-6, dt0 * 1e-3)
+                                             : 0.39810717055349726 * (double)fast_exp2f(-0.2f * fast_log2f((float)dm));
             dt = ::fmin(::fmin(100.0 * dt0, dt1), dtmax);
         }
     }
@@ -739,7 +760,6 @@ struct Ray {
         hh = ::fmin(hh, tend - t);
         h = hh;
         const double h2 = hh * hh;
-        constexpr const TsX& X = TsD::X;
 
         double s, c;
         // stages 2..6: arguments need r, θ and the four velocities only (the RHS does not
@@ -753,14 +773,14 @@ struct Ray {
             _Pragma("unroll") for (int q = 1; q < S; ++q) acc = __builtin_fma(Ts::A[S][q], A[q][i], acc); \
             vs[i] = __builtin_fma(hh, acc, v[i]);                                                     \
         }                                                                                             \
-        double rs = __builtin_fma(X.C[S] * hh, v[1], x[1]);                                           \
-        double ts = __builtin_fma(X.C[S] * hh, v[2], x[2]);                                           \
+        double rs = __builtin_fma(TsD::X.C[S] * hh, v[1], x[1]);                                           \
+        double ts = __builtin_fma(TsD::X.C[S] * hh, v[2], x[2]);                                           \
         if (S > 1) {                                                                                  \
-            double ar = X.AX[S][0] * A[0][1], at = X.AX[S][0] * A[0][2];                              \
+            double ar = TsD::X.AX[S][0] * A[0][1], at = TsD::X.AX[S][0] * A[0][2];                              \
             _Pragma("unroll") for (int q = 1; q < S - 1; ++q)                                         \
             {                                                                                         \
-                ar = __builtin_fma(X.AX[S][q], A[q][1], ar);                                          \
-                at = __builtin_fma(X.AX[S][q], A[q][2], at);                                          \
+                ar = __builtin_fma(TsD::X.AX[S][q], A[q][1], ar);                                          \
+                at = __builtin_fma(TsD::X.AX[S][q], A[q][2], at);                                          \
             }                                                                                         \
             rs = __builtin_fma(h2, ar, rs);                                                           \
             ts = __builtin_fma(h2, at, ts);                                                           \
@@ -781,10 +801,10 @@ struct Ray {
 #pragma unroll
             for (int q = 1; q < 6; ++q) acc = __builtin_fma(Ts::A[6][q], A[q][i], acc);
             vn[i] = __builtin_fma(hh, acc, v[i]);
-            double ax = X.AX[6][0] * A[0][i];
+            double ax = TsD::X.AX[6][0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 5; ++q) ax = __builtin_fma(X.AX[6][q], A[q][i], ax);
-            xn[i] = __builtin_fma(h2, ax, __builtin_fma(X.C[6] * hh, v[i], x[i]));
+            for (int q = 1; q < 5; ++q) ax = __builtin_fma(TsD::X.AX[6][q], A[q][i], ax);
+            xn[i] = __builtin_fma(h2, ax, __builtin_fma(TsD::X.C[6] * hh, v[i], x[i]));
         }
         double sn, cn;
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);
@@ -797,10 +817,10 @@ struct Ray {
             double ev = Ts::BT[0] * A[0][i];
 #pragma unroll
             for (int q = 1; q < 7; ++q) ev = __builtin_fma(Ts::BT[q], A[q][i], ev);
-            double ex = X.BTX[0] * A[0][i];
+            double ex = TsD::X.BTX[0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 6; ++q) ex = __builtin_fma(X.BTX[q], A[q][i], ex);
-            ex = __builtin_fma(hh, ex, X.SBT * v[i]);
+            for (int q = 1; q < 6; ++q) ex = __builtin_fma(TsD::X.BTX[q], A[q][i], ex);
+            ex = __builtin_fma(hh, ex, TsD::X.SBT * v[i]);
             const double skv = __builtin_fma(::fmax(::fabs(v[i]), ::fabs(vn[i])), reltol, abstol);
             const double skx = __builtin_fma(::fmax(::fabs(x[i]), ::fabs(xn[i])), reltol, abstol);
             const double av = hh * ev * rcp_fast(skv);
@@ -863,7 +883,6 @@ struct Ray {
     // y(Θ) = y0 + h Σ_m C[m] Θ^(m+1)
     GR_DEV void dense_coeffs(int comp, double hh, double C[4]) const
     {
-        constexpr const TsX& X = TsD::X;
         if (comp >= 4) {
             const int q = comp - 4;
 #pragma unroll
@@ -880,8 +899,8 @@ struct Ray {
                 double acc = 0.0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
-                    if (X.RX[i][mm] != 0.0) acc = __builtin_fma(X.RX[i][mm], A[i][comp], acc);
-                C[mm] = __builtin_fma(hh, acc, X.SR[mm] * v[comp]);
+                    if (TsD::X.RX[i][mm] != 0.0) acc = __builtin_fma(TsD::X.RX[i][mm], A[i][comp], acc);
+                C[mm] = __builtin_fma(hh, acc, TsD::X.SR[mm] * v[comp]);
             }
         }
     }

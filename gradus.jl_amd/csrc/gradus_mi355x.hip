@@ -179,7 +179,7 @@ struct gr_ctx {
     // knobs
     int64_t kernel = 1;
     int64_t block = 256;
-    int64_t refill_threshold = 8;
+    int64_t refill_threshold = 16;
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
     int64_t swizzle = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
