@@ -19,6 +19,7 @@ from .rendering import (EndpointRenderCache, apply, impact_axes, prerendergeodes
 from .status import StatusCodes
 from .tracing import (EnsembleMI355X, PolarChart, TracingConfiguration, chart_for_metric, domain_upper_hemisphere,
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
-                      map_impact_parameters, tracegeodesics, tracing_configuration)
+                      map_impact_parameters, tracegeodesic_path, tracegeodesics, tracing_configuration)
+from .special_radii import generic_isco, interpolate_plunging_velocities, plunging_fourvelocity
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -136,6 +136,7 @@ EXPORTS = [
     "gr_render_endpoints",
     "gr_trace_endpoints_device",
     "gr_trace_endpoints",
+    "gr_trace_path",
     "gr_apply_pointfunction_device",
     "gr_apply_pointfunction",
 ]
@@ -166,6 +167,7 @@ def load():
     L.gr_render_endpoints.argtypes = [vp, cfgp, plp, rgp, vp, stp]
     L.gr_trace_endpoints_device.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, vp, vp]
     L.gr_trace_endpoints.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, stp]
+    L.gr_trace_path.argtypes = [vp, cfgp, vp, vp, i64, vp, C.POINTER(i64), vp]
     L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]
     L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
     for name in EXPORTS:

@@ -133,6 +133,37 @@ __global__ void __launch_bounds__(256) k_trace_persistent(const Params p)
     ls.flush(p.stats);
 }
 
+// ---- one geodesic, every accepted step saved (single wave, lane 0) ----
+template <class Metric, int DISC>
+__global__ void __launch_bounds__(64) k_trace_path(const Params p, double* path, int64_t cap, unsigned long long* n_rows)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Metric m;
+    m.load(p.cfg.params);
+    Ray<Metric, DISC> ray;
+    ray.init(m, p, 0);
+    int64_t n = 0;
+    auto save = [&]() {
+        if (n < cap) {
+            double* row = path + 9 * n;
+            row[0] = ray.t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { row[1 + q] = ray.x[q]; row[5 + q] = ray.v[q]; }
+        }
+        ++n;
+    };
+    save();
+    for (;;) {
+        const int before = ray.nacc;
+        const bool fin = ray.step(m, p);
+        if (fin) break;
+        if (ray.nacc != before) save();
+    }
+    ray.finalize(m, p);     // resolves a pending event and writes the endpoint record
+    save();
+    *n_rows = (unsigned long long)n;
+}
+
 // ---- apply(pf, points) ----
 template <class Metric>
 __global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point* pts, double max_time, double* out)
@@ -521,6 +552,60 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     else
         hipLaunchKernelGGL((k_apply_pf<JohannsenMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     GR_HIP(hipGetLastError());
+    return GR_OK;
+}
+
+int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const double* v, int64_t cap, double* path,
+                      int64_t* n_rows, gr_point* endpoint)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if (!x || !v || !path || !n_rows || cap < 2) return fail(GR_ERR_INVALID_ARGUMENT, "x/v/path/n_rows is null or cap < 2");
+    GR_HIP(hipSetDevice(ctx->device));
+    const size_t path_bytes = sizeof(double) * 9 * (size_t)cap;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, path_bytes + sizeof(gr_point) + 16)) != GR_OK) return rc;
+    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 8 + 8)) != GR_OK) return rc;
+    double* d_path = (double*)ctx->d_scratch;
+    gr_point* d_pt = (gr_point*)((char*)ctx->d_scratch + path_bytes);
+    unsigned long long* d_n = (unsigned long long*)((char*)d_pt + sizeof(gr_point));
+    double* d_x = (double*)ctx->d_in;
+    GR_HIP(hipMemcpyAsync(d_x, x, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream));
+    GR_HIP(hipMemcpyAsync(d_x + 4, v, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream));
+    Params p;
+    Cold cd;
+    std::memset(&p, 0, sizeof p);
+    std::memset(&cd, 0, sizeof cd);
+    p.cfg = *cfg;
+    p.n = 1;
+    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+    cd.src_mode = 1;
+    cd.out_mode = 1;
+    cd.x = d_x;
+    cd.x_stride = 0;
+    cd.v = d_x + 4;
+    cd.points = d_pt;
+    cd.range = gr_range{ 0, 1, 1, 1 };
+    Cold* slot = ctx->d_cold + ctx->cold_next;
+    ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
+    GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, ctx->stream));
+    p.cold = slot;
+    const bool disc = cfg->disc_id == GR_DISC_THIN;
+    if (cfg->metric_id == GR_METRIC_KERR) {
+        if (disc) hipLaunchKernelGGL((k_trace_path<KerrMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+        else hipLaunchKernelGGL((k_trace_path<KerrMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+    } else {
+        if (disc) hipLaunchKernelGGL((k_trace_path<JohannsenMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+        else hipLaunchKernelGGL((k_trace_path<JohannsenMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+    }
+    GR_HIP(hipGetLastError());
+    unsigned long long n = 0;
+    GR_HIP(hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    GR_HIP(hipStreamSynchronize(ctx->stream));
+    *n_rows = (int64_t)n;
+    const int64_t rows = (int64_t)n < cap ? (int64_t)n : cap;
+    GR_HIP(hipMemcpy(path, d_path, sizeof(double) * 9 * (size_t)rows, hipMemcpyDeviceToHost));
+    if (endpoint) GR_HIP(hipMemcpy(endpoint, d_pt, sizeof(gr_point), hipMemcpyDeviceToHost));
     return GR_OK;
 }
 

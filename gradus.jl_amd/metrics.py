@@ -56,9 +56,13 @@ class KerrMetric(AbstractStaticAxisSymmetric):
         return [self.M, self.a]
 
     def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        """kerr-metric.jl:11-28; `r` may be a float or a special_radii.Jet."""
         M, a = self.M, self.a
         R = 2.0 * M
-        s2 = math.sin(theta) ** 2
+        s2 = s * s
         c2 = 1.0 - s2
         Sig = r * r + a * a * c2
         iSig = 1.0 / Sig
@@ -92,19 +96,25 @@ class JohannsenMetric(AbstractStaticAxisSymmetric):
         return [self.M, self.a, self.alpha13, self.alpha22, self.alpha52, self.eps3]
 
     def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        """johannsen-ad.jl:4-34; `r` may be a float or a special_radii.Jet."""
         M, a = self.M, self.a
-        A1 = 1.0 + self.alpha13 * (M / r) ** 3
-        A2 = 1.0 + self.alpha22 * (M / r) ** 2
-        A5 = 1.0 + self.alpha52 * (M / r) ** 2
-        Sig = r * r + a * a * math.cos(theta) ** 2 + self.eps3 * M ** 3 / r
+        Mr = M / r
+        A1 = 1.0 + self.alpha13 * (Mr * Mr * Mr)
+        A2 = 1.0 + self.alpha22 * (Mr * Mr)
+        A5 = 1.0 + self.alpha52 * (Mr * Mr)
+        Sig = r * r + a * a * (c * c) + (self.eps3 * M ** 3) / r
         Del = r * r - 2.0 * M * r + a * a
         r2a2 = r * r + a * a
-        s2 = math.sin(theta) ** 2
-        denom = (r2a2 * A1 - a * a * A2 * s2) ** 2
-        tt = -Sig * (Del - a * a * A2 * A2 * s2)
+        s2 = s * s
+        dn = r2a2 * A1 - (a * a * s2) * A2
+        denom = dn * dn
+        tt = -(Sig * (Del - (a * a * s2) * (A2 * A2)))
         rr = Sig / (Del * A5)
-        pp = Sig * s2 * (r2a2 ** 2 * A1 ** 2 - a * a * Del * s2)
-        tp = -a * Sig * s2 * (r2a2 * A1 * A2 - Del)
+        pp = (Sig * s2) * ((r2a2 * r2a2) * (A1 * A1) - (a * a * s2) * Del)
+        tp = -(a * ((Sig * s2) * (r2a2 * A1 * A2 - Del)))
         return (tt / denom, rr, Sig, pp / denom, tp / denom)
 
     def inner_radius(self):

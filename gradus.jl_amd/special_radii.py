@@ -1,15 +1,161 @@
-"""Host-side set-up for non-Kerr redshift: generic ISCO and the plunging-velocity table.
+"""Host-side, once-per-render set-up for non-Kerr redshift: generic ISCO and the plunging table.
 
-Reference: src/special-radii.jl:14-60 (isco root find), src/orbits/circular-orbits.jl:11-48
-(Ω, u_t, u_ϕ, energy), src/orbits/orbit-solving.jl:99-167 (PlungingInterpolation).
-Implemented in round 2 of the build; Kerr needs none of this.
+Reference: src/special-radii.jl:14-60 (isco root find), src/orbits/circular-orbits.jl:11-48,128-146
+(Ω, u_t, u_ϕ, energy, plunging_fourvelocity), src/orbits/orbit-solving.jl:99-167
+(PlungingInterpolation).  The reference differentiates the metric with ForwardDiff; here a small
+jet type (value, d/dr, d²/dr²) plays that role.  The one plunging geodesic is traced by the device
+integrator (gr_trace_path), not on the host.
 """
 from __future__ import annotations
 
+import math
 
-def generic_isco(m):
-    raise NotImplementedError("generic isco(m) root find is scheduled after the Kerr path (SURVEY §8 a18)")
+import numpy as np
 
 
-def interpolate_plunging_velocities(m, **kw):
-    raise NotImplementedError("PlungingInterpolation is scheduled after the Kerr path (SURVEY §8 a18)")
+class Jet:
+    """Truncated Taylor series in one variable: (v, d, dd)."""
+
+    __slots__ = ("v", "d", "dd")
+
+    def __init__(self, v, d=0.0, dd=0.0):
+        self.v, self.d, self.dd = float(v), float(d), float(dd)
+
+    @staticmethod
+    def lift(x):
+        return x if isinstance(x, Jet) else Jet(x)
+
+    def __add__(self, o):
+        o = Jet.lift(o)
+        return Jet(self.v + o.v, self.d + o.d, self.dd + o.dd)
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return Jet(-self.v, -self.d, -self.dd)
+
+    def __sub__(self, o):
+        return self + (-Jet.lift(o))
+
+    def __rsub__(self, o):
+        return Jet.lift(o) - self
+
+    def __mul__(self, o):
+        o = Jet.lift(o)
+        return Jet(self.v * o.v, self.d * o.v + self.v * o.d, self.dd * o.v + 2.0 * self.d * o.d + self.v * o.dd)
+
+    __rmul__ = __mul__
+
+    def inv(self):
+        i = 1.0 / self.v
+        return Jet(i, -self.d * i * i, (2.0 * self.d * self.d * i - self.dd) * i * i)
+
+    def __truediv__(self, o):
+        return self * Jet.lift(o).inv()
+
+    def __rtruediv__(self, o):
+        return Jet.lift(o) * self.inv()
+
+    def __pow__(self, n):
+        assert isinstance(n, int) and n >= 0
+        out = Jet(1.0)
+        for _ in range(n):
+            out = out * self
+        return out
+
+    def sqrt(self):
+        s = math.sqrt(self.v)
+        d = 0.5 * self.d / s
+        return Jet(s, d, (0.5 * self.dd - d * d) / s)
+
+
+def _energy_jet(m, r):
+    """CircularOrbits.energy(m, r) = -u_t with its r-derivative (circular-orbits.jl:11-48)."""
+    g = m._components(Jet(r, 1.0, 0.0), 1.0, 0.0)          # θ = π/2
+    # ∂_r g as first-order series (value = g', derivative = g'')
+    dg = [Jet(c.d, c.dd) for c in g]
+    g0 = [Jet(c.v, c.d) for c in g]
+    disc = dg[4] * dg[4] - dg[0] * dg[3]
+    if disc.v < 0:
+        return float("nan"), float("nan")
+    Om = -(dg[4] - disc.sqrt()) / dg[3]                    # _Ω_analytic, prograde
+    D = g0[0] * g0[3] - g0[4] * g0[4]
+    itt, ipp, itp = g0[3] / D, g0[0] / D, -g0[4] / D       # inverse_metric_components
+    A = -(Om * itt - itp)
+    B = Om * itp - ipp
+    den = B * B * itt + 2.0 * (A * B * itp) + A * A * ipp
+    sg = 1.0 if den.v > 0 else -1.0
+    d = (den * sg).inv().sqrt() * (-sg)                    # -sign(den) * sqrt(inv(abs(den)))
+    ut = B * d
+    return -ut.v, -ut.d
+
+
+def generic_isco(m, max_upper_bound=100.0, step=0.005):
+    """isco(m::AbstractStaticAxisSymmetric): find_isco_bounds then a bracketing root find of
+    dE/dr (special-radii.jl:14-60)."""
+    lower = None
+    n = int(math.floor((max_upper_bound - 1.0) / step + 1e-9))
+    for i in range(n + 1):
+        r = max_upper_bound - step * i
+        E, _ = _energy_jet(m, r)
+        if not (E == E) or abs(E) > 1.0:
+            lower = r
+            break
+    if lower is None:
+        raise RuntimeError("No boundaries for minimization could be determined. It is likely this configuration "
+                           "does not have an ISCO solution.")
+    lo, hi = lower, max_upper_bound
+    _, dlo = _energy_jet(m, lo)
+    if not (dlo == dlo):
+        lo += step
+        _, dlo = _energy_jet(m, lo)
+    _, dhi = _energy_jet(m, hi)
+    if (dlo > 0) == (dhi > 0):
+        raise RuntimeError("dE/dr does not change sign on the ISCO bracket")
+    for _ in range(200):
+        mid = lo + 0.5 * (hi - lo)
+        if not (lo < mid < hi):
+            break
+        _, dm = _energy_jet(m, mid)
+        if (dm > 0) == (dlo > 0):
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
+def plunging_fourvelocity(m, r):
+    """CircularOrbits.plunging_fourvelocity(m, r) -- only valid AT the ISCO (circular-orbits.jl:128-146)."""
+    g = m._components(Jet(r, 1.0, 0.0), 1.0, 0.0)
+    gv = [c.v for c in g]
+    dg = [c.d for c in g]
+    Om = -(dg[4] - math.sqrt(dg[4] * dg[4] - dg[0] * dg[3])) / dg[3]
+    D = gv[0] * gv[3] - gv[4] * gv[4]
+    itt, ipp, itp = gv[3] / D, gv[0] / D, -gv[4] / D
+    A = -(Om * itt - itp)
+    B = Om * itp - ipp
+    den = B * B * itt + 2.0 * A * B * itp + A * A * ipp
+    d = -math.copysign(1.0, den) * math.sqrt(1.0 / abs(den))
+    ut, up = B * d, A * d
+    E, L = -ut, up
+    vt = itt * ut + itp * up
+    vp = itp * ut + ipp * up
+    nom = itt * E * E - 2.0 * itp * E * L + ipp * L * L + 1.0
+    return np.array([vt, -math.sqrt(abs(nom / (-gv[1]))), 0.0, vp])
+
+
+def interpolate_plunging_velocities(m, ensemble=None, max_time=50_000.0, reltol=1e-9, δr=None):
+    """interpolate_plunging_velocities(m) -> (r, v^t, v^r, v^ϕ) sorted by r with the innermost
+    sample dropped (PlungingInterpolation, orbit-solving.jl:99-131,137-167)."""
+    from .tracing import PolarChart, tracegeodesic_path
+
+    δr = reltol * 10 if δr is None else δr
+    isco = m.isco()
+    u = np.array([0.0, isco - δr, math.pi / 2, 0.0])
+    v = plunging_fourvelocity(m, isco)
+    chart = PolarChart(m.inner_radius() * 1.000001, 12000.0)   # chart_for_metric(m; closest_approach = 1.000001)
+    path = tracegeodesic_path(m, u, v, (0.0, max_time), μ=1.0, reltol=reltol, chart=chart, ensemble=ensemble)
+    r = path.x[:, 1]
+    idx = np.argsort(r, kind="stable")[1:]
+    return (np.ascontiguousarray(r[idx]), np.ascontiguousarray(path.v[idx, 0]),
+            np.ascontiguousarray(path.v[idx, 1]), np.ascontiguousarray(path.v[idx, 3]))

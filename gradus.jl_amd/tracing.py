@@ -283,3 +283,39 @@ def tracegeodesics(m, x, v, *args, stats=False, **kwargs):
         raise TypeError("tracegeodesics(m, x, v, [disc], λ_domain; ...)")
     config = tracing_configuration(m, x, v, geometry, λs, **kwargs)
     return ensemble_solve_tracing_problem(config.ensemble, config, stats=stats)
+
+
+@dataclass
+class GeodesicPath:
+    """Every accepted step of one geodesic (the reference's single-problem ODESolution)."""
+
+    λ: np.ndarray        # (n,)
+    x: np.ndarray        # (n, 4)
+    v: np.ndarray        # (n, 4)
+    point: np.ndarray    # GeodesicPoint record of the end point
+
+
+def tracegeodesic_path(m, x, v, *args, cap=200_000, **kwargs):
+    """tracegeodesics(m, x::SVector, v::SVector, [disc], λ_domain; μ, chart, ...) for ONE geodesic,
+    returning the saved path (src/tracing/tracing.jl:88-110).  Runs on the device (gr_trace_path)."""
+    if len(args) == 2:
+        geometry, λs = args
+    elif len(args) == 1:
+        geometry, λs = None, args[0]
+    else:
+        raise TypeError("tracegeodesic_path(m, x, v, [disc], λ_domain; ...)")
+    v = np.ascontiguousarray(v, dtype=np.float64).reshape(4)
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(4)
+    config = tracing_configuration(m, x, v, geometry, λs, **kwargs)
+    cfg = config.abi_config()
+    L = _lib.load()
+    path = np.zeros((cap, 9))
+    n = C.c_int64(0)
+    pt = np.zeros(1, dtype=_lib.POINT_DTYPE)
+    _lib.check(L.gr_trace_path(config.ensemble.ctx.handle, C.byref(cfg), x.ctypes.data, v.ctypes.data, cap,
+                               path.ctypes.data, C.byref(n), pt.ctypes.data))
+    rows = min(n.value, cap)
+    if n.value > cap:
+        raise RuntimeError(f"path needs {n.value} rows; raise cap")
+    path = path[:rows]
+    return GeodesicPath(path[:, 0].copy(), path[:, 1:5].copy(), path[:, 5:9].copy(), pt[0])

@@ -196,6 +196,17 @@ int32_t gr_trace_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const doubl
 int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, int64_t x_stride,
                            const double* v, int64_t n, gr_point* points, gr_stats* stats);
 
+/* ---- tracegeodesics(m, x::SVector, v::SVector, ...): ONE geodesic with every accepted step
+ * saved (the reference's single-problem solve with save_on = true, src/tracing/tracing.jl:88-110).
+ * Used on its own and by interpolate_plunging_velocities (src/orbits/orbit-solving.jl:137-167),
+ * which traces the μ = 1 plunge from the ISCO on the same integrator.
+ * path: cap rows of 9 doubles (λ, x[4], v[4]); row 0 is the initial state, the last row the
+ * final state (after any event).  *n_rows receives the number of rows the solve produced
+ * (rows beyond cap are dropped but still counted). */
+int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x /* 4 */,
+                      const double* v /* 4, unconstrained */, int64_t cap, double* path /* host, cap x 9 */,
+                      int64_t* n_rows, gr_point* endpoint /* host, may be NULL */);
+
 /* ---- apply(pf, cache): evaluate a built-in point function on endpoint records
  * (point-functions.jl:98-101, rendering.jl:103-107) ---- */
 int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,

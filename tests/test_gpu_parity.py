@@ -221,3 +221,60 @@ def test_full_size_properties_1024(G, oracle, ens):
     v_all = np.concatenate([oracle.render_velocities(cfg, X_FAR, ALIMS, BLIMS, W, H, i0=int(i), n=1) for i in idx])
     ref = oracle.trace(cfg, X_FAR, v_all)
     _compare_points(G, oracle, pts[idx], ref)
+
+
+# ---------------- BASELINE config C4: JohannsenMetric + ThinDisc, interpolated redshift ----------------
+JOH = (1.0, 0.7, 2.0, 0.0, 0.0, 1.0)     # docs/src/getting-started.md:393
+
+
+def test_single_geodesic_path_and_plunging_table(G, oracle, ens):
+    """tracegeodesics for ONE geodesic (saved path) and the PlungingInterpolation built from it
+    (src/orbits/orbit-solving.jl:99-167) against the oracle's plunge."""
+    m = G.JohannsenMetric(*JOH)
+    isco = m.isco()
+    ocfg = oracle.make_config("johannsen", JOH)
+    assert isco == pytest.approx(oracle.isco(ocfg), rel=1e-12)
+    r, vt, vr, vp = G.interpolate_plunging_velocities(m, ensemble=ens)
+    ro, vto, vro, vpo = oracle.plunging_table(ocfg, isco)
+    assert abs(len(r) - len(ro)) <= 0.05 * len(ro) and len(r) > 50   # the start at the ISCO is marginally unstable
+    assert np.all(np.diff(r) > 0) and r[-1] < isco and r[0] < m.inner_radius() * 1.01
+    # same curve v(r): compare on the oracle's nodes inside the common range (linear interpolation
+    # between adaptive nodes is only good to ~(Δr)², so this is a 1e-3 check of the curve itself)
+    sel = (ro > r[1]) & (ro < r[-2])
+    for mine, ref in ((vt, vto), (vr, vro), (vp, vpo)):
+        np.testing.assert_allclose(np.interp(ro[sel], r, mine), ref[sel], rtol=2e-3, atol=1e-6)
+    # a null geodesic path: first row = initial state, last row = end point record
+    x = X_SMOKE
+    v = G.map_impact_parameters(m, x, 3.0, 4.0)
+    path = G.tracegeodesic_path(m, x, v, G.ThinDisc(2.0, 40.0), 200.0, ensemble=ens)
+    assert path.λ[0] == 0.0 and np.all(np.diff(path.λ) > 0)
+    np.testing.assert_array_equal(path.x[0], x)
+    np.testing.assert_array_equal(path.x[-1], path.point["x"])
+    assert path.λ[-1] == path.point["lambda_max"]
+    pts = G.tracegeodesics(m, x, v, G.ThinDisc(2.0, 40.0), 200.0, ensemble=ens)
+    assert pts[0].tobytes() == path.point.tobytes()
+
+
+@pytest.mark.parametrize("disc_in", ["isco", 2.0])
+def test_johannsen_redshift_matches_oracle(G, oracle, ens, disc_in):
+    m = G.JohannsenMetric(*JOH)
+    isco = m.isco()
+    r_in = isco if disc_in == "isco" else disc_in
+    x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+    W = H = 96
+    pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
+    _, _, img, st = G.rendergeodesics(m, x, G.ThinDisc(r_in, 50.0), 2000.0, image_width=W, image_height=H,
+                                      alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens, stats=True)
+    ocfg = oracle.make_config("johannsen", JOH, disc=(r_in, 50.0), lambda_max=2000.0)
+    # the oracle is given the SAME plunging table: the table's nodes are step-sequence dependent
+    ref, pts = oracle.rendergeodesics(ocfg, x, ALIMS, BLIMS, W, H, pf_id=oracle.PF_REDSHIFT,
+                                      filter_id=oracle.FILTER_INTERSECTED, r_isco=isco, plunge=pf.extra["plunge"],
+                                      return_points=True)
+    assert st["flagged_rays"] == 0
+    assert (np.isnan(img) != np.isnan(ref)).sum() <= 0.002 * W * H
+    both = ~np.isnan(img) & ~np.isnan(ref)
+    assert both.sum() > 500
+    np.testing.assert_allclose(img[both], ref[both], rtol=RTOL)
+    if disc_in != "isco":
+        rho = pts["x"][:, 1] * np.abs(np.sin(pts["x"][:, 2]))
+        assert ((pts["status"] == 2) & (rho < isco)).sum() > 20      # the interpolated branch is exercised
