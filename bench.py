@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--block-cols", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--emulate-shard", type=str, default=None,
+                    help="WORLD:RANK -- time one rank's shard of the image on a single GPU (diagnostic, no gather)")
     return ap.parse_args()
 
 
@@ -115,7 +117,8 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # under torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -129,6 +132,9 @@ def main():
         ens.set("waves_per_simd", args.waves_per_simd)
     m, x, d, pf, cfg = workload(G, args.size, ens)
     plan = G.shard_plan(args.size, args.size, world, rank, args.block_cols)
+    if args.emulate_shard:
+        ew, er = (int(t) for t in args.emulate_shard.split(":"))
+        plan = G.shard_plan(args.size, args.size, ew, er, args.block_cols)
     rg = plan.ray_range()
     local = torch.empty(plan.count, dtype=torch.float64, device=dev)
     stats = gdev.new_stats(dev)
@@ -141,11 +147,13 @@ def main():
         gdev.render_device(cfg, pf, local, rg, stats if i is not None else None)
         if i is not None:
             ev[i][1].record()
+        if args.emulate_shard:
+            return None
         return G.gather_image(local, plan)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -158,7 +166,7 @@ def main():
         image = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -168,6 +176,10 @@ def main():
     total_rays = args.size * args.size
     rays_per_s = total_rays * args.steps / elapsed
 
+    if args.emulate_shard:
+        print(json.dumps({"emulated_shard": args.emulate_shard, "rays": plan.count, "ms_per_step": elapsed / args.steps * 1e3,
+                          "kernel_ms": kernel_ms, "rays_per_s_this_rank": plan.count * args.steps / elapsed}))
+        return
     if rank == 0:
         # sanity: the image is a real render (hits exist, values finite and O(1))
         img = image.cpu().numpy()
@@ -234,7 +246,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -454,6 +454,11 @@ struct Cold {
     double* image;            // device
     gr_point* points;         // device
     PfDev pf;
+    // longest-first scheduling of 8x8 tiles: `tile_perm` (may be null) maps queue order -> tile;
+    // `tile_cost` (may be null) receives the step count of one representative ray per tile so
+    // the host can build the permutation for the next render of the same plane
+    const uint32_t* tile_perm;
+    uint32_t* tile_cost;
 };
 
 struct Params {
@@ -482,7 +487,8 @@ GR_DEV int64_t tile_swizzle(const Cold& p, int64_t j)
 {
     if (!p.swizzle) return j;
     const int64_t H = p.plane.height;
-    const int64_t tile = j >> 6;
+    int64_t tile = j >> 6;
+    if (p.tile_perm) tile = p.tile_perm[tile];
     const int lane = (int)(j & 63);
     const int64_t tiles_per_col = H >> 3;
     const int64_t tx = tile / tiles_per_col, ty = tile - tx * tiles_per_col;
@@ -1014,6 +1020,12 @@ struct Ray {
         }
         if (flags) status = GR_STATUS_NO_STATUS;
         const Cold& cd = cold_of(p);
+        if (cd.tile_cost) {
+            // representative ray of its 8x8 tile: local column and row both multiples of 8
+            const int64_t H = cd.plane.height;
+            const int64_t col = j / H, row = j - col * H;
+            if (((col | row) & 7) == 0) cd.tile_cost[(col >> 3) * (H >> 3) + (row >> 3)] = (uint32_t)(nacc + nrej);
+        }
         if (cd.out_mode == 1) {
             double x0[4], v0[4];
             constrained_u0(m, p, j, x0, v0);

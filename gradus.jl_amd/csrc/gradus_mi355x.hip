@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "gr_device.hpp"
 
@@ -213,7 +214,15 @@ struct gr_ctx {
     int64_t refill_threshold = 16;
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
     int64_t swizzle = 1;
+    int64_t lpt = 1;                       // longest-first tile order learned from the previous render
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // LPT state for one (config, plane, range) key
+    std::vector<unsigned char> lpt_key;
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_perm = nullptr;
+    int64_t lpt_tiles = 0, lpt_cap = 0;
+    bool lpt_have_perm = false, lpt_cost_pending = false;
+    hipEvent_t ev_cost = nullptr;
 };
 
 namespace {
@@ -292,8 +301,80 @@ int32_t launch_tmpl(gr_ctx* ctx, Params& p, hipStream_t stream)
     return GR_OK;
 }
 
-int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold, hipStream_t stream)
+// Longest-processing-time-first order of the 8x8 tiles.  The first render of a plane records the
+// step count of one ray per tile; the next render of the SAME (config, plane, range) sorts the
+// tiles by that cost, longest first, so the rays started last are the short ones and the tail of
+// the launch (queue empty, waves draining) shrinks.  Only the ORDER of the work queue is learned:
+// every ray is traced in full every time and results are bit-identical with or without it.
+int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream, bool* record)
 {
+    *record = false;
+    cold.tile_perm = nullptr;
+    cold.tile_cost = nullptr;
+    if (!ctx->lpt || ctx->kernel != 1 || !cold.swizzle || cold.src_mode != 0) return GR_OK;
+    const int64_t tiles = p.n >> 6;
+    // Measured on MI355X: longest-first pays when a launch is only a few tiles per
+    // resident wave deep (the 1/8 shard of a 2048² image: 4.0 -> 3.7 ms on the rank holding the
+    // α≈0 columns, whose rays take up to 430 steps) and costs 2-4 % on deep launches.  lpt = 2 forces it.
+    const int64_t resident_waves = (int64_t)ctx->n_cu * 8;
+    if (tiles < resident_waves) return GR_OK;
+    if (ctx->lpt == 1 && tiles >= 6 * resident_waves) return GR_OK;
+    std::vector<unsigned char> key(sizeof(gr_config) + sizeof(gr_plane) + sizeof(gr_range));
+    std::memcpy(key.data(), &p.cfg, sizeof(gr_config));
+    std::memcpy(key.data() + sizeof(gr_config), &cold.plane, sizeof(gr_plane));
+    std::memcpy(key.data() + sizeof(gr_config) + sizeof(gr_plane), &cold.range, sizeof(gr_range));
+    if (key != ctx->lpt_key) {
+        ctx->lpt_key = key;
+        ctx->lpt_have_perm = false;
+        ctx->lpt_cost_pending = false;
+        if (ctx->lpt_cap < tiles) {
+            if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+            if (ctx->d_tile_perm) (void)hipFree(ctx->d_tile_perm);
+            ctx->d_tile_cost = ctx->d_tile_perm = nullptr;
+            ctx->lpt_cap = 0;
+            GR_HIP(hipMalloc((void**)&ctx->d_tile_cost, sizeof(uint32_t) * tiles));
+            GR_HIP(hipMalloc((void**)&ctx->d_tile_perm, sizeof(uint32_t) * tiles));
+            ctx->lpt_cap = tiles;
+        }
+        ctx->lpt_tiles = tiles;
+    }
+    if (!ctx->lpt_have_perm && ctx->lpt_cost_pending) {
+        // the recording launch has to be complete before its costs can be sorted (one-time)
+        GR_HIP(hipEventSynchronize(ctx->ev_cost));
+        std::vector<uint32_t> cost((size_t)tiles), perm((size_t)tiles);
+        GR_HIP(hipMemcpy(cost.data(), ctx->d_tile_cost, sizeof(uint32_t) * tiles, hipMemcpyDeviceToHost));
+        // counting sort, descending cost, stable in tile index
+        uint32_t cmax = 0;
+        for (uint32_t c : cost) cmax = c > cmax ? c : cmax;
+        if (cmax < (1u << 24)) {
+            std::vector<uint32_t> start((size_t)cmax + 2, 0);
+            for (uint32_t c : cost) start[(size_t)(cmax - c) + 1]++;
+            for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+            for (int64_t t = 0; t < tiles; ++t) perm[start[(size_t)(cmax - cost[(size_t)t])]++] = (uint32_t)t;
+            GR_HIP(hipMemcpyAsync(ctx->d_tile_perm, perm.data(), sizeof(uint32_t) * tiles, hipMemcpyHostToDevice, stream));
+            GR_HIP(hipStreamSynchronize(stream));   // perm is a local vector
+            ctx->lpt_have_perm = true;
+        }
+        ctx->lpt_cost_pending = false;
+    }
+    if (ctx->lpt_have_perm) {
+        cold.tile_perm = ctx->d_tile_perm;
+    } else {
+        GR_HIP(hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * tiles, stream));
+        cold.tile_cost = ctx->d_tile_cost;
+        *record = true;
+    }
+    return GR_OK;
+}
+
+int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t stream)
+{
+    Cold cold = cold_in;
+    bool lpt_record = false;
+    if (p.n > 0) {
+        const int32_t lrc = lpt_prepare(ctx, p, cold, stream, &lpt_record);
+        if (lrc != GR_OK) return lrc;
+    }
     if (p.n == 0) return GR_OK;
     // stage the cold block into the next ring slot (stream-ordered before the kernel)
     Cold* slot = ctx->d_cold + ctx->cold_next;
@@ -303,9 +384,16 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold, hipStream_t strea
     p.refill_threshold = (int32_t)ctx->refill_threshold;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     const bool disc = p.cfg.disc_id == GR_DISC_THIN;
+    int32_t rc;
     if (p.cfg.metric_id == GR_METRIC_KERR)
-        return disc ? launch_tmpl<KerrMetric, 1>(ctx, p, stream) : launch_tmpl<KerrMetric, 0>(ctx, p, stream);
-    return disc ? launch_tmpl<JohannsenMetric, 1>(ctx, p, stream) : launch_tmpl<JohannsenMetric, 0>(ctx, p, stream);
+        rc = disc ? launch_tmpl<KerrMetric, 1>(ctx, p, stream) : launch_tmpl<KerrMetric, 0>(ctx, p, stream);
+    else
+        rc = disc ? launch_tmpl<JohannsenMetric, 1>(ctx, p, stream) : launch_tmpl<JohannsenMetric, 0>(ctx, p, stream);
+    if (rc == GR_OK && lpt_record) {
+        GR_HIP(hipEventRecord(ctx->ev_cost, stream));
+        ctx->lpt_cost_pending = true;
+    }
+    return rc;
 }
 
 // copy the plunging table (host pointers) into the context and fill the device-side pf
@@ -405,7 +493,8 @@ int32_t gr_ctx_create(int32_t device, gr_ctx** out)
         if (hipMalloc((void**)&c->d_queue, sizeof(unsigned long long) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"); break; }
         if (hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * N_STAT) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(stats) failed"); break; }
         if (hipMalloc((void**)&c->d_cold, sizeof(Cold) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(cold) failed"); break; }
-        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipEventCreate failed"); break; }
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
+            || hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipEventCreate failed"); break; }
     } while (0);
     if (rc != GR_OK) {
         gr_ctx_destroy(c);
@@ -423,6 +512,9 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_cold) (void)hipFree(c->d_cold);
+    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+    if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
+    if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
     if (c->d_plunge) (void)hipFree(c->d_plunge);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -451,6 +543,10 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->waves_per_simd = value;
     } else if (k == "swizzle") {
         c->swizzle = value ? 1 : 0;
+    } else if (k == "lpt") {
+        if (value < 0 || value > 2) return fail(GR_ERR_INVALID_ARGUMENT, "lpt must be 0 (off), 1 (auto) or 2 (always)");
+        c->lpt = value;
+        c->lpt_key.clear();
     } else {
         return fail(GR_ERR_INVALID_ARGUMENT, "unknown knob '" + k + "'");
     }

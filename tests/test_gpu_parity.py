@@ -278,3 +278,19 @@ def test_johannsen_redshift_matches_oracle(G, oracle, ens, disc_in):
     if disc_in != "isco":
         rho = pts["x"][:, 1] * np.abs(np.sin(pts["x"][:, 2]))
         assert ((pts["status"] == 2) & (rho < isco)).sum() > 20      # the interpolated branch is exercised
+
+
+def test_lpt_tile_order_changes_nothing_but_time(G, ens):
+    """Longest-first tile scheduling learned from the previous render of the same plane must give a
+    bit-identical image (only the order of the work queue changes)."""
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    pf = G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    kw = dict(image_width=512, image_height=512, alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens)
+    ens.set("kernel", 1).set("lpt", 0)
+    _, _, ref = G.rendergeodesics(m, X_FAR, d, 2000.0, **kw)
+    ens.set("lpt", 2)
+    imgs = [G.rendergeodesics(m, X_FAR, d, 2000.0, **kw)[2] for _ in range(3)]   # record, sort+use, use
+    ens.set("lpt", 1)
+    for im in imgs:
+        assert im.tobytes() == ref.tobytes()
