@@ -9,6 +9,7 @@ from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
 from .distributed import gather_image, shard_plan
 from .geometry import ThinDisc
+from .lineprofiles import BinningMethod, PowerLawEmissivity, bucket_simple, lineprofile
 from .metrics import JohannsenMetric, KerrMetric, inner_radius, isco
 from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix
 from .planes import (CartesianPlane, GeometricGrid, InverseGrid, LinearGrid, PolarPlane, image_plane,

@@ -84,6 +84,27 @@ class gr_pointfunction(C.Structure):
     ]
 
 
+class gr_rayset(C.Structure):
+    _fields_ = [
+        ("x_obs", C.c_double * 4),
+        ("Mx", C.c_double * 16),
+        ("alpha", C.c_void_p),
+        ("beta", C.c_void_p),
+        ("area", C.c_void_p),
+        ("n", C.c_int64),
+    ]
+
+
+class gr_binning(C.Structure):
+    _fields_ = [
+        ("r_min", C.c_double),
+        ("r_max", C.c_double),
+        ("emissivity_index", C.c_double),
+        ("n_bins", C.c_int64),
+        ("bin_edges", C.c_void_p),
+    ]
+
+
 class gr_stats(C.Structure):
     _fields_ = [
         ("rays", C.c_int64),
@@ -137,6 +158,10 @@ EXPORTS = [
     "gr_trace_endpoints_device",
     "gr_trace_endpoints",
     "gr_trace_path",
+    "gr_lineprofile_device",
+    "gr_lineprofile",
+    "gr_redshift_radius_device",
+    "gr_redshift_radius",
     "gr_apply_pointfunction_device",
     "gr_apply_pointfunction",
 ]
@@ -168,6 +193,11 @@ def load():
     L.gr_trace_endpoints_device.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, vp, vp]
     L.gr_trace_endpoints.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, stp]
     L.gr_trace_path.argtypes = [vp, cfgp, vp, vp, i64, vp, C.POINTER(i64), vp]
+    rsp, bnp = C.POINTER(gr_rayset), C.POINTER(gr_binning)
+    L.gr_lineprofile_device.argtypes = [vp, cfgp, rsp, pfp, bnp, vp, vp, vp]
+    L.gr_lineprofile.argtypes = [vp, cfgp, rsp, pfp, bnp, vp, stp]
+    L.gr_redshift_radius_device.argtypes = [vp, cfgp, rsp, pfp, C.c_double, C.c_double, vp, vp, vp]
+    L.gr_redshift_radius.argtypes = [vp, cfgp, rsp, pfp, C.c_double, C.c_double, vp, stp]
     L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]
     L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
     for name in EXPORTS:

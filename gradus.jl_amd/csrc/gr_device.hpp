@@ -81,6 +81,14 @@ GR_DEV double sqrt_fast(double x)
     return __builtin_fma(d, hh, g);
 }
 GR_DEV int sgn(double x) { return (x > 0.0) - (x < 0.0); }
+GR_DEV void gr_atomic_add(double* p, double v)
+{
+#ifdef GR_HOST_HARNESS
+    *p += v;
+#else
+    atomicAdd(p, v);
+#endif
+}
 GR_DEV float fast_log2f(float x) { return GR_LOG2F(x); }
 GR_DEV float fast_exp2f(float x) { return GR_EXP2F(x); }
 
@@ -123,6 +131,30 @@ GR_DEV void sincos_fast(double x, double& s_out, double& c_out)
     const double c0 = (q & 1) ? sn : cs;
     s_out = (q & 2) ? -s0 : s0;
     c_out = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// sin and cos of θ0 + δ from (sin θ0, cos θ0) by rotation, for the Runge-Kutta stage points of
+// one step: |δ| <= 1/16 is the common case (99.4 % of steps) and needs two short Taylor
+// polynomials (truncation < 1e-17) and four FMAs, no range reduction and no quadrant logic.
+// Larger δ takes the full evaluation.
+GR_DEV void sincos_rot(double th0, double s0, double c0, double th, double& s_out, double& c_out)
+{
+    const double d = th - th0;
+    if (::fabs(d) <= 0.0625) {
+        const double z = d * d;
+        double ps = __builtin_fma(z, 2.7557319223985893e-06, -1.9841269841269841e-04);
+        ps = __builtin_fma(z, ps, 8.3333333333333333e-03);
+        ps = __builtin_fma(z, ps, -1.6666666666666666e-01);
+        const double sd = __builtin_fma(d * z, ps, d);                    // sin δ
+        double pc = __builtin_fma(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
+        pc = __builtin_fma(z, pc, 4.1666666666666664e-02);
+        pc = __builtin_fma(z, pc, -0.5);
+        const double cm1 = z * pc;                                        // cos δ - 1
+        s_out = __builtin_fma(c0, sd, __builtin_fma(s0, cm1, s0));
+        c_out = __builtin_fma(-s0, sd, __builtin_fma(c0, cm1, c0));
+    } else {
+        sincos_fast(th, s_out, c_out);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -290,14 +322,14 @@ struct JohannsenMetric {
     }
 };
 
-// geodesic_equation (auto-diff.jl:213-226) with the sparse contraction of SURVEY App. B.1.
-// Also returns sinθ, cosθ of the evaluation point (re-used by the disc condition).
+// geodesic_equation (auto-diff.jl:213-226) with the sparse contraction of SURVEY App. B.1 at a
+// point given by r and (sinθ, cosθ).  The factors 2 and -½ of the reference's form cancel:
+//   a^t = -(g^tt T_t + g^tϕ T_ϕ), a^r = -g^rr (ġ_rr v^r - ½ D_r), ... with T_t = ġ_tt v^t + ġ_tϕ v^ϕ.
 template <class Metric>
-GR_DEV void geodesic_rhs(const Metric& m, double r, double th, double vt, double vr, double vh, double vp,
-                         double& at, double& ar, double& ah, double& ap, double& s, double& c)
+GR_DEV void geodesic_rhs_sc(const Metric& m, double r, double s, double c, double vt, double vr, double vh, double vp,
+                            double& at, double& ar, double& ah, double& ap)
 {
     double g[5], j1[5], j2[5], gi[5];
-    sincos_fast(th, s, c);
     m.eval(r, s, c, g, j1, j2, gi);
     double gd[5];
 #pragma unroll
@@ -305,14 +337,22 @@ GR_DEV void geodesic_rhs(const Metric& m, double r, double th, double vt, double
     const double vt2 = vt * vt, vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp, vtp = 2.0 * vt * vp;
     const double Dr = j1[0] * vt2 + j1[1] * vr2 + j1[2] * vh2 + j1[3] * vp2 + j1[4] * vtp;
     const double Dh = j2[0] * vt2 + j2[1] * vr2 + j2[2] * vh2 + j2[3] * vp2 + j2[4] * vtp;
-    const double St = 2.0 * (gd[0] * vt + gd[4] * vp);
-    const double Sr = 2.0 * gd[1] * vr - Dr;
-    const double Sh = 2.0 * gd[2] * vh - Dh;
-    const double Sp = 2.0 * (gd[4] * vt + gd[3] * vp);
-    at = -0.5 * (gi[0] * St + gi[4] * Sp);
-    ar = -0.5 * (gi[1] * Sr);
-    ah = -0.5 * (gi[2] * Sh);
-    ap = -0.5 * (gi[4] * St + gi[3] * Sp);
+    const double Tt = __builtin_fma(gd[0], vt, gd[4] * vp);
+    const double Tp = __builtin_fma(gd[4], vt, gd[3] * vp);
+    const double Tr = __builtin_fma(gd[1], vr, -0.5 * Dr);
+    const double Th = __builtin_fma(gd[2], vh, -0.5 * Dh);
+    at = -__builtin_fma(gi[0], Tt, gi[4] * Tp);
+    ar = -(gi[1] * Tr);
+    ah = -(gi[2] * Th);
+    ap = -__builtin_fma(gi[4], Tt, gi[3] * Tp);
+}
+
+template <class Metric>
+GR_DEV void geodesic_rhs(const Metric& m, double r, double th, double vt, double vr, double vh, double vp,
+                         double& at, double& ar, double& ah, double& ap, double& s, double& c)
+{
+    sincos_fast(th, s, c);
+    geodesic_rhs_sc(m, r, s, c, vt, vr, vh, vp, at, ar, ah, ap);
 }
 
 // constrain_time, auto-diff.jl:161-179
@@ -442,8 +482,8 @@ struct PfDev {
 // (not in the kernarg segment) and is re-read at each use, so that its ~60 scalars are not kept
 // live in SGPRs across the hot step loop.
 struct Cold {
-    int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays
-    int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records
+    int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays
+    int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs
     int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
     int32_t _pad;
     gr_plane plane;
@@ -459,6 +499,18 @@ struct Cold {
     // the host can build the permutation for the next render of the same plane
     const uint32_t* tile_perm;
     uint32_t* tile_cost;
+    // src_mode 2: rays given by impact parameters (an AbstractImagePlane, image-planes/planes.jl:180-184)
+    const double* alpha;      // device, n
+    const double* beta;       // device, n
+    const double* area;       // device, n (unnormalized_areas) or null = 1
+    // out_mode 2: BinningMethod line profile (line-profiles.jl:152-198) fused into finalize;
+    // out_mode 3: (g, ρ) pairs for a host-side emissivity
+    double lp_rmin, lp_rmax;  // minrₑ, maxrₑ
+    double lp_q;              // ε(r) = r^-q
+    int64_t lp_nbins;
+    const double* lp_edges;   // device, lp_nbins
+    double* lp_flux;          // device, lp_nbins (accumulated with fp64 atomics)
+    double* lp_pairs;         // device, n x 2
 };
 
 struct Params {
@@ -613,6 +665,7 @@ struct Ray {
     double A[7][4];     // stage accelerations; A[0] is FSAL
     double t, dt, h;    // affine time, proposed step, last used step
     double cprev;       // disc condition at x
+    double sth, cth;    // sin θ, cos θ at x (base of the stage rotations)
     float lq_old;       // log2(qold)
     int32_t ev_top;     // upper bracket j of Θ = j/7 when an event is pending
     int64_t j;          // local (swizzled) ray index
@@ -664,6 +717,19 @@ struct Ray {
                 v0[q] = p.plane.Mx[q * 4 + 0] * pb[0] + p.plane.Mx[q * 4 + 1] * pb[1] + p.plane.Mx[q * 4 + 2] * pb[2]
                         + p.plane.Mx[q * 4 + 3] * pb[3];
             }
+        } else if (p.src_mode == 2) {
+            // promote_velfunc: map_impact_parameters(m, x, αs[i], βs[i]) -- no pixel offset
+            const double ro = p.plane.x_obs[1];
+            const double iro = rcp_full(ro);
+            const double b = p.beta[jl] * iro, a = p.alpha[jl] * iro;
+            const double pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
+            const double pb[4] = { 1.0, pr, b * pr, a * pr };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x0[q] = p.plane.x_obs[q];
+                v0[q] = p.plane.Mx[q * 4 + 0] * pb[0] + p.plane.Mx[q * 4 + 1] * pb[1] + p.plane.Mx[q * 4 + 2] * pb[2]
+                        + p.plane.Mx[q * 4 + 3] * pb[3];
+            }
         } else {
             const double* xs = p.x + jl * p.x_stride;
             const double* vs = p.v + jl * 4;
@@ -699,6 +765,7 @@ struct Ray {
         lq_old = (float)LOG2_QOLDINIT;
         double s, c;
         accel(m, x[1], x[2], v, A[0], s, c);
+        sth = s; cth = c;
         cprev = DISC ? disc_cond(p, x[1], s, c) : 1.0;
 
         const double abstol = p.cfg.abstol, reltol = p.cfg.reltol;
@@ -791,7 +858,8 @@ struct Ray {
             rs = __builtin_fma(h2, ar, rs);                                                           \
             ts = __builtin_fma(h2, at, ts);                                                           \
         }                                                                                             \
-        accel(m, rs, ts, vs, A[S], s, c);                                                             \
+        sincos_rot(x[2], sth, cth, ts, s, c);                                                         \
+        geodesic_rhs_sc(m, rs, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
     }
         GR_STAGE(1)
         GR_STAGE(2)
@@ -872,6 +940,7 @@ struct Ray {
             const bool term = discrete_cb(p, xn[1], cn, status);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[i] = xn[i]; v[i] = vn[i]; A[0][i] = A[6][i]; }
+            sth = sn; cth = cn;
             t = tnew;
             dt = ::fmin(dtmax, dtnew);
             return term || !(t < tend);
@@ -1040,6 +1109,35 @@ struct Ray {
                 o->v_init[q] = v0[q];
                 o->x[q] = x[q];
                 o->v[q] = v[q];
+            }
+        } else if (cd.out_mode >= 2) {
+            // lineprofile(bins, ε, m, u, d, BinningMethod()), line-profiles.jl:186-197
+            double s, c;
+            sincos_fast(x[2], s, c);
+            const double rho = x[1] * ::fabs(s);
+            const bool in = status == GR_STATUS_INTERSECTED_WITH_GEOMETRY && rho >= cd.lp_rmin && rho <= cd.lp_rmax;
+            double g = 0.0;
+            if (in) {
+                double x0[4], v0[4];
+                constrained_u0(m, p, j, x0, v0);
+                g = redshift_pf(m, p, cd, x0, v0, x, v);
+            }
+            if (cd.out_mode == 3) {
+                cd.lp_pairs[2 * j] = in ? g : __builtin_nan("");
+                cd.lp_pairs[2 * j + 1] = in ? rho : __builtin_nan("");
+            } else if (in) {
+                const double area = cd.area ? cd.area[j] : 1.0;
+                // ε(r) g³ area with ε(r) = r^-q
+                const double eps = (cd.lp_q == 3.0) ? rcp_full(rho * rho * rho) : ::pow(rho, -cd.lp_q);
+                const double f = eps * g * g * g * area;
+                // bucket(Simple(), g, f, bins): first edge >= g, clamped to the last bin
+                int64_t lo = 0, hi = cd.lp_nbins;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (cd.lp_edges[mid] < g) lo = mid + 1; else hi = mid;
+                }
+                if (lo > cd.lp_nbins - 1) lo = cd.lp_nbins - 1;
+                if (f == f) gr_atomic_add(cd.lp_flux + lo, f);
             }
         } else {
             bool pass = true;

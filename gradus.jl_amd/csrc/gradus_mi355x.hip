@@ -705,6 +705,71 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const 
     return GR_OK;
 }
 
+static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cfg, const gr_rayset* rays)
+{
+    if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
+    if (rays->n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (rays->n > 0 && (!rays->alpha || !rays->beta)) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
+    std::memset(&p, 0, sizeof p);
+    std::memset(&cd, 0, sizeof cd);
+    p.cfg = *cfg;
+    p.n = rays->n;
+    cd.src_mode = 2;
+    std::memcpy(cd.plane.x_obs, rays->x_obs, sizeof cd.plane.x_obs);
+    std::memcpy(cd.plane.Mx, rays->Mx, sizeof cd.plane.Mx);
+    cd.plane.width = rays->n; cd.plane.height = 1;
+    cd.range = gr_range{ 0, rays->n, rays->n > 0 ? rays->n : 1, 1 };
+    cd.alpha = rays->alpha; cd.beta = rays->beta; cd.area = rays->area;
+    cd.swizzle = 0;
+    (void)ctx;
+    return GR_OK;
+}
+
+int32_t gr_lineprofile_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                              const gr_binning* b, double* d_flux, gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if (!b || b->n_bins < 1 || !b->bin_edges || !d_flux) return fail(GR_ERR_INVALID_ARGUMENT, "binning/flux is null or empty");
+    if (!(b->r_max >= b->r_min)) return fail(GR_ERR_INVALID_ARGUMENT, "maxrₑ below minrₑ");
+    if (cfg->disc_id == GR_DISC_NONE) return fail(GR_ERR_INVALID_ARGUMENT, "a line profile needs accretion geometry");
+    GR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params p;
+    Cold cd;
+    if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
+    if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "line profiles use the redshift point function");
+    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    cd.out_mode = 2;
+    cd.lp_rmin = b->r_min; cd.lp_rmax = b->r_max; cd.lp_q = b->emissivity_index;
+    cd.lp_nbins = b->n_bins; cd.lp_edges = b->bin_edges; cd.lp_flux = d_flux;
+    p.stats = (unsigned long long*)d_stats;
+    GR_HIP(hipMemsetAsync(d_flux, 0, sizeof(double) * (size_t)b->n_bins, stream));
+    return launch_trace(ctx, p, cd, stream);
+}
+
+int32_t gr_redshift_radius_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                                  double r_min, double r_max, double* d_pairs, gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params p;
+    Cold cd;
+    if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
+    if (rays->n > 0 && !d_pairs) return fail(GR_ERR_INVALID_ARGUMENT, "pairs is null");
+    if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "needs the redshift point function");
+    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    cd.out_mode = 3;
+    cd.lp_rmin = r_min; cd.lp_rmax = r_max;
+    cd.lp_pairs = d_pairs;
+    p.stats = (unsigned long long*)d_stats;
+    return launch_trace(ctx, p, cd, stream);
+}
+
 // ---- host-buffer variants: stage through the context, block until done ----
 static int32_t begin_host_call(gr_ctx* ctx, gr_stats* stats)
 {
@@ -803,6 +868,67 @@ int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_point
     if (n > 0) GR_HIP(hipMemcpyAsync(out, ctx->d_scratch, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     GR_HIP(hipStreamSynchronize(ctx->stream));
     return GR_OK;
+}
+
+// stage a host rayset on the device: alpha | beta | area contiguous in ctx->d_in
+static int32_t stage_rays(gr_ctx* ctx, const gr_rayset* rays, gr_rayset& dev, size_t extra_bytes, void** extra)
+{
+    if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
+    if (rays->n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (rays->n > 0 && (!rays->alpha || !rays->beta)) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
+    const size_t n = (size_t)rays->n;
+    int32_t rc;
+    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 3 * n + extra_bytes + 64)) != GR_OK) return rc;
+    double* base = (double*)ctx->d_in;
+    dev = *rays;
+    dev.alpha = base; dev.beta = base + n; dev.area = rays->area ? base + 2 * n : nullptr;
+    if (n) {
+        GR_HIP(hipMemcpyAsync(base, rays->alpha, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        GR_HIP(hipMemcpyAsync(base + n, rays->beta, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        if (rays->area) GR_HIP(hipMemcpyAsync(base + 2 * n, rays->area, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (extra) *extra = (void*)(base + 3 * n);
+    return GR_OK;
+}
+
+int32_t gr_lineprofile(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                       const gr_binning* b, double* flux, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!b || b->n_bins < 1 || !b->bin_edges || !flux) return fail(GR_ERR_INVALID_ARGUMENT, "binning/flux is null or empty");
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    gr_rayset dev;
+    void* extra = nullptr;
+    const size_t nb = (size_t)b->n_bins;
+    if ((rc = stage_rays(ctx, rays, dev, sizeof(double) * 2 * nb, &extra)) != GR_OK) return rc;
+    double* d_edges = (double*)extra;
+    double* d_flux = d_edges + nb;
+    GR_HIP(hipMemcpyAsync(d_edges, b->bin_edges, sizeof(double) * nb, hipMemcpyHostToDevice, ctx->stream));
+    gr_binning db = *b;
+    db.bin_edges = d_edges;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = gr_lineprofile_device(ctx, cfg, &dev, pf, &db, d_flux, stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    GR_HIP(hipMemcpyAsync(flux, d_flux, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
+}
+
+int32_t gr_redshift_radius(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                           double r_min, double r_max, double* pairs, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (rays && rays->n > 0 && !pairs) return fail(GR_ERR_INVALID_ARGUMENT, "pairs is null");
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    gr_rayset dev;
+    if ((rc = stage_rays(ctx, rays, dev, 0, nullptr)) != GR_OK) return rc;
+    const size_t bytes = sizeof(double) * 2 * (size_t)rays->n;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = gr_redshift_radius_device(ctx, cfg, &dev, pf, r_min, r_max, (double*)ctx->d_scratch,
+                                        stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    if (bytes) GR_HIP(hipMemcpyAsync(pairs, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
 }
 
 }  // extern "C"

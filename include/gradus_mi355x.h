@@ -207,6 +207,43 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x /* 4 */
                       const double* v /* 4, unconstrained */, int64_t cap, double* path /* host, cap x 9 */,
                       int64_t* n_rows, gr_point* endpoint /* host, may be NULL */);
 
+/* ---- lineprofile(bins, ε, m, x, d, BinningMethod(); plane, callback) --
+ * src/line-profiles.jl:152-198.  The rays are an AbstractImagePlane given by its impact parameters
+ * (src/image-planes/planes.jl:70-184); velocities are map_impact_parameters(m, x, α_i, β_i) with no
+ * pixel offset (planes.jl:180-184). */
+typedef struct gr_rayset {
+    double x_obs[4];
+    double Mx[16];            /* as in gr_plane                                            */
+    const double* alpha;      /* n impact parameters α                                     */
+    const double* beta;       /* n impact parameters β                                     */
+    const double* area;       /* n unnormalized_areas(plane), or NULL for 1                */
+    int64_t n;
+} gr_rayset;
+
+typedef struct gr_binning {
+    double r_min, r_max;      /* minrₑ, maxrₑ: only hits with r_min <= ρ <= r_max count    */
+    double emissivity_index;  /* ε(r) = r^-q                                               */
+    int64_t n_bins;
+    const double* bin_edges;  /* n_bins values, ascending (the `bins` argument)            */
+} gr_binning;
+
+/* flux[k] += ε(ρ) g³ area for every counted hit whose redshift g falls in bin k
+ * (bucket(Simple(), g, f, bins): first edge >= g, clamped to the last bin).  NOT normalised;
+ * the caller divides by sum(flux) (line-profiles.jl:197).  Device variant: rays->alpha/beta/area,
+ * b->bin_edges and d_flux are device pointers; d_flux is zeroed by the call. */
+int32_t gr_lineprofile_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                              const gr_pointfunction* pf, const gr_binning* b, double* d_flux,
+                              gr_stats* d_stats, void* hip_stream);
+int32_t gr_lineprofile(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                       const gr_pointfunction* pf, const gr_binning* b, double* flux, gr_stats* stats);
+/* generic emissivity: (g, ρ) per ray (NaN, NaN for rays that do not count), n x 2 doubles */
+int32_t gr_redshift_radius_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                                  const gr_pointfunction* pf, double r_min, double r_max,
+                                  double* d_pairs, gr_stats* d_stats, void* hip_stream);
+int32_t gr_redshift_radius(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                           const gr_pointfunction* pf, double r_min, double r_max, double* pairs,
+                           gr_stats* stats);
+
 /* ---- apply(pf, cache): evaluate a built-in point function on endpoint records
  * (point-functions.jl:98-101, rendering.jl:103-107) ---- */
 int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,

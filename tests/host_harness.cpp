@@ -20,7 +20,7 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
         if (tlog && k < cap) { tlog[k] = ray.t; hlog[k] = ray.dt; ++k; }
         for (;;) {
             const bool fin = ray.step(m, p);
-            if (tlog && k < cap) { tlog[k] = ray.t; hlog[k] = ray.dbg_e2; ++k; }
+            if (tlog && k < cap) { tlog[k] = ray.t; hlog[k] = ray.x[2]; ++k; }
             if (fin) break;
         }
         if (nlog) *nlog = k;

@@ -294,3 +294,41 @@ def test_lpt_tile_order_changes_nothing_but_time(G, ens):
     ens.set("lpt", 1)
     for im in imgs:
         assert im.tobytes() == ref.tobytes()
+
+
+# ---------------- BASELINE config C5: BinningMethod line profile ----------------
+def _oracle_lineprofile(oracle, G, name, params, u, disc, plane, bins, q, rmin, rmax):
+    """lineprofile(..., BinningMethod()) restated from oracle pieces + numpy (line-profiles.jl:152-198)."""
+    λ_max = 2.0 * u[1]
+    cfg = oracle.make_config(name, params, disc=disc, lambda_max=λ_max, upper_hemisphere=True)
+    a, b = G.impact_parameters(plane, u)
+    v = oracle.map_impact_parameters(cfg, u, a, b)
+    pts = oracle.trace(cfg, u, v)
+    g = oracle.apply_pf(cfg, pts, λ_max, pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_INTERSECTED, r_isco=rmin)
+    rho = pts["x"][:, 1] * np.abs(np.sin(pts["x"][:, 2]))
+    I = (pts["status"] == oracle.INTERSECTED_WITH_GEOMETRY) & (rho >= rmin) & (rho <= rmax)
+    areas = G.unnormalized_areas(plane).ravel(order="F")
+    f = rho[I] ** (-q) * g[I] ** 3 * areas[I]
+    flux = G.bucket_simple(g[I], f, bins)
+    return flux / flux.sum()
+
+
+def test_lineprofile_binning_matches_oracle_and_reference_edges(G, oracle, ens):
+    """test/line-profiles/test-binning.jl:5-32 on the device (fused and generic paths) + oracle parity."""
+    m = G.KerrMetric(M=1.0, a=0.6)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    d = G.ThinDisc(m.isco(), 250.0)
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=100, Nθ=400)
+    bins = np.linspace(0.1, 1.3, 100)
+    x, y = G.lineprofile(bins, G.PowerLawEmissivity(3), m, u, d, G.BinningMethod(), plane=plane, ensemble=ens)
+    x2, y2 = G.lineprofile(bins, lambda r: r ** -3.0, m, u, d, G.BinningMethod(), plane=plane, ensemble=ens)
+    np.testing.assert_allclose(y, y2, rtol=1e-9, atol=1e-15)          # fused == generic path
+    assert y.sum() == pytest.approx(1.0)
+    g_low = x[np.argmax(y > 0)]
+    g_high = x[len(y) - 1 - np.argmax(y[::-1] > 0) - 1]
+    assert g_low == pytest.approx(0.355, abs=0.05)
+    assert g_high == pytest.approx(1.2, abs=0.05)
+    ref = _oracle_lineprofile(oracle, G, "kerr", (1.0, 0.6), u, (m.isco(), 250.0), plane, bins, 3.0, m.isco(), 50.0)
+    # a rim ray switching bins moves ~1e-4 of the flux; bulk agreement is much tighter
+    assert np.abs(y - ref).sum() < 2e-3
+    assert np.max(np.abs(y - ref)) < 5e-4
