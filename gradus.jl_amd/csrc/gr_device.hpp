@@ -25,6 +25,34 @@
 
 #include "../../include/gradus_mi355x.h"
 
+// Scalar type of the integrator.  The fp32 build (gradus_mi355x_f32.hip) defines GR_REAL_IS_FLOAT
+// and GR_NS = gr32 and is compiled with -Xclang -cl-single-precision-constant so that every
+// floating literal below is a float there.  All I/O (gr_point, images, tables) stays double.
+#ifndef GR_NS
+#define GR_NS gr
+#endif
+#ifdef GR_REAL_IS_FLOAT
+typedef float gr_real_t;
+#define GR_FMA __builtin_fmaf
+#define GR_FABS __builtin_fabsf
+#define GR_FMAX __builtin_fmaxf
+#define GR_FMIN __builtin_fminf
+#define GR_RINT __builtin_rintf
+#define GR_SQRT __builtin_sqrtf
+#define GR_POW ::powf
+#define GR_EPS 1.1920929e-07f
+#else
+typedef double gr_real_t;
+#define GR_FMA __builtin_fma
+#define GR_FABS __builtin_fabs
+#define GR_FMAX __builtin_fmax
+#define GR_FMIN __builtin_fmin
+#define GR_RINT __builtin_rint
+#define GR_SQRT __builtin_sqrt
+#define GR_POW ::pow
+#define GR_EPS 2.220446049250313e-16
+#endif
+
 #ifdef GR_HOST_HARNESS
 // tests/host_harness.cpp compiles this header with g++ to trace single rays on the CPU next to
 // the oracle.  Test infrastructure only: the shipped library never defines GR_HOST_HARNESS.
@@ -37,50 +65,57 @@
 #else
 #include <hip/hip_runtime.h>
 #define GR_DEV __device__ __forceinline__
+#ifdef GR_REAL_IS_FLOAT
+#define GR_RCP_SEED(x) __builtin_amdgcn_rcpf(x)
+#define GR_RSQ_SEED(x) __builtin_amdgcn_rsqf(x)
+#else
 #define GR_RCP_SEED(x) __builtin_amdgcn_rcp(x)
 #define GR_RSQ_SEED(x) __builtin_amdgcn_rsq(x)
+#endif
 #define GR_LOG2F(x) __builtin_amdgcn_logf(x)     // v_log_f32
 #define GR_EXP2F(x) __builtin_amdgcn_exp2f(x)    // v_exp_f32
 #endif
 
-namespace gr {
+namespace GR_NS {
+
+typedef gr_real_t real;
 
 // ---------------------------------------------------------------------------------------
 // scalar helpers
 // ---------------------------------------------------------------------------------------
-GR_DEV double rcp_full(double x)
+GR_DEV real rcp_full(real x)
 {
     // v_rcp_f64 seed + two Newton steps: <= 1 ulp for normal, finite x
-    double r = GR_RCP_SEED(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
+    real r = GR_RCP_SEED(x);
+    real e = GR_FMA(-x, r, 1.0);
+    r = GR_FMA(r, e, r);
+    e = GR_FMA(-x, r, 1.0);
+    r = GR_FMA(r, e, r);
     return r;
 }
-GR_DEV double rcp_fast(double x)
+GR_DEV real rcp_fast(real x)
 {
     // one Newton step: ~1e-14 relative or better; used where the consumer is a tolerance test
-    double r = GR_RCP_SEED(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
+    real r = GR_RCP_SEED(x);
+    real e = GR_FMA(-x, r, 1.0);
+    return GR_FMA(r, e, r);
 }
-GR_DEV double sqrt_fast(double x)
+GR_DEV real sqrt_fast(real x)
 {
     // x > 0, normal range.  rsq seed + two coupled Newton steps (Goldschmidt): <= 1 ulp
-    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : ::sqrt(x);
-    double y = GR_RSQ_SEED(x);
-    double g = x * y, hh = 0.5 * y;
-    double r = __builtin_fma(-hh, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    hh = __builtin_fma(hh, r, hh);
-    r = __builtin_fma(-hh, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    hh = __builtin_fma(hh, r, hh);
-    const double d = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, hh, g);
+    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : GR_SQRT(x);
+    real y = GR_RSQ_SEED(x);
+    real g = x * y, hh = 0.5 * y;
+    real r = GR_FMA(-hh, g, 0.5);
+    g = GR_FMA(g, r, g);
+    hh = GR_FMA(hh, r, hh);
+    r = GR_FMA(-hh, g, 0.5);
+    g = GR_FMA(g, r, g);
+    hh = GR_FMA(hh, r, hh);
+    const real d = GR_FMA(-g, g, x);
+    return GR_FMA(d, hh, g);
 }
-GR_DEV int sgn(double x) { return (x > 0.0) - (x < 0.0); }
+GR_DEV int sgn(real x) { return (x > 0.0) - (x < 0.0); }
 GR_DEV void gr_atomic_add(double* p, double v)
 {
 #ifdef GR_HOST_HARNESS
@@ -94,41 +129,41 @@ GR_DEV float fast_exp2f(float x) { return GR_EXP2F(x); }
 
 // sin and cos of x for moderate |x| (|x| < ~1e5): two-term Cody-Waite reduction by pi/2 with
 // exact-product FMAs, then the fdlibm minimax kernels on [-pi/4, pi/4].  < 1 ulp each.
-GR_DEV void sincos_fast(double x, double& s_out, double& c_out)
+GR_DEV void sincos_fast(real x, real& s_out, real& c_out)
 {
-    const double TWO_OVER_PI = 6.36619772367581382433e-01;
-    const double PIO2_HI = 1.57079632679489655800e+00;
-    const double PIO2_LO = 6.12323399573676603587e-17;
-    const double kf = __builtin_rint(x * TWO_OVER_PI);
-    double y = __builtin_fma(-kf, PIO2_HI, x);
-    y = __builtin_fma(-kf, PIO2_LO, y);
+    const real TWO_OVER_PI = 6.36619772367581382433e-01;
+    const real PIO2_HI = 1.57079632679489655800e+00;
+    const real PIO2_LO = 6.12323399573676603587e-17;
+    const real kf = GR_RINT(x * TWO_OVER_PI);
+    real y = GR_FMA(-kf, PIO2_HI, x);
+    y = GR_FMA(-kf, PIO2_LO, y);
     const int q = (int)kf;
-    const double z = y * y;
+    const real z = y * y;
     // __kernel_sin
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+    const real S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double ps = __builtin_fma(z, S6, S5);
-    ps = __builtin_fma(z, ps, S4);
-    ps = __builtin_fma(z, ps, S3);
-    ps = __builtin_fma(z, ps, S2);
-    ps = __builtin_fma(z, ps, S1);
-    const double sn = __builtin_fma(y * z, ps, y);
+    real ps = GR_FMA(z, S6, S5);
+    ps = GR_FMA(z, ps, S4);
+    ps = GR_FMA(z, ps, S3);
+    ps = GR_FMA(z, ps, S2);
+    ps = GR_FMA(z, ps, S1);
+    const real sn = GR_FMA(y * z, ps, y);
     // __kernel_cos
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+    const real C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double pc = __builtin_fma(z, C6, C5);
-    pc = __builtin_fma(z, pc, C4);
-    pc = __builtin_fma(z, pc, C3);
-    pc = __builtin_fma(z, pc, C2);
-    pc = __builtin_fma(z, pc, C1);
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    const double cs = w + (((1.0 - w) - hz) + z * (z * pc));
+    real pc = GR_FMA(z, C6, C5);
+    pc = GR_FMA(z, pc, C4);
+    pc = GR_FMA(z, pc, C3);
+    pc = GR_FMA(z, pc, C2);
+    pc = GR_FMA(z, pc, C1);
+    const real hz = 0.5 * z;
+    const real w = 1.0 - hz;
+    const real cs = w + (((1.0 - w) - hz) + z * (z * pc));
     // quadrant
-    const double s0 = (q & 1) ? cs : sn;
-    const double c0 = (q & 1) ? sn : cs;
+    const real s0 = (q & 1) ? cs : sn;
+    const real c0 = (q & 1) ? sn : cs;
     s_out = (q & 2) ? -s0 : s0;
     c_out = ((q + 1) & 2) ? -c0 : c0;
 }
@@ -137,21 +172,21 @@ GR_DEV void sincos_fast(double x, double& s_out, double& c_out)
 // one step: |δ| <= 1/16 is the common case (99.4 % of steps) and needs two short Taylor
 // polynomials (truncation < 1e-17) and four FMAs, no range reduction and no quadrant logic.
 // Larger δ takes the full evaluation.
-GR_DEV void sincos_rot(double th0, double s0, double c0, double th, double& s_out, double& c_out)
+GR_DEV void sincos_rot(real th0, real s0, real c0, real th, real& s_out, real& c_out)
 {
-    const double d = th - th0;
-    if (::fabs(d) <= 0.0625) {
-        const double z = d * d;
-        double ps = __builtin_fma(z, 2.7557319223985893e-06, -1.9841269841269841e-04);
-        ps = __builtin_fma(z, ps, 8.3333333333333333e-03);
-        ps = __builtin_fma(z, ps, -1.6666666666666666e-01);
-        const double sd = __builtin_fma(d * z, ps, d);                    // sin δ
-        double pc = __builtin_fma(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
-        pc = __builtin_fma(z, pc, 4.1666666666666664e-02);
-        pc = __builtin_fma(z, pc, -0.5);
-        const double cm1 = z * pc;                                        // cos δ - 1
-        s_out = __builtin_fma(c0, sd, __builtin_fma(s0, cm1, s0));
-        c_out = __builtin_fma(-s0, sd, __builtin_fma(c0, cm1, c0));
+    const real d = th - th0;
+    if (GR_FABS(d) <= 0.0625) {
+        const real z = d * d;
+        real ps = GR_FMA(z, 2.7557319223985893e-06, -1.9841269841269841e-04);
+        ps = GR_FMA(z, ps, 8.3333333333333333e-03);
+        ps = GR_FMA(z, ps, -1.6666666666666666e-01);
+        const real sd = GR_FMA(d * z, ps, d);                    // sin δ
+        real pc = GR_FMA(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
+        pc = GR_FMA(z, pc, 4.1666666666666664e-02);
+        pc = GR_FMA(z, pc, -0.5);
+        const real cm1 = z * pc;                                        // cos δ - 1
+        s_out = GR_FMA(c0, sd, GR_FMA(s0, cm1, s0));
+        c_out = GR_FMA(-s0, sd, GR_FMA(c0, cm1, c0));
     } else {
         sincos_fast(th, s_out, c_out);
     }
@@ -162,26 +197,26 @@ GR_DEV void sincos_rot(double th0, double s0, double c0, double th, double& s_ou
 // (the reference differentiates every metric this way, auto-diff.jl:206-211).
 // ---------------------------------------------------------------------------------------
 struct Dual2 {
-    double v, a, b;
+    real v, a, b;
 };
-GR_DEV Dual2 dconst(double x) { return { x, 0.0, 0.0 }; }
+GR_DEV Dual2 dconst(real x) { return { x, 0.0, 0.0 }; }
 GR_DEV Dual2 operator+(Dual2 x, Dual2 y) { return { x.v + y.v, x.a + y.a, x.b + y.b }; }
 GR_DEV Dual2 operator-(Dual2 x, Dual2 y) { return { x.v - y.v, x.a - y.a, x.b - y.b }; }
 GR_DEV Dual2 operator-(Dual2 x) { return { -x.v, -x.a, -x.b }; }
-GR_DEV Dual2 operator+(Dual2 x, double y) { return { x.v + y, x.a, x.b }; }
-GR_DEV Dual2 operator+(double y, Dual2 x) { return { x.v + y, x.a, x.b }; }
-GR_DEV Dual2 operator-(Dual2 x, double y) { return { x.v - y, x.a, x.b }; }
-GR_DEV Dual2 operator-(double y, Dual2 x) { return { y - x.v, -x.a, -x.b }; }
-GR_DEV Dual2 operator*(double s, Dual2 x) { return { s * x.v, s * x.a, s * x.b }; }
-GR_DEV Dual2 operator*(Dual2 x, double s) { return { s * x.v, s * x.a, s * x.b }; }
+GR_DEV Dual2 operator+(Dual2 x, real y) { return { x.v + y, x.a, x.b }; }
+GR_DEV Dual2 operator+(real y, Dual2 x) { return { x.v + y, x.a, x.b }; }
+GR_DEV Dual2 operator-(Dual2 x, real y) { return { x.v - y, x.a, x.b }; }
+GR_DEV Dual2 operator-(real y, Dual2 x) { return { y - x.v, -x.a, -x.b }; }
+GR_DEV Dual2 operator*(real s, Dual2 x) { return { s * x.v, s * x.a, s * x.b }; }
+GR_DEV Dual2 operator*(Dual2 x, real s) { return { s * x.v, s * x.a, s * x.b }; }
 GR_DEV Dual2 operator*(Dual2 x, Dual2 y)
 {
-    return { x.v * y.v, __builtin_fma(x.a, y.v, x.v * y.a), __builtin_fma(x.b, y.v, x.v * y.b) };
+    return { x.v * y.v, GR_FMA(x.a, y.v, x.v * y.a), GR_FMA(x.b, y.v, x.v * y.b) };
 }
 GR_DEV Dual2 dinv(Dual2 y)
 {
-    const double i = rcp_full(y.v);
-    const double m = -i * i;
+    const real i = rcp_full(y.v);
+    const real m = -i * i;
     return { i, m * y.a, m * y.b };
 }
 GR_DEV Dual2 operator/(Dual2 x, Dual2 y) { return x * dinv(y); }
@@ -191,13 +226,13 @@ GR_DEV Dual2 operator/(Dual2 x, Dual2 y) { return x * dinv(y); }
 //   g[5], gr[5] = ∂_r g, gt[5] = ∂_θ g, gi[5] = inverse components (tt, rr, θθ, ϕϕ, tϕ)
 // given r and (sinθ, cosθ).
 // ---------------------------------------------------------------------------------------
-GR_DEV void inverse_generic(const double g[5], double gi[5])
+GR_DEV void inverse_generic(const real g[5], real gi[5])
 {
     // inverse_metric_components, auto-diff.jl:59-76, with a single reciprocal
-    const double D = __builtin_fma(g[0], g[3], -g[4] * g[4]);
-    const double rt = g[1] * g[2];
-    const double P = rcp_full(D * rt);
-    const double iD = P * rt;
+    const real D = GR_FMA(g[0], g[3], -g[4] * g[4]);
+    const real rt = g[1] * g[2];
+    const real P = rcp_full(D * rt);
+    const real iD = P * rt;
     gi[0] = g[3] * iD;
     gi[1] = P * D * g[2];
     gi[2] = P * D * g[1];
@@ -206,17 +241,17 @@ GR_DEV void inverse_generic(const double g[5], double gi[5])
 }
 
 struct KerrMetric {
-    double M, a;
+    real M, a;
     GR_DEV void load(const double* p) { M = p[0]; a = p[1]; }
 
     // values only (constraint, redshift)
-    GR_DEV void comps(double r, double s, double c, double g[5]) const
+    GR_DEV void comps(real r, real s, real c, real g[5]) const
     {
-        const double r2 = r * r, a2 = a * a, s2 = s * s;
-        const double Sig = __builtin_fma(a2, c * c, r2);
-        const double Del = __builtin_fma(-2.0 * M, r, r2) + a2;
-        const double iSig = rcp_full(Sig);
-        const double w = 2.0 * M * r * iSig;
+        const real r2 = r * r, a2 = a * a, s2 = s * s;
+        const real Sig = GR_FMA(a2, c * c, r2);
+        const real Del = GR_FMA(-2.0 * M, r, r2) + a2;
+        const real iSig = rcp_full(Sig);
+        const real w = 2.0 * M * r * iSig;
         g[0] = w - 1.0;
         g[1] = Sig * rcp_full(Del);
         g[2] = Sig;
@@ -225,30 +260,30 @@ struct KerrMetric {
     }
 
     // hand-differentiated kerr-metric.jl:11-28; one reciprocal for everything
-    GR_DEV void eval(double r, double s, double c, double g[5], double gr[5], double gt[5], double gi[5]) const
+    GR_DEV void eval(real r, real s, real c, real g[5], real gr[5], real gt[5], real gi[5]) const
     {
-        const double r2 = r * r, a2 = a * a, s2 = s * s, sc = s * c;
-        const double Sig = __builtin_fma(a2, c * c, r2);
-        const double Del = __builtin_fma(-2.0 * M, r, r2) + a2;
-        const double P = rcp_full(Sig * Del * s2);
-        const double Ds2 = Del * s2;
-        const double iSig = P * Ds2;           // 1/Σ
-        const double iDel = P * Sig * s2;      // 1/Δ
-        const double iDs = P * Sig;            // 1/(Δ sin²θ)
-        const double tM = 2.0 * M;
-        const double w = tM * r * iSig;        // 2Mr/Σ
-        const double iSig2 = iSig * iSig;
-        const double w_r = tM * (Sig - 2.0 * r2) * iSig2;
-        const double Sig_t = -2.0 * a2 * sc;
-        const double w_t = -w * Sig_t * iSig;
-        const double as2 = a * s2;
-        const double tr = 2.0 * r;
+        const real r2 = r * r, a2 = a * a, s2 = s * s, sc = s * c;
+        const real Sig = GR_FMA(a2, c * c, r2);
+        const real Del = GR_FMA(-2.0 * M, r, r2) + a2;
+        const real P = rcp_full(Sig * Del * s2);
+        const real Ds2 = Del * s2;
+        const real iSig = P * Ds2;           // 1/Σ
+        const real iDel = P * Sig * s2;      // 1/Δ
+        const real iDs = P * Sig;            // 1/(Δ sin²θ)
+        const real tM = 2.0 * M;
+        const real w = tM * r * iSig;        // 2Mr/Σ
+        const real iSig2 = iSig * iSig;
+        const real w_r = tM * (Sig - 2.0 * r2) * iSig2;
+        const real Sig_t = -2.0 * a2 * sc;
+        const real w_t = -w * Sig_t * iSig;
+        const real as2 = a * s2;
+        const real tr = 2.0 * r;
 
         g[0] = w - 1.0;
         g[1] = Sig * iDel;
         g[2] = Sig;
         g[4] = -as2 * w;
-        const double B = r2 + a2 - a * g[4];
+        const real B = r2 + a2 - a * g[4];
         g[3] = s2 * B;
 
         gr[0] = w_r;
@@ -273,14 +308,14 @@ struct KerrMetric {
 };
 
 struct JohannsenMetric {
-    double M, a, a13, a22, a52, e3;
+    real M, a, a13, a22, a52, e3;
     GR_DEV void load(const double* p) { M = p[0]; a = p[1]; a13 = p[2]; a22 = p[3]; a52 = p[4]; e3 = p[5]; }
 
     // johannsen-ad.jl:12-34 on an arbitrary number type
     template <class T>
     GR_DEV void components(T r, T s, T c, T g[5]) const
     {
-        const double a2 = a * a;
+        const real a2 = a * a;
         T Mr = M * inv_(r);
         T Mr2 = Mr * Mr;
         T A1 = 1.0 + a13 * (Mr2 * Mr);
@@ -302,12 +337,12 @@ struct JohannsenMetric {
         g[3] = pp * idenom;
         g[4] = tp * idenom;
     }
-    static GR_DEV double inv_(double x) { return rcp_full(x); }
+    static GR_DEV real inv_(real x) { return rcp_full(x); }
     static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
 
-    GR_DEV void comps(double r, double s, double c, double g[5]) const { components<double>(r, s, c, g); }
+    GR_DEV void comps(real r, real s, real c, real g[5]) const { components<real>(r, s, c, g); }
 
-    GR_DEV void eval(double r, double s, double c, double g[5], double gr[5], double gt[5], double gi[5]) const
+    GR_DEV void eval(real r, real s, real c, real g[5], real gr[5], real gt[5], real gi[5]) const
     {
         Dual2 gd[5];
         // seeds: r = (r;1,0), sinθ = (s;0,c), cosθ = (c;0,-s)
@@ -326,39 +361,39 @@ struct JohannsenMetric {
 // point given by r and (sinθ, cosθ).  The factors 2 and -½ of the reference's form cancel:
 //   a^t = -(g^tt T_t + g^tϕ T_ϕ), a^r = -g^rr (ġ_rr v^r - ½ D_r), ... with T_t = ġ_tt v^t + ġ_tϕ v^ϕ.
 template <class Metric>
-GR_DEV void geodesic_rhs_sc(const Metric& m, double r, double s, double c, double vt, double vr, double vh, double vp,
-                            double& at, double& ar, double& ah, double& ap)
+GR_DEV void geodesic_rhs_sc(const Metric& m, real r, real s, real c, real vt, real vr, real vh, real vp,
+                            real& at, real& ar, real& ah, real& ap)
 {
-    double g[5], j1[5], j2[5], gi[5];
+    real g[5], j1[5], j2[5], gi[5];
     m.eval(r, s, c, g, j1, j2, gi);
-    double gd[5];
+    real gd[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) gd[k] = __builtin_fma(j1[k], vr, j2[k] * vh);
-    const double vt2 = vt * vt, vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp, vtp = 2.0 * vt * vp;
-    const double Dr = j1[0] * vt2 + j1[1] * vr2 + j1[2] * vh2 + j1[3] * vp2 + j1[4] * vtp;
-    const double Dh = j2[0] * vt2 + j2[1] * vr2 + j2[2] * vh2 + j2[3] * vp2 + j2[4] * vtp;
-    const double Tt = __builtin_fma(gd[0], vt, gd[4] * vp);
-    const double Tp = __builtin_fma(gd[4], vt, gd[3] * vp);
-    const double Tr = __builtin_fma(gd[1], vr, -0.5 * Dr);
-    const double Th = __builtin_fma(gd[2], vh, -0.5 * Dh);
-    at = -__builtin_fma(gi[0], Tt, gi[4] * Tp);
+    for (int k = 0; k < 5; ++k) gd[k] = GR_FMA(j1[k], vr, j2[k] * vh);
+    const real vt2 = vt * vt, vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp, vtp = 2.0 * vt * vp;
+    const real Dr = j1[0] * vt2 + j1[1] * vr2 + j1[2] * vh2 + j1[3] * vp2 + j1[4] * vtp;
+    const real Dh = j2[0] * vt2 + j2[1] * vr2 + j2[2] * vh2 + j2[3] * vp2 + j2[4] * vtp;
+    const real Tt = GR_FMA(gd[0], vt, gd[4] * vp);
+    const real Tp = GR_FMA(gd[4], vt, gd[3] * vp);
+    const real Tr = GR_FMA(gd[1], vr, -0.5 * Dr);
+    const real Th = GR_FMA(gd[2], vh, -0.5 * Dh);
+    at = -GR_FMA(gi[0], Tt, gi[4] * Tp);
     ar = -(gi[1] * Tr);
     ah = -(gi[2] * Th);
-    ap = -__builtin_fma(gi[4], Tt, gi[3] * Tp);
+    ap = -GR_FMA(gi[4], Tt, gi[3] * Tp);
 }
 
 template <class Metric>
-GR_DEV void geodesic_rhs(const Metric& m, double r, double th, double vt, double vr, double vh, double vp,
-                         double& at, double& ar, double& ah, double& ap, double& s, double& c)
+GR_DEV void geodesic_rhs(const Metric& m, real r, real th, real vt, real vr, real vh, real vp,
+                         real& at, real& ar, real& ah, real& ap, real& s, real& c)
 {
     sincos_fast(th, s, c);
     geodesic_rhs_sc(m, r, s, c, vt, vr, vh, vp, at, ar, ah, ap);
 }
 
 // constrain_time, auto-diff.jl:161-179
-GR_DEV double constrain_time(const double g[5], double vr, double vh, double vp, double mu)
+GR_DEV real constrain_time(const real g[5], real vr, real vh, real vp, real mu)
 {
-    const double disc = -g[0] * g[1] * vr * vr - g[0] * g[2] * vh * vh - g[0] * mu * mu
+    const real disc = -g[0] * g[1] * vr * vr - g[0] * g[2] * vh * vh - g[0] * mu * mu
                         - (g[0] * g[3] - g[4] * g[4]) * vp * vp;
     return -(g[4] * vp + sqrt_fast(disc)) * rcp_full(g[0]);
 }
@@ -367,7 +402,7 @@ GR_DEV double constrain_time(const double g[5], double vr, double vh, double vp,
 // Tsit5 tableau, dense output
 // ---------------------------------------------------------------------------------------
 struct Ts {
-    static constexpr double A[7][6] = {
+    static constexpr real A[7][6] = {
         { 0, 0, 0, 0, 0, 0 },
         { 0.161, 0, 0, 0, 0, 0 },
         { -0.008480655492356989, 0.335480655492357, 0, 0, 0, 0 },
@@ -376,11 +411,11 @@ struct Ts {
         { 5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0 },
         { 0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774 },
     };
-    static constexpr double BT[7] = { -0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+    static constexpr real BT[7] = { -0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
                                       -0.1447110071732629,     0.5823571654525552,     -0.45808210592918697,
                                       0.015151515151515152 };
     // b_i(Θ) = Σ_m R[i][m] Θ^(m+1)
-    static constexpr double R[7][4] = {
+    static constexpr real R[7][4] = {
         { 1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216 },
         { 0.0, 0.13169999999999998, -0.2234, 0.1017 },
         { 0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253 },
@@ -398,51 +433,51 @@ struct Ts {
 // stage ACCELERATIONS A_i are stored (28 doubles instead of 56); results differ from the
 // first-order bookkeeping by rounding only.
 struct TsX {
-    double C[7];       // c_s = Σ_j a_sj
-    double AX[7][7];   // ā_si = Σ_{i<j<s} a_sj a_ji
-    double SBT;        // Σ_j b̃_j (zero up to rounding of the published coefficients)
-    double BTX[7];     // Σ_{j>i} b̃_j a_ji
-    double SR[4];      // Σ_j R[j][m]  (1, ~0, ~0, ~0)
-    double RX[7][4];   // Σ_{j>i} R[j][m] a_ji
-    double K2;         // max_j Σ_i |Σ_m RX[i][m] Θ_j^(m+1)| over the sample points Θ_j = j/7
+    real C[7];       // c_s = Σ_j a_sj
+    real AX[7][7];   // ā_si = Σ_{i<j<s} a_sj a_ji
+    real SBT;        // Σ_j b̃_j (zero up to rounding of the published coefficients)
+    real BTX[7];     // Σ_{j>i} b̃_j a_ji
+    real SR[4];      // Σ_j R[j][m]  (1, ~0, ~0, ~0)
+    real RX[7][4];   // Σ_{j>i} R[j][m] a_ji
+    real K2;         // max_j Σ_i |Σ_m RX[i][m] Θ_j^(m+1)| over the sample points Θ_j = j/7
 };
 constexpr TsX make_tsx()
 {
     TsX t{};
     for (int s = 0; s < 7; ++s) {
-        double c = 0.0;
+        real c = 0.0;
         for (int j = 0; j < s && j < 6; ++j) c += Ts::A[s][j];
         t.C[s] = c;
         for (int i = 0; i < 7; ++i) {
-            double a = 0.0;
+            real a = 0.0;
             for (int j = i + 1; j < s && j < 6; ++j) a += Ts::A[s][j] * Ts::A[j][i];
             t.AX[s][i] = a;
         }
     }
-    double sb = 0.0;
+    real sb = 0.0;
     for (int j = 0; j < 7; ++j) sb += Ts::BT[j];
     t.SBT = sb;
     for (int i = 0; i < 7; ++i) {
-        double a = 0.0;
+        real a = 0.0;
         for (int j = i + 1; j < 7; ++j) a += Ts::BT[j] * (i < 6 ? Ts::A[j][i] : 0.0);
         t.BTX[i] = a;
     }
     for (int m = 0; m < 4; ++m) {
-        double sr = 0.0;
+        real sr = 0.0;
         for (int j = 0; j < 7; ++j) sr += Ts::R[j][m];
         t.SR[m] = sr;
         for (int i = 0; i < 7; ++i) {
-            double a = 0.0;
+            real a = 0.0;
             for (int j = i + 1; j < 7; ++j) a += Ts::R[j][m] * (i < 6 ? Ts::A[j][i] : 0.0);
             t.RX[i][m] = a;
         }
     }
-    double k2 = 0.0;
+    real k2 = 0.0;
     for (int jj = 1; jj <= 6; ++jj) {
-        const double th = (double)jj / 7.0;
-        double sum = 0.0;
+        const real th = (real)jj / 7.0;
+        real sum = 0.0;
         for (int i = 0; i < 7; ++i) {
-            const double b = th * (t.RX[i][0] + th * (t.RX[i][1] + th * (t.RX[i][2] + th * t.RX[i][3])));
+            const real b = th * (t.RX[i][0] + th * (t.RX[i][1] + th * (t.RX[i][2] + th * t.RX[i][3])));
             sum += b < 0.0 ? -b : b;
         }
         if (sum > k2) k2 = sum;
@@ -455,15 +490,15 @@ struct TsD {
 };
 
 // PI controller constants (App. A.3)
-constexpr double PI_BETA1 = 7.0 / 50.0;
-constexpr double PI_BETA2 = 2.0 / 25.0;
-constexpr double PI_GAMMA = 0.9;
-constexpr double PI_QMIN = 0.2;
-constexpr double PI_QMAX = 10.0;
-constexpr double LOG2_QOLDINIT = -13.287712379549449;  // log2(1e-4)
+constexpr real PI_BETA1 = 7.0 / 50.0;
+constexpr real PI_BETA2 = 2.0 / 25.0;
+constexpr real PI_GAMMA = 0.9;
+constexpr real PI_QMIN = 0.2;
+constexpr real PI_QMAX = 10.0;
+constexpr real LOG2_QOLDINIT = -13.287712379549449;  // log2(1e-4)
 // bounds used to skip the event sampling (see Ray::sample_event); 1e-6 of slack for rounding
-constexpr double DENSE_K1 = 1.000001;
-constexpr double DENSE_K2 = TsD::X.K2 * 1.000001;
+constexpr real DENSE_K1 = 1.000001;
+constexpr real DENSE_K2 = TsD::X.K2 * 1.000001;
 
 // ---------------------------------------------------------------------------------------
 // kernel parameter block (uniform, lives in the kernarg segment / SGPRs)
@@ -553,24 +588,24 @@ GR_DEV int64_t range_map(const gr_range& rg, int64_t j)
     return rg.first + b * rg.stride_blocks * rg.block + (j - b * rg.block);
 }
 
-GR_DEV double range_at(double a, double b, int64_t n, int64_t k)
+GR_DEV real range_at(real a, real b, int64_t n, int64_t k)
 {
     if (n <= 1) return a;
-    const double t = (double)k / (double)(n - 1);
+    const real t = (real)k / (real)(n - 1);
     return (1.0 - t) * a + t * b;
 }
 
 // ---------------------------------------------------------------------------------------
 // point functions on a finished ray
 // ---------------------------------------------------------------------------------------
-GR_DEV double kerr_plunge_Le(double M, double rms, double a)
+GR_DEV real kerr_plunge_Le(real M, real rms, real a)
 {
     // Lₑ, redshift.jl:93
-    return ::sqrt(M) * (rms * rms - 2.0 * a * ::sqrt(M * rms) + a * a)
-           / (rms * ::sqrt(rms) - 2.0 * M * ::sqrt(rms) + a * ::sqrt(M));
+    return GR_SQRT(M) * (rms * rms - 2.0 * a * GR_SQRT(M * rms) + a * a)
+           / (rms * GR_SQRT(rms) - 2.0 * M * GR_SQRT(rms) + a * GR_SQRT(M));
 }
 
-GR_DEV double nan_linear_interp(const double* t, const double* y, int64_t n, double x)
+GR_DEV real nan_linear_interp(const double* t, const double* y, int64_t n, real x)
 {
     // NaNLinearInterpolator, interpolations.jl:7-29
     int64_t lo = 0, hi = n;
@@ -580,9 +615,9 @@ GR_DEV double nan_linear_interp(const double* t, const double* y, int64_t n, dou
     }
     int64_t idx = lo < 1 ? 1 : lo;
     if (idx > n - 1) idx = n - 1;
-    const double x1 = t[idx - 1], x2 = t[idx], y1 = y[idx - 1], y2 = y[idx];
-    const double w = (x - x1) / (x2 - x1);
-    const double v = (1.0 - w) * y1 + w * y2;
+    const real x1 = t[idx - 1], x2 = t[idx], y1 = y[idx - 1], y2 = y[idx];
+    const real w = (x - x1) / (x2 - x1);
+    const real v = (1.0 - w) * y1 + w * y2;
     if (!(v == v)) {
         if (w < 0.5) return (y1 == y1) ? y1 : 0.0;
         return (y2 == y2) ? y2 : 0.0;
@@ -592,45 +627,45 @@ GR_DEV double nan_linear_interp(const double* t, const double* y, int64_t n, dou
 
 // CircularOrbits.fourvelocity(m, ρ) at θ = π/2, circular-orbits.jl:11-37,58-61,114-121
 template <class Metric>
-GR_DEV void circular_fourvelocity(const Metric& m, double rho, double& vt, double& vp)
+GR_DEV void circular_fourvelocity(const Metric& m, real rho, real& vt, real& vp)
 {
-    double g[5], j1[5], j2[5], gi[5];
+    real g[5], j1[5], j2[5], gi[5];
     m.eval(rho, 1.0, 0.0, g, j1, j2, gi);
-    const double Dl = sqrt_fast(j1[4] * j1[4] - j1[0] * j1[3]);
-    const double Om = -(j1[4] - Dl) * rcp_full(j1[3]);
-    const double A = -(Om * gi[0] - gi[4]);
-    const double B = (Om * gi[4] - gi[3]);
-    const double den = B * B * gi[0] + 2.0 * A * B * gi[4] + A * A * gi[3];
-    const double d = -(double)sgn(den) * sqrt_fast(rcp_full(::fabs(den)));
-    const double ut = B * d, up = A * d;
+    const real Dl = sqrt_fast(j1[4] * j1[4] - j1[0] * j1[3]);
+    const real Om = -(j1[4] - Dl) * rcp_full(j1[3]);
+    const real A = -(Om * gi[0] - gi[4]);
+    const real B = (Om * gi[4] - gi[3]);
+    const real den = B * B * gi[0] + 2.0 * A * B * gi[4] + A * A * gi[3];
+    const real d = -(real)sgn(den) * sqrt_fast(rcp_full(GR_FABS(den)));
+    const real ut = B * d, up = A * d;
     vt = gi[0] * ut + gi[4] * up;
     vp = gi[4] * ut + gi[3] * up;
 }
 
 // redshift_function(m, gp) / interpolate_redshift closure; redshift.jl:192-220,246-276
 template <class Metric>
-GR_DEV double redshift_pf(const Metric& m, const Params& pp, const Cold& p, const double x0[4], const double v0[4],
-                          const double x[4], const double v[4])
+GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const real x0[4], const real v0[4],
+                          const real x[4], const real v[4])
 {
-    double s, c;
+    real s, c;
     sincos_fast(x[2], s, c);
-    const double rho = x[1] * ::fabs(s);
-    double dt_, dr_, dp_;
+    const real rho = x[1] * GR_FABS(s);
+    real dt_, dr_, dp_;
     const bool kerr_analytic = (pp.cfg.metric_id == GR_METRIC_KERR) && (p.pf.n_plunge == 0);
-    const double isco = p.pf.r_isco;
+    const real isco = p.pf.r_isco;
     if (rho < isco) {
         if (kerr_analytic) {
-            const double M = pp.cfg.params[0], a = pp.cfg.params[1];
-            const double Le = kerr_plunge_Le(M, isco, a);
-            const double H = (2.0 * M * rho - a * Le) / (rho * rho - 2.0 * M * rho + a * a);
-            const double ge = ::sqrt(1.0 - (2.0 * M) / (3.0 * isco));
-            const double q = isco / rho - 1.0;
-            const double ur = -::sqrt((2.0 * M) / (3.0 * isco)) * q * ::sqrt(q);
+            const real M = pp.cfg.params[0], a = pp.cfg.params[1];
+            const real Le = kerr_plunge_Le(M, isco, a);
+            const real H = (2.0 * M * rho - a * Le) / (rho * rho - 2.0 * M * rho + a * a);
+            const real ge = GR_SQRT(1.0 - (2.0 * M) / (3.0 * isco));
+            const real q = isco / rho - 1.0;
+            const real ur = -GR_SQRT((2.0 * M) / (3.0 * isco)) * q * GR_SQRT(q);
             dt_ = ge * (1.0 + 2.0 * M * (1.0 + H) / rho);
             dr_ = -ur;
             dp_ = ge / (rho * rho) * (Le + a * H);
         } else {
-            double rb = rho;
+            real rb = rho;
             const int64_t n = p.pf.n_plunge;
             if (rb < p.pf.plunge_r[0]) rb = p.pf.plunge_r[0];
             if (rb > p.pf.plunge_r[n - 1]) rb = p.pf.plunge_r[n - 1];
@@ -643,13 +678,13 @@ GR_DEV double redshift_pf(const Metric& m, const Params& pp, const Cold& p, cons
         dr_ = 0.0;
     }
     // _redshift_dotproduct: E_obs / E_disc with v_obs = (1,0,0,0)
-    double g[5];
+    real g[5];
     m.comps(x[1], s, c, g);
-    const double E_disc = (g[0] * v[0] + g[4] * v[3]) * dt_ + g[1] * v[1] * dr_ + (g[4] * v[0] + g[3] * v[3]) * dp_;
-    double s0, c0, g0[5];
+    const real E_disc = (g[0] * v[0] + g[4] * v[3]) * dt_ + g[1] * v[1] * dr_ + (g[4] * v[0] + g[3] * v[3]) * dp_;
+    real s0, c0, g0[5];
     sincos_fast(x0[2], s0, c0);
     m.comps(x0[1], s0, c0, g0);
-    const double E_obs = g0[0] * v0[0] + g0[4] * v0[3];
+    const real E_obs = g0[0] * v0[0] + g0[4] * v0[3];
     return E_obs * rcp_full(E_disc);
 }
 
@@ -660,31 +695,31 @@ enum : int32_t { RAY_EVENT = 0x100 };   // bit in Ray::flags while a disc event 
 
 template <class Metric, int DISC>
 struct Ray {
-    double x[4];        // (t, r, θ, ϕ) at the start of the current step
-    double v[4];        // (v^t, v^r, v^θ, v^ϕ)
-    double A[7][4];     // stage accelerations; A[0] is FSAL
-    double t, dt, h;    // affine time, proposed step, last used step
-    double cprev;       // disc condition at x
-    double sth, cth;    // sin θ, cos θ at x (base of the stage rotations)
+    real x[4];        // (t, r, θ, ϕ) at the start of the current step
+    real v[4];        // (v^t, v^r, v^θ, v^ϕ)
+    real A[7][4];     // stage accelerations; A[0] is FSAL
+    real t, dt, h;    // affine time, proposed step, last used step
+    real cprev;       // disc condition at x
+    real sth, cth;    // sin θ, cos θ at x (base of the stage rotations)
     float lq_old;       // log2(qold)
     int32_t ev_top;     // upper bracket j of Θ = j/7 when an event is pending
     int64_t j;          // local (swizzled) ray index
     int32_t status, flags;
     int32_t nacc, nrej;
 #ifdef GR_HOST_HARNESS
-    double dbg_e2;
+    real dbg_e2;
 #endif
 
     // distance_to_disc(::ThinDisc), thin-disc.jl:20-26
-    static GR_DEV double disc_cond(const Params& p, double r, double s, double c)
+    static GR_DEV real disc_cond(const Params& p, real r, real s, real c)
     {
-        const double rho = r * ::fabs(s);
+        const real rho = r * GR_FABS(s);
         if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
-        return r * ::fabs(c) - p.cfg.gtol * ::fabs(r);
+        return r * GR_FABS(c) - p.cfg.gtol * GR_FABS(r);
     }
 
     // DiscreteCallbacks in CallbackSet order: domain_upper_hemisphere, then the chart
-    static GR_DEV bool discrete_cb(const Params& p, double r, double c, int32_t& st)
+    static GR_DEV bool discrete_cb(const Params& p, real r, real c, int32_t& st)
     {
         bool term = false;
         if (p.cfg.upper_hemisphere && r * c < p.cfg.hemi_delta) { st = GR_STATUS_OUT_OF_DOMAIN; term = true; }
@@ -696,7 +731,7 @@ struct Ray {
     }
 
     // initial position / unconstrained velocity of local ray jl
-    static GR_DEV void initial_conditions(const Params& pp, int64_t jl, double x0[4], double v0[4])
+    static GR_DEV void initial_conditions(const Params& pp, int64_t jl, real x0[4], real v0[4])
     {
         const Cold& p = cold_of(pp);
         if (p.src_mode == 0) {
@@ -704,13 +739,13 @@ struct Ray {
             const int64_t i = range_map(p.range, jl);
             const int64_t H = p.plane.height;
             const int64_t xi = i / H, yi = i - xi * H;
-            const double alpha = range_at(p.plane.alpha0, p.plane.alpha1, p.plane.width, xi) + p.plane.offset;
-            const double beta = range_at(p.plane.beta0, p.plane.beta1, H, yi) + p.plane.offset;
-            const double ro = p.plane.x_obs[1];
-            const double iro = rcp_full(ro);
-            const double b = beta * iro, a = alpha * iro;
-            const double pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
-            const double pb[4] = { 1.0, pr, b * pr, a * pr };
+            const real alpha = range_at(p.plane.alpha0, p.plane.alpha1, p.plane.width, xi) + p.plane.offset;
+            const real beta = range_at(p.plane.beta0, p.plane.beta1, H, yi) + p.plane.offset;
+            const real ro = p.plane.x_obs[1];
+            const real iro = rcp_full(ro);
+            const real b = beta * iro, a = alpha * iro;
+            const real pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
+            const real pb[4] = { 1.0, pr, b * pr, a * pr };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 x0[q] = p.plane.x_obs[q];
@@ -719,11 +754,11 @@ struct Ray {
             }
         } else if (p.src_mode == 2) {
             // promote_velfunc: map_impact_parameters(m, x, αs[i], βs[i]) -- no pixel offset
-            const double ro = p.plane.x_obs[1];
-            const double iro = rcp_full(ro);
-            const double b = p.beta[jl] * iro, a = p.alpha[jl] * iro;
-            const double pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
-            const double pb[4] = { 1.0, pr, b * pr, a * pr };
+            const real ro = p.plane.x_obs[1];
+            const real iro = rcp_full(ro);
+            const real b = p.beta[jl] * iro, a = p.alpha[jl] * iro;
+            const real pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
+            const real pb[4] = { 1.0, pr, b * pr, a * pr };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 x0[q] = p.plane.x_obs[q];
@@ -739,16 +774,16 @@ struct Ray {
     }
 
     // constrain_all (constraints.jl:14-15): v^t from the null/mass-shell condition
-    static GR_DEV void constrained_u0(const Metric& m, const Params& p, int64_t jl, double x0[4], double v0[4])
+    static GR_DEV void constrained_u0(const Metric& m, const Params& p, int64_t jl, real x0[4], real v0[4])
     {
         initial_conditions(p, jl, x0, v0);
-        double s, c, g[5];
+        real s, c, g[5];
         sincos_fast(x0[2], s, c);
         m.comps(x0[1], s, c, g);
         v0[0] = constrain_time(g, v0[1], v0[2], v0[3], p.cfg.mu);
     }
 
-    static GR_DEV void accel(const Metric& m, double r, double th, const double vv[4], double a[4], double& s, double& c)
+    static GR_DEV void accel(const Metric& m, real r, real th, const real vv[4], real a[4], real& s, real& c)
     {
         geodesic_rhs(m, r, th, vv[0], vv[1], vv[2], vv[3], a[0], a[1], a[2], a[3], s, c);
     }
@@ -763,60 +798,60 @@ struct Ray {
         t = p.cfg.lambda0;
         h = 0.0;
         lq_old = (float)LOG2_QOLDINIT;
-        double s, c;
+        real s, c;
         accel(m, x[1], x[2], v, A[0], s, c);
         sth = s; cth = c;
         cprev = DISC ? disc_cond(p, x[1], s, c) : 1.0;
 
-        const double abstol = p.cfg.abstol, reltol = p.cfg.reltol;
-        const double dtmax = ::fabs(p.cfg.lambda1 - p.cfg.lambda0);
-        double iskx[4], iskv[4], d0s = 0.0, d1s = 0.0;
+        const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
+        const real dtmax = GR_FABS((real)(p.cfg.lambda1 - p.cfg.lambda0));
+        real iskx[4], iskv[4], d0s = 0.0, d1s = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            iskx[i] = rcp_full(abstol + ::fabs(x[i]) * reltol);
-            iskv[i] = rcp_full(abstol + ::fabs(v[i]) * reltol);
-            const double a0 = x[i] * iskx[i], b0 = v[i] * iskv[i];
-            const double a1 = v[i] * iskx[i], b1 = A[0][i] * iskv[i];
-            d0s = __builtin_fma(a0, a0, d0s);
-            d0s = __builtin_fma(b0, b0, d0s);
-            d1s = __builtin_fma(a1, a1, d1s);
-            d1s = __builtin_fma(b1, b1, d1s);
+            iskx[i] = rcp_full(abstol + GR_FABS(x[i]) * reltol);
+            iskv[i] = rcp_full(abstol + GR_FABS(v[i]) * reltol);
+            const real a0 = x[i] * iskx[i], b0 = v[i] * iskv[i];
+            const real a1 = v[i] * iskx[i], b1 = A[0][i] * iskv[i];
+            d0s = GR_FMA(a0, a0, d0s);
+            d0s = GR_FMA(b0, b0, d0s);
+            d1s = GR_FMA(a1, a1, d1s);
+            d1s = GR_FMA(b1, b1, d1s);
         }
-        const double d0 = sqrt_fast(d0s * 0.125), d1 = sqrt_fast(d1s * 0.125);
-        double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 * rcp_full(d1));
-        dt0 = ::fmin(dt0, dtmax);
-        if (dt0 < 10.0 * 2.220446049250313e-16) {
+        const real d0 = sqrt_fast(d0s * 0.125), d1 = sqrt_fast(d1s * 0.125);
+        real dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 * rcp_full(d1));
+        dt0 = GR_FMIN(dt0, dtmax);
+        if (dt0 < 10.0 * GR_EPS) {
             dt = 1e-6;
         } else {
-            double v1[4], a1[4];
+            real v1[4], a1[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v1[i] = __builtin_fma(dt0, A[0][i], v[i]);
-            accel(m, __builtin_fma(dt0, v[1], x[1]), __builtin_fma(dt0, v[2], x[2]), v1, a1, s, c);
-            double d2s = 0.0;
+            for (int i = 0; i < 4; ++i) v1[i] = GR_FMA(dt0, A[0][i], v[i]);
+            accel(m, GR_FMA(dt0, v[1], x[1]), GR_FMA(dt0, v[2], x[2]), v1, a1, s, c);
+            real d2s = 0.0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const double ex = (v1[i] - v[i]) * iskx[i];
-                const double ev = (a1[i] - A[0][i]) * iskv[i];
-                d2s = __builtin_fma(ex, ex, d2s);
-                d2s = __builtin_fma(ev, ev, d2s);
+                const real ex = (v1[i] - v[i]) * iskx[i];
+                const real ev = (a1[i] - A[0][i]) * iskv[i];
+                d2s = GR_FMA(ex, ex, d2s);
+                d2s = GR_FMA(ev, ev, d2s);
             }
-            const double d2 = sqrt_fast(d2s * 0.125) * rcp_full(dt0);
-            const double dm = ::fmax(d1, d2);
+            const real d2 = sqrt_fast(d2s * 0.125) * rcp_full(dt0);
+            const real dm = GR_FMAX(d1, d2);
             // 10^(-(2 + log10 dm)/5) = 10^-0.4 dm^-0.2 ; single-precision hardware log2/exp2 is ample
             // for a starting step size
-            const double dt1 = (dm <= 1e-15) ? ::fmax(1e-6, dt0 * 1e-3)
-                                             : 0.39810717055349726 * (double)fast_exp2f(-0.2f * fast_log2f((float)dm));
-            dt = ::fmin(::fmin(100.0 * dt0, dt1), dtmax);
+            const real dt1 = (dm <= 1e-15) ? GR_FMAX(1e-6, dt0 * 1e-3)
+                                             : 0.39810717055349726 * (real)fast_exp2f(-0.2f * fast_log2f((float)dm));
+            dt = GR_FMIN(GR_FMIN(100.0 * dt0, dt1), dtmax);
         }
     }
 
     // Σ_{i<n} W[i] A[i][comp], compile-time weights
     template <int N, class W>
-    GR_DEV double asum(const W& w, int comp) const
+    GR_DEV real asum(const W& w, int comp) const
     {
-        double acc = w(0) * A[0][comp];
+        real acc = w(0) * A[0][comp];
 #pragma unroll
-        for (int i = 1; i < N; ++i) acc = __builtin_fma(w(i), A[i][comp], acc);
+        for (int i = 1; i < N; ++i) acc = GR_FMA(w(i), A[i][comp], acc);
         return acc;
     }
 
@@ -824,39 +859,39 @@ struct Ray {
     // callback, reached λ1, or hit an anomaly).
     GR_DEV bool step(const Metric& m, const Params& p)
     {
-        const double tend = p.cfg.lambda1;
-        const double dtmax = ::fabs(tend - p.cfg.lambda0);
+        const real tend = p.cfg.lambda1;
+        const real dtmax = GR_FABS(tend - (real)p.cfg.lambda0);
         if (nacc + nrej >= p.cfg.maxiters) { flags |= GR_FLAG_MAXITERS; return true; }
-        double hh = ::fmin(dt, dtmax);
+        real hh = GR_FMIN(dt, dtmax);
         if (!(hh == hh)) { flags |= GR_FLAG_NAN; return true; }
-        if (hh < 4.0 * 2.220446049250313e-16 * ::fmax(::fabs(t), 1.0)) { flags |= GR_FLAG_DTMIN; return true; }
-        hh = ::fmin(hh, tend - t);
+        if (hh < 4.0 * GR_EPS * GR_FMAX(GR_FABS(t), 1.0)) { flags |= GR_FLAG_DTMIN; return true; }
+        hh = GR_FMIN(hh, tend - t);
         h = hh;
-        const double h2 = hh * hh;
+        const real h2 = hh * hh;
 
-        double s, c;
+        real s, c;
         // stages 2..6: arguments need r, θ and the four velocities only (the RHS does not
         // depend on t or ϕ)
 #define GR_STAGE(S)                                                                                   \
     {                                                                                                 \
-        double vs[4];                                                                                 \
+        real vs[4];                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
         {                                                                                             \
-            double acc = Ts::A[S][0] * A[0][i];                                                       \
-            _Pragma("unroll") for (int q = 1; q < S; ++q) acc = __builtin_fma(Ts::A[S][q], A[q][i], acc); \
-            vs[i] = __builtin_fma(hh, acc, v[i]);                                                     \
+            real acc = Ts::A[S][0] * A[0][i];                                                       \
+            _Pragma("unroll") for (int q = 1; q < S; ++q) acc = GR_FMA(Ts::A[S][q], A[q][i], acc); \
+            vs[i] = GR_FMA(hh, acc, v[i]);                                                     \
         }                                                                                             \
-        double rs = __builtin_fma(TsD::X.C[S] * hh, v[1], x[1]);                                           \
-        double ts = __builtin_fma(TsD::X.C[S] * hh, v[2], x[2]);                                           \
+        real rs = GR_FMA(TsD::X.C[S] * hh, v[1], x[1]);                                           \
+        real ts = GR_FMA(TsD::X.C[S] * hh, v[2], x[2]);                                           \
         if (S > 1) {                                                                                  \
-            double ar = TsD::X.AX[S][0] * A[0][1], at = TsD::X.AX[S][0] * A[0][2];                              \
+            real ar = TsD::X.AX[S][0] * A[0][1], at = TsD::X.AX[S][0] * A[0][2];                              \
             _Pragma("unroll") for (int q = 1; q < S - 1; ++q)                                         \
             {                                                                                         \
-                ar = __builtin_fma(TsD::X.AX[S][q], A[q][1], ar);                                          \
-                at = __builtin_fma(TsD::X.AX[S][q], A[q][2], at);                                          \
+                ar = GR_FMA(TsD::X.AX[S][q], A[q][1], ar);                                          \
+                at = GR_FMA(TsD::X.AX[S][q], A[q][2], at);                                          \
             }                                                                                         \
-            rs = __builtin_fma(h2, ar, rs);                                                           \
-            ts = __builtin_fma(h2, at, ts);                                                           \
+            rs = GR_FMA(h2, ar, rs);                                                           \
+            ts = GR_FMA(h2, at, ts);                                                           \
         }                                                                                             \
         sincos_rot(x[2], sth, cth, ts, s, c);                                                         \
         geodesic_rhs_sc(m, rs, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
@@ -868,39 +903,39 @@ struct Ray {
         GR_STAGE(5)
 #undef GR_STAGE
         // stage 7 argument = the new state
-        double xn[4], vn[4];
+        real xn[4], vn[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            double acc = Ts::A[6][0] * A[0][i];
+            real acc = Ts::A[6][0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 6; ++q) acc = __builtin_fma(Ts::A[6][q], A[q][i], acc);
-            vn[i] = __builtin_fma(hh, acc, v[i]);
-            double ax = TsD::X.AX[6][0] * A[0][i];
+            for (int q = 1; q < 6; ++q) acc = GR_FMA(Ts::A[6][q], A[q][i], acc);
+            vn[i] = GR_FMA(hh, acc, v[i]);
+            real ax = TsD::X.AX[6][0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 5; ++q) ax = __builtin_fma(TsD::X.AX[6][q], A[q][i], ax);
-            xn[i] = __builtin_fma(h2, ax, __builtin_fma(TsD::X.C[6] * hh, v[i], x[i]));
+            for (int q = 1; q < 5; ++q) ax = GR_FMA(TsD::X.AX[6][q], A[q][i], ax);
+            xn[i] = GR_FMA(h2, ax, GR_FMA(TsD::X.C[6] * hh, v[i], x[i]));
         }
-        double sn, cn;
+        real sn, cn;
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);
 
         // error estimate, squared RMS norm over all eight components
-        const double abstol = p.cfg.abstol, reltol = p.cfg.reltol;
-        double e2 = 0.0;
+        const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
+        real e2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            double ev = Ts::BT[0] * A[0][i];
+            real ev = Ts::BT[0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 7; ++q) ev = __builtin_fma(Ts::BT[q], A[q][i], ev);
-            double ex = TsD::X.BTX[0] * A[0][i];
+            for (int q = 1; q < 7; ++q) ev = GR_FMA(Ts::BT[q], A[q][i], ev);
+            real ex = TsD::X.BTX[0] * A[0][i];
 #pragma unroll
-            for (int q = 1; q < 6; ++q) ex = __builtin_fma(TsD::X.BTX[q], A[q][i], ex);
-            ex = __builtin_fma(hh, ex, TsD::X.SBT * v[i]);
-            const double skv = __builtin_fma(::fmax(::fabs(v[i]), ::fabs(vn[i])), reltol, abstol);
-            const double skx = __builtin_fma(::fmax(::fabs(x[i]), ::fabs(xn[i])), reltol, abstol);
-            const double av = hh * ev * rcp_fast(skv);
-            const double ax = hh * ex * rcp_fast(skx);
-            e2 = __builtin_fma(av, av, e2);
-            e2 = __builtin_fma(ax, ax, e2);
+            for (int q = 1; q < 6; ++q) ex = GR_FMA(TsD::X.BTX[q], A[q][i], ex);
+            ex = GR_FMA(hh, ex, TsD::X.SBT * v[i]);
+            const real skv = GR_FMA(GR_FMAX(GR_FABS(v[i]), GR_FABS(vn[i])), reltol, abstol);
+            const real skx = GR_FMA(GR_FMAX(GR_FABS(x[i]), GR_FABS(xn[i])), reltol, abstol);
+            const real av = hh * ev * rcp_fast(skv);
+            const real ax = hh * ex * rcp_fast(skx);
+            e2 = GR_FMA(av, av, e2);
+            e2 = GR_FMA(ax, ax, e2);
         }
         e2 *= 0.125;   // EEst² ; accept iff EEst <= 1
 #ifdef GR_HOST_HARNESS
@@ -916,12 +951,12 @@ struct Ray {
             qf = ::fmaxf((float)(1.0 / PI_QMAX), ::fminf((float)(1.0 / PI_QMIN), qf));   // e2 == 0 -> 1/qmax
             nacc++;
             lq_old = ::fmaxf(lE, (float)LOG2_QOLDINIT);
-            const double dtnew = hh * rcp_full((double)qf);
-            double tnew = t + hh;
-            if (::fabs(tnew - tend) < 100.0 * 2.220446049250313e-16 * ::fmax(::fabs(tnew), ::fabs(tend))) tnew = tend;
+            const real dtnew = hh * rcp_full((real)qf);
+            real tnew = t + hh;
+            if (GR_FABS(tnew - tend) < 100.0 * GR_EPS * GR_FMAX(GR_FABS(tnew), GR_FABS(tend))) tnew = tend;
 
             if (DISC) {
-                const double cnext = disc_cond(p, xn[1], sn, cn);
+                const real cnext = disc_cond(p, xn[1], sn, cn);
                 const int ps = sgn(cprev);
                 int top = 0;
                 if (ps != 0) {
@@ -942,47 +977,47 @@ struct Ray {
             for (int i = 0; i < 4; ++i) { x[i] = xn[i]; v[i] = vn[i]; A[0][i] = A[6][i]; }
             sth = sn; cth = cn;
             t = tnew;
-            dt = ::fmin(dtmax, dtnew);
+            dt = GR_FMIN(dtmax, dtnew);
             return term || !(t < tend);
         } else {
             // step_reject_controller!; a NaN state lands here too (e2 is NaN) and is flagged at
             // the top of the next attempt through the NaN step size
             nrej++;
             const float q11 = fast_exp2f((float)PI_BETA1 * lE);
-            dt = hh / (double)::fminf((float)(1.0 / PI_QMIN), q11 * (float)(1.0 / PI_GAMMA));
+            dt = hh / (real)::fminf((float)(1.0 / PI_QMIN), q11 * (float)(1.0 / PI_GAMMA));
             return false;
         }
     }
 
     // dense-output polynomial coefficients of component `comp` (0..3 position, 4..7 velocity):
     // y(Θ) = y0 + h Σ_m C[m] Θ^(m+1)
-    GR_DEV void dense_coeffs(int comp, double hh, double C[4]) const
+    GR_DEV void dense_coeffs(int comp, real hh, real C[4]) const
     {
         if (comp >= 4) {
             const int q = comp - 4;
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
-                double acc = 0.0;
+                real acc = 0.0;
 #pragma unroll
                 for (int i = 0; i < 7; ++i)
-                    if (Ts::R[i][mm] != 0.0) acc = __builtin_fma(Ts::R[i][mm], A[i][q], acc);
+                    if (Ts::R[i][mm] != 0.0) acc = GR_FMA(Ts::R[i][mm], A[i][q], acc);
                 C[mm] = acc;
             }
         } else {
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
-                double acc = 0.0;
+                real acc = 0.0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
-                    if (TsD::X.RX[i][mm] != 0.0) acc = __builtin_fma(TsD::X.RX[i][mm], A[i][comp], acc);
-                C[mm] = __builtin_fma(hh, acc, TsD::X.SR[mm] * v[comp]);
+                    if (TsD::X.RX[i][mm] != 0.0) acc = GR_FMA(TsD::X.RX[i][mm], A[i][comp], acc);
+                C[mm] = GR_FMA(hh, acc, TsD::X.SR[mm] * v[comp]);
             }
         }
     }
-    static GR_DEV double dense_eval(double u0, double hh, const double C[4], double th)
+    static GR_DEV real dense_eval(real u0, real hh, const real C[4], real th)
     {
-        const double poly = th * (C[0] + th * (C[1] + th * (C[2] + th * C[3])));
-        return __builtin_fma(hh, poly, u0);
+        const real poly = th * (C[0] + th * (C[1] + th * (C[2] + th * C[3])));
+        return GR_FMA(hh, poly, u0);
     }
 
     // ContinuousCallback safety sampling at Θ = j/7, j = 1..6 (Θ = 1 was tested by the caller).
@@ -990,37 +1025,37 @@ struct Ray {
     // A sample can only change sign if it lies inside the |cosθ| < gtol wedge.  Cheap exits first:
     // (1) a bound on how far θ can move inside the step, (2) θ alone at the six samples; the full
     // condition is evaluated only for steps that come near the equatorial plane.
-    GR_DEV int sample_event(const Params& p, int ps, double hh) const
+    GR_DEV int sample_event(const Params& p, int ps, real hh) const
     {
-        const double wedge = p.wedge;
+        const real wedge = p.wedge;
         if (ps > 0) {
             // |θ(Θ_j) - θ_0| <= h (Θ_j |v^θ| + h Σ_i |RXΣ_i(Θ_j)| |A_i^θ|) <= h (|v^θ| + K h max_i |A_i^θ|)
-            double amax = ::fabs(A[0][2]);
+            real amax = GR_FABS(A[0][2]);
 #pragma unroll
-            for (int i = 1; i < 6; ++i) amax = ::fmax(amax, ::fabs(A[i][2]));
-            const double reach = hh * (::fabs(v[2]) * DENSE_K1 + DENSE_K2 * hh * amax);
-            double d0 = x[2] - 1.5707963267948966;
-            d0 -= 3.141592653589793 * __builtin_rint(d0 * 0.3183098861837907);
-            if (::fabs(d0) - reach > wedge) return 0;
+            for (int i = 1; i < 6; ++i) amax = GR_FMAX(amax, GR_FABS(A[i][2]));
+            const real reach = hh * (GR_FABS(v[2]) * DENSE_K1 + DENSE_K2 * hh * amax);
+            real d0 = x[2] - 1.5707963267948966;
+            d0 -= 3.141592653589793 * GR_RINT(d0 * 0.3183098861837907);
+            if (GR_FABS(d0) - reach > wedge) return 0;
         }
-        double Ct[4];
+        real Ct[4];
         dense_coeffs(2, hh, Ct);
         bool any = (ps < 0);
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj) {
-            double d = dense_eval(x[2], hh, Ct, (double)(jj + 1) / 7.0) - 1.5707963267948966;
-            d -= 3.141592653589793 * __builtin_rint(d * 0.3183098861837907);
-            any |= (::fabs(d) < wedge);
+            real d = dense_eval(x[2], hh, Ct, (real)(jj + 1) / 7.0) - 1.5707963267948966;
+            d -= 3.141592653589793 * GR_RINT(d * 0.3183098861837907);
+            any |= (GR_FABS(d) < wedge);
         }
         if (!any) return 0;
-        double Cr[4];
+        real Cr[4];
         dense_coeffs(1, hh, Cr);
         for (int jj = 1; jj <= 6; ++jj) {
-            const double th = (double)jj / 7.0;
-            double s, c;
+            const real th = (real)jj / 7.0;
+            real s, c;
             sincos_fast(dense_eval(x[2], hh, Ct, th), s, c);
-            const double cj = disc_cond(p, dense_eval(x[1], hh, Cr, th), s, c);
-            if ((double)ps * cj < 0.0) return jj;
+            const real cj = disc_cond(p, dense_eval(x[1], hh, Cr, th), s, c);
+            if ((real)ps * cj < 0.0) return jj;
         }
         return 0;
     }
@@ -1029,44 +1064,44 @@ struct Ray {
     // discrete callbacks on it.  Result: final (t, x, v).
     GR_DEV void resolve_event(const Params& p)
     {
-        double Cr[4], Ct[4];
+        real Cr[4], Ct[4];
         dense_coeffs(1, h, Cr);
         dense_coeffs(2, h, Ct);
         const int ps = sgn(cprev);
-        double lo = 0.0, hi = (ev_top >= 7) ? 1.0 : (double)ev_top / 7.0;
-        double flo = cprev, fhi;
+        real lo = 0.0, hi = (ev_top >= 7) ? 1.0 : (real)ev_top / 7.0;
+        real flo = cprev, fhi;
         {
-            double s, c;
+            real s, c;
             sincos_fast(dense_eval(x[2], h, Ct, hi), s, c);
             fhi = disc_cond(p, dense_eval(x[1], h, Cr, hi), s, c);
         }
-        double theta = hi;
+        real theta = hi;
         if (fhi != 0.0) {
             // bracketing hybrid: false position with forced bisection; keeps sign(f(lo)) == ps
             for (int it = 0; it < 80; ++it) {
-                const double w = hi - lo;
-                if (w <= 4.0e-16 * ::fmax(hi, 1e-300) || w < 1e-17) break;
-                double mid;
+                const real w = hi - lo;
+                if (w <= 4.0e-16 * GR_FMAX(hi, 1e-300) || w < 1e-17) break;
+                real mid;
                 if ((it % 3) == 2 || !(flo * fhi < 0.0)) mid = lo + 0.5 * w;
                 else {
                     mid = lo - flo * w / (fhi - flo);
-                    const double guard = 1e-3 * w;
+                    const real guard = 1e-3 * w;
                     if (!(mid > lo + guard)) mid = lo + guard;
                     if (!(mid < hi - guard)) mid = hi - guard;
                 }
                 if (!(mid > lo && mid < hi)) break;
-                double s, c;
+                real s, c;
                 sincos_fast(dense_eval(x[2], h, Ct, mid), s, c);
-                const double fm = disc_cond(p, dense_eval(x[1], h, Cr, mid), s, c);
+                const real fm = disc_cond(p, dense_eval(x[1], h, Cr, mid), s, c);
                 if (sgn(fm) == ps) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
             }
             theta = lo;
         }
         // change_t_via_interpolation!: every component from the interpolant
-        double xe[4], ve[4];
+        real xe[4], ve[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            double C[4];
+            real C[4];
             dense_coeffs(i, h, C);
             xe[i] = dense_eval(x[i], h, C, theta);
             dense_coeffs(4 + i, h, C);
@@ -1075,7 +1110,7 @@ struct Ray {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x[i] = xe[i]; v[i] = ve[i]; }
         t = t + theta * h;
-        double s, c;
+        real s, c;
         sincos_fast(x[2], s, c);
         discrete_cb(p, x[1], c, status);
     }
@@ -1096,7 +1131,7 @@ struct Ray {
             if (((col | row) & 7) == 0) cd.tile_cost[(col >> 3) * (H >> 3) + (row >> 3)] = (uint32_t)(nacc + nrej);
         }
         if (cd.out_mode == 1) {
-            double x0[4], v0[4];
+            real x0[4], v0[4];
             constrained_u0(m, p, j, x0, v0);
             gr_point* o = cd.points + j;
             o->status = status;
@@ -1112,24 +1147,24 @@ struct Ray {
             }
         } else if (cd.out_mode >= 2) {
             // lineprofile(bins, ε, m, u, d, BinningMethod()), line-profiles.jl:186-197
-            double s, c;
+            real s, c;
             sincos_fast(x[2], s, c);
-            const double rho = x[1] * ::fabs(s);
+            const real rho = x[1] * GR_FABS(s);
             const bool in = status == GR_STATUS_INTERSECTED_WITH_GEOMETRY && rho >= cd.lp_rmin && rho <= cd.lp_rmax;
-            double g = 0.0;
+            real g = 0.0;
             if (in) {
-                double x0[4], v0[4];
+                real x0[4], v0[4];
                 constrained_u0(m, p, j, x0, v0);
                 g = redshift_pf(m, p, cd, x0, v0, x, v);
             }
             if (cd.out_mode == 3) {
-                cd.lp_pairs[2 * j] = in ? g : __builtin_nan("");
-                cd.lp_pairs[2 * j + 1] = in ? rho : __builtin_nan("");
+                cd.lp_pairs[2 * j] = in ? (double)g : __builtin_nan("");
+                cd.lp_pairs[2 * j + 1] = in ? (double)rho : __builtin_nan("");
             } else if (in) {
-                const double area = cd.area ? cd.area[j] : 1.0;
+                const real area = cd.area ? cd.area[j] : 1.0;
                 // ε(r) g³ area with ε(r) = r^-q
-                const double eps = (cd.lp_q == 3.0) ? rcp_full(rho * rho * rho) : ::pow(rho, -cd.lp_q);
-                const double f = eps * g * g * g * area;
+                const real eps = (cd.lp_q == 3.0) ? rcp_full(rho * rho * rho) : GR_POW(rho, -cd.lp_q);
+                const real f = eps * g * g * g * area;
                 // bucket(Simple(), g, f, bins): first edge >= g, clamped to the last bin
                 int64_t lo = 0, hi = cd.lp_nbins;
                 while (lo < hi) {
@@ -1143,16 +1178,16 @@ struct Ray {
             bool pass = true;
             if (cd.pf.filter_id == GR_FILTER_EARLY_TERM) pass = t < p.cfg.lambda1;
             else if (cd.pf.filter_id == GR_FILTER_INTERSECTED) pass = status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
-            double val = cd.pf.fill;
+            real val = cd.pf.fill;
             if (pass) {
                 if (cd.pf.pf_id == GR_PF_AFFINE_TIME) val = t;
-                else if (cd.pf.pf_id == GR_PF_STATUS) val = (double)status;
+                else if (cd.pf.pf_id == GR_PF_STATUS) val = (real)status;
                 else if (cd.pf.pf_id == GR_PF_RADIUS) {
-                    double s, c;
+                    real s, c;
                     sincos_fast(x[2], s, c);
-                    val = x[1] * ::fabs(s);
+                    val = x[1] * GR_FABS(s);
                 } else {
-                    double x0[4], v0[4];
+                    real x0[4], v0[4];
                     constrained_u0(m, p, j, x0, v0);
                     val = redshift_pf(m, p, cd, x0, v0, x, v);
                 }
@@ -1162,4 +1197,4 @@ struct Ray {
     }
 };
 
-}  // namespace gr
+}  // namespace GR_NS

@@ -17,9 +17,14 @@
 #include <string>
 #include <vector>
 
-#include "gr_device.hpp"
+#define GR_NS gr
+#include "gr_kernels.hpp"
 
 using namespace gr;
+
+// fp32 build of the same kernels (gradus_mi355x_f32.hip)
+hipError_t gr32_launch(int kernel, int block, int n_cu, int waves_per_simd, unsigned long long* queue,
+                       const void* params, hipStream_t stream);
 
 namespace {
 
@@ -38,155 +43,6 @@ int32_t fail(int32_t code, const std::string& msg)
             return fail(e_ == hipErrorOutOfMemory ? GR_ERR_OUT_OF_MEMORY : GR_ERR_HIP,            \
                         std::string(#call) + ": " + hipGetErrorString(e_));                       \
     } while (0)
-
-constexpr int N_STAT = 9;   // rays, accepted, rejected, rhs, flagged, status[4]
-
-template <class Metric, int DISC>
-struct LaneStats {
-    // per-lane 32-bit counters (a lane handles far fewer than 2^32 steps per launch)
-    unsigned rays = 0, acc = 0, rej = 0, flagged = 0, st[4] = { 0, 0, 0, 0 };
-    GR_DEV void add(const Ray<Metric, DISC>& r)
-    {
-        rays += 1;
-        acc += (unsigned)r.nacc;
-        rej += (unsigned)r.nrej;
-        flagged += r.flags ? 1 : 0;
-        const int s = r.flags ? GR_STATUS_NO_STATUS : r.status;
-        st[0] += (s == 0); st[1] += (s == 1); st[2] += (s == 2); st[3] += (s == 3);
-    }
-    GR_DEV void flush(unsigned long long* out) const
-    {
-        if (!out) return;
-        unsigned long long v[N_STAT] = { rays, acc, rej, 2ull * rays + 6ull * ((unsigned long long)acc + rej), flagged, st[0], st[1], st[2], st[3] };
-#pragma unroll
-        for (int i = 0; i < N_STAT; ++i) {
-            unsigned long long x = v[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-            if ((threadIdx.x & 63) == 0 && x) atomicAdd(out + i, x);
-        }
-    }
-};
-
-// ---- kernel 0: one ray per work-item ----
-template <class Metric, int DISC>
-__global__ void __launch_bounds__(256) k_trace_lane(const Params p)
-{
-    Metric m;
-    m.load(p.cfg.params);
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    LaneStats<Metric, DISC> ls;
-    if (gid < p.n) {
-        Ray<Metric, DISC> ray;
-        ray.init(m, p, tile_swizzle(cold_of(p), gid));
-        while (!ray.step(m, p)) {}
-        ray.finalize(m, p);
-        ls.add(ray);
-    }
-    ls.flush(p.stats);
-}
-
-// ---- kernel 1: persistent grid with wave-ballot refill ----
-template <class Metric, int DISC>
-__global__ void __launch_bounds__(256) k_trace_persistent(const Params p)
-{
-    Metric m;
-    m.load(p.cfg.params);
-    Ray<Metric, DISC> ray;
-    LaneStats<Metric, DISC> ls;
-    bool active = false, pending = false, queue_empty = false;
-    const int lane = threadIdx.x & 63;
-    const int threshold = p.refill_threshold;
-
-    for (;;) {
-        const unsigned long long act = __ballot(active);
-        const int n_idle = 64 - __popcll(act);
-        if (n_idle >= threshold || act == 0ull) {
-            if (__ballot(pending)) {
-                if (pending) {
-                    ray.finalize(m, p);
-                    ls.add(ray);
-                    pending = false;
-                }
-            }
-            if (!queue_empty) {
-                const unsigned long long idle = __ballot(!active);
-                const int n = __popcll(idle);
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(p.queue, (unsigned long long)n);
-                base = __shfl(base, 0, 64);
-                const int64_t mine = (int64_t)base + __popcll(idle & ((1ull << lane) - 1ull));
-                if (!active && mine < p.n) {
-                    ray.init(m, p, tile_swizzle(cold_of(p), mine));
-                    active = true;
-                }
-                if ((int64_t)base + n >= p.n) queue_empty = true;
-            }
-            if (__ballot(active) == 0ull) break;
-        }
-        if (active) {
-            if (ray.step(m, p)) {
-                active = false;
-                pending = true;
-            }
-        }
-    }
-    ls.flush(p.stats);
-}
-
-// ---- one geodesic, every accepted step saved (single wave, lane 0) ----
-template <class Metric, int DISC>
-__global__ void __launch_bounds__(64) k_trace_path(const Params p, double* path, int64_t cap, unsigned long long* n_rows)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Metric m;
-    m.load(p.cfg.params);
-    Ray<Metric, DISC> ray;
-    ray.init(m, p, 0);
-    int64_t n = 0;
-    auto save = [&]() {
-        if (n < cap) {
-            double* row = path + 9 * n;
-            row[0] = ray.t;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { row[1 + q] = ray.x[q]; row[5 + q] = ray.v[q]; }
-        }
-        ++n;
-    };
-    save();
-    for (;;) {
-        const int before = ray.nacc;
-        const bool fin = ray.step(m, p);
-        if (fin) break;
-        if (ray.nacc != before) save();
-    }
-    ray.finalize(m, p);     // resolves a pending event and writes the endpoint record
-    save();
-    *n_rows = (unsigned long long)n;
-}
-
-// ---- apply(pf, points) ----
-template <class Metric>
-__global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point* pts, double max_time, double* out)
-{
-    Metric m;
-    m.load(p.cfg.params);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    const gr_point gp = pts[i];
-    const Cold& cd = *p.cold;
-    bool pass = true;
-    if (cd.pf.filter_id == GR_FILTER_EARLY_TERM) pass = gp.lambda_max < max_time;
-    else if (cd.pf.filter_id == GR_FILTER_INTERSECTED) pass = gp.status == GR_STATUS_INTERSECTED_WITH_GEOMETRY;
-    double val = cd.pf.fill;
-    if (pass) {
-        if (cd.pf.pf_id == GR_PF_AFFINE_TIME) val = gp.lambda_max;
-        else if (cd.pf.pf_id == GR_PF_STATUS) val = (double)gp.status;
-        else if (cd.pf.pf_id == GR_PF_RADIUS) val = gp.x[1] * ::fabs(::sin(gp.x[2]));
-        else val = redshift_pf(m, p, cd, gp.x_init, gp.v_init, gp.x, gp.v);
-    }
-    out[i] = val;
-}
 
 }  // namespace
 
@@ -214,6 +70,7 @@ struct gr_ctx {
     int64_t refill_threshold = 16;
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
     int64_t swizzle = 1;
+    int64_t precision = 64;                // 64 = fp64 kernels, 32 = fp32 kernels (tolerance sweeps)
     int64_t lpt = 1;                       // longest-first tile order learned from the previous render
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // LPT state for one (config, plane, range) key
@@ -270,34 +127,6 @@ int32_t validate_plane(const gr_plane* pl, const gr_range* rg)
         const int64_t i = rg->first + b * rg->stride_blocks * rg->block + (last - b * rg->block);
         if (i >= pl->width * pl->height) return fail(GR_ERR_INVALID_ARGUMENT, "ray range exceeds the image");
     }
-    return GR_OK;
-}
-
-template <class Metric, int DISC>
-int32_t launch_tmpl(gr_ctx* ctx, Params& p, hipStream_t stream)
-{
-    const int block = (int)ctx->block;
-    if (ctx->kernel == 0) {
-        const int64_t grid = (p.n + block - 1) / block;
-        hipLaunchKernelGGL((k_trace_lane<Metric, DISC>), dim3((unsigned)grid), dim3(block), 0, stream, p);
-    } else {
-        int per_cu = 0;
-        GR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persistent<Metric, DISC>, block, 0));
-        if (per_cu < 1) per_cu = 1;
-        if (ctx->waves_per_simd > 0) {
-            const int want = (int)(ctx->waves_per_simd * 256 / block);
-            if (want >= 1 && want < per_cu) per_cu = want;
-        }
-        int64_t grid = (int64_t)ctx->n_cu * per_cu;
-        const int64_t need = (p.n + block - 1) / block;
-        if (grid > need) grid = need;
-        if (grid < 1) grid = 1;
-        p.queue = ctx->d_queue + ctx->queue_next;
-        ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
-        GR_HIP(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL((k_trace_persistent<Metric, DISC>), dim3((unsigned)grid), dim3(block), 0, stream, p);
-    }
-    GR_HIP(hipGetLastError());
     return GR_OK;
 }
 
@@ -383,12 +212,16 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     p.cold = slot;
     p.refill_threshold = (int32_t)ctx->refill_threshold;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    const bool disc = p.cfg.disc_id == GR_DISC_THIN;
-    int32_t rc;
-    if (p.cfg.metric_id == GR_METRIC_KERR)
-        rc = disc ? launch_tmpl<KerrMetric, 1>(ctx, p, stream) : launch_tmpl<KerrMetric, 0>(ctx, p, stream);
+    LaunchKnobs knobs{ (int)ctx->kernel, (int)ctx->block, ctx->n_cu, (int)ctx->waves_per_simd,
+                       ctx->d_queue + ctx->queue_next };
+    ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
+    hipError_t le;
+    if (ctx->precision == 32)
+        le = gr32_launch(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
     else
-        rc = disc ? launch_tmpl<JohannsenMetric, 1>(ctx, p, stream) : launch_tmpl<JohannsenMetric, 0>(ctx, p, stream);
+        le = launch_by_config(knobs, p, stream);
+    if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    const int32_t rc = GR_OK;
     if (rc == GR_OK && lpt_record) {
         GR_HIP(hipEventRecord(ctx->ev_cost, stream));
         ctx->lpt_cost_pending = true;
@@ -543,6 +376,9 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->waves_per_simd = value;
     } else if (k == "swizzle") {
         c->swizzle = value ? 1 : 0;
+    } else if (k == "precision") {
+        if (value != 32 && value != 64) return fail(GR_ERR_INVALID_ARGUMENT, "precision must be 32 or 64");
+        c->precision = value;
     } else if (k == "lpt") {
         if (value < 0 || value > 2) return fail(GR_ERR_INVALID_ARGUMENT, "lpt must be 0 (off), 1 (auto) or 2 (always)");
         c->lpt = value;

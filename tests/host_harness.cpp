@@ -6,7 +6,7 @@
 
 #include "../gradus.jl_amd/csrc/gr_device.hpp"
 
-using namespace gr;
+using namespace GR_NS;
 
 template <class Metric, int DISC>
 static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t cap, int64_t* nlog)

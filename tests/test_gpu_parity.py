@@ -332,3 +332,25 @@ def test_lineprofile_binning_matches_oracle_and_reference_edges(G, oracle, ens):
     # a rim ray switching bins moves ~1e-4 of the flux; bulk agreement is much tighter
     assert np.abs(y - ref).sum() < 2e-3
     assert np.max(np.abs(y - ref)) < 5e-4
+
+
+def test_fp32_kernels_track_fp64(G, ens):
+    """The fp32 instantiation (gr_ctx_set("precision", 32)) at tol 1e-5 against fp64 at 1e-9 on the
+    C2 scene: same classification up to rim pixels, redshift to ~1e-3."""
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    pf = G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    kw = dict(image_width=128, image_height=128, alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens)
+    ens.set("kernel", 1).set("precision", 64)
+    _, _, ref = G.rendergeodesics(m, X_FAR, d, 2000.0, **kw)
+    ens.set("precision", 32)
+    try:
+        _, _, img, st = G.rendergeodesics(m, X_FAR, d, 2000.0, abstol=1e-5, reltol=1e-5, stats=True, **kw)
+    finally:
+        ens.set("precision", 64)
+    assert st["rays"] == 128 * 128 and st["flagged_rays"] <= 0.01 * st["rays"]
+    assert (np.isnan(img) != np.isnan(ref)).sum() <= 0.02 * img.size
+    both = ~np.isnan(img) & ~np.isnan(ref)
+    assert both.sum() > 1000
+    assert np.median(np.abs(img[both] / ref[both] - 1)) < 2e-4
+    assert np.percentile(np.abs(img[both] / ref[both] - 1), 99) < 2e-2
