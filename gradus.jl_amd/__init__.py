@@ -10,7 +10,8 @@ from . import device, distributed
 from .distributed import gather_image, shard_plan
 from .geometry import ThinDisc
 from .lineprofiles import BinningMethod, PowerLawEmissivity, bucket_simple, lineprofile
-from .metrics import JohannsenMetric, KerrMetric, inner_radius, isco
+from .metrics import (BumblebeeMetric, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,
+                      MorrisThorneWormhole, inner_radius, isco)
 from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix
 from .planes import (CartesianPlane, GeometricGrid, InverseGrid, LinearGrid, PolarPlane, image_plane,
                      impact_parameters, trajectory_count, unnormalized_areas)

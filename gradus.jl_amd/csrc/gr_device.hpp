@@ -242,7 +242,7 @@ GR_DEV void inverse_generic(const real g[5], real gi[5])
 
 struct KerrMetric {
     real M, a;
-    GR_DEV void load(const double* p) { M = p[0]; a = p[1]; }
+    GR_DEV void load(const gr_config& c) { M = c.params[0]; a = c.params[1]; }
 
     // values only (constraint, redshift)
     GR_DEV void comps(real r, real s, real c, real g[5]) const
@@ -307,14 +307,27 @@ struct KerrMetric {
     }
 };
 
-struct JohannsenMetric {
-    real M, a, a13, a22, a52, e3;
-    GR_DEV void load(const double* p) { M = p[0]; a = p[1]; a13 = p[2]; a22 = p[3]; a52 = p[4]; e3 = p[5]; }
-
-    // johannsen-ad.jl:12-34 on an arbitrary number type
-    template <class T>
-    GR_DEV void components(T r, T s, T c, T g[5]) const
+// Every other AbstractStaticAxisSymmetric metric: components written once over a number type and
+// differentiated with forward-mode duals, as the reference does for all of its metrics.  One
+// functor with a (wave-uniform) switch on the metric id keeps the number of kernel instantiations
+// independent of the size of the catalogue.
+struct GenericMetric {
+    int32_t id;
+    real P[6];
+    GR_DEV void load(const gr_config& c)
     {
+        id = c.metric_id;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) P[i] = c.params[i];
+    }
+    static GR_DEV real inv_(real x) { return rcp_full(x); }
+    static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
+
+    // __JohannsenAD.metric_components, johannsen-ad.jl:12-34 ; P = M, a, α13, α22, α52, ϵ3
+    template <class T>
+    GR_DEV void johannsen(T r, T s, T c, T g[5]) const
+    {
+        const real M = P[0], a = P[1], a13 = P[2], a22 = P[3], a52 = P[4], e3 = P[5];
         const real a2 = a * a;
         T Mr = M * inv_(r);
         T Mr2 = Mr * Mr;
@@ -337,8 +350,89 @@ struct JohannsenMetric {
         g[3] = pp * idenom;
         g[4] = tp * idenom;
     }
-    static GR_DEV real inv_(real x) { return rcp_full(x); }
-    static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
+    // __MorrisThorneAD.metric_components, morris-thorne-ad.jl:4-15 ; P = b.  (ϕϕ carries sinθ to
+    // the FIRST power in the reference; reproduced as is.)
+    template <class T>
+    GR_DEV void morris_thorne(T l, T s, T c, T g[5]) const
+    {
+        const real b2 = P[0] * P[0];
+        T w = l * l + b2;
+        g[0] = (l - l) - 1.0;
+        g[1] = (l - l) + 1.0;
+        g[2] = w;
+        g[3] = w * s;
+        g[4] = l - l;
+        (void)c;
+    }
+    // __BumblebeeAD.metric_components, bumblebee-ad.jl:6-21 ; P = M, a, l
+    template <class T>
+    GR_DEV void bumblebee(T r, T s, T c, T g[5]) const
+    {
+        const real M = P[0], a = P[1], lsb = P[2];
+        T s2 = s * s;
+        T r2 = r * r;
+        T ir = inv_(r);
+        T Del = (r2 - (2.0 * M) * r) * (1.0 / (lsb + 1.0));
+        g[0] = -(1.0 - (2.0 * M) * ir);
+        g[1] = r2 * inv_(Del);
+        g[2] = r2;
+        g[3] = r2 * s2;
+        g[4] = -((2.0 * M * a) * (s2 * ir));
+        (void)c;
+    }
+    // __KerrNewmanAD.metric_components, kerr-newman-ad.jl:6-27 ; P = M, a, Q
+    template <class T>
+    GR_DEV void kerr_newman(T r, T s, T c, T g[5]) const
+    {
+        const real M = P[0], a = P[1], Q = P[2];
+        const real a2 = a * a;
+        T r2 = r * r;
+        T ac = a * c;
+        T Sig = r2 + ac * ac;
+        T s2 = s * s;
+        T Del = r2 - (2.0 * M) * r + (a2 + Q * Q);
+        T r2a2 = r2 + a2;
+        T iSig = inv_(Sig);
+        g[0] = (a2 * s2 - Del) * iSig;
+        g[1] = Sig * inv_(Del);
+        g[2] = Sig;
+        g[3] = (s2 * iSig) * (r2a2 * r2a2 - a2 * (s2 * Del));
+        g[4] = (a * (s2 * iSig)) * (Del - r2a2);
+    }
+    // __JohannsenPsaltisAD.metric_components, johannsen-psaltis-ad.jl:4-27 ; P = M, a, ϵ3
+    template <class T>
+    GR_DEV void johannsen_psaltis(T r, T s, T c, T g[5]) const
+    {
+        const real M = P[0], a = P[1], e3 = P[2];
+        const real a2 = a * a;
+        T r2 = r * r;
+        T Sig = r2 + a2 * (c * c);
+        T iSig = inv_(Sig);
+        T h = (e3 * M * M * M) * (r * (iSig * iSig));
+        T s2 = s * s;
+        T Del = r2 - (2.0 * M) * r + a2;
+        T tMr = (2.0 * M) * r;
+        T hp1 = 1.0 + h;
+        g[0] = -(hp1 * (1.0 - tMr * iSig));
+        g[1] = (Sig * hp1) * inv_(Del + a2 * (s2 * h));
+        g[2] = Sig;
+        T term1 = s2 * (r2 + a2 + (a2 * (tMr * s2)) * iSig);
+        T term2 = (h * a2) * ((Sig + tMr) * ((s2 * s2) * iSig));
+        g[3] = term1 + term2;
+        g[4] = -((a * tMr) * ((s2 * hp1) * iSig));
+    }
+
+    template <class T>
+    GR_DEV void components(T r, T s, T c, T g[5]) const
+    {
+        switch (id) {
+        case GR_METRIC_MORRIS_THORNE: morris_thorne<T>(r, s, c, g); break;
+        case GR_METRIC_BUMBLEBEE: bumblebee<T>(r, s, c, g); break;
+        case GR_METRIC_KERR_NEWMAN: kerr_newman<T>(r, s, c, g); break;
+        case GR_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis<T>(r, s, c, g); break;
+        default: johannsen<T>(r, s, c, g); break;
+        }
+    }
 
     GR_DEV void comps(real r, real s, real c, real g[5]) const { components<real>(r, s, c, g); }
 

@@ -42,7 +42,7 @@ template <class Metric, int DISC>
 __global__ void __launch_bounds__(256) k_trace_lane(const Params p)
 {
     Metric m;
-    m.load(p.cfg.params);
+    m.load(p.cfg);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     LaneStats<Metric, DISC> ls;
     if (gid < p.n) {
@@ -60,7 +60,7 @@ template <class Metric, int DISC>
 __global__ void __launch_bounds__(256) k_trace_persistent(const Params p)
 {
     Metric m;
-    m.load(p.cfg.params);
+    m.load(p.cfg);
     Ray<Metric, DISC> ray;
     LaneStats<Metric, DISC> ls;
     bool active = false, pending = false, queue_empty = false;
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(64) k_trace_path(const Params p, double* path,
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Metric m;
-    m.load(p.cfg.params);
+    m.load(p.cfg);
     Ray<Metric, DISC> ray;
     ray.init(m, p, 0);
     int64_t n = 0;
@@ -139,7 +139,7 @@ template <class Metric>
 __global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point* pts, double max_time, double* out)
 {
     Metric m;
-    m.load(p.cfg.params);
+    m.load(p.cfg);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     const gr_point gp = pts[i];
@@ -200,7 +200,7 @@ inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t 
     const bool disc = p.cfg.disc_id == GR_DISC_THIN;
     if (p.cfg.metric_id == GR_METRIC_KERR)
         return disc ? launch_tmpl<KerrMetric, 1>(k, p, stream) : launch_tmpl<KerrMetric, 0>(k, p, stream);
-    return disc ? launch_tmpl<JohannsenMetric, 1>(k, p, stream) : launch_tmpl<JohannsenMetric, 0>(k, p, stream);
+    return disc ? launch_tmpl<GenericMetric, 1>(k, p, stream) : launch_tmpl<GenericMetric, 0>(k, p, stream);
 }
 
 }  // namespace

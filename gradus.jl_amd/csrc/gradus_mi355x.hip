@@ -98,7 +98,7 @@ int32_t ensure(void** buf, size_t* cap, size_t need)
 int32_t validate_cfg(const gr_config* cfg)
 {
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
-    if (cfg->metric_id != GR_METRIC_KERR && cfg->metric_id != GR_METRIC_JOHANNSEN)
+    if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_JOHANNSEN_PSALTIS)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
     if (cfg->disc_id != GR_DISC_NONE && cfg->disc_id != GR_DISC_THIN)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
@@ -482,7 +482,7 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     if (cfg->metric_id == GR_METRIC_KERR)
         hipLaunchKernelGGL((k_apply_pf<KerrMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     else
-        hipLaunchKernelGGL((k_apply_pf<JohannsenMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
+        hipLaunchKernelGGL((k_apply_pf<GenericMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     GR_HIP(hipGetLastError());
     return GR_OK;
 }
@@ -527,8 +527,8 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const 
         if (disc) hipLaunchKernelGGL((k_trace_path<KerrMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
         else hipLaunchKernelGGL((k_trace_path<KerrMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
     } else {
-        if (disc) hipLaunchKernelGGL((k_trace_path<JohannsenMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
-        else hipLaunchKernelGGL((k_trace_path<JohannsenMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+        if (disc) hipLaunchKernelGGL((k_trace_path<GenericMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+        else hipLaunchKernelGGL((k_trace_path<GenericMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
     }
     GR_HIP(hipGetLastError());
     unsigned long long n = 0;

@@ -15,6 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 
 GR_METRIC_KERR, GR_METRIC_JOHANNSEN = 0, 1
+GR_METRIC_MORRIS_THORNE, GR_METRIC_BUMBLEBEE, GR_METRIC_KERR_NEWMAN, GR_METRIC_JOHANNSEN_PSALTIS = 2, 3, 4, 5
 
 
 class AbstractMetric:
@@ -116,6 +117,140 @@ class JohannsenMetric(AbstractStaticAxisSymmetric):
         pp = (Sig * s2) * ((r2a2 * r2a2) * (A1 * A1) - (a * a * s2) * Del)
         tp = -(a * ((Sig * s2) * (r2a2 * A1 * A2 - Del)))
         return (tt / denom, rr, Sig, pp / denom, tp / denom)
+
+    def inner_radius(self):
+        return self.M + math.sqrt(self.M ** 2 - self.a ** 2)
+
+    def isco(self):
+        from .special_radii import generic_isco
+
+        return generic_isco(self)
+
+
+@dataclass(frozen=True)
+class MorrisThorneWormhole(AbstractStaticAxisSymmetric):
+    """MorrisThorneWormhole(b = 1.0) -- src/metrics/morris-thorne-ad.jl:4-39."""
+
+    b: float = 1.0
+    metric_id = GR_METRIC_MORRIS_THORNE
+
+    def abi_params(self):
+        return [self.b]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, l, s, c):
+        w = l * l + self.b ** 2
+        # ϕϕ = (b² + l²) sin(θ): first power of sinθ, as in the reference
+        return (-1.0 + 0.0 * l, 1.0 + 0.0 * l, w, w * s, 0.0 * l)
+
+    def inner_radius(self):
+        return 0.0
+
+
+@dataclass(frozen=True)
+class BumblebeeMetric(AbstractStaticAxisSymmetric):
+    """BumblebeeMetric(M, a, l) -- src/metrics/bumblebee-ad.jl:6-52 (slow rotation, |a| < 0.3)."""
+
+    M: float = 1.0
+    a: float = 0.0
+    l: float = 0.0
+    metric_id = GR_METRIC_BUMBLEBEE
+
+    def __post_init__(self):
+        if self.l <= -1.0:
+            raise ValueError("l must be >-1")
+        if abs(self.a) > 0.3:
+            raise ValueError("This metric is for the slow rotation approximation only, and requires |a| < 0.3.")
+
+    def abi_params(self):
+        return [self.M, self.a, self.l]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        M, a, l = self.M, self.a, self.l
+        s2 = s * s
+        Del = (r * r - 2.0 * M * r) / (l + 1.0)
+        return (-(1.0 - 2.0 * M / r), r * r / Del, r * r, r * r * s2, (-2.0 * M * a * s2) / r)
+
+    def inner_radius(self):
+        return self.M + math.sqrt(self.M ** 2 - self.a ** 2)
+
+    def isco(self):
+        from .special_radii import generic_isco
+
+        return generic_isco(self)
+
+
+@dataclass(frozen=True)
+class KerrNewmanMetric(AbstractStaticAxisSymmetric):
+    """KerrNewmanMetric(M, a, Q) -- src/metrics/kerr-newman-ad.jl:6-64.  Null / uncharged
+    geodesics only: the Lorentz-force term of a charged test particle (q ≠ 0) is not on the device."""
+
+    M: float = 1.0
+    a: float = 0.0
+    Q: float = 0.0
+    metric_id = GR_METRIC_KERR_NEWMAN
+
+    def __post_init__(self):
+        if self.a ** 2 + self.Q ** 2 > self.M ** 2:
+            raise ValueError("Value error: `a^2 + Q^2` must be `<= M^2`")
+
+    def abi_params(self):
+        return [self.M, self.a, self.Q]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        M, a, Q = self.M, self.a, self.Q
+        Sig = r * r + (a * c) ** 2
+        s2 = s * s
+        Del = r * r - 2.0 * M * r + a * a + Q * Q
+        r2a2 = r * r + a * a
+        return ((a * a * s2 - Del) / Sig, Sig / Del, Sig, (s2 / Sig) * (r2a2 * r2a2 - a * a * s2 * Del),
+                (a * s2 / Sig) * (Del - r2a2))
+
+    def inner_radius(self):
+        return self.M + math.sqrt(self.M ** 2 - self.a ** 2 - self.Q ** 2)
+
+    def isco(self):
+        from .special_radii import generic_isco
+
+        return generic_isco(self)
+
+
+@dataclass(frozen=True)
+class JohannsenPsaltisMetric(AbstractStaticAxisSymmetric):
+    """JohannsenPsaltisMetric(M, a, ϵ3) -- src/metrics/johannsen-psaltis-ad.jl:4-46."""
+
+    M: float = 1.0
+    a: float = 0.0
+    eps3: float = 0.0
+    metric_id = GR_METRIC_JOHANNSEN_PSALTIS
+
+    def abi_params(self):
+        return [self.M, self.a, self.eps3]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        M, a, e3 = self.M, self.a, self.eps3
+        Sig = r * r + a * a * (c * c)
+        h = (e3 * M ** 3) * r / (Sig * Sig)
+        s2 = s * s
+        Del = r * r - 2.0 * M * r + a * a
+        tMr = 2.0 * M * r
+        tt = -((1.0 + h) * (1.0 - tMr / Sig))
+        rr = Sig * (1.0 + h) / (Del + (a * a * s2) * h)
+        term1 = s2 * (r * r + a * a + (a * a * s2) * tMr / Sig)
+        term2 = (h * (a * a)) * (Sig + tMr) * (s2 * s2) / Sig
+        tp = -((a * tMr) * (s2 * (1.0 + h)) / Sig)
+        return (tt, rr, Sig, term1 + term2, tp)
 
     def inner_radius(self):
         return self.M + math.sqrt(self.M ** 2 - self.a ** 2)

@@ -50,9 +50,20 @@ enum {
 };
 
 /* AbstractStaticAxisSymmetric metrics available on the device.
- *   KERR       src/metrics/kerr-metric.jl:11-28,62-72        params = {M, a}
- *   JOHANNSEN  src/metrics/johannsen-ad.jl:12-34,49-67       params = {M, a, α13, α22, α52, ϵ3} */
-enum { GR_METRIC_KERR = 0, GR_METRIC_JOHANNSEN = 1 };
+ *   KERR               src/metrics/kerr-metric.jl:11-28,62-72          params = {M, a}
+ *   JOHANNSEN          src/metrics/johannsen-ad.jl:12-34,49-67         params = {M, a, α13, α22, α52, ϵ3}
+ *   MORRIS_THORNE      src/metrics/morris-thorne-ad.jl:4-39            params = {b}
+ *   BUMBLEBEE          src/metrics/bumblebee-ad.jl:6-52                params = {M, a, l}
+ *   KERR_NEWMAN        src/metrics/kerr-newman-ad.jl:6-64 (null rays / q = 0 only)   params = {M, a, Q}
+ *   JOHANNSEN_PSALTIS  src/metrics/johannsen-psaltis-ad.jl:4-46        params = {M, a, ϵ3} */
+enum {
+    GR_METRIC_KERR = 0,
+    GR_METRIC_JOHANNSEN = 1,
+    GR_METRIC_MORRIS_THORNE = 2,
+    GR_METRIC_BUMBLEBEE = 3,
+    GR_METRIC_KERR_NEWMAN = 4,
+    GR_METRIC_JOHANNSEN_PSALTIS = 5
+};
 
 /* accretion geometry: ThinDisc -- src/geometry/discs/thin-disc.jl:9-26 */
 enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1 };

@@ -120,10 +120,14 @@ static inline j2 j2_cos(j2 x) { return j2_const(cos(x.v)); }
 static void metric_d2(const orc_config* c, double r, double th, d2 g[5])
 {
     d2 rr = { r, 1.0, 0.0 }, tt = { th, 0.0, 1.0 };
-    if (c->metric_id == ORC_METRIC_JOHANNSEN)
-        johannsen_components_d2(c->params, rr, tt, g);
-    else
-        kerr_components_d2(c->params, rr, tt, g);
+    switch (c->metric_id) {
+    case ORC_METRIC_JOHANNSEN: johannsen_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_MORRIS_THORNE: morris_thorne_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_BUMBLEBEE: bumblebee_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_KERR_NEWMAN: kerr_newman_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis_components_d2(c->params, rr, tt, g); break;
+    default: kerr_components_d2(c->params, rr, tt, g);
+    }
 }
 
 void orc_metric_jacobian(const orc_config* c, double r, double th, double g[5], double dr[5], double dth[5])
@@ -742,8 +746,14 @@ static void energy_jet(const orc_config* c, double r, double* E, double* dE)
 {
     j2 g[5];
     j2 rr = { r, 1.0, 0.0 }, th = { M_PI / 2.0, 0.0, 0.0 };
-    if (c->metric_id == ORC_METRIC_JOHANNSEN) johannsen_components_j2(c->params, rr, th, g);
-    else kerr_components_j2(c->params, rr, th, g);
+    switch (c->metric_id) {
+    case ORC_METRIC_JOHANNSEN: johannsen_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_MORRIS_THORNE: morris_thorne_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_BUMBLEBEE: bumblebee_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_KERR_NEWMAN: kerr_newman_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis_components_j2(c->params, rr, th, g); break;
+    default: kerr_components_j2(c->params, rr, th, g);
+    }
     /* first-order duals in r: metric g = (v,d); its r-derivative ∂g = (d,dd) */
     double gv[5], gd[5], pv[5], pd[5];
     for (int i = 0; i < 5; ++i) { gv[i] = g[i].v; gd[i] = g[i].d; pv[i] = g[i].d; pd[i] = g[i].dd; }

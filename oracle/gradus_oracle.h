@@ -39,7 +39,8 @@ enum {
     ORC_NO_STATUS = 3
 };
 
-enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1 };
+enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE = 2, ORC_METRIC_BUMBLEBEE = 3,
+       ORC_METRIC_KERR_NEWMAN = 4, ORC_METRIC_JOHANNSEN_PSALTIS = 5 };
 enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1 };
 
 /* per-ray anomaly flags (SciML retcodes that EnsembleEndpointThreads swallows) */

@@ -69,3 +69,73 @@ static void FN(johannsen_components)(const double* p, NUM r, NUM th, NUM g[5])
     g[3] = N_DIV(pp, denom);
     g[4] = N_DIV(tp, denom);
 }
+
+/* __MorrisThorneAD.metric_components, src/metrics/morris-thorne-ad.jl:4-15 (ϕϕ has sinθ to the
+ * first power in the reference; reproduced as is) */
+static void FN(morris_thorne_components)(const double* p, NUM l, NUM th, NUM g[5])
+{
+    const double b = p[0];
+    NUM w = N_ADD(N_CONST(b * b), N_MUL(l, l));
+    g[0] = N_CONST(-1.0);
+    g[1] = N_CONST(1.0);
+    g[2] = w;
+    g[3] = N_MUL(w, N_SIN(th));
+    g[4] = N_CONST(0.0);
+}
+
+/* __BumblebeeAD.metric_components, src/metrics/bumblebee-ad.jl:6-21 */
+static void FN(bumblebee_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1], l = p[2];
+    NUM s = N_SIN(th);
+    NUM s2 = N_MUL(s, s);
+    NUM r2 = N_MUL(r, r);
+    NUM Delta = N_SCALE(1.0 / (l + 1.0), N_SUB(r2, N_SCALE(2.0 * M, r)));     /* Δ :6 */
+    g[0] = N_NEG(N_SUB(N_CONST(1.0), N_DIV(N_CONST(2.0 * M), r)));
+    g[1] = N_DIV(r2, Delta);
+    g[2] = r2;
+    g[3] = N_MUL(r2, s2);
+    g[4] = N_DIV(N_SCALE(-2.0 * M * a, s2), r);
+}
+
+/* __KerrNewmanAD.metric_components, src/metrics/kerr-newman-ad.jl:6-27 */
+static void FN(kerr_newman_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1], Q = p[2];
+    const double R = 2.0 * M;
+    NUM c = N_COS(th);
+    NUM ac = N_SCALE(a, c);
+    NUM r2 = N_MUL(r, r);
+    NUM Sig = N_ADD(r2, N_MUL(ac, ac));
+    NUM s = N_SIN(th);
+    NUM s2 = N_MUL(s, s);
+    NUM Delta = N_ADD(N_SUB(r2, N_SCALE(R, r)), N_CONST(a * a + Q * Q));
+    NUM r2a2 = N_ADD(r2, N_CONST(a * a));
+    g[0] = N_DIV(N_SUB(N_SCALE(a * a, s2), Delta), Sig);
+    g[1] = N_DIV(Sig, Delta);
+    g[2] = Sig;
+    g[3] = N_MUL(N_DIV(s2, Sig), N_SUB(N_MUL(r2a2, r2a2), N_SCALE(a * a, N_MUL(s2, Delta))));
+    g[4] = N_MUL(N_DIV(N_SCALE(a, s2), Sig), N_SUB(Delta, r2a2));
+}
+
+/* __JohannsenPsaltisAD.metric_components, src/metrics/johannsen-psaltis-ad.jl:4-27 */
+static void FN(johannsen_psaltis_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1], e3 = p[2];
+    NUM c = N_COS(th);
+    NUM r2 = N_MUL(r, r);
+    NUM Sig = N_ADD(r2, N_SCALE(a * a, N_MUL(c, c)));
+    NUM h = N_DIV(N_SCALE(e3 * M * M * M, r), N_MUL(Sig, Sig));                 /* h :4 */
+    NUM s = N_SIN(th);
+    NUM s2 = N_MUL(s, s);
+    NUM Delta = N_ADD(N_SUB(r2, N_SCALE(2.0 * M, r)), N_CONST(a * a));
+    NUM hp1 = N_ADD(N_CONST(1.0), h);
+    NUM tMr = N_SCALE(2.0 * M, r);
+    g[0] = N_NEG(N_MUL(hp1, N_SUB(N_CONST(1.0), N_DIV(tMr, Sig))));
+    g[1] = N_DIV(N_MUL(Sig, hp1), N_ADD(Delta, N_SCALE(a * a, N_MUL(s2, h))));
+    g[2] = Sig;
+    NUM term1 = N_MUL(s2, N_ADD(N_ADD(r2, N_CONST(a * a)), N_DIV(N_SCALE(a * a, N_MUL(tMr, s2)), Sig)));
+    NUM term2 = N_DIV(N_MUL(N_SCALE(a * a, h), N_MUL(N_ADD(Sig, tMr), N_MUL(s2, s2))), Sig);
+    g[3] = N_ADD(term1, term2);
+    g[4] = N_NEG(N_DIV(N_MUL(N_SCALE(a, tMr), N_MUL(s2, hp1)), Sig));
+}

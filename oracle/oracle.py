@@ -17,6 +17,8 @@ _LIB_PATH = os.path.join(_HERE, "libgradus_oracle.so")
 
 OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 1, 2, 3
 METRIC_KERR, METRIC_JOHANNSEN = 0, 1
+METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "kerr-newman": 4,
+              "johannsen-psaltis": 5}
 DISC_NONE, DISC_THIN = 0, 1
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
@@ -128,9 +130,18 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def inner_radius(M, a):
-    # inner_radius(m::KerrMetric) = M + sqrt(M^2 - a^2), kerr-metric.jl:72 (same for Johannsen)
-    return M + math.sqrt(M * M - a * a)
+def inner_radius(M, a, Q=0.0):
+    # inner_radius(m::KerrMetric) = M + sqrt(M^2 - a^2), kerr-metric.jl:72 (same for Johannsen,
+    # Bumblebee, Johannsen-Psaltis; Kerr-Newman: M + sqrt(M^2 - a^2 - Q^2), kerr-newman-ad.jl:62)
+    return M + math.sqrt(M * M - a * a - Q * Q)
+
+
+def metric_inner_radius(metric, params):
+    if metric == "morris-thorne":
+        return 0.0                      # morris-thorne-ad.jl:37
+    if metric == "kerr-newman":
+        return inner_radius(params[0], params[1], params[2])
+    return inner_radius(params[0], params[1])
 
 
 def make_config(
@@ -150,10 +161,10 @@ def make_config(
     maxiters=1_000_000,
 ) -> Config:
     c = Config()
-    c.metric_id = METRIC_KERR if metric == "kerr" else METRIC_JOHANNSEN
+    c.metric_id = METRIC_IDS[metric]
     for i, p in enumerate(params):
         c.params[i] = float(p)
-    c.r_inner = inner_radius(params[0], params[1]) * closest_approach
+    c.r_inner = metric_inner_radius(metric, params) * closest_approach
     c.r_outer = outer_radius
     if disc is None:
         c.disc_id = DISC_NONE

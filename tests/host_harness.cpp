@@ -12,7 +12,7 @@ template <class Metric, int DISC>
 static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
 {
     Metric m;
-    m.load(p.cfg.params);
+    m.load(p.cfg);
     for (int64_t j = 0; j < n; ++j) {
         Ray<Metric, DISC> ray;
         ray.init(m, p, j);
@@ -35,7 +35,7 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
     if (p.cfg.metric_id == GR_METRIC_KERR) {
         if (disc) run<KerrMetric, 1>(p, p.n, tlog, hlog, cap, nlog); else run<KerrMetric, 0>(p, p.n, tlog, hlog, cap, nlog);
     } else {
-        if (disc) run<JohannsenMetric, 1>(p, p.n, tlog, hlog, cap, nlog); else run<JohannsenMetric, 0>(p, p.n, tlog, hlog, cap, nlog);
+        if (disc) run<GenericMetric, 1>(p, p.n, tlog, hlog, cap, nlog); else run<GenericMetric, 0>(p, p.n, tlog, hlog, cap, nlog);
     }
 }
 

@@ -15,7 +15,9 @@ RTOL = 1e-6
 
 
 def _metric(G, name, params):
-    return G.KerrMetric(*params) if name == "kerr" else G.JohannsenMetric(*params)
+    return {"kerr": G.KerrMetric, "johannsen": G.JohannsenMetric, "morris-thorne": G.MorrisThorneWormhole,
+            "bumblebee": G.BumblebeeMetric, "kerr-newman": G.KerrNewmanMetric,
+            "johannsen-psaltis": G.JohannsenPsaltisMetric}[name](*params)
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
@@ -26,6 +28,11 @@ def _metric(G, name, params):
         ("johannsen", (1.0, 0.0, 0.0, 0.0, 0.0, 0.0), None, 9009.448935932085),
         ("kerr", (1.0, 0.0), (0.0, 40.0), 38412.08347901267),
         ("johannsen", (1.0, 0.0, 0.0, 0.0, 0.0, 0.0), (0.0, 40.0), 38412.08386562321),
+        ("bumblebee", (1.0, 0.0, 0.0), None, 9009.452384885506),
+        ("kerr-newman", (1.0, 0.0, 0.0), None, 9009.451384824908),
+        ("morris-thorne", (1.0,), (0.0, 40.0), 9375.430228131403),
+        ("bumblebee", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.0832157869),
+        ("kerr-newman", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.08517225652),
     ],
 )
 def test_reference_fingerprints_on_device(G, ens, kernel, name, params, disc, expected):
@@ -412,3 +419,20 @@ def test_ragged_range_without_tiles(G, oracle, ens):
     lin = full.T.ravel()[first:first + count]
     np.testing.assert_array_equal(np.isnan(out), np.isnan(lin))
     np.testing.assert_array_equal(out[~np.isnan(out)], lin[~np.isnan(lin)])
+
+
+
+def test_more_reference_fingerprints_on_device(G, ens):
+    """Morris-Thorne shadow (rendergeodesics.jl:44), Johannsen-Psaltis chart test
+    (test/integration/test-charts.jl:5-18) and Kerr-Newman q = 0 (test/unit/metrics.kerr-newman.jl:25)."""
+    ens.set("kernel", 1).set("precision", 64)
+    _, _, img = G.rendergeodesics(G.MorrisThorneWormhole(1.0), X_SMOKE, 200.0, image_width=20, image_height=20,
+                                  alpha_lims=(-9.5, 9.5), beta_lims=(-9.5, 9.5), ensemble=ens)
+    assert float(np.nansum(img)) == pytest.approx(402.17907632733284, rel=1e-4)
+    u = np.array([0.0, 1000.0, math.pi / 2, 0.0])
+    _, _, img = G.rendergeodesics(G.JohannsenPsaltisMetric(1.0, 0.8831, 0.4), u, 2000.0, image_width=100,
+                                  image_height=100, alpha_lims=(-8, 8), beta_lims=(-8, 8), ensemble=ens)
+    assert float(np.nansum(img)) == pytest.approx(2.9619136946153212e6, rel=1e-6)
+    _, _, img = G.rendergeodesics(G.KerrNewmanMetric(1.0, 0.6, 0.6), u, 2000.0, image_width=40, image_height=40,
+                                  alpha_lims=(-8, 8), beta_lims=(-8, 8), ensemble=ens)
+    assert float(np.nansum(img)) == pytest.approx(428809.9681726607, rel=1e-6)

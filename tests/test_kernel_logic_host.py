@@ -31,6 +31,32 @@ def test_reference_fingerprints_kernel_logic(G, name, params, disc, expected):
     assert float(np.nansum(img)) == pytest.approx(expected, rel=1e-6)
 
 
+def _metric_by_name(G, name, params):
+    return {"kerr": G.KerrMetric, "johannsen": G.JohannsenMetric, "morris-thorne": G.MorrisThorneWormhole,
+            "bumblebee": G.BumblebeeMetric, "kerr-newman": G.KerrNewmanMetric,
+            "johannsen-psaltis": G.JohannsenPsaltisMetric}[name](*params)
+
+
+@pytest.mark.parametrize(
+    "name,params,disc,expected,rtol",
+    [
+        ("morris-thorne", (1.0,), None, 402.17907632733284, 1e-4),
+        ("bumblebee", (1.0, 0.0, 0.0), None, 9009.452384885506, 1e-6),
+        ("kerr-newman", (1.0, 0.0, 0.0), None, 9009.451384824908, 1e-6),
+        ("morris-thorne", (1.0,), (0.0, 40.0), 9375.430228131403, 1e-6),
+        ("bumblebee", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.0832157869, 1e-6),
+        ("kerr-newman", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.08517225652, 1e-6),
+    ],
+)
+def test_other_metric_fingerprints_kernel_logic(G, name, params, disc, expected, rtol):
+    m = _metric_by_name(G, name, params)
+    args = (G.ThinDisc(*disc), 200.0) if disc else (200.0,)
+    cfg = G.render_configuration(m, X_SMOKE, *args, image_width=20, image_height=20, alpha_lims=(-9.5, 9.5),
+                                 beta_lims=(-9.5, 9.5))
+    img = Hh.render(G, cfg, G.ConstPointFunctions.shadow())
+    assert float(np.nansum(img)) == pytest.approx(expected, rel=rtol)
+
+
 @pytest.mark.parametrize("name,params", [("kerr", (1.0, 0.998)), ("johannsen", (1.0, 0.7, 2.0, 0.0, 0.0, 1.0))])
 def test_endpoints_vs_oracle_kernel_logic(G, oracle, name, params):
     m = G.KerrMetric(*params) if name == "kerr" else G.JohannsenMetric(*params)

@@ -32,6 +32,36 @@ def test_rendergeodesics_fingerprints(oracle, metric, params, disc, expected):
     assert got == pytest.approx(expected, rel=1e-6)
 
 
+# the other AbstractStaticAxisSymmetric metrics of the same reference test (rendergeodesics.jl:32-67);
+# Morris-Thorne's shadow is the sum over a handful of rays that cross the throat (l <= 0) where steps
+# are large, so its recorded value is only good to the size of one step (3e-5)
+@pytest.mark.parametrize(
+    "metric,params,disc,expected,rtol",
+    [
+        ("morris-thorne", (1.0,), None, 402.17907632733284, 1e-4),
+        ("bumblebee", (1.0, 0.0, 0.0), None, 9009.452384885506, 1e-6),
+        ("kerr-newman", (1.0, 0.0, 0.0), None, 9009.451384824908, 1e-6),
+        ("morris-thorne", (1.0,), (0.0, 40.0), 9375.430228131403, 1e-6),
+        ("bumblebee", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.0832157869, 1e-6),
+        ("kerr-newman", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.08517225652, 1e-6),
+    ],
+)
+def test_rendergeodesics_fingerprints_other_metrics(oracle, metric, params, disc, expected, rtol):
+    assert _fingerprint(oracle, metric, params, disc) == pytest.approx(expected, rel=rtol)
+
+
+def test_johannsen_psaltis_chart_and_kerr_newman_fingerprints(oracle):
+    u = np.array([0.0, 1000.0, math.pi / 2, 0.0])
+    # test/integration/test-charts.jl:5-18 (rtol 1e-4 there)
+    cfg = oracle.make_config("johannsen-psaltis", (1.0, 0.8831, 0.4), lambda_max=2000.0)
+    img = oracle.rendergeodesics(cfg, u, (-8, 8), (-8, 8), 100, 100)
+    assert float(np.nansum(img)) == pytest.approx(2.9619136946153212e6, rel=1e-6)
+    # test/unit/metrics.kerr-newman.jl:7-25, q = 0 (rtol 1e-3 there)
+    cfg = oracle.make_config("kerr-newman", (1.0, 0.6, 0.6), lambda_max=2000.0)
+    img = oracle.rendergeodesics(cfg, u, (-8, 8), (-8, 8), 40, 40)
+    assert float(np.nansum(img)) == pytest.approx(428809.9681726607, rel=1e-6)
+
+
 def _count_inner(O, G, plane):
     # test/image-planes/test-polar-grids.jl:9-21, test/utils.jl:1-4
     m = G.KerrMetric()
