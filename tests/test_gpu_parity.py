@@ -436,3 +436,36 @@ def test_more_reference_fingerprints_on_device(G, ens):
     _, _, img = G.rendergeodesics(G.KerrNewmanMetric(1.0, 0.6, 0.6), u, 2000.0, image_width=40, image_height=40,
                                   alpha_lims=(-8, 8), beta_lims=(-8, 8), ensemble=ens)
     assert float(np.nansum(img)) == pytest.approx(428809.9681726607, rel=1e-6)
+
+
+def test_against_committed_golden_fixtures(G, ens):
+    """tests/golden/*.npz (oracle output committed after the oracle was pinned on the reference's
+    golden values; generator: tests/golden/make_fixtures.py)."""
+    import os
+
+    ens.set("kernel", 1).set("precision", 64)
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    f = np.load(os.path.join(gdir, "kerr_a0_thindisc_20x20_endpoints.npz"))
+    m = G.KerrMetric(*f["params"])
+    _, _, cache = G.prerendergeodesics(m, f["x_obs"], G.ThinDisc(*f["disc"]), float(f["lambda_max"]),
+                                       image_width=int(f["W"]), image_height=int(f["H"]), alpha_lims=tuple(f["alims"]),
+                                       beta_lims=tuple(f["blims"]), ensemble=ens)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    ref = f["points"]
+    assert (got["status"] != ref["status"]).sum() <= 1
+    ok = (got["status"] == ref["status"]) & (ref["status"] != 1)
+    np.testing.assert_allclose(got["lambda_max"][ok], ref["lambda_max"][ok], rtol=RTOL)
+    np.testing.assert_allclose(got["x"][ok], ref["x"][ok], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(got["v"][ok], ref["v"][ok], rtol=RTOL, atol=1e-9)
+
+    f = np.load(os.path.join(gdir, "kerr_a0998_c1_64x64_redshift.npz"))
+    m = G.KerrMetric(*f["params"])
+    pf = G.ConstPointFunctions.redshift(m, f["x_obs"]) @ G.ConstPointFunctions.filter_intersected()
+    _, _, img = G.rendergeodesics(m, f["x_obs"], G.ThinDisc(*f["disc"]), float(f["lambda_max"]), image_width=int(f["W"]),
+                                  image_height=int(f["H"]), alpha_lims=tuple(f["alims"]), beta_lims=tuple(f["blims"]),
+                                  pf=pf, ensemble=ens)
+    ref = f["image"]
+    assert (np.isnan(img) != np.isnan(ref)).sum() <= 4
+    both = ~np.isnan(img) & ~np.isnan(ref)
+    assert both.sum() > 2000
+    np.testing.assert_allclose(img[both], ref[both], rtol=RTOL)

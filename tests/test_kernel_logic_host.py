@@ -132,3 +132,19 @@ def test_fast_sincos_and_metric_derivatives(G, oracle):
     np.testing.assert_allclose(got["v_init"], ref["v_init"], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(got["x"], ref["x"], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(got["v"], ref["v"], rtol=1e-10, atol=1e-12)
+
+
+def test_kernel_logic_against_committed_golden_fixture(G):
+    import os
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    f = np.load(os.path.join(gdir, "kerr_a0998_c1_64x64_redshift.npz"))
+    m = G.KerrMetric(*f["params"])
+    cfg = G.render_configuration(m, f["x_obs"], G.ThinDisc(*f["disc"]), float(f["lambda_max"]), image_width=int(f["W"]),
+                                 image_height=int(f["H"]), alpha_lims=tuple(f["alims"]), beta_lims=tuple(f["blims"]))
+    pf = G.ConstPointFunctions.redshift(m, f["x_obs"]) @ G.ConstPointFunctions.filter_intersected()
+    img = Hh.render(G, cfg, pf)
+    ref = f["image"]
+    assert (np.isnan(img) != np.isnan(ref)).sum() <= 4
+    both = ~np.isnan(img) & ~np.isnan(ref)
+    np.testing.assert_allclose(img[both], ref[both], rtol=1e-6)
