@@ -49,6 +49,7 @@ class gr_config(C.Structure):
         ("upper_hemisphere", C.c_int32),
         ("_pad", C.c_int32),
         ("hemi_delta", C.c_double),
+        ("disc_params", C.c_double * 4),
     ]
 
 

@@ -804,12 +804,20 @@ struct Ray {
     real dbg_e2;
 #endif
 
-    // distance_to_disc(::ThinDisc), thin-disc.jl:20-26
+    // distance_to_disc(::ThinDisc), thin-disc.jl:20-26 ; distance_to_disc(::AbstractThickAccretionDisc),
+    // thick-disc.jl:60-66 with cross_section(::ShakuraSunyaev), shakura-sunyaev.jl:28-33
     static GR_DEV real disc_cond(const Params& p, real r, real s, real c)
     {
         const real rho = r * GR_FABS(s);
-        if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
-        return r * GR_FABS(c) - p.cfg.gtol * GR_FABS(r);
+        if (p.cfg.disc_id == GR_DISC_THIN) {
+            if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
+            return r * GR_FABS(c) - p.cfg.gtol * GR_FABS(r);
+        }
+        const real rin = p.cfg.disc_r_in;
+        if (rho < rin) return 1.0;
+        const real height = 3.0 * (real)p.cfg.disc_params[1] * (real)p.cfg.disc_params[0] * (1.0 - sqrt_fast(rin * rcp_full(rho)));
+        if (height <= 0.0) return 1.0;
+        return r * GR_FABS(c) - height;
     }
 
     // DiscreteCallbacks in CallbackSet order: domain_upper_hemisphere, then the chart
@@ -1122,7 +1130,8 @@ struct Ray {
     GR_DEV int sample_event(const Params& p, int ps, real hh) const
     {
         const real wedge = p.wedge;
-        if (ps > 0) {
+        const bool thin = p.cfg.disc_id == GR_DISC_THIN;
+        if (thin && ps > 0) {
             // |θ(Θ_j) - θ_0| <= h (Θ_j |v^θ| + h Σ_i |RXΣ_i(Θ_j)| |A_i^θ|) <= h (|v^θ| + K h max_i |A_i^θ|)
             real amax = GR_FABS(A[0][2]);
 #pragma unroll
@@ -1132,18 +1141,32 @@ struct Ray {
             d0 -= 3.141592653589793 * GR_RINT(d0 * 0.3183098861837907);
             if (GR_FABS(d0) - reach > wedge) return 0;
         }
-        real Ct[4];
+        real Ct[4], Cr[4];
         dense_coeffs(2, hh, Ct);
         bool any = (ps < 0);
+        if (thin) {
 #pragma unroll
-        for (int jj = 0; jj < 6; ++jj) {
-            real d = dense_eval(x[2], hh, Ct, (real)(jj + 1) / 7.0) - 1.5707963267948966;
-            d -= 3.141592653589793 * GR_RINT(d * 0.3183098861837907);
-            any |= (GR_FABS(d) < wedge);
+            for (int jj = 0; jj < 6; ++jj) {
+                real d = dense_eval(x[2], hh, Ct, (real)(jj + 1) / 7.0) - 1.5707963267948966;
+                d -= 3.141592653589793 * GR_RINT(d * 0.3183098861837907);
+                any |= (GR_FABS(d) < wedge);
+            }
+            if (!any) return 0;
+            dense_coeffs(1, hh, Cr);
+        } else {
+            // thick disc of bounded height Hmax: a sample can only be inside if |z| = r |sin d| < Hmax,
+            // and |sin d| >= (2/π)|d|, so |d| r >= (π/2) Hmax rules it out
+            dense_coeffs(1, hh, Cr);
+            const real hmax = 1.5707963267948966 * 3.0 * (real)p.cfg.disc_params[1] * (real)p.cfg.disc_params[0] * 1.000001;
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {
+                const real th = (real)(jj + 1) / 7.0;
+                real d = dense_eval(x[2], hh, Ct, th) - 1.5707963267948966;
+                d -= 3.141592653589793 * GR_RINT(d * 0.3183098861837907);
+                any |= (GR_FABS(d) * GR_FABS(dense_eval(x[1], hh, Cr, th)) < hmax);
+            }
+            if (!any) return 0;
         }
-        if (!any) return 0;
-        real Cr[4];
-        dense_coeffs(1, hh, Cr);
         for (int jj = 1; jj <= 6; ++jj) {
             const real th = (real)jj / 7.0;
             real s, c;

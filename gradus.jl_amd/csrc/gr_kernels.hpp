@@ -197,7 +197,7 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 
 inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
-    const bool disc = p.cfg.disc_id == GR_DISC_THIN;
+    const bool disc = p.cfg.disc_id != GR_DISC_NONE;
     if (p.cfg.metric_id == GR_METRIC_KERR)
         return disc ? launch_tmpl<KerrMetric, 1>(k, p, stream) : launch_tmpl<KerrMetric, 0>(k, p, stream);
     return disc ? launch_tmpl<GenericMetric, 1>(k, p, stream) : launch_tmpl<GenericMetric, 0>(k, p, stream);

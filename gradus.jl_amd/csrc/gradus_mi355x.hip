@@ -100,7 +100,7 @@ int32_t validate_cfg(const gr_config* cfg)
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
     if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_JOHANNSEN_PSALTIS)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
-    if (cfg->disc_id != GR_DISC_NONE && cfg->disc_id != GR_DISC_THIN)
+    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_SHAKURA_SUNYAEV)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
     if (!(cfg->abstol > 0.0) || !(cfg->reltol > 0.0))
         return fail(GR_ERR_INVALID_ARGUMENT, "abstol and reltol must be positive");
@@ -522,7 +522,7 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const 
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, ctx->stream));
     p.cold = slot;
-    const bool disc = cfg->disc_id == GR_DISC_THIN;
+    const bool disc = cfg->disc_id != GR_DISC_NONE;
     if (cfg->metric_id == GR_METRIC_KERR) {
         if (disc) hipLaunchKernelGGL((k_trace_path<KerrMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
         else hipLaunchKernelGGL((k_trace_path<KerrMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);

@@ -14,7 +14,7 @@ from typing import Callable, Optional
 import numpy as np
 
 from . import _lib
-from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, ThinDisc
+from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, ShakuraSunyaev, ThinDisc
 from .metrics import AbstractMetric
 from .orthonormalization import lnrbasis
 
@@ -146,6 +146,10 @@ class TracingConfiguration:
         elif isinstance(self.geometry, ThinDisc):
             c.disc_id = self.geometry.disc_id
             c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float(self.geometry.outer_radius)
+        elif isinstance(self.geometry, ShakuraSunyaev):
+            c.disc_id = self.geometry.disc_id
+            c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float("inf")
+            c.disc_params[0], c.disc_params[1] = float(self.geometry.Ṁ_Ṁedd), float(self.geometry.inv_η)
         else:
             raise NotImplementedError(f"geometry {type(self.geometry).__name__} has no device implementation")
         c.gtol = float(self.gtol)

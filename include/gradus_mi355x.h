@@ -65,8 +65,12 @@ enum {
     GR_METRIC_JOHANNSEN_PSALTIS = 5
 };
 
-/* accretion geometry: ThinDisc -- src/geometry/discs/thin-disc.jl:9-26 */
-enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1 };
+/* accretion geometry
+ *   THIN             ThinDisc        src/geometry/discs/thin-disc.jl:9-26       disc_r_in, disc_r_out, gtol
+ *   SHAKURA_SUNYAEV  ShakuraSunyaev  src/geometry/discs/shakura-sunyaev.jl:22-33 disc_r_in = inner_radius,
+ *                    disc_params = {Ṁ/Ṁ_Edd, 1/η}; height 3 (1/η)(Ṁ/Ṁ_Edd)(1 - sqrt(r_in/ρ)); thick-disc
+ *                    distance_to_disc of src/geometry/discs/thick-disc.jl:60-66 (no gtol) */
+enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2 };
 
 /* per-ray anomaly bits written next to the status (SciML retcodes MaxIters /
  * DtLessThanMin / Unstable, which EnsembleEndpointThreads discards, tracing.jl:250) */
@@ -91,6 +95,7 @@ typedef struct gr_config {
     int32_t upper_hemisphere; /* 1 = domain_upper_hemisphere callback (callbacks.jl:31)  */
     int32_t _pad;
     double hemi_delta;        /* its δ, default 1e-4                                     */
+    double disc_params[4];    /* extra geometry parameters, see GR_DISC_*                */
 } gr_config;
 
 /* GeodesicPoint{Float64,Nothing} -- src/solution-processing.jl:15-32.  152 bytes, same

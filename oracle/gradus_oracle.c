@@ -463,6 +463,15 @@ static double disc_condition(const orc_config* c, const double u[8])
 {
     const double r = u[1], th = u[2];
     const double rho = r * fabs(sin(th));
+    if (c->disc_id == ORC_DISC_SHAKURA_SUNYAEV) {
+        /* cross_section(::ShakuraSunyaev), geometry/discs/shakura-sunyaev.jl:28-33 ;
+         * distance_to_disc(::AbstractThickAccretionDisc), geometry/discs/thick-disc.jl:60-66 */
+        double height;
+        if (rho < c->disc_r_in) height = -0.0;
+        else height = 3.0 * c->disc_params[1] * c->disc_params[0] * (1.0 - sqrt(c->disc_r_in / rho));
+        if (height <= 0.0) return 1.0;
+        return r * fabs(cos(th)) - height;
+    }
     if (rho < c->disc_r_in || rho > c->disc_r_out) return 1.0;
     return r * fabs(cos(th)) - c->gtol * fabs(r);
 }
@@ -600,7 +609,7 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
 
             /* ---- handle_callbacks!: continuous first (App. A.5) ---- */
             int event = 0;
-            if (c->disc_id == ORC_DISC_THIN) {
+            if (c->disc_id != ORC_DISC_NONE) {
                 const double cprev = disc_condition(c, u); n_cond++;
                 const double cnext = disc_condition(c, unew); n_cond++;
                 const int ps = sgn(cprev);

@@ -41,7 +41,7 @@ enum {
 
 enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE = 2, ORC_METRIC_BUMBLEBEE = 3,
        ORC_METRIC_KERR_NEWMAN = 4, ORC_METRIC_JOHANNSEN_PSALTIS = 5 };
-enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1 };
+enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1, ORC_DISC_SHAKURA_SUNYAEV = 2 };
 
 /* per-ray anomaly flags (SciML retcodes that EnsembleEndpointThreads swallows) */
 enum { ORC_FLAG_MAXITERS = 1, ORC_FLAG_DTMIN = 2, ORC_FLAG_NAN = 4 };
@@ -60,6 +60,7 @@ typedef struct {
     int32_t upper_hemisphere; /* domain_upper_hemisphere callback enabled */
     int32_t _pad;
     double hemi_delta;
+    double disc_params[4];  /* ShakuraSunyaev: Mdot/Mdot_Edd, 1/eta */
 } orc_config;
 
 /* GeodesicPoint{Float64,Nothing}, src/solution-processing.jl:15-32; 152 bytes */

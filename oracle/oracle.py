@@ -19,7 +19,7 @@ OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 
 METRIC_KERR, METRIC_JOHANNSEN = 0, 1
 METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "kerr-newman": 4,
               "johannsen-psaltis": 5}
-DISC_NONE, DISC_THIN = 0, 1
+DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV = 0, 1, 2
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
 
@@ -43,6 +43,7 @@ class Config(C.Structure):
         ("upper_hemisphere", C.c_int32),
         ("_pad", C.c_int32),
         ("hemi_delta", C.c_double),
+        ("disc_params", C.c_double * 4),
     ]
 
 
@@ -168,6 +169,10 @@ def make_config(
     c.r_outer = outer_radius
     if disc is None:
         c.disc_id = DISC_NONE
+    elif isinstance(disc, dict):       # ShakuraSunyaev: {"mdot": Ṁ/Ṁedd, "inv_eta": 1/η, "inner_radius": r_isco}
+        c.disc_id = DISC_SHAKURA_SUNYAEV
+        c.disc_r_in, c.disc_r_out = float(disc["inner_radius"]), float("inf")
+        c.disc_params[0], c.disc_params[1] = float(disc["mdot"]), float(disc["inv_eta"])
     else:
         c.disc_id = DISC_THIN
         c.disc_r_in, c.disc_r_out = float(disc[0]), float(disc[1])
@@ -321,3 +326,17 @@ def trace_steps(cfg, x, v, cap=100000):
     t, r = np.zeros(cap), np.zeros(cap)
     n = lib().orc_trace_steps(C.byref(cfg), _dp(x), _dp(v), out.ctypes.data, _dp(t), _dp(r), cap)
     return out[0], t[:n], r[:n]
+
+
+def circular_energy(cfg, r):
+    """CircularOrbits.energy(m, r) at θ = π/2 (-u_t)."""
+    v = circular_fourvelocity(cfg, r)
+    g, _, _ = metric_jacobian(cfg, r, math.pi / 2)
+    return -(g[0] * v[0] + g[4] * v[3])
+
+
+def shakura_sunyaev(cfg, eddington_ratio=0.3):
+    """ShakuraSunyaev(m; eddington_ratio = 0.3), shakura-sunyaev.jl:35-54."""
+    r_isco = isco(cfg)
+    eta = 1.0 - circular_energy(cfg, r_isco)
+    return {"mdot": eddington_ratio, "inv_eta": 1.0 / eta, "inner_radius": r_isco}

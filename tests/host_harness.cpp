@@ -31,7 +31,7 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
 static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
 {
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    const bool disc = p.cfg.disc_id == GR_DISC_THIN;
+    const bool disc = p.cfg.disc_id != GR_DISC_NONE;
     if (p.cfg.metric_id == GR_METRIC_KERR) {
         if (disc) run<KerrMetric, 1>(p, p.n, tlog, hlog, cap, nlog); else run<KerrMetric, 0>(p, p.n, tlog, hlog, cap, nlog);
     } else {

@@ -469,3 +469,19 @@ def test_against_committed_golden_fixtures(G, ens):
     both = ~np.isnan(img) & ~np.isnan(ref)
     assert both.sum() > 2000
     np.testing.assert_allclose(img[both], ref[both], rtol=RTOL)
+
+
+def test_shakura_sunyaev_disc_matches_oracle(G, oracle, ens):
+    ens.set("kernel", 1).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.9)
+    d = G.ShakuraSunyaev.for_metric(m)
+    ocfg0 = oracle.make_config("kerr", (1.0, 0.9))
+    ss = oracle.shakura_sunyaev(ocfg0)
+    W = H = 96
+    _, _, cache = G.prerendergeodesics(m, X_SMOKE, d, 200.0, image_width=W, image_height=H, alpha_lims=(-30, 30),
+                                       beta_lims=(-20, 20), ensemble=ens)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    ocfg = oracle.make_config("kerr", (1.0, 0.9), disc=ss, lambda_max=200.0)
+    ref = oracle.trace(ocfg, X_SMOKE, oracle.render_velocities(ocfg, X_SMOKE, (-30, 30), (-20, 20), W, H))
+    _compare_points(G, oracle, got, ref)
+    assert (ref["status"] == 2).sum() > 1000
