@@ -809,7 +809,7 @@ struct Ray {
     static GR_DEV real disc_cond(const Params& p, real r, real s, real c)
     {
         const real rho = r * GR_FABS(s);
-        if (p.cfg.disc_id == GR_DISC_THIN) {
+        if (DISC == GR_DISC_THIN) {
             if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
             return r * GR_FABS(c) - p.cfg.gtol * GR_FABS(r);
         }
@@ -1130,7 +1130,7 @@ struct Ray {
     GR_DEV int sample_event(const Params& p, int ps, real hh) const
     {
         const real wedge = p.wedge;
-        const bool thin = p.cfg.disc_id == GR_DISC_THIN;
+        constexpr bool thin = (DISC == GR_DISC_THIN);
         if (thin && ps > 0) {
             // |θ(Θ_j) - θ_0| <= h (Θ_j |v^θ| + h Σ_i |RXΣ_i(Θ_j)| |A_i^θ|) <= h (|v^θ| + K h max_i |A_i^θ|)
             real amax = GR_FABS(A[0][2]);

@@ -197,10 +197,16 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 
 inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
-    const bool disc = p.cfg.disc_id != GR_DISC_NONE;
-    if (p.cfg.metric_id == GR_METRIC_KERR)
-        return disc ? launch_tmpl<KerrMetric, 1>(k, p, stream) : launch_tmpl<KerrMetric, 0>(k, p, stream);
-    return disc ? launch_tmpl<GenericMetric, 1>(k, p, stream) : launch_tmpl<GenericMetric, 0>(k, p, stream);
+    // DISC is the geometry id itself (0 none, 1 ThinDisc, 2 ShakuraSunyaev): compile-time in the kernels
+    const int disc = p.cfg.disc_id;
+    if (p.cfg.metric_id == GR_METRIC_KERR) {
+        if (disc == GR_DISC_THIN) return launch_tmpl<KerrMetric, GR_DISC_THIN>(k, p, stream);
+        if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<KerrMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
+        return launch_tmpl<KerrMetric, GR_DISC_NONE>(k, p, stream);
+    }
+    if (disc == GR_DISC_THIN) return launch_tmpl<GenericMetric, GR_DISC_THIN>(k, p, stream);
+    if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<GenericMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
+    return launch_tmpl<GenericMetric, GR_DISC_NONE>(k, p, stream);
 }
 
 }  // namespace

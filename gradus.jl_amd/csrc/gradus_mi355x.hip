@@ -522,14 +522,17 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const 
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, ctx->stream));
     p.cold = slot;
-    const bool disc = cfg->disc_id != GR_DISC_NONE;
+#define GR_PATH_LAUNCH(M, D) hipLaunchKernelGGL((k_trace_path<M, D>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n)
     if (cfg->metric_id == GR_METRIC_KERR) {
-        if (disc) hipLaunchKernelGGL((k_trace_path<KerrMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
-        else hipLaunchKernelGGL((k_trace_path<KerrMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+        if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(KerrMetric, GR_DISC_THIN);
+        else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(KerrMetric, GR_DISC_SHAKURA_SUNYAEV);
+        else GR_PATH_LAUNCH(KerrMetric, GR_DISC_NONE);
     } else {
-        if (disc) hipLaunchKernelGGL((k_trace_path<GenericMetric, 1>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
-        else hipLaunchKernelGGL((k_trace_path<GenericMetric, 0>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n);
+        if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(GenericMetric, GR_DISC_THIN);
+        else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(GenericMetric, GR_DISC_SHAKURA_SUNYAEV);
+        else GR_PATH_LAUNCH(GenericMetric, GR_DISC_NONE);
     }
+#undef GR_PATH_LAUNCH
     GR_HIP(hipGetLastError());
     unsigned long long n = 0;
     GR_HIP(hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
