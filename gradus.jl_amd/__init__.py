@@ -7,7 +7,7 @@ work runs in hand-written HIP kernels for gfx950; there is no CPU fallback.
 from . import _lib
 from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
-from .distributed import gather_image, shard_plan
+from .distributed import gather_image, gather_image_async, shard_plan
 from .geometry import ShakuraSunyaev, ThinDisc
 from .lineprofiles import BinningMethod, PowerLawEmissivity, bucket_simple, lineprofile
 from .metrics import (BumblebeeMetric, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,

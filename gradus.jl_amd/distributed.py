@@ -68,3 +68,41 @@ def gather_image(local, plan: ShardPlan, group=None, dst: int = 0):
         full = full.view(plan.world, plan.n_blocks, plan.block).permute(1, 0, 2).reshape(-1)
     # linear index i = x*H + y  ->  Julia's (H, W) column-major matrix
     return full.view(plan.width, plan.height).t()
+
+
+class PendingGather:
+    """Handle of an in-flight gather started by `gather_image_async`.  `result()` waits for the
+    collective (making the current stream wait, for RCCL) and returns the (H, W) image on `dst`."""
+
+    def __init__(self, work, bufs, local, plan, dst):
+        self.work, self.bufs, self.local, self.plan, self.dst = work, bufs, local, plan, dst
+
+    def result(self):
+        import torch
+
+        if self.work is not None:
+            self.work.wait()
+        plan = self.plan
+        if plan.world == 1:
+            full = self.local
+        elif plan.rank != self.dst:
+            return None
+        else:
+            full = torch.stack(self.bufs).view(plan.world, plan.n_blocks, plan.block).permute(1, 0, 2).reshape(-1)
+        return full.view(plan.width, plan.height).t()
+
+
+def gather_image_async(local, plan: ShardPlan, group=None, dst: int = 0, recv_bufs=None) -> PendingGather:
+    """Start the single end-of-render gather without blocking the stream that traces the next
+    image: RCCL runs it on its own stream, so it overlaps with the next render's kernel.  The caller
+    must not overwrite `local` (nor `recv_bufs`) before `result()` of this handle has been called."""
+    import torch
+    import torch.distributed as dist
+
+    if plan.world == 1:
+        return PendingGather(None, None, local, plan, dst)
+    bufs = None
+    if plan.rank == dst:
+        bufs = recv_bufs if recv_bufs is not None else [torch.empty_like(local) for _ in range(plan.world)]
+    work = dist.gather(local, bufs, dst=dst, group=group, async_op=True)
+    return PendingGather(work, bufs, local, plan, dst)

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, tmp):
+def _worker(rank, world, port, W, H, tmp, use_async=False):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,7 +44,13 @@ def _worker(rank, world, port, W, H, tmp):
     pts = O.trace(cfg, x, v, nthreads=1)
     local = torch.from_numpy(O.apply_pf(cfg, pts, 200.0, pf_id=O.PF_AFFINE_TIME, filter_id=O.FILTER_EARLY_TERM,
                                         nthreads=1))
-    img = G.gather_image(local, plan)
+    if use_async:
+        # the pipelined form bench.py uses: start the gather, do other work, then collect
+        handle = G.gather_image_async(local, plan)
+        _ = local.sum()
+        img = handle.result()
+    else:
+        img = G.gather_image(local, plan)
     if rank == 0:
         np.save(os.path.join(tmp, "img.npy"), img.numpy())
     else:
@@ -53,10 +59,10 @@ def _worker(rank, world, port, W, H, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_render_equals_single(oracle, G, tmp_path, world):
+@pytest.mark.parametrize("world,use_async", [(2, False), (4, False), (2, True)])
+def test_sharded_render_equals_single(oracle, G, tmp_path, world, use_async):
     W = H = 16
-    mp.spawn(_worker, args=(world, _free_port(), W, H, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), W, H, str(tmp_path), use_async), nprocs=world, join=True)
     img = np.load(tmp_path / "img.npy")
     x = np.array([0.0, 100.0, math.radians(85), 0.0])
     cfg = oracle.make_config("kerr", (1.0, 0.0), disc=(0.0, 40.0), lambda_max=200.0)
