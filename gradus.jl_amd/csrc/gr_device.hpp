@@ -1185,6 +1185,9 @@ struct Ray {
         dense_coeffs(1, h, Cr);
         dense_coeffs(2, h, Ct);
         const int ps = sgn(cprev);
+#ifdef GR_HOST_HARNESS
+        dbg_e2 = 0.0;
+#endif
         real lo = 0.0, hi = (ev_top >= 7) ? 1.0 : (real)ev_top / 7.0;
         real flo = cprev, fhi;
         {
@@ -1194,23 +1197,37 @@ struct Ray {
         }
         real theta = hi;
         if (fhi != 0.0) {
-            // bracketing hybrid: false position with forced bisection; keeps sign(f(lo)) == ps
-            for (int it = 0; it < 80; ++it) {
+            // Illinois regula falsi: brackets [lo, hi] with sign(f(lo)) == ps throughout, superlinear on
+            // the smooth part of the condition and still convergent across its jump at the disc rim
+            // The bracket is closed to 1e-13 of the step (Θ in [0, 1]): positions move by < 1e-11, two
+            // orders below what differing step sequences do to any two implementations (§4 of DESIGN.md).
+            int side = 0;
+            for (int it = 0; it < 48; ++it) {
                 const real w = hi - lo;
-                if (w <= 4.0e-16 * GR_FMAX(hi, 1e-300) || w < 1e-17) break;
-                real mid;
-                if ((it % 3) == 2 || !(flo * fhi < 0.0)) mid = lo + 0.5 * w;
-                else {
-                    mid = lo - flo * w / (fhi - flo);
-                    const real guard = 1e-3 * w;
-                    if (!(mid > lo + guard)) mid = lo + guard;
-                    if (!(mid < hi - guard)) mid = hi - guard;
+                if (w <= 1.0e-13) break;
+                real mid = lo - flo * w / (fhi - flo);
+                // on the plateau c = 1 outside the disc's radial range the condition is a step
+                // function: bisection is the optimal bracketing method there
+                const bool plateau = (flo == 1.0) || (fhi == 1.0);
+                if (plateau || !(mid > lo && mid < hi)) {
+                    mid = lo + 0.5 * w;
+                    if (!(mid > lo && mid < hi)) break;
                 }
-                if (!(mid > lo && mid < hi)) break;
                 real s, c;
                 sincos_fast(dense_eval(x[2], h, Ct, mid), s, c);
                 const real fm = disc_cond(p, dense_eval(x[1], h, Cr, mid), s, c);
-                if (sgn(fm) == ps) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+                if (sgn(fm) == ps) {
+                    lo = mid; flo = fm;
+                    if (side < 0) fhi *= 0.5;
+                    side = -1;
+                } else {
+                    hi = mid; fhi = fm;
+                    if (side > 0) flo *= 0.5;
+                    side = 1;
+                }
+#ifdef GR_HOST_HARNESS
+                dbg_e2 += 1.0;
+#endif
             }
             theta = lo;
         }

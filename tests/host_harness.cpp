@@ -23,8 +23,9 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
             if (tlog && k < cap) { tlog[k] = ray.t; hlog[k] = ray.x[2]; ++k; }
             if (fin) break;
         }
-        if (nlog) *nlog = k;
         ray.finalize(m, p);
+        if (tlog && k < cap) { tlog[k] = -1.0; hlog[k] = ray.dbg_e2; ++k; }
+        if (nlog) *nlog = k;
     }
 }
 
