@@ -614,7 +614,7 @@ struct Cold {
     int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays
     int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs
     int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
-    int32_t _pad;
+    int32_t idx32;            // 1 = every ray / pixel index fits 31 bits: 32-bit divisions in the index maps
     gr_plane plane;
     gr_range range;
     const double* x;          // device
@@ -664,6 +664,12 @@ GR_DEV const Cold& cold_of(const Params& p)
 }
 
 // local ray index -> swizzled local index so that 64 consecutive work items cover an 8x8 tile
+// integer division in the index maps: 64-bit division costs ~100 instructions on the VALU, 32-bit ~20
+GR_DEV int64_t idx_div(const Cold& p, int64_t a, int64_t b)
+{
+    return p.idx32 ? (int64_t)((uint32_t)a / (uint32_t)b) : a / b;
+}
+
 GR_DEV int64_t tile_swizzle(const Cold& p, int64_t j)
 {
     if (!p.swizzle) return j;
@@ -672,13 +678,14 @@ GR_DEV int64_t tile_swizzle(const Cold& p, int64_t j)
     if (p.tile_perm) tile = p.tile_perm[tile];
     const int lane = (int)(j & 63);
     const int64_t tiles_per_col = H >> 3;
-    const int64_t tx = tile / tiles_per_col, ty = tile - tx * tiles_per_col;
+    const int64_t tx = idx_div(p, tile, tiles_per_col), ty = tile - tx * tiles_per_col;
     return ((tx << 3) + (lane >> 3)) * H + (ty << 3) + (lane & 7);
 }
 
-GR_DEV int64_t range_map(const gr_range& rg, int64_t j)
+GR_DEV int64_t range_map(const Cold& p, int64_t j)
 {
-    const int64_t b = j / rg.block;
+    const gr_range& rg = p.range;
+    const int64_t b = idx_div(p, j, rg.block);
     return rg.first + b * rg.stride_blocks * rg.block + (j - b * rg.block);
 }
 
@@ -838,9 +845,9 @@ struct Ray {
         const Cold& p = cold_of(pp);
         if (p.src_mode == 0) {
             // _render_velocity_function, rendering.jl:140-163 ; local_momentum, utility.jl:13-20
-            const int64_t i = range_map(p.range, jl);
+            const int64_t i = range_map(p, jl);
             const int64_t H = p.plane.height;
-            const int64_t xi = i / H, yi = i - xi * H;
+            const int64_t xi = idx_div(p, i, H), yi = i - xi * H;
             const real alpha = range_at(p.plane.alpha0, p.plane.alpha1, p.plane.width, xi) + p.plane.offset;
             const real beta = range_at(p.plane.beta0, p.plane.beta1, H, yi) + p.plane.offset;
             const real ro = p.plane.x_obs[1];
@@ -1261,7 +1268,7 @@ struct Ray {
         if (cd.tile_cost) {
             // representative ray of its 8x8 tile: local column and row both multiples of 8
             const int64_t H = cd.plane.height;
-            const int64_t col = j / H, row = j - col * H;
+            const int64_t col = idx_div(cd, j, H), row = j - col * H;
             if (((col | row) & 7) == 0) cd.tile_cost[(col >> 3) * (H >> 3) + (row >> 3)] = (uint32_t)(nacc + nrej);
         }
         if (cd.out_mode == 1) {

@@ -282,6 +282,8 @@ void plane_params(gr_ctx* ctx, Params& pp, Cold& p, const gr_config* cfg, const 
     const bool cols_ok = (H % 8 == 0) && (range->first % H == 0) && (range->block % (8 * H) == 0)
                          && (range->count % (8 * H) == 0);
     p.swizzle = (ctx->swizzle && cols_ok) ? 1 : 0;
+    const int64_t lim = (int64_t)1 << 31;
+    p.idx32 = (plane->width * plane->height < lim && range->count < lim && range->block < lim) ? 1 : 0;
 }
 
 void stats_to_host(const unsigned long long* h, gr_stats* s)
