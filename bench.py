@@ -37,11 +37,14 @@ PEAK_HBM_GBS = 8000.0
 # and per ray outside the step loop, for the bench workload.
 FLOPS_JSON = os.path.join(ROOT, "oracle", "flopcount.json")
 # FP64 flops the kernel actually EXECUTES per ray, from the committed rocprofv3 PMC pass
-# (profiles/r1c_k1_summary.json: (2*FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes *
+# (profiles/r1d_k1_summary.json: (2*FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes *
 # active-lane fraction / rays).  Lower than the algorithmic count because the kernel reaches
 # the same results with hand-derived derivatives and a pre-filtered event search.
-EXECUTED_FLOPS_PER_RAY = 2.447e5
-EXECUTED_SOURCE = "profiles/r1c_k1_summary.json"
+EXECUTED_FLOPS_PER_RAY = 2.287e5
+EXECUTED_SOURCE = "profiles/r1d_k1_summary.json"
+EXECUTED_VALU_BUSY = 0.945
+# HBM bytes per launch from the same profile's FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes
+PROFILED_TRAFFIC_BYTES_PER_LAUNCH = 43201952.0
 
 
 def parse_args():
@@ -256,11 +259,13 @@ def main():
                 "flops_per_ray": flops_per_ray,
                 "flop_model": "oracle counting-scalar build" if fm else "SURVEY §8(d) estimate",
                 "kernel_ms": kernel_ms,
-                "traffic": None,
+                "traffic": (PROFILED_TRAFFIC_BYTES_PER_LAUNCH if (world == 1 and args.size == 2048) else None),
+                "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes of this workload committed under profiles/ "
+                                "(algorithmic: 8 B x rays = 33.6 MB; the excess is partial-line writes of scattered 8-B stores)",
                 "executed": {"flops_per_ray": EXECUTED_FLOPS_PER_RAY, "source": EXECUTED_SOURCE,
                              "achieved": rays_launch * EXECUTED_FLOPS_PER_RAY / (kernel_ms * 1e-3) / 1e12,
                              "frac": rays_launch * EXECUTED_FLOPS_PER_RAY / (kernel_ms * 1e-3) / 1e12
-                             / PEAK_FP64_VALU_TFLOPS, "valu_busy": 0.956, "unit": "TFLOP/s"},
+                             / PEAK_FP64_VALU_TFLOPS, "valu_busy": EXECUTED_VALU_BUSY, "unit": "TFLOP/s"},
                 "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_ray": 8},
             },
