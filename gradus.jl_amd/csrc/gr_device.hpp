@@ -53,6 +53,10 @@ typedef double gr_real_t;
 #define GR_EPS 2.220446049250313e-16
 #endif
 
+#ifndef GR_GENERIC_MIN_WAVES
+#define GR_GENERIC_MIN_WAVES 2
+#endif
+
 #ifdef GR_HOST_HARNESS
 // tests/host_harness.cpp compiles this header with g++ to trace single rays on the CPU next to
 // the oracle.  Test infrastructure only: the shipped library never defines GR_HOST_HARNESS.
@@ -241,6 +245,7 @@ GR_DEV void inverse_generic(const real g[5], real gi[5])
 }
 
 struct KerrMetric {
+    static constexpr int kMinWavesPerSimd = 1;   // fits 2 waves/SIMD on its own (197 VGPRs)
     real M, a;
     GR_DEV void load(const gr_config& c) { M = c.params[0]; a = c.params[1]; }
 
@@ -312,6 +317,9 @@ struct KerrMetric {
 // functor with a (wave-uniform) switch on the metric id keeps the number of kernel instantiations
 // independent of the size of the catalogue.
 struct GenericMetric {
+    // the dual-number evaluation wants ~285 registers; capping it at 256 (2 waves/SIMD) costs a few
+    // scratch spills but keeps the VALU busy (measured: see DESIGN.md §5)
+    static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
     int32_t id;
     real P[6];
     GR_DEV void load(const gr_config& c)

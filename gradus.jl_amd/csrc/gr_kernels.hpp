@@ -39,7 +39,7 @@ struct LaneStats {
 
 // ---- kernel 0: one ray per work-item ----
 template <class Metric, int DISC>
-__global__ void __launch_bounds__(256) k_trace_lane(const Params p)
+__global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_lane(const Params p)
 {
     Metric m;
     m.load(p.cfg);
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_trace_lane(const Params p)
 
 // ---- kernel 1: persistent grid with wave-ballot refill ----
 template <class Metric, int DISC>
-__global__ void __launch_bounds__(256) k_trace_persistent(const Params p)
+__global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_persistent(const Params p)
 {
     Metric m;
     m.load(p.cfg);

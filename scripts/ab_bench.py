@@ -14,12 +14,18 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--size", type=int, default=2048)
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--shard", default=None)
+ap.add_argument("--workload", default="kerr", choices=["kerr", "johannsen"])
 ap.add_argument("--set", action="append", default=[], help="key=value knob for every lib")
 args = ap.parse_args()
 
-m = G.KerrMetric(1.0, 0.998)
-x = np.array([0.0, 1000.0, math.radians(75), 0.0])
-pf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+if args.workload == "kerr":
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(75), 0.0])
+    pf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+else:   # BASELINE config C4; shadow pf so that no plunging table (device trace) is needed here
+    m = G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0)
+    x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+    pf = G.ConstPointFunctions.shadow()
 cfgo = G.render_configuration(m, x, G.ThinDisc(m.isco(), 50.0), 2000.0, image_width=args.size, image_height=args.size,
                               alpha_lims=(-60, 60), beta_lims=(-35, 35), ensemble=G.EnsembleMI355X.__new__(G.EnsembleMI355X))
 cfg, pl = cfgo.abi_config(), cfgo.abi_plane()
