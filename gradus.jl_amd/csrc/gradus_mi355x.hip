@@ -368,7 +368,7 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         if (value != 0 && value != 1) return fail(GR_ERR_INVALID_ARGUMENT, "kernel must be 0 or 1");
         c->kernel = value;
     } else if (k == "block") {
-        if (value < 64 || value > 1024 || value % 64) return fail(GR_ERR_INVALID_ARGUMENT, "block must be a multiple of 64 in [64, 1024]");
+        if (value < 64 || value > 256 || value % 64) return fail(GR_ERR_INVALID_ARGUMENT, "block must be a multiple of 64 in [64, 256]");
         c->block = value;
     } else if (k == "refill_threshold") {
         if (value < 1 || value > 64) return fail(GR_ERR_INVALID_ARGUMENT, "refill_threshold must be in [1, 64]");

@@ -485,3 +485,38 @@ def test_shakura_sunyaev_disc_matches_oracle(G, oracle, ens):
     ref = oracle.trace(ocfg, X_SMOKE, oracle.render_velocities(ocfg, X_SMOKE, (-30, 30), (-20, 20), W, H))
     _compare_points(G, oracle, got, ref)
     assert (ref["status"] == 2).sum() > 1000
+
+
+def test_device_resident_entry_points_and_streams(G, ens):
+    """gr_render_device / gr_render_endpoints_device with torch-owned HBM on a non-default stream
+    agree bit for bit with the host-buffer entry points; block sizes 64..256 agree too."""
+    import torch
+    from gradus_jl_amd import device as gdev
+
+    ens.set("kernel", 1).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.7)
+    d = G.ThinDisc(m.isco(), 30.0)
+    pf = G.ConstPointFunctions.redshift(m, X_SMOKE) @ G.ConstPointFunctions.filter_intersected()
+    W, H = 96, 64
+    cfg = G.render_configuration(m, X_SMOKE, d, 200.0, image_width=W, image_height=H, alpha_lims=(-25, 25),
+                                 beta_lims=(-15, 15), ensemble=ens)
+    ref_img = G.render_into_image(cfg, pf=pf)
+    ref_pts = G.ensemble_solve_tracing_problem(ens, cfg)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        img = torch.empty(W * H, dtype=torch.float64, device=dev)
+        st = gdev.new_stats(dev)
+        gdev.render_device(cfg, pf, img, stats=st)
+        raw = torch.empty(W * H * 152, dtype=torch.uint8, device=dev)
+        gdev.render_endpoints_device(cfg, raw)
+    side.synchronize()
+    assert img.view(W, H).t().cpu().numpy().tobytes() == ref_img.tobytes()
+    assert gdev.points_from_tensor(raw, W * H).tobytes() == ref_pts.tobytes()
+    assert gdev.stats_dict(st)["rays"] == W * H
+    for block in (64, 128, 256):
+        ens.set("block", block)
+        assert G.render_into_image(cfg, pf=pf).tobytes() == ref_img.tobytes()
+    ens.set("block", 256)
+    with pytest.raises(G.GradusMI355XError):
+        ens.set("block", 512)
