@@ -657,8 +657,21 @@ struct Params {
     unsigned long long* stats;  // device: 9 counters (see gr_stats order), may be null
     unsigned long long* queue;  // device: persistent-kernel work counter
     int32_t refill_threshold;
+    int32_t lds_plunge_rows;  // rows of the plunging table to stage in LDS (0 = none)
+    int32_t lds_bins;         // line-profile bins privatised in LDS (0 = none)
     int32_t _pad;
     double wedge;             // asin(gtol) with a hair of slack: |θ - π/2| beyond it cannot hit the disc
+};
+
+// Small read-mostly tables staged in LDS by the kernel prologue (null = use the global copy):
+// the PlungingInterpolation table of the non-Kerr redshift and the per-workgroup private copy of
+// the line-profile histogram.
+struct LdsView {
+    const double* pl_r;
+    const double* pl_vt;
+    const double* pl_vr;
+    const double* pl_vp;
+    double* hist;
 };
 
 // read the cold block through a pointer the optimiser cannot hoist loads from
@@ -753,8 +766,8 @@ GR_DEV void circular_fourvelocity(const Metric& m, real rho, real& vt, real& vp)
 
 // redshift_function(m, gp) / interpolate_redshift closure; redshift.jl:192-220,246-276
 template <class Metric>
-GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const real x0[4], const real v0[4],
-                          const real x[4], const real v[4])
+GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const LdsView& lds, const real x0[4],
+                        const real v0[4], const real x[4], const real v[4])
 {
     real s, c;
     sincos_fast(x[2], s, c);
@@ -776,11 +789,15 @@ GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const 
         } else {
             real rb = rho;
             const int64_t n = p.pf.n_plunge;
-            if (rb < p.pf.plunge_r[0]) rb = p.pf.plunge_r[0];
-            if (rb > p.pf.plunge_r[n - 1]) rb = p.pf.plunge_r[n - 1];
-            dt_ = nan_linear_interp(p.pf.plunge_r, p.pf.plunge_vt, n, rb);
-            dr_ = -nan_linear_interp(p.pf.plunge_r, p.pf.plunge_vr, n, rb);
-            dp_ = nan_linear_interp(p.pf.plunge_r, p.pf.plunge_vphi, n, rb);
+            const double* tr = lds.pl_r ? lds.pl_r : p.pf.plunge_r;
+            const double* tvt = lds.pl_r ? lds.pl_vt : p.pf.plunge_vt;
+            const double* tvr = lds.pl_r ? lds.pl_vr : p.pf.plunge_vr;
+            const double* tvp = lds.pl_r ? lds.pl_vp : p.pf.plunge_vphi;
+            if (rb < tr[0]) rb = tr[0];
+            if (rb > tr[n - 1]) rb = tr[n - 1];
+            dt_ = nan_linear_interp(tr, tvt, n, rb);
+            dr_ = -nan_linear_interp(tr, tvr, n, rb);
+            dp_ = nan_linear_interp(tr, tvp, n, rb);
         }
     } else {
         circular_fourvelocity(m, rho, dt_, dp_);
@@ -1265,7 +1282,7 @@ struct Ray {
     }
 
     // unpack_solution + apply_to_image!
-    GR_DEV void finalize(const Metric& m, const Params& p)
+    GR_DEV void finalize(const Metric& m, const Params& p, const LdsView& lds)
     {
         if (DISC && (flags & RAY_EVENT)) {
             resolve_event(p);
@@ -1304,7 +1321,7 @@ struct Ray {
             if (in) {
                 real x0[4], v0[4];
                 constrained_u0(m, p, j, x0, v0);
-                g = redshift_pf(m, p, cd, x0, v0, x, v);
+                g = redshift_pf(m, p, cd, lds, x0, v0, x, v);
             }
             if (cd.out_mode == 3) {
                 cd.lp_pairs[2 * j] = in ? (double)g : __builtin_nan("");
@@ -1321,7 +1338,7 @@ struct Ray {
                     if (cd.lp_edges[mid] < g) lo = mid + 1; else hi = mid;
                 }
                 if (lo > cd.lp_nbins - 1) lo = cd.lp_nbins - 1;
-                if (f == f) gr_atomic_add(cd.lp_flux + lo, f);
+                if (f == f) gr_atomic_add((lds.hist ? lds.hist : cd.lp_flux) + lo, f);
             }
         } else {
             bool pass = true;
@@ -1338,7 +1355,7 @@ struct Ray {
                 } else {
                     real x0[4], v0[4];
                     constrained_u0(m, p, j, x0, v0);
-                    val = redshift_pf(m, p, cd, x0, v0, x, v);
+                    val = redshift_pf(m, p, cd, lds, x0, v0, x, v);
                 }
             }
             cd.image[j] = val;

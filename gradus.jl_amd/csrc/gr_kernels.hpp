@@ -37,6 +37,44 @@ struct LaneStats {
     }
 };
 
+// LDS staging shared by both trace kernels: [ hist (lds_bins) | plunging table (4 x lds_plunge_rows) ]
+#ifndef GR_HOST_HARNESS
+extern __shared__ double gr_lds[];
+
+__device__ __forceinline__ LdsView lds_prologue(const Params& p)
+{
+    LdsView v{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    const int bins = p.lds_bins, rows = p.lds_plunge_rows;
+    if (bins == 0 && rows == 0) return v;
+    const Cold& cd = cold_of(p);
+    double* hist = gr_lds;
+    double* tab = gr_lds + bins;
+    for (int i = threadIdx.x; i < bins; i += blockDim.x) hist[i] = 0.0;
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+        tab[i] = cd.pf.plunge_r[i];
+        tab[rows + i] = cd.pf.plunge_vt[i];
+        tab[2 * rows + i] = cd.pf.plunge_vr[i];
+        tab[3 * rows + i] = cd.pf.plunge_vphi[i];
+    }
+    __syncthreads();
+    if (bins) v.hist = hist;
+    if (rows) { v.pl_r = tab; v.pl_vt = tab + rows; v.pl_vr = tab + 2 * rows; v.pl_vp = tab + 3 * rows; }
+    return v;
+}
+
+// one global atomic per non-empty bin per workgroup
+__device__ __forceinline__ void lds_epilogue(const Params& p, const LdsView& v)
+{
+    if (!v.hist) return;
+    __syncthreads();
+    const Cold& cd = cold_of(p);
+    for (int i = threadIdx.x; i < p.lds_bins; i += blockDim.x) {
+        const double h = v.hist[i];
+        if (h != 0.0) atomicAdd(cd.lp_flux + i, h);
+    }
+}
+#endif
+
 // ---- kernel 0: one ray per work-item ----
 template <class Metric, int DISC>
 __global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_lane(const Params p)
@@ -45,13 +83,15 @@ __global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_lane(co
     m.load(p.cfg);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     LaneStats<Metric, DISC> ls;
+    const LdsView lds = lds_prologue(p);
     if (gid < p.n) {
         Ray<Metric, DISC> ray;
         ray.init(m, p, tile_swizzle(cold_of(p), gid));
         while (!ray.step(m, p)) {}
-        ray.finalize(m, p);
+        ray.finalize(m, p, lds);
         ls.add(ray);
     }
+    lds_epilogue(p, lds);
     ls.flush(p.stats);
 }
 
@@ -66,6 +106,7 @@ __global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_persist
     bool active = false, pending = false, queue_empty = false;
     const int lane = threadIdx.x & 63;
     const int threshold = p.refill_threshold;
+    const LdsView lds = lds_prologue(p);
 
     for (;;) {
         const unsigned long long act = __ballot(active);
@@ -73,7 +114,7 @@ __global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_persist
         if (n_idle >= threshold || act == 0ull) {
             if (__ballot(pending)) {
                 if (pending) {
-                    ray.finalize(m, p);
+                    ray.finalize(m, p, lds);
                     ls.add(ray);
                     pending = false;
                 }
@@ -100,6 +141,7 @@ __global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_persist
             }
         }
     }
+    lds_epilogue(p, lds);
     ls.flush(p.stats);
 }
 
@@ -129,7 +171,8 @@ __global__ void __launch_bounds__(64) k_trace_path(const Params p, double* path,
         if (fin) break;
         if (ray.nacc != before) save();
     }
-    ray.finalize(m, p);     // resolves a pending event and writes the endpoint record
+    const LdsView no_lds{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    ray.finalize(m, p, no_lds);     // resolves a pending event and writes the endpoint record
     save();
     *n_rows = (unsigned long long)n;
 }
@@ -152,7 +195,13 @@ __global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point
         if (cd.pf.pf_id == GR_PF_AFFINE_TIME) val = gp.lambda_max;
         else if (cd.pf.pf_id == GR_PF_STATUS) val = (double)gp.status;
         else if (cd.pf.pf_id == GR_PF_RADIUS) val = gp.x[1] * ::fabs(::sin(gp.x[2]));
-        else val = redshift_pf(m, p, cd, gp.x_init, gp.v_init, gp.x, gp.v);
+        else {
+            const LdsView no_lds{ nullptr, nullptr, nullptr, nullptr, nullptr };
+            real xi[4], vi[4], xe[4], ve[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xi[q] = gp.x_init[q]; vi[q] = gp.v_init[q]; xe[q] = gp.x[q]; ve[q] = gp.v[q]; }
+            val = redshift_pf(m, p, cd, no_lds, xi, vi, xe, ve);
+        }
     }
     out[i] = val;
 }
@@ -171,12 +220,13 @@ template <class Metric, int DISC>
 hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
     const int block = k.block;
+    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows);
     if (k.kernel == 0) {
         const int64_t grid = (p.n + block - 1) / block;
-        hipLaunchKernelGGL((k_trace_lane<Metric, DISC>), dim3((unsigned)grid), dim3(block), 0, stream, p);
+        hipLaunchKernelGGL((k_trace_lane<Metric, DISC>), dim3((unsigned)grid), dim3(block), lds, stream, p);
     } else {
         int per_cu = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persistent<Metric, DISC>, block, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persistent<Metric, DISC>, block, lds);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         if (k.waves_per_simd > 0) {
@@ -190,7 +240,7 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
         p.queue = k.queue;
         e = hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_trace_persistent<Metric, DISC>), dim3((unsigned)grid), dim3(block), 0, stream, p);
+        hipLaunchKernelGGL((k_trace_persistent<Metric, DISC>), dim3((unsigned)grid), dim3(block), lds, stream, p);
     }
     return hipGetLastError();
 }

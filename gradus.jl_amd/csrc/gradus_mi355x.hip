@@ -71,6 +71,7 @@ struct gr_ctx {
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
     int64_t swizzle = 1;
     int64_t precision = 64;                // 64 = fp64 kernels, 32 = fp32 kernels (tolerance sweeps)
+    int64_t lds = 1;                       // stage the plunging table / line-profile histogram in LDS
     int64_t lpt = 1;                       // longest-first tile order learned from the previous render
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // LPT state for one (config, plane, range) key
@@ -211,6 +212,10 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     GR_HIP(hipMemcpyAsync(slot, &cold, sizeof(Cold), hipMemcpyHostToDevice, stream));
     p.cold = slot;
     p.refill_threshold = (int32_t)ctx->refill_threshold;
+    // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins)
+    p.lds_plunge_rows = (ctx->lds && cold_in.pf.pf_id == GR_PF_REDSHIFT && cold_in.out_mode != 1 && cold_in.pf.n_plunge > 0
+                         && cold_in.pf.n_plunge <= 2048) ? (int32_t)cold_in.pf.n_plunge : 0;
+    p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     LaunchKnobs knobs{ (int)ctx->kernel, (int)ctx->block, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
@@ -378,6 +383,8 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->waves_per_simd = value;
     } else if (k == "swizzle") {
         c->swizzle = value ? 1 : 0;
+    } else if (k == "lds") {
+        c->lds = value ? 1 : 0;
     } else if (k == "precision") {
         if (value != 32 && value != 64) return fail(GR_ERR_INVALID_ARGUMENT, "precision must be 32 or 64");
         c->precision = value;

@@ -23,7 +23,8 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
             if (tlog && k < cap) { tlog[k] = ray.t; hlog[k] = ray.x[2]; ++k; }
             if (fin) break;
         }
-        ray.finalize(m, p);
+        const LdsView no_lds{ nullptr, nullptr, nullptr, nullptr, nullptr };
+        ray.finalize(m, p, no_lds);
         if (tlog && k < cap) { tlog[k] = -1.0; hlog[k] = ray.dbg_e2; ++k; }
         if (nlog) *nlog = k;
     }

@@ -520,3 +520,30 @@ def test_device_resident_entry_points_and_streams(G, ens):
     ens.set("block", 256)
     with pytest.raises(G.GradusMI355XError):
         ens.set("block", 512)
+
+
+def test_lds_staging_is_transparent(G, ens):
+    """The LDS copies of the plunging table and of the line-profile histogram change nothing:
+    Johannsen redshift image bit-identical with lds on / off; line profile equal up to the order
+    of the fp64 atomic sums."""
+    ens.set("kernel", 1).set("precision", 64)
+    m = G.JohannsenMetric(*JOH)
+    x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+    pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
+    kw = dict(image_width=64, image_height=64, alpha_lims=(-20, 20), beta_lims=(-12, 12), pf=pf, ensemble=ens)
+    imgs = []
+    for lds in (1, 0):
+        ens.set("lds", lds)
+        imgs.append(G.rendergeodesics(m, x, G.ThinDisc(2.0, 50.0), 2000.0, **kw)[2])
+    assert imgs[0].tobytes() == imgs[1].tobytes() and np.isfinite(imgs[0]).sum() > 200
+    mk = G.KerrMetric(1.0, 0.6)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=64, Nθ=128)
+    bins = np.linspace(0.1, 1.3, 100)
+    ys = []
+    for lds in (1, 0):
+        ens.set("lds", lds)
+        ys.append(G.lineprofile(bins, G.PowerLawEmissivity(3), mk, u, G.ThinDisc(mk.isco(), 250.0), plane=plane,
+                                ensemble=ens)[1])
+    ens.set("lds", 1)
+    np.testing.assert_allclose(ys[0], ys[1], rtol=1e-12, atol=1e-18)
