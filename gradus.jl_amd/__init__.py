@@ -8,7 +8,7 @@ from . import _lib
 from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
 from .distributed import gather_image, gather_image_async, shard_plan
-from .geometry import ShakuraSunyaev, ThinDisc
+from .geometry import ShakuraSunyaev, ThickDisc, ThinDisc
 from .lineprofiles import BinningMethod, PowerLawEmissivity, bucket_simple, lineprofile
 from .metrics import (BumblebeeMetric, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,
                       MorrisThorneWormhole, inner_radius, isco)

@@ -50,6 +50,8 @@ class gr_config(C.Structure):
         ("_pad", C.c_int32),
         ("hemi_delta", C.c_double),
         ("disc_params", C.c_double * 4),
+        ("disc_table", C.c_void_p),
+        ("disc_table_n", C.c_int64),
     ]
 
 

@@ -653,6 +653,7 @@ struct Cold {
 struct Params {
     gr_config cfg;
     const Cold* cold;         // device
+    const double* disc_table; // device copy of cfg.disc_table (GR_DISC_TABULATED)
     int64_t n;                // rays in this call
     unsigned long long* stats;  // device: 9 counters (see gr_stats order), may be null
     unsigned long long* queue;  // device: persistent-kernel work counter
@@ -845,9 +846,22 @@ struct Ray {
             if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
             return r * GR_FABS(c) - p.cfg.gtol * GR_FABS(r);
         }
-        const real rin = p.cfg.disc_r_in;
-        if (rho < rin) return 1.0;
-        const real height = 3.0 * (real)p.cfg.disc_params[1] * (real)p.cfg.disc_params[0] * (1.0 - sqrt_fast(rin * rcp_full(rho)));
+        real height;
+        if (DISC == GR_DISC_TABULATED) {
+            // cross_section(::ThickDisc) sampled on a uniform grid (thick-disc.jl:57-58)
+            const real r0 = p.cfg.disc_params[0], r1 = p.cfg.disc_params[1];
+            if (rho < r0 || rho > r1 || rho < (real)p.cfg.disc_r_in || rho > (real)p.cfg.disc_r_out) return 1.0;
+            const int64_t n = p.cfg.disc_table_n;
+            const real u = (rho - r0) * ((real)(n - 1) * rcp_full(r1 - r0));
+            int64_t k = (int64_t)u;
+            if (k > n - 2) k = n - 2;
+            const real w = u - (real)k;
+            height = (1.0 - w) * (real)p.disc_table[k] + w * (real)p.disc_table[k + 1];
+        } else {
+            const real rin = p.cfg.disc_r_in;
+            if (rho < rin) return 1.0;
+            height = 3.0 * (real)p.cfg.disc_params[1] * (real)p.cfg.disc_params[0] * (1.0 - sqrt_fast(rin * rcp_full(rho)));
+        }
         if (height <= 0.0) return 1.0;
         return r * GR_FABS(c) - height;
     }
@@ -1189,7 +1203,9 @@ struct Ray {
             // thick disc of bounded height Hmax: a sample can only be inside if |z| = r |sin d| < Hmax,
             // and |sin d| >= (2/π)|d|, so |d| r >= (π/2) Hmax rules it out
             dense_coeffs(1, hh, Cr);
-            const real hmax = 1.5707963267948966 * 3.0 * (real)p.cfg.disc_params[1] * (real)p.cfg.disc_params[0] * 1.000001;
+            const real hmax = 1.5707963267948966 * 1.000001
+                              * (DISC == GR_DISC_TABULATED ? (real)p.cfg.disc_params[2]
+                                                           : 3.0 * (real)p.cfg.disc_params[1] * (real)p.cfg.disc_params[0]);
 #pragma unroll
             for (int jj = 0; jj < 6; ++jj) {
                 const real th = (real)(jj + 1) / 7.0;

@@ -56,6 +56,8 @@ struct gr_ctx {
     unsigned long long* d_queue = nullptr; // ring of work counters (one per in-flight launch)
     int queue_slots = 64, queue_next = 0;
     unsigned long long* d_stats = nullptr; // for host-buffer entry points
+    double* d_disc_table = nullptr;        // device copy of a tabulated disc profile
+    size_t disc_table_bytes = 0;
     Cold* d_cold = nullptr;                // ring of per-launch cold blocks
     int cold_next = 0;
     double* d_plunge = nullptr;            // 4 x n_plunge
@@ -101,13 +103,15 @@ int32_t validate_cfg(const gr_config* cfg)
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
     if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_JOHANNSEN_PSALTIS)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
-    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_SHAKURA_SUNYAEV)
+    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_TABULATED)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
     if (!(cfg->abstol > 0.0) || !(cfg->reltol > 0.0))
         return fail(GR_ERR_INVALID_ARGUMENT, "abstol and reltol must be positive");
     if (!(cfg->lambda1 > cfg->lambda0))
         return fail(GR_ERR_INVALID_ARGUMENT, "λ domain must be increasing");
     if (cfg->maxiters <= 0) return fail(GR_ERR_INVALID_ARGUMENT, "maxiters must be positive");
+    if (cfg->disc_id == GR_DISC_TABULATED && (!cfg->disc_table || cfg->disc_table_n < 2 || !(cfg->disc_params[1] > cfg->disc_params[0])))
+        return fail(GR_ERR_INVALID_ARGUMENT, "tabulated disc needs >= 2 samples on an increasing ρ grid");
     if (cfg->disc_id == GR_DISC_THIN && !(cfg->disc_r_out >= cfg->disc_r_in))
         return fail(GR_ERR_INVALID_ARGUMENT, "disc outer radius below inner radius");
     return GR_OK;
@@ -128,6 +132,19 @@ int32_t validate_plane(const gr_plane* pl, const gr_range* rg)
         const int64_t i = rg->first + b * rg->stride_blocks * rg->block + (last - b * rg->block);
         if (i >= pl->width * pl->height) return fail(GR_ERR_INVALID_ARGUMENT, "ray range exceeds the image");
     }
+    return GR_OK;
+}
+
+// device copy of a tabulated disc profile (cfg.disc_table is a host pointer)
+int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
+{
+    p.disc_table = nullptr;
+    if (p.cfg.disc_id != GR_DISC_TABULATED) return GR_OK;
+    const size_t tb = sizeof(double) * (size_t)p.cfg.disc_table_n;
+    int32_t rc = ensure((void**)&ctx->d_disc_table, &ctx->disc_table_bytes, tb);
+    if (rc != GR_OK) return rc;
+    GR_HIP(hipMemcpyAsync(ctx->d_disc_table, p.cfg.disc_table, tb, hipMemcpyHostToDevice, stream));
+    p.disc_table = ctx->d_disc_table;
     return GR_OK;
 }
 
@@ -211,6 +228,10 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cold, sizeof(Cold), hipMemcpyHostToDevice, stream));
     p.cold = slot;
+    {
+        const int32_t trc = stage_disc_table(ctx, p, stream);
+        if (trc != GR_OK) return trc;
+    }
     p.refill_threshold = (int32_t)ctx->refill_threshold;
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins)
     p.lds_plunge_rows = (ctx->lds && cold_in.pf.pf_id == GR_PF_REDSHIFT && cold_in.out_mode != 1 && cold_in.pf.n_plunge > 0
@@ -352,6 +373,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_cold) (void)hipFree(c->d_cold);
+    if (c->d_disc_table) (void)hipFree(c->d_disc_table);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
@@ -531,14 +553,17 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const 
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, ctx->stream));
     p.cold = slot;
+    if ((rc = stage_disc_table(ctx, p, ctx->stream)) != GR_OK) return rc;
 #define GR_PATH_LAUNCH(M, D) hipLaunchKernelGGL((k_trace_path<M, D>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n)
     if (cfg->metric_id == GR_METRIC_KERR) {
         if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(KerrMetric, GR_DISC_THIN);
         else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(KerrMetric, GR_DISC_SHAKURA_SUNYAEV);
+        else if (cfg->disc_id == GR_DISC_TABULATED) GR_PATH_LAUNCH(KerrMetric, GR_DISC_TABULATED);
         else GR_PATH_LAUNCH(KerrMetric, GR_DISC_NONE);
     } else {
         if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(GenericMetric, GR_DISC_THIN);
         else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(GenericMetric, GR_DISC_SHAKURA_SUNYAEV);
+        else if (cfg->disc_id == GR_DISC_TABULATED) GR_PATH_LAUNCH(GenericMetric, GR_DISC_TABULATED);
         else GR_PATH_LAUNCH(GenericMetric, GR_DISC_NONE);
     }
 #undef GR_PATH_LAUNCH

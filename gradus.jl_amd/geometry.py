@@ -3,7 +3,9 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
-GR_DISC_NONE, GR_DISC_THIN, GR_DISC_SHAKURA_SUNYAEV = 0, 1, 2
+import numpy as np
+
+GR_DISC_NONE, GR_DISC_THIN, GR_DISC_SHAKURA_SUNYAEV, GR_DISC_TABULATED = 0, 1, 2, 3
 
 
 class AbstractAccretionGeometry:
@@ -42,3 +44,25 @@ class ShakuraSunyaev(AbstractAccretionGeometry):
         if ρ < self.inner_radius:
             return -0.0
         return 3.0 * self.inv_η * self.Ṁ_Ṁedd * (1.0 - (self.inner_radius / ρ) ** 0.5)
+
+
+class ThickDisc(AbstractAccretionGeometry):
+    """ThickDisc(f; inner_radius = 0, outer_radius = Inf) -- src/geometry/discs/thick-disc.jl:30-58.
+
+    `f(ρ)` is the height cross-section (<= 0 where there is no disc).  A Python closure cannot run on
+    the device, so it is sampled on a uniform grid over `ρ_range` (`samples` points, linear
+    interpolation on the device); choose the range to cover the region where f > 0."""
+
+    disc_id = GR_DISC_TABULATED
+
+    def __init__(self, f, *, inner_radius=0.0, outer_radius=float("inf"), ρ_range=(0.0, 100.0), samples=16384):
+        if isinstance(f, (int, float)):
+            raise TypeError("Invalid constructor (you probably meant ThinDisc, not ThickDisc).")
+        self.f = f
+        self.inner_radius, self.outer_radius = float(inner_radius), float(outer_radius)
+        self.ρ_range = (float(ρ_range[0]), float(ρ_range[1]))
+        ρ = np.linspace(self.ρ_range[0], self.ρ_range[1], int(samples))
+        self.table = np.ascontiguousarray([float(f(r)) for r in ρ], dtype=np.float64)
+
+    def cross_section(self, ρ):
+        return self.f(ρ)

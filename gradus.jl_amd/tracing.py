@@ -14,7 +14,7 @@ from typing import Callable, Optional
 import numpy as np
 
 from . import _lib
-from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, ShakuraSunyaev, ThinDisc
+from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, ShakuraSunyaev, ThickDisc, ThinDisc
 from .metrics import AbstractMetric
 from .orthonormalization import lnrbasis
 
@@ -150,6 +150,12 @@ class TracingConfiguration:
             c.disc_id = self.geometry.disc_id
             c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float("inf")
             c.disc_params[0], c.disc_params[1] = float(self.geometry.Ṁ_Ṁedd), float(self.geometry.inv_η)
+        elif isinstance(self.geometry, ThickDisc):
+            g = self.geometry
+            c.disc_id = g.disc_id
+            c.disc_r_in, c.disc_r_out = g.inner_radius, g.outer_radius
+            c.disc_params[0], c.disc_params[1], c.disc_params[2] = g.ρ_range[0], g.ρ_range[1], float(g.table.max())
+            c.disc_table, c.disc_table_n = g.table.ctypes.data, g.table.size     # g keeps the array alive
         else:
             raise NotImplementedError(f"geometry {type(self.geometry).__name__} has no device implementation")
         c.gtol = float(self.gtol)

@@ -69,8 +69,12 @@ enum {
  *   THIN             ThinDisc        src/geometry/discs/thin-disc.jl:9-26       disc_r_in, disc_r_out, gtol
  *   SHAKURA_SUNYAEV  ShakuraSunyaev  src/geometry/discs/shakura-sunyaev.jl:22-33 disc_r_in = inner_radius,
  *                    disc_params = {Ṁ/Ṁ_Edd, 1/η}; height 3 (1/η)(Ṁ/Ṁ_Edd)(1 - sqrt(r_in/ρ)); thick-disc
- *                    distance_to_disc of src/geometry/discs/thick-disc.jl:60-66 (no gtol) */
-enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2 };
+ *                    distance_to_disc of src/geometry/discs/thick-disc.jl:60-66 (no gtol)
+ *   TABULATED        ThickDisc(f)    src/geometry/discs/thick-disc.jl:30-66: the user's cross_section
+ *                    closure cannot run on the device, so the host samples it on a uniform ρ grid:
+ *                    disc_params = {ρ_first, ρ_last, max height}, disc_table[disc_table_n] = f(ρ_k);
+ *                    linear interpolation, height <= 0 (or ρ outside the grid) = no disc there */
+enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_TABULATED = 3 };
 
 /* per-ray anomaly bits written next to the status (SciML retcodes MaxIters /
  * DtLessThanMin / Unstable, which EnsembleEndpointThreads discards, tracing.jl:250) */
@@ -96,6 +100,8 @@ typedef struct gr_config {
     int32_t _pad;
     double hemi_delta;        /* its δ, default 1e-4                                     */
     double disc_params[4];    /* extra geometry parameters, see GR_DISC_*                */
+    const double* disc_table; /* GR_DISC_TABULATED: HOST pointer in every entry point    */
+    int64_t disc_table_n;     /*   (copied into the context); NULL / 0 otherwise         */
 } gr_config;
 
 /* GeodesicPoint{Float64,Nothing} -- src/solution-processing.jl:15-32.  152 bytes, same

@@ -39,6 +39,8 @@ struct GrConfig                      # == gr_config
     _pad::Int32
     hemi_delta::Float64
     disc_params::NTuple{4,Float64}
+    disc_table::Ptr{Float64}
+    disc_table_n::Int64
 end
 
 struct GrStats                       # == gr_stats
@@ -78,7 +80,7 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2
     chart = config.chart::PolarChart
     GrConfig(id, did, params, chart.inner_radius, chart.outer_radius, rin, rout, gtol,
         config.λ_domain[1], config.λ_domain[2], config.abstol, config.reltol, Float64(trace.μ),
-        maxiters, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0))
+        maxiters, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0)
 end
 
 # The drop-in method: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,

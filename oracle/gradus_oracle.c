@@ -463,6 +463,29 @@ static double disc_condition(const orc_config* c, const double u[8])
 {
     const double r = u[1], th = u[2];
     const double rho = r * fabs(sin(th));
+    if (c->disc_id == ORC_DISC_TABULATED || c->disc_id == ORC_DISC_TORUS) {
+        /* ThickDisc(f): cross_section(d, ρ) = f(ρ), thick-disc.jl:57-66 (inner/outer radius 0/Inf) */
+        double height;
+        if (c->disc_id == ORC_DISC_TORUS) {
+            /* _thick_disc, test/smoke-tests/rendergeodesics.jl:7-14 */
+            const double ctr = c->disc_params[0], rad = c->disc_params[1];
+            if (rho < ctr - rad || rho > ctr + rad) height = -1.0;
+            else { const double xx = (rho - ctr) / rad; height = rad * sqrt(1.0 - xx * xx); }
+        } else {
+            const double r0 = c->disc_params[0], r1 = c->disc_params[1];
+            const int64_t n = c->disc_table_n;
+            if (rho < r0 || rho > r1) height = -1.0;
+            else {
+                const double uu = (rho - r0) * ((double)(n - 1) / (r1 - r0));
+                int64_t k = (int64_t)uu;
+                if (k > n - 2) k = n - 2;
+                const double w = uu - (double)k;
+                height = (1.0 - w) * c->disc_table[k] + w * c->disc_table[k + 1];
+            }
+        }
+        if (height <= 0.0) return 1.0;
+        return r * fabs(cos(th)) - height;
+    }
     if (c->disc_id == ORC_DISC_SHAKURA_SUNYAEV) {
         /* cross_section(::ShakuraSunyaev), geometry/discs/shakura-sunyaev.jl:28-33 ;
          * distance_to_disc(::AbstractThickAccretionDisc), geometry/discs/thick-disc.jl:60-66 */

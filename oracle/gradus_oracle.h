@@ -41,7 +41,10 @@ enum {
 
 enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE = 2, ORC_METRIC_BUMBLEBEE = 3,
        ORC_METRIC_KERR_NEWMAN = 4, ORC_METRIC_JOHANNSEN_PSALTIS = 5 };
-enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1, ORC_DISC_SHAKURA_SUNYAEV = 2 };
+/* TABULATED mirrors the product's sampled ThickDisc; TORUS is the closure `_thick_disc` of the
+ * reference's own smoke test (test/smoke-tests/rendergeodesics.jl:7-14) restated exactly, used to
+ * pin the thick-disc golden value. */
+enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1, ORC_DISC_SHAKURA_SUNYAEV = 2, ORC_DISC_TABULATED = 3, ORC_DISC_TORUS = 4 };
 
 /* per-ray anomaly flags (SciML retcodes that EnsembleEndpointThreads swallows) */
 enum { ORC_FLAG_MAXITERS = 1, ORC_FLAG_DTMIN = 2, ORC_FLAG_NAN = 4 };
@@ -60,7 +63,9 @@ typedef struct {
     int32_t upper_hemisphere; /* domain_upper_hemisphere callback enabled */
     int32_t _pad;
     double hemi_delta;
-    double disc_params[4];  /* ShakuraSunyaev: Mdot/Mdot_Edd, 1/eta */
+    double disc_params[4];  /* ShakuraSunyaev: Mdot/Mdot_Edd, 1/eta ; TABULATED: rho0, rho1, hmax ; TORUS: centre, radius */
+    const double* disc_table;
+    int64_t disc_table_n;
 } orc_config;
 
 /* GeodesicPoint{Float64,Nothing}, src/solution-processing.jl:15-32; 152 bytes */

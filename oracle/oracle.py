@@ -19,7 +19,7 @@ OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 
 METRIC_KERR, METRIC_JOHANNSEN = 0, 1
 METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "kerr-newman": 4,
               "johannsen-psaltis": 5}
-DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV = 0, 1, 2
+DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS = 0, 1, 2, 3, 4
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
 
@@ -44,6 +44,8 @@ class Config(C.Structure):
         ("_pad", C.c_int32),
         ("hemi_delta", C.c_double),
         ("disc_params", C.c_double * 4),
+        ("disc_table", C.c_void_p),
+        ("disc_table_n", C.c_int64),
     ]
 
 
@@ -169,6 +171,17 @@ def make_config(
     c.r_outer = outer_radius
     if disc is None:
         c.disc_id = DISC_NONE
+    elif isinstance(disc, dict) and "torus" in disc:     # the reference smoke test's ThickDisc closure
+        c.disc_id = DISC_TORUS
+        c.disc_r_in, c.disc_r_out = 0.0, float("inf")
+        c.disc_params[0], c.disc_params[1] = float(disc["torus"][0]), float(disc["torus"][1])
+    elif isinstance(disc, dict) and "table" in disc:     # sampled ThickDisc: {"table": heights, "range": (ρ0, ρ1)}
+        tab = np.ascontiguousarray(disc["table"], dtype=np.float64)
+        c._keep = tab
+        c.disc_id = DISC_TABULATED
+        c.disc_r_in, c.disc_r_out = 0.0, float("inf")
+        c.disc_params[0], c.disc_params[1], c.disc_params[2] = float(disc["range"][0]), float(disc["range"][1]), float(tab.max())
+        c.disc_table, c.disc_table_n = tab.ctypes.data, tab.size
     elif isinstance(disc, dict):       # ShakuraSunyaev: {"mdot": Ṁ/Ṁedd, "inv_eta": 1/η, "inner_radius": r_isco}
         c.disc_id = DISC_SHAKURA_SUNYAEV
         c.disc_r_in, c.disc_r_out = float(disc["inner_radius"]), float("inf")

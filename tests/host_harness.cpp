@@ -33,10 +33,12 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
 static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
 {
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+    p.disc_table = p.cfg.disc_table;      // host pointer is directly usable here
     const int disc = p.cfg.disc_id;
 #define HH_RUN(M) \
     do { if (disc == GR_DISC_THIN) run<M, GR_DISC_THIN>(p, p.n, tlog, hlog, cap, nlog); \
          else if (disc == GR_DISC_SHAKURA_SUNYAEV) run<M, GR_DISC_SHAKURA_SUNYAEV>(p, p.n, tlog, hlog, cap, nlog); \
+         else if (disc == GR_DISC_TABULATED) run<M, GR_DISC_TABULATED>(p, p.n, tlog, hlog, cap, nlog); \
          else run<M, GR_DISC_NONE>(p, p.n, tlog, hlog, cap, nlog); } while (0)
     if (p.cfg.metric_id == GR_METRIC_KERR) HH_RUN(KerrMetric); else HH_RUN(GenericMetric);
 #undef HH_RUN

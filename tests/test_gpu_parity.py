@@ -547,3 +547,21 @@ def test_lds_staging_is_transparent(G, ens):
                                 ensemble=ens)[1])
     ens.set("lds", 1)
     np.testing.assert_allclose(ys[0], ys[1], rtol=1e-12, atol=1e-18)
+
+
+def test_thick_disc_sampled_closure_on_device(G, oracle, ens):
+    ens.set("kernel", 1).set("precision", 64)
+
+    def torus(ρ):
+        return -1.0 if (ρ < 9.0 or ρ > 11.0) else math.sqrt(1.0 - (ρ - 10.0) ** 2)
+
+    m = G.KerrMetric(1.0, 0.9)
+    d = G.ThickDisc(torus, ρ_range=(8.5, 11.5), samples=8192)
+    W = H = 96
+    _, _, cache = G.prerendergeodesics(m, X_SMOKE, d, 200.0, image_width=W, image_height=H, alpha_lims=(-14, 14),
+                                       beta_lims=(-8, 8), ensemble=ens)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    ocfg = oracle.make_config("kerr", (1.0, 0.9), disc={"table": d.table, "range": d.ρ_range}, lambda_max=200.0)
+    ref = oracle.trace(ocfg, X_SMOKE, oracle.render_velocities(ocfg, X_SMOKE, (-14, 14), (-8, 8), W, H))
+    _compare_points(G, oracle, got, ref)
+    assert (ref["status"] == 2).sum() > 500
