@@ -156,6 +156,7 @@ EXPORTS = [
     "gr_ctx_set",
     "gr_render_device",
     "gr_render",
+    "gr_render_multi",
     "gr_render_endpoints_device",
     "gr_render_endpoints",
     "gr_trace_endpoints_device",
@@ -191,6 +192,7 @@ def load():
     cfgp, plp, pfp, rgp, stp = (C.POINTER(t) for t in (gr_config, gr_plane, gr_pointfunction, gr_range, gr_stats))
     L.gr_render_device.argtypes = [vp, cfgp, plp, pfp, rgp, vp, vp, vp]
     L.gr_render.argtypes = [vp, cfgp, plp, pfp, rgp, vp, stp]
+    L.gr_render_multi.argtypes = [C.POINTER(vp), i32, cfgp, plp, pfp, i64, vp, vp]
     L.gr_render_endpoints_device.argtypes = [vp, cfgp, plp, rgp, vp, vp, vp]
     L.gr_render_endpoints.argtypes = [vp, cfgp, plp, rgp, vp, stp]
     L.gr_trace_endpoints_device.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, vp, vp]

@@ -683,6 +683,42 @@ int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, cons
     return end_host_call(ctx, stats);
 }
 
+int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_plane* plane,
+                        const gr_pointfunction* pf, int64_t block_cols, double* image, gr_stats* stats)
+{
+    if (!ctxs || n < 1) return fail(GR_ERR_INVALID_ARGUMENT, "no contexts");
+    for (int k = 0; k < n; ++k)
+        if (!ctxs[k]) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!plane || !image) return fail(GR_ERR_INVALID_ARGUMENT, "plane/image is null");
+    const int64_t W = plane->width, H = plane->height;
+    if (W <= 0 || H <= 0) return fail(GR_ERR_INVALID_ARGUMENT, "image dimensions must be positive");
+    int64_t bc = block_cols > 0 ? block_cols : 8;
+    while (bc > 1 && W % (bc * n) != 0) bc /= 2;
+    if (W % (bc * n) != 0) return fail(GR_ERR_INVALID_ARGUMENT, "image width cannot be dealt in column blocks over the contexts");
+    const int64_t block = bc * H;                 // rays per block
+    const int64_t n_blocks = W / (bc * n);        // blocks per context
+    const int64_t count = n_blocks * block;
+    int32_t rc;
+    // phase 1: enqueue every device's trace and its strided copy home; nothing blocks here
+    for (int k = 0; k < n; ++k) {
+        gr_ctx* c = ctxs[k];
+        const size_t bytes = sizeof(double) * (size_t)count;
+        if ((rc = ensure(&c->d_scratch, &c->scratch_bytes, bytes)) != GR_OK) return rc;
+        if ((rc = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return rc;
+        const gr_range rg{ (int64_t)k * block, count, block, (int64_t)n };
+        if ((rc = gr_render_device(c, cfg, plane, pf, &rg, (double*)c->d_scratch,
+                                   stats ? (gr_stats*)c->d_stats : nullptr, c->stream)) != GR_OK) return rc;
+        // local block b of context k is image block b*n + k: one 2-D copy places all of them
+        GR_HIP(hipMemcpy2DAsync(image + (size_t)k * block, sizeof(double) * (size_t)(n * block), c->d_scratch,
+                                sizeof(double) * (size_t)block, sizeof(double) * (size_t)block, (size_t)n_blocks,
+                                hipMemcpyDeviceToHost, c->stream));
+    }
+    // phase 2: wait for all of them
+    for (int k = 0; k < n; ++k)
+        if ((rc = end_host_call(ctxs[k], stats ? &stats[k] : nullptr)) != GR_OK) return rc;
+    return GR_OK;
+}
+
 int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
                             gr_point* points, gr_stats* stats)
 {

@@ -81,10 +81,26 @@ class EnsembleMI355X:
     `ensemble_solve_tracing_problem`, src/tracing/tracing.jl:113-196).
     """
 
-    def __init__(self, device: int = 0, **knobs):
-        self.device = device
+    def __init__(self, device: int = 0, devices=None, **knobs):
+        """`devices=[0, 1, ...]` renders images on several GPUs from this one process
+        (gr_render_multi: columns dealt block-cyclically, strided D2H straight into the image)."""
+        self.device = device if devices is None else list(devices)[0]
+        self.devices = None if devices is None else [int(d) for d in devices]
         self.knobs = dict(knobs)
         self._ctx: Optional[_lib.Context] = None
+        self._extra: list = []
+
+    @property
+    def contexts(self):
+        """One context per entry of `devices` (the first is `ctx`)."""
+        if self.devices is None:
+            return [self.ctx]
+        while len(self._extra) < len(self.devices) - 1:
+            c = _lib.Context(self.devices[len(self._extra) + 1])
+            for k, v in self.knobs.items():
+                c.set(k, v)
+            self._extra.append(c)
+        return [self.ctx] + self._extra
 
     @property
     def ctx(self) -> _lib.Context:
@@ -98,6 +114,8 @@ class EnsembleMI355X:
         self.knobs[key] = value
         if self._ctx is not None:
             self._ctx.set(key, value)
+        for c in self._extra:
+            c.set(key, value)
         return self
 
 

@@ -199,6 +199,17 @@ int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane,
                   const gr_pointfunction* pf, const gr_range* range,
                   double* image /* host, range->count doubles */, gr_stats* stats /* host, may be NULL */);
 
+/* ---- the same render spread over several devices from ONE host thread (what a Julia caller of
+ * rendergeodesics(...; ensemble = EnsembleMI355X(devices)) uses; bench.py uses one process per GPU
+ * and an RCCL gather instead).  The image's columns are dealt to the n contexts block-cyclically in
+ * groups of `block_cols` columns (0 = default 8); each device traces its share asynchronously and
+ * copies it with one strided D2H copy straight into its place in `image`, so there is no exchange
+ * between devices at all.  ctxs may live on different devices or (for testing) on the same one.
+ * stats[k] receives the counters of ctxs[k] (may be NULL). */
+int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_plane* plane,
+                        const gr_pointfunction* pf, int64_t block_cols,
+                        double* image /* host, width*height doubles */, gr_stats* stats /* n entries or NULL */);
+
 /* ---- endpoints of an image plane: prerendergeodesics / EndpointRenderCache
  * (rendering.jl:56-87,121-138) ---- */
 int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane,

@@ -565,3 +565,23 @@ def test_thick_disc_sampled_closure_on_device(G, oracle, ens):
     ref = oracle.trace(ocfg, X_SMOKE, oracle.render_velocities(ocfg, X_SMOKE, (-14, 14), (-8, 8), W, H))
     _compare_points(G, oracle, got, ref)
     assert (ref["status"] == 2).sum() > 500
+
+
+def test_in_process_multi_device_render(G, ens):
+    """gr_render_multi: several contexts driven from one host thread, block-cyclic columns, strided
+    D2H straight into the image.  Exercised with 1, 2 and 4 contexts on the single device of the test
+    box; must equal the single-context render bit for bit."""
+    ens.set("kernel", 1).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    pf = G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    kw = dict(image_width=192, image_height=160, alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf)
+    _, _, ref = G.rendergeodesics(m, X_FAR, d, 2000.0, ensemble=ens, **kw)
+    for devs in ([0, 0], [0, 0, 0, 0]):
+        multi = G.EnsembleMI355X(devices=devs)
+        _, _, img, st = G.rendergeodesics(m, X_FAR, d, 2000.0, ensemble=multi, stats=True, **kw)
+        assert st["rays"] == 192 * 160
+        assert img.tobytes() == ref.tobytes()
+    with pytest.raises(G.GradusMI355XError):
+        G.rendergeodesics(m, X_FAR, d, 2000.0, ensemble=G.EnsembleMI355X(devices=[0, 0, 0]), image_width=20,
+                          image_height=20, alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf)      # 20 columns over 3 contexts
