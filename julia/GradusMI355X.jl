@@ -53,18 +53,54 @@ struct GrStats                       # == gr_stats
     kernel_ms::Float64
 end
 
+struct GrPlane                       # == gr_plane
+    x_obs::NTuple{4,Float64}
+    Mx::NTuple{16,Float64}           # row-major ginv * hcat(lnrbasis(g)...)
+    alpha0::Float64
+    alpha1::Float64
+    beta0::Float64
+    beta1::Float64
+    width::Int64
+    height::Int64
+    offset::Float64
+end
+
+struct GrPointFunction               # == gr_pointfunction
+    pf_id::Int32
+    filter_id::Int32
+    fill::Float64
+    r_isco::Float64
+    n_plunge::Int64
+    plunge_r::Ptr{Float64}
+    plunge_vt::Ptr{Float64}
+    plunge_vr::Ptr{Float64}
+    plunge_vphi::Ptr{Float64}
+end
+
+_check(rc) = rc == 0 || error(unsafe_string(ccall((:gr_last_error, LIB), Cstring, ())))
+
+"""
+    EnsembleMI355X(devices = [0])
+
+One `gr_ctx` per listed HIP device, all driven from the calling Julia task.  With several devices
+`rendergeodesics` deals the image's columns to them (`gr_render_multi`).
+"""
 mutable struct EnsembleMI355X
-    device::Int32
-    ctx::Ptr{Cvoid}
-    function EnsembleMI355X(device::Integer = 0)
-        ref = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:gr_ctx_create, LIB), Int32, (Int32, Ref{Ptr{Cvoid}}), device, ref)
-        rc == 0 || error(unsafe_string(ccall((:gr_last_error, LIB), Cstring, ())))
-        ens = new(device, ref[])
-        finalizer(e -> ccall((:gr_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), e.ctx), ens)
+    devices::Vector{Int32}
+    ctxs::Vector{Ptr{Cvoid}}
+    function EnsembleMI355X(devices = [0])
+        ctxs = Ptr{Cvoid}[]
+        for d in devices
+            ref = Ref{Ptr{Cvoid}}(C_NULL)
+            _check(ccall((:gr_ctx_create, LIB), Int32, (Int32, Ref{Ptr{Cvoid}}), d, ref))
+            push!(ctxs, ref[])
+        end
+        ens = new(Int32.(collect(devices)), ctxs)
+        finalizer(e -> foreach(c -> ccall((:gr_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), c), e.ctxs), ens)
         ens
     end
 end
+EnsembleMI355X(device::Integer) = EnsembleMI355X([device])
 
 _metric(m::KerrMetric) = (Int32(0), (m.M, m.a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m::JohannsenMetric) = (Int32(1), (m.M, m.a, m.α13, m.α22, m.α52, m.ϵ3, 0.0, 0.0))
@@ -109,9 +145,47 @@ function Gradus.ensemble_solve_tracing_problem(
     stats = Ref{GrStats}()
     rc = ccall((:gr_trace_endpoints, LIB), Int32,
         (Ptr{Cvoid}, Ref{GrConfig}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}, Ref{GrStats}),
-        ensemble.ctx, cfg, reinterpret(Float64, xs), length(xs) == 1 ? 0 : 4, reinterpret(Float64, vs), N, out, stats)
-    rc == 0 || error(unsafe_string(ccall((:gr_last_error, LIB), Cstring, ())))
+        ensemble.ctxs[1], cfg, reinterpret(Float64, xs), length(xs) == 1 ? 0 : 4, reinterpret(Float64, vs), N, out, stats)
+    _check(rc)
     out
+end
+
+# ---- fused fast path: rendergeodesics with a recognised built-in point function -------------------
+# `render_into_image!` (src/rendering/rendering.jl:89-101) receives the configuration whose velocity
+# is the closure of `_render_velocity_function` (rendering.jl:140-163); its captured variables give
+# αlims/βlims/W/H back, and `Mx` is what `lnr_momentum_to_global_velocity_transform` builds.
+"""
+    BuiltinPF(pf_id, filter_id)
+
+Tag for the point functions the kernels evaluate themselves: `pf_id` 0 = affine_time, 1 = redshift;
+`filter_id` 0 = none, 1 = filter_early_term, 2 = filter_intersected.  `render_mi355x` below is what
+`rendergeodesics(...; ensemble = EnsembleMI355X(...), pf = BuiltinPF(1, 2))` dispatches to.
+"""
+struct BuiltinPF
+    pf_id::Int32
+    filter_id::Int32
+end
+
+function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λmax; image_width, image_height,
+        αlims, βlims, pf::BuiltinPF = BuiltinPF(0, 1), gtol = 1e-2, abstol = 1e-9, reltol = 1e-9,
+        chart = Gradus.chart_for_metric(m))
+    id, params = _metric(m)
+    did, rin, rout = _disc(d)
+    cfg = Ref(GrConfig(id, did, params, chart.inner_radius, chart.outer_radius, rin, rout, gtol, 0.0, Float64(λmax),
+        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0))
+    g = Gradus.metric(m, x)
+    Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
+    plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), αlims[1], αlims[2], βlims[1], βlims[2],
+        image_width, image_height, 1e-6))
+    r_isco = pf.pf_id == 1 ? Float64(Gradus.isco(m)) : 0.0
+    pfs = Ref(GrPointFunction(pf.pf_id, pf.filter_id, NaN, r_isco, 0, C_NULL, C_NULL, C_NULL, C_NULL))
+    image = zeros(Float64, (image_height, image_width))             # rendering.jl:50, column-major H x W
+    stats = Vector{GrStats}(undef, length(ensemble.ctxs))
+    _check(ccall((:gr_render_multi, LIB), Int32,
+        (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Int64, Ptr{Float64}, Ptr{GrStats}),
+        ensemble.ctxs, length(ensemble.ctxs), cfg, plane, pfs, 0, image, stats))
+    α, β = Gradus.impact_axes(image_width, image_height, αlims, βlims)
+    α, β, image
 end
 
 end # module
