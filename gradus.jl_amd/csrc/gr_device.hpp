@@ -313,6 +313,93 @@ struct KerrMetric {
     }
 };
 
+// Johannsen metric with hand-written derivatives (johannsen-ad.jl:12-34): about half the flops of
+// the dual-number evaluation.  With N = (r²+a²)A1 - a²A2 sin²θ:
+//   g_tt = -Σ T/N², g_ϕϕ = Σ sin²θ P/N², g_tϕ = -a Σ sin²θ Q/N², g_rr = Σ/(Δ A5), g_θθ = Σ
+//   T = Δ - a²A2² sin²θ, P = (r²+a²)²A1² - a²Δ sin²θ, Q = (r²+a²)A1A2 - Δ
+// and for f = ΣXW (W = 1/N²): ∂f = (∂Σ X + Σ ∂X) W - 2 f ∂N/N.
+struct JohannsenMetric {
+    static constexpr int kMinWavesPerSimd = 2;
+    real M, a, a13, a22, a52, e3;
+    GR_DEV void load(const gr_config& c)
+    {
+        M = c.params[0]; a = c.params[1]; a13 = c.params[2]; a22 = c.params[3]; a52 = c.params[4]; e3 = c.params[5];
+    }
+
+    GR_DEV void comps(real r, real s, real c, real g[5]) const
+    {
+        real gr[5], gt[5], gi[5];
+        eval(r, s, c, g, gr, gt, gi);
+    }
+
+    GR_DEV void eval(real r, real s, real c, real g[5], real gr[5], real gt[5], real gi[5]) const
+    {
+        const real a2 = a * a, s2 = s * s, sc2 = 2.0 * s * c, r2 = r * r;
+        const real ir = rcp_full(r);
+        const real Mr = M * ir, Mr2 = Mr * Mr, Mr3 = Mr2 * Mr;
+        const real A1 = GR_FMA(a13, Mr3, 1.0), A2 = GR_FMA(a22, Mr2, 1.0), A5 = GR_FMA(a52, Mr2, 1.0);
+        const real A1r = -3.0 * a13 * Mr3 * ir, A2r = -2.0 * a22 * Mr2 * ir, A5r = -2.0 * a52 * Mr2 * ir;
+        const real eM3 = e3 * M * M * M;
+        const real Sig = GR_FMA(a2, c * c, r2) + eM3 * ir;
+        const real Sig_r = 2.0 * r - eM3 * ir * ir;
+        const real Sig_t = -a2 * sc2;
+        const real Del = GR_FMA(-2.0 * M, r, r2) + a2;
+        const real Del_r = 2.0 * r - 2.0 * M;
+        const real P1 = r2 + a2, P1r = 2.0 * r;
+        const real a2s2 = a2 * s2;
+        const real N = P1 * A1 - a2s2 * A2;
+        const real N_r = P1r * A1 + P1 * A1r - a2s2 * A2r;
+        const real N_t = -a2 * A2 * sc2;
+        const real DA5 = Del * A5;
+        // 1/N, 1/(ΔA5), 1/Σ from one reciprocal
+        const real NS = N * Sig;
+        const real Pinv = rcp_full(NS * DA5);
+        const real iN = Pinv * Sig * DA5;
+        const real iDA5 = Pinv * NS;
+        const real iSig = Pinv * N * DA5;
+        const real W = iN * iN;
+        const real A2sq = A2 * A2;
+        const real T = Del - a2s2 * A2sq;
+        const real T_r = Del_r - 2.0 * a2s2 * A2 * A2r;
+        const real T_t = -a2 * A2sq * sc2;
+        const real P1A1 = P1 * A1;
+        const real P = P1A1 * P1A1 - a2s2 * Del;
+        const real P_r = 2.0 * P1A1 * (P1r * A1 + P1 * A1r) - a2s2 * Del_r;
+        const real P_t = -a2 * Del * sc2;
+        const real Q = P1A1 * A2 - Del;
+        const real Q_r = (P1r * A1 + P1 * A1r) * A2 + P1A1 * A2r - Del_r;
+        const real SW = Sig * W;
+        const real tNr = 2.0 * N_r * iN, tNt = 2.0 * N_t * iN;
+
+        g[0] = -SW * T;
+        g[1] = Sig * iDA5;
+        g[2] = Sig;
+        g[3] = SW * s2 * P;
+        g[4] = -a * SW * s2 * Q;
+
+        gr[0] = -(Sig_r * T + Sig * T_r) * W - g[0] * tNr;
+        gr[1] = (Sig_r - g[1] * (Del_r * A5 + Del * A5r)) * iDA5;
+        gr[2] = Sig_r;
+        gr[3] = s2 * (Sig_r * P + Sig * P_r) * W - g[3] * tNr;
+        gr[4] = -a * s2 * (Sig_r * Q + Sig * Q_r) * W - g[4] * tNr;
+
+        gt[0] = -(Sig_t * T + Sig * T_t) * W - g[0] * tNt;
+        gt[1] = Sig_t * iDA5;
+        gt[2] = Sig_t;
+        gt[3] = ((Sig_t * s2 + Sig * sc2) * P + Sig * s2 * P_t) * W - g[3] * tNt;
+        gt[4] = -a * (Sig_t * s2 + Sig * sc2) * Q * W - g[4] * tNt;
+
+        // inverse: 1/g_rr = ΔA5/Σ, 1/g_θθ = 1/Σ, and the t-ϕ block
+        const real D2 = GR_FMA(g[0], g[3], -g[4] * g[4]);
+        const real iD2 = rcp_full(D2);
+        gi[0] = g[3] * iD2;
+        gi[1] = DA5 * iSig;
+        gi[2] = iSig;
+        gi[3] = g[0] * iD2;
+        gi[4] = -g[4] * iD2;
+    }
+};
+
 // Every other AbstractStaticAxisSymmetric metric: components written once over a number type and
 // differentiated with forward-mode duals, as the reference does for all of its metrics.  One
 // functor with a (wave-uniform) switch on the metric id keeps the number of kernel instantiations
