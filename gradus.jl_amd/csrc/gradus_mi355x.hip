@@ -512,6 +512,8 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     const int64_t grid = (n + block - 1) / block;
     if (cfg->metric_id == GR_METRIC_KERR)
         hipLaunchKernelGGL((k_apply_pf<KerrMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
+    else if (cfg->metric_id == GR_METRIC_JOHANNSEN)
+        hipLaunchKernelGGL((k_apply_pf<JohannsenMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     else
         hipLaunchKernelGGL((k_apply_pf<GenericMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     GR_HIP(hipGetLastError());
@@ -555,17 +557,17 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const 
     p.cold = slot;
     if ((rc = stage_disc_table(ctx, p, ctx->stream)) != GR_OK) return rc;
 #define GR_PATH_LAUNCH(M, D) hipLaunchKernelGGL((k_trace_path<M, D>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n)
-    if (cfg->metric_id == GR_METRIC_KERR) {
-        if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(KerrMetric, GR_DISC_THIN);
-        else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(KerrMetric, GR_DISC_SHAKURA_SUNYAEV);
-        else if (cfg->disc_id == GR_DISC_TABULATED) GR_PATH_LAUNCH(KerrMetric, GR_DISC_TABULATED);
-        else GR_PATH_LAUNCH(KerrMetric, GR_DISC_NONE);
-    } else {
-        if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(GenericMetric, GR_DISC_THIN);
-        else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(GenericMetric, GR_DISC_SHAKURA_SUNYAEV);
-        else if (cfg->disc_id == GR_DISC_TABULATED) GR_PATH_LAUNCH(GenericMetric, GR_DISC_TABULATED);
-        else GR_PATH_LAUNCH(GenericMetric, GR_DISC_NONE);
-    }
+#define GR_PATH_BY_DISC(M)                                                                       \
+    do {                                                                                         \
+        if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(M, GR_DISC_THIN);                       \
+        else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(M, GR_DISC_SHAKURA_SUNYAEV); \
+        else if (cfg->disc_id == GR_DISC_TABULATED) GR_PATH_LAUNCH(M, GR_DISC_TABULATED);        \
+        else GR_PATH_LAUNCH(M, GR_DISC_NONE);                                                    \
+    } while (0)
+    if (cfg->metric_id == GR_METRIC_KERR) GR_PATH_BY_DISC(KerrMetric);
+    else if (cfg->metric_id == GR_METRIC_JOHANNSEN) GR_PATH_BY_DISC(JohannsenMetric);
+    else GR_PATH_BY_DISC(GenericMetric);
+#undef GR_PATH_BY_DISC
 #undef GR_PATH_LAUNCH
     GR_HIP(hipGetLastError());
     unsigned long long n = 0;
