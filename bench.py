@@ -53,7 +53,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=2048, help="image is size x size")
-    ap.add_argument("--kernel", type=int, default=1, help="0 = one ray per lane, 1 = persistent")
+    ap.add_argument("--kernel", type=int, default=2, help="0 = one ray per lane, 1 = persistent, 2 = auto by launch depth")
+    ap.add_argument("--lpt-lane", type=int, default=None)
     ap.add_argument("--refill-threshold", type=int, default=None)
     ap.add_argument("--waves-per-simd", type=int, default=None)
     ap.add_argument("--block-cols", type=int, default=8)
@@ -133,6 +134,8 @@ def main():
         ens.set("refill_threshold", args.refill_threshold)
     if args.waves_per_simd is not None:
         ens.set("waves_per_simd", args.waves_per_simd)
+    if args.lpt_lane is not None:
+        ens.set("lpt_lane", args.lpt_lane)
     m, x, d, pf, cfg = workload(G, args.size, ens)
     plan = G.shard_plan(args.size, args.size, world, rank, args.block_cols)
     if args.emulate_shard:
@@ -240,7 +243,8 @@ def main():
                             "ThinDisc(r_isco,50), redshift∘filter_intersected, Tsit5 tol 1e-9, lambda_max=2000",
                 "sharding": f"{world} rank(s), block-cyclic by {plan.block_cols} columns, one RCCL gather per render "
                             "(overlapped with the next render's kernel, double-buffered slabs)",
-                "kernel": "persistent+wave-ballot-refill" if args.kernel == 1 else "one-ray-per-lane",
+                "kernel": {0: "one-ray-per-lane", 1: "persistent+wave-ballot-refill",
+                           2: "auto: persistent+wave-ballot-refill when >= 6 rays per resident lane, else one-ray-per-lane"}[args.kernel],
                 "rays_per_gpu": plan.count,
                 "steps_per_ray": steps_launch / rays_launch,
                 "rejected_steps_per_ray": st["rejected_steps"] / max(st["rays"], 1),

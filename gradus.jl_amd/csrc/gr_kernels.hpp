@@ -77,7 +77,10 @@ __device__ __forceinline__ void lds_epilogue(const Params& p, const LdsView& v)
 
 // ---- kernel 0: one ray per work-item ----
 template <class Metric, int DISC>
-__global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_lane(const Params p)
+#ifndef GR_LANE_MIN_WAVES
+#define GR_LANE_MIN_WAVES Metric::kMinWavesPerSimd
+#endif
+__global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Params p)
 {
     Metric m;
     m.load(p.cfg);

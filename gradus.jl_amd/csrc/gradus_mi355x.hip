@@ -67,7 +67,8 @@ struct gr_ctx {
     void* d_in = nullptr;
     size_t in_bytes = 0;
     // knobs
-    int64_t kernel = 1;
+    int64_t kernel = 2;                    // 0 lane, 1 persistent, 2 auto (by launch depth)
+    int64_t lpt_lane = 0;                  // also order tiles longest-first for the lane kernel
     int64_t block = 256;
     int64_t refill_threshold = 16;
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
@@ -153,12 +154,24 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 // tiles by that cost, longest first, so the rays started last are the short ones and the tail of
 // the launch (queue empty, waves draining) shrinks.  Only the ORDER of the work queue is learned:
 // every ray is traced in full every time and results are bit-identical with or without it.
+// Which launch shape a launch of n rays gets under kernel = 2 (auto).  Measured on MI355X with
+// bench.py --emulate-shard: below ~6 rays per resident lane the one-ray-per-lane kernel wins (no
+// refill batches to wait for: 3.5 vs 3.8 ms on a 1/8 shard of the 2048² image), above it the
+// persistent kernel does (6.4 vs 6.8 ms on a 1/4 shard, 23.8 vs 26.4 ms on the whole image).
+int resolve_kernel(const gr_ctx* ctx, int64_t n)
+{
+    if (ctx->kernel != 2) return (int)ctx->kernel;
+    const int64_t resident_lanes = (int64_t)ctx->n_cu * 8 * 64;
+    return n < 6 * resident_lanes ? 0 : 1;
+}
+
 int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream, bool* record)
 {
     *record = false;
     cold.tile_perm = nullptr;
     cold.tile_cost = nullptr;
-    if (!ctx->lpt || ctx->kernel != 1 || !cold.swizzle || cold.src_mode != 0) return GR_OK;
+    const int kern = resolve_kernel(ctx, p.n);
+    if (!ctx->lpt || (kern != 1 && !ctx->lpt_lane) || !cold.swizzle || cold.src_mode != 0) return GR_OK;
     const int64_t tiles = p.n >> 6;
     // Measured on MI355X: longest-first pays when a launch is only a few tiles per
     // resident wave deep (the 1/8 shard of a 2048² image: 4.0 -> 3.7 ms on the rank holding the
@@ -238,7 +251,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
                          && cold_in.pf.n_plunge <= 2048) ? (int32_t)cold_in.pf.n_plunge : 0;
     p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    LaunchKnobs knobs{ (int)ctx->kernel, (int)ctx->block, ctx->n_cu, (int)ctx->waves_per_simd,
+    LaunchKnobs knobs{ resolve_kernel(ctx, p.n), (int)ctx->block, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
     ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
     hipError_t le;
@@ -392,7 +405,7 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
     if (!c || !key) return fail(GR_ERR_INVALID_ARGUMENT, "ctx/key is null");
     const std::string k(key);
     if (k == "kernel") {
-        if (value != 0 && value != 1) return fail(GR_ERR_INVALID_ARGUMENT, "kernel must be 0 or 1");
+        if (value < 0 || value > 2) return fail(GR_ERR_INVALID_ARGUMENT, "kernel must be 0 (lane), 1 (persistent) or 2 (auto)");
         c->kernel = value;
     } else if (k == "block") {
         if (value < 64 || value > 256 || value % 64) return fail(GR_ERR_INVALID_ARGUMENT, "block must be a multiple of 64 in [64, 256]");
@@ -405,6 +418,9 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->waves_per_simd = value;
     } else if (k == "swizzle") {
         c->swizzle = value ? 1 : 0;
+    } else if (k == "lpt_lane") {
+        c->lpt_lane = value ? 1 : 0;
+        c->lpt_key.clear();
     } else if (k == "lds") {
         c->lds = value ? 1 : 0;
     } else if (k == "precision") {
