@@ -7,6 +7,11 @@ work runs in hand-written HIP kernels for gfx950; there is no CPU fallback.
 from . import _lib
 from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
+from . import corona
+from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGenerator, EvenSampler,
+                     GoldenSpiralGenerator, LampPostModel, LowerHemisphere, PowerLawSpectrum, RadialDiscProfile,
+                     RandomGenerator, WeierstrassSampler, coordtime_at, emissivity_at, emissivity_profile,
+                     energy_ratio, lorentz_factor, sky_angles_to_velocity, tetradframe_matrix, tracecorona)
 from .distributed import gather_image, gather_image_async, shard_plan
 from .geometry import ShakuraSunyaev, ThickDisc, ThinDisc
 from .lineprofiles import BinningMethod, PowerLawEmissivity, bucket_simple, lineprofile

@@ -1437,13 +1437,14 @@ struct Ray {
                 // ε(r) g³ area with ε(r) = r^-q
                 const real eps = (cd.lp_q == 3.0) ? rcp_full(rho * rho * rho) : GR_POW(rho, -cd.lp_q);
                 const real f = eps * g * g * g * area;
-                // bucket(Simple(), g, f, bins): first edge >= g, clamped to the last bin
+                // bucket(Simple(), g, f, bins): last edge <= g, clamped to the first / last bin
+                // (the convention the reference's emissivity golden pins, test/unit/emissivity.jl:27-48)
                 int64_t lo = 0, hi = cd.lp_nbins;
                 while (lo < hi) {
                     const int64_t mid = (lo + hi) >> 1;
-                    if (cd.lp_edges[mid] < g) lo = mid + 1; else hi = mid;
+                    if (cd.lp_edges[mid] <= g) lo = mid + 1; else hi = mid;
                 }
-                if (lo > cd.lp_nbins - 1) lo = cd.lp_nbins - 1;
+                lo = lo > 0 ? lo - 1 : 0;
                 if (f == f) gr_atomic_add((lds.hist ? lds.hist : cd.lp_flux) + lo, f);
             }
         } else {

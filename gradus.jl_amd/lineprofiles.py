@@ -4,9 +4,11 @@ The image plane (PolarPlane / CartesianPlane) is traced on the device from its i
 for a power-law emissivity the weighting ε(r) g³ area and the binning over g are fused into the
 trace kernel (fp64 atomics into the flux array), otherwise the device returns (g, ρ) per ray and
 the emissivity and `bucket` run on the host.  `bucket(Simple(), g, f, bins)` is Buckets.jl
-(third party, not vendored by the reference): restated as "first bin edge >= g, clamped to the
-last bin"; the reference's tests constrain it only through the profile's edges and unit sum
-(test/line-profiles/test-binning.jl:5-32).
+(third party, not vendored by the reference): restated as "last bin edge <= g, clamped to the
+first / last bin".  The line-profile tests constrain it only through the profile's edges and unit
+sum (test/line-profiles/test-binning.jl:5-32); the convention itself is pinned by the golden
+emissivity vector of test/unit/emissivity.jl:27-48, which goes through the same `Simple()` bucket
+(corona.py) and is reproduced to 1e-10 with this rule and not at all with the other.
 """
 from __future__ import annotations
 
@@ -38,7 +40,7 @@ class PowerLawEmissivity:
 def bucket_simple(g, f, bins):
     """bucket(Simple(), g, f, bins)"""
     bins = np.asarray(bins, dtype=np.float64)
-    idx = np.minimum(np.searchsorted(bins, g, side="left"), bins.size - 1)
+    idx = np.clip(np.searchsorted(bins, g, side="right") - 1, 0, bins.size - 1)
     return np.bincount(idx, weights=f, minlength=bins.size)
 
 

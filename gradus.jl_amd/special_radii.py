@@ -19,7 +19,9 @@ class Jet:
     __slots__ = ("v", "d", "dd")
 
     def __init__(self, v, d=0.0, dd=0.0):
-        self.v, self.d, self.dd = float(v), float(d), float(dd)
+        # floats, or numpy arrays of one shape (vectorised evaluation over many radii)
+        f = lambda z: z if isinstance(z, np.ndarray) else float(z)
+        self.v, self.d, self.dd = f(v), f(d), f(dd)
 
     @staticmethod
     def lift(x):
@@ -64,7 +66,7 @@ class Jet:
         return out
 
     def sqrt(self):
-        s = math.sqrt(self.v)
+        s = np.sqrt(self.v)
         d = 0.5 * self.d / s
         return Jet(s, d, (0.5 * self.dd - d * d) / s)
 

@@ -261,7 +261,7 @@ typedef struct gr_binning {
 } gr_binning;
 
 /* flux[k] += ε(ρ) g³ area for every counted hit whose redshift g falls in bin k
- * (bucket(Simple(), g, f, bins): first edge >= g, clamped to the last bin).  NOT normalised;
+ * (bucket(Simple(), g, f, bins): last edge <= g, clamped to the first / last bin).  NOT normalised;
  * the caller divides by sum(flux) (line-profiles.jl:197).  Device variant: rays->alpha/beta/area,
  * b->bin_edges and d_flux are device pointers; d_flux is zeroed by the call. */
 int32_t gr_lineprofile_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
