@@ -52,6 +52,7 @@ class gr_config(C.Structure):
         ("disc_params", C.c_double * 4),
         ("disc_table", C.c_void_p),
         ("disc_table_n", C.c_int64),
+        ("q", C.c_double),
     ]
 
 

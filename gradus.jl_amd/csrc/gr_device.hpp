@@ -246,6 +246,7 @@ GR_DEV void inverse_generic(const real g[5], real gi[5])
 }
 
 struct KerrMetric {
+    static constexpr bool kHasForce = false;
     static constexpr int kMinWavesPerSimd = 1;   // fits 2 waves/SIMD on its own (197 VGPRs)
     real M, a;
     GR_DEV void load(const gr_config& c) { M = c.params[0]; a = c.params[1]; }
@@ -319,6 +320,7 @@ struct KerrMetric {
 //   T = Δ - a²A2² sin²θ, P = (r²+a²)²A1² - a²Δ sin²θ, Q = (r²+a²)A1A2 - Δ
 // and for f = ΣXW (W = 1/N²): ∂f = (∂Σ X + Σ ∂X) W - 2 f ∂N/N.
 struct JohannsenMetric {
+    static constexpr bool kHasForce = false;
     static constexpr int kMinWavesPerSimd = 2;
     real M, a, a13, a22, a52, e3;
     GR_DEV void load(const gr_config& c)
@@ -408,13 +410,43 @@ struct GenericMetric {
     // the dual-number evaluation wants ~285 registers; capping it at 256 (2 waves/SIMD) costs a few
     // scratch spills but keeps the VALU busy (measured: see DESIGN.md §5)
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
+    static constexpr bool kHasForce = true;
     int32_t id;
     real P[6];
+    real qm;     // q (or q/μ): Lorentz force on a charged test particle; Kerr-Newman only
     GR_DEV void load(const gr_config& c)
     {
         id = c.metric_id;
 #pragma unroll
         for (int i = 0; i < 6; ++i) P[i] = c.params[i];
+        const double amu = c.mu < 0.0 ? -c.mu : c.mu;
+        qm = (id == GR_METRIC_KERR_NEWMAN) ? (real)(amu < 1.4901161193847656e-08 ? c.q : c.q / c.mu) : (real)0.0;
+    }
+
+    // q F^μ_κ v^κ, F = g⁻¹(∂A - ∂Aᵀ) (tracing/utility.jl:89-99), A = (rQ/Σ)(1, 0, 0, -a sin²θ)
+    // (kerr-newman-ad.jl:29-33), added to the acceleration as in kerr-newman-ad.jl:66-100.
+    // Hand-differentiated: with p = rQ/Σ, p_r = Q(Σ - 2r²)/Σ², p_θ = 2a² rQ sinθ cosθ/Σ².
+    GR_DEV void add_force(real r, real s, real c, const real gi[5], real vt, real vr, real vh, real vp,
+                          real& at, real& ar, real& ah, real& ap) const
+    {
+        if (qm == 0.0) return;
+        const real a = P[1], Q = P[2];
+        const real r2 = r * r, s2 = s * s, sc = s * c;
+        const real Sig = GR_FMA(a * a, c * c, r2);
+        const real iSig = rcp_full(Sig);
+        const real p = r * Q * iSig;
+        const real p_r = Q * (Sig - 2.0 * r2) * iSig * iSig;
+        const real p_t = 2.0 * a * a * sc * p * iSig;
+        const real Ap_r = -a * s2 * p_r;
+        const real Ap_t = -a * (2.0 * sc * p + s2 * p_t);
+        const real wt = p_r * vr + p_t * vh;
+        const real wp = Ap_r * vr + Ap_t * vh;
+        const real wr = -(p_r * vt + Ap_r * vp);
+        const real wh = -(p_t * vt + Ap_t * vp);
+        at += qm * (gi[0] * wt + gi[4] * wp);
+        ar += qm * (gi[1] * wr);
+        ah += qm * (gi[2] * wh);
+        ap += qm * (gi[4] * wt + gi[3] * wp);
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
     static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
@@ -570,6 +602,7 @@ GR_DEV void geodesic_rhs_sc(const Metric& m, real r, real s, real c, real vt, re
     ar = -(gi[1] * Tr);
     ah = -(gi[2] * Th);
     ap = -GR_FMA(gi[4], Tt, gi[3] * Tp);
+    if constexpr (Metric::kHasForce) m.add_force(r, s, c, gi, vt, vr, vh, vp, at, ar, ah, ap);
 }
 
 template <class Metric>

@@ -149,6 +149,7 @@ class TracingConfiguration:
     gtol: float = 1e-2
     μ: float = 0.0
     maxiters: int = 1_000_000
+    q: float = 0.0
 
     def abi_config(self) -> _lib.gr_config:
         c = _lib.gr_config()
@@ -180,6 +181,7 @@ class TracingConfiguration:
         c.lambda0, c.lambda1 = float(self.λ_domain[0]), float(self.λ_domain[1])
         c.abstol, c.reltol = float(self.abstol), float(self.reltol)
         c.mu = float(self.μ)
+        c.q = float(self.q)
         c.maxiters = int(self.maxiters)
         if self.callback is None:
             c.upper_hemisphere = 0
@@ -229,6 +231,7 @@ def tracing_configuration(
     gtol=1e-2,
     μ=0.0,
     maxiters=1_000_000,
+    q=0.0,
     solver="Tsit5",
     save_on=False,
 ):
@@ -266,7 +269,7 @@ def tracing_configuration(
         chart = chart_for_metric(m)
     return TracingConfiguration(
         m, position, velocity, geometry, chart, callback, ensemble, trajectories, _as_lambda_domain(λs),
-        abstol, reltol, gtol, μ, maxiters,
+        abstol, reltol, gtol, μ, maxiters, q,
     )
 
 

@@ -102,6 +102,9 @@ typedef struct gr_config {
     double disc_params[4];    /* extra geometry parameters, see GR_DISC_*                */
     const double* disc_table; /* GR_DISC_TABULATED: HOST pointer in every entry point    */
     int64_t disc_table_n;     /*   (copied into the context); NULL / 0 otherwise         */
+    double q;                 /* test-particle charge, TraceGeodesic.q (tracing.jl:1-7): adds the
+                                 Lorentz force q F^μ_ν v^ν (q/μ for μ != 0) for GR_METRIC_KERR_NEWMAN,
+                                 kerr-newman-ad.jl:66-100; ignored by metrics without a field     */
 } gr_config;
 
 /* GeodesicPoint{Float64,Nothing} -- src/solution-processing.jl:15-32.  152 bytes, same

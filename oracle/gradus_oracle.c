@@ -186,11 +186,50 @@ void orc_geodesic_equation(const orc_config* c, const double x[4], const double 
     compute_geodesic_equation(gi, j1, j2_, v, acc);
 }
 
+/* electromagnetic_potential of Kerr-Newman on dual numbers, kerr-newman-ad.jl:29-33:
+ * A = (r Q / Σ) (1, 0, 0, -a sin²θ); only A_t and A_ϕ are non-zero */
+static void kerr_newman_potential_d2(const double* p, d2 r, d2 th, d2* At, d2* Ap)
+{
+    const double a = p[1], Q = p[2];
+    d2 c = d2_cos(th), s = d2_sin(th);
+    d2 ac = d2_scale(a, c);
+    d2 Sig = d2_add(d2_mul(r, r), d2_mul(ac, ac));
+    d2 P = d2_div(d2_scale(Q, r), Sig);
+    *At = P;
+    *Ap = d2_mul(P, d2_scale(-a, d2_mul(s, s)));
+}
+
+/* q/μ · F^μ_κ v^κ with F = g⁻¹ (∂A - ∂Aᵀ), faraday_tensor, tracing/utility.jl:89-99, as added to
+ * the geodesic acceleration by geodesic_ode_problem(::KerrNewmanMetric), kerr-newman-ad.jl:66-100 */
+static void kerr_newman_lorentz_force(const orc_config* c, const double x[4], const double v[4], double f[4])
+{
+    d2 rr = { x[1], 1.0, 0.0 }, tt = { x[2], 0.0, 1.0 }, At, Ap;
+    kerr_newman_potential_d2(c->params, rr, tt, &At, &Ap);
+    double g[5], j1[5], j2_[5], gi[5];
+    orc_metric_jacobian(c, x[1], x[2], g, j1, j2_);
+    inverse_metric_components(g, gi);
+    /* w_σ = (∂_κ A_σ - ∂_σ A_κ) v^κ ; ∂_t = ∂_ϕ = 0, A_r = A_θ = 0 */
+    const double wt = At.a * v[1] + At.b * v[2];
+    const double wp = Ap.a * v[1] + Ap.b * v[2];
+    const double wr = -(At.a * v[0] + Ap.a * v[3]);
+    const double wh = -(At.b * v[0] + Ap.b * v[3]);
+    const double qm = (fabs(c->mu) < 1.4901161193847656e-08) ? c->q : c->q / c->mu;   /* trace.μ ≈ 0 */
+    f[0] = qm * (gi[0] * wt + gi[4] * wp);
+    f[1] = qm * (gi[1] * wr);
+    f[2] = qm * (gi[2] * wh);
+    f[3] = qm * (gi[4] * wt + gi[3] * wp);
+}
+
 /* _second_order_ode_f, geodesic-problem.jl:87-92 */
 static void rhs(const orc_config* c, const double u[8], double du[8])
 {
     du[0] = u[4]; du[1] = u[5]; du[2] = u[6]; du[3] = u[7];
     orc_geodesic_equation(c, u, u + 4, du + 4);
+    if (c->metric_id == ORC_METRIC_KERR_NEWMAN && c->q != 0.0) {
+        double f[4];
+        kerr_newman_lorentz_force(c, u, u + 4, f);
+        for (int i = 0; i < 4; ++i) du[4 + i] += f[i];
+    }
 }
 
 static void metric_components(const orc_config* c, double r, double th, double g[5])

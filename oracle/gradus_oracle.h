@@ -66,6 +66,7 @@ typedef struct {
     double disc_params[4];  /* ShakuraSunyaev: Mdot/Mdot_Edd, 1/eta ; TABULATED: rho0, rho1, hmax ; TORUS: centre, radius */
     const double* disc_table;
     int64_t disc_table_n;
+    double q;               /* test-particle charge (TraceGeodesic.q); Lorentz force for Kerr-Newman only */
 } orc_config;
 
 /* GeodesicPoint{Float64,Nothing}, src/solution-processing.jl:15-32; 152 bytes */

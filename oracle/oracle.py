@@ -46,6 +46,7 @@ class Config(C.Structure):
         ("disc_params", C.c_double * 4),
         ("disc_table", C.c_void_p),
         ("disc_table_n", C.c_int64),
+        ("q", C.c_double),
     ]
 
 
@@ -162,6 +163,7 @@ def make_config(
     upper_hemisphere=False,
     hemi_delta=1e-4,
     maxiters=1_000_000,
+    q=0.0,
 ) -> Config:
     c = Config()
     c.metric_id = METRIC_IDS[metric]
@@ -196,6 +198,7 @@ def make_config(
     c.maxiters = maxiters
     c.upper_hemisphere = int(bool(upper_hemisphere))
     c.hemi_delta = hemi_delta
+    c.q = q
     return c
 
 

@@ -441,6 +441,30 @@ def test_more_reference_fingerprints_on_device(G, ens):
     assert float(np.nansum(img)) == pytest.approx(428809.9681726607, rel=1e-6)
 
 
+def test_charged_test_particles_in_kerr_newman(G, oracle, ens):
+    """rendergeodesics(KerrNewmanMetric(1, 0.6, 0.6), ...; q = ±1): Lorentz force q F^μ_ν v^ν on the
+    device against the reference's fingerprints (test/unit/metrics.kerr-newman.jl:26-27, rtol 1e-3
+    there) and, end point by end point, against the oracle."""
+    u = np.array([0.0, 1000.0, math.pi / 2, 0.0])
+    m = G.KerrNewmanMetric(1.0, 0.6, 0.6)
+    kw = dict(image_width=40, image_height=40, alpha_lims=(-8, 8), beta_lims=(-8, 8), ensemble=ens)
+    for kernel in (0, 1):
+        ens.set("kernel", kernel)
+        for q, gold in ((1.0, 253280.6794972752), (-1.0, 619335.5670363897)):
+            _, _, img = G.rendergeodesics(m, u, 2000.0, q=q, **kw)
+            assert float(np.nansum(img)) == pytest.approx(gold, rel=1e-6)
+    _, _, cache = G.prerendergeodesics(m, u, 2000.0, q=1.0, **kw)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    ocfg = oracle.make_config("kerr-newman", (1.0, 0.6, 0.6), lambda_max=2000.0, q=1.0)
+    ref = oracle.trace(ocfg, u, oracle.render_velocities(ocfg, u, (-8, 8), (-8, 8), 40, 40))
+    _compare_points(G, oracle, got, ref)
+    # the charge is ignored by metrics without an electromagnetic field (as in the reference)
+    mk = G.KerrMetric(1.0, 0.6)
+    a = G.rendergeodesics(mk, u, 2000.0, q=1.0, **kw)[2]
+    b = G.rendergeodesics(mk, u, 2000.0, **kw)[2]
+    assert a.tobytes() == b.tobytes()
+
+
 def test_against_committed_golden_fixtures(G, ens):
     """tests/golden/*.npz (oracle output committed after the oracle was pinned on the reference's
     golden values; generator: tests/golden/make_fixtures.py)."""

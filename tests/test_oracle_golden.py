@@ -60,6 +60,11 @@ def test_johannsen_psaltis_chart_and_kerr_newman_fingerprints(oracle):
     cfg = oracle.make_config("kerr-newman", (1.0, 0.6, 0.6), lambda_max=2000.0)
     img = oracle.rendergeodesics(cfg, u, (-8, 8), (-8, 8), 40, 40)
     assert float(np.nansum(img)) == pytest.approx(428809.9681726607, rel=1e-6)
+    # charged test particles: Lorentz force from the Faraday tensor, same file :26-27 (rtol 1e-3 there)
+    for q, gold in ((1.0, 253280.6794972752), (-1.0, 619335.5670363897)):
+        cfg = oracle.make_config("kerr-newman", (1.0, 0.6, 0.6), lambda_max=2000.0, q=q)
+        img = oracle.rendergeodesics(cfg, u, (-8, 8), (-8, 8), 40, 40)
+        assert float(np.nansum(img)) == pytest.approx(gold, rel=1e-7)
 
 
 def _count_inner(O, G, plane):
