@@ -24,7 +24,8 @@ from .pointfunctions import ConstPointFunctions, FilterPointFunction, FilterStat
 from .rendering import (EndpointRenderCache, apply, impact_axes, prerendergeodesics, render_configuration,
                         render_into_image, rendergeodesics)
 from .status import StatusCodes
-from .tracing import (EnsembleMI355X, PolarChart, TracingConfiguration, chart_for_metric, domain_upper_hemisphere,
+from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingConfiguration, chart_for_metric,
+                      domain_upper_hemisphere, event_horizon, event_horizon_chart,
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
                       map_impact_parameters, tracegeodesic_path, tracegeodesics, tracing_configuration)
 from .special_radii import generic_isco, interpolate_plunging_velocities, plunging_fourvelocity

@@ -52,6 +52,10 @@ class gr_config(C.Structure):
         ("disc_params", C.c_double * 4),
         ("disc_table", C.c_void_p),
         ("disc_table_n", C.c_int64),
+        ("chart_table", C.c_void_p),
+        ("chart_table_n", C.c_int64),
+        ("chart_theta0", C.c_double),
+        ("chart_theta1", C.c_double),
         ("q", C.c_double),
     ]
 

@@ -38,6 +38,7 @@ typedef float gr_real_t;
 #define GR_FMAX __builtin_fmaxf
 #define GR_FMIN __builtin_fminf
 #define GR_RINT __builtin_rintf
+#define GR_FLOOR __builtin_floorf
 #define GR_SQRT __builtin_sqrtf
 #define GR_POW ::powf
 #define GR_EPS 1.1920929e-07f
@@ -48,6 +49,7 @@ typedef double gr_real_t;
 #define GR_FMAX __builtin_fmax
 #define GR_FMIN __builtin_fmin
 #define GR_RINT __builtin_rint
+#define GR_FLOOR __builtin_floor
 #define GR_SQRT __builtin_sqrt
 #define GR_POW ::pow
 #define GR_EPS 2.220446049250313e-16
@@ -775,6 +777,7 @@ struct Params {
     gr_config cfg;
     const Cold* cold;         // device
     const double* disc_table; // device copy of cfg.disc_table (GR_DISC_TABULATED)
+    const double* chart_table; // device copy of cfg.chart_table (PoloidalShapeChart); cfg.upper_hemisphere bit 1 set
     int64_t n;                // rays in this call
     unsigned long long* stats;  // device: 9 counters (see gr_stats order), may be null
     unsigned long long* queue;  // device: persistent-kernel work counter
@@ -988,12 +991,26 @@ struct Ray {
     }
 
     // DiscreteCallbacks in CallbackSet order: domain_upper_hemisphere, then the chart
-    static GR_DEV bool discrete_cb(const Params& p, real r, real c, int32_t& st)
+    // (the library keeps "a PoloidalShapeChart is active" in bit 1 of its private copy of
+    // cfg.upper_hemisphere, so the common PolarChart case tests one already-resident scalar)
+    static GR_DEV bool discrete_cb(const Params& p, real r, real th, real c, int32_t& st)
     {
         bool term = false;
-        if (p.cfg.upper_hemisphere && r * c < p.cfg.hemi_delta) { st = GR_STATUS_OUT_OF_DOMAIN; term = true; }
-        if (r <= p.cfg.r_inner || r > p.cfg.r_outer) {
-            st = (r <= p.cfg.r_inner) ? GR_STATUS_WITHIN_INNER_BOUNDARY : GR_STATUS_OUT_OF_DOMAIN;
+        const int32_t cb = p.cfg.upper_hemisphere;
+        if ((cb & 1) && r * c < p.cfg.hemi_delta) { st = GR_STATUS_OUT_OF_DOMAIN; term = true; }
+        real rmin = p.cfg.r_inner;
+        if (cb & 2) {
+            // PoloidalShapeChart (charts.jl:26-48): r_min(θ) by linear interpolation of the table
+            const int64_t n = p.cfg.chart_table_n;
+            const real idth = (real)((double)(n - 1) / (p.cfg.chart_theta1 - p.cfg.chart_theta0));
+            const real f = (th - (real)p.cfg.chart_theta0) * idth;
+            int64_t k = (int64_t)GR_FLOOR(f);
+            k = k < 0 ? 0 : (k > n - 2 ? n - 2 : k);
+            const real y0 = (real)p.chart_table[k], y1 = (real)p.chart_table[k + 1];
+            rmin = GR_FMA(f - (real)k, y1 - y0, y0);
+        }
+        if (r <= rmin || r > p.cfg.r_outer) {
+            st = (r <= rmin) ? GR_STATUS_WITHIN_INNER_BOUNDARY : GR_STATUS_OUT_OF_DOMAIN;
             term = true;
         }
         return term;
@@ -1243,7 +1260,7 @@ struct Ray {
                 }
                 cprev = cnext;
             }
-            const bool term = discrete_cb(p, xn[1], cn, status);
+            const bool term = discrete_cb(p, xn[1], xn[2], cn, status);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[i] = xn[i]; v[i] = vn[i]; A[0][i] = A[6][i]; }
             sth = sn; cth = cn;
@@ -1417,7 +1434,7 @@ struct Ray {
         t = t + theta * h;
         real s, c;
         sincos_fast(x[2], s, c);
-        discrete_cb(p, x[1], c, status);
+        discrete_cb(p, x[1], x[2], c, status);
     }
 
     // unpack_solution + apply_to_image!

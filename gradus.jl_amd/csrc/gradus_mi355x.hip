@@ -58,6 +58,8 @@ struct gr_ctx {
     unsigned long long* d_stats = nullptr; // for host-buffer entry points
     double* d_disc_table = nullptr;        // device copy of a tabulated disc profile
     size_t disc_table_bytes = 0;
+    double* d_chart_table = nullptr;       // device copy of a PoloidalShapeChart table
+    size_t chart_table_bytes = 0;
     Cold* d_cold = nullptr;                // ring of per-launch cold blocks
     int cold_next = 0;
     double* d_plunge = nullptr;            // 4 x n_plunge
@@ -113,6 +115,8 @@ int32_t validate_cfg(const gr_config* cfg)
     if (cfg->maxiters <= 0) return fail(GR_ERR_INVALID_ARGUMENT, "maxiters must be positive");
     if (cfg->disc_id == GR_DISC_TABULATED && (!cfg->disc_table || cfg->disc_table_n < 2 || !(cfg->disc_params[1] > cfg->disc_params[0])))
         return fail(GR_ERR_INVALID_ARGUMENT, "tabulated disc needs >= 2 samples on an increasing ρ grid");
+    if (cfg->chart_table_n < 0 || cfg->chart_table_n == 1 || (cfg->chart_table_n > 1 && (!cfg->chart_table || !(cfg->chart_theta1 > cfg->chart_theta0))))
+        return fail(GR_ERR_INVALID_ARGUMENT, "chart table needs >= 2 samples on an increasing θ grid");
     if (cfg->disc_id == GR_DISC_THIN && !(cfg->disc_r_out >= cfg->disc_r_in))
         return fail(GR_ERR_INVALID_ARGUMENT, "disc outer radius below inner radius");
     return GR_OK;
@@ -136,9 +140,20 @@ int32_t validate_plane(const gr_plane* pl, const gr_range* rg)
     return GR_OK;
 }
 
-// device copy of a tabulated disc profile (cfg.disc_table is a host pointer)
+// device copies of the tabulated chart and disc profile (cfg.chart_table / cfg.disc_table are host
+// pointers); records "PoloidalShapeChart active" in bit 1 of the private copy of cfg.upper_hemisphere
 int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 {
+    p.chart_table = nullptr;
+    p.cfg.upper_hemisphere = p.cfg.upper_hemisphere ? 1 : 0;
+    if (p.cfg.chart_table_n > 1) {
+        const size_t cb = sizeof(double) * (size_t)p.cfg.chart_table_n;
+        int32_t crc = ensure((void**)&ctx->d_chart_table, &ctx->chart_table_bytes, cb);
+        if (crc != GR_OK) return crc;
+        GR_HIP(hipMemcpyAsync(ctx->d_chart_table, p.cfg.chart_table, cb, hipMemcpyHostToDevice, stream));
+        p.chart_table = ctx->d_chart_table;
+        p.cfg.upper_hemisphere |= 2;
+    }
     p.disc_table = nullptr;
     if (p.cfg.disc_id != GR_DISC_TABULATED) return GR_OK;
     const size_t tb = sizeof(double) * (size_t)p.cfg.disc_table_n;
@@ -387,6 +402,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_disc_table) (void)hipFree(c->d_disc_table);
+    if (c->d_chart_table) (void)hipFree(c->d_chart_table);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);

@@ -32,6 +32,70 @@ def chart_for_metric(m: AbstractMetric, outer_radius: float = 12000.0, *, closes
     return PolarChart(m.inner_radius() * closest_approach, outer_radius)
 
 
+# ---- charts.jl:26-48,61-70 ----
+@dataclass(frozen=True, eq=False)
+class PoloidalShapeChart:
+    """Inner boundary r_min(θ): `table[k]` at θ_k uniform on [θ_first, θ_last], interpolated linearly
+    on the device (the reference wraps the same samples in a DataInterpolations.LinearInterpolation)."""
+
+    table: np.ndarray
+    θ_first: float
+    θ_last: float
+    outer_radius: float = 12000.0
+
+    def shapefunc(self, θ):
+        n = self.table.size
+        f = (np.asarray(θ, dtype=np.float64) - self.θ_first) * ((n - 1) / (self.θ_last - self.θ_first))
+        k = np.clip(np.floor(f).astype(np.int64), 0, n - 2)
+        return self.table[k] + (f - k) * (self.table[k + 1] - self.table[k])
+
+
+def event_horizon(m: AbstractMetric, *, select=max, resolution: int = 100, θε: float = 1e-7, rmax: float = 5.0,
+                  init: float = 0.0, samples: int = 20001):
+    """event_horizon(m; select = maximum, resolution, θε, rmax) special-radii.jl:105-133: for every θ
+    of range(θε, 2π - θε, resolution) the roots in r of g_tϕ² - g_tt g_ϕϕ = 0 on [init, rmax], reduced
+    by `select`; NaN where there is none.  Roots.find_zeros (third party) is restated as a dense
+    sign-change scan followed by bisection."""
+    θs = np.linspace(θε, 2.0 * math.pi - θε, resolution)
+    rs = np.full(resolution, np.nan)
+    rgrid = np.linspace(init, rmax, samples)[1:]           # r = 0 itself is singular
+    for i, θ in enumerate(θs):
+        s, c = math.sin(θ), math.cos(θ)
+
+        def cond(r):
+            g = m._components(r, s, c)
+            return g[4] * g[4] - g[0] * g[3]
+
+        with np.errstate(all="ignore"):
+            f = cond(rgrid) + 0.0 * rgrid
+        ok = np.isfinite(f)
+        roots = [float(r) for r in rgrid[ok & (f == 0.0)]]
+        idx = np.nonzero(ok[:-1] & ok[1:] & (np.signbit(f[:-1]) != np.signbit(f[1:])) & (f[:-1] != 0) & (f[1:] != 0))[0]
+        for k in idx:
+          with np.errstate(all="ignore"):
+              lo, hi, flo = rgrid[k], rgrid[k + 1], f[k]
+              for _ in range(200):
+                  mid = 0.5 * (lo + hi)
+                  if not (lo < mid < hi):
+                      break
+                  fm = cond(mid)
+                  if (fm < 0) == (flo < 0):
+                      lo, flo = mid, fm
+                  else:
+                      hi = mid
+              # a sign change through a pole (1/Σ-type blow-up) is not a root
+              if abs(cond(0.5 * (lo + hi))) < 1e-6 * max(1.0, np.nanmax(np.abs(f[max(k - 1, 0):k + 3]))):
+                  roots.append(0.5 * (lo + hi))
+        if roots:
+            rs[i] = select(roots)
+    return rs, θs
+
+
+def event_horizon_chart(m: AbstractMetric, *, outer_radius: float = 12000.0, closest_approach: float = 1.01, **kwargs):
+    rs, θs = event_horizon(m, **kwargs)
+    return PoloidalShapeChart(np.ascontiguousarray(rs * closest_approach), float(θs[0]), float(θs[-1]), outer_radius)
+
+
 # ---- callbacks.jl:31-40 ----
 @dataclass(frozen=True)
 class DomainUpperHemisphere:
@@ -159,7 +223,13 @@ class TracingConfiguration:
         c.metric_id = m.metric_id
         for i, p in enumerate(m.abi_params()):
             c.params[i] = float(p)
-        c.r_inner, c.r_outer = float(self.chart.inner_radius), float(self.chart.outer_radius)
+        if isinstance(self.chart, PoloidalShapeChart):
+            ch = self.chart
+            c.r_inner, c.r_outer = float(np.nanmin(ch.table)), float(ch.outer_radius)
+            c.chart_table, c.chart_table_n = ch.table.ctypes.data, ch.table.size      # the chart keeps it alive
+            c.chart_theta0, c.chart_theta1 = ch.θ_first, ch.θ_last
+        else:
+            c.r_inner, c.r_outer = float(self.chart.inner_radius), float(self.chart.outer_radius)
         if self.geometry is None:
             c.disc_id = GR_DISC_NONE
         elif isinstance(self.geometry, ThinDisc):

@@ -102,6 +102,13 @@ typedef struct gr_config {
     double disc_params[4];    /* extra geometry parameters, see GR_DISC_*                */
     const double* disc_table; /* GR_DISC_TABULATED: HOST pointer in every entry point    */
     int64_t disc_table_n;     /*   (copied into the context); NULL / 0 otherwise         */
+    /* PoloidalShapeChart (charts.jl:26-48, event_horizon_chart :61-70): inner boundary r_min(θ),
+     * chart_table[k] = r_min(θ_k) on the uniform grid θ_k = chart_theta0 + k (chart_theta1 -
+     * chart_theta0)/(n-1), already scaled by closest_approach; linear interpolation (end intervals
+     * extended).  HOST pointer, copied into the context.  n = 0: PolarChart with r_inner.       */
+    const double* chart_table;
+    int64_t chart_table_n;
+    double chart_theta0, chart_theta1;
     double q;                 /* test-particle charge, TraceGeodesic.q (tracing.jl:1-7): adds the
                                  Lorentz force q F^μ_ν v^ν (q/μ for μ != 0) for GR_METRIC_KERR_NEWMAN,
                                  kerr-newman-ad.jl:66-100; ignored by metrics without a field     */

@@ -41,6 +41,10 @@ struct GrConfig                      # == gr_config
     disc_params::NTuple{4,Float64}
     disc_table::Ptr{Float64}
     disc_table_n::Int64
+    chart_table::Ptr{Float64}
+    chart_table_n::Int64
+    chart_theta0::Float64
+    chart_theta1::Float64
     q::Float64
 end
 
@@ -117,7 +121,7 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2
     chart = config.chart::PolarChart
     GrConfig(id, did, params, chart.inner_radius, chart.outer_radius, rin, rout, gtol,
         config.λ_domain[1], config.λ_domain[2], config.abstol, config.reltol, Float64(trace.μ),
-        maxiters, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0, Float64(trace.q))
+        maxiters, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0, Ptr{Float64}(C_NULL), 0, 0.0, 0.0, Float64(trace.q))
 end
 
 # The drop-in method: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,
@@ -173,7 +177,7 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     id, params = _metric(m)
     did, rin, rout = _disc(d)
     cfg = Ref(GrConfig(id, did, params, chart.inner_radius, chart.outer_radius, rin, rout, gtol, 0.0, Float64(λmax),
-        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0, 0.0))
+        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0, Ptr{Float64}(C_NULL), 0, 0.0, 0.0, 0.0))
     g = Gradus.metric(m, x)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
     plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), αlims[1], αlims[2], βlims[1], βlims[2],

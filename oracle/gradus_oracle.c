@@ -549,8 +549,21 @@ static int discrete_callbacks(const orc_config* c, const double u[8], int* statu
     if (c->upper_hemisphere) {
         if (u[1] * cos(u[2]) < c->hemi_delta) { *status = ORC_OUT_OF_DOMAIN; term = 1; }
     }
-    if (u[1] <= c->r_inner || u[1] > c->r_outer) {
-        *status = (u[1] <= c->r_inner) ? ORC_WITHIN_INNER_BOUNDARY : ORC_OUT_OF_DOMAIN;
+    double rmin = c->r_inner;
+    if (c->chart_table_n > 1) {
+        /* PoloidalShapeChart: rmin = shapefunc(θ), a linear interpolation over the tabulated
+         * horizon shape (charts.jl:31-48, 61-70; DataInterpolations.LinearInterpolation [3P]) */
+        const int64_t n = c->chart_table_n;
+        const double dth = (c->chart_theta1 - c->chart_theta0) / (double)(n - 1);
+        double f = (u[2] - c->chart_theta0) / dth;
+        int64_t k = (int64_t)floor(f);
+        if (k < 0) k = 0;
+        if (k > n - 2) k = n - 2;
+        const double w = f - (double)k;
+        rmin = c->chart_table[k] + w * (c->chart_table[k + 1] - c->chart_table[k]);
+    }
+    if (u[1] <= rmin || u[1] > c->r_outer) {
+        *status = (u[1] <= rmin) ? ORC_WITHIN_INNER_BOUNDARY : ORC_OUT_OF_DOMAIN;
         term = 1;
     }
     return term;

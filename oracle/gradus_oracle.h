@@ -66,6 +66,9 @@ typedef struct {
     double disc_params[4];  /* ShakuraSunyaev: Mdot/Mdot_Edd, 1/eta ; TABULATED: rho0, rho1, hmax ; TORUS: centre, radius */
     const double* disc_table;
     int64_t disc_table_n;
+    const double* chart_table;  /* PoloidalShapeChart: r_min(θ_k) on a uniform θ grid (charts.jl:26-48); n = 0: PolarChart */
+    int64_t chart_table_n;
+    double chart_theta0, chart_theta1;
     double q;               /* test-particle charge (TraceGeodesic.q); Lorentz force for Kerr-Newman only */
 } orc_config;
 

@@ -46,6 +46,10 @@ class Config(C.Structure):
         ("disc_params", C.c_double * 4),
         ("disc_table", C.c_void_p),
         ("disc_table_n", C.c_int64),
+        ("chart_table", C.c_void_p),
+        ("chart_table_n", C.c_int64),
+        ("chart_theta0", C.c_double),
+        ("chart_theta1", C.c_double),
         ("q", C.c_double),
     ]
 
@@ -164,6 +168,8 @@ def make_config(
     hemi_delta=1e-4,
     maxiters=1_000_000,
     q=0.0,
+    chart_table=None,
+    chart_theta=(0.0, 0.0),
 ) -> Config:
     c = Config()
     c.metric_id = METRIC_IDS[metric]
@@ -199,6 +205,11 @@ def make_config(
     c.upper_hemisphere = int(bool(upper_hemisphere))
     c.hemi_delta = hemi_delta
     c.q = q
+    if chart_table is not None:       # PoloidalShapeChart: r_min(θ_k), θ_k uniform on chart_theta
+        tab = np.ascontiguousarray(chart_table, dtype=np.float64)
+        c._keep_chart = tab
+        c.chart_table, c.chart_table_n = tab.ctypes.data, tab.size
+        c.chart_theta0, c.chart_theta1 = float(chart_theta[0]), float(chart_theta[1])
     return c
 
 

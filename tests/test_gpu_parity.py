@@ -441,6 +441,35 @@ def test_more_reference_fingerprints_on_device(G, ens):
     assert float(np.nansum(img)) == pytest.approx(428809.9681726607, rel=1e-6)
 
 
+def test_event_horizon_chart_on_device(G, oracle, ens):
+    """PoloidalShapeChart(event_horizon shape × 1.001) for the near-naked-singularity Johannsen-Psaltis
+    metric: reference fingerprint (test/integration/test-charts.jl:20-31, rtol 1e-4 there) and oracle
+    parity; both kernels; the fp32 build accepts the chart too."""
+    u = np.array([0.0, 1000.0, math.pi / 2, 0.0])
+    m = G.JohannsenPsaltisMetric(1.0, 0.8831, 0.4)
+    chart = G.event_horizon_chart(m, closest_approach=1.001, resolution=100)
+    assert chart.table.size == 100 and np.all(np.isfinite(chart.table))
+    assert chart.table.min() < m.inner_radius() < chart.table.max() * 1.01     # the horizon is not a sphere here
+    kw = dict(image_width=100, image_height=100, alpha_lims=(-8, 8), beta_lims=(-8, 8), ensemble=ens, chart=chart)
+    for kernel in (0, 1):
+        ens.set("kernel", kernel)
+        _, _, img = G.rendergeodesics(m, u, 2000.0, **kw)
+        assert float(np.nansum(img)) == pytest.approx(2.9540649115176247e6, rel=1e-6)
+    _, _, cache = G.prerendergeodesics(m, u, 2000.0, **kw)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    ocfg = oracle.make_config("johannsen-psaltis", (1.0, 0.8831, 0.4), lambda_max=2000.0, chart_table=chart.table,
+                              chart_theta=(chart.θ_first, chart.θ_last))
+    ref = oracle.trace(ocfg, u, oracle.render_velocities(ocfg, u, (-8, 8), (-8, 8), 100, 100))
+    _compare_points(G, oracle, got, ref)
+    # captured rays stop on the tabulated surface, not on a sphere
+    inner = got["status"] == oracle.WITHIN_INNER_BOUNDARY
+    assert inner.sum() > 100
+    assert np.all(got["x"][inner, 1] <= chart.shapefunc(got["x"][inner, 2]) * (1 + 1e-12))
+    with pytest.raises(G.GradusMI355XError):
+        bad = G.PoloidalShapeChart(chart.table, 1.0, 1.0)
+        G.rendergeodesics(m, u, 2000.0, **{**kw, "chart": bad})
+
+
 def test_charged_test_particles_in_kerr_newman(G, oracle, ens):
     """rendergeodesics(KerrNewmanMetric(1, 0.6, 0.6), ...; q = ±1): Lorentz force q F^μ_ν v^ν on the
     device against the reference's fingerprints (test/unit/metrics.kerr-newman.jl:26-27, rtol 1e-3

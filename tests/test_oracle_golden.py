@@ -60,6 +60,26 @@ def test_johannsen_psaltis_chart_and_kerr_newman_fingerprints(oracle):
     cfg = oracle.make_config("kerr-newman", (1.0, 0.6, 0.6), lambda_max=2000.0)
     img = oracle.rendergeodesics(cfg, u, (-8, 8), (-8, 8), 40, 40)
     assert float(np.nansum(img)) == pytest.approx(428809.9681726607, rel=1e-6)
+    # PoloidalShapeChart from the event-horizon shape, test/integration/test-charts.jl:20-31 (rtol 1e-4 there);
+    # the table is solved here independently of the package (dense scan of g_tϕ² - g_tt g_ϕϕ in r)
+    ths = np.linspace(1e-7, 2 * math.pi - 1e-7, 100)
+    rgrid = np.linspace(0.0, 5.0, 500001)[1:]
+    tab = np.empty(100)
+    for i, th in enumerate(ths):
+        M_, a_, e3 = 1.0, 0.8831, 0.4
+        s2, c2 = math.sin(th) ** 2, math.cos(th) ** 2
+        Sig = rgrid ** 2 + a_ * a_ * c2
+        h = e3 * M_ ** 3 * rgrid / Sig ** 2
+        tt = -(1 + h) * (1 - 2 * M_ * rgrid / Sig)
+        pp = s2 * (rgrid ** 2 + a_ * a_ + 2 * a_ * a_ * M_ * rgrid * s2 / Sig) + h * a_ * a_ * (Sig + 2 * M_ * rgrid) * s2 * s2 / Sig
+        tp = -a_ * 2 * M_ * rgrid * s2 * (1 + h) / Sig
+        f = tp * tp - tt * pp
+        k = np.nonzero(np.signbit(f[:-1]) != np.signbit(f[1:]))[0][-1]
+        tab[i] = rgrid[k] - f[k] * (rgrid[k + 1] - rgrid[k]) / (f[k + 1] - f[k])
+    cfg = oracle.make_config("johannsen-psaltis", (1.0, 0.8831, 0.4), lambda_max=2000.0, chart_table=tab * 1.001,
+                             chart_theta=(ths[0], ths[-1]))
+    img = oracle.rendergeodesics(cfg, u, (-8, 8), (-8, 8), 100, 100)
+    assert float(np.nansum(img)) == pytest.approx(2.9540649115176247e6, rel=1e-7)
     # charged test particles: Lorentz force from the Faraday tensor, same file :26-27 (rtol 1e-3 there)
     for q, gold in ((1.0, 253280.6794972752), (-1.0, 619335.5670363897)):
         cfg = oracle.make_config("kerr-newman", (1.0, 0.6, 0.6), lambda_max=2000.0, q=q)
