@@ -961,10 +961,11 @@ struct Ray {
     real dbg_e2;
 #endif
 
-    // distance_to_disc(::ThinDisc), thin-disc.jl:20-26 ; distance_to_disc(::AbstractThickAccretionDisc),
+    // distance_to_disc(::DatumPlane), datum-plane.jl:6-10 ; distance_to_disc(::ThinDisc), thin-disc.jl:20-26 ; distance_to_disc(::AbstractThickAccretionDisc),
     // thick-disc.jl:60-66 with cross_section(::ShakuraSunyaev), shakura-sunyaev.jl:28-33
     static GR_DEV real disc_cond(const Params& p, real r, real s, real c)
     {
+        if (DISC == GR_DISC_DATUM) return r * c - (real)p.cfg.disc_params[0];   // signed: no underside
         const real rho = r * GR_FABS(s);
         if (DISC == GR_DISC_THIN) {
             if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
@@ -1339,6 +1340,8 @@ struct Ray {
             }
             if (!any) return 0;
             dense_coeffs(1, hh, Cr);
+        } else if (DISC == GR_DISC_DATUM) {
+            dense_coeffs(1, hh, Cr);      // no pre-filter: every sample is evaluated
         } else {
             // thick disc of bounded height Hmax: a sample can only be inside if |z| = r |sin d| < Hmax,
             // and |sin d| >= (2/π)|d|, so |d| r >= (π/2) Hmax rules it out

@@ -5,7 +5,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-GR_DISC_NONE, GR_DISC_THIN, GR_DISC_SHAKURA_SUNYAEV, GR_DISC_TABULATED = 0, 1, 2, 3
+GR_DISC_NONE, GR_DISC_THIN, GR_DISC_SHAKURA_SUNYAEV, GR_DISC_TABULATED, GR_DISC_DATUM = 0, 1, 2, 3, 4
 
 
 class AbstractAccretionGeometry:
@@ -19,6 +19,16 @@ class ThinDisc(AbstractAccretionGeometry):
     inner_radius: float = 0.0
     outer_radius: float = 500.0
     disc_id = GR_DISC_THIN
+
+
+@dataclass(frozen=True)
+class DatumPlane(AbstractAccretionGeometry):
+    """DatumPlane(height) -- src/geometry/discs/datum-plane.jl:1-10: the surface r cosθ = height, hit
+    from above only (signed distance, no gtol, no radial extent)."""
+
+    height: float = 0.0
+    disc_id = GR_DISC_DATUM
+    inner_radius = 0.0
 
 
 @dataclass(frozen=True)

@@ -14,7 +14,7 @@ from typing import Callable, Optional
 import numpy as np
 
 from . import _lib
-from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, ShakuraSunyaev, ThickDisc, ThinDisc
+from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, DatumPlane, ShakuraSunyaev, ThickDisc, ThinDisc
 from .metrics import AbstractMetric
 from .orthonormalization import lnrbasis
 
@@ -235,6 +235,9 @@ class TracingConfiguration:
         elif isinstance(self.geometry, ThinDisc):
             c.disc_id = self.geometry.disc_id
             c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float(self.geometry.outer_radius)
+        elif isinstance(self.geometry, DatumPlane):
+            c.disc_id = self.geometry.disc_id
+            c.disc_params[0] = float(self.geometry.height)
         elif isinstance(self.geometry, ShakuraSunyaev):
             c.disc_id = self.geometry.disc_id
             c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float("inf")

@@ -1,0 +1,283 @@
+"""Cunningham transfer functions on device-traced geodesics (second half).
+
+Mirror of src/transfer-functions/cunningham-transfer-functions.jl:1-387 for discs that the transfer
+function solvers see as a datum plane (ThinDisc -> DatumPlane(0), :1-5), with the precision solvers
+of src/tracing/precision-solvers.jl:73-236 (offset for a target radius) and :401-451 (Jacobian).
+
+MI355X-first restructuring.  The reference solves one (rₑ, θ) at a time: a Newton iteration in the
+image-plane offset r, each evaluation one geodesic carried on dual numbers, then one more
+dual-number geodesic for ∂(ρ, g)/∂(α, β), then a golden-section search in θ for g_min / g_max --
+all serial, threaded over rₑ only.  Here EVERY pending (rₑ, θ) problem of EVERY emission radius
+advances in lock-step: one safeguarded-Newton iteration for the whole batch is one call of
+`gr_trace_endpoints` (two rays per problem: r and r(1+ε), the derivative by differences), the
+Jacobians of the whole batch are one call (four rays per problem, central differences) and the
+golden-section searches of all radii and of both extrema share their launches as well.  A table of
+150 radii costs the same ~200 launches as one radius.
+
+Parity: the converged offsets solve the same equation ρ(r, θ) = rₑ to the same tolerance
+(zero_atol = 1e-7), so they do not depend on the iteration path; derivatives by differences agree
+with the reference's forward-mode ones to ~1e-6.  Pinned on the reference's recorded values
+(test/smoke-tests/cunningham-transfer-functions.jl:25-39, atol 1e-3 there).  `Optim.GoldenSection`
+(third party) is restated from its published algorithm.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from .geometry import DatumPlane, ThinDisc
+from .pointfunctions import ConstPointFunctions
+from .status import StatusCodes
+from .tracing import (chart_for_metric, ensemble_solve_tracing_problem, map_impact_parameters,
+                      tracing_configuration)
+
+GOLDEN = 0.5 * (3.0 - math.sqrt(5.0))
+
+
+@dataclass
+class CunninghamTransferData:
+    """types.jl:1-12"""
+
+    g_star: np.ndarray
+    f: np.ndarray
+    t: np.ndarray
+    gmin: float
+    gmax: float
+    rₑ: float
+
+
+def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, **solver_opts):
+    """(α, β) arrays -> (end points, g): every ray against DatumPlane(0) on the device."""
+    from .rendering import apply_pointfunction
+
+    plane = DatumPlane(0.0)
+
+    def trace(α, β):
+        v = map_impact_parameters(m, x, np.asarray(α, dtype=np.float64), np.asarray(β, dtype=np.float64))
+        config = tracing_configuration(m, x, v, plane, max_time, chart=chart, ensemble=ensemble, **solver_opts)
+        pts = ensemble_solve_tracing_problem(config.ensemble, config)
+        g = apply_pointfunction(config.ensemble, config, redshift_pf, pts, max_time)
+        return pts, g
+
+    return trace
+
+
+def _rho(pts):
+    return pts["x"][:, 1] * np.abs(np.sin(pts["x"][:, 2]))
+
+
+def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zero_atol=1e-7, max_iter=50, eps=1e-5):
+    """_find_offset_for_radius (precision-solvers.jl:135-236) for a batch of (r_target, θ) problems.
+
+    Safeguarded Newton on y(r) = ρ(r, θ) - r_target, which is monotonic in r: the start
+    max(20, r_target), the Newton update, the bracket kept from points that fall short of the target
+    or into the hole, the biased bisection (2·contra + x)/3 when a step leaves the bracket and the
+    acceptance tests (|y| <= zero_atol to converge, 1e-4·r_target to be usable) follow the reference;
+    dy/dr comes from a second ray at r(1+ε) instead of a dual number.  Once |y| <= zero_atol the
+    iteration is continued while it still gains (Newton is quadratic: one or two more launches), down to
+    1e-11 r_target: the redshift of neighbouring samples near g_min / g_max differs by ~1e-9, less than
+    what a 1e-7 residual in ρ moves g, and the transfer function there divides by that difference.
+    Returns (r, end points, g) with r = NaN where no usable offset exists."""
+    r_target = np.asarray(r_target, dtype=np.float64)
+    θ = np.asarray(θ, dtype=np.float64)
+    n = r_target.size
+    cs, sn = np.cos(θ), np.sin(θ)
+    x = np.maximum(20.0, r_target)
+    lo = np.zeros(n)                      # contra point: known to fall short (or captured)
+    hi = np.full(n, np.inf)
+    y = np.full(n, np.inf)
+    ybest = np.full(n, np.inf)
+    xbest = x.copy()
+    best_pts, best_g = None, np.full(n, np.nan)
+    done = np.zeros(n, dtype=bool)
+    active = np.arange(n)
+    for _ in range(max_iter + 1):
+        if active.size == 0:
+            break
+        xa = x[active]
+        rr = np.concatenate([xa, xa * (1.0 + eps)])
+        tt = np.concatenate([θ[active], θ[active]])
+        pts, g = trace(rr * np.cos(tt) + α0, rr * np.sin(tt) + β0)
+        k = active.size
+        if best_pts is None:
+            best_pts = np.zeros(n, dtype=pts.dtype)
+        ρ0, ρ1 = _rho(pts[:k]), _rho(pts[k:])
+        hit = pts["status"][:k] == StatusCodes.IntersectedWithGeometry
+        ya = ρ0 - r_target[active]
+        df = (ρ1 - ρ0) / (xa * eps)
+        # keep the best point seen; `polished`: already acceptable and no longer improving
+        improved = hit & (np.abs(ya) < ybest[active])
+        polished = hit & (ybest[active] <= zero_atol) & (np.abs(ya) >= 0.5 * ybest[active])
+        ia = active[improved]
+        best_pts[ia] = pts[:k][improved]
+        best_g[ia] = g[:k][improved]
+        xbest[ia] = xa[improved]
+        ybest[ia] = np.abs(ya[improved])
+        y[active] = ya
+        conv = polished | (hit & (np.abs(ya) <= 1e-11 * np.maximum(r_target[active], 1.0)))
+        # bracket bookkeeping
+        below = (~hit) | (ya < 0.0)
+        lo[active] = np.where(below, np.maximum(lo[active], xa), lo[active])
+        hi[active] = np.where(~below, np.minimum(hi[active], xa), hi[active])
+        with np.errstate(all="ignore"):
+            nx = xa - ya / df
+        la, ha = lo[active], hi[active]
+        near_hole = ρ0 < (r_min + 1.0)
+        bad = ~np.isfinite(nx) | (nx <= la) | (nx >= ha) | (~hit) | (near_hole & below)
+        bis = np.where(np.isfinite(ha), (2.0 * la + ha) / 3.0, 2.0 * xa)
+        # a bracket that has collapsed to rounding: accept what we have
+        stuck = np.isfinite(ha) & ((ha - la) <= 4.0 * np.finfo(np.float64).eps * np.maximum(ha, 1.0))
+        nx = np.where(bad, bis, nx)
+        x[active] = np.where(conv | stuck, xa, nx)
+        done[active] = conv | stuck
+        active = active[~(conv | stuck)]
+    r = xbest.copy()
+    ok = (best_pts["status"] == StatusCodes.IntersectedWithGeometry) & (ybest <= 1e-4 * r_target)
+    r[~ok] = np.nan
+    return r, best_pts, best_g
+
+
+def jacobians(trace, r, θ, *, α0=0.0, β0=0.0, rel_step=3e-4):
+    """|∂(ρ, g)/∂(α, β)|⁻¹ (jacobian_∂αβ_∂gr, precision-solvers.jl:401-451) for a batch, by central
+    differences: four rays per problem in one launch."""
+    r, θ = np.asarray(r, dtype=np.float64), np.asarray(θ, dtype=np.float64)
+    α, β = r * np.cos(θ) + α0, r * np.sin(θ) + β0
+    δ = rel_step * np.maximum(np.abs(r), 1.0)
+    pts, g = trace(np.concatenate([α + δ, α - δ, α, α]), np.concatenate([β, β, β + δ, β - δ]))
+    n = r.size
+    ρ = _rho(pts)
+    ok = np.all((pts["status"] == StatusCodes.IntersectedWithGeometry).reshape(4, n), axis=0)
+    dρ_dα = (ρ[:n] - ρ[n:2 * n]) / (2 * δ)
+    dρ_dβ = (ρ[2 * n:3 * n] - ρ[3 * n:]) / (2 * δ)
+    dg_dα = (g[:n] - g[n:2 * n]) / (2 * δ)
+    dg_dβ = (g[2 * n:3 * n] - g[3 * n:]) / (2 * δ)
+    with np.errstate(all="ignore"):
+        J = np.abs(1.0 / (dρ_dα * dg_dβ - dρ_dβ * dg_dα))
+    return np.where(ok, J, np.nan)
+
+
+class _Workhorse:
+    """_rear_workhorse for a datum plane (cunningham-transfer-functions.jl:229-251): (g, J, t) for a
+    batch of (rₑ, θ), failing loudly like the reference when an offset cannot be found."""
+
+    def __init__(self, trace, r_min, setup):
+        self.trace, self.r_min, self.s = trace, r_min, setup
+
+    def __call__(self, rₑ, θ):
+        s = self.s
+        r, pts, g = find_offsets_for_radius(self.trace, rₑ, θ, r_min=self.r_min, α0=s["α0"], β0=s["β0"],
+                                            zero_atol=s["zero_atol"])
+        if np.any(np.isnan(r)):
+            k = int(np.nonzero(np.isnan(r))[0][0])
+            raise RuntimeError(f"Transfer function integration failed (rₑ={np.asarray(rₑ)[k]}, θ={np.asarray(θ)[k]}).")
+        J = jacobians(self.trace, r, θ, α0=s["α0"], β0=s["β0"])
+        return g, J, pts["x"][:, 0].copy()
+
+
+def _golden_section_batch(f, lower, upper, iterations):
+    """Optim.optimize(f, lower, upper, GoldenSection(); iterations) for a batch of independent
+    one-dimensional problems advanced in lock-step; `f(θ_array)` evaluates all of them at once.
+    Returns the minima found (Optim.minimum)."""
+    lower, upper = np.array(lower, dtype=np.float64), np.array(upper, dtype=np.float64)
+    xmin = lower + GOLDEN * (upper - lower)
+    fmin = f(xmin)
+    for _ in range(iterations):
+        right = (upper - xmin) > (xmin - lower)
+        new_x = np.where(right, xmin + GOLDEN * (upper - xmin), xmin - GOLDEN * (xmin - lower))
+        new_f = f(new_x)
+        better = new_f < fmin
+        # right step:  better -> lower = xmin ; else upper = new_x ;  left step mirrored
+        lower = np.where(right & better, xmin, np.where(~right & ~better, new_x, lower))
+        upper = np.where(right & ~better, new_x, np.where(~right & better, xmin, upper))
+        xmin = np.where(better, new_x, xmin)
+        fmin = np.where(better, new_f, fmin)
+    return fmin
+
+
+def _check_gmin_gmax(gmin, gmax, gs):
+    """utils.jl:70-103"""
+    if math.isnan(gmin):
+        gmin = float(np.min(gs))
+    if math.isnan(gmax):
+        gmax = float(np.max(gs))
+    if gmin == gmax:
+        gmin, gmax = float(np.min(gs)), float(np.max(gs))
+        if gmin == gmax:
+            raise RuntimeError("Cannot use extrema")
+    return min(gmin, float(np.min(gs))), max(gmax, float(np.max(gs)))
+
+
+def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offset=0.3, zero_atol=1e-7, α0=0.0, β0=0.0,
+                                  chart=None, max_time=None, redshift_pf=None, ensemble=None, tracer=None,
+                                  **solver_opts):
+    """cunningham_transfer_function (cunningham-transfer-functions.jl:337-387) for every emission
+    radius of `radii` at once.  Returns a list of CunninghamTransferData.
+
+    `tracer` replaces the device tracer by another `(α, β) -> (points, g)` callable (the CPU tests
+    use it to drive this host logic with oracle-traced rays); the default traces on the MI355X."""
+    if not isinstance(d, (ThinDisc, DatumPlane)):
+        raise NotImplementedError("transfer functions are implemented for thin discs (datum plane at z = 0)")
+    x = np.asarray(x, dtype=np.float64)
+    radii = np.atleast_1d(np.asarray(radii, dtype=np.float64))
+    max_time = 2.0 * x[1] if max_time is None else max_time
+    chart = chart_for_metric(m, 2.0 * x[1]) if chart is None else chart
+    if tracer is None:
+        if redshift_pf is None:
+            redshift_pf = ConstPointFunctions.redshift(m, x, **({"ensemble": ensemble} if m.metric_id != 0 else {}))
+        tracer = device_tracer(m, x, max_time, chart, redshift_pf, ensemble, **solver_opts)
+    setup = dict(α0=float(α0), β0=float(β0), zero_atol=float(zero_atol))
+    work = _Workhorse(tracer, m.inner_radius(), setup)
+
+    R = radii.size
+    M = N + 2 * N_extrema
+    K = N // 5
+    θs0 = np.concatenate([np.linspace(-2 * θ_offset, 2 * θ_offset, K), np.linspace(-math.pi / 2, 3 * math.pi / 2, N - 2 * K),
+                          np.linspace(math.pi - 2 * θ_offset, math.pi + 2 * θ_offset, K)])
+    data = np.full((R, 4, M), np.nan)           # rows: θ, g, J, t  (utils.jl:1-30)
+    g, J, t = work(np.repeat(radii, N), np.tile(θs0, R))
+    data[:, 0, :N] = θs0
+    data[:, 1, :N] = g.reshape(R, N)
+    data[:, 2, :N] = J.reshape(R, N)
+    data[:, 3, :N] = t.reshape(R, N)
+
+    # _search_extremal! (:390-438): golden section for g_min about θ = 0 and for g_max about θ = π,
+    # every attempt stored; both searches of every radius share their launches
+    slot = [N]
+    n_iter = (M - N) // 2 - 1
+    rr2 = np.concatenate([radii, radii])
+    sign = np.concatenate([np.ones(R), -np.ones(R)])
+
+    def objective(θ2):
+        θ2 = np.array(θ2, dtype=np.float64)
+        pole = (np.abs(θ2) < 1e-4) | (np.abs(np.abs(θ2) - math.pi) < 1e-4)
+        θ2 = np.where(pole, θ2 + 1e-4, θ2)
+        g, J, t = work(rr2, θ2)
+        i = slot[0]
+        for half, col in ((slice(0, R), i), (slice(R, 2 * R), M - 1 - (i - N))):
+            data[:, 0, col], data[:, 1, col], data[:, 2, col], data[:, 3, col] = θ2[half], g[half], J[half], t[half]
+        slot[0] += 1
+        return sign * g
+
+    lower = np.concatenate([np.full(R, -θ_offset), np.full(R, math.pi - θ_offset)])
+    upper = np.concatenate([np.full(R, θ_offset), np.full(R, math.pi + θ_offset)])
+    best = _golden_section_batch(objective, lower, upper, n_iter)
+    gmin_c, gmax_c = best[:R], -best[R:]
+
+    out = []
+    for k in range(R):
+        dk = data[k][:, ~np.isnan(data[k, 0])]
+        dk = dk[:, np.argsort(dk[0], kind="stable")]
+        gmin, gmax = _check_gmin_gmax(float(gmin_c[k]), float(gmax_c[k]), dk[1])
+        Js = (gmax - gmin) * dk[2]
+        gstar = (dk[1] - gmin) / (gmax - gmin)
+        with np.errstate(invalid="ignore"):
+            f = (1.0 / (math.pi * radii[k])) * dk[1] * np.sqrt(gstar * (1.0 - gstar)) * Js
+        out.append(CunninghamTransferData(gstar, f, dk[3].copy(), gmin, gmax, float(radii[k])))
+    return out
+
+
+def cunningham_transfer_function(m, x, d, rₑ, **kwargs):
+    """cunningham_transfer_function(m, x, d, rₑ; N, chart, ...) for one emission radius."""
+    return cunningham_transfer_functions(m, x, d, [rₑ], **kwargs)[0]

@@ -73,8 +73,11 @@ enum {
  *   TABULATED        ThickDisc(f)    src/geometry/discs/thick-disc.jl:30-66: the user's cross_section
  *                    closure cannot run on the device, so the host samples it on a uniform ρ grid:
  *                    disc_params = {ρ_first, ρ_last, max height}, disc_table[disc_table_n] = f(ρ_k);
- *                    linear interpolation, height <= 0 (or ρ outside the grid) = no disc there */
-enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_TABULATED = 3 };
+ *                    linear interpolation, height <= 0 (or ρ outside the grid) = no disc there
+ *   DATUM            DatumPlane      src/geometry/discs/datum-plane.jl:1-10: the plane z = r cosθ = height
+ *                    (disc_params[0]), signed (no underside), no radial extent; what the transfer-function
+ *                    solvers trace against for a thin disc (cunningham-transfer-functions.jl:1-5) */
+enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_TABULATED = 3, GR_DISC_DATUM = 4 };
 
 /* per-ray anomaly bits written next to the status (SciML retcodes MaxIters /
  * DtLessThanMin / Unstable, which EnsembleEndpointThreads discards, tracing.jl:250) */

@@ -501,6 +501,8 @@ static double rms8(const double x[8])
 static double disc_condition(const orc_config* c, const double u[8])
 {
     const double r = u[1], th = u[2];
+    /* distance_to_disc(::DatumPlane), datum-plane.jl:6-10: signed height above the plane */
+    if (c->disc_id == ORC_DISC_DATUM) return r * cos(th) - c->disc_params[0];
     const double rho = r * fabs(sin(th));
     if (c->disc_id == ORC_DISC_TABULATED || c->disc_id == ORC_DISC_TORUS) {
         /* ThickDisc(f): cross_section(d, ρ) = f(ρ), thick-disc.jl:57-66 (inner/outer radius 0/Inf) */

@@ -19,7 +19,7 @@ OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 
 METRIC_KERR, METRIC_JOHANNSEN = 0, 1
 METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "kerr-newman": 4,
               "johannsen-psaltis": 5}
-DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS = 0, 1, 2, 3, 4
+DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS, DISC_DATUM = 0, 1, 2, 3, 4, 5
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
 
@@ -179,6 +179,9 @@ def make_config(
     c.r_outer = outer_radius
     if disc is None:
         c.disc_id = DISC_NONE
+    elif isinstance(disc, dict) and "datum" in disc:     # DatumPlane(height)
+        c.disc_id = DISC_DATUM
+        c.disc_params[0] = float(disc["datum"])
     elif isinstance(disc, dict) and "torus" in disc:     # the reference smoke test's ThickDisc closure
         c.disc_id = DISC_TORUS
         c.disc_r_in, c.disc_r_out = 0.0, float("inf")
