@@ -746,9 +746,10 @@ def test_cunningham_transfer_functions_on_device(G, oracle, ens):
                               outer_radius=2 * x[1])
 
     def otrace(al, be):
-        pts = oracle.trace(ocfg, x, oracle.map_impact_parameters(ocfg, x, np.asarray(al), np.asarray(be)))
+        # few threads: hundreds of tiny batches, thread start-up would dominate on a many-core host
+        pts = oracle.trace(ocfg, x, oracle.map_impact_parameters(ocfg, x, np.asarray(al), np.asarray(be)), nthreads=8)
         return pts, oracle.apply_pf(ocfg, pts, 2 * x[1], pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_NONE,
-                                    r_isco=m.isco())
+                                    r_isco=m.isco(), nthreads=8)
 
     ref = G.cunningham_transfer_functions(m, x, d, [10.0, 300.0], N=80, tracer=otrace)
     for c, r in zip(ref, (out[1], out[3])):
