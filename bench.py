@@ -37,14 +37,14 @@ PEAK_HBM_GBS = 8000.0
 # and per ray outside the step loop, for the bench workload.
 FLOPS_JSON = os.path.join(ROOT, "oracle", "flopcount.json")
 # FP64 flops the kernel actually EXECUTES per ray, from the committed rocprofv3 PMC pass
-# (profiles/r1d_k1_summary.json: (2*FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes *
+# (profiles/r1e_auto_summary.json: (2*FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes *
 # active-lane fraction / rays).  Lower than the algorithmic count because the kernel reaches
 # the same results with hand-derived derivatives and a pre-filtered event search.
-EXECUTED_FLOPS_PER_RAY = 2.287e5
-EXECUTED_SOURCE = "profiles/r1d_k1_summary.json"
-EXECUTED_VALU_BUSY = 0.945
+EXECUTED_FLOPS_PER_RAY = 2.244e5
+EXECUTED_SOURCE = "profiles/r1e_auto_summary.json"
+EXECUTED_VALU_BUSY = 0.917
 # HBM bytes per launch from the same profile's FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes
-PROFILED_TRAFFIC_BYTES_PER_LAUNCH = 43201952.0
+PROFILED_TRAFFIC_BYTES_PER_LAUNCH = 40672800.0
 
 
 def parse_args():
@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--lpt-lane", type=int, default=None)
     ap.add_argument("--refill-threshold", type=int, default=None)
     ap.add_argument("--waves-per-simd", type=int, default=None)
+    ap.add_argument("--block", type=int, default=None, help="workgroup size (64..256, diagnostic)")
     ap.add_argument("--block-cols", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -134,6 +135,8 @@ def main():
         ens.set("refill_threshold", args.refill_threshold)
     if args.waves_per_simd is not None:
         ens.set("waves_per_simd", args.waves_per_simd)
+    if args.block is not None:
+        ens.set("block", args.block)
     if args.lpt_lane is not None:
         ens.set("lpt_lane", args.lpt_lane)
     m, x, d, pf, cfg = workload(G, args.size, ens)
@@ -244,7 +247,7 @@ def main():
                 "sharding": f"{world} rank(s), block-cyclic by {plan.block_cols} columns, one RCCL gather per render "
                             "(overlapped with the next render's kernel, double-buffered slabs)",
                 "kernel": {0: "one-ray-per-lane", 1: "persistent+wave-ballot-refill",
-                           2: "auto: persistent+wave-ballot-refill when >= 6 rays per resident lane, else one-ray-per-lane"}[args.kernel],
+                           2: "auto: one ray per lane, 8x8 pixel tiles, one-wave workgroups (image planes)"}[args.kernel],
                 "rays_per_gpu": plan.count,
                 "steps_per_ray": steps_launch / rays_launch,
                 "rejected_steps_per_ray": st["rejected_steps"] / max(st["rays"], 1),

@@ -71,7 +71,7 @@ struct gr_ctx {
     // knobs
     int64_t kernel = 2;                    // 0 lane, 1 persistent, 2 auto (by launch depth)
     int64_t lpt_lane = 0;                  // also order tiles longest-first for the lane kernel
-    int64_t block = 256;
+    int64_t block = 0;                    // 0 = auto: 64 for the one-ray-per-lane kernel, 256 for the persistent one
     int64_t refill_threshold = 16;
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
     int64_t swizzle = 1;
@@ -170,14 +170,28 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 // the launch (queue empty, waves draining) shrinks.  Only the ORDER of the work queue is learned:
 // every ray is traced in full every time and results are bit-identical with or without it.
 // Which launch shape a launch of n rays gets under kernel = 2 (auto).  Measured on MI355X with
-// bench.py --emulate-shard: below ~6 rays per resident lane the one-ray-per-lane kernel wins (no
-// refill batches to wait for: 3.5 vs 3.8 ms on a 1/8 shard of the 2048² image), above it the
-// persistent kernel does (6.4 vs 6.8 ms on a 1/4 shard, 23.8 vs 26.4 ms on the whole image).
-int resolve_kernel(const gr_ctx* ctx, int64_t n)
+// Launch shape when the caller leaves it to the library (kernel = 2, block = 0).  Measured on MI355X
+// (scripts/kernel_shapes.py, bench.py --emulate-shard):
+//  * image planes (8x8 pixel tiles per wave): one ray per lane in ONE-WAVE workgroups.  The hardware
+//    dispatcher then refills a SIMD the moment a single wave retires, which beats the persistent
+//    kernel's wave-ballot refill at every depth (2048²: 23.3 vs 23.8 ms; 1/8 shard: 3.3 vs 3.7 ms;
+//    Johannsen 1024²: 8.5 vs 9.6 ms), and 256-thread workgroups of the same kernel by 5-10 %.
+//  * line profiles: persistent (every workgroup flushes its LDS histogram at exit; a quarter of a
+//    million one-wave workgroups would turn that into 5e7 global atomics: 31 vs 21 ms at 2048² rays).
+//  * ray arrays in caller order (no tiles, neighbours may differ wildly in length): persistent with
+//    wave-ballot refill, except for launches only a few rays per resident lane deep.
+int resolve_kernel(const gr_ctx* ctx, int64_t n, const Cold& cold)
 {
     if (ctx->kernel != 2) return (int)ctx->kernel;
+    if (cold.out_mode == 2) return 1;
+    if (cold.src_mode == 0 && cold.swizzle) return 0;
     const int64_t resident_lanes = (int64_t)ctx->n_cu * 8 * 64;
     return n < 6 * resident_lanes ? 0 : 1;
+}
+int resolve_block(const gr_ctx* ctx, int kernel)
+{
+    if (ctx->block) return (int)ctx->block;
+    return kernel == 0 ? 64 : 256;
 }
 
 int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream, bool* record)
@@ -185,7 +199,7 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
     *record = false;
     cold.tile_perm = nullptr;
     cold.tile_cost = nullptr;
-    const int kern = resolve_kernel(ctx, p.n);
+    const int kern = resolve_kernel(ctx, p.n, cold);
     if (!ctx->lpt || (kern != 1 && !ctx->lpt_lane) || !cold.swizzle || cold.src_mode != 0) return GR_OK;
     const int64_t tiles = p.n >> 6;
     // Measured on MI355X: longest-first pays when a launch is only a few tiles per
@@ -261,12 +275,18 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
         if (trc != GR_OK) return trc;
     }
     p.refill_threshold = (int32_t)ctx->refill_threshold;
-    // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins)
-    p.lds_plunge_rows = (ctx->lds && cold_in.pf.pf_id == GR_PF_REDSHIFT && cold_in.out_mode != 1 && cold_in.pf.n_plunge > 0
+    const int kern_sel = resolve_kernel(ctx, p.n, cold);
+    const int block_sel = resolve_block(ctx, kern_sel);
+    // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
+    // A table is staged per workgroup, so only where a workgroup is several waves (with one-wave
+    // workgroups 8 copies per CU would cap the occupancy; the table is read at finalize only and
+    // stays in L2 anyway).
+    p.lds_plunge_rows = (ctx->lds && block_sel >= 256 && cold_in.pf.pf_id == GR_PF_REDSHIFT && cold_in.out_mode != 1
+                         && cold_in.pf.n_plunge > 0
                          && cold_in.pf.n_plunge <= 2048) ? (int32_t)cold_in.pf.n_plunge : 0;
     p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    LaunchKnobs knobs{ resolve_kernel(ctx, p.n), (int)ctx->block, ctx->n_cu, (int)ctx->waves_per_simd,
+    LaunchKnobs knobs{ kern_sel, block_sel, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
     ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
     hipError_t le;
@@ -424,7 +444,7 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         if (value < 0 || value > 2) return fail(GR_ERR_INVALID_ARGUMENT, "kernel must be 0 (lane), 1 (persistent) or 2 (auto)");
         c->kernel = value;
     } else if (k == "block") {
-        if (value < 64 || value > 256 || value % 64) return fail(GR_ERR_INVALID_ARGUMENT, "block must be a multiple of 64 in [64, 256]");
+        if (value != 0 && (value < 64 || value > 256 || value % 64)) return fail(GR_ERR_INVALID_ARGUMENT, "block must be 0 (auto) or a multiple of 64 in [64, 256]");
         c->block = value;
     } else if (k == "refill_threshold") {
         if (value < 1 || value > 64) return fail(GR_ERR_INVALID_ARGUMENT, "refill_threshold must be in [1, 64]");

@@ -198,8 +198,12 @@ const char* gr_last_error(void);
 /* Create / destroy a context on HIP device `device`. */
 int32_t gr_ctx_create(int32_t device, gr_ctx** out);
 int32_t gr_ctx_destroy(gr_ctx* ctx);
-/* Tuning knobs: key/value, e.g. ("kernel", 0 = one-ray-per-lane, 1 = persistent with
- * wave-ballot refill), ("block", threads per workgroup), ("refill_threshold", lanes). */
+/* Tuning knobs: key/value.  ("kernel", 0 = one ray per lane, 1 = persistent with wave-ballot
+ * refill, 2 = chosen per launch [default]: image planes -> one ray per lane in one-wave workgroups,
+ * line profiles and caller-ordered ray arrays -> persistent); ("block", threads per workgroup,
+ * 0 = auto [default]: 64 for kernel 0, 256 for kernel 1); ("refill_threshold", idle lanes that
+ * trigger a refill, default 16); ("waves_per_simd"), ("swizzle"), ("lpt"), ("lpt_lane"), ("lds"),
+ * ("precision", 64 | 32). */
 int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
 
 /* ---- fused render: rendergeodesics / render_into_image! (rendering.jl:28-54,89-107) ----
