@@ -109,19 +109,42 @@ EnsembleMI355X(device::Integer) = EnsembleMI355X([device])
 
 _metric(m::KerrMetric) = (Int32(0), (m.M, m.a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m::JohannsenMetric) = (Int32(1), (m.M, m.a, m.α13, m.α22, m.α52, m.ϵ3, 0.0, 0.0))
+_metric(m::MorrisThorneWormhole) = (Int32(2), (m.b, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+_metric(m::BumblebeeMetric) = (Int32(3), (m.M, m.a, m.l, 0.0, 0.0, 0.0, 0.0, 0.0))
+_metric(m::KerrNewmanMetric) = (Int32(4), (m.M, m.a, m.Q, 0.0, 0.0, 0.0, 0.0, 0.0))
+_metric(m::JohannsenPsaltisMetric) = (Int32(5), (m.M, m.a, m.ϵ3, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m) = error("GradusMI355X: metric $(typeof(m)) has no device implementation; use a CPU ensemble")
 
-_disc(::Nothing) = (Int32(0), 0.0, 0.0)
-_disc(d::ThinDisc) = (Int32(1), Float64(d.inner_radius), Float64(d.outer_radius))
+# (disc_id, disc_r_in, disc_r_out, disc_params)
+_disc(::Nothing) = (Int32(0), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
+_disc(d::ThinDisc) = (Int32(1), Float64(d.inner_radius), Float64(d.outer_radius), (0.0, 0.0, 0.0, 0.0))
+_disc(d::ShakuraSunyaev) = (Int32(2), Float64(d.inner_radius), Inf, (Float64(d.Ṁ_Ṁedd), Float64(d.inv_η), 0.0, 0.0))
+_disc(d::DatumPlane) = (Int32(4), 0.0, 0.0, (Float64(d.height), 0.0, 0.0, 0.0))
+# ThickDisc(f) closures cannot cross the ABI: sample them with `sampled_thick_disc` (Python host:
+# geometry.ThickDisc) before tracing, or keep a CPU ensemble
 _disc(d) = error("GradusMI355X: geometry $(typeof(d)) has no device implementation; use a CPU ensemble")
 
+# chart -> (r_inner, r_outer, table, θ_first, θ_last).  A PoloidalShapeChart built by
+# event_horizon_chart wraps LinearInterpolation(r_min(θ_k), θ_k) on a uniform θ range (charts.jl:61-70).
+_chart(c::PolarChart) = (Float64(c.inner_radius), Float64(c.outer_radius), Float64[], 0.0, 0.0)
+function _chart(c::Gradus.PoloidalShapeChart)
+    θ = collect(Float64, c.shapefunc.t)
+    all(isapprox.(diff(θ), θ[2] - θ[1]; rtol = 1e-9)) || error("GradusMI355X: the chart's θ grid must be uniform")
+    tab = collect(Float64, c.shapefunc.u)
+    (minimum(filter(!isnan, tab)), Float64(c.outer_radius), tab, θ[1], θ[end])
+end
+
+# Returns the config and the arrays it points into (keep them alive for the duration of the call).
 function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2, maxiters = 1_000_000)
     id, params = _metric(config.metric)
-    did, rin, rout = _disc(config.geometry)
-    chart = config.chart::PolarChart
-    GrConfig(id, did, params, chart.inner_radius, chart.outer_radius, rin, rout, gtol,
+    did, rin, rout, dparams = _disc(config.geometry)
+    r_in, r_out, tab, θ0, θ1 = _chart(config.chart)
+    hemi = Int32(0)          # set to 1 by callers that recognise `domain_upper_hemisphere()` in the callback set
+    cfg = GrConfig(id, did, params, r_in, r_out, rin, rout, gtol,
         config.λ_domain[1], config.λ_domain[2], config.abstol, config.reltol, Float64(trace.μ),
-        maxiters, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0, Ptr{Float64}(C_NULL), 0, 0.0, 0.0, Float64(trace.q))
+        maxiters, hemi, Int32(0), 1e-4, dparams, Ptr{Float64}(C_NULL), 0,
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(trace.q))
+    cfg, tab
 end
 
 # The drop-in method: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,
@@ -144,11 +167,12 @@ function Gradus.ensemble_solve_tracing_problem(
     # host; constrain_all is applied on the device
     xs = config.position isa SVector ? [config.position] : config.position
     vs = config.velocity isa Function ? [config.velocity(i) for i = 1:N] : config.velocity
-    cfg = Ref(_config(config, trace; gtol = gtol))
+    cfg_val, keep = _config(config, trace; gtol = gtol)
+    cfg = Ref(cfg_val)
     out = Vector{GeodesicPoint{Float64,Nothing}}(undef, N)
     @assert sizeof(eltype(out)) == 152
     stats = Ref{GrStats}()
-    rc = ccall((:gr_trace_endpoints, LIB), Int32,
+    rc = GC.@preserve keep xs vs ccall((:gr_trace_endpoints, LIB), Int32,
         (Ptr{Cvoid}, Ref{GrConfig}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}, Ref{GrStats}),
         ensemble.ctxs[1], cfg, reinterpret(Float64, xs), length(xs) == 1 ? 0 : 4, reinterpret(Float64, vs), N, out, stats)
     _check(rc)
@@ -173,11 +197,13 @@ end
 
 function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λmax; image_width, image_height,
         αlims, βlims, pf::BuiltinPF = BuiltinPF(0, 1), gtol = 1e-2, abstol = 1e-9, reltol = 1e-9,
-        chart = Gradus.chart_for_metric(m))
+        chart = Gradus.chart_for_metric(m), q = 0.0)
     id, params = _metric(m)
-    did, rin, rout = _disc(d)
-    cfg = Ref(GrConfig(id, did, params, chart.inner_radius, chart.outer_radius, rin, rout, gtol, 0.0, Float64(λmax),
-        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, (0.0, 0.0, 0.0, 0.0), Ptr{Float64}(C_NULL), 0, Ptr{Float64}(C_NULL), 0, 0.0, 0.0, 0.0))
+    did, rin, rout, dparams = _disc(d)
+    r_in, r_out, tab, θ0, θ1 = _chart(chart)
+    cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
+        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, dparams, Ptr{Float64}(C_NULL), 0,
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q)))
     g = Gradus.metric(m, x)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
     plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), αlims[1], αlims[2], βlims[1], βlims[2],
@@ -186,7 +212,7 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     pfs = Ref(GrPointFunction(pf.pf_id, pf.filter_id, NaN, r_isco, 0, C_NULL, C_NULL, C_NULL, C_NULL))
     image = zeros(Float64, (image_height, image_width))             # rendering.jl:50, column-major H x W
     stats = Vector{GrStats}(undef, length(ensemble.ctxs))
-    _check(ccall((:gr_render_multi, LIB), Int32,
+    _check(GC.@preserve tab ccall((:gr_render_multi, LIB), Int32,
         (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Int64, Ptr{Float64}, Ptr{GrStats}),
         ensemble.ctxs, length(ensemble.ctxs), cfg, plane, pfs, 0, image, stats))
     α, β = Gradus.impact_axes(image_width, image_height, αlims, βlims)
