@@ -7,14 +7,14 @@ work runs in hand-written HIP kernels for gfx950; there is no CPU fallback.
 from . import _lib
 from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
-from . import corona, transferfunctions
+from . import corona, transfer_functions
 from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGenerator, EvenSampler,
                      GoldenSpiralGenerator, LampPostModel, LowerHemisphere, PowerLawSpectrum, RadialDiscProfile,
                      RandomGenerator, WeierstrassSampler, coordtime_at, emissivity_at, emissivity_profile,
                      energy_ratio, lorentz_factor, sky_angles_to_velocity, tetradframe_matrix, tracecorona)
 from .distributed import gather_image, gather_image_async, shard_plan
 from .geometry import DatumPlane, ShakuraSunyaev, ThickDisc, ThinDisc
-from .lineprofiles import BinningMethod, PowerLawEmissivity, bucket_simple, lineprofile
+from .lineprofiles import BinningMethod, PowerLawEmissivity, TransferFunctionMethod, bucket_simple, lineprofile
 from .metrics import (BumblebeeMetric, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,
                       MorrisThorneWormhole, inner_radius, isco)
 from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix
@@ -28,7 +28,9 @@ from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingCon
                       domain_upper_hemisphere, event_horizon, event_horizon_chart,
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
                       map_impact_parameters, tracegeodesic_path, tracegeodesics, tracing_configuration)
-from .transferfunctions import CunninghamTransferData, cunningham_transfer_function, cunningham_transfer_functions
+from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBranches, TransferBranches,
+                                cunningham_transfer_function, cunningham_transfer_functions, integrate_lineprofile,
+                                interpolate_branches, splitbranches, transferfunctions)
 from .special_radii import generic_isco, interpolate_plunging_velocities, plunging_fourvelocity
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -27,6 +27,11 @@ class BinningMethod:
     pass
 
 
+class TransferFunctionMethod:
+    """line-profiles.jl:126-152: Cunningham transfer functions integrated over the disc (the
+    reference's default method); the transfer functions of all radii are solved in one batch on the device."""
+
+
 class PowerLawEmissivity:
     """ε(r) = r^-q ; recognised by `lineprofile` and evaluated on the device."""
 
@@ -64,8 +69,19 @@ def _rayset(config, plane, keep):
 def lineprofile(bins, ε, m, u, d, method=None, *, λ_max=None, redshift_pf=None, minrₑ=None, maxrₑ=50.0,
                 plane=None, callback="default", ensemble=None, stats=False, **solver_args):
     """Returns (bins, flux / sum(flux))."""
+    if isinstance(method, TransferFunctionMethod):
+        from .transfer_functions import integrate_lineprofile, transferfunctions
+
+        kw = dict(solver_args)
+        numrₑ = kw.pop("numre", 100)      # identifiers are NFKC-normalised: the keyword numrₑ arrives as "numre"
+        h = kw.pop("h", 2e-8)
+        n_radii = kw.pop("n_radii", 1000)
+        tfs = transferfunctions(m, u, d, minrₑ=(m.isco() + 1e-2 if minrₑ is None else minrₑ), maxrₑ=maxrₑ, numrₑ=numrₑ,
+                                ensemble=ensemble, **kw)
+        bins = np.ascontiguousarray(bins, dtype=np.float64)
+        return bins, integrate_lineprofile(ε, tfs, bins, h=h, n_radii=n_radii)
     if method is not None and not isinstance(method, BinningMethod):
-        raise NotImplementedError("only BinningMethod() runs on the device")
+        raise NotImplementedError("method must be BinningMethod() or TransferFunctionMethod()")
     u = np.asarray(u, dtype=np.float64)
     bins = np.ascontiguousarray(bins, dtype=np.float64)
     λ_max = 2.0 * u[1] if λ_max is None else λ_max

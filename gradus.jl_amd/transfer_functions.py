@@ -281,3 +281,191 @@ def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offs
 def cunningham_transfer_function(m, x, d, rₑ, **kwargs):
     """cunningham_transfer_function(m, x, d, rₑ; N, chart, ...) for one emission radius."""
     return cunningham_transfer_functions(m, x, d, [rₑ], **kwargs)[0]
+
+
+# ------------------------------------------------------------------------------------------
+# branches, radial interpolation and integration into line profiles
+# (cunningham-transfer-functions.jl:45-176, transfer-functions-2d.jl:1-84, integration.jl)
+# ------------------------------------------------------------------------------------------
+def _interp(t, u, x):
+    """NaNLinearInterpolator (interpolations.jl:1-30) on arrays."""
+    from .corona import _nan_linear_interp
+
+    return _nan_linear_interp(t, u, x)
+
+
+@dataclass
+class TransferBranches:
+    """types.jl:107-128: each branch as its own (g✶ knots, values) pair."""
+
+    upper_g: np.ndarray
+    upper_f: np.ndarray
+    upper_t: np.ndarray
+    lower_g: np.ndarray
+    lower_f: np.ndarray
+    lower_t: np.ndarray
+    gmin: float
+    gmax: float
+    rₑ: float
+
+
+def splitbranches(ctf: CunninghamTransferData):
+    """cunningham-transfer-functions.jl:105-150 -> (lower g✶, f, t, upper g✶, f, t)"""
+    g, f, t = ctf.g_star, ctf.f, ctf.t
+    imin, imax = int(np.argmin(g)), int(np.argmax(g))
+    i1, i2 = (imin, imax) if imax > imin else (imax, imin)
+    if i1 == i2:
+        raise RuntimeError(f"Resolved same min/max for rₑ = {ctf.rₑ}")
+    b1 = np.arange(i1, i2 + 1)
+    b2 = np.concatenate([np.arange(0, i1 + 1), np.arange(i2, g.size)])
+    if f[b1][1] > f[b1][0]:
+        lo, up = b2, b1
+    else:
+        lo, up = b1, b2
+    return g[lo].copy(), f[lo].copy(), t[lo].copy(), g[up].copy(), f[up].copy(), t[up].copy()
+
+
+def _sorted_with_adjustments(g1, f1, t1, g2, f2, t2, h):
+    """_make_sorted_with_adjustments! (:61-103)"""
+    out = []
+    I1, I2 = np.argsort(g1, kind="stable"), np.argsort(g2, kind="stable")
+    g1, f1, t1, g2, f2, t2 = g1[I1], f1[I1], t1[I1], g2[I2], f2[I2], t2[I2]
+    t_lo, t_hi = 0.5 * (t1[0] + t2[0]), 0.5 * (t1[-1] + t2[-1])
+    for g, f, t in ((g1, f1, t1), (g2, f2, t2)):
+        J = (g < 1.0 - h) & (g > h)
+        g, f, t = g[J].copy(), f[J].copy(), t[J].copy()
+        t[0], t[-1] = t_lo, t_hi
+        g[0], g[-1] = 0.0, 1.0
+        out += [g, f, t]
+    return out
+
+
+def interpolate_branches(ctf: CunninghamTransferData, h=1e-6) -> TransferBranches:
+    """cunningham-transfer-functions.jl:152-176"""
+    lg, lf, lt, ug, uf, ut = _sorted_with_adjustments(*splitbranches(ctf), h)
+    return TransferBranches(ug, uf, ut, lg, lf, lt, ctf.gmin, ctf.gmax, ctf.rₑ)
+
+
+@dataclass
+class InterpolatingTransferBranches:
+    """transfer-functions-2d.jl:1-84: branches sorted by radius; calling it interpolates in rₑ."""
+
+    branches: list
+    radii: np.ndarray
+    gmin: np.ndarray
+    gmax: np.ndarray
+
+    @staticmethod
+    def from_branches(branches):
+        branches = sorted(branches, key=lambda b: b.rₑ)
+        return InterpolatingTransferBranches(branches, np.array([b.rₑ for b in branches]),
+                                             np.array([b.gmin for b in branches]), np.array([b.gmax for b in branches]))
+
+    def inner_radius(self):
+        return float(self.radii[0])
+
+    def outer_radius(self):
+        return float(self.radii[-1])
+
+    def at(self, r):
+        """(gmin, gmax, summed-branch evaluator g✶ -> f_lower + f_upper) at radius r."""
+        idx = int(np.clip(np.searchsorted(self.radii, r, side="right") - 1, 0, self.radii.size - 2))
+        r1, r2 = self.radii[idx], self.radii[idx + 1]
+        w = (r - r1) / (r2 - r1)
+        b1, b2 = self.branches[idx], self.branches[idx + 1]
+        gmin = (1 - w) * self.gmin[idx] + w * self.gmin[idx + 1]
+        gmax = (1 - w) * self.gmax[idx] + w * self.gmax[idx + 1]
+
+        def both(gs):
+            fl = (1 - w) * _interp(b1.lower_g, b1.lower_f, gs) + w * _interp(b2.lower_g, b2.lower_f, gs)
+            fu = (1 - w) * _interp(b1.upper_g, b1.upper_f, gs) + w * _interp(b2.upper_g, b2.upper_f, gs)
+            return np.where(np.isnan(fl), 0.0, fl) + np.where(np.isnan(fu), 0.0, fu)
+
+        return gmin, gmax, both
+
+
+def transferfunctions(m, x, d, *, minrₑ=None, maxrₑ=50.0, numrₑ=100, radii=None, h=1e-6, **kwargs):
+    """transferfunctions(m, x, d; minrₑ, maxrₑ, numrₑ) (:535-556): every radius in one batch on the device."""
+    from .planes import InverseGrid
+
+    if radii is None:
+        minrₑ = m.isco() + 1e-2 if minrₑ is None else minrₑ
+        radii = InverseGrid()(minrₑ, maxrₑ, numrₑ)
+    ctfs = cunningham_transfer_functions(m, x, d, radii, **kwargs)
+    return InterpolatingTransferBranches.from_branches([interpolate_branches(c, h=h) for c in ctfs])
+
+
+def integrate_lineprofile(ε, tfs: InterpolatingTransferBranches, g_grid, *, rmin=None, rmax=None, g_scale=1.0, h=1e-8,
+                          n_radii=1000, quadrature_points=7):
+    """integrate_lineprofile (integration.jl:205-262,330-372): ∫∫ over rₑ (inverse grid, n_radii annuli)
+    and over each bin of g (Gauss-Legendre, with the analytic treatment of the integrable
+    1/sqrt(g✶(1-g✶)) edges :152-203), then `_normalize!` (utils.jl:113-125)."""
+    from .planes import InverseGrid
+
+    g_grid = np.asarray(g_grid, dtype=np.float64)
+    rmin = tfs.inner_radius() if rmin is None else rmin
+    rmax = tfs.outer_radius() if rmax is None else rmax
+    X, W = np.polynomial.legendre.leggauss(quadrature_points)
+    radii = np.asarray(InverseGrid()(rmin, rmax, n_radii))
+    out = np.zeros(g_grid.size)
+    lo_all, hi_all = g_grid[:-1] / g_scale, g_grid[1:] / g_scale
+    r_prev = rmin - (radii[1] - rmin)
+    for rₑ in radii:
+        gmin, gmax, both = tfs.at(rₑ)
+        span = gmax - gmin
+
+        def S(g):
+            gs = (g - gmin) / span
+            with np.errstate(all="ignore"):
+                return (g * g) * both(gs) * g / np.sqrt(gs * (1.0 - gs))
+
+        θw = (rₑ - r_prev) * rₑ * ε(rₑ) * math.pi / span
+        r_prev = rₑ
+        glo = np.clip(lo_all, gmin, gmax)
+        ghi = np.clip(hi_all, gmin, gmax)
+        live = np.nonzero(glo != ghi)[0]
+        if live.size == 0:
+            continue
+        lo, hi, glo, ghi = lo_all[live], hi_all[live], glo[live], ghi[live]
+        slo, shi = (lo - gmin) / span, (hi - gmin) / span
+        lum = np.zeros(live.size)
+        done = np.zeros(live.size, dtype=bool)
+
+        def edge(lim, lim_gs):
+            gh = span * lim_gs + gmin
+            return S(gh) * np.abs(np.sqrt(gh) - np.sqrt(lim)) * math.sqrt(h)
+
+        # lower edge (g✶ < h)
+        a = slo < h
+        a_in = a & (shi > h)
+        a_all = a & ~(shi > h)
+        if np.any(a_in):
+            lum[a_in] += edge(glo[a_in], np.full(a_in.sum(), h))
+            glo = np.where(a_in, span * h + gmin, glo)
+        if np.any(a_all):
+            lum[a_all] = edge(glo[a_all], shi[a_all])
+            done |= a_all
+        # upper edge (g✶ > 1 - h)
+        b = (shi > 1.0 - h) & ~done
+        b_in = b & (slo < 1.0 - h)
+        b_all = b & ~(slo < 1.0 - h)
+        if np.any(b_in):
+            lum[b_in] += edge(ghi[b_in], np.full(b_in.sum(), 1.0 - h))
+            ghi = np.where(b_in, span * (1.0 - h) + gmin, ghi)
+        if np.any(b_all):
+            lum[b_all] = edge(ghi[b_all], slo[b_all])
+            done |= b_all
+        q = ~done
+        if np.any(q):
+            half = 0.5 * (ghi[q] - glo[q])
+            nodes = (X[None, :] + 1.0) * half[:, None] + glo[q][:, None]
+            vals = S(nodes.ravel()).reshape(nodes.shape)
+            lum[q] += (vals @ W) * half
+        out[live] += np.where(np.isfinite(lum), lum, 0.0) * θw
+    # _normalize!
+    flux = out.copy()
+    flux[:-1] = flux[:-1] / (g_grid[1:] + g_grid[:-1])
+    total = flux[:-1].sum()
+    if total > 0:
+        flux = flux / total
+    return flux

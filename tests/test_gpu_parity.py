@@ -765,3 +765,31 @@ def test_cunningham_transfer_functions_on_device(G, oracle, ens):
     assert len(table) == 60 and all(np.all(np.isfinite(c.f)) for c in table)
     assert (t2 - t1) < 8 * (t1 - t0)           # 60x the work, far less than 60x the time
     print(f"transfer functions: 1 radius {t1 - t0:.2f} s, 60 radii {t2 - t1:.2f} s")
+
+
+def test_transfer_function_line_profiles_on_device(G, ens):
+    """test/line-profiles/test-cunningham.jl on the device (Kerr a = 0.6 and Johannsen-Psaltis ϵ3 = 2 at
+    60°), and the two independent routes to a line profile -- image-plane binning (C5 path) and
+    integrated transfer functions -- against each other."""
+    ens.set("kernel", 2).set("precision", 64)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    d = G.ThinDisc(0.0, 250.0)
+    bins = np.linspace(0.1, 1.3, 100)
+    eps = lambda r: r ** -3.0
+    for m, lo in ((G.KerrMetric(M=1.0, a=0.6), 0.355), (G.JohannsenPsaltisMetric(1.0, 0.6, 2.0), 0.27)):
+        x, y = G.lineprofile(bins, eps, m, u, d, G.TransferFunctionMethod(), N=40, numrₑ=30, ensemble=ens)
+        g_low = x[np.argmax(y > 0)]
+        g_high = x[len(y) - 1 - np.argmax(y[::-1] > 0) - 1]
+        assert g_low == pytest.approx(lo, abs=0.05)
+        assert g_high == pytest.approx(1.2, abs=0.05)
+        assert y.sum() == pytest.approx(1.0)
+    m = G.KerrMetric(M=1.0, a=0.6)
+    x, y_tf = G.lineprofile(bins, eps, m, u, d, G.TransferFunctionMethod(), N=80, numrₑ=60, ensemble=ens)
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=700, Nθ=1500, r_max=250.0)
+    _, y_bin = G.lineprofile(bins, G.PowerLawEmissivity(3), m, u, G.ThinDisc(0.0, 250.0), G.BinningMethod(), plane=plane,
+                             minrₑ=m.isco() + 1e-2, maxrₑ=50.0, ensemble=ens)
+    # same weighting in the end: the transfer function carries one power of g, the integrand g³ and
+    # `_normalize!` takes one back (÷ (g_i + g_{i+1})): ∝ ε g³ dα dβ, as the binning method sums
+    l1 = float(np.abs(y_tf - y_bin).sum())
+    print(f"line profile, transfer functions vs image-plane binning: L1 = {l1:.4f}, Linf = {np.abs(y_tf - y_bin).max():.5f}")
+    assert l1 < 0.05

@@ -1,4 +1,4 @@
-"""Cunningham transfer functions (gradus.jl_amd/transferfunctions.py): the batched host logic driven
+"""Cunningham transfer functions (gradus.jl_amd/transfer_functions.py): the batched host logic driven
 with oracle-traced rays (no GPU in this suite), against the reference's recorded values
 (test/smoke-tests/cunningham-transfer-functions.jl:25-39)."""
 import math
@@ -28,7 +28,7 @@ def oracle_tracer(G, oracle, a, x, max_time):
 def ctf(G, oracle, a, angle, radii, **kw):
     x = np.array([0.0, 100_000.0, math.radians(angle), 0.0])
     m, tr, calls = oracle_tracer(G, oracle, a, x, 2 * x[1])
-    out = G.transferfunctions.cunningham_transfer_functions(m, x, G.ThinDisc(0.0, float("inf")), radii, N=80, tracer=tr,
+    out = G.transfer_functions.cunningham_transfer_functions(m, x, G.ThinDisc(0.0, float("inf")), radii, N=80, tracer=tr,
                                                             **kw)
     return out, calls
 
@@ -48,7 +48,7 @@ def test_datum_plane_is_hit_from_above_only(G, oracle):
 
 
 def test_golden_section_restatement():
-    from gradus_jl_amd.transferfunctions import _golden_section_batch
+    from gradus_jl_amd.transfer_functions import _golden_section_batch
 
     seen = []
 
@@ -112,3 +112,37 @@ def test_problem_cases_run_clean(G, oracle):
     for a, angle, r in cases:
         out, _ = ctf(G, oracle, a, angle, [r])
         assert out[0].f.size == 114 and np.all(np.isfinite(out[0].f)) and out[0].gmin < out[0].gmax
+
+
+def test_transfer_function_line_profile_reference_edges(G, oracle):
+    """lineprofile(bins, r -> r^-3, m, u, d, TransferFunctionMethod(); N = 40, numrₑ = 30),
+    test/line-profiles/test-cunningham.jl:5-23: edges of the Kerr a = 0.6, 60° profile and unit sum."""
+    a = 0.6
+    m = G.KerrMetric(1.0, a)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    cfg = oracle.make_config("kerr", (1.0, a), disc={"datum": 0.0}, lambda_max=2 * u[1], outer_radius=2 * u[1])
+
+    def trace(al, be):
+        pts = oracle.trace(cfg, u, oracle.map_impact_parameters(cfg, u, np.asarray(al), np.asarray(be)))
+        return pts, oracle.apply_pf(cfg, pts, 2 * u[1], pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_NONE,
+                                    r_isco=m.isco())
+
+    tfs = G.transferfunctions(m, u, G.ThinDisc(0.0, 250.0), numrₑ=30, N=40, tracer=trace)
+    assert tfs.radii.size == 30 and np.all(np.diff(tfs.radii) > 0)
+    assert tfs.inner_radius() == pytest.approx(m.isco() + 1e-2) and tfs.outer_radius() == pytest.approx(50.0)
+    bins = np.linspace(0.1, 1.3, 100)
+    y = G.integrate_lineprofile(lambda r: r ** -3.0, tfs, bins, h=2e-8, n_radii=1000)
+    g_low = bins[np.argmax(y > 0)]
+    g_high = bins[len(y) - 1 - np.argmax(y[::-1] > 0) - 1]
+    assert g_low == pytest.approx(0.355, abs=0.05)
+    assert g_high == pytest.approx(1.2, abs=0.05)
+    assert y.sum() == pytest.approx(1.0)
+    assert np.all(y >= 0) and np.argmax(y) > 80              # blue horn dominates at 60°
+    # branches: both span g✶ in [0, 1] with the extrema pinned (cunningham-transfer-functions.jl:61-103)
+    b = tfs.branches[10]
+    for g in (b.lower_g, b.upper_g):
+        assert g[0] == 0.0 and g[-1] == 1.0 and np.all(np.diff(g) >= 0)
+    # a steeper emissivity moves flux to the red wing
+    y6 = G.integrate_lineprofile(lambda r: r ** -6.0, tfs, bins, h=2e-8)
+    red = bins < 0.7
+    assert y6[red].sum() > 1.3 * y[red].sum()
