@@ -7,7 +7,7 @@ work runs in hand-written HIP kernels for gfx950; there is no CPU fallback.
 from . import _lib
 from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
-from . import corona, transfer_functions
+from . import corona, reverberation, transfer_functions
 from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGenerator, EvenSampler,
                      GoldenSpiralGenerator, LampPostModel, LowerHemisphere, PowerLawSpectrum, RadialDiscProfile,
                      RandomGenerator, WeierstrassSampler, coordtime_at, emissivity_at, emissivity_profile,
@@ -31,6 +31,8 @@ from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingCon
 from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBranches, TransferBranches,
                                 cunningham_transfer_function, cunningham_transfer_functions, integrate_lineprofile,
                                 interpolate_branches, splitbranches, transferfunctions)
+from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, lagtransfer,
+                            observer_to_disc)
 from .special_radii import generic_isco, interpolate_plunging_velocities, plunging_fourvelocity
 
 __all__ = [n for n in dir() if not n.startswith("_")]

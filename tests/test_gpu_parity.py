@@ -793,3 +793,20 @@ def test_transfer_function_line_profiles_on_device(G, ens):
     l1 = float(np.abs(y_tf - y_bin).sum())
     print(f"line profile, transfer functions vs image-plane binning: L1 = {l1:.4f}, Linf = {np.abs(y_tf - y_bin).max():.5f}")
     assert l1 < 0.05
+
+
+def test_lagtransfer_on_device(G, ens):
+    """test/transfer-functions/test-2d.jl:4-33 on the device: exact intersection counts of both ray sets
+    and the binned flux sum."""
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(M=1.0, a=0.998)
+    x = np.array([0.0, 1e6, math.radians(30), 0.0])
+    d = G.ThinDisc(m.isco(), 500.0)
+    model = G.LampPostModel(h=10.0, θ=math.radians(0.0001))
+    tf = G.lagtransfer(m, x, d, model, plane=G.PolarPlane(G.GeometricGrid(), Nr=20, Nθ=20), n_samples=100,
+                       sampler=G.EvenSampler(domain=G.BothHemispheres(), generator=G.GoldenSpiralGenerator()), ensemble=ens)
+    assert tf.observer_to_disc.size == 337
+    assert tf.coronal_geodesics.geodesic_points.size == 58
+    t, E, f = G.binflux(tf, N_t=100, N_E=100, ensemble=ens)
+    assert float(np.nansum(f)) == pytest.approx(3.9126785201177956, abs=1e-2)
+    assert float(np.nansum(f)) == pytest.approx(3.9126785201177956, rel=1e-5)

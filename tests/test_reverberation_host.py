@@ -1,0 +1,54 @@
+"""lagtransfer / binflux host logic (gradus.jl_amd/reverberation.py) on oracle-traced rays, against
+the exact counts and the flux sum recorded in test/transfer-functions/test-2d.jl:4-33."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_lagtransfer_counts_and_binned_flux(G, oracle):
+    K, RV = G.corona, G.reverberation
+    m = G.KerrMetric(M=1.0, a=0.998)
+    x = np.array([0.0, 1e6, math.radians(30), 0.0])
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=20, Nθ=20)
+    disc = (m.isco(), 500.0)
+    model = G.LampPostModel(h=10.0, θ=math.radians(0.0001))
+    max_t = 2 * x[1]
+    s = G.EvenSampler(domain=G.BothHemispheres(), generator=G.GoldenSpiralGenerator())
+    xs, vs, vsrc = K.sample_position_direction_velocity(m, model, s, 100)
+    assert xs[0, 2] == pytest.approx(1e-3)                       # pole guard of corona-models.jl:18-24
+    ccfg = oracle.make_config("kerr", (1.0, 0.998), disc=disc, lambda_max=max_t, upper_hemisphere=True)
+    gps = oracle.trace(ccfg, xs, vs)
+    mask = gps["status"] == oracle.INTERSECTED_WITH_GEOMETRY
+    assert mask.sum() == 58                                      # length(tf.coronal_geodesics.geodesic_points)
+    ce = K.CoronaGeodesics(m, G.ThinDisc(*disc), model, gps[mask], vsrc[mask])
+    ocfg = oracle.make_config("kerr", (1.0, 0.998), disc=disc, lambda_max=max_t, upper_hemisphere=True,
+                              outer_radius=1.1 * x[1])
+    a, b = G.impact_parameters(plane, x)
+    o2d = oracle.trace(ocfg, x, oracle.map_impact_parameters(ocfg, x, a, b))
+    tf = RV.assemble_lagtransfer(max_t, x, plane, ce, o2d)
+    assert tf.observer_to_disc.size == 337                       # length(tf.observer_to_disc)
+    assert tf.image_plane_areas.size == 337
+    g = oracle.apply_pf(ocfg, tf.observer_to_disc, max_t, pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_NONE,
+                        r_isco=m.isco())
+    t, E, f = RV.binflux(tf, g=g, N_t=100, N_E=100)
+    assert f.shape == (100, 100) and t.size == 100 and E.size == 100
+    assert float(np.nansum(f)) == pytest.approx(3.9126785201177956, abs=1e-2)     # the reference's tolerance
+    assert float(np.nansum(f)) == pytest.approx(3.9126785201177956, rel=1e-5)     # what is reached
+    # every photon lands in a cell; arrival times are delays after the direct continuum (t - t0 > 0)
+    de, dt = E[1] - E[0], t[1] - t[0]
+    assert float(np.nansum(f)) * de * dt == pytest.approx(1.0, rel=1e-12)
+    assert t[0] > 0 and 0.05 * 6.4 < E[0] < E[-1] < 1.5 * 6.4
+
+
+def test_bin_transfer_function_cells(G):
+    RV = G.reverberation
+    t = np.array([0.0, 0.5, 1.0, 1.0])
+    e = np.array([1.0, 1.0, 2.0, 3.0])
+    fl = np.array([1.0, 2.0, 3.0, 4.0])
+    tb, eb, tf = RV.bin_transfer_function(t, e, fl, N_E=3, N_t=3)
+    np.testing.assert_allclose(tb, [0.0, 0.5, 1.0])
+    np.testing.assert_allclose(eb, [1.0, 2.0, 3.0])
+    expect = np.full((3, 3), np.nan)
+    expect[0, 0], expect[0, 1], expect[1, 2], expect[2, 2] = 1.0, 2.0, 3.0, 4.0
+    np.testing.assert_allclose(tf, expect / 0.5)
