@@ -29,10 +29,11 @@ from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingCon
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
                       map_impact_parameters, tracegeodesic_path, tracegeodesics, tracing_configuration)
 from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBranches, TransferBranches,
-                                cunningham_transfer_function, cunningham_transfer_functions, integrate_lineprofile,
+                                cunningham_transfer_function, cunningham_transfer_functions, integrate_lagtransfer,
+                                integrate_lineprofile,
                                 interpolate_branches, splitbranches, transferfunctions)
-from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, lagtransfer,
-                            observer_to_disc)
+from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, lag_frequency,
+                            lagtransfer, observer_to_disc)
 from .special_radii import generic_isco, interpolate_plunging_velocities, plunging_fourvelocity
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -417,7 +417,8 @@ def build_radial_profile(m, spec, points, source_velocities, *, grid=None, N=100
     xb[:, 1], xb[:, 2] = bins, math.pi / 2
     vb = disc_velocity(xb)
     A = dr * _proper_area(m, bins, math.pi / 2)
-    ε = source_to_disc_emissivity(m, spec, grouped, A, xb, g_at, vb)
+    with np.errstate(all="ignore"):          # empty bins: 0 photons x (0 redshift)^-Γ = NaN, as in the reference
+        ε = source_to_disc_emissivity(m, spec, grouped, A, xb, g_at, vb)
     return RadialDiscProfile(bins, ε, ts)
 
 

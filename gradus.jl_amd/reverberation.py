@@ -113,3 +113,38 @@ def binflux(tf: LagTransferFunction, profile=None, *, redshift=None, g=None, E0=
     F = f / f.sum()
     tb, eb, td = bin_transfer_function(t, g * E0, F, **kwargs)
     return tb - t0, eb, td
+
+
+# ------------------------------------------------------------------------------------------
+# lag-frequency spectra (src/reverberation.jl:1-45)
+# ------------------------------------------------------------------------------------------
+def extend_domain_with_zeros(x, y, x_max):
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    dx = x[1] - x[0]
+    n = int(math.floor((x_max - x.min()) / dx + 1e-9)) + 1          # range(minimum(x), x_max, step = Δx)
+    xb = x.min() + dx * np.arange(n)
+    yb = np.zeros(n)
+    yb[:y.size] = y
+    return xb, yb
+
+
+def sum_impulse_response(f):
+    return np.nansum(np.asarray(f, dtype=np.float64), axis=0)
+
+
+def lag_frequency(t, ψ, *, R=1.0, flo=5e-5):
+    """lag_frequency(t, ψ) / lag_frequency(t, f::Matrix; flo) (reverberation.jl:29-45): time lag
+    -atan(Im F / (1 + Re F)) / (2π ν) of the impulse response's Fourier transform at ν > 0.
+    A matrix (g, t) is first summed over g and zero-padded to 1 / flo."""
+    ψ = np.asarray(ψ, dtype=np.float64)
+    t = np.asarray(t, dtype=np.float64)
+    if ψ.ndim == 2:
+        t, ψ = extend_domain_with_zeros(t, sum_impulse_response(ψ), 1.0 / flo)
+    n = t.size
+    freq = np.fft.fftfreq(n, d=(t[1] - t[0]))
+    F = R * np.fft.fft(ψ)
+    I = slice(0, n // 2)
+    with np.errstate(all="ignore"):
+        φ = np.arctan(F.imag[I] / (1.0 + F.real[I]))
+        τ = φ / (2.0 * math.pi * freq[I])
+    return freq[I], -τ

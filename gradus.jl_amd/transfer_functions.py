@@ -376,9 +376,18 @@ class InterpolatingTransferBranches:
         gmin = (1 - w) * self.gmin[idx] + w * self.gmin[idx + 1]
         gmax = (1 - w) * self.gmax[idx] + w * self.gmax[idx + 1]
 
+        def lerp(ga, ya, gb, yb):
+            return lambda gs: (1 - w) * _interp(ga, ya, gs) + w * _interp(gb, yb, gs)
+
+        # NB transfer-functions-2d.jl:83-84 unpacks (lower_f, upper_f, lower_t, upper_t) into variables
+        # named the other way round; the (f, t) pairs stay together, so only the labels are swapped
+        self._last = dict(lower_f=lerp(b1.lower_g, b1.lower_f, b2.lower_g, b2.lower_f),
+                          upper_f=lerp(b1.upper_g, b1.upper_f, b2.upper_g, b2.upper_f),
+                          lower_t=lerp(b1.lower_g, b1.lower_t, b2.lower_g, b2.lower_t),
+                          upper_t=lerp(b1.upper_g, b1.upper_t, b2.upper_g, b2.upper_t))
+
         def both(gs):
-            fl = (1 - w) * _interp(b1.lower_g, b1.lower_f, gs) + w * _interp(b2.lower_g, b2.lower_f, gs)
-            fu = (1 - w) * _interp(b1.upper_g, b1.upper_f, gs) + w * _interp(b2.upper_g, b2.upper_f, gs)
+            fl, fu = self._last["lower_f"](gs), self._last["upper_f"](gs)
             return np.where(np.isnan(fl), 0.0, fl) + np.where(np.isnan(fu), 0.0, fu)
 
         return gmin, gmax, both
@@ -393,6 +402,44 @@ def transferfunctions(m, x, d, *, minrₑ=None, maxrₑ=50.0, numrₑ=100, radii
         radii = InverseGrid()(minrₑ, maxrₑ, numrₑ)
     ctfs = cunningham_transfer_functions(m, x, d, radii, **kwargs)
     return InterpolatingTransferBranches.from_branches([interpolate_branches(c, h=h) for c in ctfs])
+
+
+def _integrate_bins(S, lo, hi, gmin, gmax, h, X, W):
+    """integrate_bin (integration.jl:164-203) for an array of bins [lo, hi] that overlap [gmin, gmax]:
+    Gauss-Legendre inside, the closed-form edge term where 1/sqrt(g✶(1-g✶)) blows up."""
+    span = gmax - gmin
+    glo, ghi = np.clip(lo, gmin, gmax), np.clip(hi, gmin, gmax)
+    slo, shi = (lo - gmin) / span, (hi - gmin) / span
+    lum = np.zeros(lo.size)
+    done = np.zeros(lo.size, dtype=bool)
+
+    def edge(lim, lim_gs):
+        gh = span * lim_gs + gmin
+        return S(gh) * np.abs(np.sqrt(gh) - np.sqrt(lim)) * math.sqrt(h)
+
+    a = slo < h
+    a_in, a_all = a & (shi > h), a & ~(shi > h)
+    if np.any(a_in):
+        lum[a_in] += edge(glo[a_in], np.full(int(a_in.sum()), h))
+        glo = np.where(a_in, span * h + gmin, glo)
+    if np.any(a_all):
+        lum[a_all] = edge(glo[a_all], shi[a_all])
+        done |= a_all
+    b = (shi > 1.0 - h) & ~done
+    b_in, b_all = b & (slo < 1.0 - h), b & ~(slo < 1.0 - h)
+    if np.any(b_in):
+        lum[b_in] += edge(ghi[b_in], np.full(int(b_in.sum()), 1.0 - h))
+        ghi = np.where(b_in, span * (1.0 - h) + gmin, ghi)
+    if np.any(b_all):
+        lum[b_all] = edge(ghi[b_all], slo[b_all])
+        done |= b_all
+    q = ~done
+    if np.any(q):
+        half = 0.5 * (ghi[q] - glo[q])
+        nodes = (X[None, :] + 1.0) * half[:, None] + glo[q][:, None]
+        vals = S(nodes.ravel()).reshape(nodes.shape)
+        lum[q] += (vals @ W) * half
+    return np.where(np.isfinite(lum), lum, 0.0)
 
 
 def integrate_lineprofile(ε, tfs: InterpolatingTransferBranches, g_grid, *, rmin=None, rmax=None, g_scale=1.0, h=1e-8,
@@ -426,46 +473,81 @@ def integrate_lineprofile(ε, tfs: InterpolatingTransferBranches, g_grid, *, rmi
         live = np.nonzero(glo != ghi)[0]
         if live.size == 0:
             continue
-        lo, hi, glo, ghi = lo_all[live], hi_all[live], glo[live], ghi[live]
-        slo, shi = (lo - gmin) / span, (hi - gmin) / span
-        lum = np.zeros(live.size)
-        done = np.zeros(live.size, dtype=bool)
-
-        def edge(lim, lim_gs):
-            gh = span * lim_gs + gmin
-            return S(gh) * np.abs(np.sqrt(gh) - np.sqrt(lim)) * math.sqrt(h)
-
-        # lower edge (g✶ < h)
-        a = slo < h
-        a_in = a & (shi > h)
-        a_all = a & ~(shi > h)
-        if np.any(a_in):
-            lum[a_in] += edge(glo[a_in], np.full(a_in.sum(), h))
-            glo = np.where(a_in, span * h + gmin, glo)
-        if np.any(a_all):
-            lum[a_all] = edge(glo[a_all], shi[a_all])
-            done |= a_all
-        # upper edge (g✶ > 1 - h)
-        b = (shi > 1.0 - h) & ~done
-        b_in = b & (slo < 1.0 - h)
-        b_all = b & ~(slo < 1.0 - h)
-        if np.any(b_in):
-            lum[b_in] += edge(ghi[b_in], np.full(b_in.sum(), 1.0 - h))
-            ghi = np.where(b_in, span * (1.0 - h) + gmin, ghi)
-        if np.any(b_all):
-            lum[b_all] = edge(ghi[b_all], slo[b_all])
-            done |= b_all
-        q = ~done
-        if np.any(q):
-            half = 0.5 * (ghi[q] - glo[q])
-            nodes = (X[None, :] + 1.0) * half[:, None] + glo[q][:, None]
-            vals = S(nodes.ravel()).reshape(nodes.shape)
-            lum[q] += (vals @ W) * half
-        out[live] += np.where(np.isfinite(lum), lum, 0.0) * θw
+        out[live] += _integrate_bins(S, lo_all[live], hi_all[live], gmin, gmax, h, X, W) * θw
     # _normalize!
     flux = out.copy()
     flux[:-1] = flux[:-1] / (g_grid[1:] + g_grid[:-1])
     total = flux[:-1].sum()
+    if total > 0:
+        flux = flux / total
+    return flux
+
+
+def integrate_lagtransfer(prof, tfs: InterpolatingTransferBranches, g_grid, t_grid, *, rmin=None, rmax=None, g_scale=1.0,
+                          h=1e-8, n_radii=1000, quadrature_points=7, t0=0.0):
+    """integrate_lagtransfer (integration.jl:264-289,374-453): the (g, t) response of the disc to a flash
+    of the corona.  `prof` provides emissivity_at(r) and coordtime_at(r) (source -> disc time); each
+    annulus and g-bin deposits its lower- and upper-branch flux at (source -> disc) + (disc -> observer)
+    - t0.  Rows are then normalised like the line profile (`_normalize!` for matrices; its final
+    row-maximum rescaling is discarded by the reference's own call chain and is not applied)."""
+    from .planes import GeometricGrid
+
+    g_grid = np.asarray(g_grid, dtype=np.float64)
+    t_grid = np.asarray(t_grid, dtype=np.float64)
+    rmin = tfs.inner_radius() if rmin is None else rmin
+    rmax = tfs.outer_radius() if rmax is None else rmax
+    X, W = np.polynomial.legendre.leggauss(quadrature_points)
+    radii = np.asarray(GeometricGrid()(rmin, rmax, n_radii))
+    out = np.zeros((g_grid.size, t_grid.size))
+    r_prev = rmin - (radii[1] - rmin)
+    for rₑ in radii:
+        gmin, gmax, _ = tfs.at(rₑ)
+        br = tfs._last
+        span = gmax - gmin
+
+        def make_S(fb):
+            def S(g):
+                gs = (g - gmin) / span
+                f = fb(gs)
+                with np.errstate(all="ignore"):
+                    return (g * g) * np.where(np.isnan(f), 0.0, f) * g / np.sqrt(gs * (1.0 - gs))
+            return S
+
+        θw = (rₑ - r_prev) * rₑ * float(prof.emissivity_at(rₑ)) * math.pi / span
+        t_sd = float(prof.coordtime_at(rₑ)) - t0
+        r_prev = rₑ
+        glo = np.clip(g_grid[:-1] / g_scale, gmin, gmax)
+        ghi = np.clip(g_grid[1:] / g_scale, gmin, gmax)
+        live = np.nonzero(glo != ghi)[0]
+        if live.size == 0:
+            continue
+        glo, ghi = glo[live], ghi[live]
+        k1 = _integrate_bins(make_S(br["lower_f"]), glo, ghi, gmin, gmax, h, X, W)
+        k2 = _integrate_bins(make_S(br["upper_f"]), glo, ghi, gmin, gmax, h, X, W)
+
+        def times(gs):
+            """_time_g✶ (:96-102): near an extremum the two branches' times are blended"""
+            gs = np.clip(gs, 0.0, 1.0)
+            tl, tu = br["lower_t"](gs), br["upper_t"](gs)
+            lo_e, hi_e = gs < h, gs > 1.0 - h
+            ω = np.where(lo_e, gs / h, 1.0 - (1.0 - gs) / h)
+            at = np.where(lo_e, h, 1.0 - h)
+            tle, tue = br["lower_t"](at), br["upper_t"](at)
+            edge = lo_e | hi_e
+            t1 = np.where(edge, tle * ω + (1.0 - ω) * tue, tl)
+            t2 = np.where(edge, tue * ω + (1.0 - ω) * tle, tu)
+            return t1, t2
+
+        tl1, tu1 = times((glo - gmin) / span)
+        tl2, tu2 = times((ghi - gmin) / span)
+        i1 = np.searchsorted(t_grid, 0.5 * (tl1 + tl2) + t_sd, side="left")
+        i2 = np.searchsorted(t_grid, 0.5 * (tu1 + tu2) + t_sd, side="left")
+        ok1, ok2 = i1 < t_grid.size, i2 < t_grid.size
+        np.add.at(out, (live[ok1], i1[ok1]), k1[ok1] * θw)
+        np.add.at(out, (live[ok2], i2[ok2]), k2[ok2] * θw)
+    flux = out.copy()
+    flux[:-1, :] = flux[:-1, :] / (g_grid[1:] + g_grid[:-1])[:, None]
+    total = flux[:-1, :].sum()
     if total > 0:
         flux = flux / total
     return flux

@@ -810,3 +810,23 @@ def test_lagtransfer_on_device(G, ens):
     t, E, f = G.binflux(tf, N_t=100, N_E=100, ensemble=ens)
     assert float(np.nansum(f)) == pytest.approx(3.9126785201177956, abs=1e-2)
     assert float(np.nansum(f)) == pytest.approx(3.9126785201177956, rel=1e-5)
+
+
+def test_semi_analytic_lag_transfer_on_device(G, ens):
+    """test/transfer-functions/test-2d.jl:35-79 end to end on the device: emissivity profile from 5000 corona
+    rays, transfer functions at 5 radii (from the ISCO itself), (g, t) integration; then the
+    lag-frequency spectrum."""
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(M=1.0, a=0.998)
+    x = np.array([0.0, 1e6, math.radians(30), 0.0])
+    model = G.LampPostModel(h=10.0, θ=math.radians(0.0001))
+    prof = G.emissivity_profile(m, G.ThinDisc(m.isco(), 500.0), model, n_samples=5000, ensemble=ens,
+                                sampler=G.EvenSampler(domain=G.BothHemispheres(), generator=G.GoldenSpiralGenerator()))
+    radii = G.InverseGrid()(m.isco(), 100.0, 5)
+    itb = G.transferfunctions(m, x, G.ThinDisc(0.0, 500.0), radii=radii, ensemble=ens)
+    bins, tbins = np.linspace(0.0, 1.5, 100), np.linspace(0.0, 150.0, 100)
+    flux = G.integrate_lagtransfer(prof, itb, bins, tbins, t0=x[1], n_radii=1000, rmin=min(radii), rmax=max(radii))
+    assert float(flux.sum()) == pytest.approx(1.0, abs=1e-2)
+    assert float(flux[39, :].sum()) == pytest.approx(0.021759503160585468, abs=1e-4)
+    freq, tau = G.lag_frequency(tbins, flux)
+    assert np.all(np.isfinite(tau[1:50])) and tau[1] > 0

@@ -52,3 +52,53 @@ def test_bin_transfer_function_cells(G):
     expect = np.full((3, 3), np.nan)
     expect[0, 0], expect[0, 1], expect[1, 2], expect[2, 2] = 1.0, 2.0, 3.0, 4.0
     np.testing.assert_allclose(tf, expect / 0.5)
+
+
+def test_semi_analytic_lag_transfer_reference_values(G, oracle):
+    """test/transfer-functions/test-2d.jl:35-79: Monte-Carlo emissivity profile (5000 golden-spiral rays)
+    x transfer functions at 5 radii from the ISCO out, integrated over (g, t)."""
+    K = G.corona
+    m = G.KerrMetric(M=1.0, a=0.998)
+    x = np.array([0.0, 1e6, math.radians(30), 0.0])
+    model = G.LampPostModel(h=10.0, θ=math.radians(0.0001))
+    pcfg = oracle.make_config("kerr", (1.0, 0.998), mu=1.0, closest_approach=1.000001, lambda_max=50000.0)
+    proj = K.keplerian_velocity_projector(m, plunging=oracle.plunging_table(pcfg, m.isco()))
+    s = G.EvenSampler(domain=G.BothHemispheres(), generator=G.GoldenSpiralGenerator())
+    xs, vs, vsrc = K.sample_position_direction_velocity(m, model, s, 5000)
+    ccfg = oracle.make_config("kerr", (1.0, 0.998), disc=(m.isco(), 500.0), lambda_max=10000.0, upper_hemisphere=True)
+    gps = oracle.trace(ccfg, xs, vs)
+    mask = gps["status"] == oracle.INTERSECTED_WITH_GEOMETRY
+    prof = K.build_radial_profile(m, K.PowerLawSpectrum(2.0), gps[mask], vsrc[mask], N=100, disc_velocity=proj)
+    cfg = oracle.make_config("kerr", (1.0, 0.998), disc={"datum": 0.0}, lambda_max=2 * x[1], outer_radius=2 * x[1])
+
+    def trace(al, be):
+        pts = oracle.trace(cfg, x, oracle.map_impact_parameters(cfg, x, np.asarray(al), np.asarray(be)))
+        return pts, oracle.apply_pf(cfg, pts, 2 * x[1], pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_NONE,
+                                    r_isco=m.isco())
+
+    radii = G.InverseGrid()(m.isco(), 100.0, 5)
+    itb = G.transferfunctions(m, x, G.ThinDisc(0.0, 500.0), radii=radii, tracer=trace)
+    bins, tbins = np.linspace(0.0, 1.5, 100), np.linspace(0.0, 150.0, 100)
+    flux = G.integrate_lagtransfer(prof, itb, bins, tbins, t0=x[1], n_radii=1000, rmin=min(radii), rmax=max(radii))
+    assert flux.shape == (100, 100)
+    assert float(flux.sum()) == pytest.approx(1.0, abs=1e-2)
+    assert float(flux[39, :].sum()) == pytest.approx(0.021759503160585468, abs=1e-4)      # flux[40, :] in Julia
+    assert float(flux[39, :].sum()) == pytest.approx(0.021759503160585468, rel=2e-3)
+    # the response starts after the light-travel delay and the red wing arrives first from small radii
+    first = np.argmax(flux.sum(axis=0) > 0)
+    assert tbins[first] > 5.0
+    # lag-frequency spectrum of this response: finite, positive lag at low frequencies
+    freq, tau = G.lag_frequency(tbins, flux)
+    assert freq.size == tau.size and freq[1] == pytest.approx(5e-5, rel=0.02)
+    assert np.all(np.isfinite(tau[1:50])) and tau[1] > 0
+
+
+def test_lag_frequency_of_a_delayed_pulse(G):
+    """a δ-response at delay T with small amplitude has lag ≈ A sin(2πνT)/(2πν(1 + A cos(2πνT))) -> A·T at ν -> 0"""
+    t = np.arange(0.0, 400.0, 1.0)
+    psi = np.zeros_like(t)
+    psi[50] = 0.1
+    freq, tau = G.lag_frequency(t, psi)
+    nu = freq[1:20]
+    expect = np.arctan(0.1 * np.sin(2 * np.pi * nu * 50.0) / (1 + 0.1 * np.cos(2 * np.pi * nu * 50.0))) / (2 * np.pi * nu)
+    np.testing.assert_allclose(tau[1:20], expect, rtol=1e-9, atol=1e-12)
