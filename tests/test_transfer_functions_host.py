@@ -106,12 +106,25 @@ def test_reference_values_inner_disc(G, oracle, angle, gold):
 
 
 def test_problem_cases_run_clean(G, oracle):
-    """'ones that have been problematic in the past' (same file :41-51): no failures, finite output."""
-    cases = [(-0.6, 88, 784.8253509875607), (-0.998, 88, 953.9915665264327), (0.0, 88, 631.1007589946363),
-             (0.744, 88, 3.1880132176627862), (0.9, 88, 952.1406350219423)]
-    for a, angle, r in cases:
-        out, _ = ctf(G, oracle, a, angle, [r])
-        assert out[0].f.size == 114 and np.all(np.isfinite(out[0].f)) and out[0].gmin < out[0].gmax
+    """'ones that have been problematic in the past' (smoke-tests/cunningham-transfer-functions.jl:41-51 and
+    test/transfer-functions/test-problem-cases.jl:20-35): grazing inclinations, retrograde spins, the
+    ISCO itself, a = 1 -- every root find of every case converges, output is finite."""
+    cases = [(-0.6, 1e5, 88, 784.8253509875607), (-0.998, 1e5, 88, 953.9915665264327), (-0.450, 1e5, 88, 952.1406350219423),
+             (0.0, 1e5, 88, 631.1007589946363), (0.9, 1e5, 88, 952.1406350219423), (0.744, 1e5, 88, 3.1880132176627862),
+             (0.998, 5e5, 88.0, 1.2469706551751847), (0.10324137931034483, 5e5, 82.06896551724138, 21.755193176415617),
+             (0.0, 5e5, 88.0, 264.549754423346), (0.998, 5e5, 88.0, 1.2369706551751847),
+             (0.034413793103448276, 5e5, 88.0, 396.93135746662), (0.0, 5e5, 88.0, 794.4185036834359),
+             (0.9291724137931034, 5e5, 88.0, 2.1204839212537308)]
+    for a, r_obs, angle, r in cases:
+        x = np.array([0.0, r_obs, math.radians(angle), 0.0])
+        m, tr, _ = oracle_tracer(G, oracle, a, x, 2 * r_obs)
+        c = G.transfer_functions.cunningham_transfer_function(m, x, G.ThinDisc(0.0, float("inf")), r, N=80, tracer=tr)
+        assert c.f.size == 114 and np.all(np.isfinite(c.f)) and 0 < c.gmin < c.gmax < 2.0, (a, angle, r)
+    # the extremal hole with the emitter 1 % outside the horizon: runs; samples behind the hole may be NaN
+    x = np.array([0.0, 1e5, math.radians(88), 0.0])
+    m, tr, _ = oracle_tracer(G, oracle, 1.0, x, 2e5)
+    c = G.transfer_functions.cunningham_transfer_function(m, x, G.ThinDisc(0.0, float("inf")), 1.01, N=80, tracer=tr)
+    assert c.f.size == 114 and np.isfinite(c.f).sum() > 50
 
 
 def test_transfer_function_line_profile_reference_edges(G, oracle):
