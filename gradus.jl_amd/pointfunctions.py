@@ -7,10 +7,7 @@ the trace kernel; arbitrary Python callables are applied on the host to device-t
 """
 from __future__ import annotations
 
-import math
 from typing import Callable, Optional
-
-import numpy as np
 
 from .metrics import AbstractMetric, KerrMetric
 from .status import StatusCodes

@@ -8,8 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from dataclasses import dataclass, field
-from typing import Callable, Optional
+from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 

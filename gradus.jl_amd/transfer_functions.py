@@ -83,7 +83,6 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
     r_target = np.asarray(r_target, dtype=np.float64)
     θ = np.asarray(θ, dtype=np.float64)
     n = r_target.size
-    cs, sn = np.cos(θ), np.sin(θ)
     x = np.maximum(20.0, r_target)
     lo = np.zeros(n)                      # contra point: known to fall short (or captured)
     hi = np.full(n, np.inf)
@@ -91,7 +90,6 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
     ybest = np.full(n, np.inf)
     xbest = x.copy()
     best_pts, best_g = None, np.full(n, np.nan)
-    done = np.zeros(n, dtype=bool)
     active = np.arange(n)
     for _ in range(max_iter + 1):
         if active.size == 0:
@@ -131,7 +129,6 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
         stuck = np.isfinite(ha) & ((ha - la) <= 4.0 * np.finfo(np.float64).eps * np.maximum(ha, 1.0))
         nx = np.where(bad, bis, nx)
         x[active] = np.where(conv | stuck, xa, nx)
-        done[active] = conv | stuck
         active = active[~(conv | stuck)]
     r = xbest.copy()
     ok = (best_pts["status"] == StatusCodes.IntersectedWithGeometry) & (ybest <= 1e-4 * r_target)
