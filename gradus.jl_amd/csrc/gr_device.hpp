@@ -1132,16 +1132,6 @@ struct Ray {
         }
     }
 
-    // Σ_{i<n} W[i] A[i][comp], compile-time weights
-    template <int N, class W>
-    GR_DEV real asum(const W& w, int comp) const
-    {
-        real acc = w(0) * A[0][comp];
-#pragma unroll
-        for (int i = 1; i < N; ++i) acc = GR_FMA(w(i), A[i][comp], acc);
-        return acc;
-    }
-
     // One attempted Tsit5 step.  Returns true when the ray has finished (terminated by a
     // callback, reached λ1, or hit an anomaly).
     GR_DEV bool step(const Metric& m, const Params& p)
