@@ -830,3 +830,61 @@ def test_semi_analytic_lag_transfer_on_device(G, ens):
     assert float(flux[39, :].sum()) == pytest.approx(0.021759503160585468, abs=1e-4)
     freq, tau = G.lag_frequency(tbins, flux)
     assert np.all(np.isfinite(tau[1:50])) and tau[1] > 0
+
+
+def test_randomised_scenes_on_device_vs_oracle(G, oracle, ens):
+    """72 random scenes through the C ABI against the oracle: metric family and parameters (incl. charged
+    test particles in Kerr-Newman), observer radius / inclination, thin disc or datum plane, gtol >= 0.005,
+    tolerance, upper-hemisphere callback, window, both kernels.  Same acceptance as the host-compiled
+    kernel-logic test (tests/test_kernel_logic_host.py): disc hits and full-λ rays to 1e3·tol, captured /
+    out-of-domain rays by status."""
+    rng = np.random.default_rng(20251002)
+    fam = [
+        ("kerr", lambda: (1.0, float(rng.uniform(-0.998, 0.998))), G.KerrMetric),
+        ("johannsen", lambda: (1.0, float(rng.uniform(0, 0.9)), float(rng.uniform(-1, 2)), float(rng.uniform(-1, 1)),
+                               float(rng.uniform(-1, 1)), float(rng.uniform(-1, 2))), G.JohannsenMetric),
+        ("bumblebee", lambda: (1.0, float(rng.uniform(0, 0.29)), float(rng.uniform(-0.5, 1))), G.BumblebeeMetric),
+        ("kerr-newman", lambda: (lambda a: (1.0, a, float(rng.uniform(0, math.sqrt(1 - a * a) * 0.95))))(
+            float(rng.uniform(0, 0.9))), G.KerrNewmanMetric),
+        ("johannsen-psaltis", lambda: (1.0, float(rng.uniform(0, 0.8)), float(rng.uniform(-0.5, 1))),
+         G.JohannsenPsaltisMetric),
+        ("morris-thorne", lambda: (float(rng.uniform(0.5, 3)),), G.MorrisThorneWormhole),
+    ]
+    total_mismatch = total = 0
+    for case in range(72):
+        name, gen, cls = fam[case % 6] if case >= 24 else fam[0]
+        params = gen()
+        r_obs = float(10 ** rng.uniform(1.3, 3.2))
+        th = float(np.radians(rng.uniform(5, 175)))
+        datum = bool(rng.integers(0, 4) == 0) and th < math.pi / 2 - 0.1
+        rin = float(rng.uniform(0, 8))
+        rout = float(rin + 10 ** rng.uniform(0, 2.3))
+        gtol = float(10 ** rng.uniform(-2.3, -1))
+        tol = float(rng.choice([1e-9, 1e-7, 1e-5]))
+        hemi = bool(rng.integers(0, 2))
+        q = float(rng.uniform(-1, 1)) if (name == "kerr-newman" and rng.integers(0, 2)) else 0.0
+        lam = float(rng.uniform(1.2, 3) * r_obs)
+        lim = float(rng.uniform(5, 60))
+        W = H = 16
+        m = cls(*params)
+        x = np.array([0.0, r_obs, th, 0.0])
+        ens.set("kernel", int(rng.integers(0, 2)))
+        d = G.DatumPlane(0.0) if datum else G.ThinDisc(rin, rout)
+        _, _, cache = G.prerendergeodesics(m, x, d, lam, image_width=W, image_height=H, alpha_lims=(-lim, lim),
+                                           beta_lims=(-lim, lim), gtol=gtol, abstol=tol, reltol=tol, q=q, ensemble=ens,
+                                           callback=G.domain_upper_hemisphere() if hemi else None)
+        got = np.ascontiguousarray(cache.points.T).ravel()
+        ocfg = oracle.make_config(name, params, disc=({"datum": 0.0} if datum else (rin, rout)), lambda_max=lam, gtol=gtol,
+                                  abstol=tol, reltol=tol, upper_hemisphere=hemi, q=q)
+        ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-lim, lim), (-lim, lim), W, H), nthreads=16)
+        mism = int((got["status"] != ref["status"]).sum())
+        total_mismatch += mism
+        total += got.size
+        assert mism <= 8, (case, name, params, mism)
+        ok = (got["status"] == ref["status"]) & (ref["status"] >= 2) & (ref["flags"] == 0) & (got["flags"] == 0)
+        if ok.any():
+            scale = np.maximum(np.abs(ref["x"][ok]), 1.0)
+            err = np.abs(got["x"][ok] - ref["x"][ok]) / scale
+            assert np.sort(err.max(axis=1))[-2 if err.shape[0] > 1 else -1] < max(1e3 * tol, 1e-6), (case, name, params)
+    assert total_mismatch <= 0.003 * total
+    ens.set("kernel", 2)
