@@ -14,6 +14,7 @@ from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGe
                      energy_ratio, lorentz_factor, sky_angles_to_velocity, tetradframe_matrix, tracecorona)
 from .distributed import gather_image, gather_image_async, shard_plan
 from .geometry import DatumPlane, ShakuraSunyaev, ThickDisc, ThinDisc
+from .polish_doughnut import PolishDoughnut
 from .lineprofiles import BinningMethod, PowerLawEmissivity, TransferFunctionMethod, bucket_simple, lineprofile
 from .metrics import (BumblebeeMetric, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,
                       MorrisThorneWormhole, inner_radius, isco)

@@ -340,6 +340,8 @@ def tracing_configuration(
         trajectories = velocity.shape[0]
     if chart is None:
         chart = chart_for_metric(m)
+    if hasattr(geometry, "thick_disc") and not isinstance(geometry, AbstractAccretionGeometry):
+        geometry = geometry.thick_disc()         # PolishDoughnut: its isobar, sampled like any ThickDisc(f)
     return TracingConfiguration(
         m, position, velocity, geometry, chart, callback, ensemble, trajectories, _as_lambda_domain(λs),
         abstol, reltol, gtol, μ, maxiters, q,

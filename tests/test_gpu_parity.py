@@ -888,3 +888,24 @@ def test_randomised_scenes_on_device_vs_oracle(G, oracle, ens):
             assert np.sort(err.max(axis=1))[-2 if err.shape[0] > 1 else -1] < max(1e3 * tol, 1e-6), (case, name, params)
     assert total_mismatch <= 0.003 * total
     ens.set("kernel", 2)
+
+
+def test_polish_doughnut_on_device(G, oracle, ens):
+    """A PolishDoughnut as device geometry (its isobar sampled like a ThickDisc) against the oracle tracing the
+    same table; the torus casts a shadow band across the image."""
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.2)
+    d = G.PolishDoughnut(m, rₖ=12.0, n=0.21)
+    x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+    W = H = 96
+    _, _, cache = G.prerendergeodesics(m, x, d, 2000.0, image_width=W, image_height=H, alpha_lims=(-25, 25),
+                                       beta_lims=(-15, 15), ensemble=ens)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    td = d.thick_disc()
+    ocfg = oracle.make_config("kerr", (1.0, 0.2), disc={"table": td.table, "range": td.ρ_range}, lambda_max=2000.0)
+    ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-25, 25), (-15, 15), W, H))
+    _compare_points(G, oracle, got, ref)
+    hit = got["status"] == 2
+    assert 1000 < hit.sum() < 7000
+    ρ = got["x"][hit, 1] * np.abs(np.sin(got["x"][hit, 2]))
+    assert ρ.min() >= d.inner_radius - 1e-6 and ρ.max() <= d.outer_radius + 1e-6
