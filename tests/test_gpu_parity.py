@@ -230,6 +230,67 @@ def test_full_size_properties_1024(G, oracle, ens):
     _compare_points(G, oracle, pts[idx], ref)
 
 
+def test_full_size_properties_2048_bench_workload(G, oracle, ens):
+    """The bench workload itself (BASELINE config C3, 2048² = 4 194 304 rays) through size-independent
+    properties: the fused image equals the redshift of the end-point records ray for ray, E and L_z are
+    conserved on every ray, every hit lies on the gtol wedge inside the disc's radial range, the
+    image is mirror-consistent with the end points' classification; and oracle parity on a 64 x 64
+    strided subset of the same pixels.  Default launch shape (one-wave workgroups)."""
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.998)
+    isco = m.isco()
+    W = H = 2048
+    d = G.ThinDisc(isco, 50.0)
+    pf = G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    kw = dict(image_width=W, image_height=H, alpha_lims=ALIMS, beta_lims=BLIMS, ensemble=ens)
+    _, _, img, st = G.rendergeodesics(m, X_FAR, d, 2000.0, pf=pf, stats=True, **kw)
+    assert st["rays"] == W * H and st["flagged_rays"] == 0
+    _, _, cache = G.prerendergeodesics(m, X_FAR, d, 2000.0, **kw)
+    pts = np.ascontiguousarray(cache.points.T).ravel()
+    hit = pts["status"] == G.StatusCodes.IntersectedWithGeometry
+    assert np.array_equal(np.isfinite(img).T.ravel(), hit)                   # same rays classified as hits
+    again = G.apply(pf, cache)
+    np.testing.assert_array_equal(np.isnan(again), np.isnan(img))
+    np.testing.assert_allclose(again[~np.isnan(img)], img[~np.isnan(img)], rtol=1e-12)   # fused == endpoints + apply
+    assert int(hit.sum()) == st["status_count"][2] and 1_250_000 < hit.sum() < 1_350_000
+
+    s2 = np.sin(pts["x"][:, 2]) ** 2
+    def EL(x, v):
+        s2 = np.sin(x[:, 2]) ** 2
+        Sig = x[:, 1] ** 2 + 0.998 ** 2 * (1 - s2)
+        w = 2 * x[:, 1] / Sig
+        gtt, gtp = w - 1, -0.998 * s2 * w
+        gpp = s2 * (x[:, 1] ** 2 + 0.998 ** 2 - 0.998 * gtp)
+        return -(gtt * v[:, 0] + gtp * v[:, 3]), gtp * v[:, 0] + gpp * v[:, 3]
+
+    E0, L0 = EL(pts["x_init"], pts["v_init"])
+    E1, L1 = EL(pts["x"], pts["v"])
+    fin = pts["status"] != G.StatusCodes.WithinInnerBoundary
+    assert np.max(np.abs(E1[fin] / E0[fin] - 1)) < 1e-6
+    assert np.max(np.abs(L1[fin] - L0[fin]) / np.maximum(np.abs(L0[fin]), 1.0)) < 1e-6
+    assert np.all(np.abs(np.cos(pts["x"][hit, 2])) <= 0.01 + 1e-9)
+    rho = pts["x"][hit, 1] * np.sqrt(s2[hit])
+    assert rho.min() >= isco * (1 - 1e-6) and rho.max() <= 50.0 * (1 + 1e-6)     # rim hits sit on the radial edge itself
+    # closed-form redshift of a Keplerian emitter seen by a static distant observer: g = 1/(u^t (1 - Ω L/E))
+    r = rho
+    Om = 1.0 / (r ** 1.5 + 0.998)
+    ut = (r ** 1.5 + 0.998) / np.sqrt(r ** 3 - 3 * r ** 2 + 2 * 0.998 * r ** 1.5)
+    g_closed = 1.0 / (ut * (1.0 - Om * L1[hit] / E1[hit]))
+    g_img = img.T.ravel()[hit]
+    # the disc surface is the |cosθ| = 0.01 wedge, not the equator: the closed form (equatorial) agrees to O(gtol²)
+    assert np.max(np.abs(g_img / g_closed - 1)) < 3e-3 and np.median(np.abs(g_img / g_closed - 1)) < 3e-4
+
+    idx = (np.arange(0, W, 32)[:, None] * H + np.arange(0, H, 32)[None, :]).ravel()
+    cfg = oracle.make_config("kerr", (1.0, 0.998), disc=(isco, 50.0), lambda_max=2000.0)
+    v_all = np.concatenate([oracle.render_velocities(cfg, X_FAR, ALIMS, BLIMS, W, H, i0=int(i), n=1) for i in idx])
+    ref = oracle.trace(cfg, X_FAR, v_all)
+    _compare_points(G, oracle, pts[idx], ref)
+    gref = oracle.apply_pf(cfg, ref, 2000.0, pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_INTERSECTED, r_isco=isco)
+    both = np.isfinite(gref) & np.isfinite(img.T.ravel()[idx])
+    assert both.sum() > 1000
+    np.testing.assert_allclose(img.T.ravel()[idx][both], gref[both], rtol=RTOL)      # north-star tolerance
+
+
 # ---------------- BASELINE config C4: JohannsenMetric + ThinDisc, interpolated redshift ----------------
 JOH = (1.0, 0.7, 2.0, 0.0, 0.0, 1.0)     # docs/src/getting-started.md:393
 
