@@ -278,12 +278,14 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     const int kern_sel = resolve_kernel(ctx, p.n, cold);
     const int block_sel = resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
-    // A table is staged per workgroup, so only where a workgroup is several waves (with one-wave
-    // workgroups 8 copies per CU would cap the occupancy; the table is read at finalize only and
-    // stays in L2 anyway).
-    p.lds_plunge_rows = (ctx->lds && block_sel >= 256 && cold_in.pf.pf_id == GR_PF_REDSHIFT && cold_in.out_mode != 1
+    // A table is staged per workgroup: with one-wave workgroups a CU holds 8 copies, so it is staged
+    // only while those fit the 160 KB of LDS without capping the occupancy (<= 640 rows of 32 B).
+    // The table is read at finalize only: on the Johannsen 1024² render (605 rows) staged and
+    // L2-served lookups are within run-to-run noise of each other (8.5-8.7 ms).
+    const int64_t lds_rows_max = block_sel >= 256 ? 2048 : 640;
+    p.lds_plunge_rows = (ctx->lds && cold_in.pf.pf_id == GR_PF_REDSHIFT && cold_in.out_mode != 1
                          && cold_in.pf.n_plunge > 0
-                         && cold_in.pf.n_plunge <= 2048) ? (int32_t)cold_in.pf.n_plunge : 0;
+                         && cold_in.pf.n_plunge <= lds_rows_max) ? (int32_t)cold_in.pf.n_plunge : 0;
     p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     LaunchKnobs knobs{ kern_sel, block_sel, ctx->n_cu, (int)ctx->waves_per_simd,
