@@ -16,7 +16,7 @@ from .distributed import gather_image, gather_image_async, shard_plan
 from .geometry import DatumPlane, ShakuraSunyaev, ThickDisc, ThinDisc
 from .polish_doughnut import PolishDoughnut
 from .lineprofiles import BinningMethod, PowerLawEmissivity, TransferFunctionMethod, bucket_simple, lineprofile
-from .metrics import (BumblebeeMetric, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,
+from .metrics import (BumblebeeMetric, DilatonAxion, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,
                       MorrisThorneWormhole, inner_radius, isco)
 from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix
 from .planes import (CartesianPlane, GeometricGrid, InverseGrid, LinearGrid, PolarPlane, image_plane,

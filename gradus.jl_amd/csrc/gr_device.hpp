@@ -552,10 +552,38 @@ struct GenericMetric {
         g[4] = -((a * tMr) * ((s2 * hp1) * iSig));
     }
 
+    // __DilatonAxionAD.metric_components, dilaton-axion-ad.jl:8-46 ; P = M, a, β, b
+    template <class T>
+    GR_DEV void dilaton_axion(T r, T s, T c, T g[5]) const
+    {
+        const real M = P[0], a = P[1], be = P[2], b = P[3];
+        const real R = M, a2 = a * a;
+        const bool z = (be == 0.0);
+        const real bb = z ? 0.0 : be * rcp_full(b), ba = z ? 0.0 : be * rcp_full(a), bab = z ? 0.0 : be * rcp_full(a * b);
+        T s2 = s * s;
+        T r2 = r * r;
+        T Sig = r2 + a2 * (c * c);
+        T Del = r2 + a2 - (2.0 * R) * r;
+        T bt = (2.0 * b) * r + be * be;
+        T Delh = Del - bt - (R * (R + 2.0 * b) * bb * bb);
+        T Sigh = Sig - bt + (R * R * bb) * (bb - (2.0 * a) * c);
+        T del = r2 - (2.0 * b) * r + a2;
+        T W = 1.0 + (bab * (2.0 * c - bab) + ba * ba) * inv_(s2);
+        T Was = W * (a * s);
+        T A = del * del - Delh * (Was * Was);
+        T iSigh = inv_(Sigh);
+        g[0] = -((Delh - a2 * s2) * iSigh);
+        g[1] = Sigh * inv_(Delh);
+        g[2] = Sigh;
+        g[3] = (A * s2) * iSigh;
+        g[4] = -((a * (del - Delh * W)) * (s2 * iSigh));
+    }
+
     template <class T>
     GR_DEV void components(T r, T s, T c, T g[5]) const
     {
         switch (id) {
+        case GR_METRIC_DILATON_AXION: dilaton_axion<T>(r, s, c, g); break;
         case GR_METRIC_MORRIS_THORNE: morris_thorne<T>(r, s, c, g); break;
         case GR_METRIC_BUMBLEBEE: bumblebee<T>(r, s, c, g); break;
         case GR_METRIC_KERR_NEWMAN: kerr_newman<T>(r, s, c, g); break;

@@ -16,6 +16,7 @@ import numpy as np
 
 GR_METRIC_KERR, GR_METRIC_JOHANNSEN = 0, 1
 GR_METRIC_MORRIS_THORNE, GR_METRIC_BUMBLEBEE, GR_METRIC_KERR_NEWMAN, GR_METRIC_JOHANNSEN_PSALTIS = 2, 3, 4, 5
+GR_METRIC_DILATON_AXION = 6
 
 
 class AbstractMetric:
@@ -254,6 +255,51 @@ class JohannsenPsaltisMetric(AbstractStaticAxisSymmetric):
 
     def inner_radius(self):
         return self.M + math.sqrt(self.M ** 2 - self.a ** 2)
+
+    def isco(self):
+        from .special_radii import generic_isco
+
+        return generic_isco(self)
+
+
+@dataclass(frozen=True)
+class DilatonAxion(AbstractStaticAxisSymmetric):
+    """DilatonAxion(M, a, β, b): Einstein-Maxwell-dilaton-axion metric -- src/metrics/dilaton-axion-ad.jl:8-75."""
+
+    M: float = 1.0
+    a: float = 0.5
+    β: float = 0.0
+    b: float = 1.0
+    metric_id = GR_METRIC_DILATON_AXION
+
+    def abi_params(self):
+        return [self.M, self.a, self.β, self.b]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        M, a, be, b = self.M, self.a, self.β, self.b
+        R = M
+        bb = 0.0 if be == 0.0 else be / b
+        ba = 0.0 if be == 0.0 else be / a
+        bab = 0.0 if be == 0.0 else be / (a * b)
+        s2 = s * s
+        Sig = r * r + a * a * (c * c)
+        Del = r * r + a * a - (2.0 * R) * r
+        bt = (2.0 * b) * r + be * be
+        Delh = Del - bt - R * (R + 2.0 * b) * bb * bb
+        Sigh = Sig - bt + (R * R * bb) * (bb - 2.0 * a * c)
+        de = r * r - (2.0 * b) * r + a * a
+        W = 1.0 + (bab * (2.0 * c - bab) + ba * ba) / s2
+        Was = W * a * s
+        A = de * de - Delh * (Was * Was)
+        return (-((Delh - a * a * s2) / Sigh), Sigh / Delh, Sigh, (A * s2) / Sigh, -((a * (de - Delh * W)) * s2 / Sigh))
+
+    def inner_radius(self):
+        M, a, be, b = self.M, self.a, self.β, self.b
+        bb = 0.0 if be == 0.0 else be / b
+        return M + b + math.sqrt((M + b) ** 2 - a * a + be * be - (M - 2.0 * b) * M * bb * bb)
 
     def isco(self):
         from .special_radii import generic_isco

@@ -62,7 +62,8 @@ enum {
     GR_METRIC_MORRIS_THORNE = 2,
     GR_METRIC_BUMBLEBEE = 3,
     GR_METRIC_KERR_NEWMAN = 4,
-    GR_METRIC_JOHANNSEN_PSALTIS = 5
+    GR_METRIC_JOHANNSEN_PSALTIS = 5,
+    GR_METRIC_DILATON_AXION = 6        /* DilatonAxion(M, a, β, b) src/metrics/dilaton-axion-ad.jl:49-70 */
 };
 
 /* accretion geometry

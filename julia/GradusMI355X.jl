@@ -113,6 +113,7 @@ _metric(m::MorrisThorneWormhole) = (Int32(2), (m.b, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0
 _metric(m::BumblebeeMetric) = (Int32(3), (m.M, m.a, m.l, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m::KerrNewmanMetric) = (Int32(4), (m.M, m.a, m.Q, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m::JohannsenPsaltisMetric) = (Int32(5), (m.M, m.a, m.ϵ3, 0.0, 0.0, 0.0, 0.0, 0.0))
+_metric(m::DilatonAxion) = (Int32(6), (m.M, m.a, m.β, m.b, 0.0, 0.0, 0.0, 0.0))
 _metric(m) = error("GradusMI355X: metric $(typeof(m)) has no device implementation; use a CPU ensemble")
 
 # (disc_id, disc_r_in, disc_r_out, disc_params)

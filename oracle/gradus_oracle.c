@@ -126,6 +126,7 @@ static void metric_d2(const orc_config* c, double r, double th, d2 g[5])
     case ORC_METRIC_BUMBLEBEE: bumblebee_components_d2(c->params, rr, tt, g); break;
     case ORC_METRIC_KERR_NEWMAN: kerr_newman_components_d2(c->params, rr, tt, g); break;
     case ORC_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_DILATON_AXION: dilaton_axion_components_d2(c->params, rr, tt, g); break;
     default: kerr_components_d2(c->params, rr, tt, g);
     }
 }
@@ -838,6 +839,7 @@ static void energy_jet(const orc_config* c, double r, double* E, double* dE)
     case ORC_METRIC_BUMBLEBEE: bumblebee_components_j2(c->params, rr, th, g); break;
     case ORC_METRIC_KERR_NEWMAN: kerr_newman_components_j2(c->params, rr, th, g); break;
     case ORC_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_DILATON_AXION: dilaton_axion_components_j2(c->params, rr, th, g); break;
     default: kerr_components_j2(c->params, rr, th, g);
     }
     /* first-order duals in r: metric g = (v,d); its r-derivative ∂g = (d,dd) */

@@ -139,3 +139,31 @@ static void FN(johannsen_psaltis_components)(const double* p, NUM r, NUM th, NUM
     g[3] = N_ADD(term1, term2);
     g[4] = N_NEG(N_DIV(N_MUL(N_SCALE(a, tMr), N_MUL(s2, hp1)), Sig));
 }
+
+/* __DilatonAxionAD.metric_components, src/metrics/dilaton-axion-ad.jl:8-46 ; p = M, a, β, b */
+static void FN(dilaton_axion_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1], be = p[2], b = p[3];
+    const double R = M;
+    const double bb = (be == 0.0) ? 0.0 : be / b;             /* βb  :24 */
+    const double ba = (be == 0.0) ? 0.0 : be / a;             /* βa  :25 */
+    const double bab = (be == 0.0) ? 0.0 : be / (a * b);      /* βab :26 */
+    NUM c = N_COS(th), s = N_SIN(th);
+    NUM s2 = N_MUL(s, s);
+    NUM r2 = N_MUL(r, r);
+    NUM Sig = N_ADD(r2, N_SCALE(a * a, N_MUL(c, c)));                                   /* Σ(r,a,θ)   :9  */
+    NUM Del = N_SUB(N_ADD(r2, N_CONST(a * a)), N_SCALE(2.0 * R, r));                    /* Δ(r,2R,a)  :10 */
+    NUM bt = N_ADD(N_CONST(be * be), N_SCALE(2.0 * b, r));                              /* β² + 2br        */
+    NUM Delh = N_SUB(N_SUB(Del, bt), N_CONST(R * (R + 2.0 * b) * bb * bb));             /* Δhat       :13 */
+    NUM Sigh = N_ADD(N_SUB(Sig, bt), N_SCALE(R * R * bb, N_SUB(N_CONST(bb), N_SCALE(2.0 * a, c))));  /* Σhat :12 */
+    NUM del = N_ADD(N_SUB(r2, N_SCALE(2.0 * b, r)), N_CONST(a * a));                    /* δ          :15 */
+    NUM W = N_ADD(N_CONST(1.0),
+                  N_DIV(N_ADD(N_SCALE(bab, N_SUB(N_SCALE(2.0, c), N_CONST(bab))), N_CONST(ba * ba)), s2));  /* W :17 */
+    NUM Was = N_MUL(W, N_SCALE(a, s));
+    NUM A = N_SUB(N_MUL(del, del), N_MUL(Delh, N_MUL(Was, Was)));                       /* A          :18 */
+    g[0] = N_NEG(N_DIV(N_SUB(Delh, N_SCALE(a * a, s2)), Sigh));
+    g[1] = N_DIV(Sigh, Delh);
+    g[2] = Sigh;
+    g[3] = N_DIV(N_MUL(A, s2), Sigh);
+    g[4] = N_NEG(N_DIV(N_MUL(N_SCALE(a, N_SUB(del, N_MUL(Delh, W))), s2), Sigh));
+}

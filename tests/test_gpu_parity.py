@@ -17,7 +17,7 @@ RTOL = 1e-6
 def _metric(G, name, params):
     return {"kerr": G.KerrMetric, "johannsen": G.JohannsenMetric, "morris-thorne": G.MorrisThorneWormhole,
             "bumblebee": G.BumblebeeMetric, "kerr-newman": G.KerrNewmanMetric,
-            "johannsen-psaltis": G.JohannsenPsaltisMetric}[name](*params)
+            "johannsen-psaltis": G.JohannsenPsaltisMetric, "dilaton-axion": G.DilatonAxion}[name](*params)
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
@@ -894,7 +894,7 @@ def test_semi_analytic_lag_transfer_on_device(G, ens):
 
 
 def test_randomised_scenes_on_device_vs_oracle(G, oracle, ens):
-    """72 random scenes through the C ABI against the oracle: metric family and parameters (incl. charged
+    """84 random scenes through the C ABI against the oracle: metric family and parameters (incl. charged
     test particles in Kerr-Newman), observer radius / inclination, thin disc or datum plane, gtol >= 0.005,
     tolerance, upper-hemisphere callback, window, both kernels.  Same acceptance as the host-compiled
     kernel-logic test (tests/test_kernel_logic_host.py): disc hits and full-λ rays to 1e3·tol, captured /
@@ -910,10 +910,12 @@ def test_randomised_scenes_on_device_vs_oracle(G, oracle, ens):
         ("johannsen-psaltis", lambda: (1.0, float(rng.uniform(0, 0.8)), float(rng.uniform(-0.5, 1))),
          G.JohannsenPsaltisMetric),
         ("morris-thorne", lambda: (float(rng.uniform(0.5, 3)),), G.MorrisThorneWormhole),
+        ("dilaton-axion", lambda: (1.0, float(rng.uniform(0.1, 0.8)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.3, 1.5))),
+         G.DilatonAxion),
     ]
     total_mismatch = total = 0
-    for case in range(72):
-        name, gen, cls = fam[case % 6] if case >= 24 else fam[0]
+    for case in range(84):
+        name, gen, cls = fam[case % 7] if case >= 24 else fam[0]
         params = gen()
         r_obs = float(10 ** rng.uniform(1.3, 3.2))
         th = float(np.radians(rng.uniform(5, 175)))

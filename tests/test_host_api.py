@@ -74,6 +74,26 @@ def test_kerr_isco_matches_reference_table(G):
     assert G.KerrMetric(1.0, -0.998).isco() == pytest.approx(8.99437445480357, abs=1e-12)
 
 
+def test_dilaton_axion_metric_and_isco(G, oracle):
+    """DilatonAxion: ISCOs recorded in test/smoke-tests/special-radii.jl:15-36 (atol 1e-5 there), components
+    against the oracle's dual-number restatement, and the horizon radius formula."""
+    assert G.DilatonAxion(M=1.0, a=0.6, β=-0.5, b=0.1).isco() == pytest.approx(29.701502242023523, abs=1e-5)
+    assert G.DilatonAxion(M=1.0, a=0.0, b=0.0, β=0.0).isco() == pytest.approx(6.0, abs=1e-5)
+    p = (1.0, 0.5, 0.2, 1.0)
+    m = G.DilatonAxion(*p)
+    cfg = oracle.make_config("dilaton-axion", p)
+    for r, th in ((7.0, 1.1), (4.2, 0.3), (30.0, 2.5)):
+        np.testing.assert_allclose(m.metric_components(r, th), oracle.metric_jacobian(cfg, r, th)[0], rtol=1e-13, atol=1e-15)
+    assert m.isco() == pytest.approx(oracle.isco(cfg), rel=1e-10)
+    assert cfg.r_inner == pytest.approx(1.01 * m.inner_radius())
+    # β = 0, b = 0 is Kerr
+    k = G.KerrMetric(1.0, 0.5)
+    np.testing.assert_allclose(G.DilatonAxion(1.0, 0.5, 0.0, 0.0).metric_components(5.0, 1.0), k.metric_components(5.0, 1.0),
+                               rtol=1e-13)
+    with pytest.raises(ValueError):
+        G.DilatonAxion(M=1.0, a=0.6, β=-0.5, b=0.1).inner_radius()        # no horizon for these couplings
+
+
 def test_planes(G):
     assert G.trajectory_count(G.PolarPlane(G.LinearGrid(), Nr=10, Nθ=10)) == 100
     pl = G.CartesianPlane(G.LinearGrid(), x_min=0.1, y_min=0.1, Nx=12, Ny=12)
