@@ -88,8 +88,25 @@ class PendingGather:
         elif plan.rank != self.dst:
             return None
         else:
-            full = torch.stack(self.bufs).view(plan.world, plan.n_blocks, plan.block).permute(1, 0, 2).reshape(-1)
+            # receive buffers that are consecutive rows of one [world, count] tensor (see
+            # `gather_buffers`) need no stacking copy: one permute kernel undoes the deal
+            base = getattr(self.bufs[0], "_base", None)
+            if (base is not None and base.dim() == 2 and base.shape[0] == plan.world
+                    and all(getattr(b, "_base", None) is base for b in self.bufs)):
+                stacked = base
+            else:
+                stacked = torch.stack(self.bufs)
+            full = stacked.view(plan.world, plan.n_blocks, plan.block).permute(1, 0, 2).reshape(-1)
         return full.view(plan.width, plan.height).t()
+
+
+def gather_buffers(plan: ShardPlan, like):
+    """Receive buffers for `gather_image_async` on the destination rank: `world` rows of ONE
+    [world, count] tensor, so the assembled image is a single permute away."""
+    import torch
+
+    base = torch.empty((plan.world, plan.count), dtype=like.dtype, device=like.device)
+    return [base[i] for i in range(plan.world)]
 
 
 def gather_image_async(local, plan: ShardPlan, group=None, dst: int = 0, recv_bufs=None) -> PendingGather:

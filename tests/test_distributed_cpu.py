@@ -46,7 +46,9 @@ def _worker(rank, world, port, W, H, tmp, use_async=False):
                                         nthreads=1))
     if use_async:
         # the pipelined form bench.py uses: start the gather, do other work, then collect
-        handle = G.gather_image_async(local, plan)
+        # (use_async == 2: with the single-tensor receive buffers bench.py hands in -- no stacking copy)
+        recv = G.gather_buffers(plan, local) if (use_async == 2 and rank == 0) else None
+        handle = G.gather_image_async(local, plan, recv_bufs=recv)
         _ = local.sum()
         img = handle.result()
     else:
@@ -59,7 +61,7 @@ def _worker(rank, world, port, W, H, tmp, use_async=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,use_async", [(2, False), (4, False), (2, True)])
+@pytest.mark.parametrize("world,use_async", [(2, False), (4, False), (2, True), (4, 2)])
 def test_sharded_render_equals_single(oracle, G, tmp_path, world, use_async):
     W = H = 16
     mp.spawn(_worker, args=(world, _free_port(), W, H, str(tmp_path), use_async), nprocs=world, join=True)
