@@ -95,7 +95,7 @@ def cpu_baseline(size, seconds):
         return S * S / (time.perf_counter() - t0), img
 
     rate, _ = run(48)
-    S = int(min(512, max(48, math.sqrt(rate * seconds))))
+    S = int(min(1024, max(48, math.sqrt(rate * seconds))))
     rate, _ = run(S)
     return {
         "value": rate, "unit": "geodesics/s", "cores": threads, "kind": "port",
