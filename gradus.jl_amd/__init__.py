@@ -33,7 +33,8 @@ from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBr
                                 cunningham_transfer_function, cunningham_transfer_functions, integrate_lagtransfer,
                                 integrate_lineprofile,
                                 interpolate_branches, splitbranches, transferfunctions)
-from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, lag_frequency,
+from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, continuum_time,
+                            lag_frequency,
                             lagtransfer, observer_to_disc)
 from .special_radii import generic_isco, interpolate_plunging_velocities, plunging_fourvelocity
 

@@ -148,3 +148,58 @@ def lag_frequency(t, ψ, *, R=1.0, flo=5e-5):
         φ = np.arctan(F.imag[I] / (1.0 + F.real[I]))
         τ = φ / (2.0 * math.pi * freq[I])
     return freq[I], -τ
+
+
+# ------------------------------------------------------------------------------------------
+# continuum (source -> observer) light-travel time, src/reverberation.jl:81-93
+# ------------------------------------------------------------------------------------------
+def continuum_time(m, x, model, *, ensemble=None, tracer=None, tol=1e-7, max_iter=40, **solver_opts):
+    """Coordinate time of the geodesic joining the observer `x` and the (point) source of `model`.
+
+    The reference minimises, with Nelder-Mead over (α, β), the closest approach of the observer's ray
+    to the source (a custom ContinuousCallback records the distance and stops the ray within 1e-2 of
+    it) and reads the time where that ray stopped.  Here the same ray is found as a root instead: the
+    observer's rays are traced against the horizontal plane through the source (`DatumPlane(z_src)`,
+    end points only, so the whole search runs through `gr_trace_endpoints`), and a Newton iteration
+    on (α, β) -- three rays per launch, Jacobian by differences -- moves the crossing point onto the
+    source.  The time of that crossing is the answer; it differs from the reference's by at most its
+    1e-2 stopping radius."""
+    from .geometry import DatumPlane
+    from .tracing import map_impact_parameters
+
+    x = np.asarray(x, dtype=np.float64)
+    pos, _ = model.sample_position_velocity(m)
+    rs, θs, ϕs = pos[1], pos[2], pos[3]
+    target = np.array([rs * math.sin(θs) * math.cos(ϕs), rs * math.sin(θs) * math.sin(ϕs)])
+    plane = DatumPlane(rs * math.cos(θs))
+    max_t = 2.0 * x[1]
+    if tracer is None:
+        chart = chart_for_metric(m, 2.0 * x[1])
+
+        def tracer(α, β):
+            v = map_impact_parameters(m, x, np.asarray(α, dtype=np.float64), np.asarray(β, dtype=np.float64))
+            return tracegeodesics(m, x, v, plane, max_t, chart=chart, ensemble=ensemble, **solver_opts)
+
+    def hit_xy(pts):
+        r, θ, ϕ = pts["x"][:, 1], pts["x"][:, 2], pts["x"][:, 3]
+        return np.stack([r * np.sin(θ) * np.cos(ϕ), r * np.sin(θ) * np.sin(ϕ)], axis=1)
+
+    p = np.array([0.0, 0.0])
+    δ = 1e-4 * max(1.0, rs)
+    for _ in range(max_iter):
+        pts = tracer(np.array([p[0], p[0] + δ, p[0]]), np.array([p[1], p[1], p[1] + δ]))
+        if not np.all(pts["status"] == StatusCodes.IntersectedWithGeometry):
+            raise RuntimeError("continuum_time: the observer's rays do not reach the source plane")
+        xy = hit_xy(pts)
+        F = xy[0] - target
+        if math.hypot(*F) <= tol * max(1.0, rs):
+            return float(pts["x"][0, 0])
+        J = np.column_stack([(xy[1] - xy[0]) / δ, (xy[2] - xy[0]) / δ])
+        step = np.linalg.solve(J, F)
+        # damp steps that would leave the neighbourhood in which the plane is still hit
+        lim = 0.5 * max(5.0, float(np.hypot(*p)) + rs)
+        n = float(np.hypot(*step))
+        if n > lim:
+            step *= lim / n
+        p = p - step
+    raise RuntimeError("continuum_time did not converge")

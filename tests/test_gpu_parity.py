@@ -972,3 +972,24 @@ def test_polish_doughnut_on_device(G, oracle, ens):
     assert 1000 < hit.sum() < 7000
     ρ = got["x"][hit, 1] * np.abs(np.sin(got["x"][hit, 2]))
     assert ρ.min() >= d.inner_radius - 1e-6 and ρ.max() <= d.outer_radius + 1e-6
+
+
+def test_reverberation_chain_on_device(G, ens):
+    """test/smoke-tests/reverberation.jl:1-45 end to end on the device (continuum_time, emissivity_profile,
+    transfer functions with β₀ = 2, integrate_lagtransfer, lag_frequency)."""
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 10_000.0, math.radians(45), 0.0])
+    d = G.ThinDisc(0.0, float("inf"))
+    model = G.LampPostModel()
+    t0 = G.continuum_time(m, x, model, ensemble=ens)
+    assert 10_000.0 < t0 < 10_030.0
+    prof = G.emissivity_profile(m, d, model, n_samples=500, ensemble=ens)
+    radii = G.InverseGrid()(m.isco(), 100.0, 10)
+    itb = G.transferfunctions(m, x, d, radii=radii, β0=2.0, ensemble=ens)
+    bins, tbins = np.linspace(0.0, 1.5, 100), np.linspace(0.0, 100.0, 100)
+    flux = G.integrate_lagtransfer(prof, itb, bins, tbins, t0=t0, n_radii=100, h=1e-8, rmin=min(radii), rmax=max(radii))
+    flux[flux == 0] = np.nan
+    freq, tau = G.lag_frequency(tbins, flux)
+    assert float(freq.sum()) == pytest.approx(2449.8787687490535, rel=1e-2)
+    assert float(tau[131]) == pytest.approx(9.322742661315855, rel=1e-2)

@@ -102,3 +102,42 @@ def test_lag_frequency_of_a_delayed_pulse(G):
     nu = freq[1:20]
     expect = np.arctan(0.1 * np.sin(2 * np.pi * nu * 50.0) / (1 + 0.1 * np.cos(2 * np.pi * nu * 50.0))) / (2 * np.pi * nu)
     np.testing.assert_allclose(tau[1:20], expect, rtol=1e-9, atol=1e-12)
+
+
+def test_reverberation_smoke_chain_reference_values(G, oracle):
+    """test/smoke-tests/reverberation.jl:1-45: continuum time, angular emissivity profile (500 rays),
+    transfer functions at 10 radii with the image-plane origin offset β₀ = 2, (g, t) integration and
+    the lag-frequency spectrum: sum(freq) and τ[132] as recorded (rtol 1e-2 there)."""
+    K, RV = G.corona, G.reverberation
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 10_000.0, math.radians(45), 0.0])
+    model = G.LampPostModel()
+    pos, vsrc = model.sample_position_velocity(m)
+    pcfg = oracle.make_config("kerr", (1.0, 0.998), disc={"datum": pos[1] * math.cos(pos[2])}, lambda_max=2 * x[1],
+                              outer_radius=2 * x[1])
+    t0 = RV.continuum_time(m, x, model, tracer=lambda a, b: oracle.trace(
+        pcfg, x, oracle.map_impact_parameters(pcfg, x, np.asarray(a), np.asarray(b))))
+    # light travel time from r = 5 on the axis to r = 1e4 at 45°: a little more than the coordinate distance
+    assert 10_000.0 < t0 < 10_030.0
+    plcfg = oracle.make_config("kerr", (1.0, 0.998), mu=1.0, closest_approach=1.000001, lambda_max=50000.0)
+    proj = K.keplerian_velocity_projector(m, plunging=oracle.plunging_table(plcfg, m.isco()))
+    ds = np.radians(np.linspace(0.01, 179.99, 500))
+    ccfg = oracle.make_config("kerr", (1.0, 0.998), disc=(0.0, float("inf")), lambda_max=10000.0, upper_hemisphere=True)
+    gps = oracle.trace(ccfg, pos, K.polar_angle_velocities(m, pos, vsrc, ds))
+    prof = K.point_source_profile_from_points(m, K.PowerLawSpectrum(2.0), vsrc, ds, gps, proj)
+    cfg = oracle.make_config("kerr", (1.0, 0.998), disc={"datum": 0.0}, lambda_max=2 * x[1], outer_radius=2 * x[1])
+
+    def trace(al, be):
+        pts = oracle.trace(cfg, x, oracle.map_impact_parameters(cfg, x, np.asarray(al), np.asarray(be)))
+        return pts, oracle.apply_pf(cfg, pts, 2 * x[1], pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_NONE,
+                                    r_isco=m.isco())
+
+    radii = G.InverseGrid()(m.isco(), 100.0, 10)
+    itb = G.transferfunctions(m, x, G.ThinDisc(0.0, float("inf")), radii=radii, tracer=trace, β0=2.0)
+    bins, tbins = np.linspace(0.0, 1.5, 100), np.linspace(0.0, 100.0, 100)
+    flux = G.integrate_lagtransfer(prof, itb, bins, tbins, t0=t0, n_radii=100, h=1e-8, rmin=min(radii), rmax=max(radii))
+    flux[flux == 0] = np.nan
+    freq, tau = G.lag_frequency(tbins, flux)
+    assert float(freq.sum()) == pytest.approx(2449.8787687490535, rel=1e-2)
+    assert float(tau[131]) == pytest.approx(9.322742661315855, rel=1e-2)          # τ1[132] in Julia
+    assert float(freq.sum()) == pytest.approx(2449.8787687490535, rel=1e-12)
