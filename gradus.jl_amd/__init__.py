@@ -9,7 +9,8 @@ from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
 from . import corona, reverberation, transfer_functions
 from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGenerator, EvenSampler,
-                     GoldenSpiralGenerator, LampPostModel, LowerHemisphere, PowerLawSpectrum, RadialDiscProfile,
+                     GoldenSpiralGenerator, LampPostModel, LowerHemisphere, PowerLawSpectrum, RadialDiscProfile, RingCorona,
+                     SourceVelocities,
                      RandomGenerator, WeierstrassSampler, coordtime_at, emissivity_at, emissivity_profile,
                      energy_ratio, lorentz_factor, sky_angles_to_velocity, tetradframe_matrix, tracecorona)
 from .distributed import gather_buffers, gather_image, gather_image_async, shard_plan

@@ -188,6 +188,53 @@ class BeamedPointSource(AbstractCoronaModel):
         return x, constrain_normalize(m, x, vbar, μ=1.0)
 
 
+class SourceVelocities:
+    """src/corona/models/extended.jl:1-46"""
+
+    @staticmethod
+    def co_rotating(m, x):
+        """the source co-rotates with the (Keplerian) disc below it"""
+        s = math.sin(x[2])
+        v = circular_fourvelocity(m, np.array([max(m.isco(), x[1] * s)]))[0] * s
+        g = m.metric_components(x[1], x[2])
+        v = v / math.sqrt(abs(_dot(g, v, v)))
+        return np.array([constrain_time(g, v, 1.0), v[1], v[2], v[3]])
+
+    @staticmethod
+    def stationary(m, x):
+        g = m.metric_components(x[1], x[2])
+        return np.array([1.0 / math.sqrt(-g[0]), 0.0, 0.0, 0.0])
+
+
+class RingCorona(AbstractCoronaModel):
+    """RingCorona(vf, r, h): an infinitely thin ring of radius r at height h (extended.jl:55-82).  A
+    representative point of the ring is returned; axis symmetry does the rest.  Its emissivity goes
+    through the generic Monte-Carlo route (`emissivity_profile(..., sampler=...)`); the reference's
+    dedicated arm-by-arm integrator (ring.jl) is not restated."""
+
+    def __init__(self, *args, r=5.0, h=5.0, vf=SourceVelocities.co_rotating):
+        # RingCorona(vf, r, h) | RingCorona(r, h) | RingCorona(; r, h, vf)   (extended.jl:67-71)
+        if len(args) == 3:
+            vf, r, h = args
+        elif len(args) == 2:
+            r, h = args
+        elif args:
+            raise TypeError("RingCorona(vf, r, h) | RingCorona(r, h) | RingCorona(r=, h=, vf=)")
+        self.vf, self.r, self.h = vf, float(r), float(h)
+
+    def sample_position_velocity(self, m):
+        x = np.array([0.0, math.hypot(self.r, self.h), math.atan2(self.r, self.h), 0.0])
+        return x, np.asarray(self.vf(m, x), dtype=np.float64)
+
+
+def oblate_spheroid_to_spherical(x, h, a):
+    """utils.jl:186-200: (x along the equatorial axis, height h) -> Boyer-Lindquist (r, θ)"""
+    if abs(a) < 1e-8:
+        return math.hypot(x, h), math.atan2(x, h)
+    cosθ = math.sqrt((math.sqrt(4 * a * a * h * h + (h * h + x * x - a * a) ** 2) + a * a - h * h - x * x) / (2 * a * a))
+    return h / cosθ, math.acos(cosθ)
+
+
 def sample_position_direction_velocity(m, model, sampler, N):
     """corona-models.jl:1-33 -> (xs, vs, vs_source), each (N, 4)."""
     idx = np.arange(1, N + 1)

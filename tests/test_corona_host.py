@@ -175,3 +175,19 @@ def test_beamed_point_source_at_rest_equals_lamp_post(G, K, oracle, kerr_setup):
     gps = oracle.trace(cfg, x, K.polar_angle_velocities(m, x, v, ds))
     moving = K.point_source_profile_from_points(m, K.PowerLawSpectrum(2.0), v, ds, gps, proj)
     assert moving.emissivity_at(3.0) < 0.5 * profs[0].emissivity_at(3.0)
+
+
+def test_ring_corona_source_velocity_and_oblate_coordinates(G, K):
+    """test/unit/coronal-beaming.jl:64-77 and test/unit/coordinates.jl"""
+    m = G.KerrMetric(1.0, 0.998)
+    x, v = G.RingCorona(G.SourceVelocities.co_rotating, 2.082, 50.0).sample_position_velocity(m)
+    gold = np.array([1.204, 0.0, 0.0, 0.300])          # recorded to 4 digits; Julia's ≈ on vectors compares norms
+    assert np.linalg.norm(v - gold) <= 1e-3 * max(np.linalg.norm(v), np.linalg.norm(gold))
+    g = m.metric_components(x[1], x[2])
+    assert K._dot(g, v, v) == pytest.approx(-1.0, abs=1e-12)
+    assert x[1] == pytest.approx(math.hypot(2.082, 50.0)) and x[2] == pytest.approx(math.atan2(2.082, 50.0))
+    xs, vs = G.RingCorona(G.SourceVelocities.stationary, 5.0, 5.0).sample_position_velocity(m)
+    assert vs[3] == 0.0 and K._dot(m.metric_components(xs[1], xs[2]), vs, vs) == pytest.approx(-1.0, abs=1e-12)
+    r, th = K.oblate_spheroid_to_spherical(1.02, 1.113, 0.998)
+    assert r == pytest.approx(1.3872, abs=1e-3) and th == pytest.approx(math.acos(0.8023), abs=1e-3)
+    assert K.oblate_spheroid_to_spherical(3.0, 4.0, 0.0) == pytest.approx((5.0, math.atan2(3.0, 4.0)))
