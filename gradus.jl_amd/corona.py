@@ -132,7 +132,8 @@ def sky_angles_to_velocity(m, x, v_source, θ, ϕ, E0=1.0):
 # corona models (src/corona/models/lamp-post.jl)
 # ------------------------------------------------------------------------------------------
 class AbstractCoronaModel:
-    point_source = False
+    point_source = False      # on-axis point source: the angular emissivity method applies
+    fixed_position = False    # sample_position_velocity is deterministic: one tetrad serves every sample
 
     def sample_position_velocity(self, m):
         raise NotImplementedError(
@@ -212,6 +213,8 @@ class RingCorona(AbstractCoronaModel):
     through the generic Monte-Carlo route (`emissivity_profile(..., sampler=...)`); the reference's
     dedicated arm-by-arm integrator (ring.jl) is not restated."""
 
+    fixed_position = True
+
     def __init__(self, *args, r=5.0, h=5.0, vf=SourceVelocities.co_rotating):
         # RingCorona(vf, r, h) | RingCorona(r, h) | RingCorona(; r, h, vf)   (extended.jl:67-71)
         if len(args) == 3:
@@ -241,7 +244,7 @@ def sample_position_direction_velocity(m, model, sampler, N):
     i = geti(sampler, idx, N)
     θ, ϕ = sample_angles(sampler, i, N)
     rmin = m.inner_radius() * 1.9
-    if model.point_source:
+    if model.point_source or model.fixed_position:
         x, v = model.sample_position_velocity(m)
         if x[1] < rmin:
             raise ValueError("source position lies inside 1.9 inner radii")
