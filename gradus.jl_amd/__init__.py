@@ -29,7 +29,7 @@ from .status import StatusCodes
 from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingConfiguration, chart_for_metric,
                       domain_upper_hemisphere, event_horizon, event_horizon_chart,
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
-                      map_impact_parameters, tracegeodesic_path, tracegeodesics, tracing_configuration)
+                      map_impact_parameters, tracegeodesic_path, tracegeodesic_paths, tracegeodesics, tracing_configuration)
 from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBranches, TransferBranches,
                                 cunningham_transfer_function, cunningham_transfer_functions, integrate_lagtransfer,
                                 integrate_lineprofile,

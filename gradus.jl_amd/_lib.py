@@ -167,6 +167,7 @@ EXPORTS = [
     "gr_trace_endpoints_device",
     "gr_trace_endpoints",
     "gr_trace_path",
+    "gr_trace_paths",
     "gr_lineprofile_device",
     "gr_lineprofile",
     "gr_redshift_radius_device",
@@ -203,6 +204,7 @@ def load():
     L.gr_trace_endpoints_device.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, vp, vp]
     L.gr_trace_endpoints.argtypes = [vp, cfgp, vp, i64, vp, i64, vp, stp]
     L.gr_trace_path.argtypes = [vp, cfgp, vp, vp, i64, vp, C.POINTER(i64), vp]
+    L.gr_trace_paths.argtypes = [vp, cfgp, vp, i64, vp, i64, i64, vp, vp, vp]
     rsp, bnp = C.POINTER(gr_rayset), C.POINTER(gr_binning)
     L.gr_lineprofile_device.argtypes = [vp, cfgp, rsp, pfp, bnp, vp, vp, vp]
     L.gr_lineprofile.argtypes = [vp, cfgp, rsp, pfp, bnp, vp, stp]

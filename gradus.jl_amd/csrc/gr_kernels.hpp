@@ -148,19 +148,22 @@ __global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_persist
     ls.flush(p.stats);
 }
 
-// ---- one geodesic, every accepted step saved (single wave, lane 0) ----
+// ---- geodesics with every accepted step saved: one ray per lane, ray j writes rows of 9 doubles
+// (λ, x[4], v[4]) into path[j * cap ...] ----
 template <class Metric, int DISC>
 __global__ void __launch_bounds__(64) k_trace_path(const Params p, double* path, int64_t cap, unsigned long long* n_rows)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= p.n) return;
     Metric m;
     m.load(p.cfg);
     Ray<Metric, DISC> ray;
-    ray.init(m, p, 0);
+    ray.init(m, p, j);
+    double* const mine = path + 9 * cap * j;
     int64_t n = 0;
     auto save = [&]() {
         if (n < cap) {
-            double* row = path + 9 * n;
+            double* row = mine + 9 * n;
             row[0] = ray.t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { row[1 + q] = ray.x[q]; row[5 + q] = ray.v[q]; }
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(64) k_trace_path(const Params p, double* path,
     const LdsView no_lds{ nullptr, nullptr, nullptr, nullptr, nullptr };
     ray.finalize(m, p, no_lds);     // resolves a pending event and writes the endpoint record
     save();
-    *n_rows = (unsigned long long)n;
+    n_rows[j] = (unsigned long long)n;
 }
 
 // ---- apply(pf, points) ----

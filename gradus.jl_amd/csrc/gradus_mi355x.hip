@@ -574,43 +574,49 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     return GR_OK;
 }
 
-int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const double* v, int64_t cap, double* path,
-                      int64_t* n_rows, gr_point* endpoint)
+int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64_t x_stride, const double* v, int64_t n,
+                       int64_t cap, double* path, int64_t* n_rows, gr_point* endpoints)
 {
     if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
     int32_t rc;
     if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
-    if (!x || !v || !path || !n_rows || cap < 2) return fail(GR_ERR_INVALID_ARGUMENT, "x/v/path/n_rows is null or cap < 2");
+    if (!x || !v || !path || !n_rows || cap < 2 || n < 0 || (x_stride != 0 && x_stride != 4))
+        return fail(GR_ERR_INVALID_ARGUMENT, "x/v/path/n_rows is null, cap < 2, n < 0 or x_stride not 0 / 4");
+    if (n == 0) return GR_OK;
     GR_HIP(hipSetDevice(ctx->device));
-    const size_t path_bytes = sizeof(double) * 9 * (size_t)cap;
-    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, path_bytes + sizeof(gr_point) + 16)) != GR_OK) return rc;
-    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 8 + 8)) != GR_OK) return rc;
+    const size_t path_bytes = sizeof(double) * 9 * (size_t)cap * (size_t)n;
+    const size_t pt_bytes = sizeof(gr_point) * (size_t)n;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, path_bytes + pt_bytes + 8 * (size_t)n + 16)) != GR_OK) return rc;
+    const size_t nx = x_stride ? (size_t)n : 1;
+    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 4 * (nx + (size_t)n) + 8)) != GR_OK) return rc;
     double* d_path = (double*)ctx->d_scratch;
     gr_point* d_pt = (gr_point*)((char*)ctx->d_scratch + path_bytes);
-    unsigned long long* d_n = (unsigned long long*)((char*)d_pt + sizeof(gr_point));
+    unsigned long long* d_n = (unsigned long long*)((char*)d_pt + pt_bytes);
     double* d_x = (double*)ctx->d_in;
-    GR_HIP(hipMemcpyAsync(d_x, x, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream));
-    GR_HIP(hipMemcpyAsync(d_x + 4, v, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream));
+    double* d_v = d_x + 4 * nx;
+    GR_HIP(hipMemcpyAsync(d_x, x, sizeof(double) * 4 * nx, hipMemcpyHostToDevice, ctx->stream));
+    GR_HIP(hipMemcpyAsync(d_v, v, sizeof(double) * 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     Params p;
     Cold cd;
     std::memset(&p, 0, sizeof p);
     std::memset(&cd, 0, sizeof cd);
     p.cfg = *cfg;
-    p.n = 1;
+    p.n = n;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     cd.src_mode = 1;
     cd.out_mode = 1;
     cd.x = d_x;
-    cd.x_stride = 0;
-    cd.v = d_x + 4;
+    cd.x_stride = x_stride;
+    cd.v = d_v;
     cd.points = d_pt;
-    cd.range = gr_range{ 0, 1, 1, 1 };
+    cd.range = gr_range{ 0, n, n, 1 };
     Cold* slot = ctx->d_cold + ctx->cold_next;
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, ctx->stream));
     p.cold = slot;
     if ((rc = stage_disc_table(ctx, p, ctx->stream)) != GR_OK) return rc;
-#define GR_PATH_LAUNCH(M, D) hipLaunchKernelGGL((k_trace_path<M, D>), dim3(1), dim3(64), 0, ctx->stream, p, d_path, cap, d_n)
+    const unsigned grid = (unsigned)((n + 63) / 64);
+#define GR_PATH_LAUNCH(M, D) hipLaunchKernelGGL((k_trace_path<M, D>), dim3(grid), dim3(64), 0, ctx->stream, p, d_path, cap, d_n)
 #define GR_PATH_BY_DISC(M)                                                                       \
     do {                                                                                         \
         if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(M, GR_DISC_THIN);                       \
@@ -625,14 +631,18 @@ int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const 
 #undef GR_PATH_BY_DISC
 #undef GR_PATH_LAUNCH
     GR_HIP(hipGetLastError());
-    unsigned long long n = 0;
-    GR_HIP(hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters are copied as int64");
+    GR_HIP(hipMemcpyAsync(n_rows, d_n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    GR_HIP(hipMemcpyAsync(path, d_path, path_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (endpoints) GR_HIP(hipMemcpyAsync(endpoints, d_pt, pt_bytes, hipMemcpyDeviceToHost, ctx->stream));
     GR_HIP(hipStreamSynchronize(ctx->stream));
-    *n_rows = (int64_t)n;
-    const int64_t rows = (int64_t)n < cap ? (int64_t)n : cap;
-    GR_HIP(hipMemcpy(path, d_path, sizeof(double) * 9 * (size_t)rows, hipMemcpyDeviceToHost));
-    if (endpoint) GR_HIP(hipMemcpy(endpoint, d_pt, sizeof(gr_point), hipMemcpyDeviceToHost));
     return GR_OK;
+}
+
+int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x, const double* v, int64_t cap, double* path,
+                      int64_t* n_rows, gr_point* endpoint)
+{
+    return gr_trace_paths(ctx, cfg, x, 0, v, 1, cap, path, n_rows, endpoint);
 }
 
 static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cfg, const gr_rayset* rays)

@@ -425,3 +425,35 @@ def tracegeodesic_path(m, x, v, *args, cap=200_000, **kwargs):
         raise RuntimeError(f"path needs {n.value} rows; raise cap")
     path = path[:rows]
     return GeodesicPath(path[:, 0].copy(), path[:, 1:5].copy(), path[:, 5:9].copy(), pt[0])
+
+
+def tracegeodesic_paths(m, x, v, *args, cap=2048, **kwargs):
+    """tracegeodesics(m, xs, vs, [disc], λ_domain; ...) with save_on = true for MANY geodesics: every
+    accepted step of every ray (src/tracing/tracing.jl:113-149), one ray per lane on the device
+    (gr_trace_paths).  `x` is one position or an (n, 4) array; returns a list of GeodesicPath."""
+    if len(args) == 2:
+        geometry, λs = args
+    elif len(args) == 1:
+        geometry, λs = None, args[0]
+    else:
+        raise TypeError("tracegeodesic_paths(m, x, v, [disc], λ_domain; ...)")
+    v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 4)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = v.shape[0]
+    stride = 0 if x.ndim == 1 else 4
+    if stride == 4 and x.shape[0] != n:
+        raise ValueError("positions and velocities must have the same length")
+    config = tracing_configuration(m, x if stride == 0 else x[0], v, geometry, λs, **kwargs)
+    cfg = config.abi_config()
+    L = _lib.load()
+    while True:
+        path = np.zeros((n, cap, 9))
+        rows = np.zeros(n, dtype=np.int64)
+        pts = np.zeros(n, dtype=_lib.POINT_DTYPE)
+        _lib.check(L.gr_trace_paths(config.ensemble.ctx.handle, C.byref(cfg), x.ctypes.data, stride, v.ctypes.data, n, cap,
+                                    path.ctypes.data, rows.ctypes.data, pts.ctypes.data))
+        if n == 0 or rows.max() <= cap:
+            break
+        cap = int(rows.max())                      # a ray needed more rows than provided: once more, large enough
+    return [GeodesicPath(path[j, :rows[j], 0].copy(), path[j, :rows[j], 1:5].copy(), path[j, :rows[j], 5:9].copy(), pts[j])
+            for j in range(n)]

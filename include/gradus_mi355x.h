@@ -257,6 +257,14 @@ int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, i
 int32_t gr_trace_path(gr_ctx* ctx, const gr_config* cfg, const double* x /* 4 */,
                       const double* v /* 4, unconstrained */, int64_t cap, double* path /* host, cap x 9 */,
                       int64_t* n_rows, gr_point* endpoint /* host, may be NULL */);
+/* The same for n geodesics at once (tracegeodesics(m, xs, vs, ...) with save_on = true, the
+ * EnsembleProblem solve of src/tracing/tracing.jl:113-149; the reference's benchmark suite
+ * benchmark/integrator/benchmark-tracing.jl "many-geodesic" cases): ray j fills path[j * cap * 9 ...],
+ * n_rows[j], endpoints[j].  x_stride = 0: one position for all rays, 4: one per ray. */
+int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64_t x_stride,
+                       const double* v /* n x 4, unconstrained */, int64_t n, int64_t cap,
+                       double* path /* host, n x cap x 9 */, int64_t* n_rows /* host, n */,
+                       gr_point* endpoints /* host, n, may be NULL */);
 
 /* ---- lineprofile(bins, ε, m, x, d, BinningMethod(); plane, callback) --
  * src/line-profiles.jl:152-198.  The rays are an AbstractImagePlane given by its impact parameters

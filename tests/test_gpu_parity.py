@@ -1011,3 +1011,33 @@ def test_ring_corona_traces_and_illuminates_the_disc(G, ens):
     assert ok.sum() >= 8
     peak = prof.radii[ok][np.argmax(prof.ε[ok])]
     assert 3.0 < peak < 16.0                                   # brightest under the ring (r = 8)
+
+
+def test_batched_saved_paths(G, oracle, ens):
+    """tracegeodesics(m, xs, vs, ...) with every step saved (gr_trace_paths): ray by ray identical to the
+    single-geodesic entry point, last row == end-point record, step counts == the oracle's."""
+    m = G.KerrMetric(1.0, 0.7)
+    x = np.array([0.0, 300.0, math.radians(65), 0.0])
+    al, be = np.meshgrid(np.linspace(-9, 9, 12), np.linspace(-9, 9, 11))
+    vs = G.map_impact_parameters(m, x, al.ravel(), be.ravel())
+    d = G.ThinDisc(m.isco(), 30.0)
+    paths = G.tracegeodesic_paths(m, x, vs, d, 600.0, cap=64, ensemble=ens)        # cap too small on purpose: retried
+    assert len(paths) == vs.shape[0]
+    ends = G.tracegeodesics(m, x, vs, d, 600.0, ensemble=ens)
+    ocfg = oracle.make_config("kerr", (1.0, 0.7), disc=(m.isco(), 30.0), lambda_max=600.0)
+    for j in (0, 17, 66, 131):
+        one = G.tracegeodesic_path(m, x, vs[j], d, 600.0, ensemble=ens)
+        assert one.λ.tobytes() == paths[j].λ.tobytes() and one.x.tobytes() == paths[j].x.tobytes()
+        assert one.v.tobytes() == paths[j].v.tobytes()
+        ref_pt, st = oracle.trace(ocfg, x, vs[j:j + 1], stats=True)
+        assert abs((paths[j].λ.size - 2) - int(st["accepted"][0])) <= 2
+    for j, p in enumerate(paths):
+        assert p.point["status"] == ends["status"][j]
+        np.testing.assert_array_equal(p.x[-1], ends["x"][j])
+        np.testing.assert_array_equal(p.v[-1], ends["v"][j])
+        assert p.λ[0] == 0.0 and np.all(np.diff(p.λ) > 0) and p.λ[-1] == ends["lambda_max"][j]
+    # per-ray start positions
+    xs = np.tile(x, (vs.shape[0], 1))
+    xs[:, 1] += np.arange(vs.shape[0]) * 0.01
+    p2 = G.tracegeodesic_paths(m, xs, vs, d, 600.0, ensemble=ens)
+    assert p2[5].x[0, 1] == xs[5, 1] and p2[0].x.tobytes() == paths[0].x.tobytes()
