@@ -269,6 +269,15 @@ def test_full_size_properties_2048_bench_workload(G, oracle, ens):
     assert np.max(np.abs(E1[fin] / E0[fin] - 1)) < 1e-6
     assert np.max(np.abs(L1[fin] - L0[fin]) / np.maximum(np.abs(L0[fin]), 1.0)) < 1e-6
     assert np.all(np.abs(np.cos(pts["x"][hit, 2])) <= 0.01 + 1e-9)
+
+    def carter(x, v, E, L):
+        # Q = p_θ² + cos²θ (L²/sin²θ - a² E²) for a null geodesic, p_θ = Σ v^θ
+        c2 = np.cos(x[:, 2]) ** 2
+        Sig = x[:, 1] ** 2 + 0.998 ** 2 * c2
+        return (Sig * v[:, 2]) ** 2 + c2 * (L * L / (1 - c2) - 0.998 ** 2 * E * E)
+
+    Q0, Q1 = carter(pts["x_init"], pts["v_init"], E0, L0), carter(pts["x"], pts["v"], E1, L1)
+    assert np.max(np.abs(Q1[fin] - Q0[fin]) / np.maximum(np.abs(Q0[fin]), 1.0)) < 1e-6      # Carter's constant
     rho = pts["x"][hit, 1] * np.sqrt(s2[hit])
     assert rho.min() >= isco * (1 - 1e-6) and rho.max() <= 50.0 * (1 + 1e-6)     # rim hits sit on the radial edge itself
     # closed-form redshift of a Keplerian emitter seen by a static distant observer: g = 1/(u^t (1 - Ω L/E))
