@@ -121,9 +121,28 @@ _disc(::Nothing) = (Int32(0), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
 _disc(d::ThinDisc) = (Int32(1), Float64(d.inner_radius), Float64(d.outer_radius), (0.0, 0.0, 0.0, 0.0))
 _disc(d::ShakuraSunyaev) = (Int32(2), Float64(d.inner_radius), Inf, (Float64(d.Ṁ_Ṁedd), Float64(d.inv_η), 0.0, 0.0))
 _disc(d::DatumPlane) = (Int32(4), 0.0, 0.0, (Float64(d.height), 0.0, 0.0, 0.0))
-# ThickDisc(f) closures cannot cross the ABI: sample them with `sampled_thick_disc` (Python host:
-# geometry.ThickDisc) before tracing, or keep a CPU ensemble
 _disc(d) = error("GradusMI355X: geometry $(typeof(d)) has no device implementation; use a CPU ensemble")
+
+"""
+    SampledThickDisc(d::AbstractThickAccretionDisc, ρ_min, ρ_max; samples = 16384)
+
+A thick disc whose `cross_section` closure cannot cross the ABI (`ThickDisc(f)`, `PolishDoughnut`, ...),
+sampled on a uniform ρ grid for the device (GR_DISC_TABULATED: linear interpolation, height <= 0 = no
+disc there).  Pass it as the geometry; keep it alive for the duration of the call (it owns the table).
+"""
+struct SampledThickDisc{D}
+    disc::D
+    ρ_min::Float64
+    ρ_max::Float64
+    table::Vector{Float64}
+end
+function SampledThickDisc(d, ρ_min, ρ_max; samples = 16384)
+    ρs = range(Float64(ρ_min), Float64(ρ_max), samples)
+    SampledThickDisc(d, Float64(ρ_min), Float64(ρ_max), [Float64(Gradus.cross_section(d, ρ)) for ρ in ρs])
+end
+_disc(d::SampledThickDisc) = (Int32(3), 0.0, Inf, (d.ρ_min, d.ρ_max, maximum(d.table), 0.0))
+_disc_table(d) = Float64[]
+_disc_table(d::SampledThickDisc) = d.table
 
 # chart -> (r_inner, r_outer, table, θ_first, θ_last).  A PoloidalShapeChart built by
 # event_horizon_chart wraps LinearInterpolation(r_min(θ_k), θ_k) on a uniform θ range (charts.jl:61-70).
@@ -140,12 +159,14 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2
     id, params = _metric(config.metric)
     did, rin, rout, dparams = _disc(config.geometry)
     r_in, r_out, tab, θ0, θ1 = _chart(config.chart)
+    dtab = _disc_table(config.geometry)
     hemi = Int32(0)          # set to 1 by callers that recognise `domain_upper_hemisphere()` in the callback set
     cfg = GrConfig(id, did, params, r_in, r_out, rin, rout, gtol,
         config.λ_domain[1], config.λ_domain[2], config.abstol, config.reltol, Float64(trace.μ),
-        maxiters, hemi, Int32(0), 1e-4, dparams, Ptr{Float64}(C_NULL), 0,
+        maxiters, hemi, Int32(0), 1e-4, dparams,
+        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(trace.q))
-    cfg, tab
+    cfg, (tab, dtab)
 end
 
 # The drop-in method: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,
@@ -202,8 +223,10 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     id, params = _metric(m)
     did, rin, rout, dparams = _disc(d)
     r_in, r_out, tab, θ0, θ1 = _chart(chart)
+    dtab = _disc_table(d)
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
-        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, dparams, Ptr{Float64}(C_NULL), 0,
+        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, dparams,
+        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q)))
     g = Gradus.metric(m, x)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
@@ -213,7 +236,7 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     pfs = Ref(GrPointFunction(pf.pf_id, pf.filter_id, NaN, r_isco, 0, C_NULL, C_NULL, C_NULL, C_NULL))
     image = zeros(Float64, (image_height, image_width))             # rendering.jl:50, column-major H x W
     stats = Vector{GrStats}(undef, length(ensemble.ctxs))
-    _check(GC.@preserve tab ccall((:gr_render_multi, LIB), Int32,
+    _check(GC.@preserve tab dtab ccall((:gr_render_multi, LIB), Int32,
         (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Int64, Ptr{Float64}, Ptr{GrStats}),
         ensemble.ctxs, length(ensemble.ctxs), cfg, plane, pfs, 0, image, stats))
     α, β = Gradus.impact_axes(image_width, image_height, αlims, βlims)
