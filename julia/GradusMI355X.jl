@@ -16,7 +16,7 @@ using Gradus: TracingConfiguration, EnsembleProblem, GeodesicPoint, StatusCodes,
     KerrMetric, JohannsenMetric, ThinDisc, PolarChart, lnr_momentum_to_global_velocity_transform
 using StaticArrays
 
-export EnsembleMI355X
+export EnsembleMI355X, SampledThickDisc, render_mi355x
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
 
