@@ -155,15 +155,22 @@ function _chart(c::Gradus.PoloidalShapeChart)
 end
 
 # Returns the config and the arrays it points into (keep them alive for the duration of the call).
-function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2, maxiters = 1_000_000)
+function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2, maxiters = 1_000_000,
+        upper_hemisphere = nothing)
     id, params = _metric(config.metric)
     did, rin, rout, dparams = _disc(config.geometry)
     r_in, r_out, tab, θ0, θ1 = _chart(config.chart)
     dtab = _disc_table(config.geometry)
-    hemi = Int32(0)          # set to 1 by callers that recognise `domain_upper_hemisphere()` in the callback set
+    # SciML callbacks are opaque closures and cannot cross the ABI.  `domain_upper_hemisphere(δ)`
+    # (callbacks.jl:31-40) is implemented on the device: request it with the solver option
+    # `upper_hemisphere = δ` instead of `callback = domain_upper_hemisphere(δ)`; any other callback is refused.
+    isnothing(config.callback) || isnothing(upper_hemisphere) == false ||
+        error("GradusMI355X: callbacks cannot run on the device (use `upper_hemisphere = δ` for domain_upper_hemisphere)")
+    hemi = isnothing(upper_hemisphere) ? Int32(0) : Int32(1)
+    δ = isnothing(upper_hemisphere) ? 1e-4 : Float64(upper_hemisphere)
     cfg = GrConfig(id, did, params, r_in, r_out, rin, rout, gtol,
         config.λ_domain[1], config.λ_domain[2], config.abstol, config.reltol, Float64(trace.μ),
-        maxiters, hemi, Int32(0), 1e-4, dparams,
+        maxiters, hemi, Int32(0), δ, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(trace.q))
     cfg, (tab, dtab)
@@ -180,6 +187,7 @@ function Gradus.ensemble_solve_tracing_problem(
     save_on = false,
     trace = Gradus.TraceGeodesic(),
     gtol = 1e-2,
+    upper_hemisphere = nothing,
     solver_opts...,
 )
     save_on && error("Cannot use `EnsembleMI355X` with `save_on`")
@@ -189,7 +197,7 @@ function Gradus.ensemble_solve_tracing_problem(
     # host; constrain_all is applied on the device
     xs = config.position isa SVector ? [config.position] : config.position
     vs = config.velocity isa Function ? [config.velocity(i) for i = 1:N] : config.velocity
-    cfg_val, keep = _config(config, trace; gtol = gtol)
+    cfg_val, keep = _config(config, trace; gtol = gtol, upper_hemisphere = upper_hemisphere)
     cfg = Ref(cfg_val)
     out = Vector{GeodesicPoint{Float64,Nothing}}(undef, N)
     @assert sizeof(eltype(out)) == 152
