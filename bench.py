@@ -97,8 +97,11 @@ def cpu_baseline(size, seconds):
     rate, _ = run(48)
     S = int(min(1024, max(48, math.sqrt(rate * seconds))))
     rate, _ = run(S)
+    import shutil
+
     return {
         "value": rate, "unit": "geodesics/s", "cores": threads, "kind": "port",
+        "julia_on_host": shutil.which("julia") is not None,     # the reference itself could only be timed if it were
         "sample": f"{S}x{S} pixels spanning the same image plane, C oracle with OpenMP on {threads} threads "
                   f"(restatement of the reference algorithm; Julia is not available on this box)",
     }
