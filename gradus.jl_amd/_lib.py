@@ -172,6 +172,8 @@ EXPORTS = [
     "gr_lineprofile",
     "gr_redshift_radius_device",
     "gr_redshift_radius",
+    "gr_ray_summary_device",
+    "gr_ray_summary",
     "gr_apply_pointfunction_device",
     "gr_apply_pointfunction",
 ]
@@ -210,6 +212,8 @@ def load():
     L.gr_lineprofile.argtypes = [vp, cfgp, rsp, pfp, bnp, vp, stp]
     L.gr_redshift_radius_device.argtypes = [vp, cfgp, rsp, pfp, C.c_double, C.c_double, vp, vp, vp]
     L.gr_redshift_radius.argtypes = [vp, cfgp, rsp, pfp, C.c_double, C.c_double, vp, stp]
+    L.gr_ray_summary_device.argtypes = [vp, cfgp, rsp, pfp, vp, vp, vp]
+    L.gr_ray_summary.argtypes = [vp, cfgp, rsp, pfp, vp, stp]
     L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]
     L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
     for name in EXPORTS:

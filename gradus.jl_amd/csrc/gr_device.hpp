@@ -771,7 +771,7 @@ struct PfDev {
 // live in SGPRs across the hot step loop.
 struct Cold {
     int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays
-    int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs
+    int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs, 4 = (g, ρ, t, status)
     int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
     int32_t idx32;            // 1 = every ray / pixel index fits 31 bits: 32-bit divisions in the index maps
     gr_plane plane;
@@ -1500,7 +1500,14 @@ struct Ray {
                 constrained_u0(m, p, j, x0, v0);
                 g = redshift_pf(m, p, cd, lds, x0, v0, x, v);
             }
-            if (cd.out_mode == 3) {
+            if (cd.out_mode == 4) {
+                // ray summary for the precision solvers: (g, ρ, t, status) -- 32 B instead of the
+                // 152-B end-point record plus a second pass for the redshift
+                cd.lp_pairs[4 * j] = in ? (double)g : __builtin_nan("");
+                cd.lp_pairs[4 * j + 1] = (double)rho;
+                cd.lp_pairs[4 * j + 2] = (double)x[0];
+                cd.lp_pairs[4 * j + 3] = (double)status;
+            } else if (cd.out_mode == 3) {
                 cd.lp_pairs[2 * j] = in ? (double)g : __builtin_nan("");
                 cd.lp_pairs[2 * j + 1] = in ? (double)rho : __builtin_nan("");
             } else if (in) {

@@ -710,6 +710,28 @@ int32_t gr_redshift_radius_device(gr_ctx* ctx, const gr_config* cfg, const gr_ra
     return launch_trace(ctx, p, cd, stream);
 }
 
+int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                              double* d_out, gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params p;
+    Cold cd;
+    if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
+    if (rays->n > 0 && !d_out) return fail(GR_ERR_INVALID_ARGUMENT, "out is null");
+    if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "needs the redshift point function");
+    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    cd.out_mode = 4;
+    cd.lp_rmin = 0.0;
+    cd.lp_rmax = INFINITY;
+    cd.lp_pairs = d_out;
+    p.stats = (unsigned long long*)d_stats;
+    return launch_trace(ctx, p, cd, stream);
+}
+
 // ---- host-buffer variants: stage through the context, block until done ----
 static int32_t begin_host_call(gr_ctx* ctx, gr_stats* stats)
 {
@@ -904,6 +926,24 @@ int32_t gr_redshift_radius(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* r
     if ((rc = gr_redshift_radius_device(ctx, cfg, &dev, pf, r_min, r_max, (double*)ctx->d_scratch,
                                         stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
     if (bytes) GR_HIP(hipMemcpyAsync(pairs, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
+}
+
+int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                       double* out, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (rays && rays->n > 0 && !out) return fail(GR_ERR_INVALID_ARGUMENT, "out is null");
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    gr_rayset dev;
+    if ((rc = stage_rays(ctx, rays, dev, 0, nullptr)) != GR_OK) return rc;
+    const size_t bytes = sizeof(double) * 4 * (size_t)rays->n;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = gr_ray_summary_device(ctx, cfg, &dev, pf, (double*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
+                                    ctx->stream)) != GR_OK) return rc;
+    if (bytes) GR_HIP(hipMemcpyAsync(out, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
 }
 

@@ -48,18 +48,46 @@ class CunninghamTransferData:
     rₑ: float
 
 
+SUMMARY_DTYPE = np.dtype([("status", np.int32), ("x", np.float64, (4,))])
+
+
 def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, **solver_opts):
-    """(α, β) arrays -> (end points, g): every ray against DatumPlane(0) on the device."""
-    from .rendering import apply_pointfunction
+    """(α, β) arrays -> (ray summaries, g): every ray against DatumPlane(0) on the device.  One launch
+    (`gr_ray_summary`: impact parameters in, 32 B per ray out -- g, ρ, t, status); the summaries are
+    presented with the `status` / `x` fields of end-point records (x = (t, ρ, π/2, 0)) that the solvers read."""
+    import ctypes as C
+
+    from . import _lib
+    from .lineprofiles import _rayset
+    from .rendering import abi_pointfunction
 
     plane = DatumPlane(0.0)
+    config = tracing_configuration(m, x, np.zeros((1, 4)), plane, max_time, chart=chart, ensemble=ensemble, **solver_opts)
+    cfg = config.abi_config()
+    pf, keep_pf = abi_pointfunction(redshift_pf)
+    L = _lib.load()
+    Mx = None
 
     def trace(α, β):
-        v = map_impact_parameters(m, x, np.asarray(α, dtype=np.float64), np.asarray(β, dtype=np.float64))
-        config = tracing_configuration(m, x, v, plane, max_time, chart=chart, ensemble=ensemble, **solver_opts)
-        pts = ensemble_solve_tracing_problem(config.ensemble, config)
-        g = apply_pointfunction(config.ensemble, config, redshift_pf, pts, max_time)
-        return pts, g
+        nonlocal Mx
+        α = np.ascontiguousarray(α, dtype=np.float64)
+        β = np.ascontiguousarray(β, dtype=np.float64)
+        rs = _lib.gr_rayset()
+        if Mx is None:
+            from .tracing import lnr_momentum_to_global_velocity_matrix
+
+            Mx = lnr_momentum_to_global_velocity_matrix(m, config.position)
+        for i in range(4):
+            rs.x_obs[i] = float(config.position[i])
+            for k in range(4):
+                rs.Mx[4 * i + k] = float(Mx[i, k])
+        rs.alpha, rs.beta, rs.area, rs.n = α.ctypes.data, β.ctypes.data, None, α.size
+        out = np.zeros((α.size, 4))
+        _lib.check(L.gr_ray_summary(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, None))
+        pts = np.zeros(α.size, dtype=SUMMARY_DTYPE)
+        pts["status"] = out[:, 3].astype(np.int32)
+        pts["x"][:, 0], pts["x"][:, 1], pts["x"][:, 2] = out[:, 2], out[:, 1], math.pi / 2
+        return pts, out[:, 0].copy()
 
     return trace
 

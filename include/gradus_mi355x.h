@@ -303,6 +303,17 @@ int32_t gr_redshift_radius(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* r
                            const gr_pointfunction* pf, double r_min, double r_max, double* pairs,
                            gr_stats* stats);
 
+/* ---- ray summaries for the precision solvers (find_offset_for_radius, jacobian_∂αβ_∂gr,
+ * src/tracing/precision-solvers.jl:135-236,401-451): per ray of an impact-parameter set, 4 doubles
+ * (g, ρ, t, status) = (redshift of the end point or NaN if the ray did not reach the geometry,
+ * r |sinθ| and coordinate time of the end point, status code) -- everything one solver iteration
+ * reads, in one launch and 32 B per ray. ---- */
+int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                              const gr_pointfunction* pf, double* d_out /* n x 4 */, gr_stats* d_stats,
+                              void* hip_stream);
+int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                       const gr_pointfunction* pf, double* out /* host, n x 4 */, gr_stats* stats);
+
 /* ---- apply(pf, cache): evaluate a built-in point function on endpoint records
  * (point-functions.jl:98-101, rendering.jl:103-107) ---- */
 int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,

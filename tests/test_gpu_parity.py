@@ -1050,3 +1050,32 @@ def test_batched_saved_paths(G, oracle, ens):
     xs[:, 1] += np.arange(vs.shape[0]) * 0.01
     p2 = G.tracegeodesic_paths(m, xs, vs, d, 600.0, ensemble=ens)
     assert p2[5].x[0, 1] == xs[5, 1] and p2[0].x.tobytes() == paths[0].x.tobytes()
+
+
+def test_ray_summary_equals_endpoints_plus_redshift(G, ens):
+    """gr_ray_summary (one launch, 32 B per ray) against the two-launch route it replaces in the
+    transfer-function solver: end-point records + gr_apply_pointfunction."""
+    from gradus_jl_amd.rendering import apply_pointfunction
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.9)
+    x = np.array([0.0, 1000.0, math.radians(50), 0.0])
+    pf = G.ConstPointFunctions.redshift(m, x)
+    rng = np.random.default_rng(5)
+    al, be = rng.uniform(-25, 25, 4000), rng.uniform(-25, 25, 4000)
+    trace = device_tracer(m, x, 2000.0, G.chart_for_metric(m, 2000.0), pf, ens)
+    pts, g = trace(al, be)
+    v = G.map_impact_parameters(m, x, al, be)
+    cfg = G.tracing_configuration(m, x, v, G.DatumPlane(0.0), 2000.0, chart=G.chart_for_metric(m, 2000.0), ensemble=ens)
+    ref = G.ensemble_solve_tracing_problem(ens, cfg)
+    gref = apply_pointfunction(ens, cfg, pf, ref, 2000.0)
+    np.testing.assert_array_equal(pts["status"], ref["status"])
+    hit = ref["status"] == 2
+    assert 3000 < hit.sum() < 4000
+    # (the summary path maps impact parameters to velocities on the device, the other one on the host:
+    # initial conditions agree to rounding, results to the integration tolerance)
+    np.testing.assert_allclose(pts["x"][hit, 0], ref["x"][hit, 0], rtol=1e-8)
+    np.testing.assert_allclose(pts["x"][hit, 1], ref["x"][hit, 1] * np.abs(np.sin(ref["x"][hit, 2])), rtol=1e-7)
+    np.testing.assert_allclose(g[hit], gref[hit], rtol=1e-7)
+    assert np.all(np.isnan(g[~hit]))
