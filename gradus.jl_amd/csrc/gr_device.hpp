@@ -247,20 +247,35 @@ GR_DEV void inverse_generic(const real g[5], real gi[5])
     gi[4] = -g[4] * iD;
 }
 
-struct KerrMetric {
-    static constexpr bool kHasForce = false;
-    static constexpr int kMinWavesPerSimd = 1;   // fits 2 waves/SIMD on its own (197 VGPRs)
+// Kerr (kerr-metric.jl:11-28) and, with CHARGED, Kerr-Newman (kerr-newman-ad.jl:6-27): the same
+// closed forms with Δ -> Δ + Q² and 2Mr -> 2Mr - Q²; g_tt g_ϕϕ - g_tϕ² = -Δ sin²θ holds for both.
+template <bool CHARGED>
+struct KerrFamily {
+    static constexpr bool kHasForce = CHARGED;
+    static constexpr int kMinWavesPerSimd = CHARGED ? 2 : 1;   // Kerr fits 2 waves/SIMD on its own (197 VGPRs)
     real M, a;
-    GR_DEV void load(const gr_config& c) { M = c.params[0]; a = c.params[1]; }
+    real Q, Q2, qm;      // CHARGED only: charge, its square, test-particle q (or q/μ)
+    GR_DEV void load(const gr_config& c)
+    {
+        M = c.params[0]; a = c.params[1];
+        Q = Q2 = qm = 0.0;
+        if (CHARGED) {
+            Q = c.params[2];
+            Q2 = Q * Q;
+            const double amu = c.mu < 0.0 ? -c.mu : c.mu;
+            qm = (real)(amu < 1.4901161193847656e-08 ? c.q : c.q / c.mu);
+        }
+    }
 
     // values only (constraint, redshift)
     GR_DEV void comps(real r, real s, real c, real g[5]) const
     {
         const real r2 = r * r, a2 = a * a, s2 = s * s;
         const real Sig = GR_FMA(a2, c * c, r2);
-        const real Del = GR_FMA(-2.0 * M, r, r2) + a2;
+        real Del = GR_FMA(-2.0 * M, r, r2) + a2;
+        if (CHARGED) Del += Q2;
         const real iSig = rcp_full(Sig);
-        const real w = 2.0 * M * r * iSig;
+        const real w = CHARGED ? (2.0 * M * r - Q2) * iSig : 2.0 * M * r * iSig;
         g[0] = w - 1.0;
         g[1] = Sig * rcp_full(Del);
         g[2] = Sig;
@@ -268,21 +283,26 @@ struct KerrMetric {
         g[3] = s2 * (r2 + a2 - a * g[4]);
     }
 
-    // hand-differentiated kerr-metric.jl:11-28; one reciprocal for everything
+    // hand-differentiated; one reciprocal for everything
     GR_DEV void eval(real r, real s, real c, real g[5], real gr[5], real gt[5], real gi[5]) const
     {
         const real r2 = r * r, a2 = a * a, s2 = s * s, sc = s * c;
         const real Sig = GR_FMA(a2, c * c, r2);
-        const real Del = GR_FMA(-2.0 * M, r, r2) + a2;
+        real Del = GR_FMA(-2.0 * M, r, r2) + a2;
+        if (CHARGED) Del += Q2;
         const real P = rcp_full(Sig * Del * s2);
         const real Ds2 = Del * s2;
         const real iSig = P * Ds2;           // 1/Σ
         const real iDel = P * Sig * s2;      // 1/Δ
         const real iDs = P * Sig;            // 1/(Δ sin²θ)
         const real tM = 2.0 * M;
-        const real w = tM * r * iSig;        // 2Mr/Σ
         const real iSig2 = iSig * iSig;
-        const real w_r = tM * (Sig - 2.0 * r2) * iSig2;
+        real w = tM * r * iSig;              // (2Mr - Q²)/Σ
+        real w_r = tM * (Sig - 2.0 * r2) * iSig2;
+        if (CHARGED) {
+            w -= Q2 * iSig;
+            w_r += 2.0 * r * Q2 * iSig2;
+        }
         const real Sig_t = -2.0 * a2 * sc;
         const real w_t = -w * Sig_t * iSig;
         const real as2 = a * s2;
@@ -307,14 +327,40 @@ struct KerrMetric {
         gt[4] = -a * (2.0 * sc * w + s2 * w_t);
         gt[3] = 2.0 * sc * B - as2 * gt[4];
 
-        // g_tt g_ϕϕ - g_tϕ² = -Δ sin²θ for Kerr
         gi[0] = -B * iDel;
         gi[1] = Del * iSig;
         gi[2] = iSig;
         gi[3] = -g[0] * iDs;
         gi[4] = g[4] * iDs;
     }
+
+    // q F^μ_κ v^κ, F = g⁻¹(∂A - ∂Aᵀ) (tracing/utility.jl:89-99), A = (rQ/Σ)(1, 0, 0, -a sin²θ)
+    // (kerr-newman-ad.jl:29-33), added to the acceleration as in kerr-newman-ad.jl:66-100.
+    // Hand-differentiated: with p = rQ/Σ, p_r = Q(Σ - 2r²)/Σ², p_θ = 2a² rQ sinθ cosθ/Σ².
+    GR_DEV void add_force(real r, real s, real c, const real gi[5], real vt, real vr, real vh, real vp,
+                          real& at, real& ar, real& ah, real& ap) const
+    {
+        if (!CHARGED || qm == 0.0) return;
+        const real r2 = r * r, s2 = s * s, sc = s * c;
+        const real Sig = GR_FMA(a * a, c * c, r2);
+        const real iSig = rcp_full(Sig);
+        const real p = r * Q * iSig;
+        const real p_r = Q * (Sig - 2.0 * r2) * iSig * iSig;
+        const real p_t = 2.0 * a * a * sc * p * iSig;
+        const real Ap_r = -a * s2 * p_r;
+        const real Ap_t = -a * (2.0 * sc * p + s2 * p_t);
+        const real wt = p_r * vr + p_t * vh;
+        const real wp = Ap_r * vr + Ap_t * vh;
+        const real wr = -(p_r * vt + Ap_r * vp);
+        const real wh = -(p_t * vt + Ap_t * vp);
+        at += qm * (gi[0] * wt + gi[4] * wp);
+        ar += qm * (gi[1] * wr);
+        ah += qm * (gi[2] * wh);
+        ap += qm * (gi[4] * wt + gi[3] * wp);
+    }
 };
+typedef KerrFamily<false> KerrMetric;
+typedef KerrFamily<true> KerrNewmanMetric;
 
 // Johannsen metric with hand-written derivatives (johannsen-ad.jl:12-34): about half the flops of
 // the dual-number evaluation.  With N = (r²+a²)A1 - a²A2 sin²θ:
@@ -412,43 +458,14 @@ struct GenericMetric {
     // the dual-number evaluation wants ~285 registers; capping it at 256 (2 waves/SIMD) costs a few
     // scratch spills but keeps the VALU busy (measured: see DESIGN.md §5)
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
-    static constexpr bool kHasForce = true;
+    static constexpr bool kHasForce = false;
     int32_t id;
     real P[6];
-    real qm;     // q (or q/μ): Lorentz force on a charged test particle; Kerr-Newman only
     GR_DEV void load(const gr_config& c)
     {
         id = c.metric_id;
 #pragma unroll
         for (int i = 0; i < 6; ++i) P[i] = c.params[i];
-        const double amu = c.mu < 0.0 ? -c.mu : c.mu;
-        qm = (id == GR_METRIC_KERR_NEWMAN) ? (real)(amu < 1.4901161193847656e-08 ? c.q : c.q / c.mu) : (real)0.0;
-    }
-
-    // q F^μ_κ v^κ, F = g⁻¹(∂A - ∂Aᵀ) (tracing/utility.jl:89-99), A = (rQ/Σ)(1, 0, 0, -a sin²θ)
-    // (kerr-newman-ad.jl:29-33), added to the acceleration as in kerr-newman-ad.jl:66-100.
-    // Hand-differentiated: with p = rQ/Σ, p_r = Q(Σ - 2r²)/Σ², p_θ = 2a² rQ sinθ cosθ/Σ².
-    GR_DEV void add_force(real r, real s, real c, const real gi[5], real vt, real vr, real vh, real vp,
-                          real& at, real& ar, real& ah, real& ap) const
-    {
-        if (qm == 0.0) return;
-        const real a = P[1], Q = P[2];
-        const real r2 = r * r, s2 = s * s, sc = s * c;
-        const real Sig = GR_FMA(a * a, c * c, r2);
-        const real iSig = rcp_full(Sig);
-        const real p = r * Q * iSig;
-        const real p_r = Q * (Sig - 2.0 * r2) * iSig * iSig;
-        const real p_t = 2.0 * a * a * sc * p * iSig;
-        const real Ap_r = -a * s2 * p_r;
-        const real Ap_t = -a * (2.0 * sc * p + s2 * p_t);
-        const real wt = p_r * vr + p_t * vh;
-        const real wp = Ap_r * vr + Ap_t * vh;
-        const real wr = -(p_r * vt + Ap_r * vp);
-        const real wh = -(p_t * vt + Ap_t * vp);
-        at += qm * (gi[0] * wt + gi[4] * wp);
-        ar += qm * (gi[1] * wr);
-        ah += qm * (gi[2] * wh);
-        ap += qm * (gi[4] * wt + gi[3] * wp);
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
     static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
@@ -510,25 +527,6 @@ struct GenericMetric {
         g[4] = -((2.0 * M * a) * (s2 * ir));
         (void)c;
     }
-    // __KerrNewmanAD.metric_components, kerr-newman-ad.jl:6-27 ; P = M, a, Q
-    template <class T>
-    GR_DEV void kerr_newman(T r, T s, T c, T g[5]) const
-    {
-        const real M = P[0], a = P[1], Q = P[2];
-        const real a2 = a * a;
-        T r2 = r * r;
-        T ac = a * c;
-        T Sig = r2 + ac * ac;
-        T s2 = s * s;
-        T Del = r2 - (2.0 * M) * r + (a2 + Q * Q);
-        T r2a2 = r2 + a2;
-        T iSig = inv_(Sig);
-        g[0] = (a2 * s2 - Del) * iSig;
-        g[1] = Sig * inv_(Del);
-        g[2] = Sig;
-        g[3] = (s2 * iSig) * (r2a2 * r2a2 - a2 * (s2 * Del));
-        g[4] = (a * (s2 * iSig)) * (Del - r2a2);
-    }
     // __JohannsenPsaltisAD.metric_components, johannsen-psaltis-ad.jl:4-27 ; P = M, a, ϵ3
     template <class T>
     GR_DEV void johannsen_psaltis(T r, T s, T c, T g[5]) const
@@ -586,7 +584,6 @@ struct GenericMetric {
         case GR_METRIC_DILATON_AXION: dilaton_axion<T>(r, s, c, g); break;
         case GR_METRIC_MORRIS_THORNE: morris_thorne<T>(r, s, c, g); break;
         case GR_METRIC_BUMBLEBEE: bumblebee<T>(r, s, c, g); break;
-        case GR_METRIC_KERR_NEWMAN: kerr_newman<T>(r, s, c, g); break;
         case GR_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis<T>(r, s, c, g); break;
         default: johannsen<T>(r, s, c, g); break;
         }

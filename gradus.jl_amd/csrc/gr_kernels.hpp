@@ -262,6 +262,13 @@ inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t 
         if (disc == GR_DISC_DATUM) return launch_tmpl<KerrMetric, GR_DISC_DATUM>(k, p, stream);
         return launch_tmpl<KerrMetric, GR_DISC_NONE>(k, p, stream);
     }
+    if (p.cfg.metric_id == GR_METRIC_KERR_NEWMAN) {
+        if (disc == GR_DISC_THIN) return launch_tmpl<KerrNewmanMetric, GR_DISC_THIN>(k, p, stream);
+        if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<KerrNewmanMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
+        if (disc == GR_DISC_TABULATED) return launch_tmpl<KerrNewmanMetric, GR_DISC_TABULATED>(k, p, stream);
+        if (disc == GR_DISC_DATUM) return launch_tmpl<KerrNewmanMetric, GR_DISC_DATUM>(k, p, stream);
+        return launch_tmpl<KerrNewmanMetric, GR_DISC_NONE>(k, p, stream);
+    }
     if (p.cfg.metric_id == GR_METRIC_JOHANNSEN) {
         if (disc == GR_DISC_THIN) return launch_tmpl<JohannsenMetric, GR_DISC_THIN>(k, p, stream);
         if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<JohannsenMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);

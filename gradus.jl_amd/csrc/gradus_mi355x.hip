@@ -566,6 +566,8 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     const int64_t grid = (n + block - 1) / block;
     if (cfg->metric_id == GR_METRIC_KERR)
         hipLaunchKernelGGL((k_apply_pf<KerrMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
+    else if (cfg->metric_id == GR_METRIC_KERR_NEWMAN)
+        hipLaunchKernelGGL((k_apply_pf<KerrNewmanMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     else if (cfg->metric_id == GR_METRIC_JOHANNSEN)
         hipLaunchKernelGGL((k_apply_pf<JohannsenMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     else
@@ -626,6 +628,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
         else GR_PATH_LAUNCH(M, GR_DISC_NONE);                                                    \
     } while (0)
     if (cfg->metric_id == GR_METRIC_KERR) GR_PATH_BY_DISC(KerrMetric);
+    else if (cfg->metric_id == GR_METRIC_KERR_NEWMAN) GR_PATH_BY_DISC(KerrNewmanMetric);
     else if (cfg->metric_id == GR_METRIC_JOHANNSEN) GR_PATH_BY_DISC(JohannsenMetric);
     else GR_PATH_BY_DISC(GenericMetric);
 #undef GR_PATH_BY_DISC
