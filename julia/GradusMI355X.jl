@@ -130,12 +130,22 @@ A thick disc whose `cross_section` closure cannot cross the ABI (`ThickDisc(f)`,
 sampled on a uniform ρ grid for the device (GR_DISC_TABULATED: linear interpolation, height <= 0 = no
 disc there).  Pass it as the geometry; keep it alive for the duration of the call (it owns the table).
 """
-struct SampledThickDisc{D}
+struct SampledThickDisc{D} <: Gradus.AbstractThickAccretionDisc{Float64}
     disc::D
     ρ_min::Float64
     ρ_max::Float64
     table::Vector{Float64}
 end
+# the same interpolation the device applies, so a CPU ensemble sees the identical surface
+function Gradus.cross_section(d::SampledThickDisc, ρ)
+    (d.ρ_min <= ρ <= d.ρ_max) || return -one(ρ)
+    n = length(d.table)
+    u = (ρ - d.ρ_min) * (n - 1) / (d.ρ_max - d.ρ_min)
+    k = clamp(floor(Int, u), 0, n - 2)
+    w = u - k
+    (1 - w) * d.table[k+1] + w * d.table[k+2]
+end
+Gradus.inner_radius(d::SampledThickDisc) = d.ρ_min
 function SampledThickDisc(d, ρ_min, ρ_max; samples = 16384)
     ρs = range(Float64(ρ_min), Float64(ρ_max), samples)
     SampledThickDisc(d, Float64(ρ_min), Float64(ρ_max), [Float64(Gradus.cross_section(d, ρ)) for ρ in ρs])
