@@ -92,17 +92,31 @@ def _energy_jet(m, r):
     return -ut.v, -ut.d
 
 
+def _energy_values(m, r):
+    """CircularOrbits.energy(m, r) for an array of radii (values only; NaN where no circular orbit exists)."""
+    with np.errstate(all="ignore"):
+        g = [Jet.lift(c) for c in m._components(Jet(r, np.ones_like(r), np.zeros_like(r)), 1.0, 0.0)]
+        gv = [c.v + 0.0 * r for c in g]
+        dg = [c.d + 0.0 * r for c in g]
+        Om = -(dg[4] - np.sqrt(dg[4] * dg[4] - dg[0] * dg[3])) / dg[3]
+        D = gv[0] * gv[3] - gv[4] * gv[4]
+        itt, ipp, itp = gv[3] / D, gv[0] / D, -gv[4] / D
+        A = -(Om * itt - itp)
+        B = Om * itp - ipp
+        den = B * B * itt + 2.0 * A * B * itp + A * A * ipp
+        return B * np.sign(den) * np.sqrt(1.0 / np.abs(den))          # -u_t = -B d,  d = -sign(den)/sqrt|den|
+
+
 def generic_isco(m, max_upper_bound=100.0, step=0.005):
     """isco(m::AbstractStaticAxisSymmetric): find_isco_bounds then a bracketing root find of
-    dE/dr (special-radii.jl:14-60)."""
+    dE/dr (special-radii.jl:14-60).  The downward scan for the bound is evaluated for all radii at once."""
     lower = None
     n = int(math.floor((max_upper_bound - 1.0) / step + 1e-9))
-    for i in range(n + 1):
-        r = max_upper_bound - step * i
-        E, _ = _energy_jet(m, r)
-        if not (E == E) or abs(E) > 1.0:
-            lower = r
-            break
+    rs = max_upper_bound - step * np.arange(n + 1)
+    E = _energy_values(m, rs)
+    bad = ~(E == E) | (np.abs(E) > 1.0)
+    if bad.any():
+        lower = float(rs[int(np.argmax(bad))])
     if lower is None:
         raise RuntimeError("No boundaries for minimization could be determined. It is likely this configuration "
                            "does not have an ISCO solution.")
