@@ -27,7 +27,7 @@ from .rendering import (EndpointRenderCache, apply, impact_axes, prerendergeodes
                         render_into_image, rendergeodesics)
 from .status import StatusCodes
 from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingConfiguration, chart_for_metric,
-                      domain_upper_hemisphere, event_horizon, event_horizon_chart,
+                      domain_upper_hemisphere, event_horizon, event_horizon_chart, is_naked_singularity,
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
                       map_impact_parameters, tracegeodesic_path, tracegeodesic_paths, tracegeodesics, tracing_configuration)
 from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBranches, TransferBranches,
@@ -37,6 +37,9 @@ from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBr
 from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, continuum_time,
                             lag_frequency,
                             lagtransfer, observer_to_disc)
-from .special_radii import generic_isco, interpolate_plunging_velocities, plunging_fourvelocity
+from .special_radii import (CircularOrbits, PlungingInterpolation, generic_isco, interpolate_plunging_velocities,
+                            plunging_fourvelocity)
 
 __all__ = [n for n in dir() if not n.startswith("_")]
+
+interpolate_redshift = ConstPointFunctions.interpolate_redshift

@@ -68,7 +68,11 @@ def _rayset(config, plane, keep):
 
 def lineprofile(bins, ε, m, u, d, method=None, *, λ_max=None, redshift_pf=None, minrₑ=None, maxrₑ=50.0,
                 plane=None, callback="default", ensemble=None, stats=False, **solver_args):
-    """Returns (bins, flux / sum(flux))."""
+    """lineprofile(bins, ε, m, u, d, [method]; ...) -> (bins, normalised flux).  As in the reference
+    (line-profiles.jl:100-119) the default method is TransferFunctionMethod(); BinningMethod() bins the
+    image plane `plane` (fused on the device for a power-law ε)."""
+    if method is None:
+        method = TransferFunctionMethod()
     if isinstance(method, TransferFunctionMethod):
         from .transfer_functions import integrate_lineprofile, transferfunctions
 

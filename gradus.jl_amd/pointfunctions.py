@@ -105,6 +105,18 @@ class ConstPointFunctions:
         return ConstPointFunctions.affine_time() @ ConstPointFunctions.filter_early_term()
 
     @staticmethod
+    def interpolate_redshift(plunging, u=None):
+        """interpolate_redshift(plunging_interpolation, u) (redshift.jl:246-276): Keplerian outside the ISCO,
+        the tabulated plunge inside, for any metric (Kerr included)."""
+        m = plunging.m
+        extra = {"r_isco": m.isco(), "plunge": tuple(plunging)}
+
+        def _host(_m, gp, max_time, **_kw):
+            raise NotImplementedError("redshift is evaluated on the device (gr_apply_pointfunction)")
+
+        return PointFunction(_host, device_pf=GR_PF_REDSHIFT, extra=extra)
+
+    @staticmethod
     def redshift(m: AbstractMetric, u=None, **kw):
         """redshift(::KerrMetric, _) = analytic; other metrics: interpolate_redshift(m, u)."""
         if isinstance(m, KerrMetric):
@@ -112,7 +124,7 @@ class ConstPointFunctions:
         else:
             from .special_radii import interpolate_plunging_velocities
 
-            extra = {"r_isco": m.isco(), "plunge": interpolate_plunging_velocities(m, **kw)}
+            extra = {"r_isco": m.isco(), "plunge": tuple(interpolate_plunging_velocities(m, **kw))}
 
         def _host(_m, gp, max_time, **_kw):
             raise NotImplementedError("redshift is evaluated on the device (gr_apply_pointfunction)")

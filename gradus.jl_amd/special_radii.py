@@ -160,6 +160,76 @@ def plunging_fourvelocity(m, r):
     return np.array([vt, -math.sqrt(abs(nom / (-gv[1]))), 0.0, vp])
 
 
+class PlungingInterpolation:
+    """PlungingInterpolation(m, ...) (orbit-solving.jl:99-131): the tabulated plunge (r, v^t, v^r, v^ϕ) below
+    the ISCO of `m`.  Unpacks like the 4-tuple of arrays it wraps; calling it interpolates linearly."""
+
+    def __init__(self, m, r, vt, vr, vϕ):
+        self.m, self.r, self.vt, self.vr, self.vϕ = m, r, vt, vr, vϕ
+
+    def __iter__(self):
+        return iter((self.r, self.vt, self.vr, self.vϕ))
+
+    def __getitem__(self, i):
+        return (self.r, self.vt, self.vr, self.vϕ)[i]
+
+    def __len__(self):
+        return 4
+
+    def __call__(self, r):
+        from .corona import _nan_linear_interp
+
+        r = np.asarray(r, dtype=np.float64)
+        return np.stack([_nan_linear_interp(self.r, self.vt, r), _nan_linear_interp(self.r, self.vr, r),
+                         np.zeros_like(r), _nan_linear_interp(self.r, self.vϕ, r)], axis=-1)
+
+
+class CircularOrbits:
+    """CircularOrbits.{Ω, energy, angmom, fourvelocity, plunging_fourvelocity} for prograde equatorial orbits
+    of any static axis-symmetric metric (src/orbits/circular-orbits.jl:11-146); radii may be arrays."""
+
+    @staticmethod
+    def _parts(m, r):
+        r = np.asarray(r, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            g = [Jet.lift(c) for c in m._components(Jet(r, np.ones_like(r), np.zeros_like(r)), 1.0, 0.0)]
+            gv = [c.v + 0.0 * r for c in g]
+            dg = [c.d + 0.0 * r for c in g]
+            Om = -(dg[4] - np.sqrt(dg[4] * dg[4] - dg[0] * dg[3])) / dg[3]
+            D = gv[0] * gv[3] - gv[4] * gv[4]
+            itt, ipp, itp = gv[3] / D, gv[0] / D, -gv[4] / D
+            A = -(Om * itt - itp)
+            B = Om * itp - ipp
+            den = B * B * itt + 2.0 * A * B * itp + A * A * ipp
+            d = -np.sign(den) * np.sqrt(1.0 / np.abs(den))
+        return Om, B * d, A * d, (itt, ipp, itp)
+
+    @staticmethod
+    def Ω(m, r):
+        return CircularOrbits._parts(m, r)[0]
+
+    @staticmethod
+    def energy(m, r):
+        return -CircularOrbits._parts(m, r)[1]
+
+    @staticmethod
+    def angmom(m, r):
+        return CircularOrbits._parts(m, r)[2]
+
+    @staticmethod
+    def fourvelocity(m, r):
+        _, ut, up, (itt, ipp, itp) = CircularOrbits._parts(m, r)
+        r = np.asarray(r, dtype=np.float64)
+        out = np.zeros(r.shape + (4,))
+        out[..., 0] = itt * ut + itp * up
+        out[..., 3] = itp * ut + ipp * up
+        return out
+
+    @staticmethod
+    def plunging_fourvelocity(m, r):
+        return plunging_fourvelocity(m, r)
+
+
 def interpolate_plunging_velocities(m, ensemble=None, max_time=50_000.0, reltol=1e-9, δr=None):
     """interpolate_plunging_velocities(m) -> (r, v^t, v^r, v^ϕ) sorted by r with the innermost
     sample dropped (PlungingInterpolation, orbit-solving.jl:99-131,137-167)."""
@@ -173,5 +243,5 @@ def interpolate_plunging_velocities(m, ensemble=None, max_time=50_000.0, reltol=
     path = tracegeodesic_path(m, u, v, (0.0, max_time), μ=1.0, reltol=reltol, chart=chart, ensemble=ensemble)
     r = path.x[:, 1]
     idx = np.argsort(r, kind="stable")[1:]
-    return (np.ascontiguousarray(r[idx]), np.ascontiguousarray(path.v[idx, 0]),
-            np.ascontiguousarray(path.v[idx, 1]), np.ascontiguousarray(path.v[idx, 3]))
+    return PlungingInterpolation(m, np.ascontiguousarray(r[idx]), np.ascontiguousarray(path.v[idx, 0]),
+                                 np.ascontiguousarray(path.v[idx, 1]), np.ascontiguousarray(path.v[idx, 3]))

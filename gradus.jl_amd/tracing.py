@@ -91,6 +91,13 @@ def event_horizon(m: AbstractMetric, *, select=max, resolution: int = 100, θε:
     return rs, θs
 
 
+def is_naked_singularity(m: AbstractMetric, *, resolution: int = 100, θε: float = 1e-7, rmax: float = 5.0):
+    """is_naked_singularity(m; resolution, θε, rmax) (special-radii.jl:135-146): some polar angle has no
+    horizon radius in (0, rmax]."""
+    rs, _ = event_horizon(m, resolution=resolution, θε=θε, rmax=rmax)
+    return bool(np.any(np.isnan(rs)))
+
+
 def event_horizon_chart(m: AbstractMetric, *, outer_radius: float = 12000.0, closest_approach: float = 1.01, **kwargs):
     rs, θs = event_horizon(m, **kwargs)
     return PoloidalShapeChart(np.ascontiguousarray(rs * closest_approach), float(θs[0]), float(θs[-1]), outer_radius)

@@ -37,7 +37,7 @@ bins = np.linspace(0.1, 1.5, 180)
 
 
 def c5():
-    return G.lineprofile(bins, G.PowerLawEmissivity(3), m, u5, G.ThinDisc(m.isco(), 250.0), plane=plane, ensemble=ens,
+    return G.lineprofile(bins, G.PowerLawEmissivity(3), m, u5, G.ThinDisc(m.isco(), 250.0), G.BinningMethod(), plane=plane, ensemble=ens,
                          stats=True)[2]["kernel_ms"]
 
 

@@ -669,7 +669,7 @@ def test_lds_staging_is_transparent(G, ens):
     ys = []
     for lds in (1, 0):
         ens.set("lds", lds)
-        ys.append(G.lineprofile(bins, G.PowerLawEmissivity(3), mk, u, G.ThinDisc(mk.isco(), 250.0), plane=plane,
+        ys.append(G.lineprofile(bins, G.PowerLawEmissivity(3), mk, u, G.ThinDisc(mk.isco(), 250.0), G.BinningMethod(), plane=plane,
                                 ensemble=ens)[1])
     ens.set("lds", 1)
     np.testing.assert_allclose(ys[0], ys[1], rtol=1e-12, atol=1e-18)
