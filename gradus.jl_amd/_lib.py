@@ -100,6 +100,7 @@ class gr_rayset(C.Structure):
         ("beta", C.c_void_p),
         ("area", C.c_void_p),
         ("n", C.c_int64),
+        ("height", C.c_void_p),
     ]
 
 
@@ -174,6 +175,8 @@ EXPORTS = [
     "gr_redshift_radius",
     "gr_ray_summary_device",
     "gr_ray_summary",
+    "gr_rayset_endpoints_device",
+    "gr_rayset_endpoints",
     "gr_apply_pointfunction_device",
     "gr_apply_pointfunction",
 ]
@@ -214,6 +217,8 @@ def load():
     L.gr_redshift_radius.argtypes = [vp, cfgp, rsp, pfp, C.c_double, C.c_double, vp, stp]
     L.gr_ray_summary_device.argtypes = [vp, cfgp, rsp, pfp, vp, vp, vp]
     L.gr_ray_summary.argtypes = [vp, cfgp, rsp, pfp, vp, stp]
+    L.gr_rayset_endpoints_device.argtypes = [vp, cfgp, rsp, vp, vp, vp]
+    L.gr_rayset_endpoints.argtypes = [vp, cfgp, rsp, vp, stp]
     L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]
     L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
     for name in EXPORTS:

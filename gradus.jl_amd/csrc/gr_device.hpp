@@ -788,6 +788,7 @@ struct Cold {
     const double* alpha;      // device, n
     const double* beta;       // device, n
     const double* area;       // device, n (unnormalized_areas) or null = 1
+    const double* height;     // device, n per-ray DatumPlane heights or null = cfg.disc_params[0]
     // out_mode 2: BinningMethod line profile (line-profiles.jl:152-198) fused into finalize;
     // out_mode 3: (g, ρ) pairs for a host-side emissivity
     double lp_rmin, lp_rmax;  // minrₑ, maxrₑ
@@ -982,15 +983,16 @@ struct Ray {
     int64_t j;          // local (swizzled) ray index
     int32_t status, flags;
     int32_t nacc, nrej;
+    real hdat;          // GR_DISC_DATUM: this ray's plane height (dead in every other instantiation)
 #ifdef GR_HOST_HARNESS
     real dbg_e2;
 #endif
 
     // distance_to_disc(::DatumPlane), datum-plane.jl:6-10 ; distance_to_disc(::ThinDisc), thin-disc.jl:20-26 ; distance_to_disc(::AbstractThickAccretionDisc),
     // thick-disc.jl:60-66 with cross_section(::ShakuraSunyaev), shakura-sunyaev.jl:28-33
-    static GR_DEV real disc_cond(const Params& p, real r, real s, real c)
+    GR_DEV real disc_cond(const Params& p, real r, real s, real c) const
     {
-        if (DISC == GR_DISC_DATUM) return r * c - (real)p.cfg.disc_params[0];   // signed: no underside
+        if (DISC == GR_DISC_DATUM) return r * c - hdat;   // signed: no underside
         const real rho = r * GR_FABS(s);
         if (DISC == GR_DISC_THIN) {
             if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
@@ -1113,6 +1115,11 @@ struct Ray {
         real s, c;
         accel(m, x[1], x[2], v, A[0], s, c);
         sth = s; cth = c;
+        if (DISC == GR_DISC_DATUM) {
+            // datumplane(d, rₑ) (datum-plane.jl:14-17): one plane per ray when the set carries heights
+            const Cold& cd = cold_of(p);
+            hdat = (cd.src_mode == 2 && cd.height) ? (real)cd.height[jl] : (real)p.cfg.disc_params[0];
+        }
         cprev = DISC ? disc_cond(p, x[1], s, c) : 1.0;
 
         const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;

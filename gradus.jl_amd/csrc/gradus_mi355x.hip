@@ -663,6 +663,7 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
     cd.plane.width = rays->n; cd.plane.height = 1;
     cd.range = gr_range{ 0, rays->n, rays->n > 0 ? rays->n : 1, 1 };
     cd.alpha = rays->alpha; cd.beta = rays->beta; cd.area = rays->area;
+    cd.height = cfg->disc_id == GR_DISC_DATUM ? rays->height : nullptr;
     cd.swizzle = 0;
     (void)ctx;
     return GR_OK;
@@ -731,6 +732,24 @@ int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     cd.lp_rmin = 0.0;
     cd.lp_rmax = INFINITY;
     cd.lp_pairs = d_out;
+    p.stats = (unsigned long long*)d_stats;
+    return launch_trace(ctx, p, cd, stream);
+}
+
+int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, gr_point* d_points,
+                                   gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params p;
+    Cold cd;
+    if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
+    if (rays->n > 0 && !d_points) return fail(GR_ERR_INVALID_ARGUMENT, "points is null");
+    cd.out_mode = 1;
+    cd.points = d_points;
     p.stats = (unsigned long long*)d_stats;
     return launch_trace(ctx, p, cd, stream);
 }
@@ -871,7 +890,7 @@ int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_point
     return GR_OK;
 }
 
-// stage a host rayset on the device: alpha | beta | area contiguous in ctx->d_in
+// stage a host rayset on the device: alpha | beta | area | height contiguous in ctx->d_in
 static int32_t stage_rays(gr_ctx* ctx, const gr_rayset* rays, gr_rayset& dev, size_t extra_bytes, void** extra)
 {
     if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
@@ -879,16 +898,18 @@ static int32_t stage_rays(gr_ctx* ctx, const gr_rayset* rays, gr_rayset& dev, si
     if (rays->n > 0 && (!rays->alpha || !rays->beta)) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
     const size_t n = (size_t)rays->n;
     int32_t rc;
-    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 3 * n + extra_bytes + 64)) != GR_OK) return rc;
+    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 4 * n + extra_bytes + 64)) != GR_OK) return rc;
     double* base = (double*)ctx->d_in;
     dev = *rays;
     dev.alpha = base; dev.beta = base + n; dev.area = rays->area ? base + 2 * n : nullptr;
+    dev.height = rays->height ? base + 3 * n : nullptr;
     if (n) {
         GR_HIP(hipMemcpyAsync(base, rays->alpha, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
         GR_HIP(hipMemcpyAsync(base + n, rays->beta, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
         if (rays->area) GR_HIP(hipMemcpyAsync(base + 2 * n, rays->area, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        if (rays->height) GR_HIP(hipMemcpyAsync(base + 3 * n, rays->height, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     }
-    if (extra) *extra = (void*)(base + 3 * n);
+    if (extra) *extra = (void*)(base + 4 * n);
     return GR_OK;
 }
 
@@ -947,6 +968,23 @@ int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
     if ((rc = gr_ray_summary_device(ctx, cfg, &dev, pf, (double*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
                                     ctx->stream)) != GR_OK) return rc;
     if (bytes) GR_HIP(hipMemcpyAsync(out, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
+}
+
+int32_t gr_rayset_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, gr_point* points, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (rays && rays->n > 0 && !points) return fail(GR_ERR_INVALID_ARGUMENT, "points is null");
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    gr_rayset dev;
+    if ((rc = stage_rays(ctx, rays, dev, 0, nullptr)) != GR_OK) return rc;
+    const size_t bytes = sizeof(gr_point) * (size_t)rays->n;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = gr_rayset_endpoints_device(ctx, cfg, &dev, (gr_point*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
+                                         ctx->stream)) != GR_OK) return rc;
+    if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
 }
 

@@ -51,44 +51,62 @@ class CunninghamTransferData:
 SUMMARY_DTYPE = np.dtype([("status", np.int32), ("x", np.float64, (4,))])
 
 
-def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, **solver_opts):
-    """(α, β) arrays -> (ray summaries, g): every ray against DatumPlane(0) on the device.  One launch
-    (`gr_ray_summary`: impact parameters in, 32 B per ray out -- g, ρ, t, status); the summaries are
-    presented with the `status` / `x` fields of end-point records (x = (t, ρ, π/2, 0)) that the solvers read."""
+def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, callback=None, **solver_opts):
+    """(α, β[, heights]) arrays -> (ray summaries, g): every ray against `geometry` (default
+    DatumPlane(0); with `heights`, one DatumPlane per ray -- datumplane(d, rₑ), datum-plane.jl:14-17)
+    on the device.  One launch (`gr_ray_summary`: impact parameters in, 32 B per ray out -- g, ρ, t,
+    status); the summaries are presented with the `status` / `x` fields of end-point records
+    (x = (t, ρ, π/2, 0)) that the solvers read.  `trace.endpoints(α, β[, heights])` returns the full
+    152-B GeodesicPoint records of the same rays (`gr_rayset_endpoints`)."""
     import ctypes as C
 
     from . import _lib
-    from .lineprofiles import _rayset
     from .rendering import abi_pointfunction
 
-    plane = DatumPlane(0.0)
-    config = tracing_configuration(m, x, np.zeros((1, 4)), plane, max_time, chart=chart, ensemble=ensemble, **solver_opts)
+    plane = DatumPlane(0.0) if geometry is None else geometry
+    config = tracing_configuration(m, x, np.zeros((1, 4)), plane, max_time, chart=chart, ensemble=ensemble,
+                                   callback=callback, **solver_opts)
     cfg = config.abi_config()
     pf, keep_pf = abi_pointfunction(redshift_pf)
     L = _lib.load()
-    Mx = None
+    from .tracing import lnr_momentum_to_global_velocity_matrix
 
-    def trace(α, β):
-        nonlocal Mx
+    Mx = lnr_momentum_to_global_velocity_matrix(m, config.position)
+
+    def rayset(α, β, heights):
         α = np.ascontiguousarray(α, dtype=np.float64)
         β = np.ascontiguousarray(β, dtype=np.float64)
         rs = _lib.gr_rayset()
-        if Mx is None:
-            from .tracing import lnr_momentum_to_global_velocity_matrix
-
-            Mx = lnr_momentum_to_global_velocity_matrix(m, config.position)
         for i in range(4):
             rs.x_obs[i] = float(config.position[i])
             for k in range(4):
                 rs.Mx[4 * i + k] = float(Mx[i, k])
         rs.alpha, rs.beta, rs.area, rs.n = α.ctypes.data, β.ctypes.data, None, α.size
-        out = np.zeros((α.size, 4))
+        keep = (α, β)
+        if heights is not None:
+            if not isinstance(plane, DatumPlane):
+                raise ValueError("per-ray heights need a DatumPlane")
+            h = np.ascontiguousarray(np.broadcast_to(heights, α.shape), dtype=np.float64)
+            rs.height = h.ctypes.data
+            keep += (h,)
+        return rs, keep
+
+    def trace(α, β, heights=None):
+        rs, keep = rayset(α, β, heights)
+        out = np.zeros((rs.n, 4))
         _lib.check(L.gr_ray_summary(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, None))
-        pts = np.zeros(α.size, dtype=SUMMARY_DTYPE)
+        pts = np.zeros(rs.n, dtype=SUMMARY_DTYPE)
         pts["status"] = out[:, 3].astype(np.int32)
         pts["x"][:, 0], pts["x"][:, 1], pts["x"][:, 2] = out[:, 2], out[:, 1], math.pi / 2
         return pts, out[:, 0].copy()
 
+    def endpoints(α, β, heights=None):
+        rs, keep = rayset(α, β, heights)
+        pts = np.zeros(rs.n, dtype=_lib.POINT_DTYPE)
+        _lib.check(L.gr_rayset_endpoints(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), pts.ctypes.data, None))
+        return pts
+
+    trace.endpoints = endpoints
     return trace
 
 
@@ -96,7 +114,8 @@ def _rho(pts):
     return pts["x"][:, 1] * np.abs(np.sin(pts["x"][:, 2]))
 
 
-def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zero_atol=1e-7, max_iter=50, eps=1e-5):
+def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zero_atol=1e-7, max_iter=50, eps=1e-5,
+                            heights=None):
     """_find_offset_for_radius (precision-solvers.jl:135-236) for a batch of (r_target, θ) problems.
 
     Safeguarded Newton on y(r) = ρ(r, θ) - r_target, which is monotonic in r: the start
@@ -125,7 +144,10 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
         xa = x[active]
         rr = np.concatenate([xa, xa * (1.0 + eps)])
         tt = np.concatenate([θ[active], θ[active]])
-        pts, g = trace(rr * np.cos(tt) + α0, rr * np.sin(tt) + β0)
+        if heights is None:
+            pts, g = trace(rr * np.cos(tt) + α0, rr * np.sin(tt) + β0)
+        else:       # one datum plane per problem (thick discs: precision-solvers.jl:270-277)
+            pts, g = trace(rr * np.cos(tt) + α0, rr * np.sin(tt) + β0, np.concatenate([heights[active], heights[active]]))
         k = active.size
         if best_pts is None:
             best_pts = np.zeros(n, dtype=pts.dtype)
@@ -144,7 +166,10 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
         y[active] = ya
         conv = polished | (hit & (np.abs(ya) <= 1e-11 * np.maximum(r_target[active], 1.0)))
         # bracket bookkeeping
-        below = (~hit) | (ya < 0.0)
+        # a ray that neither hits nor is captured has left the chart: its offset is too large
+        # (the reference projects such an end point onto the equator and gets y > 0)
+        captured = pts["status"][:k] == StatusCodes.WithinInnerBoundary
+        below = captured | (hit & (ya < 0.0))
         lo[active] = np.where(below, np.maximum(lo[active], xa), lo[active])
         hi[active] = np.where(~below, np.minimum(hi[active], xa), hi[active])
         with np.errstate(all="ignore"):
@@ -201,6 +226,39 @@ class _Workhorse:
         return g, J, pts["x"][:, 0].copy()
 
 
+class _ThickWorkhorse:
+    """_rear_workhorse for a thick disc (cunningham-transfer-functions.jl:253-300) for a batch of
+    (rₑ, θ): the offset is found against datumplane(d, rₑ) -- one plane per problem, all in the same
+    launches --, the ray is re-traced against the disc itself for 1.1 λ_max, and a point whose
+    re-trace ends elsewhere (status differs or !isapprox(x, x_thick, rtol = 1e-3)) is obscured: its
+    Jacobian is NaN.  Visible points get the Jacobian against the thick surface under
+    `domain_upper_hemisphere()` (precision-solvers.jl:401-451)."""
+
+    def __init__(self, datum_trace, thick_trace, jac_trace, d, r_min, setup):
+        self.datum, self.thick, self.jac, self.d = datum_trace, thick_trace, jac_trace, d
+        self.r_min, self.s = r_min, setup
+
+    def __call__(self, rₑ, θ):
+        s = self.s
+        rₑ, θ = np.asarray(rₑ, dtype=np.float64), np.asarray(θ, dtype=np.float64)
+        h = np.array([float(self.d.cross_section(float(r))) for r in rₑ])
+        r, _, g = find_offsets_for_radius(self.datum, rₑ, θ, r_min=self.r_min, α0=s["α0"], β0=s["β0"],
+                                          zero_atol=s["zero_atol"], heights=h)
+        if np.any(np.isnan(r)):
+            k = int(np.nonzero(np.isnan(r))[0][0])
+            raise RuntimeError(f"Transfer function integration failed (rₑ={rₑ[k]}, θ={θ[k]}).")
+        α, β = r * np.cos(θ) + s["α0"], r * np.sin(θ) + s["β0"]
+        gp = self.datum.endpoints(α, β, h)
+        gp_thick = self.thick.endpoints(α, β)
+        # the re-trace runs to 1.1 λ_max only: a later hit would have been left at NoStatus
+        same = (gp_thick["status"] == gp["status"]) & (gp_thick["lambda_max"] <= 1.1 * gp["lambda_max"])
+        dx = np.linalg.norm(gp["x"] - gp_thick["x"], axis=1)
+        close = dx <= 1e-3 * np.maximum(np.linalg.norm(gp["x"], axis=1), np.linalg.norm(gp_thick["x"], axis=1))
+        J = jacobians(self.jac, r, θ, α0=s["α0"], β0=s["β0"])
+        visible = same & close & np.isfinite(J)
+        return g, np.where(visible, J, np.nan), gp["x"][:, 0].copy()
+
+
 def _golden_section_batch(f, lower, upper, iterations):
     """Optim.optimize(f, lower, upper, GoldenSection(); iterations) for a batch of independent
     one-dimensional problems advanced in lock-step; `f(θ_array)` evaluates all of them at once.
@@ -236,14 +294,15 @@ def _check_gmin_gmax(gmin, gmax, gs):
 
 def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offset=0.3, zero_atol=1e-7, α0=0.0, β0=0.0,
                                   chart=None, max_time=None, redshift_pf=None, ensemble=None, tracer=None,
-                                  **solver_opts):
+                                  thick_tracers=None, **solver_opts):
     """cunningham_transfer_function (cunningham-transfer-functions.jl:337-387) for every emission
     radius of `radii` at once.  Returns a list of CunninghamTransferData.
 
     `tracer` replaces the device tracer by another `(α, β) -> (points, g)` callable (the CPU tests
     use it to drive this host logic with oracle-traced rays); the default traces on the MI355X."""
-    if not isinstance(d, (ThinDisc, DatumPlane)):
-        raise NotImplementedError("transfer functions are implemented for thin discs (datum plane at z = 0)")
+    thick = hasattr(d, "cross_section")
+    if not thick and not isinstance(d, (ThinDisc, DatumPlane)):
+        raise NotImplementedError(f"transfer functions: no implementation for {type(d).__name__}")
     x = np.asarray(x, dtype=np.float64)
     radii = np.atleast_1d(np.asarray(radii, dtype=np.float64))
     max_time = 2.0 * x[1] if max_time is None else max_time
@@ -253,7 +312,16 @@ def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offs
             redshift_pf = ConstPointFunctions.redshift(m, x, **({"ensemble": ensemble} if m.metric_id != 0 else {}))
         tracer = device_tracer(m, x, max_time, chart, redshift_pf, ensemble, **solver_opts)
     setup = dict(α0=float(α0), β0=float(β0), zero_atol=float(zero_atol))
-    work = _Workhorse(tracer, m.inner_radius(), setup)
+    if thick:
+        from .tracing import domain_upper_hemisphere
+
+        if thick_tracers is None:
+            mk = lambda geometry, callback: device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=geometry,
+                                                          callback=callback, **solver_opts)
+            thick_tracers = (mk(d, None), mk(d, domain_upper_hemisphere()))
+        work = _ThickWorkhorse(tracer, thick_tracers[0], thick_tracers[1], d, m.inner_radius(), setup)
+    else:
+        work = _Workhorse(tracer, m.inner_radius(), setup)
 
     R = radii.size
     M = N + 2 * N_extrema

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GR_ABI_VERSION 1
+#define GR_ABI_VERSION 2
 
 typedef enum {
     GR_OK = 0,
@@ -277,6 +277,10 @@ typedef struct gr_rayset {
     const double* beta;       /* n impact parameters β                                     */
     const double* area;       /* n unnormalized_areas(plane), or NULL for 1                */
     int64_t n;
+    const double* height;     /* GR_DISC_DATUM only: n plane heights, one DatumPlane per ray
+                                 (datumplane(d, rₑ), datum-plane.jl:14-17: what the thick-disc
+                                 transfer-function solvers trace against, one plane per emission
+                                 radius), or NULL for cfg->disc_params[0]                   */
 } gr_rayset;
 
 typedef struct gr_binning {
@@ -313,6 +317,15 @@ int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
                               void* hip_stream);
 int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
                        const gr_pointfunction* pf, double* out /* host, n x 4 */, gr_stats* stats);
+
+/* ---- end points of an impact-parameter ray set: tracegeodesics(m, x, i -> map_impact_parameters(m, x,
+ * α[i], β[i]), d, ...; ensemble = EnsembleEndpointThreads()) as impact_parameters_for_radius_obscured
+ * (src/tracing/precision-solvers.jl:363-372) and the thick-disc transfer-function workhorse
+ * (src/transfer-functions/cunningham-transfer-functions.jl:253-300) call it. ---- */
+int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                                   gr_point* d_points /* n */, gr_stats* d_stats, void* hip_stream);
+int32_t gr_rayset_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                            gr_point* points /* host, n */, gr_stats* stats);
 
 /* ---- apply(pf, cache): evaluate a built-in point function on endpoint records
  * (point-functions.jl:98-101, rendering.jl:103-107) ---- */

@@ -1079,3 +1079,76 @@ def test_ray_summary_equals_endpoints_plus_redshift(G, ens):
     np.testing.assert_allclose(pts["x"][hit, 1], ref["x"][hit, 1] * np.abs(np.sin(ref["x"][hit, 2])), rtol=1e-7)
     np.testing.assert_allclose(g[hit], gref[hit], rtol=1e-7)
     assert np.all(np.isnan(g[~hit]))
+
+
+def test_rayset_endpoints_with_one_datum_plane_per_ray(G, oracle, ens):
+    """gr_rayset_endpoints with gr_rayset.height: every ray against its own DatumPlane (datumplane(d, rₑ),
+    datum-plane.jl:14-17) in one launch == the oracle run once per plane; without heights == the
+    plane of the configuration; and the summaries of the same rays carry the same (ρ, t, status)."""
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.9)
+    x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+    rng = np.random.default_rng(5)
+    n = 600
+    al, be = rng.uniform(-25, 25, n), rng.uniform(-20, 20, n)
+    hs = rng.choice([0.0, 0.4, 1.1, 2.5], n)
+    pf = G.ConstPointFunctions.redshift(m, x)
+    trace = device_tracer(m, x, 2000.0, G.chart_for_metric(m, 2000.0), pf, ens)
+    got = trace.endpoints(al, be, hs)
+    for h in np.unique(hs):
+        I = hs == h
+        ocfg = oracle.make_config("kerr", (1.0, 0.9), disc={"datum": float(h)}, lambda_max=2000.0, outer_radius=2000.0)
+        ref = oracle.trace(ocfg, x, oracle.map_impact_parameters(ocfg, x, al[I], be[I]))
+        _compare_points(G, oracle, got[I], ref, median=1e-10)
+        hit = got["status"][I] == 2
+        z = got["x"][I][hit, 1] * np.cos(got["x"][I][hit, 2])
+        assert hit.sum() > 50 and np.all(np.abs(z - h) < 1e-7)
+    plain = trace.endpoints(al, be)
+    zero = trace.endpoints(al, be, np.zeros(n))
+    assert plain.tobytes() == zero.tobytes()
+    summ, g = trace(al, be, hs)
+    np.testing.assert_array_equal(summ["status"], got["status"])
+    np.testing.assert_allclose(summ["x"][:, 0], got["x"][:, 0], rtol=1e-13)
+    np.testing.assert_allclose(summ["x"][:, 1], got["x"][:, 1] * np.abs(np.sin(got["x"][:, 2])), rtol=1e-13)
+    # empty set
+    assert trace.endpoints(np.zeros(0), np.zeros(0), np.zeros(0)).size == 0
+
+
+def test_thick_disc_transfer_functions_on_device(G, oracle, ens):
+    """test/transfer-functions/test-thick-disc.jl through the device tracer: the datum-plane offsets
+    (one plane per emission radius), the visibility re-trace against the ShakuraSunyaev surface and the
+    thick-surface Jacobians, several radii in the same launches.  Recorded sums to the 1-2 % their
+    extremal samples allow (see tests/test_transfer_functions_host.py); the well-conditioned samples
+    agree with the same host logic driven by oracle-traced rays."""
+    import sys, os
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_transfer_functions_host import thick_oracle_tracers
+
+    ens.set("kernel", 2).set("precision", 64)
+    for a, angle, r_e, edd, gold, tol in ((0.998, 75, 3.0, 0.3, 14.64279128586961, 1.5e-2),
+                                          (0.2, 20, 5.469668466100368, 0.2, 21.581370829241525, 1.8e-2)):
+        m = G.KerrMetric(1.0, a)
+        x = np.array([0.0, 10_000.0, math.radians(angle), 0.0])
+        d = G.ShakuraSunyaev.for_metric(m, eddington_ratio=edd)
+        tf = G.cunningham_transfer_function(m, x, d, r_e, β0=2.0, ensemble=ens)
+        assert float(np.nansum(tf.f)) == pytest.approx(gold, rel=tol)
+        datum, thick, jac = thick_oracle_tracers(G, oracle, m, a, x, d, 2 * x[1])
+        ref = G.transfer_functions.cunningham_transfer_functions(m, x, d, [r_e], tracer=datum, thick_tracers=(thick, jac), β0=2.0)[0]
+        assert tf.gmin == pytest.approx(ref.gmin, rel=1e-7) and tf.gmax == pytest.approx(ref.gmax, rel=1e-7)
+        core = np.isfinite(ref.f) & (ref.g_star > 1e-3) & (ref.g_star < 1 - 1e-3)
+        assert core.sum() > 70 and np.array_equal(np.isfinite(tf.f)[core], np.isfinite(ref.f)[core])
+        np.testing.assert_allclose(tf.g_star[core], ref.g_star[core], atol=1e-6)
+        np.testing.assert_allclose(tf.f[core], ref.f[core], rtol=2e-3)
+    # a table of radii in one batch: same values as one at a time
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 10_000.0, math.radians(60), 0.0])
+    d = G.ShakuraSunyaev.for_metric(m)
+    radii = [3.0, 6.0, 12.0, 40.0]
+    table = G.cunningham_transfer_functions(m, x, d, radii, β0=1.0, ensemble=ens)
+    single = G.cunningham_transfer_function(m, x, d, 12.0, β0=1.0, ensemble=ens)
+    core = np.isfinite(single.f) & (single.g_star > 1e-3) & (single.g_star < 1 - 1e-3)
+    np.testing.assert_allclose(table[2].f[core], single.f[core], rtol=1e-6)
+    assert all(np.isfinite(c.f).sum() > 60 for c in table)

