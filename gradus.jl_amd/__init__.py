@@ -37,6 +37,8 @@ from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBr
 from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, continuum_time,
                             lag_frequency,
                             lagtransfer, observer_to_disc)
+from .precision_solvers import (find_offset_for_radius, impact_parameters_for_radius, impact_parameters_for_radius_obscured,
+                                impact_parameters_for_target, jacobian_αβ_gr, optimize_for_target)
 from .special_radii import (CircularOrbits, PlungingInterpolation, generic_isco, interpolate_plunging_velocities,
                             plunging_fourvelocity)
 

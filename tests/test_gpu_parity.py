@@ -1152,3 +1152,53 @@ def test_thick_disc_transfer_functions_on_device(G, oracle, ens):
     core = np.isfinite(single.f) & (single.g_star > 1e-3) & (single.g_star < 1 - 1e-3)
     np.testing.assert_allclose(table[2].f[core], single.f[core], rtol=1e-6)
     assert all(np.isfinite(c.f).sum() > 60 for c in table)
+
+
+def test_precision_solvers_on_device(G, ens):
+    """src/tracing/precision-solvers.jl on the device tracer: the recorded impact parameters of
+    test/integration/test-precision.jl (rtol 1e-3 there), rings of impact parameters for a radius, and
+    the obscured variant for a thick disc."""
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(M=1.0, a=1.0)
+    u = np.array([0.0, 1000.0, math.pi / 2, 0.0])
+    α, β, acc = G.impact_parameters_for_target(np.array([10.0, 0.005, 0.0]), m, u, ensemble=ens)
+    # the reference's Nelder-Mead stops 4.6e-3 away from this target (its recorded `accuracy`), so its
+    # (α, β) are only good to about that: |α| itself is 4e-3.  The ray found here passes through the target.
+    assert acc < 1e-6
+    assert α == pytest.approx(-0.004013630261097743, abs=4.6e-3) and β == pytest.approx(10.969606493445841, rel=2e-3)
+    target = np.array([10.0, math.radians(40), -math.pi / 4])
+    α, β, gp, acc = G.optimize_for_target(target, m, u, ensemble=ens)
+    assert α == pytest.approx(4.848373364532467, rel=1e-3) and β == pytest.approx(8.02066263349774, rel=1e-3)
+    assert gp["x"][0] == pytest.approx(1005.2700874611182, rel=1e-3) and acc < 1e-6
+    np.testing.assert_allclose(gp["x"][1:3], target[:2], rtol=1e-6)
+    assert math.remainder(gp["x"][3] - target[2], 2 * math.pi) == pytest.approx(0.0, abs=1e-6)
+
+    # a ring on a thin disc: every ray lands on the radius asked for
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+    d = G.ThinDisc(0.0, float("inf"))
+    a, b = G.impact_parameters_for_radius(m, x, d, 8.0, N=64, ensemble=ens)
+    assert np.all(np.isfinite(a)) and a[0] == pytest.approx(a[-1], abs=1e-9)
+    pts = G.tracegeodesics(m, x, G.map_impact_parameters(m, x, a, b), G.DatumPlane(0.0), 2000.0, ensemble=ens)
+    assert np.all(pts["status"] == 2)
+    np.testing.assert_allclose(pts["x"][:, 1] * np.sin(pts["x"][:, 2]), 8.0, atol=2e-7)
+    assert G.find_offset_for_radius(m, x, d, 8.0, 0.3, ensemble=ens) == pytest.approx(float(np.hypot(a[3], b[3])), rel=0.2)
+    J = G.jacobian_αβ_gr(m, x, d, a[5], b[5], ensemble=ens)
+    assert np.isfinite(J) and J > 0
+
+    # thick disc: the far side of an inner ring is hidden behind the disc at high inclination
+    ss = G.ShakuraSunyaev.for_metric(m, eddington_ratio=0.3)
+    x = np.array([0.0, 1000.0, math.radians(80), 0.0])
+    # (the ring's image is lifted off the image-plane origin by the plane's height: centre the angles on β₀ as
+    # the reference's thick-disc tests do)
+    a0, b0 = G.impact_parameters_for_radius(m, x, ss, 4.0, N=90, β0=2.0, ensemble=ens)
+    a1, b1 = G.impact_parameters_for_radius_obscured(m, x, ss, 4.0, N=90, β0=2.0, ensemble=ens)
+    vis = np.isfinite(a1)
+    print("ring:", np.isfinite(a0).sum(), "offsets,", vis.sum(), "visible")
+    assert np.isfinite(a0).sum() > 80 and 10 < vis.sum() < np.isfinite(a0).sum()
+    np.testing.assert_array_equal(a1[vis], a0[vis])
+    # the visible rays end on the disc surface at the ring's radius and height
+    pts = G.tracegeodesics(m, x, G.map_impact_parameters(m, x, a1[vis], b1[vis]), ss, 2000.0, ensemble=ens)
+    ρ = pts["x"][:, 1] * np.sin(pts["x"][:, 2])
+    np.testing.assert_allclose(ρ, 4.0, atol=1e-5)
+    np.testing.assert_allclose(pts["x"][:, 1] * np.cos(pts["x"][:, 2]), ss.cross_section(4.0), atol=1e-5)

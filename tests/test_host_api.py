@@ -129,3 +129,17 @@ def test_pointfunction_composition(G):
     custom = G.PointFunction(lambda m, gp, t, **kw: gp["x"][1]) @ CPF.filter_intersected()
     assert not custom.fusable
     assert math.isnan(custom(None, gp, 10.0))
+
+
+def test_thick_disc_surface_vectors():
+    """test/discs/test-geometry.jl: unit tangent of the ShakuraSunyaev surface (atol 1e-5 there)."""
+    import gradus_jl_amd as G
+    from gradus_jl_amd.precision_solvers import _cartesian_surface_normal, _cartesian_tangent_vector
+
+    m = G.KerrMetric(1.0, 0.9)
+    d = G.ShakuraSunyaev.for_metric(m)
+    np.testing.assert_allclose(_cartesian_tangent_vector(d, 2.6), [0.689693957000099, 0.0, 0.724100991352412], atol=1e-5)
+    np.testing.assert_allclose(_cartesian_tangent_vector(d, 6.6), [0.9679192396299138, 0.0, 0.2512615083021063], atol=1e-5)
+    np.testing.assert_allclose(_cartesian_tangent_vector(d, 1.0), [1, 0, 0], atol=1e-5)
+    n = _cartesian_surface_normal(d, 2.6)
+    assert abs(float(n @ _cartesian_tangent_vector(d, 2.6))) < 1e-12 and n[2] > 0
