@@ -17,8 +17,8 @@ from .distributed import gather_buffers, gather_image, gather_image_async, shard
 from .geometry import DatumPlane, ShakuraSunyaev, ThickDisc, ThinDisc
 from .polish_doughnut import PolishDoughnut
 from .lineprofiles import BinningMethod, PowerLawEmissivity, TransferFunctionMethod, bucket_simple, lineprofile
-from .metrics import (BumblebeeMetric, DilatonAxion, JohannsenMetric, JohannsenPsaltisMetric, KerrMetric, KerrNewmanMetric,
-                      MorrisThorneWormhole, inner_radius, isco)
+from .metrics import (BumblebeeMetric, DilatonAxion, JohannsenMetric, JohannsenPsaltisMetric, KerrDarkMatter, KerrMetric,
+                      KerrNewmanMetric, KerrRefractive, MorrisThorneWormhole, NoZMetric, SphericalMetric, inner_radius, isco)
 from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix
 from .planes import (CartesianPlane, GeometricGrid, InverseGrid, LinearGrid, PolarPlane, image_plane,
                      impact_parameters, trajectory_count, unnormalized_areas)

@@ -41,6 +41,7 @@ typedef float gr_real_t;
 #define GR_FLOOR __builtin_floorf
 #define GR_SQRT __builtin_sqrtf
 #define GR_POW ::powf
+#define GR_ATAN ::atanf
 #define GR_EPS 1.1920929e-07f
 #else
 typedef double gr_real_t;
@@ -52,6 +53,7 @@ typedef double gr_real_t;
 #define GR_FLOOR __builtin_floor
 #define GR_SQRT __builtin_sqrt
 #define GR_POW ::pow
+#define GR_ATAN ::atan
 #define GR_EPS 2.220446049250313e-16
 #endif
 
@@ -469,6 +471,14 @@ struct GenericMetric {
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
     static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
+    static GR_DEV real val_(real x) { return x; }
+    static GR_DEV real val_(Dual2 x) { return x.v; }
+    static GR_DEV real atan_(real x) { return GR_ATAN(x); }
+    static GR_DEV Dual2 atan_(Dual2 x)
+    {
+        const real w = rcp_full(GR_FMA(x.v, x.v, 1.0));
+        return { GR_ATAN(x.v), w * x.a, w * x.b };
+    }
 
     // __JohannsenAD.metric_components, johannsen-ad.jl:12-34 ; P = M, a, α13, α22, α52, ϵ3
     template <class T>
@@ -577,10 +587,104 @@ struct GenericMetric {
         g[4] = -((a * (del - Delh * W)) * (s2 * iSigh));
     }
 
+    // SphericalMetric (flat space in spherical coordinates), minkowski.jl:4-13
+    template <class T>
+    GR_DEV void spherical(T r, T s, T c, T g[5]) const
+    {
+        T r2 = r * r;
+        g[0] = (r - r) - 1.0;
+        g[1] = (r - r) + 1.0;
+        g[2] = r2;
+        g[3] = r2 * (s * s);
+        g[4] = r - r;
+        (void)c;
+    }
+    // __KerrDarkMatter.metric_components, kerr-dark-matter.jl:6-49 ; P = M_bh, a, M_dm, Δr, rₛ: Kerr with
+    // the mass M_bh + M_dm G((r - rₛ)/Δr), G(x) = (3 - 2x) x², switched on between rₛ and rₛ + Δr
+    template <class T>
+    GR_DEV void kerr_dark_matter(T r, T s, T c, T g[5]) const
+    {
+        const real Mbh = P[0], a = P[1], Mdm = P[2], dR = P[3], rs = P[4];
+        const real a2 = a * a;
+        const real rv = val_(r);
+        T M = (r - r) + Mbh;
+        if (rv >= rs + dR) {
+            M = M + Mdm;
+        } else if (rv >= rs) {
+            T dr = (r - rs) * rcp_full(dR);
+            M = M + Mdm * ((3.0 - 2.0 * dr) * (dr * dr));
+        }
+        T R = 2.0 * M;
+        T s2 = s * s;
+        T r2 = r * r;
+        T Sig = r2 + a2 * (1.0 - s2);
+        T iSig = inv_(Sig);
+        T Rr = R * r;
+        g[0] = -(1.0 - Rr * iSig);
+        g[1] = Sig * inv_(r2 + a2 - Rr);
+        g[2] = Sig;
+        g[3] = s2 * (r2 + a2 + (a2 * (s2 * Rr)) * iSig);
+        g[4] = -((a * (Rr * s2)) * iSig);
+        (void)c;
+    }
+    // __KerrRefractiveAD.metric_components, kerr-refractive-ad.jl:8-33 ; P = M, a, n, corona_radius: Kerr
+    // with tt / n², tϕ / n inside the corona; the boundary is the smooth step of utils.jl:158-168
+    // (δx = 2.5, atan(1e4 t)/π), whose gradient the rays must see
+    template <class T>
+    GR_DEV void kerr_refractive(T r, T s, T c, T g[5]) const
+    {
+        const real M = P[0], a = P[1], n0 = P[2], rc = P[3];
+        const real a2 = a * a, R = 2.0 * M;
+        T r2 = r * r;
+        T Sig = r2 + a2 * (c * c);
+        T iSig = inv_(Sig);
+        T s2 = s * s;
+        T Rr = R * r;
+        const real rv = val_(r);
+        T t = (r - r) + ((rv <= rc - 1.25) ? 1.0 : 0.0);
+        if (rv > rc - 1.25 && rv <= rc + 1.25)
+            t = 0.5 - 0.3183098861837907 * atan_(1e4 * ((r - rc) * 0.4));
+        T n = t + n0 * (1.0 - t);
+        T in = inv_(n);
+        g[0] = -(1.0 - Rr * iSig) * (in * in);
+        g[1] = Sig * inv_(r2 - Rr + a2);
+        g[2] = Sig;
+        g[3] = s2 * (r2 + a2 + (a2 * (s2 * Rr)) * iSig);
+        g[4] = -((a * (Rr * s2)) * iSig) * in;
+    }
+    // __NoZMetric.metric_components, noz-metric.jl:7-47 ; P = M, a, ϵ (y = cosθ; the θθ component carries
+    // the dy² = sin²θ dθ² factor as written there)
+    template <class T>
+    GR_DEV void noz(T r, T s, T y, T g[5]) const
+    {
+        const real M = P[0], a = P[1], e = P[2];
+        const real a2 = a * a;
+        T s2 = s * s;
+        T y2 = y * y;
+        T eps = (e * M * a) * y;
+        T r2 = r * r;
+        T a2y2 = a2 * y2;
+        T S = r2 + a2y2;
+        T tMr = (2.0 * M) * r;
+        T iD = inv_(S * S + (r2 - tMr + a2y2) * eps);
+        T Se = S + eps;
+        T omy2 = 1.0 - y2;
+        T big = r2 * r2 + (a2 * a2) * y2 + r2 * (a2 + a2y2 + eps) + a2 * eps + tMr * (a2 - a2y2 - eps);
+        g[0] = (tMr * S) * iD - 1.0;
+        g[1] = Se * inv_(r2 - tMr + a2);
+        g[2] = (Se * inv_(omy2)) * s2;
+        g[3] = ((omy2 * Se) * big) * iD;
+        g[4] = -(((a * tMr) * (omy2 * Se)) * iD);
+    }
+
     template <class T>
     GR_DEV void components(T r, T s, T c, T g[5]) const
     {
         switch (id) {
+        case GR_METRIC_SPHERICAL: spherical<T>(r, s, c, g); break;
+        case GR_METRIC_KERR_DARK_MATTER: kerr_dark_matter<T>(r, s, c, g); break;
+        case GR_METRIC_KERR_REFRACTIVE: kerr_refractive<T>(r, s, c, g); break;
+        case GR_METRIC_NOZ: noz<T>(r, s, c, g); break;
         case GR_METRIC_DILATON_AXION: dilaton_axion<T>(r, s, c, g); break;
         case GR_METRIC_MORRIS_THORNE: morris_thorne<T>(r, s, c, g); break;
         case GR_METRIC_BUMBLEBEE: bumblebee<T>(r, s, c, g); break;

@@ -104,7 +104,7 @@ int32_t ensure(void** buf, size_t* cap, size_t need)
 int32_t validate_cfg(const gr_config* cfg)
 {
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
-    if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_DILATON_AXION)
+    if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_NOZ)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
     if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_DATUM)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));

@@ -17,6 +17,7 @@ import numpy as np
 GR_METRIC_KERR, GR_METRIC_JOHANNSEN = 0, 1
 GR_METRIC_MORRIS_THORNE, GR_METRIC_BUMBLEBEE, GR_METRIC_KERR_NEWMAN, GR_METRIC_JOHANNSEN_PSALTIS = 2, 3, 4, 5
 GR_METRIC_DILATON_AXION = 6
+GR_METRIC_SPHERICAL, GR_METRIC_KERR_DARK_MATTER, GR_METRIC_KERR_REFRACTIVE, GR_METRIC_NOZ = 7, 8, 9, 10
 
 
 class AbstractMetric:
@@ -305,6 +306,163 @@ class DilatonAxion(AbstractStaticAxisSymmetric):
         from .special_radii import generic_isco
 
         return generic_isco(self)
+
+
+def _where(cond, a, b):
+    """a where cond else b, for floats, arrays and Jets of either (piecewise metric functions)."""
+    from .special_radii import Jet
+
+    if isinstance(a, Jet) or isinstance(b, Jet):
+        a, b = Jet.lift(a), Jet.lift(b)
+        return Jet(np.where(cond, a.v, b.v) + 0.0, np.where(cond, a.d, b.d) + 0.0, np.where(cond, a.dd, b.dd) + 0.0)
+    out = np.where(cond, a, b)
+    return float(out) if np.ndim(out) == 0 else out
+
+
+def _value(x):
+    return x.v if hasattr(x, "dd") else x
+
+
+@dataclass(frozen=True)
+class SphericalMetric(AbstractStaticAxisSymmetric):
+    """SphericalMetric(): flat space in spherical coordinates -- src/metrics/minkowski.jl:1-15."""
+
+    metric_id = GR_METRIC_SPHERICAL
+
+    def abi_params(self):
+        return []
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        return (-1.0 + 0.0 * r, 1.0 + 0.0 * r, r * r, r * r * (s * s), 0.0 * r)
+
+    def inner_radius(self):
+        return 4.0 * float(np.finfo(np.float64).eps)
+
+    def isco(self):
+        return 0.0
+
+
+@dataclass(frozen=True)
+class KerrDarkMatter(AbstractStaticAxisSymmetric):
+    """KerrDarkMatter(M, a, M_dark_matter, Δr, rₛ) -- src/metrics/kerr-dark-matter.jl:6-70 (arXiv:2003.06829):
+    the Kerr metric with the mass M + M_dark_matter G((r - rₛ)/Δr) enclosed at radius r."""
+
+    M: float = 1.0
+    a: float = 0.0
+    M_dark_matter: float = 2.0
+    Δr: float = 20.0
+    rₛ: float = 10.0
+    metric_id = GR_METRIC_KERR_DARK_MATTER
+
+    def abi_params(self):
+        return [self.M, self.a, self.M_dark_matter, self.Δr, self.rₛ]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        a = self.a
+        rv = _value(r)
+        dr = (r - self.rₛ) / self.Δr
+        G = (3.0 - 2.0 * dr) * (dr * dr)
+        Mdm = _where(rv < self.rₛ, 0.0 * r, _where(rv < self.rₛ + self.Δr, self.M_dark_matter * G, self.M_dark_matter + 0.0 * r))
+        R = 2.0 * (self.M + Mdm)
+        s2 = s * s
+        Sig = r * r + a * a * (1.0 - s2)
+        Rr = R * r
+        return (-(1.0 - Rr / Sig), Sig / (r * r + a * a - Rr), Sig, s2 * (r * r + a * a + (a * a * s2) * Rr / Sig),
+                -(a * Rr * s2) / Sig)
+
+    def inner_radius(self):
+        return self.M + math.sqrt(self.M ** 2 - self.a ** 2)
+
+    def isco(self):
+        from .special_radii import generic_isco
+
+        return generic_isco(self)
+
+
+def _smooth_interpolate(x, x0, δx=2.5, smoothing_offset=1e4):
+    """utils.jl:158-168"""
+    if x <= x0 - δx / 2:
+        return 1.0
+    if x <= x0 + δx / 2:
+        return 1.0 - (math.atan(smoothing_offset * (x - x0) / δx) / math.pi + 0.5)
+    return 0.0
+
+
+@dataclass(frozen=True)
+class KerrRefractive(AbstractStaticAxisSymmetric):
+    """KerrRefractive(M, a, n, corona_radius) -- src/metrics/kerr-refractive-ad.jl:8-64: Kerr with a
+    path-length ansatz equivalent to a refractive index n inside the corona radius."""
+
+    M: float = 1.0
+    a: float = 0.0
+    n: float = 1.0
+    corona_radius: float = 20.0
+    metric_id = GR_METRIC_KERR_REFRACTIVE
+
+    def abi_params(self):
+        return [self.M, self.a, self.n, self.corona_radius]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, c):
+        a = self.a
+        R = 2.0 * self.M
+        Sig = r * r + a * a * (c * c)
+        s2 = s * s
+        t = _smooth_interpolate(float(_value(r)), self.corona_radius)
+        n = t + (1.0 - t) * self.n
+        return (-(1.0 - R * r / Sig) / (n * n), Sig / (r * r - R * r + a * a), Sig,
+                s2 * (r * r + a * a + (s2 * R * r * a * a) / Sig), (-(R * r * a * s2) / Sig) / n)
+
+    def inner_radius(self):
+        return self.M + math.sqrt(self.M ** 2 - self.a ** 2)
+
+    def isco(self):
+        return kerr_isco(self.M, self.a)                 # kerr-refractive-ad.jl:61
+
+
+@dataclass(frozen=True)
+class NoZMetric(AbstractStaticAxisSymmetric):
+    """NoZMetric(M, a, ϵ) -- src/metrics/noz-metric.jl:7-66 (a Kerr deformation without reflection symmetry
+    about the equatorial plane).  Circular orbits leave the plane θ = π/2 there, so its `isco` and circular
+    velocities (noz-metric.jl:68-120) are not provided; tracing and every geometric callback work."""
+
+    M: float = 1.0
+    a: float = 0.0
+    ϵ: float = 0.0
+    metric_id = GR_METRIC_NOZ
+
+    def abi_params(self):
+        return [self.M, self.a, self.ϵ]
+
+    def metric_components(self, r, theta):
+        return self._components(r, math.sin(theta), math.cos(theta))
+
+    def _components(self, r, s, y):
+        M, a = self.M, self.a
+        a2 = a * a
+        s2, y2 = s * s, y * y
+        eps = self.ϵ * M * a * y
+        S = r * r + a2 * y2
+        tMr = 2.0 * M * r
+        D = S * S + (r * r - tMr + a2 * y2) * eps
+        Se = S + eps
+        big = r ** 4 + a2 * a2 * y2 + r * r * (a2 + a2 * y2 + eps) + a2 * eps + tMr * (a2 - a2 * y2 - eps)
+        return (-1.0 + tMr * S / D, Se / (r * r - tMr + a2), (Se / (1.0 - y2)) * s2, (1.0 - y2) * Se * big / D,
+                -(tMr * a * (1.0 - y2) * Se) / D)
+
+    def inner_radius(self):
+        return self.M + math.sqrt(self.M ** 2 - self.a ** 2)
+
+    def isco(self):
+        raise NotImplementedError("NoZMetric: circular orbits leave the equatorial plane (noz-metric.jl:68-120)")
 
 
 def kerr_isco(M, a):

@@ -63,7 +63,11 @@ enum {
     GR_METRIC_BUMBLEBEE = 3,
     GR_METRIC_KERR_NEWMAN = 4,
     GR_METRIC_JOHANNSEN_PSALTIS = 5,
-    GR_METRIC_DILATON_AXION = 6        /* DilatonAxion(M, a, β, b) src/metrics/dilaton-axion-ad.jl:49-70 */
+    GR_METRIC_DILATON_AXION = 6,       /* DilatonAxion(M, a, β, b) src/metrics/dilaton-axion-ad.jl:49-70 */
+    GR_METRIC_SPHERICAL = 7,           /* SphericalMetric() (flat space) src/metrics/minkowski.jl:1-15; no params */
+    GR_METRIC_KERR_DARK_MATTER = 8,    /* KerrDarkMatter(M, a, M_dark_matter, Δr, rₛ) src/metrics/kerr-dark-matter.jl:6-70 */
+    GR_METRIC_KERR_REFRACTIVE = 9,     /* KerrRefractive(M, a, n, corona_radius) src/metrics/kerr-refractive-ad.jl:8-58 */
+    GR_METRIC_NOZ = 10                 /* NoZMetric(M, a, ϵ) src/metrics/noz-metric.jl:7-66 */
 };
 
 /* accretion geometry

@@ -114,6 +114,10 @@ _metric(m::BumblebeeMetric) = (Int32(3), (m.M, m.a, m.l, 0.0, 0.0, 0.0, 0.0, 0.0
 _metric(m::KerrNewmanMetric) = (Int32(4), (m.M, m.a, m.Q, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m::JohannsenPsaltisMetric) = (Int32(5), (m.M, m.a, m.ϵ3, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m::DilatonAxion) = (Int32(6), (m.M, m.a, m.β, m.b, 0.0, 0.0, 0.0, 0.0))
+_metric(m::Gradus.SphericalMetric) = (Int32(7), (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+_metric(m::KerrDarkMatter) = (Int32(8), (m.M, m.a, m.M_dark_matter, m.Δr, m.rₛ, 0.0, 0.0, 0.0))
+_metric(m::KerrRefractive) = (Int32(9), (m.M, m.a, m.n, m.corona_radius, 0.0, 0.0, 0.0, 0.0))
+_metric(m::NoZMetric) = (Int32(10), (m.M, m.a, m.ϵ, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m) = error("GradusMI355X: metric $(typeof(m)) has no device implementation; use a CPU ensemble")
 
 # (disc_id, disc_r_in, disc_r_out, disc_params)

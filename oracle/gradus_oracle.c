@@ -41,7 +41,11 @@ static inline d2 d2_div(d2 x, d2 y)
 static inline d2 d2_sin(d2 x) { double s = sin(x.v), c = cos(x.v); d2 r = { s, c * x.a, c * x.b }; return r; }
 static inline d2 d2_cos(d2 x) { double s = sin(x.v), c = cos(x.v); d2 r = { c, -s * x.a, -s * x.b }; return r; }
 
+static inline d2 d2_atan(d2 x) { double w = 1.0 / (1.0 + x.v * x.v); d2 r = { atan(x.v), w * x.a, w * x.b }; return r; }
+
 #define NUM d2
+#define N_ATAN d2_atan
+#define N_VAL(x) ((x).v)
 #define FN(name) name##_d2
 #define N_CONST d2_const
 #define N_ADD d2_add
@@ -64,6 +68,8 @@ static inline d2 d2_cos(d2 x) { double s = sin(x.v), c = cos(x.v); d2 r = { c, -
 #undef N_NEG
 #undef N_SIN
 #undef N_COS
+#undef N_ATAN
+#undef N_VAL
 
 /* Second-order jet in one variable (r) at fixed θ: value, d/dr, d²/dr².  Needed only for
  * the generic ISCO condition dE/dr = 0 (special-radii.jl:20-23), where the reference nests
@@ -90,7 +96,16 @@ static inline j2 j2_div(j2 x, j2 y) { return j2_mul(x, j2_inv(y)); }
 static inline j2 j2_sin(j2 x) { return j2_const(sin(x.v)); }
 static inline j2 j2_cos(j2 x) { return j2_const(cos(x.v)); }
 
+static inline j2 j2_atan(j2 x)
+{
+    double w = 1.0 / (1.0 + x.v * x.v);
+    j2 r = { atan(x.v), w * x.d, w * x.dd - 2.0 * x.v * x.d * x.d * w * w };
+    return r;
+}
+
 #define NUM j2
+#define N_ATAN j2_atan
+#define N_VAL(x) ((x).v)
 #define FN(name) name##_j2
 #define N_CONST j2_const
 #define N_ADD j2_add
@@ -113,6 +128,8 @@ static inline j2 j2_cos(j2 x) { return j2_const(cos(x.v)); }
 #undef N_NEG
 #undef N_SIN
 #undef N_COS
+#undef N_ATAN
+#undef N_VAL
 
 /* ------------------------------------------------------------------------------------
  * metric_jacobian, auto-diff.jl:206-211
@@ -127,6 +144,10 @@ static void metric_d2(const orc_config* c, double r, double th, d2 g[5])
     case ORC_METRIC_KERR_NEWMAN: kerr_newman_components_d2(c->params, rr, tt, g); break;
     case ORC_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis_components_d2(c->params, rr, tt, g); break;
     case ORC_METRIC_DILATON_AXION: dilaton_axion_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_SPHERICAL: spherical_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_KERR_DARK_MATTER: kerr_dark_matter_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_KERR_REFRACTIVE: kerr_refractive_components_d2(c->params, rr, tt, g); break;
+    case ORC_METRIC_NOZ: noz_components_d2(c->params, rr, tt, g); break;
     default: kerr_components_d2(c->params, rr, tt, g);
     }
 }
@@ -840,6 +861,10 @@ static void energy_jet(const orc_config* c, double r, double* E, double* dE)
     case ORC_METRIC_KERR_NEWMAN: kerr_newman_components_j2(c->params, rr, th, g); break;
     case ORC_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis_components_j2(c->params, rr, th, g); break;
     case ORC_METRIC_DILATON_AXION: dilaton_axion_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_SPHERICAL: spherical_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_KERR_DARK_MATTER: kerr_dark_matter_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_KERR_REFRACTIVE: kerr_refractive_components_j2(c->params, rr, th, g); break;
+    case ORC_METRIC_NOZ: noz_components_j2(c->params, rr, th, g); break;
     default: kerr_components_j2(c->params, rr, th, g);
     }
     /* first-order duals in r: metric g = (v,d); its r-derivative ∂g = (d,dd) */

@@ -40,7 +40,8 @@ enum {
 };
 
 enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE = 2, ORC_METRIC_BUMBLEBEE = 3,
-       ORC_METRIC_KERR_NEWMAN = 4, ORC_METRIC_JOHANNSEN_PSALTIS = 5, ORC_METRIC_DILATON_AXION = 6 };
+       ORC_METRIC_KERR_NEWMAN = 4, ORC_METRIC_JOHANNSEN_PSALTIS = 5, ORC_METRIC_DILATON_AXION = 6,
+       ORC_METRIC_SPHERICAL = 7, ORC_METRIC_KERR_DARK_MATTER = 8, ORC_METRIC_KERR_REFRACTIVE = 9, ORC_METRIC_NOZ = 10 };
 /* TABULATED mirrors the product's sampled ThickDisc; TORUS is the closure `_thick_disc` of the
  * reference's own smoke test (test/smoke-tests/rendergeodesics.jl:7-14) restated exactly, used to
  * pin the thick-disc golden value. */

@@ -10,7 +10,8 @@
  *   FN(name)            name mangler
  *   N_CONST(x)          lift a double
  *   N_ADD N_SUB N_MUL N_DIV (NUM,NUM)->NUM ; N_SCALE(double,NUM) ; N_NEG(NUM)
- *   N_SIN(NUM) N_COS(NUM)
+ *   N_SIN(NUM) N_COS(NUM) N_ATAN(NUM)
+ *   N_VAL(NUM)          the value as a double (for the piecewise definitions)
  */
 
 /* __BoyerLindquistAD.metric_components, src/metrics/kerr-metric.jl:11-28 */
@@ -166,4 +167,110 @@ static void FN(dilaton_axion_components)(const double* p, NUM r, NUM th, NUM g[5
     g[2] = Sigh;
     g[3] = N_DIV(N_MUL(A, s2), Sigh);
     g[4] = N_NEG(N_DIV(N_MUL(N_SCALE(a, N_SUB(del, N_MUL(Delh, W))), s2), Sigh));
+}
+
+/* SphericalMetric (Minkowski in spherical coordinates), src/metrics/minkowski.jl:4-13 */
+static void FN(spherical_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    (void)p;
+    NUM s = N_SIN(th);
+    NUM r2 = N_MUL(r, r);
+    g[0] = N_CONST(-1.0);
+    g[1] = N_CONST(1.0);
+    g[2] = r2;
+    g[3] = N_MUL(r2, N_MUL(s, s));
+    g[4] = N_CONST(0.0);
+}
+
+/* __KerrDarkMatter.metric_components, src/metrics/kerr-dark-matter.jl:6-49 ; p = M_bh, a, M_dm, Δr, rₛ */
+static void FN(kerr_dark_matter_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double Mbh = p[0], a = p[1], Mdm = p[2], dR = p[3], rs = p[4];
+    NUM M = N_CONST(Mbh);
+    if (N_VAL(r) < rs) {                                   /* dark_matter_mass :15-23 */
+    } else if (N_VAL(r) < rs + dR) {
+        NUM dr = N_DIV(N_SUB(r, N_CONST(rs)), N_CONST(dR));                 /* G :10-13 */
+        NUM G = N_MUL(N_SUB(N_CONST(3.0), N_SCALE(2.0, dr)), N_MUL(dr, dr));
+        M = N_ADD(M, N_SCALE(Mdm, G));
+    } else {
+        M = N_ADD(M, N_CONST(Mdm));
+    }
+    NUM R = N_SCALE(2.0, M);
+    NUM s = N_SIN(th);
+    NUM sin2 = N_MUL(s, s);
+    NUM cos2 = N_SUB(N_CONST(1.0), sin2);
+    NUM r2 = N_MUL(r, r);
+    NUM Sig = N_ADD(r2, N_SCALE(a * a, cos2));
+    NUM Rr = N_MUL(R, r);
+    NUM Delta = N_SUB(N_ADD(r2, N_CONST(a * a)), Rr);
+    g[0] = N_NEG(N_SUB(N_CONST(1.0), N_DIV(Rr, Sig)));
+    g[1] = N_DIV(Sig, Delta);
+    g[2] = Sig;
+    g[3] = N_MUL(sin2, N_ADD(N_ADD(r2, N_CONST(a * a)), N_DIV(N_SCALE(a * a, N_MUL(sin2, Rr)), Sig)));
+    g[4] = N_DIV(N_NEG(N_SCALE(a, N_MUL(Rr, sin2))), Sig);
+}
+
+/* _smooth_interpolate(x, x₀; δx = 2.5, smoothing_offset = 1e4), src/utils.jl:158-168 */
+static NUM FN(smooth_interpolate)(NUM x, double x0)
+{
+    const double dx = 2.5, off = 1e4;
+    if (N_VAL(x) <= x0 - dx / 2) return N_CONST(1.0);
+    if (N_VAL(x) <= x0 + dx / 2) {
+        NUM t = N_DIV(N_SUB(x, N_CONST(x0)), N_CONST(dx));
+        NUM v = N_ADD(N_SCALE(1.0 / M_PI, N_ATAN(N_SCALE(off, t))), N_CONST(0.5));
+        return N_SUB(N_CONST(1.0), v);
+    }
+    return N_CONST(0.0);
+}
+
+/* __KerrRefractiveAD.metric_components, src/metrics/kerr-refractive-ad.jl:8-33 ; p = M, a, n, corona_radius */
+static void FN(kerr_refractive_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1], n0 = p[2], rc = p[3];
+    const double R = 2.0 * M;
+    NUM c = N_COS(th);
+    NUM r2 = N_MUL(r, r);
+    NUM Sig = N_ADD(r2, N_SCALE(a * a, N_MUL(c, c)));
+    NUM s = N_SIN(th);
+    NUM sin2 = N_MUL(s, s);
+    NUM Rr = N_SCALE(R, r);
+    NUM Delta = N_ADD(N_SUB(r2, Rr), N_CONST(a * a));
+    NUM tt = N_NEG(N_SUB(N_CONST(1.0), N_DIV(Rr, Sig)));
+    NUM pp = N_MUL(sin2, N_ADD(N_ADD(r2, N_CONST(a * a)), N_DIV(N_SCALE(a * a, N_MUL(sin2, Rr)), Sig)));
+    NUM tp = N_DIV(N_NEG(N_SCALE(a, N_MUL(Rr, sin2))), Sig);
+    NUM t = FN(smooth_interpolate)(r, rc);
+    NUM n = N_ADD(t, N_SCALE(n0, N_SUB(N_CONST(1.0), t)));               /* n = t + (1 - t) n */
+    g[0] = N_DIV(tt, N_MUL(n, n));
+    g[1] = N_DIV(Sig, Delta);
+    g[2] = Sig;
+    g[3] = pp;
+    g[4] = N_DIV(tp, n);
+}
+
+/* __NoZMetric.metric_components, src/metrics/noz-metric.jl:7-47 ; p = M, a, ϵ */
+static void FN(noz_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    const double M = p[0], a = p[1], e = p[2];
+    NUM s = N_SIN(th);
+    NUM sin2 = N_MUL(s, s);
+    NUM y = N_COS(th);
+    NUM y2 = N_MUL(y, y);
+    NUM eps = N_SCALE(e * M * a, y);                                       /* epsilon :7 */
+    NUM r2 = N_MUL(r, r);
+    NUM a2y2 = N_SCALE(a * a, y2);
+    NUM S = N_ADD(r2, a2y2);                                               /* r² + a²y² */
+    NUM tMr = N_SCALE(2.0 * M, r);
+    NUM D = N_ADD(N_MUL(S, S), N_MUL(N_ADD(N_SUB(r2, tMr), a2y2), eps));   /* common denominator */
+    NUM Se = N_ADD(S, eps);
+    NUM omy2 = N_SUB(N_CONST(1.0), y2);
+    NUM big = N_ADD(N_ADD(N_ADD(N_ADD(N_MUL(r2, r2), N_SCALE(a * a * a * a, y2)),
+                                N_MUL(r2, N_ADD(N_ADD(N_CONST(a * a), a2y2), eps))),
+                          N_SCALE(a * a, eps)),
+                    N_MUL(tMr, N_SUB(N_SUB(N_CONST(a * a), a2y2), eps)));
+    NUM yy = N_DIV(Se, omy2);
+    g[0] = N_ADD(N_CONST(-1.0), N_DIV(N_MUL(tMr, S), D));
+    g[1] = N_DIV(Se, N_ADD(N_SUB(r2, tMr), N_CONST(a * a)));
+    g[2] = N_MUL(yy, sin2);
+    g[3] = N_DIV(N_MUL(N_MUL(omy2, Se), big), D);
+    g[4] = N_NEG(N_DIV(N_MUL(N_SCALE(a, tMr), N_MUL(omy2, Se)), D));
 }

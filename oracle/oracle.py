@@ -18,7 +18,8 @@ _LIB_PATH = os.path.join(_HERE, "libgradus_oracle.so")
 OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 1, 2, 3
 METRIC_KERR, METRIC_JOHANNSEN = 0, 1
 METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "kerr-newman": 4,
-              "johannsen-psaltis": 5, "dilaton-axion": 6}
+              "johannsen-psaltis": 5, "dilaton-axion": 6, "spherical": 7, "kerr-dark-matter": 8,
+              "kerr-refractive": 9, "noz": 10}
 DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS, DISC_DATUM = 0, 1, 2, 3, 4, 5
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
@@ -149,6 +150,8 @@ def metric_inner_radius(metric, params):
         return 0.0                      # morris-thorne-ad.jl:37
     if metric == "kerr-newman":
         return inner_radius(params[0], params[1], params[2])
+    if metric == "spherical":
+        return 4.0 * np.finfo(np.float64).eps          # minkowski.jl:15
     if metric == "dilaton-axion":       # dilaton-axion-ad.jl:72-75
         M, a, be, b = params[:4]
         bb = 0.0 if be == 0.0 else be / b
