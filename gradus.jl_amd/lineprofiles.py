@@ -13,6 +13,7 @@ emissivity vector of test/unit/emissivity.jl:27-48, which goes through the same 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -49,9 +50,29 @@ def bucket_simple(g, f, bins):
     return np.bincount(idx, weights=f, minlength=bins.size)
 
 
+def _tile_order(n_rows, n_cols, tr=8, tc=8):
+    """Permutation of the column-major ray index of an n_rows x n_cols plane that walks it in tr x tc
+    tiles: the 64 rays a wave traces together are then neighbours in BOTH plane coordinates (similar
+    length, same fate), like the 8 x 8 pixel tiles of the render kernels.  A histogram does not care in
+    which order its rays arrive."""
+    if os.environ.get("GRADUS_MI355X_TILE_RAYS", "1") == "0" or n_rows < tr or n_cols < tc:
+        return None
+    R, Cc = (n_rows // tr) * tr, (n_cols // tc) * tc
+    i = np.arange(R, dtype=np.int64).reshape(R // tr, 1, tr, 1)           # [tile row, tile col, row in tile, col in tile]
+    j = np.arange(Cc, dtype=np.int64).reshape(1, Cc // tc, 1, tc)
+    core = np.transpose(i + n_rows * j, (1, 0, 3, 2)).reshape(-1)         # tiles down a column strip, lanes column-major in the tile
+    rest = np.ones(n_rows * n_cols, dtype=bool)
+    rest[core] = False
+    return np.concatenate([core, np.nonzero(rest)[0]])
+
+
 def _rayset(config, plane, keep):
     αs, βs = impact_parameters(plane, config.position)
     areas = np.ascontiguousarray(unnormalized_areas(plane).ravel(order="F"), dtype=np.float64)
+    shape = unnormalized_areas(plane).shape
+    perm = _tile_order(shape[0], shape[1]) if αs.size == shape[0] * shape[1] else None
+    if perm is not None:
+        αs, βs, areas = αs[perm], βs[perm], areas[perm]
     αs = np.ascontiguousarray(αs, dtype=np.float64)
     βs = np.ascontiguousarray(βs, dtype=np.float64)
     keep += [αs, βs, areas]
