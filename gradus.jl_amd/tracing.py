@@ -141,7 +141,10 @@ def map_impact_parameters(m: AbstractMetric, x, α, β):
     if np.ndim(α) == 0 and np.ndim(β) == 0:
         return Mx @ local_momentum(x[1], float(α), float(β))
     αs, βs = np.broadcast_arrays(np.asarray(α, dtype=np.float64), np.asarray(β, dtype=np.float64))
-    return np.stack([Mx @ local_momentum(x[1], a, b) for a, b in zip(αs.ravel(), βs.ravel())])
+    a, b = αs.ravel() / x[1], βs.ravel() / x[1]
+    pr = -1.0 / np.sqrt(1.0 + a * a + b * b)
+    pbar = np.stack([np.ones_like(pr), pr, b * pr, a * pr], axis=1)          # local_momentum, row per ray
+    return pbar @ Mx.T
 
 
 # ---- Gradus.jl:412 / ext/GradusDiffEqGPUExt: the ensemble type selects the backend ----
