@@ -1097,8 +1097,16 @@ struct Ray {
     GR_DEV real disc_cond(const Params& p, real r, real s, real c) const
     {
         if (DISC == GR_DISC_DATUM) return r * c - hdat;   // signed: no underside
+        if (DISC == GR_DISC_ELLIPTICAL) {
+            // distance_to_disc(::EllipticalDisc), geometry/discs.jl:57-72 (the radial test is on r itself there)
+            const real a = p.cfg.disc_params[0], b = p.cfg.disc_params[1];
+            if (a < r || r < (real)p.cfg.disc_r_in) return 1.0;
+            const real q = r * rcp_full(a);
+            const real y = sqrt_fast(GR_FMAX((1.0 - q * q) * b * b, 0.0));
+            return GR_FABS(r * c) - y - p.cfg.gtol * GR_FABS(r);
+        }
         const real rho = r * GR_FABS(s);
-        if (DISC == GR_DISC_THIN) {
+        if (DISC == GR_DISC_THIN || DISC == GR_DISC_PRECESSING_THIN) {
             if (rho < p.cfg.disc_r_in || rho > p.cfg.disc_r_out) return 1.0;
             return r * GR_FABS(c) - p.cfg.gtol * GR_FABS(r);
         }
@@ -1120,6 +1128,20 @@ struct Ray {
         }
         if (height <= 0.0) return 1.0;
         return r * GR_FABS(c) - height;
+    }
+
+    // the geometry condition at a full position: axisymmetric discs ignore ϕ; PrecessingDisc(ThinDisc, β, γ)
+    // (geometry/discs.jl:74-96) rotates the direction by Rx(-β) after shifting ϕ by γ and hands (r, θ') to the
+    // thin disc.  disc_params = {β, γ, cos β, sin β}.
+    GR_DEV real disc_cond4(const Params& p, real r, real s, real c, real phi) const
+    {
+        if (DISC != GR_DISC_PRECESSING_THIN) return disc_cond(p, r, s, c);
+        real sp, cp;
+        sincos_fast(phi - (real)p.cfg.disc_params[1], sp, cp);
+        const real cb = p.cfg.disc_params[2], sb = p.cfg.disc_params[3];
+        const real v1 = s * sp, v2 = s * cp;
+        const real x2 = cb * v2 - sb * c, x3 = sb * v2 + cb * c;     // R = [1 0 0; 0 cβ -sβ; 0 sβ cβ]
+        return disc_cond(p, r, sqrt_fast(GR_FMA(v1, v1, x2 * x2)), x3);
     }
 
     // DiscreteCallbacks in CallbackSet order: domain_upper_hemisphere, then the chart
@@ -1224,7 +1246,7 @@ struct Ray {
             const Cold& cd = cold_of(p);
             hdat = (cd.src_mode == 2 && cd.height) ? (real)cd.height[jl] : (real)p.cfg.disc_params[0];
         }
-        cprev = DISC ? disc_cond(p, x[1], s, c) : 1.0;
+        cprev = DISC ? disc_cond4(p, x[1], s, c, x[3]) : 1.0;
 
         const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
         const real dtmax = GR_FABS((real)(p.cfg.lambda1 - p.cfg.lambda0));
@@ -1371,7 +1393,7 @@ struct Ray {
             if (GR_FABS(tnew - tend) < 100.0 * GR_EPS * GR_FMAX(GR_FABS(tnew), GR_FABS(tend))) tnew = tend;
 
             if (DISC) {
-                const real cnext = disc_cond(p, xn[1], sn, cn);
+                const real cnext = disc_cond4(p, xn[1], sn, cn, xn[3]);
                 const int ps = sgn(cprev);
                 int top = 0;
                 if (ps != 0) {
@@ -1466,7 +1488,7 @@ struct Ray {
             }
             if (!any) return 0;
             dense_coeffs(1, hh, Cr);
-        } else if (DISC == GR_DISC_DATUM) {
+        } else if (DISC == GR_DISC_DATUM || DISC == GR_DISC_PRECESSING_THIN || DISC == GR_DISC_ELLIPTICAL) {
             dense_coeffs(1, hh, Cr);      // no pre-filter: every sample is evaluated
         } else {
             // thick disc of bounded height Hmax: a sample can only be inside if |z| = r |sin d| < Hmax,
@@ -1484,11 +1506,14 @@ struct Ray {
             }
             if (!any) return 0;
         }
+        real Cp[4] = { 0.0, 0.0, 0.0, 0.0 };
+        if (DISC == GR_DISC_PRECESSING_THIN) dense_coeffs(3, hh, Cp);
         for (int jj = 1; jj <= 6; ++jj) {
             const real th = (real)jj / 7.0;
             real s, c;
             sincos_fast(dense_eval(x[2], hh, Ct, th), s, c);
-            const real cj = disc_cond(p, dense_eval(x[1], hh, Cr, th), s, c);
+            const real cj = disc_cond4(p, dense_eval(x[1], hh, Cr, th), s, c,
+                                       DISC == GR_DISC_PRECESSING_THIN ? dense_eval(x[3], hh, Cp, th) : (real)0.0);
             if ((real)ps * cj < 0.0) return jj;
         }
         return 0;
@@ -1498,9 +1523,10 @@ struct Ray {
     // discrete callbacks on it.  Result: final (t, x, v).
     GR_DEV void resolve_event(const Params& p)
     {
-        real Cr[4], Ct[4];
+        real Cr[4], Ct[4], Cp[4] = { 0.0, 0.0, 0.0, 0.0 };
         dense_coeffs(1, h, Cr);
         dense_coeffs(2, h, Ct);
+        if (DISC == GR_DISC_PRECESSING_THIN) dense_coeffs(3, h, Cp);
         const int ps = sgn(cprev);
 #ifdef GR_HOST_HARNESS
         dbg_e2 = 0.0;
@@ -1510,7 +1536,7 @@ struct Ray {
         {
             real s, c;
             sincos_fast(dense_eval(x[2], h, Ct, hi), s, c);
-            fhi = disc_cond(p, dense_eval(x[1], h, Cr, hi), s, c);
+            fhi = disc_cond4(p, dense_eval(x[1], h, Cr, hi), s, c, DISC == GR_DISC_PRECESSING_THIN ? dense_eval(x[3], h, Cp, hi) : (real)0.0);
         }
         real theta = hi;
         if (fhi != 0.0) {
@@ -1532,7 +1558,8 @@ struct Ray {
                 }
                 real s, c;
                 sincos_fast(dense_eval(x[2], h, Ct, mid), s, c);
-                const real fm = disc_cond(p, dense_eval(x[1], h, Cr, mid), s, c);
+                const real fm = disc_cond4(p, dense_eval(x[1], h, Cr, mid), s, c,
+                                           DISC == GR_DISC_PRECESSING_THIN ? dense_eval(x[3], h, Cp, mid) : (real)0.0);
                 if (sgn(fm) == ps) {
                     lo = mid; flo = fm;
                     if (side < 0) fhi *= 0.5;

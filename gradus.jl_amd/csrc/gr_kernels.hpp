@@ -253,13 +253,15 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 
 inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
-    // DISC is the geometry id itself (0 none, 1 ThinDisc, 2 ShakuraSunyaev): compile-time in the kernels
+    // DISC is the geometry id itself (GR_DISC_*): compile-time in the kernels
     const int disc = p.cfg.disc_id;
     if (p.cfg.metric_id == GR_METRIC_KERR) {
         if (disc == GR_DISC_THIN) return launch_tmpl<KerrMetric, GR_DISC_THIN>(k, p, stream);
         if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<KerrMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
         if (disc == GR_DISC_TABULATED) return launch_tmpl<KerrMetric, GR_DISC_TABULATED>(k, p, stream);
         if (disc == GR_DISC_DATUM) return launch_tmpl<KerrMetric, GR_DISC_DATUM>(k, p, stream);
+        if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<KerrMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
+        if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<KerrMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
         return launch_tmpl<KerrMetric, GR_DISC_NONE>(k, p, stream);
     }
     if (p.cfg.metric_id == GR_METRIC_KERR_NEWMAN) {
@@ -267,6 +269,8 @@ inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t 
         if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<KerrNewmanMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
         if (disc == GR_DISC_TABULATED) return launch_tmpl<KerrNewmanMetric, GR_DISC_TABULATED>(k, p, stream);
         if (disc == GR_DISC_DATUM) return launch_tmpl<KerrNewmanMetric, GR_DISC_DATUM>(k, p, stream);
+        if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<KerrNewmanMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
+        if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<KerrNewmanMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
         return launch_tmpl<KerrNewmanMetric, GR_DISC_NONE>(k, p, stream);
     }
     if (p.cfg.metric_id == GR_METRIC_JOHANNSEN) {
@@ -274,12 +278,16 @@ inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t 
         if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<JohannsenMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
         if (disc == GR_DISC_TABULATED) return launch_tmpl<JohannsenMetric, GR_DISC_TABULATED>(k, p, stream);
         if (disc == GR_DISC_DATUM) return launch_tmpl<JohannsenMetric, GR_DISC_DATUM>(k, p, stream);
+        if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<JohannsenMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
+        if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<JohannsenMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
         return launch_tmpl<JohannsenMetric, GR_DISC_NONE>(k, p, stream);
     }
     if (disc == GR_DISC_THIN) return launch_tmpl<GenericMetric, GR_DISC_THIN>(k, p, stream);
     if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<GenericMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
     if (disc == GR_DISC_TABULATED) return launch_tmpl<GenericMetric, GR_DISC_TABULATED>(k, p, stream);
     if (disc == GR_DISC_DATUM) return launch_tmpl<GenericMetric, GR_DISC_DATUM>(k, p, stream);
+    if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<GenericMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
+    if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<GenericMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
     return launch_tmpl<GenericMetric, GR_DISC_NONE>(k, p, stream);
 }
 

@@ -106,7 +106,7 @@ int32_t validate_cfg(const gr_config* cfg)
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
     if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_NOZ)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
-    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_DATUM)
+    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_PRECESSING_THIN)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
     if (!(cfg->abstol > 0.0) || !(cfg->reltol > 0.0))
         return fail(GR_ERR_INVALID_ARGUMENT, "abstol and reltol must be positive");
@@ -625,6 +625,8 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
         else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(M, GR_DISC_SHAKURA_SUNYAEV); \
         else if (cfg->disc_id == GR_DISC_TABULATED) GR_PATH_LAUNCH(M, GR_DISC_TABULATED);        \
         else if (cfg->disc_id == GR_DISC_DATUM) GR_PATH_LAUNCH(M, GR_DISC_DATUM);                \
+        else if (cfg->disc_id == GR_DISC_ELLIPTICAL) GR_PATH_LAUNCH(M, GR_DISC_ELLIPTICAL);      \
+        else if (cfg->disc_id == GR_DISC_PRECESSING_THIN) GR_PATH_LAUNCH(M, GR_DISC_PRECESSING_THIN); \
         else GR_PATH_LAUNCH(M, GR_DISC_NONE);                                                    \
     } while (0)
     if (cfg->metric_id == GR_METRIC_KERR) GR_PATH_BY_DISC(KerrMetric);

@@ -6,6 +6,7 @@ from dataclasses import dataclass
 import numpy as np
 
 GR_DISC_NONE, GR_DISC_THIN, GR_DISC_SHAKURA_SUNYAEV, GR_DISC_TABULATED, GR_DISC_DATUM = 0, 1, 2, 3, 4
+GR_DISC_ELLIPTICAL, GR_DISC_PRECESSING_THIN = 5, 6
 
 
 class AbstractAccretionGeometry:
@@ -29,6 +30,36 @@ class DatumPlane(AbstractAccretionGeometry):
     height: float = 0.0
     disc_id = GR_DISC_DATUM
     inner_radius = 0.0
+
+
+@dataclass(frozen=True)
+class EllipticalDisc(AbstractAccretionGeometry):
+    """EllipticalDisc(inner_radius, semi_major, semi_minor) -- src/geometry/discs.jl:57-72: a disc whose
+    half-thickness follows the ellipse sqrt((1 - (r/semi_major)²) semi_minor²)."""
+
+    inner_radius: float
+    semi_major: float
+    semi_minor: float
+    disc_id = GR_DISC_ELLIPTICAL
+
+
+@dataclass(frozen=True)
+class PrecessingDisc(AbstractAccretionGeometry):
+    """PrecessingDisc(disc, β, γ) -- src/geometry/discs.jl:74-96: `disc` tilted by β about the x axis and turned by γ
+    about the spin axis.  The device implements it around a ThinDisc."""
+
+    disc: ThinDisc
+    β: float
+    γ: float
+    disc_id = GR_DISC_PRECESSING_THIN
+
+    def __post_init__(self):
+        if not isinstance(self.disc, ThinDisc):
+            raise NotImplementedError("PrecessingDisc runs on the device around a ThinDisc")
+
+    @property
+    def inner_radius(self):
+        return self.disc.inner_radius
 
 
 @dataclass(frozen=True)

@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from .geometry import GR_DISC_NONE, AbstractAccretionGeometry, DatumPlane, ShakuraSunyaev, ThickDisc, ThinDisc
+from .geometry import (GR_DISC_NONE, AbstractAccretionGeometry, DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev,
+                       ThickDisc, ThinDisc)
 from .metrics import AbstractMetric
 from .orthonormalization import lnrbasis
 
@@ -248,6 +249,17 @@ class TracingConfiguration:
         elif isinstance(self.geometry, DatumPlane):
             c.disc_id = self.geometry.disc_id
             c.disc_params[0] = float(self.geometry.height)
+        elif isinstance(self.geometry, EllipticalDisc):
+            g = self.geometry
+            c.disc_id = g.disc_id
+            c.disc_r_in, c.disc_r_out = float(g.inner_radius), float("inf")
+            c.disc_params[0], c.disc_params[1] = float(g.semi_major), float(g.semi_minor)
+        elif isinstance(self.geometry, PrecessingDisc):
+            g = self.geometry
+            c.disc_id = g.disc_id
+            c.disc_r_in, c.disc_r_out = float(g.disc.inner_radius), float(g.disc.outer_radius)
+            c.disc_params[0], c.disc_params[1] = float(g.β), float(g.γ)
+            c.disc_params[2], c.disc_params[3] = math.cos(g.β), math.sin(g.β)
         elif isinstance(self.geometry, ShakuraSunyaev):
             c.disc_id = self.geometry.disc_id
             c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float("inf")

@@ -81,8 +81,13 @@ enum {
  *                    linear interpolation, height <= 0 (or ρ outside the grid) = no disc there
  *   DATUM            DatumPlane      src/geometry/discs/datum-plane.jl:1-10: the plane z = r cosθ = height
  *                    (disc_params[0]), signed (no underside), no radial extent; what the transfer-function
- *                    solvers trace against for a thin disc (cunningham-transfer-functions.jl:1-5) */
-enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_TABULATED = 3, GR_DISC_DATUM = 4 };
+ *                    solvers trace against for a thin disc (cunningham-transfer-functions.jl:1-5)
+ *   ELLIPTICAL       EllipticalDisc  src/geometry/discs.jl:57-72: disc_r_in = inner_radius, disc_params = {semi_major,
+ *                    semi_minor}; |z| < sqrt((1 - (r/a)²) b²) + gtol |r| for inner_radius <= r <= semi_major
+ *   PRECESSING_THIN  PrecessingDisc(ThinDisc(r_in, r_out), β, γ)  src/geometry/discs.jl:74-96: the thin disc tilted by β
+ *                    about the x axis and turned by γ about the spin axis; disc_params = {β, γ, cos β, sin β} */
+enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_TABULATED = 3, GR_DISC_DATUM = 4,
+       GR_DISC_ELLIPTICAL = 5, GR_DISC_PRECESSING_THIN = 6 };
 
 /* per-ray anomaly bits written next to the status (SciML retcodes MaxIters /
  * DtLessThanMin / Unstable, which EnsembleEndpointThreads discards, tracing.jl:250) */

@@ -125,6 +125,9 @@ _disc(::Nothing) = (Int32(0), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
 _disc(d::ThinDisc) = (Int32(1), Float64(d.inner_radius), Float64(d.outer_radius), (0.0, 0.0, 0.0, 0.0))
 _disc(d::ShakuraSunyaev) = (Int32(2), Float64(d.inner_radius), Inf, (Float64(d.Ṁ_Ṁedd), Float64(d.inv_η), 0.0, 0.0))
 _disc(d::DatumPlane) = (Int32(4), 0.0, 0.0, (Float64(d.height), 0.0, 0.0, 0.0))
+_disc(d::EllipticalDisc) = (Int32(5), Float64(d.inner_radius), Inf, (Float64(d.semi_major), Float64(d.semi_minor), 0.0, 0.0))
+_disc(d::PrecessingDisc{T,<:ThinDisc}) where {T} =
+    (Int32(6), Float64(d.disc.inner_radius), Float64(d.disc.outer_radius), (Float64(d.β), Float64(d.γ), cos(d.β), sin(d.β)))
 _disc(d) = error("GradusMI355X: geometry $(typeof(d)) has no device implementation; use a CPU ensemble")
 
 """

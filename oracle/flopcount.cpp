@@ -41,6 +41,7 @@ static inline Counted sqrt(Counted a) { ++g_sqrt; return std::sqrt(a.v); }
 static inline Counted cbrt(Counted a) { ++g_trans; return std::cbrt(a.v); }
 static inline Counted sin(Counted a) { ++g_trans; return std::sin(a.v); }
 static inline Counted atan(Counted a) { ++g_trans; return std::atan(a.v); }
+static inline Counted atan2(Counted a, Counted b) { ++g_trans; return std::atan2(a.v, b.v); }
 static inline Counted cos(Counted a) { ++g_trans; return std::cos(a.v); }
 static inline Counted pow(Counted a, Counted b) { ++g_trans; return std::pow(a.v, b.v); }
 static inline Counted log10(Counted a) { ++g_trans; return std::log10(a.v); }

@@ -522,9 +522,28 @@ static double rms8(const double x[8])
  * _equatorial_project / _spinaxis_project utils.jl:146-152 */
 static double disc_condition(const orc_config* c, const double u[8])
 {
-    const double r = u[1], th = u[2];
+    double r = u[1], th = u[2];
     /* distance_to_disc(::DatumPlane), datum-plane.jl:6-10: signed height above the plane */
     if (c->disc_id == ORC_DISC_DATUM) return r * cos(th) - c->disc_params[0];
+    if (c->disc_id == ORC_DISC_ELLIPTICAL) {
+        /* distance_to_disc(::EllipticalDisc), geometry/discs.jl:57-72 (radial test on r = x4[2], as written there);
+         * disc_r_in = inner_radius, disc_params = {semi_major, semi_minor} */
+        const double a = c->disc_params[0], b = c->disc_params[1];
+        if (a < r || r < c->disc_r_in) return 1.0;
+        const double y = sqrt((1.0 - (r / a) * (r / a)) * b * b);
+        return fabs(r * cos(th)) - y - c->gtol * fabs(r);
+    }
+    if (c->disc_id == ORC_DISC_PRECESSING_THIN) {
+        /* distance_to_disc(::PrecessingDisc), geometry/discs.jl:74-96 around a ThinDisc: the position is
+         * rotated by R = Rx(-β) after shifting ϕ by γ, then handed to the inner disc; disc_params = {β, γ} */
+        const double be = c->disc_params[0], ga = c->disc_params[1];
+        const double ph = u[3] - ga;
+        const double v1 = sin(th) * sin(ph), v2 = sin(th) * cos(ph), v3 = cos(th);
+        const double cb = cos(-be), sb = sin(-be);
+        /* SMatrix{3,3}(1,0,0, 0,cos(-β),-sin(-β), 0,sin(-β),cos(-β)) is column-major */
+        const double x1 = v1, x2 = cb * v2 + sb * v3, x3 = -sb * v2 + cb * v3;
+        th = atan2(sqrt(x1 * x1 + x2 * x2), x3);
+    }
     const double rho = r * fabs(sin(th));
     if (c->disc_id == ORC_DISC_TABULATED || c->disc_id == ORC_DISC_TORUS) {
         /* ThickDisc(f): cross_section(d, ρ) = f(ρ), thick-disc.jl:57-66 (inner/outer radius 0/Inf) */

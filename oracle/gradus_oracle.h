@@ -46,7 +46,8 @@ enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE =
  * reference's own smoke test (test/smoke-tests/rendergeodesics.jl:7-14) restated exactly, used to
  * pin the thick-disc golden value. */
 enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1, ORC_DISC_SHAKURA_SUNYAEV = 2, ORC_DISC_TABULATED = 3, ORC_DISC_TORUS = 4,
-       ORC_DISC_DATUM = 5 /* DatumPlane(height = disc_params[0]), datum-plane.jl:1-10 */ };
+       ORC_DISC_DATUM = 5 /* DatumPlane(height = disc_params[0]), datum-plane.jl:1-10 */,
+       ORC_DISC_ELLIPTICAL = 6, ORC_DISC_PRECESSING_THIN = 7 /* geometry/discs.jl:57-96 */ };
 
 /* per-ray anomaly flags (SciML retcodes that EnsembleEndpointThreads swallows) */
 enum { ORC_FLAG_MAXITERS = 1, ORC_FLAG_DTMIN = 2, ORC_FLAG_NAN = 4 };

@@ -21,6 +21,7 @@ METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "ke
               "johannsen-psaltis": 5, "dilaton-axion": 6, "spherical": 7, "kerr-dark-matter": 8,
               "kerr-refractive": 9, "noz": 10}
 DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS, DISC_DATUM = 0, 1, 2, 3, 4, 5
+DISC_ELLIPTICAL, DISC_PRECESSING_THIN = 6, 7
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
 
@@ -189,6 +190,14 @@ def make_config(
     elif isinstance(disc, dict) and "datum" in disc:     # DatumPlane(height)
         c.disc_id = DISC_DATUM
         c.disc_params[0] = float(disc["datum"])
+    elif isinstance(disc, dict) and "ellipse" in disc:   # EllipticalDisc: {"ellipse": (inner_radius, semi_major, semi_minor)}
+        c.disc_id = DISC_ELLIPTICAL
+        c.disc_r_in, c.disc_r_out = float(disc["ellipse"][0]), float("inf")
+        c.disc_params[0], c.disc_params[1] = float(disc["ellipse"][1]), float(disc["ellipse"][2])
+    elif isinstance(disc, dict) and "precessing" in disc:  # PrecessingDisc(ThinDisc(r_in, r_out), β, γ): {"precessing": (r_in, r_out, β, γ)}
+        c.disc_id = DISC_PRECESSING_THIN
+        c.disc_r_in, c.disc_r_out = float(disc["precessing"][0]), float(disc["precessing"][1])
+        c.disc_params[0], c.disc_params[1] = float(disc["precessing"][2]), float(disc["precessing"][3])
     elif isinstance(disc, dict) and "torus" in disc:     # the reference smoke test's ThickDisc closure
         c.disc_id = DISC_TORUS
         c.disc_r_in, c.disc_r_out = 0.0, float("inf")

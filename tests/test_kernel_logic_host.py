@@ -331,3 +331,50 @@ def test_remaining_metrics_reduce_to_kerr_and_flat_space(G, oracle):
     np.testing.assert_allclose(cart(got, "x")[far], end[far], atol=2e-6)
     np.testing.assert_allclose(got["x"][far, 0], got["v_init"][far, 0] * got["lambda_max"][far], rtol=1e-9)
     assert flat.metric_id == 7
+
+
+def _new_disc_cases(G):
+    return [
+        ("ellipse", G.EllipticalDisc(2.0, 30.0, 4.0), {"ellipse": (2.0, 30.0, 4.0)}),
+        ("precessing", G.PrecessingDisc(G.ThinDisc(3.0, 40.0), 0.35, 0.8), {"precessing": (3.0, 40.0, 0.35, 0.8)}),
+    ]
+
+
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("name,params", [("kerr", (1.0, 0.9)), ("johannsen-psaltis", (1.0, 0.5, 0.8))])
+def test_elliptical_and_precessing_discs_kernel_logic(G, oracle, which, name, params):
+    """EllipticalDisc and PrecessingDisc(ThinDisc, β, γ) (src/geometry/discs.jl:57-96; no recorded values in
+    the reference's tests): the device event logic compiled for the host against the oracle."""
+    label, d, od = _new_disc_cases(G)[which]
+    m = _metric_by_name(G, name, params)
+    x = np.array([0.0, 300.0, math.radians(65), 0.0])
+    W = H = 32
+    cfg = G.render_configuration(m, x, d, 700.0, image_width=W, image_height=H, alpha_lims=(-45, 45), beta_lims=(-35, 35))
+    got = Hh.render_endpoints(G, cfg)
+    ocfg = oracle.make_config(name, params, disc=od, lambda_max=700.0)
+    ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-45, 45), (-35, 35), W, H))
+    mism = got["status"] != ref["status"]
+    assert mism.sum() <= 4, label
+    hit = ~mism & (ref["status"] == 2)
+    assert hit.sum() > 150
+    np.testing.assert_allclose(got["lambda_max"][hit], ref["lambda_max"][hit], rtol=1e-6)
+    np.testing.assert_allclose(got["x"][hit], ref["x"][hit], rtol=1e-6, atol=1e-8)
+
+
+def test_precessing_disc_limits(G, oracle):
+    """β = γ = 0 is the thin disc itself; a tilt by β about the x axis leaves the hits on the tilted plane."""
+    m = G.KerrMetric(1.0, 0.0)
+    x = np.array([0.0, 300.0, math.radians(65), 0.0])
+    kw = dict(image_width=24, image_height=24, alpha_lims=(-45, 45), beta_lims=(-35, 35))
+    a = Hh.render_endpoints(G, G.render_configuration(m, x, G.PrecessingDisc(G.ThinDisc(3.0, 40.0), 0.0, 0.0), 700.0, **kw))
+    b = Hh.render_endpoints(G, G.render_configuration(m, x, G.ThinDisc(3.0, 40.0), 700.0, **kw))
+    np.testing.assert_array_equal(a["status"], b["status"])
+    np.testing.assert_allclose(a["x"], b["x"], rtol=1e-9, atol=1e-12)
+    β, γ = 0.4, 0.3
+    c = Hh.render_endpoints(G, G.render_configuration(m, x, G.PrecessingDisc(G.ThinDisc(3.0, 40.0), β, γ), 700.0, gtol=1e-3, **kw))
+    hit = c["status"] == 2
+    assert hit.sum() > 100
+    r, th, ph = c["x"][hit, 1], c["x"][hit, 2], c["x"][hit, 3] - γ
+    v = np.stack([np.sin(th) * np.sin(ph), np.sin(th) * np.cos(ph), np.cos(th)], axis=1)
+    z_disc = math.sin(β) * v[:, 1] + math.cos(β) * v[:, 2]          # third row of Rx(-β): height above the tilted plane / r
+    assert np.max(np.abs(z_disc)) < 1.1e-3
