@@ -94,6 +94,8 @@ mutable struct EnsembleMI355X
     devices::Vector{Int32}
     ctxs::Vector{Ptr{Cvoid}}
     function EnsembleMI355X(devices = [0])
+        abi = ccall((:gr_abi_version, LIB), Int32, ())
+        abi == 2 || error("GradusMI355X: libgradus_mi355x.so has ABI version $abi, this binding is written for 2")
         ctxs = Ptr{Cvoid}[]
         for d in devices
             ref = Ref{Ptr{Cvoid}}(C_NULL)
