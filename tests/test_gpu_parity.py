@@ -1280,3 +1280,30 @@ def test_elliptical_and_precessing_discs_on_device(G, oracle, ens, kernel):
     _, _, img = G.rendergeodesics(m, x, G.PrecessingDisc(G.ThinDisc(m.isco(), 40.0), 0.35, 0.8), 700.0, pf=pf, **kw)
     assert np.isfinite(img).sum() > 600 and 0.2 < np.nanmin(img) and np.nanmax(img) < 1.6
     ens.set("kernel", 2)
+
+
+def test_contexts_release_their_device_memory(G):
+    """gr_ctx_create / gr_ctx_destroy in a loop with calls of growing size in between: the context's staging
+    buffers (scratch, inputs, tables, cold blocks) are freed with it -- free HBM returns to where it was."""
+    import torch
+
+    m = G.KerrMetric(1.0, 0.9)
+    d = G.ThinDisc(m.isco(), 30.0)
+
+    def cycle(size):
+        ens = G.EnsembleMI355X(0)
+        G.prerendergeodesics(m, X_SMOKE, d, 200.0, image_width=size, image_height=size, alpha_lims=(-25, 25),
+                             beta_lims=(-15, 15), ensemble=ens)
+        G.rendergeodesics(G.JohannsenMetric(1.0, 0.5, 0.3, 0.0, 0.0, 0.0), X_SMOKE, d, 200.0, image_width=size,
+                          image_height=size, alpha_lims=(-25, 25), beta_lims=(-15, 15), ensemble=ens)
+        for c in ens.contexts:
+            c.close()
+
+    cycle(64)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for k in range(40):
+        cycle(64 + 16 * (k % 8))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 64 << 20, f"leaked {(free0 - free1) >> 20} MiB over 40 contexts"
