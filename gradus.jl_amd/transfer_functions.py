@@ -1,7 +1,8 @@
 """Cunningham transfer functions on device-traced geodesics (second half).
 
-Mirror of src/transfer-functions/cunningham-transfer-functions.jl:1-387 for discs that the transfer
-function solvers see as a datum plane (ThinDisc -> DatumPlane(0), :1-5), with the precision solvers
+Mirror of src/transfer-functions/cunningham-transfer-functions.jl:1-387: discs that the transfer
+function solvers see as a datum plane (ThinDisc -> DatumPlane(0), :1-5) and thick discs (one datum plane
+per emission radius, visibility re-trace, thick-surface Jacobians, :253-300), with the precision solvers
 of src/tracing/precision-solvers.jl:73-236 (offset for a target radius) and :401-451 (Jacobian).
 
 MI355X-first restructuring.  The reference solves one (rₑ, θ) at a time: a Newton iteration in the
@@ -9,7 +10,7 @@ image-plane offset r, each evaluation one geodesic carried on dual numbers, then
 dual-number geodesic for ∂(ρ, g)/∂(α, β), then a golden-section search in θ for g_min / g_max --
 all serial, threaded over rₑ only.  Here EVERY pending (rₑ, θ) problem of EVERY emission radius
 advances in lock-step: one safeguarded-Newton iteration for the whole batch is one call of
-`gr_trace_endpoints` (two rays per problem: r and r(1+ε), the derivative by differences), the
+`gr_ray_summary` (two rays per problem: r and r(1+ε), the derivative by differences), the
 Jacobians of the whole batch are one call (four rays per problem, central differences) and the
 golden-section searches of all radii and of both extrema share their launches as well.  A table of
 150 radii costs the same ~200 launches as one radius.
@@ -30,8 +31,7 @@ import numpy as np
 from .geometry import DatumPlane, ThinDisc
 from .pointfunctions import ConstPointFunctions
 from .status import StatusCodes
-from .tracing import (chart_for_metric, ensemble_solve_tracing_problem, map_impact_parameters,
-                      tracing_configuration)
+from .tracing import chart_for_metric, tracing_configuration
 
 GOLDEN = 0.5 * (3.0 - math.sqrt(5.0))
 
