@@ -14,7 +14,7 @@ from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGe
                      RandomGenerator, WeierstrassSampler, coordtime_at, emissivity_at, emissivity_profile,
                      energy_ratio, lorentz_factor, sky_angles_to_velocity, tetradframe_matrix, tracecorona)
 from .distributed import gather_buffers, gather_image, gather_image_async, shard_plan
-from .geometry import DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev, ThickDisc, ThinDisc
+from .geometry import DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev, ThickDisc, ThinDisc, WarpedThinDisc
 from .polish_doughnut import PolishDoughnut
 from .lineprofiles import BinningMethod, PowerLawEmissivity, TransferFunctionMethod, bucket_simple, lineprofile
 from .metrics import (BumblebeeMetric, DilatonAxion, JohannsenMetric, JohannsenPsaltisMetric, KerrDarkMatter, KerrMetric,
@@ -37,6 +37,8 @@ from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBr
 from .reverberation import (AnalyticRadialDiscProfile, LagTransferFunction, bin_transfer_function, binflux, continuum_time,
                             lag_frequency,
                             lagtransfer, observer_to_disc)
+from .orbit_solving import (measure_stability, solve_equatorial_circular_orbit, trace_equatorial_circular_orbit,
+                            trace_single_orbit)
 from .precision_solvers import (find_offset_for_radius, impact_parameters_for_radius, impact_parameters_for_radius_obscured,
                                 impact_parameters_for_target, jacobian_αβ_gr, optimize_for_target)
 from .special_radii import (CircularOrbits, PlungingInterpolation, generic_isco, interpolate_plunging_velocities,
@@ -45,3 +47,59 @@ from .special_radii import (CircularOrbits, PlungingInterpolation, generic_isco,
 __all__ = [n for n in dir() if not n.startswith("_")]
 
 interpolate_redshift = ConstPointFunctions.interpolate_redshift
+
+
+# ---- small pieces of the reference's exported surface (src/Gradus.jl exports) ----
+def metric_components(m, rθ):
+    """metric_components(m, rθ): (g_tt, g_rr, g_θθ, g_ϕϕ, g_tϕ)"""
+    return m.metric_components(rθ[0], rθ[1])
+
+
+def cross_section(d, ρ):
+    """cross_section(d::AbstractThickAccretionDisc, ρ) (geometry/discs.jl:27-53)"""
+    return d.cross_section(ρ)
+
+
+def g_to_g_star(g, gmin, gmax):
+    """g_to_g✶ (transfer-functions/utils.jl): (g - gmin) / (gmax - gmin)"""
+    return (g - gmin) / (gmax - gmin)
+
+
+def g_star_to_g(g_star, gmin, gmax):
+    """g✶_to_g: (gmax - gmin) g✶ + gmin"""
+    return (gmax - gmin) * g_star + gmin
+
+
+def minkowski_matrix():
+    """minkowski_matrix() (metrics/minkowski.jl:36-41)"""
+    import numpy as _np
+
+    return _np.diag([-1.0, 1.0, 1.0, 1.0])
+
+
+def spherical_to_cartesian(v):
+    """spherical_to_cartesian((r, θ, ϕ)) -> (x, y, z)"""
+    import numpy as _np
+
+    r, θ, ϕ = v[-3], v[-2], v[-1]
+    return _np.array([r * _np.sin(θ) * _np.cos(ϕ), r * _np.sin(θ) * _np.sin(ϕ), r * _np.cos(θ)])
+
+
+def cartesian_squared_distance(m, x1, x2):
+    """cartesian_squared_distance(m, x1, x2) (geometry/geometry.jl): squared Euclidean distance of two four-positions
+    in the coordinates' own (r, θ, ϕ)"""
+    import numpy as _np
+
+    return float(_np.sum((spherical_to_cartesian(x1) - spherical_to_cartesian(x2)) ** 2))
+
+
+def cartesian_distance(m, x1, x2):
+    return cartesian_squared_distance(m, x1, x2) ** 0.5
+
+
+def unpack_solution(points):
+    """unpack_solution(sol): the device entry points already return GeodesicPoint records."""
+    return points
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]

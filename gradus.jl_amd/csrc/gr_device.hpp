@@ -1121,6 +1121,9 @@ struct Ray {
             if (k > n - 2) k = n - 2;
             const real w = u - (real)k;
             height = (1.0 - w) * (real)p.disc_table[k] + w * (real)p.disc_table[k + 1];
+            // WarpedThinDisc (thin-disc.jl:42-66): the table is the signed height h(ρ) of a thin sheet,
+            // hit from either side within the thin disc's tolerance wedge
+            if (p.cfg.disc_params[3] != 0.0) return GR_FABS(height - r * c) - p.cfg.gtol * GR_FABS(r);
         } else {
             const real rin = p.cfg.disc_r_in;
             if (rho < rin) return 1.0;
@@ -1497,12 +1500,16 @@ struct Ray {
             const real hmax = 1.5707963267948966 * 1.000001
                               * (DISC == GR_DISC_TABULATED ? (real)p.cfg.disc_params[2]
                                                            : 3.0 * (real)p.cfg.disc_params[1] * (real)p.cfg.disc_params[0]);
+            // a warped thin sheet is also hit within gtol |r| of its surface
+            const real warp = (DISC == GR_DISC_TABULATED && p.cfg.disc_params[3] != 0.0)
+                                  ? (real)(1.5707963267948966 * 1.000001) * (real)p.cfg.gtol : (real)0.0;
 #pragma unroll
             for (int jj = 0; jj < 6; ++jj) {
                 const real th = (real)(jj + 1) / 7.0;
                 real d = dense_eval(x[2], hh, Ct, th) - 1.5707963267948966;
                 d -= 3.141592653589793 * GR_RINT(d * 0.3183098861837907);
-                any |= (GR_FABS(d) * GR_FABS(dense_eval(x[1], hh, Cr, th)) < hmax);
+                const real rr = GR_FABS(dense_eval(x[1], hh, Cr, th));
+                any |= (GR_FABS(d) * rr < hmax + warp * rr);
             }
             if (!any) return 0;
         }

@@ -107,3 +107,18 @@ class ThickDisc(AbstractAccretionGeometry):
 
     def cross_section(self, ρ):
         return self.f(ρ)
+
+
+class WarpedThinDisc(AbstractAccretionGeometry):
+    """WarpedThinDisc(f; inner_radius = 0, outer_radius = 500) -- src/geometry/discs/thin-disc.jl:28-66: a thin sheet
+    at the signed height f(ρ) above the equatorial plane.  Like ThickDisc(f), the closure is sampled on a uniform ρ
+    grid by the host (here over [inner_radius, outer_radius]) and interpolated on the device."""
+
+    disc_id = GR_DISC_TABULATED
+
+    def __init__(self, f, *, inner_radius=0.0, outer_radius=500.0, samples=16384):
+        self.f = f
+        self.inner_radius, self.outer_radius = float(inner_radius), float(outer_radius)
+        self.ρ_range = (self.inner_radius, self.outer_radius)
+        ρ = np.linspace(self.ρ_range[0], self.ρ_range[1], int(samples))
+        self.table = np.ascontiguousarray([float(f(r)) for r in ρ], dtype=np.float64)

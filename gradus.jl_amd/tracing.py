@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from .geometry import (GR_DISC_NONE, AbstractAccretionGeometry, DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev,
-                       ThickDisc, ThinDisc)
+                       ThickDisc, ThinDisc, WarpedThinDisc)
 from .metrics import AbstractMetric
 from .orthonormalization import lnrbasis
 
@@ -264,6 +264,13 @@ class TracingConfiguration:
             c.disc_id = self.geometry.disc_id
             c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float("inf")
             c.disc_params[0], c.disc_params[1] = float(self.geometry.Ṁ_Ṁedd), float(self.geometry.inv_η)
+        elif isinstance(self.geometry, WarpedThinDisc):
+            g = self.geometry
+            c.disc_id = g.disc_id
+            c.disc_r_in, c.disc_r_out = g.inner_radius, g.outer_radius
+            c.disc_params[0], c.disc_params[1] = g.ρ_range[0], g.ρ_range[1]
+            c.disc_params[2], c.disc_params[3] = float(np.abs(g.table).max()), 1.0
+            c.disc_table, c.disc_table_n = g.table.ctypes.data, g.table.size     # g keeps the array alive
         elif isinstance(self.geometry, ThickDisc):
             g = self.geometry
             c.disc_id = g.disc_id

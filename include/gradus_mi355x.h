@@ -78,7 +78,10 @@ enum {
  *   TABULATED        ThickDisc(f)    src/geometry/discs/thick-disc.jl:30-66: the user's cross_section
  *                    closure cannot run on the device, so the host samples it on a uniform ρ grid:
  *                    disc_params = {ρ_first, ρ_last, max height}, disc_table[disc_table_n] = f(ρ_k);
- *                    linear interpolation, height <= 0 (or ρ outside the grid) = no disc there
+ *                    linear interpolation, height <= 0 (or ρ outside the grid) = no disc there.
+ *                    disc_params[3] != 0: WarpedThinDisc (thin-disc.jl:42-66) -- the table is the SIGNED height
+ *                    h(ρ) of a thin sheet, |h(ρ) - r cosθ| < gtol |r| within disc_r_in <= ρ <= disc_r_out
+ *                    (disc_params[2] = max |h|)
  *   DATUM            DatumPlane      src/geometry/discs/datum-plane.jl:1-10: the plane z = r cosθ = height
  *                    (disc_params[0]), signed (no underside), no radial extent; what the transfer-function
  *                    solvers trace against for a thin disc (cunningham-transfer-functions.jl:1-5)

@@ -563,6 +563,11 @@ static double disc_condition(const orc_config* c, const double u[8])
                 if (k > n - 2) k = n - 2;
                 const double w = uu - (double)k;
                 height = (1.0 - w) * c->disc_table[k] + w * c->disc_table[k + 1];
+                /* distance_to_disc(::WarpedThinDisc), thin-disc.jl:55-66: the table is the signed height h(ρ) */
+                if (c->disc_id == ORC_DISC_TABULATED && c->disc_params[3] != 0.0) {
+                    if (rho < c->disc_r_in || rho > c->disc_r_out) return 1.0;
+                    return fabs(height - r * cos(th)) - c->gtol * fabs(r);
+                }
             }
         }
         if (height <= 0.0) return 1.0;

@@ -209,6 +209,9 @@ def make_config(
         c.disc_r_in, c.disc_r_out = 0.0, float("inf")
         c.disc_params[0], c.disc_params[1], c.disc_params[2] = float(disc["range"][0]), float(disc["range"][1]), float(tab.max())
         c.disc_table, c.disc_table_n = tab.ctypes.data, tab.size
+        if disc.get("warped"):         # WarpedThinDisc: signed height table over [inner_radius, outer_radius]
+            c.disc_r_in, c.disc_r_out = float(disc["range"][0]), float(disc["range"][1])
+            c.disc_params[2], c.disc_params[3] = float(np.abs(tab).max()), 1.0
     elif isinstance(disc, dict):       # ShakuraSunyaev: {"mdot": Ṁ/Ṁedd, "inv_eta": 1/η, "inner_radius": r_isco}
         c.disc_id = DISC_SHAKURA_SUNYAEV
         c.disc_r_in, c.disc_r_out = float(disc["inner_radius"]), float("inf")

@@ -1307,3 +1307,38 @@ def test_contexts_release_their_device_memory(G):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(0)
     assert free0 - free1 < 64 << 20, f"leaked {(free0 - free1) >> 20} MiB over 40 contexts"
+
+
+def test_warped_thin_disc_on_device(G, oracle, ens):
+    """WarpedThinDisc(f) through the C ABI (tabulated geometry with the signed-height flag) against the oracle."""
+    ens.set("kernel", 2).set("precision", 64)
+    d = G.WarpedThinDisc(lambda ρ: 0.8 * math.sin(ρ / 6.0), inner_radius=3.0, outer_radius=45.0, samples=4096)
+    x = np.array([0.0, 300.0, math.radians(65), 0.0])
+    for name, params in (("kerr", (1.0, 0.9)), ("johannsen", (1.0, 0.6, 0.5, 0.0, 0.0, 0.3))):
+        m = _metric(G, name, params)
+        for kernel in (0, 1):
+            ens.set("kernel", kernel)
+            _, _, cache = G.prerendergeodesics(m, x, d, 700.0, image_width=64, image_height=64, alpha_lims=(-50, 50),
+                                               beta_lims=(-35, 35), ensemble=ens)
+            got = np.ascontiguousarray(cache.points.T).ravel()
+            ocfg = oracle.make_config(name, params, disc={"table": d.table, "range": d.ρ_range, "warped": True}, lambda_max=700.0)
+            ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-50, 50), (-35, 35), 64, 64))
+            _compare_points(G, oracle, got, ref, median=1e-10)
+            assert (got["status"] == 2).sum() > 1200
+    ens.set("kernel", 2)
+
+
+def test_circular_orbits_found_by_tracing(G, ens):
+    """test/smoke-tests/circular-orbits.jl:5-22: Σ vϕ over r = 6:0.5:10 of the orbits found by the OPTIMISER
+    (golden section on the radial excursion of device-traced μ = 1 geodesics, all radii in lock-step) against the
+    recorded values (atol 1e-6 there), and against CircularOrbits' closed form per radius."""
+    ens.set("kernel", 2).set("precision", 64)
+    rs = np.arange(6.0, 10.0 + 1e-9, 0.5)
+    for m, expected in ((G.KerrMetric(M=1.0, a=0.0), 0.5432533297869712), (G.KerrMetric(M=1.0, a=1.0), 0.5016710246454921),
+                        (G.KerrMetric(M=1.0, a=-1.0), 0.5993458160081419),
+                        (G.JohannsenMetric(M=1.0, a=1.0, alpha22=1.0), 0.4980454719932759)):
+        vϕ = G.solve_equatorial_circular_orbit(m, rs, ensemble=ens)
+        assert float(np.sum(vϕ)) == pytest.approx(expected, abs=2e-6)
+        np.testing.assert_allclose(vϕ, G.CircularOrbits.fourvelocity(m, rs)[:, 3], atol=1e-6)
+    path = G.trace_equatorial_circular_orbit(G.KerrMetric(1.0, 0.5), 7.0, ensemble=ens)
+    assert np.ptp(path.x[:, 1]) < 1e-4 and path.x[-1, 3] > 2 * math.pi

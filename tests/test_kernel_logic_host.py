@@ -378,3 +378,32 @@ def test_precessing_disc_limits(G, oracle):
     v = np.stack([np.sin(th) * np.sin(ph), np.sin(th) * np.cos(ph), np.cos(th)], axis=1)
     z_disc = math.sin(β) * v[:, 1] + math.cos(β) * v[:, 2]          # third row of Rx(-β): height above the tilted plane / r
     assert np.max(np.abs(z_disc)) < 1.1e-3
+
+
+def test_warped_thin_disc_kernel_logic(G, oracle):
+    """WarpedThinDisc(f) (src/geometry/discs/thin-disc.jl:28-66): a thin sheet at signed height f(ρ), sampled on a
+    grid by the host -- device event logic compiled for the host against the oracle on the same table; a flat
+    sheet f = 0 is the ThinDisc."""
+    f = lambda ρ: 0.8 * math.sin(ρ / 6.0)
+    d = G.WarpedThinDisc(f, inner_radius=3.0, outer_radius=45.0, samples=4096)
+    m = G.KerrMetric(1.0, 0.9)
+    x = np.array([0.0, 300.0, math.radians(65), 0.0])
+    W = H = 32
+    kw = dict(image_width=W, image_height=H, alpha_lims=(-50, 50), beta_lims=(-35, 35))
+    got = Hh.render_endpoints(G, G.render_configuration(m, x, d, 700.0, **kw))
+    ocfg = oracle.make_config("kerr", (1.0, 0.9), disc={"table": d.table, "range": d.ρ_range, "warped": True}, lambda_max=700.0)
+    ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-50, 50), (-35, 35), W, H))
+    mism = got["status"] != ref["status"]
+    assert mism.sum() <= 4
+    hit = ~mism & (ref["status"] == 2)
+    assert hit.sum() > 300
+    np.testing.assert_allclose(got["x"][hit], ref["x"][hit], rtol=1e-6, atol=1e-8)
+    ρ = got["x"][hit, 1] * np.sin(got["x"][hit, 2])
+    z = got["x"][hit, 1] * np.cos(got["x"][hit, 2])
+    assert np.all(np.abs(z - 0.8 * np.sin(ρ / 6.0)) <= 1e-2 * got["x"][hit, 1] * (1 + 1e-6) + 2e-4)   # inside the gtol wedge of the sheet
+    assert np.all((ρ >= 3.0 - 1e-9) & (ρ <= 45.0 + 1e-9)) and z.min() < -0.3 and z.max() > 0.3
+    flat = Hh.render_endpoints(G, G.render_configuration(m, x, G.WarpedThinDisc(lambda ρ: 0.0, inner_radius=3.0, outer_radius=45.0,
+                                                                                samples=64), 700.0, **kw))
+    thin = Hh.render_endpoints(G, G.render_configuration(m, x, G.ThinDisc(3.0, 45.0), 700.0, **kw))
+    np.testing.assert_array_equal(flat["status"], thin["status"])
+    np.testing.assert_allclose(flat["x"], thin["x"], rtol=1e-9, atol=1e-12)
