@@ -30,7 +30,8 @@ from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingCon
                       domain_upper_hemisphere, event_horizon, event_horizon_chart, is_naked_singularity,
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
                       map_impact_parameters, tracegeodesic_path, tracegeodesic_paths, tracegeodesics, tracing_configuration)
-from .transfer_functions import (CunninghamTransferData, InterpolatingTransferBranches, TransferBranches,
+from .transfer_functions import (CunninghamTransferData, CunninghamTransferGrid, CunninghamTransferTable,
+                                make_transfer_function_table, transfer_function_grid, InterpolatingTransferBranches, TransferBranches,
                                 cunningham_transfer_function, cunningham_transfer_functions, integrate_lagtransfer,
                                 integrate_lineprofile,
                                 interpolate_branches, splitbranches, transferfunctions)

@@ -644,3 +644,91 @@ def integrate_lagtransfer(prof, tfs: InterpolatingTransferBranches, g_grid, t_gr
     if total > 0:
         flux = flux / total
     return flux
+
+
+# ------------------------------------------------------------------------------------------
+# grids and tables of transfer functions (cunningham-transfer-functions.jl:440-530, types.jl:14-130)
+# ------------------------------------------------------------------------------------------
+@dataclass
+class CunninghamTransferGrid:
+    """types.jl:14-44: the branches of every radius resampled on one g✶ grid; matrices are [g✶, r]."""
+
+    r_grid: np.ndarray
+    g_star_grid: np.ndarray
+    g_min: np.ndarray
+    g_max: np.ndarray
+    lower_f: np.ndarray
+    upper_f: np.ndarray
+    lower_time: np.ndarray
+    upper_time: np.ndarray
+
+    def inner_radius(self):
+        return float(self.r_grid[0])
+
+    def outer_radius(self):
+        return float(self.r_grid[-1])
+
+    def fields(self):
+        return (self.r_grid, self.g_star_grid, self.g_min, self.g_max, self.lower_f, self.upper_f, self.lower_time, self.upper_time)
+
+
+def transfer_function_grid(itfs_or_metric, *args, Ng=20, h_grid=1e-3, **kwargs):
+    """transfer_function_grid(itfs, Ng; h) / transfer_function_grid(m, x, d, radii; Ng, h_grid, ...) (:463-501)"""
+    if isinstance(itfs_or_metric, InterpolatingTransferBranches):
+        itfs = itfs_or_metric
+    else:
+        x, d, radii = args
+        itfs = transferfunctions(itfs_or_metric, x, d, radii=radii, **kwargs)
+    gs = np.linspace(0.0, 1.0, int(Ng))
+    gc = np.clip(gs, h_grid, 1.0 - h_grid)
+    col = lambda key_g, key_y: np.stack([_interp(getattr(b, key_g), getattr(b, key_y), gc) for b in itfs.branches], axis=1)
+    return CunninghamTransferGrid(itfs.radii.copy(), gs, itfs.gmin.copy(), itfs.gmax.copy(), col("lower_g", "lower_f"),
+                                  col("upper_g", "upper_f"), col("lower_g", "lower_t"), col("upper_g", "upper_t"))
+
+
+@dataclass
+class CunninghamTransferTable:
+    """types.jl:97-130: grids on a rectangular lattice of parameters (spin, inclination); calling the table
+    interpolates every field multi-linearly (the reference's MultilinearInterpolator over the same fields)."""
+
+    params: tuple
+    grids: np.ndarray          # object array, one CunninghamTransferGrid per lattice point
+
+    def __call__(self, *point):
+        axes = [np.asarray(p, dtype=np.float64) for p in self.params]
+        if len(point) != len(axes):
+            raise ValueError("one coordinate per table axis")
+        corners = [()]
+        weights = [1.0]
+        for ax, p in zip(axes, point):
+            if ax.size == 1:
+                i, w = 0, 0.0
+                lo_hi = ((i, 1.0),)
+            else:
+                i = int(np.clip(np.searchsorted(ax, p, side="right") - 1, 0, ax.size - 2))
+                w = float((p - ax[i]) / (ax[i + 1] - ax[i]))
+                lo_hi = ((i, 1.0 - w), (i + 1, w))
+            corners, weights = ([c + (k,) for c in corners for k, _ in lo_hi],
+                                [wt * wk for wt in weights for _, wk in lo_hi])
+        acc = None
+        for c, wt in zip(corners, weights):
+            f = self.grids[c].fields()
+            acc = [wt * a for a in f] if acc is None else [s + wt * a for s, a in zip(acc, f)]
+        return CunninghamTransferGrid(*acc)
+
+
+def make_transfer_function_table(metric_type, d, a_range, θ_range, *, r_max=500.0, n_radii=150, r_obs=10000.0, **kwargs):
+    """make_transfer_function_table(M, d, a_range, θ_range; r_max, n_radii) (:503-530): for every (a, θ in degrees) the
+    grid of `n_radii` transfer functions between isco + 1e-2 and r_max, observer at r = 10⁴.  Each lattice point is
+    one batch on the device (all its radii share their launches)."""
+    from .planes import InverseGrid
+
+    a_range, θ_range = [float(a) for a in a_range], [float(t) for t in θ_range]
+    grids = np.empty((len(a_range), len(θ_range)), dtype=object)
+    for i, a in enumerate(a_range):
+        m = metric_type(1.0, a)
+        radii = InverseGrid()(m.isco() + 1e-2, r_max, n_radii)
+        for j, θ in enumerate(θ_range):
+            x = np.array([0.0, float(r_obs), math.radians(θ), 0.0])
+            grids[i, j] = transfer_function_grid(m, x, d, radii, **kwargs)
+    return CunninghamTransferTable((np.array(a_range), np.array(θ_range)), grids)

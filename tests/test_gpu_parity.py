@@ -1342,3 +1342,26 @@ def test_circular_orbits_found_by_tracing(G, ens):
         np.testing.assert_allclose(vϕ, G.CircularOrbits.fourvelocity(m, rs)[:, 3], atol=1e-6)
     path = G.trace_equatorial_circular_orbit(G.KerrMetric(1.0, 0.5), 7.0, ensemble=ens)
     assert np.ptp(path.x[:, 1]) < 1e-4 and path.x[-1, 3] > 2 * math.pi
+
+
+def test_transfer_function_table_on_device(G, ens):
+    """make_transfer_function_table (cunningham-transfer-functions.jl:503-530): a 2 x 2 lattice in (spin, inclination)
+    of 24-radius grids, each lattice point one batch on the device; the table interpolates between them."""
+    import time
+
+    ens.set("kernel", 2).set("precision", 64)
+    t0 = time.perf_counter()
+    table = G.make_transfer_function_table(G.KerrMetric, G.ThinDisc(0.0, float("inf")), [0.5, 0.9], [30.0, 60.0], r_max=200.0,
+                                           n_radii=24, ensemble=ens)
+    dt = time.perf_counter() - t0
+    assert table.grids.shape == (2, 2)
+    for g in table.grids.ravel():
+        assert g.lower_f.shape == (20, 24) and np.all(np.isfinite(g.lower_f)) and np.all(np.isfinite(g.upper_time))
+        assert np.all(np.diff(g.r_grid) > 0) and np.all(g.g_min < g.g_max)
+    # higher inclination -> broader range of redshifts at every radius
+    assert np.all(table.grids[1, 1].g_max - table.grids[1, 1].g_min > table.grids[1, 0].g_max - table.grids[1, 0].g_min)
+    mid = table(0.7, 45.0)
+    assert mid.lower_f.shape == (20, 24) and np.all(np.isfinite(mid.upper_f))
+    lo, hi = np.minimum(table.grids[0, 0].g_max, table.grids[1, 1].g_max), np.maximum(table.grids[0, 1].g_max, table.grids[1, 0].g_max)
+    assert np.all(mid.g_max >= np.minimum(lo, table.grids[0, 0].g_max) - 1e-12) and np.all(mid.g_max <= hi + 0.2)
+    print(f"transfer-function table: 4 lattice points x 24 radii in {dt:.2f} s")

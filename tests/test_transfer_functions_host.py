@@ -244,3 +244,24 @@ def test_thick_disc_problem_cases_do_not_raise(G, oracle):
                               (0.998, 903.9954031222643, 85, 1.5)):
         tf = thick_ctf(G, oracle, a, angle, r_e, 0.3, β0)
         assert tf.f.size == 114 and 0 < tf.gmin < tf.gmax
+
+
+def test_transfer_function_grid_and_table_interpolation(G, oracle):
+    """transfer_function_grid (cunningham-transfer-functions.jl:463-501): the branches of every radius on one g✶
+    grid, clamped to [h, 1 - h]; CunninghamTransferTable interpolates the fields multi-linearly (types.jl:97-130)."""
+    x = np.array([0.0, 100_000.0, math.radians(30), 0.0])
+    m, tr, _ = oracle_tracer(G, oracle, 0.998, x, 2 * x[1])
+    itb = G.transferfunctions(m, x, G.ThinDisc(0.0, float("inf")), radii=[8.0, 12.0, 20.0], tracer=tr)
+    grid = G.transfer_function_grid(itb, Ng=20)
+    assert grid.lower_f.shape == (20, 3) and np.all(np.isfinite(grid.lower_f)) and np.all(grid.upper_f >= 0)
+    np.testing.assert_allclose(grid.r_grid, [8.0, 12.0, 20.0])
+    b = itb.branches[1]
+    from gradus_jl_amd.transfer_functions import _interp
+
+    np.testing.assert_allclose(grid.upper_f[5, 1], _interp(b.upper_g, b.upper_f, np.array([5 / 19]))[0])
+    np.testing.assert_allclose(grid.lower_time[0, 1], _interp(b.lower_g, b.lower_t, np.array([1e-3]))[0])      # clamped end
+    g2 = G.CunninghamTransferGrid(*[2.0 * f for f in grid.fields()])
+    table = G.CunninghamTransferTable((np.array([0.0, 1.0]), np.array([30.0])), np.array([[grid], [g2]], dtype=object))
+    mid = table(0.25, 30.0)
+    np.testing.assert_allclose(mid.upper_f, 1.25 * grid.upper_f)
+    np.testing.assert_allclose(mid.g_min, 1.25 * grid.g_min)
