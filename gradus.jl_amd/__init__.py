@@ -26,7 +26,7 @@ from .pointfunctions import ConstPointFunctions, FilterPointFunction, FilterStat
 from .rendering import (EndpointRenderCache, apply, impact_axes, prerendergeodesics, render_configuration,
                         render_into_image, rendergeodesics)
 from .status import StatusCodes
-from .tracing import (EnsembleMI355X, PolarChart, PoloidalShapeChart, TracingConfiguration, chart_for_metric,
+from .tracing import (EnsembleMI355X, TraceGeodesic, TraceWindings, winding_number, PolarChart, PoloidalShapeChart, TracingConfiguration, chart_for_metric,
                       domain_upper_hemisphere, event_horizon, event_horizon_chart, is_naked_singularity,
                       ensemble_solve_tracing_problem, local_momentum, lnr_momentum_to_global_velocity_transform,
                       map_impact_parameters, tracegeodesic_path, tracegeodesic_paths, tracegeodesics, tracing_configuration)

@@ -57,6 +57,9 @@ class gr_config(C.Structure):
         ("chart_theta0", C.c_double),
         ("chart_theta1", C.c_double),
         ("q", C.c_double),
+        ("count_windings", C.c_int32),
+        ("_pad2", C.c_int32),
+        ("winding_plane", C.c_double),
     ]
 
 

@@ -893,6 +893,7 @@ struct Cold {
     const double* beta;       // device, n
     const double* area;       // device, n (unnormalized_areas) or null = 1
     const double* height;     // device, n per-ray DatumPlane heights or null = cfg.disc_params[0]
+    double winding_plane;     // TraceWindings.plane_inc (cfg.count_windings)
     // out_mode 2: BinningMethod line profile (line-profiles.jl:152-198) fused into finalize;
     // out_mode 3: (g, ρ) pairs for a host-side emissivity
     double lp_rmin, lp_rmax;  // minrₑ, maxrₑ
@@ -1085,7 +1086,7 @@ struct Ray {
     float lq_old;       // log2(qold)
     int32_t ev_top;     // upper bracket j of Θ = j/7 when an event is pending
     int64_t j;          // local (swizzled) ray index
-    int32_t status, flags;
+    int32_t status, flags;      // flags: GR_FLAG_* | RAY_EVENT in bits 0..15, TraceWindings count in bits 16..31
     int32_t nacc, nrej;
     real hdat;          // GR_DISC_DATUM: this ray's plane height (dead in every other instantiation)
 #ifdef GR_HOST_HARNESS
@@ -1148,23 +1149,34 @@ struct Ray {
     }
 
     // DiscreteCallbacks in CallbackSet order: domain_upper_hemisphere, then the chart
-    // (the library keeps "a PoloidalShapeChart is active" in bit 1 of its private copy of
-    // cfg.upper_hemisphere, so the common PolarChart case tests one already-resident scalar)
-    static GR_DEV bool discrete_cb(const Params& p, real r, real th, real c, int32_t& st)
+    // (the library keeps "a PoloidalShapeChart is active" in bit 1 and "count windings" in bit 2 of its private
+    // copy of cfg.upper_hemisphere, so the common PolarChart case tests one already-resident scalar)
+    static GR_DEV bool discrete_cb(const Params& p, real r, real th, real c, int32_t& st, int32_t& fl)
     {
         bool term = false;
         const int32_t cb = p.cfg.upper_hemisphere;
-        if ((cb & 1) && r * c < p.cfg.hemi_delta) { st = GR_STATUS_OUT_OF_DOMAIN; term = true; }
         real rmin = p.cfg.r_inner;
-        if (cb & 2) {
-            // PoloidalShapeChart (charts.jl:26-48): r_min(θ) by linear interpolation of the table
-            const int64_t n = p.cfg.chart_table_n;
-            const real idth = (real)((double)(n - 1) / (p.cfg.chart_theta1 - p.cfg.chart_theta0));
-            const real f = (th - (real)p.cfg.chart_theta0) * idth;
-            int64_t k = (int64_t)GR_FLOOR(f);
-            k = k < 0 ? 0 : (k > n - 2 ? n - 2 : k);
-            const real y0 = (real)p.chart_table[k], y1 = (real)p.chart_table[k + 1];
-            rmin = GR_FMA(f - (real)k, y1 - y0, y0);
+        if (cb) {
+            // the optional callbacks sit behind ONE scalar test, so the plain PolarChart trace pays nothing for them
+            if (cb & 4) {
+                // winding_callback (photon-rings.jl:1-15): the count lives in the upper half of the ray's flag word,
+                // the plane in the cold block
+                const real wp = (real)cold_of(p).winding_plane;
+                if ((fl & 0x10000) ? th < wp : th > wp) {
+                    if ((fl & 0xFFFF0000) != 0xFFFF0000) fl += 0x10000;
+                }
+            }
+            if ((cb & 1) && r * c < p.cfg.hemi_delta) { st = GR_STATUS_OUT_OF_DOMAIN; term = true; }
+            if (cb & 2) {
+                // PoloidalShapeChart (charts.jl:26-48): r_min(θ) by linear interpolation of the table
+                const int64_t n = p.cfg.chart_table_n;
+                const real idth = (real)((double)(n - 1) / (p.cfg.chart_theta1 - p.cfg.chart_theta0));
+                const real f = (th - (real)p.cfg.chart_theta0) * idth;
+                int64_t k = (int64_t)GR_FLOOR(f);
+                k = k < 0 ? 0 : (k > n - 2 ? n - 2 : k);
+                const real y0 = (real)p.chart_table[k], y1 = (real)p.chart_table[k + 1];
+                rmin = GR_FMA(f - (real)k, y1 - y0, y0);
+            }
         }
         if (r <= rmin || r > p.cfg.r_outer) {
             st = (r <= rmin) ? GR_STATUS_WITHIN_INNER_BOUNDARY : GR_STATUS_OUT_OF_DOMAIN;
@@ -1412,7 +1424,7 @@ struct Ray {
                 }
                 cprev = cnext;
             }
-            const bool term = discrete_cb(p, xn[1], xn[2], cn, status);
+            const bool term = discrete_cb(p, xn[1], xn[2], cn, status, flags);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[i] = xn[i]; v[i] = vn[i]; A[0][i] = A[6][i]; }
             sth = sn; cth = cn;
@@ -1597,7 +1609,7 @@ struct Ray {
         t = t + theta * h;
         real s, c;
         sincos_fast(x[2], s, c);
-        discrete_cb(p, x[1], x[2], c, status);
+        discrete_cb(p, x[1], x[2], c, status, flags);
     }
 
     // unpack_solution + apply_to_image!
@@ -1607,7 +1619,7 @@ struct Ray {
             resolve_event(p);
             flags &= ~RAY_EVENT;
         }
-        if (flags) status = GR_STATUS_NO_STATUS;
+        if (flags & GR_FLAG_MASK) status = GR_STATUS_NO_STATUS;
         const Cold& cd = cold_of(p);
         if (cd.tile_cost) {
             // representative ray of its 8x8 tile: local column and row both multiples of 8
@@ -1675,6 +1687,7 @@ struct Ray {
             if (pass) {
                 if (cd.pf.pf_id == GR_PF_AFFINE_TIME) val = t;
                 else if (cd.pf.pf_id == GR_PF_STATUS) val = (real)status;
+                else if (cd.pf.pf_id == GR_PF_WINDING) val = (real)((uint32_t)flags >> 16);
                 else if (cd.pf.pf_id == GR_PF_RADIUS) {
                     real s, c;
                     sincos_fast(x[2], s, c);

@@ -19,8 +19,8 @@ struct LaneStats {
         rays += 1;
         acc += (unsigned)r.nacc;
         rej += (unsigned)r.nrej;
-        flagged += r.flags ? 1 : 0;
-        const int s = r.flags ? GR_STATUS_NO_STATUS : r.status;
+        flagged += (r.flags & GR_FLAG_MASK) ? 1 : 0;
+        const int s = (r.flags & GR_FLAG_MASK) ? GR_STATUS_NO_STATUS : r.status;
         st[0] += (s == 0); st[1] += (s == 1); st[2] += (s == 2); st[3] += (s == 3);
     }
     GR_DEV void flush(unsigned long long* out) const
@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point
     if (pass) {
         if (cd.pf.pf_id == GR_PF_AFFINE_TIME) val = gp.lambda_max;
         else if (cd.pf.pf_id == GR_PF_STATUS) val = (double)gp.status;
+        else if (cd.pf.pf_id == GR_PF_WINDING) val = (double)((uint32_t)gp.flags >> 16);
         else if (cd.pf.pf_id == GR_PF_RADIUS) val = gp.x[1] * ::fabs(::sin(gp.x[2]));
         else {
             const LdsView no_lds{ nullptr, nullptr, nullptr, nullptr, nullptr };

@@ -141,7 +141,8 @@ int32_t validate_plane(const gr_plane* pl, const gr_range* rg)
 }
 
 // device copies of the tabulated chart and disc profile (cfg.chart_table / cfg.disc_table are host
-// pointers); records "PoloidalShapeChart active" in bit 1 of the private copy of cfg.upper_hemisphere
+// pointers); records "PoloidalShapeChart active" in bit 1 and "count windings" in bit 2 of the private copy of
+// cfg.upper_hemisphere
 int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 {
     p.chart_table = nullptr;
@@ -154,6 +155,7 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
         p.chart_table = ctx->d_chart_table;
         p.cfg.upper_hemisphere |= 2;
     }
+    if (p.cfg.count_windings) p.cfg.upper_hemisphere |= 4;     // TraceWindings: bit 2
     p.disc_table = nullptr;
     if (p.cfg.disc_id != GR_DISC_TABULATED) return GR_OK;
     const size_t tb = sizeof(double) * (size_t)p.cfg.disc_table_n;
@@ -259,6 +261,7 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
 int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t stream)
 {
     Cold cold = cold_in;
+    cold.winding_plane = p.cfg.winding_plane;
     bool lpt_record = false;
     if (p.n > 0) {
         const int32_t lrc = lpt_prepare(ctx, p, cold, stream, &lpt_record);
@@ -309,7 +312,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
 int32_t stage_pf(gr_ctx* ctx, const gr_pointfunction* pf, PfDev& out, hipStream_t stream)
 {
     if (!pf) return fail(GR_ERR_INVALID_ARGUMENT, "point function is null");
-    if (pf->pf_id < GR_PF_AFFINE_TIME || pf->pf_id > GR_PF_RADIUS)
+    if (pf->pf_id < GR_PF_AFFINE_TIME || pf->pf_id > GR_PF_WINDING)
         return fail(GR_ERR_UNSUPPORTED, "unknown pf_id " + std::to_string(pf->pf_id));
     if (pf->filter_id < GR_FILTER_NONE || pf->filter_id > GR_FILTER_INTERSECTED)
         return fail(GR_ERR_UNSUPPORTED, "unknown filter_id " + std::to_string(pf->filter_id));
@@ -607,6 +610,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     cd.src_mode = 1;
     cd.out_mode = 1;
+    cd.winding_plane = p.cfg.winding_plane;
     cd.x = d_x;
     cd.x_stride = x_stride;
     cd.v = d_v;

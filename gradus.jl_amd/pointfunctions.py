@@ -12,7 +12,7 @@ from typing import Callable, Optional
 from .metrics import AbstractMetric, KerrMetric
 from .status import StatusCodes
 
-GR_PF_AFFINE_TIME, GR_PF_REDSHIFT, GR_PF_STATUS, GR_PF_RADIUS = 0, 1, 2, 3
+GR_PF_AFFINE_TIME, GR_PF_REDSHIFT, GR_PF_STATUS, GR_PF_RADIUS, GR_PF_WINDING = 0, 1, 2, 3, 4
 GR_FILTER_NONE, GR_FILTER_EARLY_TERM, GR_FILTER_INTERSECTED = 0, 1, 2
 
 
@@ -99,6 +99,11 @@ class ConstPointFunctions:
     @staticmethod
     def affine_time():
         return PointFunction(lambda m, gp, max_time, **kw: gp["lambda_max"], device_pf=GR_PF_AFFINE_TIME)
+
+    @staticmethod
+    def winding():
+        """PointFunction((m, gp, t) -> gp.aux.winding) for a TraceWindings render (photon-ring order)."""
+        return PointFunction(lambda m, gp, max_time, **kw: float((int(gp["flags"]) & 0xFFFFFFFF) >> 16), device_pf=GR_PF_WINDING)
 
     @staticmethod
     def shadow():

@@ -104,6 +104,30 @@ def event_horizon_chart(m: AbstractMetric, *, outer_radius: float = 12000.0, clo
     return PoloidalShapeChart(np.ascontiguousarray(rs * closest_approach), float(θs[0]), float(θs[-1]), outer_radius)
 
 
+# ---- tracing.jl:1-7, photon-rings.jl:17-24 ----
+@dataclass(frozen=True)
+class TraceGeodesic:
+    """TraceGeodesic(μ = 0, q = 0)"""
+
+    μ: float = 0.0
+    q: float = 0.0
+
+
+@dataclass(frozen=True)
+class TraceWindings:
+    """TraceWindings(μ = 0, plane_inc = π/2) -- src/tracing/photon-rings.jl: counts how often the geodesic has crossed
+    the cone θ = plane_inc (checked at step ends, as the reference's DiscreteCallback does).  The count is the
+    `winding` of a point (`winding_number(points)`, `ConstPointFunctions.winding()`)."""
+
+    μ: float = 0.0
+    plane_inc: float = math.pi / 2
+
+
+def winding_number(points):
+    """gp.aux.winding of TraceWindings end points (carried in bits 16..31 of the records' flags)."""
+    return (np.asarray(points["flags"]).astype(np.uint32) >> 16).astype(np.int64)
+
+
 # ---- callbacks.jl:31-40 ----
 @dataclass(frozen=True)
 class DomainUpperHemisphere:
@@ -225,6 +249,7 @@ class TracingConfiguration:
     μ: float = 0.0
     maxiters: int = 1_000_000
     q: float = 0.0
+    winding_plane: Optional[float] = None      # TraceWindings.plane_inc (photon-rings.jl:17-24); None = plain TraceGeodesic
 
     def abi_config(self) -> _lib.gr_config:
         c = _lib.gr_config()
@@ -284,6 +309,8 @@ class TracingConfiguration:
         c.abstol, c.reltol = float(self.abstol), float(self.reltol)
         c.mu = float(self.μ)
         c.q = float(self.q)
+        if self.winding_plane is not None:
+            c.count_windings, c.winding_plane = 1, float(self.winding_plane)
         c.maxiters = int(self.maxiters)
         if self.callback is None:
             c.upper_hemisphere = 0
@@ -336,7 +363,17 @@ def tracing_configuration(
     q=0.0,
     solver="Tsit5",
     save_on=False,
+    trace=None,
 ):
+    winding_plane = None
+    if trace is not None:
+        # TraceGeodesic(μ, q) / TraceWindings(μ, plane_inc): the `trace` keyword of tracegeodesics (tracing.jl:66-80)
+        if isinstance(trace, TraceWindings):
+            μ, winding_plane = trace.μ, trace.plane_inc
+        elif isinstance(trace, TraceGeodesic):
+            μ, q = trace.μ, trace.q
+        else:
+            raise NotImplementedError(f"trace {type(trace).__name__} has no device implementation")
     if solver != "Tsit5":
         raise NotImplementedError("the device integrator is Tsit5 (configuration.jl:99)")
     if save_on:
@@ -373,7 +410,7 @@ def tracing_configuration(
         geometry = geometry.thick_disc()         # PolishDoughnut: its isobar, sampled like any ThickDisc(f)
     return TracingConfiguration(
         m, position, velocity, geometry, chart, callback, ensemble, trajectories, _as_lambda_domain(λs),
-        abstol, reltol, gtol, μ, maxiters, q,
+        abstol, reltol, gtol, μ, maxiters, q, winding_plane,
     )
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GR_ABI_VERSION 2
+#define GR_ABI_VERSION 3
 
 typedef enum {
     GR_OK = 0,
@@ -94,7 +94,7 @@ enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_
 
 /* per-ray anomaly bits written next to the status (SciML retcodes MaxIters /
  * DtLessThanMin / Unstable, which EnsembleEndpointThreads discards, tracing.jl:250) */
-enum { GR_FLAG_MAXITERS = 1, GR_FLAG_DTMIN = 2, GR_FLAG_NAN = 4 };
+enum { GR_FLAG_MAXITERS = 1, GR_FLAG_DTMIN = 2, GR_FLAG_NAN = 4, GR_FLAG_MASK = 0xFFFF /* bits 16..31: winding count */ };
 
 /* TracingConfiguration (src/tracing/configuration.jl:3-29) + TraceGeodesic.μ
  * (src/tracing/tracing.jl:1-7) + the geometry callback's gtol (src/geometry/bootstrap.jl:8)
@@ -128,6 +128,11 @@ typedef struct gr_config {
     double q;                 /* test-particle charge, TraceGeodesic.q (tracing.jl:1-7): adds the
                                  Lorentz force q F^μ_ν v^ν (q/μ for μ != 0) for GR_METRIC_KERR_NEWMAN,
                                  kerr-newman-ad.jl:66-100; ignored by metrics without a field     */
+    int32_t count_windings;   /* 1 = TraceWindings (src/tracing/photon-rings.jl:1-71): count the crossings of the
+                                 cone θ = winding_plane at step ends; the count is returned in bits 16..31 of
+                                 gr_point.flags and by GR_PF_WINDING                                  */
+    int32_t _pad2;
+    double winding_plane;     /* TraceWindings.plane_inc, default π/2                                */
 } gr_config;
 
 /* GeodesicPoint{Float64,Nothing} -- src/solution-processing.jl:15-32.  152 bytes, same
@@ -170,7 +175,8 @@ enum {
     GR_PF_AFFINE_TIME = 0,    /* gp.λ_max                                                */
     GR_PF_REDSHIFT = 1,       /* ConstPointFunctions.redshift(m, x)                      */
     GR_PF_STATUS = 2,         /* Float64(gp.status)                                      */
-    GR_PF_RADIUS = 3          /* _equatorial_project(gp.x)                               */
+    GR_PF_RADIUS = 3,         /* _equatorial_project(gp.x)                               */
+    GR_PF_WINDING = 4         /* gp.aux.winding of a TraceWindings trace (photon-ring order) */
 };
 enum {
     GR_FILTER_NONE = 0,

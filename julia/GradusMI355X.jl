@@ -46,6 +46,9 @@ struct GrConfig                      # == gr_config
     chart_theta0::Float64
     chart_theta1::Float64
     q::Float64
+    count_windings::Int32            # TraceWindings (tracing/photon-rings.jl): count in bits 16..31 of GeodesicPoint padding
+    _pad2::Int32
+    winding_plane::Float64
 end
 
 struct GrStats                       # == gr_stats
@@ -95,7 +98,7 @@ mutable struct EnsembleMI355X
     ctxs::Vector{Ptr{Cvoid}}
     function EnsembleMI355X(devices = [0])
         abi = ccall((:gr_abi_version, LIB), Int32, ())
-        abi == 2 || error("GradusMI355X: libgradus_mi355x.so has ABI version $abi, this binding is written for 2")
+        abi == 3 || error("GradusMI355X: libgradus_mi355x.so has ABI version $abi, this binding is written for 3")
         ctxs = Ptr{Cvoid}[]
         for d in devices
             ref = Ref{Ptr{Cvoid}}(C_NULL)
@@ -191,7 +194,10 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2
         config.λ_domain[1], config.λ_domain[2], config.abstol, config.reltol, Float64(trace.μ),
         maxiters, hemi, Int32(0), δ, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
-        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(trace.q))
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1,
+        trace isa Gradus.TraceWindings ? 0.0 : Float64(trace.q),
+        trace isa Gradus.TraceWindings ? Int32(1) : Int32(0), Int32(0),
+        trace isa Gradus.TraceWindings ? Float64(trace.plane_inc) : π / 2)
     cfg, (tab, dtab)
 end
 
@@ -254,7 +260,7 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
         abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
-        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q)))
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q), Int32(0), Int32(0), π / 2))
     g = Gradus.metric(m, x)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
     plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), αlims[1], αlims[2], βlims[1], βlims[2],

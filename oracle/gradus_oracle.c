@@ -638,6 +638,7 @@ static void save_state(save_t* s, const double u[8], double t)
 
 static void integrate(const orc_config* c, const double u0[8], orc_point* out, orc_raystats* st, save_t* save)
 {
+    int winding = 0;
     const double abstol = c->abstol, reltol = c->reltol;
     const double t0 = c->lambda0, tend = c->lambda1;
     const double dtmax = fabs(tend - t0);
@@ -785,6 +786,8 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
             }
             /* ---- then the discrete callbacks, on the (possibly moved) state ---- */
             if (discrete_callbacks(c, unew, &status)) terminated = 1;
+            /* winding_callback of TraceWindings, photon-rings.jl:1-15 (a DiscreteCallback merged into the set) */
+            if (c->count_windings && ((winding % 2 == 0) ? unew[2] > c->winding_plane : unew[2] < c->winding_plane)) winding++;
 
             /* apply_step! */
             memcpy(u, unew, sizeof u);
@@ -804,7 +807,7 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
     }
 
     out->status = status;
-    out->flags = flags;
+    out->flags = flags | ((winding > 0xFFFF ? 0xFFFF : winding) << 16);   /* gp.aux.winding in the upper half */
     out->lambda_min = t0;
     out->lambda_max = t;
     memcpy(out->x_init, u0, 4 * sizeof(double));

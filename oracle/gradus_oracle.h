@@ -73,6 +73,9 @@ typedef struct {
     int64_t chart_table_n;
     double chart_theta0, chart_theta1;
     double q;               /* test-particle charge (TraceGeodesic.q); Lorentz force for Kerr-Newman only */
+    int32_t count_windings; /* TraceWindings (tracing/photon-rings.jl): the count lands in bits 16..31 of orc_point.flags */
+    int32_t _pad2;
+    double winding_plane;   /* TraceWindings.plane_inc */
 } orc_config;
 
 /* GeodesicPoint{Float64,Nothing}, src/solution-processing.jl:15-32; 152 bytes */

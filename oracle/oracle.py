@@ -53,6 +53,9 @@ class Config(C.Structure):
         ("chart_theta0", C.c_double),
         ("chart_theta1", C.c_double),
         ("q", C.c_double),
+        ("count_windings", C.c_int32),
+        ("_pad2", C.c_int32),
+        ("winding_plane", C.c_double),
     ]
 
 
@@ -178,6 +181,7 @@ def make_config(
     q=0.0,
     chart_table=None,
     chart_theta=(0.0, 0.0),
+    winding_plane=None,
 ) -> Config:
     c = Config()
     c.metric_id = METRIC_IDS[metric]
@@ -227,6 +231,8 @@ def make_config(
     c.upper_hemisphere = int(bool(upper_hemisphere))
     c.hemi_delta = hemi_delta
     c.q = q
+    if winding_plane is not None:      # TraceWindings(μ, plane_inc)
+        c.count_windings, c.winding_plane = 1, float(winding_plane)
     if chart_table is not None:       # PoloidalShapeChart: r_min(θ_k), θ_k uniform on chart_theta
         tab = np.ascontiguousarray(chart_table, dtype=np.float64)
         c._keep_chart = tab

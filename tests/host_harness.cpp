@@ -34,6 +34,7 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
 {
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
     p.disc_table = p.cfg.disc_table;      // host pointer is directly usable here
+    p.cfg.upper_hemisphere = (p.cfg.upper_hemisphere ? 1 : 0) | (p.cfg.count_windings ? 4 : 0);   // as stage_disc_table does
     const int disc = p.cfg.disc_id;
 #define HH_RUN(M) \
     do { if (disc == GR_DISC_THIN) run<M, GR_DISC_THIN>(p, p.n, tlog, hlog, cap, nlog); \
@@ -56,7 +57,7 @@ int hh_render_endpoints(const gr_config* cfg, const gr_plane* plane, const gr_ra
 {
     Params p; Cold c;
     std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
-    p.cfg = *cfg; p.n = rg->count; p.cold = &c;
+    p.cfg = *cfg; p.n = rg->count; p.cold = &c; c.winding_plane = cfg->winding_plane;
     c.src_mode = 0; c.out_mode = 1; c.plane = *plane; c.range = *rg; c.points = out;
     dispatch(p, nullptr, nullptr, 0, nullptr);
     return 0;
@@ -66,7 +67,7 @@ int hh_render(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, c
 {
     Params p; Cold c;
     std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
-    p.cfg = *cfg; p.n = rg->count; p.cold = &c;
+    p.cfg = *cfg; p.n = rg->count; p.cold = &c; c.winding_plane = cfg->winding_plane;
     c.src_mode = 0; c.out_mode = 0; c.plane = *plane; c.range = *rg; c.image = image;
     c.pf.pf_id = pf->pf_id; c.pf.filter_id = pf->filter_id; c.pf.fill = pf->fill; c.pf.r_isco = pf->r_isco;
     c.pf.n_plunge = pf->n_plunge; c.pf.plunge_r = pf->plunge_r; c.pf.plunge_vt = pf->plunge_vt;
@@ -79,7 +80,7 @@ int hh_trace_endpoints(const gr_config* cfg, const double* x, int64_t x_stride, 
 {
     Params p; Cold c;
     std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
-    p.cfg = *cfg; p.n = n; p.cold = &c;
+    p.cfg = *cfg; p.n = n; p.cold = &c; c.winding_plane = cfg->winding_plane;
     c.src_mode = 1; c.out_mode = 1; c.x = x; c.x_stride = x_stride; c.v = v; c.points = out;
     c.range = gr_range{ 0, n, n > 0 ? n : 1, 1 };
     dispatch(p, nullptr, nullptr, 0, nullptr);
@@ -91,7 +92,7 @@ int64_t hh_step_log(const gr_config* cfg, const gr_plane* plane, int64_t i, gr_p
 {
     Params p; Cold c;
     std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
-    p.cfg = *cfg; p.n = 1; p.cold = &c;
+    p.cfg = *cfg; p.n = 1; p.cold = &c; c.winding_plane = cfg->winding_plane;
     c.src_mode = 0; c.out_mode = 1; c.plane = *plane; c.range = gr_range{ i, 1, 1, 1 }; c.points = out;
     int64_t n = 0;
     dispatch(p, tlog, hlog, cap, &n);

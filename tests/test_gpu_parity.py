@@ -1365,3 +1365,29 @@ def test_transfer_function_table_on_device(G, ens):
     lo, hi = np.minimum(table.grids[0, 0].g_max, table.grids[1, 1].g_max), np.maximum(table.grids[0, 1].g_max, table.grids[1, 0].g_max)
     assert np.all(mid.g_max >= np.minimum(lo, table.grids[0, 0].g_max) - 1e-12) and np.all(mid.g_max <= hi + 0.2)
     print(f"transfer-function table: 4 lattice points x 24 radii in {dt:.2f} s")
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_trace_windings_on_device(G, oracle, ens, kernel):
+    """TraceWindings through the C ABI: the winding number of every ray (bits 16..31 of gr_point.flags and the fused
+    GR_PF_WINDING image) against the oracle; a plain trace leaves those bits zero; `apply` of the winding point
+    function on an end-point cache equals the fused image."""
+    ens.set("kernel", kernel).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.9)
+    x = np.array([0.0, 200.0, math.radians(80), 0.0])
+    W = H = 96
+    kw = dict(image_width=W, image_height=H, alpha_lims=(-8, 8), beta_lims=(-8, 8), ensemble=ens)
+    _, _, cache = G.prerendergeodesics(m, x, 400.0, trace=G.TraceWindings(), **kw)
+    got = np.ascontiguousarray(cache.points.T).ravel()
+    ocfg = oracle.make_config("kerr", (1.0, 0.9), lambda_max=400.0, winding_plane=math.pi / 2)
+    ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-8, 8), (-8, 8), W, H))
+    same = got["status"] == ref["status"]
+    assert (~same).sum() <= 4
+    wg, wr = G.winding_number(got), G.winding_number(ref)
+    assert (wg[same] != wr[same]).sum() <= 6 and wg.max() >= 3
+    _, _, img = G.rendergeodesics(m, x, 400.0, pf=G.ConstPointFunctions.winding(), trace=G.TraceWindings(), **kw)
+    np.testing.assert_array_equal(img.T.ravel(), wg.astype(float))
+    np.testing.assert_array_equal(G.apply(G.ConstPointFunctions.winding(), cache).T.ravel(), wg.astype(float))
+    _, _, plain = G.prerendergeodesics(m, x, 400.0, **kw)
+    assert np.all(plain.points["flags"] == 0)
+    ens.set("kernel", 2)

@@ -407,3 +407,34 @@ def test_warped_thin_disc_kernel_logic(G, oracle):
     thin = Hh.render_endpoints(G, G.render_configuration(m, x, G.ThinDisc(3.0, 45.0), 700.0, **kw))
     np.testing.assert_array_equal(flat["status"], thin["status"])
     np.testing.assert_allclose(flat["x"], thin["x"], rtol=1e-9, atol=1e-12)
+
+
+def test_trace_windings_kernel_logic(G, oracle):
+    """TraceWindings (src/tracing/photon-rings.jl): the number of times a ray has crossed θ = plane_inc, counted
+    at step ends -- device logic compiled for the host against the oracle, ray for ray; rays that reach the
+    far side without being captured cross the equatorial plane once, higher orders hug the photon ring."""
+    m = G.KerrMetric(1.0, 0.9)
+    x = np.array([0.0, 200.0, math.radians(80), 0.0])
+    W = H = 48
+    cfg = G.render_configuration(m, x, 400.0, image_width=W, image_height=H, alpha_lims=(-8, 8), beta_lims=(-8, 8),
+                                 trace=G.TraceWindings())
+    got = Hh.render_endpoints(G, cfg)
+    ocfg = oracle.make_config("kerr", (1.0, 0.9), lambda_max=400.0, winding_plane=math.pi / 2)
+    ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-8, 8), (-8, 8), W, H))
+    same = got["status"] == ref["status"]
+    assert (~same).sum() <= 2
+    wg, wr = G.winding_number(got), G.winding_number(ref)
+    assert (wg[same] != wr[same]).sum() <= 3          # a step end can fall either side of the plane for a grazing ray
+    assert np.all((got["flags"] & 0xFFFF) == 0)
+    escaped = got["status"] == 3
+    assert set(np.unique(wg[escaped])) >= {1, 2} and wg.max() >= 3
+    img = Hh.render(G, cfg, G.ConstPointFunctions.winding())
+    np.testing.assert_array_equal(img.T.ravel(), wg.astype(float))
+    # a tilted counting plane
+    cfg2 = G.render_configuration(m, x, 400.0, image_width=16, image_height=16, alpha_lims=(-8, 8), beta_lims=(-8, 8),
+                                  trace=G.TraceWindings(0.0, 1.2))
+    o2 = oracle.make_config("kerr", (1.0, 0.9), lambda_max=400.0, winding_plane=1.2)
+    r2 = oracle.trace(o2, x, oracle.render_velocities(o2, x, (-8, 8), (-8, 8), 16, 16))
+    g2 = Hh.render_endpoints(G, cfg2)
+    ok = g2["status"] == r2["status"]
+    assert (G.winding_number(g2)[ok] != G.winding_number(r2)[ok]).sum() <= 1
