@@ -1391,3 +1391,19 @@ def test_trace_windings_on_device(G, oracle, ens, kernel):
     _, _, plain = G.prerendergeodesics(m, x, 400.0, **kw)
     assert np.all(plain.points["flags"] == 0)
     ens.set("kernel", 2)
+
+
+def test_plain_c_client_renders_the_reference_fingerprint(G, tmp_path):
+    """tests/c/c_abi_smoke.c: a C11 program that dlopen's the library and renders the reference's 20 x 20 shadow
+    through gr_render -- the boundary is usable without Python or torch."""
+    import subprocess
+    import sys, os
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_host_api import _build_c_client
+
+    exe = _build_c_client(tmp_path)
+    rc = subprocess.run([exe, G._lib.LIB_PATH], capture_output=True, text=True)
+    print(rc.stdout)
+    assert rc.returncode == 0, rc.stdout + rc.stderr
+    assert "fingerprint 9009.4" in rc.stdout          # the program itself checks it to 1e-6

@@ -143,3 +143,27 @@ def test_thick_disc_surface_vectors():
     np.testing.assert_allclose(_cartesian_tangent_vector(d, 1.0), [1, 0, 0], atol=1e-5)
     n = _cartesian_surface_normal(d, 2.6)
     assert abs(float(n @ _cartesian_tangent_vector(d, 2.6))) < 1e-12 and n[2] > 0
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "c_abi_smoke.c"), "-ldl", "-lm", "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_library_refuses_without_a_device(G, tmp_path):
+    """include/gradus_mi355x.h compiles as C11 (static asserts on the struct sizes included); the C client loads the
+    library, checks the ABI version and -- on a host without a GPU -- gets GR_ERR_NO_DEVICE, not a CPU result."""
+    import subprocess
+
+    import torch
+
+    exe = _build_c_client(tmp_path)
+    rc = subprocess.run([exe, G._lib.LIB_PATH], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert rc.returncode == 0, rc.stdout + rc.stderr
+    else:
+        assert rc.returncode == 3 and "no HIP device" in rc.stdout, rc.stdout + rc.stderr
