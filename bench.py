@@ -160,7 +160,8 @@ def main():
     # Double-buffered slabs: the gather of render i (RCCL, its own stream) overlaps the kernel of
     # render i+1; a slab is only traced into again after its previous gather has completed.
     locals_ = [torch.empty(plan.count, dtype=torch.float64, device=dev) for _ in range(2)]
-    recv = [G.gather_buffers(plan, locals_[0]) if (rank == 0 and world > 1) else None for _ in range(2)]
+    forced = os.environ.get("GRADUS_FORCE_COLLECTIVE") == "1"      # one rank through RCCL as well (diagnostic)
+    recv = [G.gather_buffers(plan, locals_[0]) if (rank == 0 and (world > 1 or forced)) else None for _ in range(2)]
     pending = [None, None]
     stats = gdev.new_stats(dev)
     last_image = [None]

@@ -1407,3 +1407,24 @@ def test_plain_c_client_renders_the_reference_fingerprint(G, tmp_path):
     print(rc.stdout)
     assert rc.returncode == 0, rc.stdout + rc.stderr
     assert "fingerprint 9009.4" in rc.stdout          # the program itself checks it to 1e-6
+
+
+def test_bench_collective_path_on_one_gpu():
+    """bench.py under torch.distributed.run with one rank pushed through the RCCL gather (GRADUS_FORCE_COLLECTIVE=1) and
+    two renders in flight -- the stream hand-over between the trace kernels, the collective and the assembly that
+    the multi-GPU runs rely on -- produces a valid line and the same throughput class as the plain run."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRADUS_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "1", "--size", "1024", "--steps", "6", "--warmup", "2",
+           "--streams", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["renders_in_flight"] == 2 and line["value"] > 5e7
+    assert line["roofline"]["launch_ms"] > 1.5 * line["roofline"]["kernel_ms"]          # launches overlapped pairwise
