@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test: N random scenes through the C ABI against the oracle (same acceptance as
 tests/test_gpu_parity.py::test_randomised_scenes_on_device_vs_oracle), any seed, all eleven metric
-families, thin / datum / Shakura-Sunyaev / sampled thick discs, both kernels.  Prints failing cases.
+families, thin / datum / Shakura-Sunyaev / sampled thick / elliptical / precessing / warped discs, both kernels.  Prints failing cases.
 
     python scripts/soak.py [n_scenes] [seed]
 """
@@ -18,9 +18,17 @@ from oracle import oracle
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+# python scripts/soak.py N SEED CASE [tol]: replay only scene CASE (optionally at another tolerance), on the device or --
+# with SOAK_HOST=1 -- on the host-compiled kernel logic (tests/host_harness.cpp), and print its parameters
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+tol_override = float(sys.argv[4]) if len(sys.argv) > 4 else None
+HOST = os.environ.get("SOAK_HOST") == "1"
+if HOST:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as Hh
 rng = np.random.default_rng(seed)
 U = lambda a, b: float(rng.uniform(a, b))
-ens = G.EnsembleMI355X(0)
+ens = None if HOST else G.EnsembleMI355X(0)
 
 fam = [
     ("kerr", lambda: (1.0, U(-0.998, 0.998)), G.KerrMetric),
@@ -43,7 +51,7 @@ for case in range(n_scenes):
     params = gen()
     r_obs = float(10 ** U(1.3, 3.2))
     th = float(np.radians(U(5, 175)))
-    kind = ["thin", "thin", "datum", "ss", "table"][int(rng.integers(0, 5))]
+    kind = ["thin", "thin", "datum", "ss", "table", "ellipse", "precess", "warped"][int(rng.integers(0, 8))]
     if kind == "datum" and th > math.pi / 2 - 0.1:
         kind = "thin"
     rin = U(0, 8)
@@ -57,7 +65,9 @@ for case in range(n_scenes):
     W = H = 16
     m = cls(*params)
     x = np.array([0.0, r_obs, th, 0.0])
-    ens.set("kernel", int(rng.integers(0, 2)))
+    kern = int(rng.integers(0, 2))
+    if not HOST:
+        ens.set("kernel", kern)
     if kind == "thin":
         d, od = G.ThinDisc(rin, rout), (rin, rout)
     elif kind == "datum":
@@ -66,16 +76,39 @@ for case in range(n_scenes):
     elif kind == "ss":
         mdot, inv_eta, r0 = U(0.05, 0.4), U(5, 20), U(1.5, 8)
         d, od = G.ShakuraSunyaev(mdot, inv_eta, r0), {"mdot": mdot, "inv_eta": inv_eta, "inner_radius": r0}
+    elif kind == "ellipse":
+        e = (U(1.5, 4), U(15, 60), U(0.5, 5))
+        d, od = G.EllipticalDisc(*e), {"ellipse": e}
+    elif kind == "precess":
+        b, g = U(0, 0.6), U(0, 6.28)
+        d, od = G.PrecessingDisc(G.ThinDisc(rin, rout), b, g), {"precessing": (rin, rout, b, g)}
+    elif kind == "warped":
+        amp, wl = U(0.1, 1.5), U(3, 12)
+        d = G.WarpedThinDisc(lambda ρ, amp=amp, wl=wl: amp * math.sin(ρ / wl), inner_radius=rin, outer_radius=rout, samples=4096)
+        od = {"table": d.table, "range": d.ρ_range, "warped": True}
     else:
         r0, w, hh = U(5, 20), U(1, 5), U(0.3, 3)
         f = lambda ρ, r0=r0, w=w, hh=hh: hh * math.sqrt(max(0.0, 1 - ((ρ - r0) / w) ** 2)) if abs(ρ - r0) < w else -1.0
         d = G.ThickDisc(f, ρ_range=(max(r0 - w, 0.0), r0 + w), samples=4096)
         od = {"table": d.table, "range": d.ρ_range}
+    if only is not None and case != only:
+        continue
+    if tol_override is not None:
+        tol = tol_override
+    if only is not None:
+        print("scene", case, name, params, kind, od if kind not in ("table", "warped") else kind, dict(r_obs=r_obs, th=math.degrees(th), gtol=gtol,
+              tol=tol, hemi=hemi, q=q, lam=lam, lim=lim))
     try:
-        _, _, cache = G.prerendergeodesics(m, x, d, lam, image_width=W, image_height=H, alpha_lims=(-lim, lim),
+        if HOST:
+            cfgh = G.render_configuration(m, x, d, lam, image_width=W, image_height=H, alpha_lims=(-lim, lim), beta_lims=(-lim, lim),
+                                          gtol=gtol, abstol=tol, reltol=tol, q=q, callback=G.domain_upper_hemisphere() if hemi else None)
+            got = Hh.render_endpoints(G, cfgh)
+            cache = None
+        else:
+          _, _, cache = G.prerendergeodesics(m, x, d, lam, image_width=W, image_height=H, alpha_lims=(-lim, lim),
                                            beta_lims=(-lim, lim), gtol=gtol, abstol=tol, reltol=tol, q=q, ensemble=ens,
                                            callback=G.domain_upper_hemisphere() if hemi else None)
-        got = np.ascontiguousarray(cache.points.T).ravel()
+          got = np.ascontiguousarray(cache.points.T).ravel()
         ocfg = oracle.make_config(name, params, disc=od, lambda_max=lam, gtol=gtol, abstol=tol, reltol=tol, upper_hemisphere=hemi, q=q)
         ref = oracle.trace(ocfg, x, oracle.render_velocities(ocfg, x, (-lim, lim), (-lim, lim), W, H), nthreads=16)
     except Exception as e:      # noqa: BLE001
