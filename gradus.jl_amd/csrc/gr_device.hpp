@@ -254,7 +254,7 @@ GR_DEV void inverse_generic(const real g[5], real gi[5])
 template <bool CHARGED>
 struct KerrFamily {
     static constexpr bool kHasForce = CHARGED;
-    static constexpr int kMinWavesPerSimd = CHARGED ? 2 : 1;   // Kerr fits 2 waves/SIMD on its own (197 VGPRs)
+    static constexpr int kMinWavesPerSimd = CHARGED ? 2 : 1;   // Kerr fits 2 waves/SIMD on its own (182 VGPRs)
     real M, a;
     real Q, Q2, qm;      // CHARGED only: charge, its square, test-particle q (or q/μ)
     GR_DEV void load(const gr_config& c)
