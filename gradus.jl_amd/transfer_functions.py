@@ -115,7 +115,7 @@ def _rho(pts):
 
 
 def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zero_atol=1e-7, max_iter=50, eps=1e-5,
-                            heights=None):
+                            heights=None, x0=None):
     """_find_offset_for_radius (precision-solvers.jl:135-236) for a batch of (r_target, θ) problems.
 
     Safeguarded Newton on y(r) = ρ(r, θ) - r_target, which is monotonic in r: the start
@@ -126,17 +126,25 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
     iteration is continued while it still gains (Newton is quadratic: one or two more launches), down to
     1e-11 r_target: the redshift of neighbouring samples near g_min / g_max differs by ~1e-9, less than
     what a 1e-7 residual in ρ moves g, and the transfer function there divides by that difference.
+    `x0` (optional) replaces the reference's cold start by a guess per problem.  (Tried for the golden-section
+    searches -- each point started from the offsets of its neighbour: 20 % fewer launches, but the extremal samples,
+    where g - g_min is at the integrator's noise floor, then depend on the path and the recorded statistics move by
+    1e-3; not used.)
     Returns (r, end points, g) with r = NaN where no usable offset exists."""
     r_target = np.asarray(r_target, dtype=np.float64)
     θ = np.asarray(θ, dtype=np.float64)
     n = r_target.size
     x = np.maximum(20.0, r_target)
+    if x0 is not None:
+        x0 = np.asarray(x0, dtype=np.float64)
+        x = np.where(np.isfinite(x0) & (x0 > 0.0), x0, x)
     lo = np.zeros(n)                      # contra point: known to fall short (or captured)
     hi = np.full(n, np.inf)
     y = np.full(n, np.inf)
     ybest = np.full(n, np.inf)
     xbest = x.copy()
     best_pts, best_g = None, np.full(n, np.nan)
+    n_polish = np.zeros(n, dtype=np.int64)
     active = np.arange(n)
     for _ in range(max_iter + 1):
         if active.size == 0:
@@ -164,7 +172,10 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
         xbest[ia] = xa[improved]
         ybest[ia] = np.abs(ya[improved])
         y[active] = ya
-        conv = polished | (hit & (np.abs(ya) <= 1e-11 * np.maximum(r_target[active], 1.0)))
+        # ... but not for ever: below ~1e-9 r the residual is the integrator's noise, and a lucky factor two is
+        # always available there.  Newton squares the error, so three iterations past zero_atol are at the floor.
+        n_polish[active] += (hit & (ybest[active] <= zero_atol)).astype(np.int64)
+        conv = polished | (n_polish[active] >= 4) | (hit & (np.abs(ya) <= 1e-11 * np.maximum(r_target[active], 1.0)))
         # bracket bookkeeping
         # a ray that neither hits nor is captured has left the chart: its offset is too large
         # (the reference projects such an end point onto the equator and gets y > 0)
@@ -178,8 +189,11 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
         near_hole = ρ0 < (r_min + 1.0)
         bad = ~np.isfinite(nx) | (nx <= la) | (nx >= ha) | (~hit) | (near_hole & below)
         bis = np.where(np.isfinite(ha), (2.0 * la + ha) / 3.0, 2.0 * xa)
-        # a bracket that has collapsed to rounding: accept what we have
-        stuck = np.isfinite(ha) & ((ha - la) <= 4.0 * np.finfo(np.float64).eps * np.maximum(ha, 1.0))
+        # a bracket that has collapsed below what the map can resolve: accept what we have.  The traced map ρ(r) is
+        # only piecewise continuous (a change in the number of integration steps moves ρ by a few 1e-7 at tolerance
+        # 1e-9); when the target falls into such a jump no offset reaches zero_atol and bisection would run on to
+        # rounding.  1e-10 r in the offset is 1e-10 in ρ, three orders below zero_atol.
+        stuck = np.isfinite(ha) & ((ha - la) <= 1e-10 * np.maximum(ha, 1.0))
         nx = np.where(bad, bis, nx)
         x[active] = np.where(conv | stuck, xa, nx)
         active = active[~(conv | stuck)]
@@ -215,10 +229,11 @@ class _Workhorse:
     def __init__(self, trace, r_min, setup):
         self.trace, self.r_min, self.s = trace, r_min, setup
 
-    def __call__(self, rₑ, θ):
+    def __call__(self, rₑ, θ, x0=None):
         s = self.s
         r, pts, g = find_offsets_for_radius(self.trace, rₑ, θ, r_min=self.r_min, α0=s["α0"], β0=s["β0"],
-                                            zero_atol=s["zero_atol"])
+                                            zero_atol=s["zero_atol"], x0=x0)
+        self.last_r = r
         if np.any(np.isnan(r)):
             k = int(np.nonzero(np.isnan(r))[0][0])
             raise RuntimeError(f"Transfer function integration failed (rₑ={np.asarray(rₑ)[k]}, θ={np.asarray(θ)[k]}).")
@@ -238,12 +253,13 @@ class _ThickWorkhorse:
         self.datum, self.thick, self.jac, self.d = datum_trace, thick_trace, jac_trace, d
         self.r_min, self.s = r_min, setup
 
-    def __call__(self, rₑ, θ):
+    def __call__(self, rₑ, θ, x0=None):
         s = self.s
         rₑ, θ = np.asarray(rₑ, dtype=np.float64), np.asarray(θ, dtype=np.float64)
         h = np.array([float(self.d.cross_section(float(r))) for r in rₑ])
         r, _, g = find_offsets_for_radius(self.datum, rₑ, θ, r_min=self.r_min, α0=s["α0"], β0=s["β0"],
-                                          zero_atol=s["zero_atol"], heights=h)
+                                          zero_atol=s["zero_atol"], heights=h, x0=x0)
+        self.last_r = r
         if np.any(np.isnan(r)):
             k = int(np.nonzero(np.isnan(r))[0][0])
             raise RuntimeError(f"Transfer function integration failed (rₑ={rₑ[k]}, θ={θ[k]}).")
