@@ -915,8 +915,9 @@ struct Params {
     int32_t refill_threshold;
     int32_t lds_plunge_rows;  // rows of the plunging table to stage in LDS (0 = none)
     int32_t lds_bins;         // line-profile bins privatised in LDS (0 = none)
-    int32_t _pad;
+    int32_t maxiters32;       // cfg.maxiters clamped to int32: the per-step test is one 32-bit compare
     double wedge;             // asin(gtol) with a hair of slack: |θ - π/2| beyond it cannot hit the disc
+    double dtmax;             // |λ1 - λ0|, formed once on the host instead of once per step per lane
 };
 
 // Small read-mostly tables staged in LDS by the kernel prologue (null = use the global copy):
@@ -1264,7 +1265,7 @@ struct Ray {
         cprev = DISC ? disc_cond4(p, x[1], s, c, x[3]) : 1.0;
 
         const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
-        const real dtmax = GR_FABS((real)(p.cfg.lambda1 - p.cfg.lambda0));
+        const real dtmax = (real)p.dtmax;
         real iskx[4], iskv[4], d0s = 0.0, d1s = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1310,11 +1311,14 @@ struct Ray {
     GR_DEV bool step(const Metric& m, const Params& p)
     {
         const real tend = p.cfg.lambda1;
-        const real dtmax = GR_FABS(tend - (real)p.cfg.lambda0);
-        if (nacc + nrej >= p.cfg.maxiters) { flags |= GR_FLAG_MAXITERS; return true; }
+        const real dtmax = (real)p.dtmax;
+        if (nacc + nrej >= p.maxiters32) { flags |= GR_FLAG_MAXITERS; return true; }
         real hh = GR_FMIN(dt, dtmax);
-        if (!(hh == hh)) { flags |= GR_FLAG_NAN; return true; }
-        if (hh < 4.0 * GR_EPS * GR_FMAX(GR_FABS(t), 1.0)) { flags |= GR_FLAG_DTMIN; return true; }
+        // one comparison on the common path: a NaN step size fails it as well and is told apart inside
+        if (!(hh >= 4.0 * GR_EPS * GR_FMAX(GR_FABS(t), 1.0))) {
+            flags |= (hh == hh) ? GR_FLAG_DTMIN : GR_FLAG_NAN;
+            return true;
+        }
         hh = GR_FMIN(hh, tend - t);
         h = hh;
         const real h2 = hh * hh;

@@ -10,6 +10,7 @@
 // Output is one double per ray (fused PointFunction) or one 152-byte GeodesicPoint per ray.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -291,6 +292,8 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
                          && cold_in.pf.n_plunge <= lds_rows_max) ? (int32_t)cold_in.pf.n_plunge : 0;
     p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
+    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
     LaunchKnobs knobs{ kern_sel, block_sel, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
     ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
@@ -608,6 +611,8 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     p.cfg = *cfg;
     p.n = n;
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
+    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
     cd.src_mode = 1;
     cd.out_mode = 1;
     cd.winding_plane = p.cfg.winding_plane;

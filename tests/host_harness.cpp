@@ -2,6 +2,8 @@
 // the host with g++ so that tests can run the exact kernel logic ray by ray on a CPU, next to the
 // oracle, and log its steps.  Never linked into libgradus_mi355x.so.
 #define GR_HOST_HARNESS 1
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "../gradus.jl_amd/csrc/gr_device.hpp"
@@ -33,6 +35,8 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
 static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
 {
     p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
+    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
     p.disc_table = p.cfg.disc_table;      // host pointer is directly usable here
     p.cfg.upper_hemisphere = (p.cfg.upper_hemisphere ? 1 : 0) | (p.cfg.count_windings ? 4 : 0);   // as stage_disc_table does
     const int disc = p.cfg.disc_id;
