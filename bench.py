@@ -41,14 +41,14 @@ PEAK_HBM_GBS = 8000.0
 # and per ray outside the step loop, for the bench workload.
 FLOPS_JSON = os.path.join(ROOT, "oracle", "flopcount.json")
 # FP64 flops the kernel actually EXECUTES per ray, from the committed rocprofv3 PMC pass
-# (profiles/r1g_head_summary.json: (2*FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes *
+# (profiles/r1h_head_summary.json: (2*FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes *
 # active-lane fraction / rays).  Lower than the algorithmic count because the kernel reaches
 # the same results with hand-derived derivatives and a pre-filtered event search.
-EXECUTED_FLOPS_PER_RAY = 2.250e5
-EXECUTED_SOURCE = "profiles/r1g_head_summary.json"
-EXECUTED_VALU_BUSY = 0.912
+EXECUTED_FLOPS_PER_RAY = 2.244e5
+EXECUTED_SOURCE = "profiles/r1h_head_summary.json"
+EXECUTED_VALU_BUSY = 0.919
 # HBM bytes per launch from the same profile's FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes
-PROFILED_TRAFFIC_BYTES_PER_LAUNCH = 40666144.0
+PROFILED_TRAFFIC_BYTES_PER_LAUNCH = 40671168.0
 
 
 def parse_args():
