@@ -84,6 +84,7 @@ def _rayset(config, plane, keep):
         for k in range(4):
             rs.Mx[4 * i + k] = float(Mx[i, k])
     rs.alpha, rs.beta, rs.area, rs.n = αs.ctypes.data, βs.ctypes.data, areas.ctypes.data, αs.size
+    rs._tiled = perm is not None
     return rs, areas
 
 
@@ -126,6 +127,22 @@ def lineprofile(bins, ε, m, u, d, method=None, *, λ_max=None, redshift_pf=None
     st = _lib.gr_stats()
     L = _lib.load()
     h = config.ensemble.ctx.handle
+    # The library takes caller-ordered ray sets to the persistent kernel (neighbours may differ wildly).  Rays handed
+    # over in tiles are as coherent as an image plane, and then one ray per lane wins while a ray is long: measured
+    # on C5 (4096² rays) -4 % at tolerance 1e-9, -6 % at 1e-7, even at 1e-5, +18 % at 1e-3 (21 vs 18 ms: with 14
+    # steps per ray the per-workgroup histogram flush decides).
+    ens = config.ensemble
+    lane = getattr(rs, "_tiled", False) and ens.knobs.get("kernel", 2) == 2 and max(config.abstol, config.reltol) <= 1e-6
+    if lane:
+        ens.ctx.set("kernel", 0)
+    try:
+        return _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, stats)
+    finally:
+        if lane:
+            ens.ctx.set("kernel", 2)
+
+
+def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, stats):
     if isinstance(ε, PowerLawEmissivity):
         b = _lib.gr_binning(float(minrₑ), float(maxrₑ), ε.q, bins.size, bins.ctypes.data)
         flux = np.zeros(bins.size)

@@ -13,12 +13,16 @@ d = G.ThinDisc(m.isco(), 250.0)
 plane = G.PolarPlane(G.GeometricGrid(), Nr=N, Nθ=N, r_min=1.0, r_max=250.0)
 bins = np.linspace(0.1, 1.5, 180)
 ens = G.EnsembleMI355X(0)
+tol = 1e-9
 for kv in sys.argv[3:]:
     k, v = kv.split("=")
-    ens.set(k, int(v))
+    if k == "tol":
+        tol = float(v)
+    else:
+        ens.set(k, int(v))
 ms = []
 for _ in range(reps):
     x, y, st = G.lineprofile(bins, G.PowerLawEmissivity(3), m, u, d, G.BinningMethod(), plane=plane, maxrₑ=250.0,
-                             ensemble=ens, stats=True)
+                             ensemble=ens, stats=True, abstol=tol, reltol=tol)
     ms.append(st["kernel_ms"])
 print(os.environ.get("GRADUS_MI355X_LIB", "in-tree"), N, " ".join(f"{t:.2f}" for t in ms), "steps/ray", st["accepted_steps"] / st["rays"])
