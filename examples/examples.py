@@ -119,3 +119,27 @@ m = G.KerrMetric(1.0, 0.998)
 x = np.array([0.0, 10_000.0, math.radians(75), 0.0])
 ctfs, dt = timed(lambda: G.cunningham_transfer_functions(m, x, G.ThinDisc(0.0, float("inf")), [4.0, 7.0, 10.0, 12.0], ensemble=ens))
 print(f"transfer functions at rₑ = 4, 7, 10, 12 in {dt:.2f} s: g ranges " + ", ".join(f"[{c.gmin:.3f}, {c.gmax:.3f}]" for c in ctfs))
+
+# ## Photon rings: the order of every image-plane ray (TraceWindings)
+m = G.KerrMetric(1.0, 0.9)
+x = np.array([0.0, 1000.0, math.radians(80), 0.0])
+(_, _, img), dt = timed(lambda: G.rendergeodesics(m, x, 2000.0, image_width=1024, image_height=1024, alpha_lims=(-8, 8), beta_lims=(-8, 8),
+                                                  pf=CPF.winding(), trace=G.TraceWindings(), ensemble=ens))
+print(f"photon rings: 1024² winding numbers in {dt:.2f} s; pixels of order 0..4+: {[int((img == k).sum()) for k in range(4)] + [int((img >= 4).sum())]}")
+
+# ## Transfer functions of a thick disc, the ring of an emission radius as the observer sees it, a ray through a point
+ss = G.ShakuraSunyaev.for_metric(m, eddington_ratio=0.3)
+xo = np.array([0.0, 10_000.0, math.radians(75), 0.0])
+ctf, dt = timed(lambda: G.cunningham_transfer_function(m, xo, ss, 4.0, β0=2.0, ensemble=ens))
+print(f"thick-disc transfer function at rₑ = 4: {np.isfinite(ctf.f).sum()} of {ctf.f.size} samples visible, g in [{ctf.gmin:.3f}, {ctf.gmax:.3f}] ({dt:.2f} s)")
+a_, b_ = G.impact_parameters_for_radius_obscured(m, x, ss, 4.0, N=200, β0=2.0, ensemble=ens)
+print(f"ring at rₑ = 4 behind a Shakura-Sunyaev disc at 80°: {np.isfinite(a_).sum()} of 200 directions visible")
+α_, β_, acc = G.impact_parameters_for_target(np.array([10.0, math.radians(40), -math.pi / 4]), m, np.array([0.0, 1000.0, math.pi / 2, 0.0]), ensemble=ens)
+print(f"ray through (r, θ, ϕ) = (10, 40°, -45°): α = {α_:.4f}, β = {β_:.4f}, passes within {acc:.1e}")
+
+# ## More geometry: a warped sheet and a tilted disc
+for name, d in (("WarpedThinDisc", G.WarpedThinDisc(lambda ρ: 1.5 * math.sin(ρ / 5.0), inner_radius=m.isco(), outer_radius=40.0)),
+                ("PrecessingDisc", G.PrecessingDisc(G.ThinDisc(m.isco(), 40.0), 0.4, 0.7))):
+    _, _, img = G.rendergeodesics(m, x, d, 2000.0, image_width=600, image_height=400, alpha_lims=(-45, 45), beta_lims=(-30, 30),
+                                  pf=CPF.redshift(m, x) @ CPF.filter_intersected(), ensemble=ens)
+    print(f"geometry {name}: {np.isfinite(img).sum()} pixels, g in [{np.nanmin(img):.3f}, {np.nanmax(img):.3f}]")
