@@ -397,7 +397,12 @@ def cunningham_transfer_function(m, x, d, rₑ, **kwargs):
 # (cunningham-transfer-functions.jl:45-176, transfer-functions-2d.jl:1-84, integration.jl)
 # ------------------------------------------------------------------------------------------
 def _interp(t, u, x):
-    """NaNLinearInterpolator (interpolations.jl:1-30) on arrays."""
+    """NaNLinearInterpolator (interpolations.jl:1-30) on arrays.  Inside the knots and without NaN values -- the
+    case of every branch evaluation of the integrators -- that is plain linear interpolation (np.interp, ten times
+    faster than the general form: the line-profile integration calls this 12 000 times)."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.size and t[0] <= x.min() and x.max() <= t[-1] and not np.isnan(u).any():
+        return np.interp(x, t, u)
     from .corona import _nan_linear_interp
 
     return _nan_linear_interp(t, u, x)
