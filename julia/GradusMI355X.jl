@@ -16,7 +16,7 @@ using Gradus: TracingConfiguration, EnsembleProblem, GeodesicPoint, StatusCodes,
     KerrMetric, JohannsenMetric, ThinDisc, PolarChart, lnr_momentum_to_global_velocity_transform
 using StaticArrays
 
-export EnsembleMI355X, SampledThickDisc, render_mi355x
+export EnsembleMI355X, SampledThickDisc, render_mi355x, winding_numbers
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
 
@@ -200,6 +200,16 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2
         trace isa Gradus.TraceWindings ? Float64(trace.plane_inc) : π / 2)
     cfg, (tab, dtab)
 end
+
+"""
+    winding_numbers(points)
+
+`gp.aux.winding` of end points traced with `trace = TraceWindings(...)` on `EnsembleMI355X`: the library returns
+`GeodesicPoint{Float64,Nothing}` records and carries the count in bits 16..31 of the four padding bytes after `status`.
+"""
+winding_numbers(points::Vector{<:GeodesicPoint}) = GC.@preserve points [
+    Int(unsafe_load(Ptr{UInt32}(pointer(points, i)) + 4) >> 16) for i in eachindex(points)
+]
 
 # The drop-in method: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,
 # Nothing} is isbits with the layout of gr_point (152 bytes), so the result vector is filled in
