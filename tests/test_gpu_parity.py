@@ -1428,3 +1428,46 @@ def test_bench_collective_path_on_one_gpu():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["renders_in_flight"] == 2 and line["value"] > 5e7
     assert line["roofline"]["launch_ms"] > 1.5 * line["roofline"]["kernel_ms"]          # launches overlapped pairwise
+
+
+def test_c_abi_rejects_bad_input_without_touching_the_device(G, ens):
+    """Error behaviour of the boundary: configuration mistakes come back as negative codes with a
+    message -- unknown metric / geometry / point-function ids, null pointers, negative counts, unsorted limits --
+    and nothing throws or aborts; a valid call afterwards still works."""
+    import ctypes as C
+
+    L = G._lib.load()
+    h = ens.ctx.handle
+    m = G.KerrMetric(1.0, 0.5)
+    cfgo = G.render_configuration(m, X_SMOKE, G.ThinDisc(2.0, 30.0), 200.0, image_width=16, image_height=16, alpha_lims=(-9, 9),
+                                  beta_lims=(-9, 9), ensemble=ens)
+    cfg, pl = cfgo.abi_config(), cfgo.abi_plane()
+    rg = G._lib.gr_range(0, 256, 256, 1)
+    img = np.zeros(256)
+    pf = G._lib.gr_pointfunction()
+    pf.pf_id, pf.filter_id, pf.fill = 0, 0, float("nan")
+
+    def call(cfg_=cfg, pl_=pl, pf_=pf, rg_=rg, img_=img):
+        return L.gr_render(h, C.byref(cfg_), C.byref(pl_), C.byref(pf_), C.byref(rg_), img_.ctypes.data if img_ is not None else None, None)
+
+    assert call() == 0
+    for field, value, code in (("metric_id", 11, -2), ("metric_id", -1, -2), ("disc_id", 7, -2), ("abstol", -1.0, -1)):
+        bad = type(cfg).from_buffer_copy(cfg)
+        setattr(bad, field, value)
+        assert call(cfg_=bad) == code, field
+        assert len(L.gr_last_error()) > 0
+    badpf = type(pf).from_buffer_copy(pf)
+    badpf.pf_id = 9
+    assert call(pf_=badpf) == -2
+    badpl = type(pl).from_buffer_copy(pl)
+    badpl.alpha0, badpl.alpha1 = 5.0, -5.0
+    assert call(pl_=badpl) == -1
+    assert call(img_=None) == -1
+    rs = G._lib.gr_rayset()
+    rs.n = -3
+    assert L.gr_rayset_endpoints(h, C.byref(cfg), C.byref(rs), None, None) == -1
+    rs.n = 4                                    # alpha / beta missing
+    pts = np.zeros(4, dtype=G.POINT_DTYPE)
+    assert L.gr_rayset_endpoints(h, C.byref(cfg), C.byref(rs), pts.ctypes.data, None) == -1
+    assert L.gr_render(None, C.byref(cfg), C.byref(pl), C.byref(pf), C.byref(rg), img.ctypes.data, None) == -1
+    assert call() == 0 and np.isfinite(img).sum() > 0
