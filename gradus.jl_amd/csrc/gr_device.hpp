@@ -1436,9 +1436,11 @@ struct Ray {
             dt = GR_FMIN(dtmax, dtnew);
             return term || !(t < tend);
         } else {
-            // step_reject_controller!; a NaN state lands here too (e2 is NaN) and is flagged at
-            // the top of the next attempt through the NaN step size
+            // step_reject_controller!; a NaN state lands here too (e2 is NaN).  fminf(1/qmin, NaN) returns
+            // 1/qmin, so the step size would stay finite and the ray would be rejected ~25 times down to
+            // dt < dtmin: test for it here (rejected steps only, so the accepted path pays nothing)
             nrej++;
+            if (!(e2 == e2)) { flags |= GR_FLAG_NAN; return true; }
             const float q11 = fast_exp2f((float)PI_BETA1 * lE);
             dt = hh / (real)::fminf((float)(1.0 / PI_QMIN), q11 * (float)(1.0 / PI_GAMMA));
             return false;

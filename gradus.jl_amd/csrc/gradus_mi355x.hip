@@ -87,6 +87,13 @@ struct gr_ctx {
     int64_t lpt_tiles = 0, lpt_cap = 0;
     bool lpt_have_perm = false, lpt_cost_pending = false;
     hipEvent_t ev_cost = nullptr;
+    // The staged tables (plunging table, disc profile, chart) are single ctx-owned buffers.  A launch that reads
+    // them records `ev_tables` on its stream; the next staging on a DIFFERENT stream first waits for that event,
+    // so a table is never overwritten under a kernel that is still reading it (launches without tables -- Kerr
+    // with a thin disc, the bench workload -- never wait on each other).
+    hipEvent_t ev_tables = nullptr;
+    hipStream_t tables_stream = nullptr;
+    bool tables_busy = false;
 };
 
 namespace {
@@ -99,6 +106,21 @@ int32_t ensure(void** buf, size_t* cap, size_t need)
     *cap = 0;
     GR_HIP(hipMalloc(buf, need));
     *cap = need;
+    return GR_OK;
+}
+
+// make `stream` wait for the last launch that read the ctx-owned staged tables (if it ran on another stream)
+int32_t tables_acquire(gr_ctx* ctx, hipStream_t stream)
+{
+    if (ctx->tables_busy && ctx->tables_stream != stream) GR_HIP(hipStreamWaitEvent(stream, ctx->ev_tables, 0));
+    return GR_OK;
+}
+// called after a launch that reads staged tables
+int32_t tables_release(gr_ctx* ctx, hipStream_t stream)
+{
+    GR_HIP(hipEventRecord(ctx->ev_tables, stream));
+    ctx->tables_stream = stream;
+    ctx->tables_busy = true;
     return GR_OK;
 }
 
@@ -148,6 +170,10 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 {
     p.chart_table = nullptr;
     p.cfg.upper_hemisphere = p.cfg.upper_hemisphere ? 1 : 0;
+    if (p.cfg.chart_table_n > 1 || p.cfg.disc_id == GR_DISC_TABULATED) {
+        const int32_t arc = tables_acquire(ctx, stream);
+        if (arc != GR_OK) return arc;
+    }
     if (p.cfg.chart_table_n > 1) {
         const size_t cb = sizeof(double) * (size_t)p.cfg.chart_table_n;
         int32_t crc = ensure((void**)&ctx->d_chart_table, &ctx->chart_table_bytes, cb);
@@ -303,16 +329,19 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     else
         le = launch_by_config(knobs, p, stream);
     if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
-    const int32_t rc = GR_OK;
-    if (rc == GR_OK && lpt_record) {
+    if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0) {
+        const int32_t trc = tables_release(ctx, stream);
+        if (trc != GR_OK) return trc;
+    }
+    if (lpt_record) {
         GR_HIP(hipEventRecord(ctx->ev_cost, stream));
         ctx->lpt_cost_pending = true;
     }
-    return rc;
+    return GR_OK;
 }
 
 // copy the plunging table (host pointers) into the context and fill the device-side pf
-int32_t stage_pf(gr_ctx* ctx, const gr_pointfunction* pf, PfDev& out, hipStream_t stream)
+int32_t stage_pf(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf, PfDev& out, hipStream_t stream)
 {
     if (!pf) return fail(GR_ERR_INVALID_ARGUMENT, "point function is null");
     if (pf->pf_id < GR_PF_AFFINE_TIME || pf->pf_id > GR_PF_WINDING)
@@ -329,7 +358,12 @@ int32_t stage_pf(gr_ctx* ctx, const gr_pointfunction* pf, PfDev& out, hipStream_
         if (pf->n_plunge < 2 || !pf->plunge_r || !pf->plunge_vt || !pf->plunge_vr || !pf->plunge_vphi)
             return fail(GR_ERR_INVALID_ARGUMENT, "plunging table needs >= 2 rows and four arrays");
         const int64_t n = pf->n_plunge;
+        {
+            const int32_t arc = tables_acquire(ctx, stream);
+            if (arc != GR_OK) return arc;
+        }
         if (ctx->plunge_cap < n) {
+            // a smaller table may still be read by a launch in flight on this very stream: hipFree waits for the device
             if (ctx->d_plunge) (void)hipFree(ctx->d_plunge);
             ctx->d_plunge = nullptr;
             ctx->plunge_cap = 0;
@@ -347,6 +381,10 @@ int32_t stage_pf(gr_ctx* ctx, const gr_pointfunction* pf, PfDev& out, hipStream_
     }
     if (pf->pf_id == GR_PF_REDSHIFT && !(pf->r_isco > 0.0))
         return fail(GR_ERR_INVALID_ARGUMENT, "redshift needs r_isco > 0");
+    // n_plunge = 0 selects the analytic Cunningham plunge, which exists for Kerr only (redshift.jl:93-164); every
+    // other metric interpolates a tabulated plunge inside its ISCO (redshift.jl:246-276) and must bring the table
+    if (pf->pf_id == GR_PF_REDSHIFT && cfg->metric_id != GR_METRIC_KERR && pf->n_plunge < 2)
+        return fail(GR_ERR_INVALID_ARGUMENT, "redshift of a non-Kerr metric needs a plunging table (n_plunge >= 2)");
     return GR_OK;
 }
 
@@ -411,7 +449,8 @@ int32_t gr_ctx_create(int32_t device, gr_ctx** out)
         if (hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * N_STAT) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(stats) failed"); break; }
         if (hipMalloc((void**)&c->d_cold, sizeof(Cold) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(cold) failed"); break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
-            || hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipEventCreate failed"); break; }
+            || hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipEventCreate failed"); break; }
     } while (0);
     if (rc != GR_OK) {
         gr_ctx_destroy(c);
@@ -434,6 +473,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
+    if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
     if (c->d_plunge) (void)hipFree(c->d_plunge);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -493,7 +533,7 @@ int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plan
     Params p;
     Cold cd;
     plane_params(ctx, p, cd, cfg, plane, range);
-    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     cd.out_mode = 0;
     cd.image = d_image;
     p.stats = (unsigned long long*)d_stats;   // same layout: 9 x 64-bit counters then kernel_ms
@@ -562,7 +602,7 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     std::memset(&cd, 0, sizeof cd);
     p.cfg = *cfg;
     p.n = n;
-    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     if (n == 0) return GR_OK;
     Cold* slot = ctx->d_cold + ctx->cold_next;
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
@@ -579,6 +619,7 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     else
         hipLaunchKernelGGL((k_apply_pf<GenericMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
     GR_HIP(hipGetLastError());
+    if (cd.pf.n_plunge > 0 && (rc = tables_release(ctx, stream)) != GR_OK) return rc;
     return GR_OK;
 }
 
@@ -645,6 +686,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
 #undef GR_PATH_BY_DISC
 #undef GR_PATH_LAUNCH
     GR_HIP(hipGetLastError());
+    if ((p.disc_table || p.chart_table) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters are copied as int64");
     GR_HIP(hipMemcpyAsync(n_rows, d_n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     GR_HIP(hipMemcpyAsync(path, d_path, path_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -695,7 +737,7 @@ int32_t gr_lineprofile_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     Cold cd;
     if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
     if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "line profiles use the redshift point function");
-    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     cd.out_mode = 2;
     cd.lp_rmin = b->r_min; cd.lp_rmax = b->r_max; cd.lp_q = b->emissivity_index;
     cd.lp_nbins = b->n_bins; cd.lp_edges = b->bin_edges; cd.lp_flux = d_flux;
@@ -717,7 +759,7 @@ int32_t gr_redshift_radius_device(gr_ctx* ctx, const gr_config* cfg, const gr_ra
     if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
     if (rays->n > 0 && !d_pairs) return fail(GR_ERR_INVALID_ARGUMENT, "pairs is null");
     if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "needs the redshift point function");
-    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     cd.out_mode = 3;
     cd.lp_rmin = r_min; cd.lp_rmax = r_max;
     cd.lp_pairs = d_pairs;
@@ -738,7 +780,7 @@ int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
     if (rays->n > 0 && !d_out) return fail(GR_ERR_INVALID_ARGUMENT, "out is null");
     if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "needs the redshift point function");
-    if ((rc = stage_pf(ctx, pf, cd.pf, stream)) != GR_OK) return rc;
+    if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     cd.out_mode = 4;
     cd.lp_rmin = 0.0;
     cd.lp_rmax = INFINITY;
@@ -776,6 +818,7 @@ static int32_t begin_host_call(gr_ctx* ctx, gr_stats* stats)
 
 static int32_t end_host_call(gr_ctx* ctx, gr_stats* stats)
 {
+    GR_HIP(hipSetDevice(ctx->device));
     GR_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     unsigned long long h[N_STAT];
     if (stats) GR_HIP(hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -795,6 +838,7 @@ int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, cons
     if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!range) return fail(GR_ERR_INVALID_ARGUMENT, "range is null");
     if (!image && range->count > 0) return fail(GR_ERR_INVALID_ARGUMENT, "image is null");
+    GR_HIP(hipSetDevice(ctx->device));      // before any allocation: ensure() mallocs on the current device
     int32_t rc;
     const size_t bytes = sizeof(double) * (size_t)(range->count > 0 ? range->count : 0);
     if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
@@ -825,6 +869,7 @@ int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, co
     for (int k = 0; k < n; ++k) {
         gr_ctx* c = ctxs[k];
         const size_t bytes = sizeof(double) * (size_t)count;
+        GR_HIP(hipSetDevice(c->device));      // context k's scratch image must live on device k
         if ((rc = ensure(&c->d_scratch, &c->scratch_bytes, bytes)) != GR_OK) return rc;
         if ((rc = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return rc;
         const gr_range rg{ (int64_t)k * block, count, block, (int64_t)n };
@@ -847,6 +892,7 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
     if (!range) return fail(GR_ERR_INVALID_ARGUMENT, "range is null");
     if (!points && range->count > 0) return fail(GR_ERR_INVALID_ARGUMENT, "points is null");
+    GR_HIP(hipSetDevice(ctx->device));      // before any allocation: ensure() mallocs on the current device
     int32_t rc;
     const size_t bytes = sizeof(gr_point) * (size_t)(range->count > 0 ? range->count : 0);
     if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
@@ -864,6 +910,7 @@ int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, i
     if (n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
     if (x_stride != 0 && x_stride != 4) return fail(GR_ERR_INVALID_ARGUMENT, "x_stride must be 0 or 4");
     if (n > 0 && (!x || !v || !points)) return fail(GR_ERR_INVALID_ARGUMENT, "x/v/points is null");
+    GR_HIP(hipSetDevice(ctx->device));      // before any allocation: ensure() mallocs on the current device
     int32_t rc;
     const size_t nx = (size_t)(x_stride == 0 ? 4 : 4 * n), nv = (size_t)(4 * n);
     const size_t out_bytes = sizeof(gr_point) * (size_t)n;
@@ -890,9 +937,9 @@ int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_point
     if (n > 0 && (!points || !out)) return fail(GR_ERR_INVALID_ARGUMENT, "points/out is null");
     int32_t rc;
     const size_t in_bytes = sizeof(gr_point) * (size_t)n, out_bytes = sizeof(double) * (size_t)n;
+    GR_HIP(hipSetDevice(ctx->device));      // before any allocation: ensure() mallocs on the current device
     if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, in_bytes ? in_bytes : 8)) != GR_OK) return rc;
     if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, out_bytes ? out_bytes : 8)) != GR_OK) return rc;
-    GR_HIP(hipSetDevice(ctx->device));
     if (n > 0) GR_HIP(hipMemcpyAsync(ctx->d_in, points, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = gr_apply_pointfunction_device(ctx, cfg, pf, (const gr_point*)ctx->d_in, n, max_time,
                                             (double*)ctx->d_scratch, ctx->stream)) != GR_OK) return rc;

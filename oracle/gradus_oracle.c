@@ -549,10 +549,17 @@ static double disc_condition(const orc_config* c, const double u[8])
         /* ThickDisc(f): cross_section(d, ρ) = f(ρ), thick-disc.jl:57-66 (inner/outer radius 0/Inf) */
         double height;
         if (c->disc_id == ORC_DISC_TORUS) {
-            /* _thick_disc, test/smoke-tests/rendergeodesics.jl:7-14 */
+            /* _thick_disc, test/smoke-tests/rendergeodesics.jl:7-14.  disc_params[3] selects the LEGACY thick-disc
+             * semantics the smoke test's recorded fingerprints were computed with (tests/test_thick_disc_independent.py):
+             * bit 0 = subtract gtol |r| like the thin disc, bit 1 = cross section at the spherical radius u[2]
+             * (the convention thick-disc.jl:16-27's docstring still shows).  0 = the reference as it is today. */
+            const int legacy = (int)c->disc_params[3];
             const double ctr = c->disc_params[0], rad = c->disc_params[1];
-            if (rho < ctr - rad || rho > ctr + rad) height = -1.0;
-            else { const double xx = (rho - ctr) / rad; height = rad * sqrt(1.0 - xx * xx); }
+            const double q = (legacy & 2) ? r : rho;
+            if (q < ctr - rad || q > ctr + rad) height = -1.0;
+            else { const double xx = (q - ctr) / rad; height = rad * sqrt(1.0 - xx * xx); }
+            if (height <= 0.0) return 1.0;
+            return r * fabs(cos(th)) - height - ((legacy & 1) ? c->gtol * fabs(r) : 0.0);
         } else {
             const double r0 = c->disc_params[0], r1 = c->disc_params[1];
             const int64_t n = c->disc_table_n;
@@ -580,7 +587,8 @@ static double disc_condition(const orc_config* c, const double u[8])
         if (rho < c->disc_r_in) height = -0.0;
         else height = 3.0 * c->disc_params[1] * c->disc_params[0] * (1.0 - sqrt(c->disc_r_in / rho));
         if (height <= 0.0) return 1.0;
-        return r * fabs(cos(th)) - height;
+        /* disc_params[3] bit 0: legacy semantics (- gtol |r|), see ORC_DISC_TORUS above */
+        return r * fabs(cos(th)) - height - (((int)c->disc_params[3] & 1) ? c->gtol * fabs(r) : 0.0);
     }
     if (rho < c->disc_r_in || rho > c->disc_r_out) return 1.0;
     return r * fabs(cos(th)) - c->gtol * fabs(r);

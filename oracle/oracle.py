@@ -206,6 +206,7 @@ def make_config(
         c.disc_id = DISC_TORUS
         c.disc_r_in, c.disc_r_out = 0.0, float("inf")
         c.disc_params[0], c.disc_params[1] = float(disc["torus"][0]), float(disc["torus"][1])
+        c.disc_params[3] = float(disc.get("legacy", 0))     # see disc_condition(): pre-2023 thick-disc semantics
     elif isinstance(disc, dict) and "table" in disc:     # sampled ThickDisc: {"table": heights, "range": (ρ0, ρ1)}
         tab = np.ascontiguousarray(disc["table"], dtype=np.float64)
         c._keep = tab
@@ -220,6 +221,7 @@ def make_config(
         c.disc_id = DISC_SHAKURA_SUNYAEV
         c.disc_r_in, c.disc_r_out = float(disc["inner_radius"]), float("inf")
         c.disc_params[0], c.disc_params[1] = float(disc["mdot"]), float(disc["inv_eta"])
+        c.disc_params[3] = float(disc.get("legacy", 0))
     else:
         c.disc_id = DISC_THIN
         c.disc_r_in, c.disc_r_out = float(disc[0]), float(disc[1])

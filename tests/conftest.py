@@ -36,7 +36,23 @@ def G(built):
     return gradus_jl_amd
 
 
+# library defaults of every launch knob (gradus_mi355x.hip, struct gr_ctx)
+KNOB_DEFAULTS = {"kernel": 2, "block": 0, "refill_threshold": 16, "waves_per_simd": 0, "swizzle": 1, "lpt_lane": 0,
+                 "lds": 1, "precision": 64, "lpt": 1}
+
+
 @pytest.fixture(scope="session")
-def ens(G):
-    """One EnsembleMI355X on device 0 for the whole GPU session; fails loudly without a GPU."""
+def _ens_session(G):
+    """One EnsembleMI355X (one gr_ctx) on device 0 for the whole GPU session; fails loudly without a GPU."""
     return G.EnsembleMI355X(0)
+
+
+@pytest.fixture
+def ens(_ens_session):
+    """The session's ensemble with every launch knob back at the library default, so that no test inherits the
+    kernel / precision / lpt / block choice of the test that ran before it."""
+    for k, v in KNOB_DEFAULTS.items():
+        _ens_session.set(k, v)
+    yield _ens_session
+    for k, v in KNOB_DEFAULTS.items():
+        _ens_session.set(k, v)
