@@ -38,24 +38,44 @@ PEAK_HBM_GBS = 8000.0
 
 # Algorithmic flops of the reference formulation, counted by the oracle compiled on a counting
 # scalar (oracle/flopcount.cpp, `make -C oracle count`): per attempted Tsit5 step
-# and per ray outside the step loop, for the bench workload.
+# and per ray outside the step loop, for the bench workload.  Reported as `roofline.algorithmic_equivalent`,
+# never as the hardware fraction.
 FLOPS_JSON = os.path.join(ROOT, "oracle", "flopcount.json")
-# FP64 flops the kernel actually EXECUTES per ray, from the committed rocprofv3 PMC pass
-# (profiles/r1h_head_summary.json: (2*FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes *
-# active-lane fraction / rays).  Lower than the algorithmic count because the kernel reaches
-# the same results with hand-derived derivatives and a pre-filtered event search.
-EXECUTED_FLOPS_PER_RAY = 2.244e5
-EXECUTED_SOURCE = "profiles/r1h_head_summary.json"
-EXECUTED_VALU_BUSY = 0.919
-# HBM bytes per launch from the same profile's FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE passes
-PROFILED_TRAFFIC_BYTES_PER_LAUNCH = 40671168.0
+# The FP64 work the kernel actually EXECUTES comes from the committed rocprofv3 PMC passes of THIS build of the
+# kernels: profiles/CURRENT names the summary (written by scripts/profile_pmc.sh + summarize_pmc.py), whose
+# `source_sha16` must equal the hash of the kernel sources in this tree and whose kernel must be the one launched.
+PROFILE_POINTER = os.path.join(ROOT, "profiles", "CURRENT")
+
+
+def profile_evidence(size, world):
+    """(summary dict, relative path) of the committed profile that belongs to this build and workload, or
+    (None, reason)."""
+    from gradus_jl_amd._lib import kernel_source_sha16
+
+    try:
+        rel = open(PROFILE_POINTER).read().strip()
+        with open(os.path.join(ROOT, rel)) as f:
+            summ = json.load(f)
+    except Exception as e:      # noqa: BLE001
+        return None, f"no committed profile summary ({type(e).__name__}: {e})"
+    sha = kernel_source_sha16()
+    if summ.get("source_sha16") != sha:
+        return None, f"{rel} was taken from kernel sources {summ.get('source_sha16')}, this tree is {sha}: re-profile"
+    if "k_trace_lane<gr::KerrFamily<false>, 1>" not in (summ.get("kernel") or ""):
+        return None, f"{rel} profiles {summ.get('kernel')}, not the bench kernel"
+    if summ.get("rays_per_launch") != size * size or world != 1:
+        return None, f"{rel} is a {summ.get('rays_per_launch')}-ray launch; this run launches {size * size // world} rays per GPU"
+    for k in ("executed_fp64_flops_per_launch", "valu_busy", "avg_ms"):
+        if k not in summ:
+            return None, f"{rel} lacks {k}"
+    return summ, rel
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=2048, help="image is size x size")
     ap.add_argument("--kernel", type=int, default=2, help="0 = one ray per lane, 1 = persistent, 2 = auto by launch depth")
     ap.add_argument("--lpt-lane", type=int, default=None)
@@ -64,6 +84,8 @@ def parse_args():
     ap.add_argument("--block", type=int, default=None, help="workgroup size (64..256, diagnostic)")
     ap.add_argument("--block-cols", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-call", action="store_true",
+                    help="skip the second timed leg (blocking gr_render into a host buffer, D2H included)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=0,
                     help="renders in flight: 2 = consecutive renders alternate between two HIP streams, so the next render's "
@@ -224,6 +246,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- second leg (N = 1): the blocking host entry point, image copied D2H into a host buffer every step
+    #      ("wall time of the blocking ABI call, H2D/D2H included, ctx creation excluded") ----
+    host_call = None
+    if world == 1 and not args.no_host_call and not args.emulate_shard:
+        import ctypes as C
+
+        from gradus_jl_amd import _lib
+        from gradus_jl_amd.rendering import abi_pointfunction
+
+        acfg, apl = cfg.abi_config(), cfg.abi_plane()
+        apf, keep_pf = abi_pointfunction(pf)
+        n_all = args.size * args.size
+        arg_rg = _lib.gr_range(0, n_all, n_all, 1)
+        host_img = np.empty(n_all, dtype=np.float64)        # a plain (pageable) array, like Julia's `zeros(T, (H, W))`
+        hst = _lib.gr_stats()
+        L = _lib.load()
+
+        def host_step():
+            _lib.check(L.gr_render(ens.ctx.handle, C.byref(acfg), C.byref(apl), C.byref(apf), C.byref(arg_rg),
+                                   host_img.ctypes.data, C.byref(hst)))
+
+        for _ in range(max(args.warmup, 1)):
+            host_step()
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for _ in range(args.steps):
+            host_step()
+        th = time.perf_counter() - th0
+        host_call = {"value": n_all * args.steps / th, "unit": "geodesics/s", "ms_per_step": th / args.steps * 1e3,
+                     "steps": args.steps, "entry": "gr_render (blocking; kernel + 32 MiB D2H into a pageable host array)",
+                     "kernel_plus_copy_ms_last": hst.kernel_ms}
+
     launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # start -> end of one launch on its own stream
     # with two renders in flight consecutive launches overlap pairwise: the duration that prices a launch is then
     # the busy span of the device divided by the launches
@@ -244,16 +298,33 @@ def main():
 
         rays_launch = st["rays"] / args.steps
         steps_launch = (st["accepted_steps"] + st["rejected_steps"]) / args.steps
-        fm = flop_model()
-        if fm:
-            flops_launch = rays_launch * fm["flops_per_ray_fixed"] + steps_launch * fm["flops_per_step"]
-            flops_per_ray = flops_launch / rays_launch
-        else:
-            flops_per_ray = 3.0e5          # SURVEY §8(d) estimate until oracle/flopcount.json exists
-            flops_launch = rays_launch * flops_per_ray
-        achieved_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
         bytes_launch = rays_launch * 8.0   # fused render: 8 B written per ray, 0 B read
         achieved_gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        # ---- hardware fraction: FP64 flops the kernel EXECUTED (rocprofv3 counters of this very build, per ray)
+        #      x the rays this run launched / the launch duration measured live with HIP events ----
+        summ, src = profile_evidence(args.size, world)
+        if summ is not None:
+            ex_per_ray = summ["executed_fp64_flops_per_launch"] / summ["rays_per_launch"]
+            ex_tflops = rays_launch * ex_per_ray / (kernel_ms * 1e-3) / 1e12
+            traffic = summ.get("hbm_read_bytes_per_launch", 0.0) + summ.get("hbm_write_bytes_per_launch", 0.0)
+            executed = {"achieved": ex_tflops, "frac": ex_tflops / PEAK_FP64_VALU_TFLOPS, "flops_per_ray_executed": ex_per_ray,
+                        "valu_busy": summ["valu_busy"], "valu_insts_per_wave": summ.get("valu_insts_per_wave"),
+                        "profile": src, "profile_kernel": summ["kernel"], "profile_source_sha16": summ["source_sha16"],
+                        "profile_avg_ms": summ["avg_ms"], "profile_timed_calls": summ.get("timed_calls"),
+                        "traffic": traffic or None}
+        else:
+            sys.stderr.write(f"bench.py: roofline.frac withheld: {src}\n")
+            executed = {"achieved": None, "frac": None, "traffic": None, "profile": None, "profile_error": src}
+        fm = flop_model()
+        alg = None
+        if fm:
+            flops_launch = rays_launch * fm["flops_per_ray_fixed"] + steps_launch * fm["flops_per_step"]
+            alg_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
+            alg = {"flops_per_ray": flops_launch / rays_launch, "achieved": alg_tflops, "unit": "TFLOP/s-equivalent",
+                   "ratio_to_peak": alg_tflops / PEAK_FP64_VALU_TFLOPS,
+                   "note": "the launch priced at the flops of the REFERENCE formulation (oracle compiled on a counting "
+                           "scalar, oracle/flopcount.json): a throughput-equivalent figure, not a hardware fraction -- "
+                           "the kernel reaches the same results with about half of these flops"}
         line = {
             "metric": "geodesics/sec, 2048^2 Kerr image plane (fp64 null geodesics, redshift image)",
             "value": rays_per_s,
@@ -267,6 +338,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "value_definition": "device-resident: rays traced / wall time of the timed region, image left in HBM "
+                                "(N > 1: gathered onto rank 0 over RCCL inside the region); the blocking host call "
+                                "with the D2H copy that SURVEY §8(d) names is `host_call` beside it",
             "config": {
                 "workload": f"KerrMetric(a=0.998) {args.size}x{args.size} image plane, r_obs=1000, theta=75deg, "
                             "ThinDisc(r_isco,50), redshift∘filter_intersected, Tsit5 tol 1e-9, lambda_max=2000",
@@ -279,32 +353,32 @@ def main():
                 "steps_per_ray": steps_launch / rays_launch,
                 "rejected_steps_per_ray": st["rejected_steps"] / max(st["rays"], 1),
                 "status_count_rank0": st["status_count"],
+                "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
             },
             "roofline": {
                 "bound": "fp64-valu",
-                "note": "neither HBM nor MFMA binds this path (SURVEY §8d): the ODE state lives in registers; "
-                        "peak = FP64 vector ALU. `achieved` prices the launch at the ALGORITHMIC flops of the "
-                        "reference formulation (oracle on a counting scalar); `executed` is what the kernel "
-                        "really issues (rocprofv3 PMC). HBM fraction reported beside it.",
-                "achieved": achieved_tflops,
+                "note": "neither HBM nor MFMA binds this path (SURVEY §8d): the ODE state lives in registers; peak = FP64 "
+                        "vector ALU.  achieved = FP64 flops the kernel EXECUTED per ray (rocprofv3 SQ_INSTS_VALU_{FMA,MUL,"
+                        "ADD,TRANS}_F64 x 64 lanes x active-lane fraction, from the committed summary of this build) x "
+                        "rays per launch / launch duration measured here with HIP events.",
+                "achieved": executed["achieved"],
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP64_VALU_TFLOPS,
-                "flops_per_ray": flops_per_ray,
-                "flop_model": "oracle counting-scalar build" if fm else "SURVEY §8(d) estimate",
+                "frac": executed["frac"],
                 "kernel_ms": kernel_ms,
                 "launch_ms": launch_ms,
-                "traffic": (PROFILED_TRAFFIC_BYTES_PER_LAUNCH if (world == 1 and args.size == 2048) else None),
-                "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes of this workload committed under profiles/ "
-                                "(algorithmic: 8 B x rays = 33.6 MB; the excess is partial-line writes of scattered 8-B stores)",
-                "executed": {"flops_per_ray": EXECUTED_FLOPS_PER_RAY, "source": EXECUTED_SOURCE,
-                             "achieved": rays_launch * EXECUTED_FLOPS_PER_RAY / (kernel_ms * 1e-3) / 1e12,
-                             "frac": rays_launch * EXECUTED_FLOPS_PER_RAY / (kernel_ms * 1e-3) / 1e12
-                             / PEAK_FP64_VALU_TFLOPS, "valu_busy": EXECUTED_VALU_BUSY, "unit": "TFLOP/s"},
+                "traffic": executed["traffic"],
+                "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes); "
+                                "algorithmic: 8 B x rays",
+                "algorithmic_bytes": bytes_launch,
+                "executed": executed,
+                "algorithmic_equivalent": alg,
                 "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_ray": 8},
             },
         }
+        if host_call is not None:
+            line["host_call"] = host_call
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds)

@@ -14,6 +14,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GRADUS_MI355X_LIB selects another build of the same library (A/B timing of compiler flags)
 LIB_PATH = os.environ.get("GRADUS_MI355X_LIB") or os.path.join(_HERE, "csrc", "libgradus_mi355x.so")
 
+
+
+def kernel_source_sha16() -> str:
+    """sha256[:16] over the kernel sources of the library in this tree.  rocprofv3 summaries under profiles/ record
+    it, and bench.py refuses to price a launch with counters taken from a different build of the kernels."""
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    for rel in ("gradus.jl_amd/csrc/gr_device.hpp", "gradus.jl_amd/csrc/gr_kernels.hpp",
+                "gradus.jl_amd/csrc/gradus_mi355x.hip", "gradus.jl_amd/csrc/gradus_mi355x_f32.hip",
+                "include/gradus_mi355x.h"):
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 GR_OK = 0
 ERROR_NAMES = {
     -1: "GR_ERR_INVALID_ARGUMENT",

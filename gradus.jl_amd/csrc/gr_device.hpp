@@ -1084,7 +1084,11 @@ struct Ray {
     real t, dt, h;    // affine time, proposed step, last used step
     real cprev;       // disc condition at x
     real sth, cth;    // sin θ, cos θ at x (base of the stage rotations)
+#ifdef GR_CONTROLLER_F64
+    double lq_old;      // log2(qold)
+#else
     float lq_old;       // log2(qold)
+#endif
     int32_t ev_top;     // upper bracket j of Θ = j/7 when an event is pending
     int64_t j;          // local (swizzled) ray index
     int32_t status, flags;      // flags: GR_FLAG_* | RAY_EVENT in bits 0..15, TraceWindings count in bits 16..31
@@ -1253,7 +1257,7 @@ struct Ray {
         constrained_u0(m, p, jl, x, v);
         t = p.cfg.lambda0;
         h = 0.0;
-        lq_old = (float)LOG2_QOLDINIT;
+        lq_old = LOG2_QOLDINIT;
         real s, c;
         accel(m, x[1], x[2], v, A[0], s, c);
         sth = s; cth = c;
@@ -1300,8 +1304,13 @@ struct Ray {
             const real dm = GR_FMAX(d1, d2);
             // 10^(-(2 + log10 dm)/5) = 10^-0.4 dm^-0.2 ; single-precision hardware log2/exp2 is ample
             // for a starting step size
+#ifdef GR_CONTROLLER_F64
+            const real dt1 = (dm <= 1e-15) ? GR_FMAX(1e-6, dt0 * 1e-3)
+                                             : 0.39810717055349726 * (real)::exp2(-0.2 * ::log2((double)dm));
+#else
             const real dt1 = (dm <= 1e-15) ? GR_FMAX(1e-6, dt0 * 1e-3)
                                              : 0.39810717055349726 * (real)fast_exp2f(-0.2f * fast_log2f((float)dm));
+#endif
             dt = GR_FMIN(GR_FMIN(100.0 * dt0, dt1), dtmax);
         }
     }
@@ -1401,12 +1410,27 @@ struct Ray {
         // PI controller in log2 space: q = EEst^β1 / qold^β2 / γ.  The step factor is formed with
         // single-precision hardware log2/exp2 (relative error ~1e-6 in dt, far below anything the
         // 1e-9 tolerance can see; the reference's DiffEqBase.fastpow is itself Float32-based).
-        const float lE = 0.5f * fast_log2f((float)e2);       // log2(EEst); -inf when e2 underflows
+        // GR_CONTROLLER_F64 builds the same controller on double-precision log2/exp2 (A/B of the disc-rim
+        // classification against the oracle, scripts/controller_ab.py).
+#ifdef GR_CONTROLLER_F64
+        typedef double ctl_t;
+#define GR_CTL_LOG2(x) ::log2((double)(x))
+#define GR_CTL_EXP2(x) ::exp2((double)(x))
+#define GR_CTL_MIN(a, b) ::fmin((double)(a), (double)(b))
+#define GR_CTL_MAX(a, b) ::fmax((double)(a), (double)(b))
+#else
+        typedef float ctl_t;
+#define GR_CTL_LOG2(x) fast_log2f((float)(x))
+#define GR_CTL_EXP2(x) fast_exp2f((float)(x))
+#define GR_CTL_MIN(a, b) ::fminf((float)(a), (float)(b))
+#define GR_CTL_MAX(a, b) ::fmaxf((float)(a), (float)(b))
+#endif
+        const ctl_t lE = (ctl_t)0.5 * GR_CTL_LOG2(e2);       // log2(EEst); -inf when e2 underflows
         if (e2 <= 1.0) {
-            float qf = fast_exp2f((float)PI_BETA1 * lE - (float)PI_BETA2 * lq_old) * (float)(1.0 / PI_GAMMA);
-            qf = ::fmaxf((float)(1.0 / PI_QMAX), ::fminf((float)(1.0 / PI_QMIN), qf));   // e2 == 0 -> 1/qmax
+            ctl_t qf = GR_CTL_EXP2((ctl_t)PI_BETA1 * lE - (ctl_t)PI_BETA2 * (ctl_t)lq_old) * (ctl_t)(1.0 / PI_GAMMA);
+            qf = GR_CTL_MAX((ctl_t)(1.0 / PI_QMAX), GR_CTL_MIN((ctl_t)(1.0 / PI_QMIN), qf));   // e2 == 0 -> 1/qmax
             nacc++;
-            lq_old = ::fmaxf(lE, (float)LOG2_QOLDINIT);
+            lq_old = GR_CTL_MAX(lE, (ctl_t)LOG2_QOLDINIT);
             const real dtnew = hh * rcp_full((real)qf);
             real tnew = t + hh;
             if (GR_FABS(tnew - tend) < 100.0 * GR_EPS * GR_FMAX(GR_FABS(tnew), GR_FABS(tend))) tnew = tend;
@@ -1441,10 +1465,14 @@ struct Ray {
             // dt < dtmin: test for it here (rejected steps only, so the accepted path pays nothing)
             nrej++;
             if (!(e2 == e2)) { flags |= GR_FLAG_NAN; return true; }
-            const float q11 = fast_exp2f((float)PI_BETA1 * lE);
-            dt = hh / (real)::fminf((float)(1.0 / PI_QMIN), q11 * (float)(1.0 / PI_GAMMA));
+            const ctl_t q11 = GR_CTL_EXP2((ctl_t)PI_BETA1 * lE);
+            dt = hh / (real)GR_CTL_MIN((ctl_t)(1.0 / PI_QMIN), q11 * (ctl_t)(1.0 / PI_GAMMA));
             return false;
         }
+#undef GR_CTL_LOG2
+#undef GR_CTL_EXP2
+#undef GR_CTL_MIN
+#undef GR_CTL_MAX
     }
 
     // dense-output polynomial coefficients of component `comp` (0..3 position, 4..7 velocity):

@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgradus_oracle.so")
+# GRADUS_ORACLE_LIB selects another build of the same source (oracle/Makefile: nofma, asan)
+_LIB_PATH = os.environ.get("GRADUS_ORACLE_LIB") or os.path.join(_HERE, "libgradus_oracle.so")
 
 OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 1, 2, 3
 METRIC_KERR, METRIC_JOHANNSEN = 0, 1
