@@ -254,6 +254,7 @@ GR_DEV void inverse_generic(const real g[5], real gi[5])
 template <bool CHARGED>
 struct KerrFamily {
     static constexpr bool kHasForce = CHARGED;
+    static constexpr bool kFusedRhs = true;                    // rhs() below replaces eval() + the generic contraction
     static constexpr int kMinWavesPerSimd = CHARGED ? 2 : 1;   // Kerr fits 2 waves/SIMD on its own (182 VGPRs)
     real M, a;
     real Q, Q2, qm;      // CHARGED only: charge, its square, test-particle q (or q/μ)
@@ -336,6 +337,72 @@ struct KerrFamily {
         gi[4] = g[4] * iDs;
     }
 
+    // The whole right-hand side a^μ = -Γ^μ_{κλ} v^κ v^λ in one pass (metric_jacobian + inverse_metric_components +
+    // compute_geodesic_equation of auto-diff.jl:59-141,206-226 for this metric), without forming the ten derivative
+    // components.  With w = (2Mr - Q²)/Σ every component is g_tt = w - 1, g_tϕ = -a s² w, g_ϕϕ = s²(r² + a² + a² s² w),
+    // g_rr = Σ/Δ, g_θθ = Σ, so along the ray (ẋ = d/dλ, s² = sin²θ, (s²)˙ = 2 sc v^θ):
+    //   ġ_tt = ẇ,  ġ_tϕ = -a((s²)˙ w + s² ẇ),  ġ_ϕϕ = (s²)˙ B + s²(2r v^r - a ġ_tϕ),   B = r² + a² - a g_tϕ
+    //   D_r  = ∂_r g_μν v^μ v^ν = w_r U² + 2r(v_θ² + s² v_ϕ²) + ∂_r g_rr v_r²,          U = v^t - a s² v^ϕ
+    //   D_θ  = w_θ U² + 2sc [B v_ϕ² + a w v^ϕ (a s² v^ϕ - 2 v^t) - a²(v_θ² + v_r²/Δ)]
+    // and g^tt = -B/Δ, g^tϕ = g_tϕ/(Δ s²), g^ϕϕ = (1 - w)/(Δ s²) (g_tt g_ϕϕ - g_tϕ² = -Δ s²).  About 90 FP64
+    // instructions against ~125 for eval() + the generic contraction; same numbers up to rounding
+    // (tests/test_kernel_logic_host.py::test_fused_kerr_rhs_equals_generic_contraction).
+    GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
+                    real& at, real& ar, real& ah, real& ap) const
+    {
+        const real a2 = a * a, tM = 2.0 * M;
+        const real r2 = r * r, s2 = s * s, sc = s * c;
+        const real Sig = GR_FMA(a2, c * c, r2);
+        real Del = GR_FMA(-tM, r, r2) + a2;
+        if (CHARGED) Del += Q2;
+        const real Ds2 = Del * s2;
+        const real P = rcp_full(Sig * Ds2);
+        const real iSig = P * Ds2;           // 1/Σ
+        const real iDs = P * Sig;            // 1/(Δ sin²θ)
+        const real iDel = iDs * s2;          // 1/Δ
+        const real tr = 2.0 * r;
+        const real n = CHARGED ? GR_FMA(tM, r, -Q2) : tM * r;       // 2Mr - Q²
+        const real w = n * iSig;
+        const real w_r = GR_FMA(-tr, n, tM * Sig) * (iSig * iSig);  // (2M Σ - 2r n)/Σ²
+        const real mSig_t = (2.0 * a2) * sc;                        // -∂_θ Σ
+        const real w_t = (w * iSig) * mSig_t;                       // ∂_θ w = -w ∂_θΣ/Σ
+        // t-ϕ block
+        const real wd = GR_FMA(w_r, vr, w_t * vh);                  // ẇ
+        const real s2d = (2.0 * sc) * vh;                           // (s²)˙
+        const real q = a * s2;
+        const real gtp = -(q * w);                                  // g_tϕ
+        const real B = GR_FMA(-a, gtp, r2 + a2);
+        const real gtpd = -a * GR_FMA(s2d, w, s2 * wd);             // ġ_tϕ
+        const real gppd = GR_FMA(s2d, B, s2 * GR_FMA(tr, vr, -a * gtpd));   // ġ_ϕϕ
+        const real Tt = GR_FMA(wd, vt, gtpd * vp);
+        const real Tp = GR_FMA(gtpd, vt, gppd * vp);
+        const real gitp = gtp * iDs;                                // g^tϕ
+        const real gipp = (1.0 - w) * iDs;                          // g^ϕϕ
+        at = GR_FMA(B * iDel, Tt, -(gitp * Tp));                    // -(g^tt T_t + g^tϕ T_ϕ), g^tt = -B/Δ
+        ap = -GR_FMA(gitp, Tt, gipp * Tp);
+        // r equation
+        const real U = GR_FMA(-q, vp, vt);
+        const real U2 = U * U;
+        const real vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp;
+        const real grr = Sig * iDel;
+        const real grr_r = GR_FMA(-grr, tr - tM, tr) * iDel;        // ∂_r (Σ/Δ)
+        const real mSt_iDel = mSig_t * iDel;                        // -∂_θ g_rr
+        const real grrd = GR_FMA(grr_r, vr, -(mSt_iDel * vh));      // ġ_rr
+        const real Dr = GR_FMA(w_r, U2, GR_FMA(grr_r, vr2, tr * GR_FMA(s2, vp2, vh2)));
+        ar = -((Del * iSig) * GR_FMA(-0.5, Dr, grrd * vr));
+        // θ equation
+        const real W1 = GR_FMA(-2.0, vt, q * vp);                   // a s² v^ϕ - 2 v^t
+        real K = GR_FMA((a * w) * vp, W1, B * vp2);
+        K = GR_FMA(-a2, GR_FMA(vr2, iDel, vh2), K);
+        const real Dh = GR_FMA(w_t, U2, (2.0 * sc) * K);
+        const real ghhd = GR_FMA(tr, vr, -(mSig_t * vh));           // ġ_θθ = Σ˙
+        ah = -(iSig * GR_FMA(-0.5, Dh, ghhd * vh));
+        if (CHARGED) {
+            real gi[5] = { -(B * iDel), Del * iSig, iSig, gipp, gitp };
+            add_force(r, s, c, gi, vt, vr, vh, vp, at, ar, ah, ap);
+        }
+    }
+
     // q F^μ_κ v^κ, F = g⁻¹(∂A - ∂Aᵀ) (tracing/utility.jl:89-99), A = (rQ/Σ)(1, 0, 0, -a sin²θ)
     // (kerr-newman-ad.jl:29-33), added to the acceleration as in kerr-newman-ad.jl:66-100.
     // Hand-differentiated: with p = rQ/Σ, p_r = Q(Σ - 2r²)/Σ², p_θ = 2a² rQ sinθ cosθ/Σ².
@@ -371,6 +438,7 @@ typedef KerrFamily<true> KerrNewmanMetric;
 // and for f = ΣXW (W = 1/N²): ∂f = (∂Σ X + Σ ∂X) W - 2 f ∂N/N.
 struct JohannsenMetric {
     static constexpr bool kHasForce = false;
+    static constexpr bool kFusedRhs = false;
     static constexpr int kMinWavesPerSimd = 2;
     real M, a, a13, a22, a52, e3;
     GR_DEV void load(const gr_config& c)
@@ -461,6 +529,7 @@ struct GenericMetric {
     // scratch spills but keeps the VALU busy (measured: see DESIGN.md §5)
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
     static constexpr bool kHasForce = false;
+    static constexpr bool kFusedRhs = false;
     int32_t id;
     real P[6];
     GR_DEV void load(const gr_config& c)
@@ -714,8 +783,8 @@ struct GenericMetric {
 // point given by r and (sinθ, cosθ).  The factors 2 and -½ of the reference's form cancel:
 //   a^t = -(g^tt T_t + g^tϕ T_ϕ), a^r = -g^rr (ġ_rr v^r - ½ D_r), ... with T_t = ġ_tt v^t + ġ_tϕ v^ϕ.
 template <class Metric>
-GR_DEV void geodesic_rhs_sc(const Metric& m, real r, real s, real c, real vt, real vr, real vh, real vp,
-                            real& at, real& ar, real& ah, real& ap)
+GR_DEV void geodesic_rhs_generic(const Metric& m, real r, real s, real c, real vt, real vr, real vh, real vp,
+                                 real& at, real& ar, real& ah, real& ap)
 {
     real g[5], j1[5], j2[5], gi[5];
     m.eval(r, s, c, g, j1, j2, gi);
@@ -734,6 +803,20 @@ GR_DEV void geodesic_rhs_sc(const Metric& m, real r, real s, real c, real vt, re
     ah = -(gi[2] * Th);
     ap = -GR_FMA(gi[4], Tt, gi[3] * Tp);
     if constexpr (Metric::kHasForce) m.add_force(r, s, c, gi, vt, vr, vh, vp, at, ar, ah, ap);
+}
+
+// the right-hand side the integrator calls: the metric's own fused form where it has one
+template <class Metric>
+GR_DEV void geodesic_rhs_sc(const Metric& m, real r, real s, real c, real vt, real vr, real vh, real vp,
+                            real& at, real& ar, real& ah, real& ap)
+{
+#ifndef GR_NO_FUSED_RHS
+    if constexpr (Metric::kFusedRhs) {
+        m.rhs(r, s, c, vt, vr, vh, vp, at, ar, ah, ap);
+        return;
+    }
+#endif
+    geodesic_rhs_generic(m, r, s, c, vt, vr, vh, vp, at, ar, ah, ap);
 }
 
 template <class Metric>
@@ -1096,6 +1179,7 @@ struct Ray {
     real hdat;          // GR_DISC_DATUM: this ray's plane height (dead in every other instantiation)
 #ifdef GR_HOST_HARNESS
     real dbg_e2;
+    mutable int dbg_bits;   // per attempted step: bit s = stage s took the full sincos; 8 = event sampling past the reach bound; 9 = past the θ samples
 #endif
 
     // distance_to_disc(::DatumPlane), datum-plane.jl:6-10 ; distance_to_disc(::ThinDisc), thin-disc.jl:20-26 ; distance_to_disc(::AbstractThickAccretionDisc),
@@ -1315,12 +1399,21 @@ struct Ray {
         }
     }
 
+#ifdef GR_HOST_HARNESS
+#define GR_DBG_BIT(b) dbg_bits |= (b)
+#else
+#define GR_DBG_BIT(b)
+#endif
     // One attempted Tsit5 step.  Returns true when the ray has finished (terminated by a
     // callback, reached λ1, or hit an anomaly).
     GR_DEV bool step(const Metric& m, const Params& p)
     {
         const real tend = p.cfg.lambda1;
         const real dtmax = (real)p.dtmax;
+        GR_DBG_BIT(0);
+#ifdef GR_HOST_HARNESS
+        dbg_bits = 0;
+#endif
         if (nacc + nrej >= p.maxiters32) { flags |= GR_FLAG_MAXITERS; return true; }
         real hh = GR_FMIN(dt, dtmax);
         // one comparison on the common path: a NaN step size fails it as well and is told apart inside
@@ -1357,6 +1450,7 @@ struct Ray {
             ts = GR_FMA(h2, at, ts);                                                           \
         }                                                                                             \
         sincos_rot(x[2], sth, cth, ts, s, c);                                                         \
+        GR_DBG_BIT((GR_FABS(ts - x[2]) <= 0.0625) ? 0 : (1 << S));                                    \
         geodesic_rhs_sc(m, rs, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
     }
         GR_STAGE(1)
@@ -1378,12 +1472,23 @@ struct Ray {
             for (int q = 1; q < 5; ++q) ax = GR_FMA(TsD::X.AX[6][q], A[q][i], ax);
             xn[i] = GR_FMA(h2, ax, GR_FMA(TsD::X.C[6] * hh, v[i], x[i]));
         }
+        // sin/cos at the new state by rotating the step's base as well (the RHS at the new state is stage 7 and the
+        // base of the next step).  Rotation errors random-walk by ~1 ulp per step, so the base is re-synchronised
+        // with a full evaluation every 64 accepted steps (and whenever the rotation falls back to it anyway).
         real sn, cn;
+#ifndef GR_NO_ROT_FINAL
+        if ((nacc & 63) == 63) sincos_fast(xn[2], sn, cn);
+        else sincos_rot(x[2], sth, cth, xn[2], sn, cn);
+        geodesic_rhs_sc(m, xn[1], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);
+#else
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);
+#endif
 
-        // error estimate, squared RMS norm over all eight components
+        // error estimate, squared RMS norm over all eight components.  ũ_v = h Σ b̃_q A_q and ũ_x = h² Σ b̄_i A_i
+        // (the Σ b̃_j v term of the position error carries Σ b̃ = 1.4e-17 and is dropped: 1e-8 of the tolerance
+        // scale at most); the common factors h² and 1/8 are applied once to the sums.
         const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
-        real e2 = 0.0;
+        real e2v = 0.0, e2x = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             real ev = Ts::BT[0] * A[0][i];
@@ -1392,17 +1497,16 @@ struct Ray {
             real ex = TsD::X.BTX[0] * A[0][i];
 #pragma unroll
             for (int q = 1; q < 6; ++q) ex = GR_FMA(TsD::X.BTX[q], A[q][i], ex);
-            ex = GR_FMA(hh, ex, TsD::X.SBT * v[i]);
             const real skv = GR_FMA(GR_FMAX(GR_FABS(v[i]), GR_FABS(vn[i])), reltol, abstol);
             const real skx = GR_FMA(GR_FMAX(GR_FABS(x[i]), GR_FABS(xn[i])), reltol, abstol);
             // the bare v_rcp_f64 seed is good to 4.6e-8 (measured, scripts/rcp_accuracy.hip): ample for
             // a quantity that only feeds the step-size controller and the accept test
-            const real av = hh * ev * rcp_raw(skv);
-            const real ax = hh * ex * rcp_raw(skx);
-            e2 = GR_FMA(av, av, e2);
-            e2 = GR_FMA(ax, ax, e2);
+            const real av = ev * rcp_raw(skv);
+            const real ax = ex * rcp_raw(skx);
+            e2v = GR_FMA(av, av, e2v);
+            e2x = GR_FMA(ax, ax, e2x);
         }
-        e2 *= 0.125;   // EEst² ; accept iff EEst <= 1
+        real e2 = (0.125 * h2) * GR_FMA(h2, e2x, e2v);   // EEst² ; accept iff EEst <= 1
 #ifdef GR_HOST_HARNESS
         dbg_e2 = e2;
 #endif
@@ -1521,10 +1625,11 @@ struct Ray {
 #pragma unroll
             for (int i = 1; i < 6; ++i) amax = GR_FMAX(amax, GR_FABS(A[i][2]));
             const real reach = hh * (GR_FABS(v[2]) * DENSE_K1 + DENSE_K2 * hh * amax);
-            real d0 = x[2] - 1.5707963267948966;
-            d0 -= 3.141592653589793 * GR_RINT(d0 * 0.3183098861837907);
-            if (GR_FABS(d0) - reach > wedge) return 0;
+            // distance of θ from the equatorial plane (mod π) is asin|cosθ| >= |cosθ|, and cosθ of the step's base
+            // is at hand: |cosθ| - reach > wedge rules every sample out
+            if (GR_FABS(cth) - reach > wedge) return 0;
         }
+        GR_DBG_BIT(1 << 8);
         real Ct[4], Cr[4];
         dense_coeffs(2, hh, Ct);
         bool any = (ps < 0);
@@ -1536,6 +1641,7 @@ struct Ray {
                 any |= (GR_FABS(d) < wedge);
             }
             if (!any) return 0;
+            GR_DBG_BIT(1 << 9);
             dense_coeffs(1, hh, Cr);
         } else if (DISC == GR_DISC_DATUM || DISC == GR_DISC_PRECESSING_THIN || DISC == GR_DISC_ELLIPTICAL) {
             dense_coeffs(1, hh, Cr);      // no pre-filter: every sample is evaluated

@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(256) k_apply_pf(const Params p, const gr_point
 }
 
 
+#ifndef GR_NO_LAUNCHER      // scripts/kernel_probe.sh instantiates single kernels without the dispatch table
 // launch knobs handed over by the host side (gr_ctx is not visible here)
 struct LaunchKnobs {
     int kernel;              // 0 = lane, 1 = persistent
@@ -291,6 +292,7 @@ inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t 
     if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<GenericMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
     return launch_tmpl<GenericMetric, GR_DISC_NONE>(k, p, stream);
 }
+#endif  // GR_NO_LAUNCHER
 
 }  // namespace
 }  // namespace GR_NS

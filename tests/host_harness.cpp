@@ -55,7 +55,83 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
 #undef HH_RUN
 }
 
+// Lock-step emulation of one wave (64 rays of an 8x8 pixel tile): at wave iteration k every still-active lane does
+// its k-th attempted step, as the lanes of k_trace_lane do.  Counts, per wave-iteration, how often ANY lane takes a
+// divergent block (those blocks then cost the whole wave their instructions): full sincos per stage, event sampling
+// past the reach bound, past the θ samples.  out[0] = wave-iterations, out[1..5] = full-sincos stages 1..5,
+// out[6] = sampling level 1, out[7] = level 2, out[8] = lane-steps, out[9] = lane-level sum of level-1.
+template <class Metric, int DISC>
+static void wave_stats(const Params& p, const int64_t* tiles, int64_t n_tiles, double* out)
+{
+    Metric m;
+    m.load(p.cfg);
+    const Cold& cd = *p.cold;
+    const int64_t H = cd.plane.height;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        Ray<Metric, DISC> ray[64];
+        bool act[64];
+        const int64_t tiles_per_col = H >> 3;
+        const int64_t tx = tiles[t] / tiles_per_col, ty = tiles[t] - tx * tiles_per_col;
+        for (int l = 0; l < 64; ++l) {
+            const int64_t j = ((tx << 3) + (l >> 3)) * H + (ty << 3) + (l & 7);
+            ray[l].init(m, p, j);
+            act[l] = true;
+        }
+        for (;;) {
+            int bits = 0, nact = 0;
+            for (int l = 0; l < 64; ++l) {
+                if (!act[l]) continue;
+                ++nact;
+                if (ray[l].step(m, p)) act[l] = false;
+                bits |= ray[l].dbg_bits;
+                out[8] += 1.0;
+                if (ray[l].dbg_bits & (1 << 8)) out[9] += 1.0;
+            }
+            if (!nact) break;
+            out[0] += 1.0;
+            for (int s = 1; s <= 5; ++s) if (bits & (1 << s)) out[s] += 1.0;
+            if (bits & (1 << 8)) out[6] += 1.0;
+            if (bits & (1 << 9)) out[7] += 1.0;
+        }
+    }
+}
+
 extern "C" {
+
+int hh_wave_stats(const gr_config* cfg, const gr_plane* plane, const int64_t* tiles, int64_t n_tiles, double* out)
+{
+    Params p; Cold c;
+    std::memset(&p, 0, sizeof p); std::memset(&c, 0, sizeof c);
+    const int64_t n = plane->width * plane->height;
+    p.cfg = *cfg; p.n = n; p.cold = &c; c.winding_plane = cfg->winding_plane;
+    c.src_mode = 0; c.out_mode = 0; c.plane = *plane; c.range = gr_range{ 0, n, n, 1 };
+    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
+    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
+    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
+    p.cfg.upper_hemisphere = 0;
+    for (int i = 0; i < 10; ++i) out[i] = 0.0;
+    if (cfg->metric_id != GR_METRIC_KERR || cfg->disc_id != GR_DISC_THIN) return -1;
+    wave_stats<KerrMetric, GR_DISC_THIN>(p, tiles, n_tiles, out);
+    return 0;
+}
+
+// both forms of the right-hand side at one point: the metric's fused rhs() and eval() + the generic contraction
+int hh_rhs_both(const gr_config* cfg, double r, double th, const double* v, double* fused, double* generic)
+{
+    const double s = std::sin(th), c = std::cos(th);
+    if (cfg->metric_id == GR_METRIC_KERR) {
+        KerrMetric m; m.load(*cfg);
+        m.rhs(r, s, c, v[0], v[1], v[2], v[3], fused[0], fused[1], fused[2], fused[3]);
+        geodesic_rhs_generic(m, r, s, c, v[0], v[1], v[2], v[3], generic[0], generic[1], generic[2], generic[3]);
+    } else if (cfg->metric_id == GR_METRIC_KERR_NEWMAN) {
+        KerrNewmanMetric m; m.load(*cfg);
+        m.rhs(r, s, c, v[0], v[1], v[2], v[3], fused[0], fused[1], fused[2], fused[3]);
+        geodesic_rhs_generic(m, r, s, c, v[0], v[1], v[2], v[3], generic[0], generic[1], generic[2], generic[3]);
+    } else {
+        return -1;
+    }
+    return 0;
+}
 
 int hh_render_endpoints(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, gr_point* out)
 {

@@ -42,7 +42,9 @@ def test_reference_fingerprints_on_device(G, ens, kernel, name, params, disc, ex
     args = (G.ThinDisc(*disc), 200.0) if disc else (200.0,)
     _, _, img = G.rendergeodesics(m, X_SMOKE, *args, image_width=20, image_height=20, alpha_lims=(-9.5, 9.5),
                                   beta_lims=(-9.5, 9.5), ensemble=ens)
-    assert float(np.nansum(img)) == pytest.approx(expected, rel=1e-6)
+    # Morris-Thorne + thin disc: a few huge steps in a nearly flat exterior; the oracle's own fingerprint moves by
+    # 1.7e-6 / 8.9e-6 when its tolerance is nudged by -/+10 % (tests/test_kernel_logic_host.py), so 1e-5 there
+    assert float(np.nansum(img)) == pytest.approx(expected, rel=1e-5 if (name == "morris-thorne" and disc) else 1e-6)
 
 
 def _compare_points(G, O, got, ref, rtol=RTOL, median=1e-11):

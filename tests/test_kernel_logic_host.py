@@ -43,7 +43,10 @@ def _metric_by_name(G, name, params):
         ("morris-thorne", (1.0,), None, 402.17907632733284, 1e-4),
         ("bumblebee", (1.0, 0.0, 0.0), None, 9009.452384885506, 1e-6),
         ("kerr-newman", (1.0, 0.0, 0.0), None, 9009.451384824908, 1e-6),
-        ("morris-thorne", (1.0,), (0.0, 40.0), 9375.430228131403, 1e-6),
+        # the wormhole's exterior is nearly flat: a handful of huge steps, so the event time read off the 4th-order
+        # dense output depends on the step sequence at the 1e-5 level -- the ORACLE's own value moves from
+        # 9375.42973 (tol 1e-9) to 9375.41423 (0.9e-9) and 9375.34697 (1.1e-9); converged: 9375.3402
+        ("morris-thorne", (1.0,), (0.0, 40.0), 9375.430228131403, 1e-5),
         ("bumblebee", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.0832157869, 1e-6),
         ("kerr-newman", (1.0, 0.0, 0.0), (0.0, 40.0), 38412.08517225652, 1e-6),
     ],
@@ -132,6 +135,40 @@ def test_fast_sincos_and_metric_derivatives(G, oracle):
     np.testing.assert_allclose(got["v_init"], ref["v_init"], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(got["x"], ref["x"], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(got["v"], ref["v"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["kerr", "kerr-newman"])
+def test_fused_kerr_rhs_equals_generic_contraction(G, oracle, name):
+    """KerrFamily::rhs (the fused form the step loop calls) against eval() + the generic sparse contraction and against
+    the oracle's dual-number geodesic_equation, at random points and velocities (Kerr-Newman: incl. the Lorentz force)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(11)
+    L = Hh.lib()
+    worst_fg = worst_fo = 0.0
+    for _ in range(400):
+        M = rng.uniform(0.5, 1.5)
+        Q = rng.uniform(0.0, 0.3) * M if name == "kerr-newman" else 0.0
+        a = rng.uniform(-0.998, 0.998) * math.sqrt(M * M - Q * Q)
+        params = (M, a, Q) if name == "kerr-newman" else (M, a)
+        m = G.KerrNewmanMetric(*params) if name == "kerr-newman" else G.KerrMetric(*params)
+        r = 1.05 * m.inner_radius() + 10.0 ** rng.uniform(-1, 3)
+        th = rng.uniform(0.02, math.pi - 0.02)
+        v = np.array([rng.uniform(1, 2), rng.uniform(-1, 1), rng.uniform(-1, 1) / r, rng.uniform(-1, 1) / r])
+        q = 0.7 if name == "kerr-newman" else 0.0
+        cfg = G.tracing_configuration(m, np.array([0.0, r, th, 0.0]), v, None, (0.0, 1.0), q=q).abi_config()
+        fused, generic = np.zeros(4), np.zeros(4)
+        assert L.hh_rhs_both(C.byref(cfg), C.c_double(r), C.c_double(th), v.ctypes.data_as(C.c_void_p),
+                             fused.ctypes.data_as(C.c_void_p), generic.ctypes.data_as(C.c_void_p)) == 0
+        scale = np.abs(generic).max()
+        worst_fg = max(worst_fg, np.abs(fused - generic).max() / scale)
+        # the oracle's geodesic_equation is the force-free part: compare it with q = 0
+        cfg0 = G.tracing_configuration(m, np.array([0.0, r, th, 0.0]), v, None, (0.0, 1.0)).abi_config()
+        assert L.hh_rhs_both(C.byref(cfg0), C.c_double(r), C.c_double(th), v.ctypes.data_as(C.c_void_p),
+                             fused.ctypes.data_as(C.c_void_p), generic.ctypes.data_as(C.c_void_p)) == 0
+        ref = oracle.geodesic_equation(oracle.make_config(name, params), np.array([0.0, r, th, 0.0]), v)
+        worst_fo = max(worst_fo, np.abs(fused - ref).max() / np.abs(ref).max())
+    assert worst_fg < 2e-13 and worst_fo < 2e-13, (worst_fg, worst_fo)
 
 
 def test_kernel_logic_against_committed_golden_fixture(G):
