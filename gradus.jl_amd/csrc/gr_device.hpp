@@ -178,20 +178,20 @@ GR_DEV void sincos_fast(real x, real& s_out, real& c_out)
 }
 
 // sin and cos of θ0 + δ from (sin θ0, cos θ0) by rotation, for the Runge-Kutta stage points of
-// one step: |δ| <= 1/16 is the common case (99.4 % of steps) and needs two short Taylor
-// polynomials (truncation < 1e-17) and four FMAs, no range reduction and no quadrant logic.
-// Larger δ takes the full evaluation.
+// one step.  |δ| <= 1/32 covers every stage of 99 % of the steps of a WAVE at tolerance 1e-9 (the largest |δ| over
+// the 64 lanes is below 2^-5 in 99.05 % and below 2^-4 in all of the wave-steps of the bench image: tests/host_harness.cpp
+// hh_wave_stats) and needs two three-term polynomials (truncation 2.5e-18 / 2.3e-17, below half an ulp) and four
+// FMAs: no range reduction, no quadrant logic.  Larger δ takes the full evaluation.
+constexpr real SINCOS_ROT_MAX = 0.03125;
 GR_DEV void sincos_rot(real th0, real s0, real c0, real th, real& s_out, real& c_out)
 {
     const real d = th - th0;
-    if (GR_FABS(d) <= 0.0625) {
+    if (GR_FABS(d) <= SINCOS_ROT_MAX) {
         const real z = d * d;
-        real ps = GR_FMA(z, 2.7557319223985893e-06, -1.9841269841269841e-04);
-        ps = GR_FMA(z, ps, 8.3333333333333333e-03);
+        real ps = GR_FMA(z, -1.9841269841269841e-04, 8.3333333333333333e-03);
         ps = GR_FMA(z, ps, -1.6666666666666666e-01);
         const real sd = GR_FMA(d * z, ps, d);                    // sin δ
-        real pc = GR_FMA(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
-        pc = GR_FMA(z, pc, 4.1666666666666664e-02);
+        real pc = GR_FMA(z, -1.3888888888888889e-03, 4.1666666666666664e-02);
         pc = GR_FMA(z, pc, -0.5);
         const real cm1 = z * pc;                                        // cos δ - 1
         s_out = GR_FMA(c0, sd, GR_FMA(s0, cm1, s0));
@@ -255,7 +255,11 @@ template <bool CHARGED>
 struct KerrFamily {
     static constexpr bool kHasForce = CHARGED;
     static constexpr bool kFusedRhs = true;                    // rhs() below replaces eval() + the generic contraction
-    static constexpr int kMinWavesPerSimd = CHARGED ? 2 : 1;   // Kerr fits 2 waves/SIMD on its own (182 VGPRs)
+    static constexpr int kMinWavesPerSimd = CHARGED ? 2 : 1;   // persistent kernel: Kerr fits 2 waves/SIMD on its own
+    // one-ray-per-lane kernel: capped at 168 VGPRs = 3 waves/SIMD.  The few spilled values (36-68 B of scratch) live in
+    // the rarely executed event-sampling blocks, none on the step's main path; the third wave hides the dependent
+    // FP64 chains that two waves leave exposed: 22.95 -> 21.97 ms on the 2048² image (profiles/r2_ab_variants.txt)
+    static constexpr int kLaneWavesPerSimd = CHARGED ? 2 : 3;
     real M, a;
     real Q, Q2, qm;      // CHARGED only: charge, its square, test-particle q (or q/μ)
     GR_DEV void load(const gr_config& c)
@@ -344,8 +348,9 @@ struct KerrFamily {
     //   ġ_tt = ẇ,  ġ_tϕ = -a((s²)˙ w + s² ẇ),  ġ_ϕϕ = (s²)˙ B + s²(2r v^r - a ġ_tϕ),   B = r² + a² - a g_tϕ
     //   D_r  = ∂_r g_μν v^μ v^ν = w_r U² + 2r(v_θ² + s² v_ϕ²) + ∂_r g_rr v_r²,          U = v^t - a s² v^ϕ
     //   D_θ  = w_θ U² + 2sc [B v_ϕ² + a w v^ϕ (a s² v^ϕ - 2 v^t) - a²(v_θ² + v_r²/Δ)]
-    // and g^tt = -B/Δ, g^tϕ = g_tϕ/(Δ s²), g^ϕϕ = (1 - w)/(Δ s²) (g_tt g_ϕϕ - g_tϕ² = -Δ s²).  About 90 FP64
-    // instructions against ~125 for eval() + the generic contraction; same numbers up to rounding
+    // and g^tt = -B/Δ, g^tϕ = g_tϕ/(Δ s²), g^ϕϕ = (1 - w)/(Δ s²) (g_tt g_ϕϕ - g_tϕ² = -Δ s²).  The derivative of g_rr
+    // never appears on its own either: g^rr ½∂_r g_rr = r/Σ - (r - M)/Δ.  84 FP64 instructions against 95 for eval() + the
+    // generic contraction as the compiler leaves it (scripts/kernel_probe.sh); same numbers up to rounding
     // (tests/test_kernel_logic_host.py::test_fused_kerr_rhs_equals_generic_contraction).
     GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
                     real& at, real& ar, real& ah, real& ap) const
@@ -362,43 +367,42 @@ struct KerrFamily {
         const real iDel = iDs * s2;          // 1/Δ
         const real tr = 2.0 * r;
         const real n = CHARGED ? GR_FMA(tM, r, -Q2) : tM * r;       // 2Mr - Q²
+        const real wiS = n * (iSig * iSig);                         // w/Σ
         const real w = n * iSig;
-        const real w_r = GR_FMA(-tr, n, tM * Sig) * (iSig * iSig);  // (2M Σ - 2r n)/Σ²
+        const real hw_r = GR_FMA(-r, wiS, M * iSig);                // ½ ∂_r w = (MΣ - r n)/Σ²
         const real mSig_t = (2.0 * a2) * sc;                        // -∂_θ Σ
-        const real w_t = (w * iSig) * mSig_t;                       // ∂_θ w = -w ∂_θΣ/Σ
-        // t-ϕ block
-        const real wd = GR_FMA(w_r, vr, w_t * vh);                  // ẇ
-        const real s2d = (2.0 * sc) * vh;                           // (s²)˙
+        const real w_t = wiS * mSig_t;                              // ∂_θ w = -w ∂_θΣ/Σ
         const real q = a * s2;
+        const real U = GR_FMA(-q, vp, vt);                          // v^t - a s² v^ϕ
+        const real U2 = U * U;
+        const real vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp, vrvh = vr * vh;
+        // t-ϕ block:  T_t = ġ_tt v^t + ġ_tϕ v^ϕ = ẇ U - (a (s²)˙ w) v^ϕ ,  T_ϕ = ġ_tϕ U + ((s²)˙ B + 2 r s² v^r) v^ϕ
+        const real wd = GR_FMA(2.0 * hw_r, vr, w_t * vh);           // ẇ
+        const real s2d = (2.0 * sc) * vh;                           // (s²)˙
+        const real z1 = (a * s2d) * w;
         const real gtp = -(q * w);                                  // g_tϕ
         const real B = GR_FMA(-a, gtp, r2 + a2);
-        const real gtpd = -a * GR_FMA(s2d, w, s2 * wd);             // ġ_tϕ
-        const real gppd = GR_FMA(s2d, B, s2 * GR_FMA(tr, vr, -a * gtpd));   // ġ_ϕϕ
-        const real Tt = GR_FMA(wd, vt, gtpd * vp);
-        const real Tp = GR_FMA(gtpd, vt, gppd * vp);
+        const real gtpd = -GR_FMA(q, wd, z1);                       // ġ_tϕ
+        const real Tt = GR_FMA(wd, U, -(z1 * vp));
+        const real Tp = GR_FMA(gtpd, U, GR_FMA(s2d, B, (tr * s2) * vr) * vp);
         const real gitp = gtp * iDs;                                // g^tϕ
         const real gipp = (1.0 - w) * iDs;                          // g^ϕϕ
-        at = GR_FMA(B * iDel, Tt, -(gitp * Tp));                    // -(g^tt T_t + g^tϕ T_ϕ), g^tt = -B/Δ
+        const real BiD = B * iDel;                                  // -g^tt
+        at = GR_FMA(BiD, Tt, -(gitp * Tp));                         // -(g^tt T_t + g^tϕ T_ϕ)
         ap = -GR_FMA(gitp, Tt, gipp * Tp);
-        // r equation
-        const real U = GR_FMA(-q, vp, vt);
-        const real U2 = U * U;
-        const real vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp;
-        const real grr = Sig * iDel;
-        const real grr_r = GR_FMA(-grr, tr - tM, tr) * iDel;        // ∂_r (Σ/Δ)
-        const real mSt_iDel = mSig_t * iDel;                        // -∂_θ g_rr
-        const real grrd = GR_FMA(grr_r, vr, -(mSt_iDel * vh));      // ġ_rr
-        const real Dr = GR_FMA(w_r, U2, GR_FMA(grr_r, vr2, tr * GR_FMA(s2, vp2, vh2)));
-        ar = -((Del * iSig) * GR_FMA(-0.5, Dr, grrd * vr));
-        // θ equation
-        const real W1 = GR_FMA(-2.0, vt, q * vp);                   // a s² v^ϕ - 2 v^t
-        real K = GR_FMA((a * w) * vp, W1, B * vp2);
-        K = GR_FMA(-a2, GR_FMA(vr2, iDel, vh2), K);
-        const real Dh = GR_FMA(w_t, U2, (2.0 * sc) * K);
-        const real ghhd = GR_FMA(tr, vr, -(mSig_t * vh));           // ġ_θθ = Σ˙
-        ah = -(iSig * GR_FMA(-0.5, Dh, ghhd * vh));
+        // r equation: -g^rr (ġ_rr v^r - ½ D_r) with g^rr ½∂_r g_rr = r/Σ - (r - M)/Δ and ∂_θ g_rr = ∂_θΣ/Δ
+        const real girr = Del * iSig;
+        const real crr = GR_FMA(-r, iSig, (r - M) * iDel);
+        const real k1 = mSig_t * iSig;
+        const real in = GR_FMA(hw_r, U2, r * GR_FMA(s2, vp2, vh2));
+        ar = GR_FMA(girr, in, GR_FMA(k1, vrvh, crr * vr2));
+        // θ equation: -(1/Σ)(2 r v^r v^θ - sc X),  X = a²(v_θ² - v_r²/Δ + w U²/Σ) + B v_ϕ² + a w v^ϕ (a s² v^ϕ - 2 v^t)
+        const real W1 = GR_FMA(-2.0, vt, q * vp);
+        real X = GR_FMA((a * w) * vp, W1, B * vp2);
+        X = GR_FMA(a2, GR_FMA(wiS, U2, GR_FMA(-vr2, iDel, vh2)), X);
+        ah = iSig * GR_FMA(sc, X, -(tr * vrvh));
         if (CHARGED) {
-            real gi[5] = { -(B * iDel), Del * iSig, iSig, gipp, gitp };
+            real gi[5] = { -BiD, girr, iSig, gipp, gitp };
             add_force(r, s, c, gi, vt, vr, vh, vp, at, ar, ah, ap);
         }
     }
@@ -440,6 +444,7 @@ struct JohannsenMetric {
     static constexpr bool kHasForce = false;
     static constexpr bool kFusedRhs = false;
     static constexpr int kMinWavesPerSimd = 2;
+    static constexpr int kLaneWavesPerSimd = 2;
     real M, a, a13, a22, a52, e3;
     GR_DEV void load(const gr_config& c)
     {
@@ -528,6 +533,7 @@ struct GenericMetric {
     // the dual-number evaluation wants ~285 registers; capping it at 256 (2 waves/SIMD) costs a few
     // scratch spills but keeps the VALU busy (measured: see DESIGN.md §5)
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
+    static constexpr int kLaneWavesPerSimd = GR_GENERIC_MIN_WAVES;
     static constexpr bool kHasForce = false;
     static constexpr bool kFusedRhs = false;
     int32_t id;
@@ -1179,6 +1185,7 @@ struct Ray {
     real hdat;          // GR_DISC_DATUM: this ray's plane height (dead in every other instantiation)
 #ifdef GR_HOST_HARNESS
     real dbg_e2;
+    real dbg_dmax;          // per attempted step: largest |θ_stage - θ_base| (harness statistics)
     mutable int dbg_bits;   // per attempted step: bit s = stage s took the full sincos; 8 = event sampling past the reach bound; 9 = past the θ samples
 #endif
 
@@ -1401,8 +1408,10 @@ struct Ray {
 
 #ifdef GR_HOST_HARNESS
 #define GR_DBG_BIT(b) dbg_bits |= (b)
+#define GR_DBG_DMAX(d) dbg_dmax = GR_FMAX(dbg_dmax, (d))
 #else
 #define GR_DBG_BIT(b)
+#define GR_DBG_DMAX(d)
 #endif
     // One attempted Tsit5 step.  Returns true when the ray has finished (terminated by a
     // callback, reached λ1, or hit an anomaly).
@@ -1413,6 +1422,7 @@ struct Ray {
         GR_DBG_BIT(0);
 #ifdef GR_HOST_HARNESS
         dbg_bits = 0;
+        dbg_dmax = 0.0;
 #endif
         if (nacc + nrej >= p.maxiters32) { flags |= GR_FLAG_MAXITERS; return true; }
         real hh = GR_FMIN(dt, dtmax);
@@ -1450,7 +1460,8 @@ struct Ray {
             ts = GR_FMA(h2, at, ts);                                                           \
         }                                                                                             \
         sincos_rot(x[2], sth, cth, ts, s, c);                                                         \
-        GR_DBG_BIT((GR_FABS(ts - x[2]) <= 0.0625) ? 0 : (1 << S));                                    \
+        GR_DBG_BIT((GR_FABS(ts - x[2]) <= SINCOS_ROT_MAX) ? 0 : (1 << S));                                    \
+        GR_DBG_DMAX(GR_FABS(ts - x[2]));                                                              \
         geodesic_rhs_sc(m, rs, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
     }
         GR_STAGE(1)
@@ -1477,6 +1488,7 @@ struct Ray {
         // with a full evaluation every 64 accepted steps (and whenever the rotation falls back to it anyway).
         real sn, cn;
 #ifndef GR_NO_ROT_FINAL
+        GR_DBG_DMAX(GR_FABS(xn[2] - x[2]));
         if ((nacc & 63) == 63) sincos_fast(xn[2], sn, cn);
         else sincos_rot(x[2], sth, cth, xn[2], sn, cn);
         geodesic_rhs_sc(m, xn[1], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);

@@ -78,7 +78,7 @@ __device__ __forceinline__ void lds_epilogue(const Params& p, const LdsView& v)
 // ---- kernel 0: one ray per work-item ----
 template <class Metric, int DISC>
 #ifndef GR_LANE_MIN_WAVES
-#define GR_LANE_MIN_WAVES Metric::kMinWavesPerSimd
+#define GR_LANE_MIN_WAVES Metric::kLaneWavesPerSimd
 #endif
 __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Params p)
 {
@@ -99,8 +99,11 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
 }
 
 // ---- kernel 1: persistent grid with wave-ballot refill ----
+#ifndef GR_PERSISTENT_MIN_WAVES
+#define GR_PERSISTENT_MIN_WAVES Metric::kMinWavesPerSimd
+#endif
 template <class Metric, int DISC>
-__global__ void __launch_bounds__(256, Metric::kMinWavesPerSimd) k_trace_persistent(const Params p)
+__global__ void __launch_bounds__(256, GR_PERSISTENT_MIN_WAVES) k_trace_persistent(const Params p)
 {
     Metric m;
     m.load(p.cfg);

@@ -6,20 +6,42 @@
 #     using Gradus, GradusMI355X
 #     α, β, img = rendergeodesics(m, x, d, 2000.0; pf = pf, ensemble = EnsembleMI355X())
 #
-# All logic lives behind the C ABI (include/gradus_mi355x.h); this file only flattens Julia
-# structs into the POD structs and ccall's.  It cannot be exercised in the build container
-# (no Julia there); the same ABI is exercised from Python by the test-suite.
+# Two methods are added, nothing in Gradus' src/ changes:
+#
+#   Gradus.ensemble_solve_tracing_problem(::EnsembleMI355X, problem, config; ...)   src/tracing/tracing.jl:151-196
+#       the generic boundary: every caller that passes `ensemble = EnsembleMI355X()` (tracegeodesics,
+#       prerendergeodesics, lineprofile(BinningMethod), tracecorona, ...) gets a Vector{GeodesicPoint}
+#       traced on the device (gr_trace_endpoints / gr_render_endpoints).
+#   Gradus.render_into_image!(image, trace, config::TracingConfiguration{...,<:EnsembleMI355X}; pf) rendering.jl:89-101
+#       the fused path of rendergeodesics: when the velocity is the closure of _render_velocity_function
+#       (rendering.jl:140-163) and `pf` is one of the built-in point functions, pixels are turned into rays on
+#       the device and the point function is evaluated in the kernel (gr_render_multi: 8 B per ray leave the
+#       GPU instead of 152 B).  Anything else falls through to the generic method above plus Gradus' own
+#       apply_to_image!.
+#
+# What cannot cross the C ABI is detected and handed back to the CPU with a warning (SURVEY §8b): unknown metric or
+# geometry types, solvers other than Tsit5, user callbacks other than domain_upper_hemisphere, save_on = true.
+#
+# All logic lives behind the C ABI (include/gradus_mi355x.h); this file only flattens Julia structs into the POD
+# structs and ccall's.  It cannot be exercised in the build container (no Julia there); tests/test_julia_binding.py
+# parses this file and checks every struct mirror and every ccall signature against the C header and against the
+# ctypes binding that the GPU tests drive.
 module GradusMI355X
 
 using Gradus
 using Gradus: TracingConfiguration, EnsembleProblem, GeodesicPoint, StatusCodes, AbstractTrace,
-    KerrMetric, JohannsenMetric, ThinDisc, PolarChart, lnr_momentum_to_global_velocity_transform
+    KerrMetric, JohannsenMetric, ThinDisc, PolarChart, ConstPointFunctions, PointFunction
 using StaticArrays
+import SciMLBase
 
 export EnsembleMI355X, SampledThickDisc, render_mi355x, winding_numbers
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
+const ABI_VERSION = 3
 
+# ---------------------------------------------------------------------------------------------------------------
+# POD mirrors of include/gradus_mi355x.h (field order and types checked by tests/test_julia_binding.py)
+# ---------------------------------------------------------------------------------------------------------------
 struct GrConfig                      # == gr_config
     metric_id::Int32
     disc_id::Int32
@@ -63,7 +85,7 @@ end
 
 struct GrPlane                       # == gr_plane
     x_obs::NTuple{4,Float64}
-    Mx::NTuple{16,Float64}           # row-major ginv * hcat(lnrbasis(g)...)
+    Mx::NTuple{16,Float64}           # ROW-major ginv * hcat(lnrbasis(g)...): Mx[4(i-1)+k] = M[i,k]
     alpha0::Float64
     alpha1::Float64
     beta0::Float64
@@ -85,7 +107,19 @@ struct GrPointFunction               # == gr_pointfunction
     plunge_vphi::Ptr{Float64}
 end
 
+struct GrRange                       # == gr_range
+    first::Int64
+    count::Int64
+    block::Int64
+    stride_blocks::Int64
+end
+
 _check(rc) = rc == 0 || error(unsafe_string(ccall((:gr_last_error, LIB), Cstring, ())))
+
+"What the device cannot do: caught at the boundary and handed back to a CPU ensemble."
+struct UnsupportedOnDevice <: Exception
+    msg::String
+end
 
 """
     EnsembleMI355X(devices = [0])
@@ -98,7 +132,7 @@ mutable struct EnsembleMI355X
     ctxs::Vector{Ptr{Cvoid}}
     function EnsembleMI355X(devices = [0])
         abi = ccall((:gr_abi_version, LIB), Int32, ())
-        abi == 3 || error("GradusMI355X: libgradus_mi355x.so has ABI version $abi, this binding is written for 3")
+        abi == ABI_VERSION || error("GradusMI355X: libgradus_mi355x.so has ABI version $abi, this binding is written for $ABI_VERSION")
         ctxs = Ptr{Cvoid}[]
         for d in devices
             ref = Ref{Ptr{Cvoid}}(C_NULL)
@@ -112,6 +146,9 @@ mutable struct EnsembleMI355X
 end
 EnsembleMI355X(device::Integer) = EnsembleMI355X([device])
 
+# ---------------------------------------------------------------------------------------------------------------
+# Julia objects -> plain data
+# ---------------------------------------------------------------------------------------------------------------
 _metric(m::KerrMetric) = (Int32(0), (m.M, m.a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
 _metric(m::JohannsenMetric) = (Int32(1), (m.M, m.a, m.α13, m.α22, m.α52, m.ϵ3, 0.0, 0.0))
 _metric(m::MorrisThorneWormhole) = (Int32(2), (m.b, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
@@ -123,7 +160,7 @@ _metric(m::Gradus.SphericalMetric) = (Int32(7), (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0
 _metric(m::KerrDarkMatter) = (Int32(8), (m.M, m.a, m.M_dark_matter, m.Δr, m.rₛ, 0.0, 0.0, 0.0))
 _metric(m::KerrRefractive) = (Int32(9), (m.M, m.a, m.n, m.corona_radius, 0.0, 0.0, 0.0, 0.0))
 _metric(m::NoZMetric) = (Int32(10), (m.M, m.a, m.ϵ, 0.0, 0.0, 0.0, 0.0, 0.0))
-_metric(m) = error("GradusMI355X: metric $(typeof(m)) has no device implementation; use a CPU ensemble")
+_metric(m) = throw(UnsupportedOnDevice("metric $(typeof(m)) has no device implementation"))
 
 # (disc_id, disc_r_in, disc_r_out, disc_params)
 _disc(::Nothing) = (Int32(0), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
@@ -133,7 +170,7 @@ _disc(d::DatumPlane) = (Int32(4), 0.0, 0.0, (Float64(d.height), 0.0, 0.0, 0.0))
 _disc(d::EllipticalDisc) = (Int32(5), Float64(d.inner_radius), Inf, (Float64(d.semi_major), Float64(d.semi_minor), 0.0, 0.0))
 _disc(d::PrecessingDisc{T,<:ThinDisc}) where {T} =
     (Int32(6), Float64(d.disc.inner_radius), Float64(d.disc.outer_radius), (Float64(d.β), Float64(d.γ), cos(d.β), sin(d.β)))
-_disc(d) = error("GradusMI355X: geometry $(typeof(d)) has no device implementation; use a CPU ensemble")
+_disc(d) = throw(UnsupportedOnDevice("geometry $(typeof(d)) has no device implementation"))
 
 """
     SampledThickDisc(d::AbstractThickAccretionDisc, ρ_min, ρ_max; samples = 16384)
@@ -171,33 +208,104 @@ _disc_table(d::SampledThickDisc) = d.table
 _chart(c::PolarChart) = (Float64(c.inner_radius), Float64(c.outer_radius), Float64[], 0.0, 0.0)
 function _chart(c::Gradus.PoloidalShapeChart)
     θ = collect(Float64, c.shapefunc.t)
-    all(isapprox.(diff(θ), θ[2] - θ[1]; rtol = 1e-9)) || error("GradusMI355X: the chart's θ grid must be uniform")
+    all(isapprox.(diff(θ), θ[2] - θ[1]; rtol = 1e-9)) || throw(UnsupportedOnDevice("the chart's θ grid must be uniform"))
     tab = collect(Float64, c.shapefunc.u)
     (minimum(filter(!isnan, tab)), Float64(c.outer_radius), tab, θ[1], θ[end])
 end
+_chart(c) = throw(UnsupportedOnDevice("chart $(typeof(c)) has no device implementation"))
+
+# ---------------------------------------------------------------------------------------------------------------
+# What the reference leaves inside closures: gtol, the hemisphere callback, the trace
+# ---------------------------------------------------------------------------------------------------------------
+_closure_name(f) = String(nameof(typeof(f)))
+
+"""
+    _callbacks(config) -> (gtol, δ_or_nothing)
+
+`tracing_configuration(trace, m, x, v, geometry, ...; gtol, callback)` (src/geometry/bootstrap.jl:1-22) CONSUMES `gtol`
+and merges `geometry_collision_callback(geometry, trace; gtol)` -- a `ContinuousCallback` whose condition is the
+closure `_distance_to_disc_wrapper` over `(g, gtol)` (bootstrap.jl:43-60) -- into `config.callback` together with any
+user callback (`merge_callbacks`, src/tracing/callbacks.jl:13-23).  So for every trace with a disc `config.callback`
+is NOT nothing.  The geometry callback is what the device implements itself (from `config.geometry`); it is recognised
+here, `gtol` is read back out of its closure, and only what remains is a *user* callback:
+`domain_upper_hemisphere(δ)` (callbacks.jl:31-40, closure `_domain_upper_hemisphere_check` over `δ`) runs on the device,
+anything else is refused.
+"""
+function _callbacks(config::TracingConfiguration)
+    gtol = 1e-2          # bootstrap.jl:8 default; overwritten by what the geometry callback carries
+    δ = nothing
+    cb = config.callback
+    isnothing(cb) && return (gtol, δ)
+    conts, discs = if cb isa SciMLBase.CallbackSet
+        (cb.continuous_callbacks, cb.discrete_callbacks)
+    elseif cb isa SciMLBase.ContinuousCallback
+        ((cb,), ())
+    elseif cb isa SciMLBase.DiscreteCallback
+        ((), (cb,))
+    elseif cb isa Tuple
+        (filter(c -> c isa SciMLBase.ContinuousCallback, cb), filter(c -> c isa SciMLBase.DiscreteCallback, cb))
+    else
+        throw(UnsupportedOnDevice("callback of type $(typeof(cb))"))
+    end
+    seen_geometry = false
+    for c in conts
+        cond = c.condition
+        if !seen_geometry && !isnothing(config.geometry) && hasproperty(cond, :g) && hasproperty(cond, :gtol) &&
+           cond.g === config.geometry
+            gtol = Float64(cond.gtol)
+            seen_geometry = true
+        else
+            throw(UnsupportedOnDevice("a user ContinuousCallback ($(_closure_name(cond)))"))
+        end
+    end
+    for c in discs
+        cond = c.condition
+        if occursin("_domain_upper_hemisphere_check", _closure_name(cond)) && hasproperty(cond, :δ)
+            δ = Float64(cond.δ)
+        else
+            throw(UnsupportedOnDevice("a user DiscreteCallback ($(_closure_name(cond))); only domain_upper_hemisphere runs on the device"))
+        end
+    end
+    !isnothing(config.geometry) && config.geometry isa Gradus.AbstractAccretionDisc && !seen_geometry &&
+        throw(UnsupportedOnDevice("the geometry's collision callback was not found in config.callback"))
+    (gtol, δ)
+end
+
+"""
+    _trace_of(problem) -> AbstractTrace
+
+`solve_tracing_problem(problem, config; solver_opts...)` (tracing.jl:83-87) does not forward the trace; it lives in the
+problem builder that `assemble_tracing_problem` closed over (geodesic-problem.jl:141-150: `_problem_builder` captures
+`trace`, `config`, `cbs`; `wrap_arguments` :158-191 captures it as `_problem_func` in `prob_func`).  μ and q are read
+from there, not from keyword arguments that never arrive.
+"""
+function _trace_of(problem::EnsembleProblem)
+    pf = problem.prob_func
+    if hasproperty(pf, :_problem_func) && hasproperty(getproperty(pf, :_problem_func), :trace)
+        return getproperty(pf, :_problem_func).trace
+    end
+    throw(UnsupportedOnDevice("cannot recover the trace (μ, q) from the problem builder"))
+end
 
 # Returns the config and the arrays it points into (keep them alive for the duration of the call).
-function _config(config::TracingConfiguration, trace::AbstractTrace; gtol = 1e-2, maxiters = 1_000_000,
-        upper_hemisphere = nothing)
+function _config(config::TracingConfiguration, trace::AbstractTrace; maxiters = 1_000_000)
+    config.solver isa Gradus.Tsit5 || throw(UnsupportedOnDevice("solver $(typeof(config.solver)); the device integrates with Tsit5"))
+    trace isa Union{Gradus.TraceGeodesic,Gradus.TraceWindings} || throw(UnsupportedOnDevice("trace $(typeof(trace))"))
     id, params = _metric(config.metric)
     did, rin, rout, dparams = _disc(config.geometry)
     r_in, r_out, tab, θ0, θ1 = _chart(config.chart)
     dtab = _disc_table(config.geometry)
-    # SciML callbacks are opaque closures and cannot cross the ABI.  `domain_upper_hemisphere(δ)`
-    # (callbacks.jl:31-40) is implemented on the device: request it with the solver option
-    # `upper_hemisphere = δ` instead of `callback = domain_upper_hemisphere(δ)`; any other callback is refused.
-    isnothing(config.callback) || isnothing(upper_hemisphere) == false ||
-        error("GradusMI355X: callbacks cannot run on the device (use `upper_hemisphere = δ` for domain_upper_hemisphere)")
-    hemi = isnothing(upper_hemisphere) ? Int32(0) : Int32(1)
-    δ = isnothing(upper_hemisphere) ? 1e-4 : Float64(upper_hemisphere)
+    gtol, δ = _callbacks(config)
+    windings = trace isa Gradus.TraceWindings
+    q = hasproperty(trace, :q) ? Float64(trace.q) : 0.0
+    (q == 0.0 || config.metric isa KerrNewmanMetric) || throw(UnsupportedOnDevice("charged test particles outside Kerr-Newman"))
     cfg = GrConfig(id, did, params, r_in, r_out, rin, rout, gtol,
-        config.λ_domain[1], config.λ_domain[2], config.abstol, config.reltol, Float64(trace.μ),
-        maxiters, hemi, Int32(0), δ, dparams,
+        Float64(config.λ_domain[1]), Float64(config.λ_domain[2]), Float64(config.abstol), Float64(config.reltol),
+        Float64(trace.μ), maxiters,
+        isnothing(δ) ? Int32(0) : Int32(1), Int32(0), isnothing(δ) ? 1e-4 : δ, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1,
-        trace isa Gradus.TraceWindings ? 0.0 : Float64(trace.q),
-        trace isa Gradus.TraceWindings ? Int32(1) : Int32(0), Int32(0),
-        trace isa Gradus.TraceWindings ? Float64(trace.plane_inc) : π / 2)
+        q, windings ? Int32(1) : Int32(0), Int32(0), windings ? Float64(trace.plane_inc) : π / 2)
     cfg, (tab, dtab)
 end
 
@@ -211,75 +319,204 @@ winding_numbers(points::Vector{<:GeodesicPoint}) = GC.@preserve points [
     Int(unsafe_load(Ptr{UInt32}(pointer(points, i)) + 4) >> 16) for i in eachindex(points)
 ]
 
-# The drop-in method: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,
-# Nothing} is isbits with the layout of gr_point (152 bytes), so the result vector is filled in
-# place by the library.
+# ---------------------------------------------------------------------------------------------------------------
+# The render closure and the built-in point functions, recognised structurally
+# ---------------------------------------------------------------------------------------------------------------
+"""
+    _render_plane(config) -> GrPlane or nothing
+
+`_render_velocity_function` (rendering.jl:140-163) returns the closure `velfunc(i)` over `αs`, `βs`, `image_height`,
+`xfm`, `position`.  Its ranges give back `αlims`, `βlims`, `W`, `H`; `Mx = inv(g) * hcat(lnrbasis(g)...)` is what
+`lnr_momentum_to_global_velocity_transform` built (tracing/utility.jl:32-40).  Julia matrices are column-major, the ABI
+wants `Mx` row-major: hence `permutedims`.
+"""
+function _render_plane(config::TracingConfiguration)
+    v = config.velocity
+    (v isa Function && hasproperty(v, :αs) && hasproperty(v, :βs) && hasproperty(v, :image_height)) || return nothing
+    x = config.position
+    x isa SVector{4} || return nothing
+    αs, βs = v.αs, v.βs
+    H = Int64(v.image_height)
+    (length(βs) == H && length(αs) * H == config.trajectories) || return nothing
+    g = Gradus.metric(config.metric, x)
+    Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
+    GrPlane(Tuple(Float64.(x)), Tuple(Float64.(permutedims(Mx))), Float64(first(αs)), Float64(last(αs)),
+        Float64(first(βs)), Float64(last(βs)), Int64(length(αs)), H, 1e-6)
+end
+
+const _AFFINE_F = typeof(ConstPointFunctions.affine_time().f)
+const _EARLY_F = typeof(ConstPointFunctions.filter_early_term().f)
+const _INTERSECTED_F = typeof(ConstPointFunctions.filter_intersected().f)
+
+# base function -> (pf_id, r_isco, plunging table or nothing)
+function _builtin_base(f, m)
+    f isa _AFFINE_F && return (Int32(0), 0.0, nothing)
+    if f === Gradus._redshift_guard
+        # redshift(::KerrMetric, _) = PointFunction(_redshift_guard) (const-point-functions.jl:76): analytic plunge
+        m isa KerrMetric || return nothing
+        return (Int32(1), Float64(Gradus.isco(m)), nothing)
+    end
+    if hasproperty(f, :plunging_interpolation) && hasproperty(f, :isco)
+        # _interpolate_redshift_closure (redshift.jl:246-276): PlungingInterpolation holds three NaNLinearInterpolators
+        # over the same radii (orbit-solving.jl:99-131, interpolations.jl:1-45)
+        pintrp = f.plunging_interpolation
+        pintrp.m == m || return nothing
+        tab = (collect(Float64, pintrp.t.t), collect(Float64, pintrp.t.u), collect(Float64, pintrp.r.u), collect(Float64, pintrp.ϕ.u))
+        return (Int32(1), Float64(f.isco), tab)
+    end
+    nothing
+end
+
+"""
+    _builtin_pf(pf, m) -> (GrPointFunction, keepalive) or nothing
+
+Recognises `affine_time`, `redshift(m, x)` (Kerr: analytic; other metrics: `interpolate_redshift`) on their own or
+composed with `filter_early_term` / `filter_intersected` through `∘` (point-functions.jl:107-120: the composite is a
+`PointFunction` over a closure with fields `f1`, `f2`, `pf2`).  `shadow()` is `affine_time() ∘ filter_early_term()`.
+"""
+function _builtin_pf(pf, m)
+    pf isa PointFunction || return nothing
+    f = pf.f
+    base, filter_id, fill = f, Int32(0), NaN
+    if hasproperty(f, :f1) && hasproperty(f, :f2) && hasproperty(f, :pf2)
+        filter_id = f.f2 isa _EARLY_F ? Int32(1) : f.f2 isa _INTERSECTED_F ? Int32(2) : return nothing
+        fill = Float64(f.pf2.default)
+        base = f.f1
+    end
+    b = _builtin_base(base, m)
+    isnothing(b) && return nothing
+    pf_id, r_isco, tab = b
+    if isnothing(tab)
+        return (GrPointFunction(pf_id, filter_id, fill, r_isco, 0, C_NULL, C_NULL, C_NULL, C_NULL), nothing)
+    end
+    (GrPointFunction(pf_id, filter_id, fill, r_isco, length(tab[1]), pointer(tab[1]), pointer(tab[2]), pointer(tab[3]),
+        pointer(tab[4])), tab)
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# The generic boundary: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,Nothing} is isbits
+# with the layout of gr_point (152 bytes), so the result vector is filled in place by the library.
+# ---------------------------------------------------------------------------------------------------------------
+function _cpu_fallback(reason, problem, config; kwargs...)
+    @warn "EnsembleMI355X: $reason -- tracing on the CPU with EnsembleEndpointThreads instead"
+    Gradus.ensemble_solve_tracing_problem(Gradus.EnsembleEndpointThreads(), problem, config; kwargs...)
+end
+
 function Gradus.ensemble_solve_tracing_problem(
     ensemble::EnsembleMI355X,
     problem::EnsembleProblem,
-    config::TracingConfiguration{Float64};
+    config::TracingConfiguration{T};
     progress_bar = nothing,
     save_on = false,
-    trace = Gradus.TraceGeodesic(),
-    gtol = 1e-2,
-    upper_hemisphere = nothing,
+    maxiters = 1_000_000,               # OrdinaryDiffEq's default for adaptive solvers
     solver_opts...,
-)
-    save_on && error("Cannot use `EnsembleMI355X` with `save_on`")
-    isnothing(progress_bar) || @warn "Progress meter is not supported by EnsembleMI355X."
+) where {T}
+    save_on && error("Cannot use `EnsembleMI355X` with `save_on`")       # as tracing.jl:159-161 for EnsembleEndpointThreads
+    isnothing(progress_bar) || @warn "Progress meter is not supported by EnsembleMI355X." maxlog = 1
     N = config.trajectories
-    # unconstrained initial velocities: evaluate the (arbitrary) Julia velocity closure on the
-    # host; constrain_all is applied on the device
-    xs = config.position isa SVector ? [config.position] : config.position
-    vs = config.velocity isa Function ? [config.velocity(i) for i = 1:N] : config.velocity
-    cfg_val, keep = _config(config, trace; gtol = gtol, upper_hemisphere = upper_hemisphere)
+    local cfg_val, keep
+    try
+        T === Float64 || throw(UnsupportedOnDevice("number type $T; the boundary carries Float64"))
+        isempty(solver_opts) || throw(UnsupportedOnDevice("solver options $(keys(solver_opts))"))
+        cfg_val, keep = _config(config, _trace_of(problem); maxiters = maxiters)
+    catch e
+        e isa UnsupportedOnDevice || rethrow()
+        return _cpu_fallback(e.msg, problem, config; progress_bar, save_on, maxiters, solver_opts...)
+    end
     cfg = Ref(cfg_val)
     out = Vector{GeodesicPoint{Float64,Nothing}}(undef, N)
     @assert sizeof(eltype(out)) == 152
     stats = Ref{GrStats}()
-    rc = GC.@preserve keep xs vs ccall((:gr_trace_endpoints, LIB), Int32,
+    plane = _render_plane(config)
+    if !isnothing(plane)
+        # the pixel -> velocity closure of rendergeodesics / prerendergeodesics: rays are made on the device
+        pl = Ref(plane)
+        rg = Ref(GrRange(0, N, max(N, 1), 1))
+        _check(GC.@preserve keep out ccall((:gr_render_endpoints, LIB), Int32,
+            (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrPlane}, Ref{GrRange}, Ptr{Cvoid}, Ref{GrStats}),
+            ensemble.ctxs[1], cfg, pl, rg, out, stats))
+        return out
+    end
+    # arbitrary velocity closures are evaluated on the host (UNCONSTRAINED: constrain_all runs on the device with
+    # the trace's μ); (xs, vs) arrays are passed through
+    xs = config.position isa SVector ? [SVector{4,Float64}(config.position)] : Vector{SVector{4,Float64}}(config.position)
+    vs = config.velocity isa Function ? SVector{4,Float64}[config.velocity(i) for i = 1:N] :
+         Vector{SVector{4,Float64}}(config.velocity)
+    _check(GC.@preserve keep xs vs out ccall((:gr_trace_endpoints, LIB), Int32,
         (Ptr{Cvoid}, Ref{GrConfig}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}, Ref{GrStats}),
-        ensemble.ctxs[1], cfg, reinterpret(Float64, xs), length(xs) == 1 ? 0 : 4, reinterpret(Float64, vs), N, out, stats)
-    _check(rc)
+        ensemble.ctxs[1], cfg, reinterpret(Float64, xs), length(xs) == 1 ? 0 : 4, reinterpret(Float64, vs), N, out, stats))
     out
 end
 
-# ---- fused fast path: rendergeodesics with a recognised built-in point function -------------------
-# `render_into_image!` (src/rendering/rendering.jl:89-101) receives the configuration whose velocity
-# is the closure of `_render_velocity_function` (rendering.jl:140-163); its captured variables give
-# αlims/βlims/W/H back, and `Mx` is what `lnr_momentum_to_global_velocity_transform` builds.
-"""
-    BuiltinPF(pf_id, filter_id)
-
-Tag for the point functions the kernels evaluate themselves: `pf_id` 0 = affine_time, 1 = redshift;
-`filter_id` 0 = none, 1 = filter_early_term, 2 = filter_intersected.  `render_mi355x` below is what
-`rendergeodesics(...; ensemble = EnsembleMI355X(...), pf = BuiltinPF(1, 2))` dispatches to.
-"""
-struct BuiltinPF
-    pf_id::Int32
-    filter_id::Int32
+# ---------------------------------------------------------------------------------------------------------------
+# The fused path of rendergeodesics: render_into_image! (rendering.jl:89-101) specialised on the ensemble type, which
+# TracingConfiguration carries as its 9th type parameter (configuration.jl:3-16,57).
+# ---------------------------------------------------------------------------------------------------------------
+function Gradus.render_into_image!(
+    image,
+    trace::AbstractTrace,
+    config::TracingConfiguration{T,<:Any,<:Any,<:Any,<:Any,<:Any,<:Any,<:Any,<:EnsembleMI355X};
+    pf = ConstPointFunctions.shadow(T),       # == the reference's default: affine_time ∘ (λ_max < max_time), NaN
+    solver_opts...,
+) where {T}
+    ens = config.ensemble
+    fused = nothing
+    # what reaches here besides `pf`: `save_on = false` (render_configuration, rendering.jl:20) and `verbose`
+    plain = all(k -> k === :verbose || (k === :save_on && solver_opts[k] == false), keys(solver_opts))
+    if T === Float64 && image isa Matrix{Float64} && plain
+        try
+            plane = _render_plane(config)
+            bpf = _builtin_pf(pf, config.metric)
+            if !isnothing(plane) && !isnothing(bpf) && size(image) == (plane.height, plane.width)
+                cfg_val, keep = _config(config, trace)
+                fused = (cfg_val, keep, plane, bpf)
+            end
+        catch e
+            e isa UnsupportedOnDevice || rethrow()
+        end
+    end
+    if isnothing(fused)
+        # user-defined point functions, Float32 configurations, ...: device-traced end points (the generic method
+        # above) + Gradus' own apply_to_image!
+        return invoke(Gradus.render_into_image!, Tuple{Any,AbstractTrace,TracingConfiguration}, image, trace, config;
+            pf = pf, solver_opts...)
+    end
+    cfg_val, keep, plane, (gpf, keep_pf) = fused
+    cfg, pl, pfr = Ref(cfg_val), Ref(plane), Ref(gpf)
+    stats = Vector{GrStats}(undef, length(ens.ctxs))
+    # image is the column-major H x W matrix of rendering.jl:50: ray i = (x-1) H + y is image[i], the order the
+    # library writes; block_cols = 0 lets it pick the deal of columns over the ensemble's devices
+    _check(GC.@preserve keep keep_pf image ccall((:gr_render_multi, LIB), Int32,
+        (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Int64, Ptr{Float64}, Ptr{GrStats}),
+        ens.ctxs, length(ens.ctxs), cfg, pl, pfr, 0, image, stats))
+    image
 end
 
+# ---------------------------------------------------------------------------------------------------------------
+# The same fused call without going through Gradus' configuration machinery (scripts, benchmarks)
+# ---------------------------------------------------------------------------------------------------------------
 function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λmax; image_width, image_height,
-        αlims, βlims, pf::BuiltinPF = BuiltinPF(0, 1), gtol = 1e-2, abstol = 1e-9, reltol = 1e-9,
-        chart = Gradus.chart_for_metric(m), q = 0.0)
+        αlims, βlims, pf = ConstPointFunctions.shadow(), gtol = 1e-2, abstol = 1e-9, reltol = 1e-9,
+        chart = Gradus.chart_for_metric(m), μ = 0.0, q = 0.0)
     id, params = _metric(m)
     did, rin, rout, dparams = _disc(d)
     r_in, r_out, tab, θ0, θ1 = _chart(chart)
     dtab = _disc_table(d)
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
-        abstol, reltol, 0.0, 1_000_000, Int32(0), Int32(0), 1e-4, dparams,
+        abstol, reltol, Float64(μ), 1_000_000, Int32(0), Int32(0), 1e-4, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q), Int32(0), Int32(0), π / 2))
     g = Gradus.metric(m, x)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
-    plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), αlims[1], αlims[2], βlims[1], βlims[2],
-        image_width, image_height, 1e-6))
-    r_isco = pf.pf_id == 1 ? Float64(Gradus.isco(m)) : 0.0
-    pfs = Ref(GrPointFunction(pf.pf_id, pf.filter_id, NaN, r_isco, 0, C_NULL, C_NULL, C_NULL, C_NULL))
+    plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), Float64(αlims[1]), Float64(αlims[2]), Float64(βlims[1]),
+        Float64(βlims[2]), image_width, image_height, 1e-6))
+    bpf = _builtin_pf(pf, m)
+    isnothing(bpf) && error("render_mi355x: `pf` is not one of the built-in point functions the kernels evaluate")
+    gpf, keep_pf = bpf
+    pfs = Ref(gpf)
     image = zeros(Float64, (image_height, image_width))             # rendering.jl:50, column-major H x W
     stats = Vector{GrStats}(undef, length(ensemble.ctxs))
-    _check(GC.@preserve tab dtab ccall((:gr_render_multi, LIB), Int32,
+    _check(GC.@preserve tab dtab keep_pf ccall((:gr_render_multi, LIB), Int32,
         (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Int64, Ptr{Float64}, Ptr{GrStats}),
         ensemble.ctxs, length(ensemble.ctxs), cfg, plane, pfs, 0, image, stats))
     α, β = Gradus.impact_axes(image_width, image_height, αlims, βlims)

@@ -79,11 +79,13 @@ static void wave_stats(const Params& p, const int64_t* tiles, int64_t n_tiles, d
         }
         for (;;) {
             int bits = 0, nact = 0;
+            double dmax = 0.0;
             for (int l = 0; l < 64; ++l) {
                 if (!act[l]) continue;
                 ++nact;
                 if (ray[l].step(m, p)) act[l] = false;
                 bits |= ray[l].dbg_bits;
+                dmax = std::fmax(dmax, (double)ray[l].dbg_dmax);
                 out[8] += 1.0;
                 if (ray[l].dbg_bits & (1 << 8)) out[9] += 1.0;
             }
@@ -92,6 +94,10 @@ static void wave_stats(const Params& p, const int64_t* tiles, int64_t n_tiles, d
             for (int s = 1; s <= 5; ++s) if (bits & (1 << s)) out[s] += 1.0;
             if (bits & (1 << 8)) out[6] += 1.0;
             if (bits & (1 << 9)) out[7] += 1.0;
+            // histogram of the wave's largest |δ| in this iteration: out[10 + k] counts 2^-(k+1) < dmax <= 2^-k, k = 0..23
+            int k = dmax > 0.0 ? (int)std::floor(-std::log2(dmax)) : 23;
+            k = k < 0 ? 0 : (k > 23 ? 23 : k);
+            out[10 + k] += 1.0;
         }
     }
 }
@@ -109,7 +115,7 @@ int hh_wave_stats(const gr_config* cfg, const gr_plane* plane, const int64_t* ti
     p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
     p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
     p.cfg.upper_hemisphere = 0;
-    for (int i = 0; i < 10; ++i) out[i] = 0.0;
+    for (int i = 0; i < 34; ++i) out[i] = 0.0;
     if (cfg->metric_id != GR_METRIC_KERR || cfg->disc_id != GR_DISC_THIN) return -1;
     wave_stats<KerrMetric, GR_DISC_THIN>(p, tiles, n_tiles, out);
     return 0;
