@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 evidence for every kernel of DESIGN.md §5's table: scripts/profile_all.sh <round tag, e.g. r2>
+# -> gpurun_out/prof_<tag>_<workload>/{summary.json,kernel_stats.csv}; copy those into profiles/ to commit them.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+T=${1:-r2}
+cd $R
+bash scripts/profile_pmc.sh ${T}_head
+PROF_CMD="scripts/sibling_workloads.py c4" PROF_KERNEL="k_trace_lane<gr::JohannsenMetric" bash scripts/profile_pmc.sh ${T}_c4
+PROF_CMD="scripts/sibling_workloads.py generic" PROF_KERNEL="k_trace_lane<gr::GenericMetric" bash scripts/profile_pmc.sh ${T}_generic
+PROF_CMD="scripts/sibling_workloads.py c5" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_c5
+PROF_CMD="scripts/sibling_workloads.py c5p" PROF_KERNEL="k_trace_persistent<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_c5p
+PROF_F32=1 PROF_CMD="scripts/sibling_workloads.py c5f32" PROF_KERNEL="gr32::" bash scripts/profile_pmc.sh ${T}_c5f32
+PROF_CMD="scripts/sibling_workloads.py applypf" PROF_KERNEL="k_apply_pf" bash scripts/profile_pmc.sh ${T}_applypf
+PROF_CMD="scripts/sibling_workloads.py endpoints" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_endpoints
+# drop the bulky raw traces, keep summaries
+for d in gpurun_out/prof_${T}_*; do rm -rf $d/trace $d/pmcA $d/pmcB $d/pmcC $d/pmcD; done

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""The kernels beside the headline one, each as a small loop of launches for rocprofv3 (scripts/profile_pmc.sh with
+PROF_CMD="scripts/sibling_workloads.py <which>" PROF_KERNEL=<substring of the kernel name>):
+
+    c4        JohannsenMetric(a=0.7, α13=2, ϵ3=1) 1024², ThinDisc(isco, 50), interpolated redshift   k_trace_lane<JohannsenMetric,1>
+    generic   JohannsenPsaltisMetric(a=0.7, ϵ3=1) 1024², ThinDisc, shadow (dual-number functor)       k_trace_lane<GenericMetric,1>
+    c5        BASELINE config 5 line profile, 4096² polar-plane rays, fp64 tol 1e-9                  k_trace_lane<KerrFamily<false>,1> (tiled rays)
+    c5p       the same through the persistent kernel                                                  k_trace_persistent<...>
+    c5f32     config 5 with the fp32 kernels at tol 1e-5                                              gr32::k_trace_*
+    applypf   apply(pf, cache) on the 2048² end points of the bench plane                             k_apply_pf
+    endpoints gr_render_endpoints_device, 2048² Kerr (152-B records)                                  k_trace_lane<KerrFamily<false>,1>
+
+Prints one JSON line {"rays": rays per launch, "launches": n, ...} (bench.log of the profile run); the first 2
+launches are warm-up, like bench.py's.
+"""
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import gradus_jl_amd as G
+
+which = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ens = G.EnsembleMI355X(0)
+ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
+ms = []
+extra = {}
+
+if which in ("c4", "generic"):
+    if which == "c4":
+        m = G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0)
+        x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+        pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
+    else:
+        m = G.JohannsenPsaltisMetric(1.0, 0.7, 1.0)
+        x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+        pf = G.ConstPointFunctions.shadow()
+    S = 1024
+    for _ in range(reps):
+        _, _, img, st = G.rendergeodesics(m, x, G.ThinDisc(m.isco(), 50.0), 2000.0, image_width=S, image_height=S,
+                                          alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens, stats=True)
+        ms.append(st["kernel_ms"])
+    rays = S * S
+elif which in ("c5", "c5p", "c5f32"):
+    m = G.KerrMetric(1.0, 0.998)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    d = G.ThinDisc(m.isco(), 250.0)
+    N = 4096
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=N, Nθ=N, r_min=1.0, r_max=250.0)
+    bins = np.linspace(0.1, 1.5, 180)
+    tol = 1e-9
+    if which == "c5p":
+        ens.set("kernel", 1)
+    if which == "c5f32":
+        ens.set("precision", 32)
+        tol = 1e-5
+    for _ in range(reps):
+        xs, ys, st = G.lineprofile(bins, G.PowerLawEmissivity(3), m, u, d, G.BinningMethod(), plane=plane, maxrₑ=250.0,
+                                   ensemble=ens, stats=True, abstol=tol, reltol=tol)
+        ms.append(st["kernel_ms"])
+    rays = N * N
+    extra = {"tol": tol, "steps_per_ray": st["accepted_steps"] / st["rays"]}
+elif which in ("applypf", "endpoints"):
+    import torch
+
+    from gradus_jl_amd import _lib
+    from gradus_jl_amd import device as gdev
+    import ctypes as C
+    from gradus_jl_amd.rendering import abi_pointfunction
+
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(75), 0.0])
+    pf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+    S = 2048
+    cfg = G.render_configuration(m, x, G.ThinDisc(m.isco(), 50.0), 2000.0, image_width=S, image_height=S, alpha_lims=ALIMS,
+                                 beta_lims=BLIMS, ensemble=ens)
+    dev = torch.device("cuda", 0)
+    n = S * S
+    raw = torch.empty(n * 152, dtype=torch.uint8, device=dev)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    acfg = cfg.abi_config()
+    apf, keep = abi_pointfunction(pf)
+    L = _lib.load()
+    if which == "endpoints":
+        for i in range(reps):
+            ev[i][0].record()
+            gdev.render_endpoints_device(cfg, raw)
+            ev[i][1].record()
+    else:
+        gdev.render_endpoints_device(cfg, raw)
+        for i in range(reps):
+            ev[i][0].record()
+            _lib.check(L.gr_apply_pointfunction_device(ens.ctx.handle, C.byref(acfg), C.byref(apf), C.c_void_p(raw.data_ptr()), n, 2000.0,
+                                                       C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            ev[i][1].record()
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in ev]
+    rays = n
+    extra = {"bytes_per_ray": 160 if which == "applypf" else 152}
+else:
+    raise SystemExit(f"unknown workload {which}")
+
+print(json.dumps({"workload": which, "rays": rays, "launches": reps, "ms": ms, "ms_median_after_warmup": float(np.median(ms[2:])),
+                  "rays_per_s": rays / float(np.median(ms[2:])) * 1e3, **extra}))
