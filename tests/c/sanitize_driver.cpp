@@ -1,0 +1,103 @@
+// sanitize_driver.cpp -- TEST INFRASTRUCTURE.  One executable that links the CPU oracle (oracle/gradus_oracle.c) and the
+// host build of the device integrator (tests/host_harness.cpp) and pushes a handful of scenes through both, for
+// AddressSanitizer / UndefinedBehaviorSanitizer runs (GPU sanitizers are not available on the test pool):
+//
+//     make -C tests/c asan        (builds and runs; any report makes the run fail)
+//
+// Scenes: Kerr / Johannsen / Kerr-Newman(q) / Johannsen-Psaltis x no disc / thin disc / Shakura-Sunyaev / the
+// smoke-test torus, 12 x 12 pixels each, plus a plunging table and the fused point function.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../oracle/gradus_oracle.h"
+#include "../../include/gradus_mi355x.h"
+
+extern "C" {
+int hh_render_endpoints(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, gr_point* out);
+int hh_render(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, const gr_pointfunction* pf, double* image);
+}
+
+static const double PI = 3.141592653589793;
+
+int main()
+{
+    static_assert(sizeof(orc_config) == sizeof(gr_config), "oracle and product configs are the same POD");
+    static_assert(sizeof(orc_point) == sizeof(gr_point) && sizeof(gr_point) == 152, "GeodesicPoint is 152 bytes");
+    const int W = 12, H = 12, N = W * H;
+    const double x[4] = { 0.0, 100.0, 85.0 * PI / 180.0, 0.0 };
+    struct Scene { int metric; double p[4]; int disc; double q; };
+    const Scene scenes[] = {
+        { ORC_METRIC_KERR, { 1.0, 0.998, 0, 0 }, ORC_DISC_NONE, 0 },   { ORC_METRIC_KERR, { 1.0, 0.998, 0, 0 }, ORC_DISC_THIN, 0 },
+        { ORC_METRIC_KERR, { 1.0, 0.0, 0, 0 }, ORC_DISC_SHAKURA_SUNYAEV, 0 }, { ORC_METRIC_JOHANNSEN, { 1.0, 0.7, 2.0, 0 }, ORC_DISC_THIN, 0 },
+        { ORC_METRIC_KERR_NEWMAN, { 1.0, 0.5, 0.4, 0 }, ORC_DISC_THIN, 0.7 }, { ORC_METRIC_JOHANNSEN_PSALTIS, { 1.0, 0.6, 1.0, 0 }, ORC_DISC_THIN, 0 },
+    };
+    int bad = 0;
+    for (const Scene& s : scenes) {
+        orc_config c;
+        std::memset(&c, 0, sizeof c);
+        c.metric_id = s.metric;
+        for (int i = 0; i < 4; ++i) c.params[i] = s.p[i];
+        if (s.metric == ORC_METRIC_JOHANNSEN) { c.params[5] = 1.0; c.params[3] = 0.0; }
+        const double M = s.p[0], a = s.p[1], Q = s.metric == ORC_METRIC_KERR_NEWMAN ? s.p[2] : 0.0;
+        c.r_inner = 1.01 * (M + std::sqrt(M * M - a * a - Q * Q));
+        c.r_outer = 12000.0;
+        c.disc_id = s.disc;
+        c.disc_r_in = s.disc == ORC_DISC_SHAKURA_SUNYAEV ? 6.0 : 2.0;
+        c.disc_r_out = s.disc == ORC_DISC_SHAKURA_SUNYAEV ? INFINITY : 40.0;
+        c.disc_params[0] = 0.3; c.disc_params[1] = 1.0 / (1.0 - std::sqrt(8.0 / 9.0));
+        c.gtol = 1e-2; c.lambda0 = 0.0; c.lambda1 = 200.0; c.abstol = c.reltol = 1e-9; c.maxiters = 1000000;
+        c.hemi_delta = 1e-4; c.q = s.q; c.winding_plane = PI / 2;
+        std::vector<double> v(4 * N);
+        orc_render_velocities(&c, x, -9.5, 9.5, -9.5, 9.5, W, H, 0, N, v.data());
+        std::vector<orc_point> ref(N);
+        if (orc_trace(&c, x, 0, v.data(), N, ref.data(), nullptr, 2) != 0) { std::printf("orc_trace failed\n"); return 2; }
+        // the same scene through the host build of the device integrator
+        gr_config g;
+        std::memcpy(&g, &c, sizeof g);
+        g.disc_id = s.disc;      // THIN / SHAKURA_SUNYAEV / NONE share their ids between the two enums
+        gr_plane pl;
+        std::memset(&pl, 0, sizeof pl);
+        std::memcpy(pl.x_obs, x, sizeof x);
+        orc_lnr_transform(&c, x, pl.Mx);
+        pl.alpha0 = -9.5; pl.alpha1 = 9.5; pl.beta0 = -9.5; pl.beta1 = 9.5; pl.width = W; pl.height = H; pl.offset = 1e-6;
+        const gr_range rg{ 0, N, N, 1 };
+        std::vector<gr_point> got(N);
+        hh_render_endpoints(&g, &pl, &rg, got.data());
+        int mism = 0;
+        double worst = 0.0;
+        for (int i = 0; i < N; ++i) {
+            if (got[i].status != ref[i].status) { ++mism; continue; }
+            if (ref[i].status == 1) continue;      // captured rays stop at whichever step lands inside the chart
+            for (int k = 1; k < 3; ++k) worst = std::fmax(worst, std::fabs(got[i].x[k] - ref[i].x[k]) / std::fmax(1.0, std::fabs(ref[i].x[k])));
+        }
+        std::printf("metric %d disc %d: status mismatches %d / %d, worst end-point difference %.2e\n", s.metric, s.disc, mism, N, worst);
+        if (mism > 3 || worst > 1e-6) ++bad;
+        // fused point function + the oracle's
+        gr_pointfunction pf;
+        std::memset(&pf, 0, sizeof pf);
+        pf.pf_id = GR_PF_AFFINE_TIME; pf.filter_id = GR_FILTER_EARLY_TERM; pf.fill = NAN;
+        std::vector<double> img(N);
+        hh_render(&g, &pl, &rg, &pf, img.data());
+        orc_pf opf;
+        std::memset(&opf, 0, sizeof opf);
+        opf.pf_id = ORC_PF_AFFINE_TIME; opf.filter_id = ORC_FILTER_EARLY_TERM; opf.fill = NAN;
+        std::vector<double> oimg(N);
+        orc_apply_pf(&c, &opf, ref.data(), N, 200.0, oimg.data(), 2);
+    }
+    {   // plunging table (mu = 1 trace with every step saved)
+        orc_config c;
+        std::memset(&c, 0, sizeof c);
+        c.metric_id = ORC_METRIC_JOHANNSEN; c.params[0] = 1.0; c.params[1] = 0.7; c.params[2] = 2.0; c.params[5] = 1.0;
+        c.r_inner = 1.000001 * (1.0 + std::sqrt(1.0 - 0.49)); c.r_outer = 12000.0; c.lambda1 = 50000.0; c.abstol = c.reltol = 1e-9;
+        c.maxiters = 1000000; c.mu = 1.0; c.gtol = 1e-2;
+        const double isco = orc_isco(&c);
+        std::vector<double> r(4096), vt(4096), vr(4096), vp(4096);
+        const long long n = orc_plunging_table(&c, isco, r.data(), vt.data(), vr.data(), vp.data(), 4096);
+        std::printf("plunging table: isco %.6f, %lld rows\n", isco, n);
+        if (n < 50) ++bad;
+    }
+    std::printf(bad ? "FAILED\n" : "OK\n");
+    return bad ? 1 : 0;
+}
