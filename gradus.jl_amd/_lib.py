@@ -23,8 +23,8 @@ def kernel_source_sha16() -> str:
 
     h = hashlib.sha256()
     root = os.path.dirname(_HERE)
-    for rel in ("gradus.jl_amd/csrc/gr_device.hpp", "gradus.jl_amd/csrc/gr_kernels.hpp",
-                "gradus.jl_amd/csrc/gradus_mi355x.hip", "gradus.jl_amd/csrc/gradus_mi355x_f32.hip",
+    for rel in ("gradus.jl_amd/csrc/gr_device.hpp", "gradus.jl_amd/csrc/gr_kernels.hpp", "gradus.jl_amd/csrc/kernels_tu.hip",
+                "gradus.jl_amd/csrc/gradus_mi355x.hip",
                 "include/gradus_mi355x.h"):
         with open(os.path.join(root, rel), "rb") as f:
             h.update(f.read())

@@ -526,12 +526,14 @@ struct JohannsenMetric {
 };
 
 // Every other AbstractStaticAxisSymmetric metric: components written once over a number type and
-// differentiated with forward-mode duals, as the reference does for all of its metrics.  One
-// functor with a (wave-uniform) switch on the metric id keeps the number of kernel instantiations
-// independent of the size of the catalogue.
-struct GenericMetric {
-    // the dual-number evaluation wants ~285 registers; capping it at 256 (2 waves/SIMD) costs a few
-    // scratch spills but keeps the VALU busy (measured: see DESIGN.md §5)
+// differentiated with forward-mode duals, as the reference does for all of its metrics.  The functor is a template on
+// the metric id, so each metric gets its own kernels holding only its own component function (one translation unit
+// per metric, kernels_tu.hip).  Round 1 had ONE functor with a wave-uniform switch: every one of the six RHS sites of a
+// step then carried all nine metric bodies -- a 9 600-instruction step loop (57 KB of code against a 64 KB
+// instruction cache), 180 B of scratch per lane and 1.8x the time of Kerr.  ID < 0 keeps the run-time switch
+// (tests/host_harness.cpp traces every metric through one instantiation).
+template <int ID>
+struct GenericMetricT {
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
     static constexpr int kLaneWavesPerSimd = GR_GENERIC_MIN_WAVES;
     static constexpr bool kHasForce = false;
@@ -540,7 +542,7 @@ struct GenericMetric {
     real P[6];
     GR_DEV void load(const gr_config& c)
     {
-        id = c.metric_id;
+        id = ID >= 0 ? ID : c.metric_id;
 #pragma unroll
         for (int i = 0; i < 6; ++i) P[i] = c.params[i];
     }
@@ -755,16 +757,27 @@ struct GenericMetric {
     template <class T>
     GR_DEV void components(T r, T s, T c, T g[5]) const
     {
-        switch (id) {
-        case GR_METRIC_SPHERICAL: spherical<T>(r, s, c, g); break;
-        case GR_METRIC_KERR_DARK_MATTER: kerr_dark_matter<T>(r, s, c, g); break;
-        case GR_METRIC_KERR_REFRACTIVE: kerr_refractive<T>(r, s, c, g); break;
-        case GR_METRIC_NOZ: noz<T>(r, s, c, g); break;
-        case GR_METRIC_DILATON_AXION: dilaton_axion<T>(r, s, c, g); break;
-        case GR_METRIC_MORRIS_THORNE: morris_thorne<T>(r, s, c, g); break;
-        case GR_METRIC_BUMBLEBEE: bumblebee<T>(r, s, c, g); break;
-        case GR_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis<T>(r, s, c, g); break;
-        default: johannsen<T>(r, s, c, g); break;
+        if constexpr (ID == GR_METRIC_SPHERICAL) spherical<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_KERR_DARK_MATTER) kerr_dark_matter<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_KERR_REFRACTIVE) kerr_refractive<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_NOZ) noz<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_DILATON_AXION) dilaton_axion<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_MORRIS_THORNE) morris_thorne<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_BUMBLEBEE) bumblebee<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_JOHANNSEN_PSALTIS) johannsen_psaltis<T>(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_JOHANNSEN) johannsen<T>(r, s, c, g);
+        else {
+            switch (id) {
+            case GR_METRIC_SPHERICAL: spherical<T>(r, s, c, g); break;
+            case GR_METRIC_KERR_DARK_MATTER: kerr_dark_matter<T>(r, s, c, g); break;
+            case GR_METRIC_KERR_REFRACTIVE: kerr_refractive<T>(r, s, c, g); break;
+            case GR_METRIC_NOZ: noz<T>(r, s, c, g); break;
+            case GR_METRIC_DILATON_AXION: dilaton_axion<T>(r, s, c, g); break;
+            case GR_METRIC_MORRIS_THORNE: morris_thorne<T>(r, s, c, g); break;
+            case GR_METRIC_BUMBLEBEE: bumblebee<T>(r, s, c, g); break;
+            case GR_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis<T>(r, s, c, g); break;
+            default: johannsen<T>(r, s, c, g); break;
+            }
         }
     }
 
@@ -784,6 +797,13 @@ struct GenericMetric {
         inverse_generic(g, gi);
     }
 };
+typedef GenericMetricT<-1> GenericMetric;      // run-time switch over the catalogue
+
+// metric id -> functor type (the ids of include/gradus_mi355x.h)
+template <int ID> struct MetricOf { typedef GenericMetricT<ID> type; };
+template <> struct MetricOf<GR_METRIC_KERR> { typedef KerrFamily<false> type; };
+template <> struct MetricOf<GR_METRIC_KERR_NEWMAN> { typedef KerrFamily<true> type; };
+template <> struct MetricOf<GR_METRIC_JOHANNSEN> { typedef JohannsenMetric type; };
 
 // geodesic_equation (auto-diff.jl:213-226) with the sparse contraction of SURVEY App. B.1 at a
 // point given by r and (sinθ, cosθ).  The factors 2 and -½ of the reference's form cancel:
@@ -992,6 +1012,8 @@ struct Cold {
     double* lp_flux;          // device, lp_nbins (accumulated with fp64 atomics)
     double* lp_pairs;         // device, n x 2
 };
+
+constexpr int N_STAT = 9;   // statistics counters of a launch: rays, accepted, rejected, rhs, flagged, status[4]
 
 struct Params {
     gr_config cfg;

@@ -8,7 +8,6 @@
 namespace GR_NS {
 namespace {
 
-constexpr int N_STAT = 9;   // rays, accepted, rejected, rhs, flagged, status[4]
 
 template <class Metric, int DISC>
 struct LaneStats {
@@ -256,44 +255,46 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
     return hipGetLastError();
 }
 
-inline hipError_t launch_by_config(const LaunchKnobs& k, Params& p, hipStream_t stream)
+// DISC is the geometry id itself (GR_DISC_*): compile-time in the kernels
+template <class Metric>
+hipError_t launch_metric(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
-    // DISC is the geometry id itself (GR_DISC_*): compile-time in the kernels
-    const int disc = p.cfg.disc_id;
-    if (p.cfg.metric_id == GR_METRIC_KERR) {
-        if (disc == GR_DISC_THIN) return launch_tmpl<KerrMetric, GR_DISC_THIN>(k, p, stream);
-        if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<KerrMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
-        if (disc == GR_DISC_TABULATED) return launch_tmpl<KerrMetric, GR_DISC_TABULATED>(k, p, stream);
-        if (disc == GR_DISC_DATUM) return launch_tmpl<KerrMetric, GR_DISC_DATUM>(k, p, stream);
-        if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<KerrMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
-        if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<KerrMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
-        return launch_tmpl<KerrMetric, GR_DISC_NONE>(k, p, stream);
+    switch (p.cfg.disc_id) {
+    case GR_DISC_THIN: return launch_tmpl<Metric, GR_DISC_THIN>(k, p, stream);
+    case GR_DISC_SHAKURA_SUNYAEV: return launch_tmpl<Metric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
+    case GR_DISC_TABULATED: return launch_tmpl<Metric, GR_DISC_TABULATED>(k, p, stream);
+    case GR_DISC_DATUM: return launch_tmpl<Metric, GR_DISC_DATUM>(k, p, stream);
+    case GR_DISC_ELLIPTICAL: return launch_tmpl<Metric, GR_DISC_ELLIPTICAL>(k, p, stream);
+    case GR_DISC_PRECESSING_THIN: return launch_tmpl<Metric, GR_DISC_PRECESSING_THIN>(k, p, stream);
+    default: return launch_tmpl<Metric, GR_DISC_NONE>(k, p, stream);
     }
-    if (p.cfg.metric_id == GR_METRIC_KERR_NEWMAN) {
-        if (disc == GR_DISC_THIN) return launch_tmpl<KerrNewmanMetric, GR_DISC_THIN>(k, p, stream);
-        if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<KerrNewmanMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
-        if (disc == GR_DISC_TABULATED) return launch_tmpl<KerrNewmanMetric, GR_DISC_TABULATED>(k, p, stream);
-        if (disc == GR_DISC_DATUM) return launch_tmpl<KerrNewmanMetric, GR_DISC_DATUM>(k, p, stream);
-        if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<KerrNewmanMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
-        if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<KerrNewmanMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
-        return launch_tmpl<KerrNewmanMetric, GR_DISC_NONE>(k, p, stream);
+}
+
+template <class Metric>
+hipError_t launch_path_metric(const Params& p, double* d_path, int64_t cap, unsigned long long* d_n, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((p.n + 63) / 64);
+#define GR_PATH_LAUNCH(D) hipLaunchKernelGGL((k_trace_path<Metric, D>), dim3(grid), dim3(64), 0, stream, p, d_path, cap, d_n)
+    switch (p.cfg.disc_id) {
+    case GR_DISC_THIN: GR_PATH_LAUNCH(GR_DISC_THIN); break;
+    case GR_DISC_SHAKURA_SUNYAEV: GR_PATH_LAUNCH(GR_DISC_SHAKURA_SUNYAEV); break;
+    case GR_DISC_TABULATED: GR_PATH_LAUNCH(GR_DISC_TABULATED); break;
+    case GR_DISC_DATUM: GR_PATH_LAUNCH(GR_DISC_DATUM); break;
+    case GR_DISC_ELLIPTICAL: GR_PATH_LAUNCH(GR_DISC_ELLIPTICAL); break;
+    case GR_DISC_PRECESSING_THIN: GR_PATH_LAUNCH(GR_DISC_PRECESSING_THIN); break;
+    default: GR_PATH_LAUNCH(GR_DISC_NONE); break;
     }
-    if (p.cfg.metric_id == GR_METRIC_JOHANNSEN) {
-        if (disc == GR_DISC_THIN) return launch_tmpl<JohannsenMetric, GR_DISC_THIN>(k, p, stream);
-        if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<JohannsenMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
-        if (disc == GR_DISC_TABULATED) return launch_tmpl<JohannsenMetric, GR_DISC_TABULATED>(k, p, stream);
-        if (disc == GR_DISC_DATUM) return launch_tmpl<JohannsenMetric, GR_DISC_DATUM>(k, p, stream);
-        if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<JohannsenMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
-        if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<JohannsenMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
-        return launch_tmpl<JohannsenMetric, GR_DISC_NONE>(k, p, stream);
-    }
-    if (disc == GR_DISC_THIN) return launch_tmpl<GenericMetric, GR_DISC_THIN>(k, p, stream);
-    if (disc == GR_DISC_SHAKURA_SUNYAEV) return launch_tmpl<GenericMetric, GR_DISC_SHAKURA_SUNYAEV>(k, p, stream);
-    if (disc == GR_DISC_TABULATED) return launch_tmpl<GenericMetric, GR_DISC_TABULATED>(k, p, stream);
-    if (disc == GR_DISC_DATUM) return launch_tmpl<GenericMetric, GR_DISC_DATUM>(k, p, stream);
-    if (disc == GR_DISC_ELLIPTICAL) return launch_tmpl<GenericMetric, GR_DISC_ELLIPTICAL>(k, p, stream);
-    if (disc == GR_DISC_PRECESSING_THIN) return launch_tmpl<GenericMetric, GR_DISC_PRECESSING_THIN>(k, p, stream);
-    return launch_tmpl<GenericMetric, GR_DISC_NONE>(k, p, stream);
+#undef GR_PATH_LAUNCH
+    return hipGetLastError();
+}
+
+template <class Metric>
+hipError_t launch_apply_metric(const Params& p, const gr_point* pts, double max_time, double* out, hipStream_t stream)
+{
+    const int block = 256;
+    const int64_t grid = (p.n + block - 1) / block;
+    hipLaunchKernelGGL((k_apply_pf<Metric>), dim3((unsigned)grid), dim3(block), 0, stream, p, pts, max_time, out);
+    return hipGetLastError();
 }
 #endif  // GR_NO_LAUNCHER
 

@@ -1,4 +1,5 @@
-// gradus_mi355x.hip -- kernels and the C ABI of libgradus_mi355x.so (see include/gradus_mi355x.h).
+// gradus_mi355x.hip -- host side of libgradus_mi355x.so: the C ABI of include/gradus_mi355x.h, contexts, staging and the
+// dispatch to the per-metric kernel objects (kernels_tu.hip, one translation unit per metric id and precision).
 //
 // Two launch shapes for the same per-lane integrator (gr_device.hpp):
 //   kernel 0  "lane"        one ray per work-item, 8x8-pixel tiles per wave; a wave lives as
@@ -19,13 +20,39 @@
 #include <vector>
 
 #define GR_NS gr
-#include "gr_kernels.hpp"
+#include "gr_device.hpp"
 
 using namespace gr;
 
-// fp32 build of the same kernels (gradus_mi355x_f32.hip)
-hipError_t gr32_launch(int kernel, int block, int n_cu, int waves_per_simd, unsigned long long* queue,
-                       const void* params, hipStream_t stream);
+// ---- the per-metric kernel objects (kernels_tu.hip) ----
+#define GR_DECLARE_METRIC(ID)                                                                                          \
+    hipError_t gr64_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);             \
+    hipError_t gr32_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);             \
+    hipError_t gr64_launch_path_m##ID(const void*, double*, int64_t, unsigned long long*, hipStream_t);                \
+    hipError_t gr64_launch_apply_m##ID(const void*, const gr_point*, double, double*, hipStream_t);
+GR_DECLARE_METRIC(0) GR_DECLARE_METRIC(1) GR_DECLARE_METRIC(2) GR_DECLARE_METRIC(3) GR_DECLARE_METRIC(4) GR_DECLARE_METRIC(5)
+GR_DECLARE_METRIC(6) GR_DECLARE_METRIC(7) GR_DECLARE_METRIC(8) GR_DECLARE_METRIC(9) GR_DECLARE_METRIC(10)
+#undef GR_DECLARE_METRIC
+static_assert(GR_METRIC_NOZ == 10, "one kernel object per metric id 0..10: extend the tables below with the catalogue");
+
+namespace {
+struct LaunchKnobs {
+    int kernel;              // 0 = lane, 1 = persistent
+    int block;
+    int n_cu;
+    int waves_per_simd;      // 0 = from the occupancy query
+    unsigned long long* queue;   // work counter of the persistent kernel (zeroed by the launcher)
+};
+typedef hipError_t (*trace_fn)(int, int, int, int, unsigned long long*, const void*, hipStream_t);
+typedef hipError_t (*path_fn)(const void*, double*, int64_t, unsigned long long*, hipStream_t);
+typedef hipError_t (*apply_fn)(const void*, const gr_point*, double, double*, hipStream_t);
+#define GR_ROW(F) { F##0, F##1, F##2, F##3, F##4, F##5, F##6, F##7, F##8, F##9, F##10 }
+const trace_fn kTrace64[11] = GR_ROW(gr64_launch_trace_m);
+const trace_fn kTrace32[11] = GR_ROW(gr32_launch_trace_m);
+const path_fn kPath64[11] = GR_ROW(gr64_launch_path_m);
+const apply_fn kApply64[11] = GR_ROW(gr64_launch_apply_m);
+#undef GR_ROW
+}  // namespace
 
 namespace {
 
@@ -323,11 +350,9 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     LaunchKnobs knobs{ kern_sel, block_sel, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
     ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
-    hipError_t le;
-    if (ctx->precision == 32)
-        le = gr32_launch(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
-    else
-        le = launch_by_config(knobs, p, stream);
+    // validate_cfg() has pinned metric_id to [GR_METRIC_KERR, GR_METRIC_NOZ]
+    const trace_fn fn = (ctx->precision == 32 ? kTrace32 : kTrace64)[p.cfg.metric_id];
+    const hipError_t le = fn(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
     if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
     if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0) {
         const int32_t trc = tables_release(ctx, stream);
@@ -608,16 +633,7 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, stream));
     p.cold = slot;
-    const int block = 256;
-    const int64_t grid = (n + block - 1) / block;
-    if (cfg->metric_id == GR_METRIC_KERR)
-        hipLaunchKernelGGL((k_apply_pf<KerrMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
-    else if (cfg->metric_id == GR_METRIC_KERR_NEWMAN)
-        hipLaunchKernelGGL((k_apply_pf<KerrNewmanMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
-    else if (cfg->metric_id == GR_METRIC_JOHANNSEN)
-        hipLaunchKernelGGL((k_apply_pf<JohannsenMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
-    else
-        hipLaunchKernelGGL((k_apply_pf<GenericMetric>), dim3((unsigned)grid), dim3(block), 0, stream, p, d_points, max_time, d_out);
+    GR_HIP(kApply64[cfg->metric_id](&p, d_points, max_time, d_out, stream));
     GR_HIP(hipGetLastError());
     if (cd.pf.n_plunge > 0 && (rc = tables_release(ctx, stream)) != GR_OK) return rc;
     return GR_OK;
@@ -667,24 +683,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, ctx->stream));
     p.cold = slot;
     if ((rc = stage_disc_table(ctx, p, ctx->stream)) != GR_OK) return rc;
-    const unsigned grid = (unsigned)((n + 63) / 64);
-#define GR_PATH_LAUNCH(M, D) hipLaunchKernelGGL((k_trace_path<M, D>), dim3(grid), dim3(64), 0, ctx->stream, p, d_path, cap, d_n)
-#define GR_PATH_BY_DISC(M)                                                                       \
-    do {                                                                                         \
-        if (cfg->disc_id == GR_DISC_THIN) GR_PATH_LAUNCH(M, GR_DISC_THIN);                       \
-        else if (cfg->disc_id == GR_DISC_SHAKURA_SUNYAEV) GR_PATH_LAUNCH(M, GR_DISC_SHAKURA_SUNYAEV); \
-        else if (cfg->disc_id == GR_DISC_TABULATED) GR_PATH_LAUNCH(M, GR_DISC_TABULATED);        \
-        else if (cfg->disc_id == GR_DISC_DATUM) GR_PATH_LAUNCH(M, GR_DISC_DATUM);                \
-        else if (cfg->disc_id == GR_DISC_ELLIPTICAL) GR_PATH_LAUNCH(M, GR_DISC_ELLIPTICAL);      \
-        else if (cfg->disc_id == GR_DISC_PRECESSING_THIN) GR_PATH_LAUNCH(M, GR_DISC_PRECESSING_THIN); \
-        else GR_PATH_LAUNCH(M, GR_DISC_NONE);                                                    \
-    } while (0)
-    if (cfg->metric_id == GR_METRIC_KERR) GR_PATH_BY_DISC(KerrMetric);
-    else if (cfg->metric_id == GR_METRIC_KERR_NEWMAN) GR_PATH_BY_DISC(KerrNewmanMetric);
-    else if (cfg->metric_id == GR_METRIC_JOHANNSEN) GR_PATH_BY_DISC(JohannsenMetric);
-    else GR_PATH_BY_DISC(GenericMetric);
-#undef GR_PATH_BY_DISC
-#undef GR_PATH_LAUNCH
+    GR_HIP(kPath64[cfg->metric_id](&p, d_path, cap, d_n, ctx->stream));
     GR_HIP(hipGetLastError());
     if ((p.disc_table || p.chart_table) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters are copied as int64");

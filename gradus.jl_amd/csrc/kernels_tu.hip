@@ -1,0 +1,56 @@
+// kernels_tu.hip -- the device code of ONE metric: compiled once per metric id and per precision,
+//
+//     hipcc ... -DGR_TU_METRIC=<GR_METRIC_* id> -c kernels_tu.hip -o kernels_m<id>.o                       (fp64)
+//     hipcc ... -DGR_TU_METRIC=<id> -DGR_TU_F32 -Xclang -cl-single-precision-constant ... -o kernels32_m<id>.o   (fp32)
+//
+// so that every metric's kernels hold only that metric's component function (gr_device.hpp, GenericMetricT) and the
+// library builds on all cores at once (__graft_entry__.build_hip).  The fp32 objects are the same source with
+// real = float (every floating literal of gr_device.hpp / gr_kernels.hpp is single precision there); they carry the
+// trace kernels only: gr_ctx_set(ctx, "precision", 32) selects them for tolerance sweeps.  Inputs, outputs and tables
+// stay double in both.
+//
+// Exports (plain signatures: the host unit, gradus_mi355x.hip, passes its gr::Params by address -- gr32::Params has the
+// same layout, its fields are double / integer / pointers only):
+//     gr64_launch_trace_m<ID>, gr64_launch_path_m<ID>, gr64_launch_apply_m<ID>      gr32_launch_trace_m<ID>
+#ifndef GR_TU_METRIC
+#error "compile with -DGR_TU_METRIC=<metric id>"
+#endif
+#ifdef GR_TU_F32
+#define GR_REAL_IS_FLOAT 1
+#define GR_NS gr32
+#define GR_TU_PREFIX gr32
+#else
+#define GR_NS gr
+#define GR_TU_PREFIX gr64
+#endif
+#include <hip/hip_runtime.h>
+
+#include "gr_kernels.hpp"
+
+#define GR_CAT3_(a, b, c) a##b##c
+#define GR_CAT3(a, b, c) GR_CAT3_(a, b, c)
+#define GR_TU_NAME(what) GR_CAT3(GR_TU_PREFIX, what, GR_TU_METRIC)
+
+namespace {
+typedef GR_NS::MetricOf<GR_TU_METRIC>::type TuMetric;
+}
+
+hipError_t GR_TU_NAME(_launch_trace_m)(int kernel, int block, int n_cu, int waves_per_simd, unsigned long long* queue,
+                                       const void* params, hipStream_t stream)
+{
+    GR_NS::Params p = *reinterpret_cast<const GR_NS::Params*>(params);
+    GR_NS::LaunchKnobs k{ kernel, block, n_cu, waves_per_simd, queue };
+    return GR_NS::launch_metric<TuMetric>(k, p, stream);
+}
+
+#ifndef GR_TU_F32
+hipError_t GR_TU_NAME(_launch_path_m)(const void* params, double* d_path, int64_t cap, unsigned long long* d_n, hipStream_t stream)
+{
+    return GR_NS::launch_path_metric<TuMetric>(*reinterpret_cast<const GR_NS::Params*>(params), d_path, cap, d_n, stream);
+}
+
+hipError_t GR_TU_NAME(_launch_apply_m)(const void* params, const gr_point* pts, double max_time, double* out, hipStream_t stream)
+{
+    return GR_NS::launch_apply_metric<TuMetric>(*reinterpret_cast<const GR_NS::Params*>(params), pts, max_time, out, stream);
+}
+#endif

@@ -1,31 +1,44 @@
 #!/bin/bash
-# Build libgradus_mi355x.so of a given git revision (or the working tree with "WORK") into ab/<name>.so
-# usage: scripts/build_variant.sh <rev|WORK> <name> [extra hipcc flags...]
-# FAST=1 reuses the in-tree fp32 object (gradus.jl_amd/csrc/gradus_mi355x_f32.o) instead of recompiling that unit:
-# fine for A/B timing of the fp64 kernels, NOT for anything that runs the fp32 kernels.
+# Build libgradus_mi355x.so of the working tree (or of a git revision that already has the per-metric layout) into
+# ab/<name>.so with extra hipcc flags, for interleaved A/B timing (scripts/ab_bench.py).
+#   scripts/build_variant.sh <rev|WORK> <name> [extra hipcc flags...]
+# METRICS="0 1" limits the kernel objects that are recompiled with the extra flags (the others are taken from the
+# in-tree build): A/B of one metric's kernels in seconds.  Revisions from before the per-metric layout (round 1) are
+# built by their own recipe: git worktree + that revision's __graft_entry__.build_hip().
 set -e
 REV=$1; NAME=$2; shift 2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/ab; mkdir -p $OUT
-TMP=$(mktemp -d)
-if [ "$REV" = "WORK" ]; then
-  cp -r "$ROOT/gradus.jl_amd/csrc" $TMP/csrc; mkdir -p $TMP/inc; cp "$ROOT/include/gradus_mi355x.h" $TMP/inc/
-else
-  mkdir -p $TMP/csrc $TMP/inc
-  for f in gr_device.hpp gr_kernels.hpp gradus_mi355x.hip gradus_mi355x_f32.hip; do git -C $ROOT show "$REV:gradus.jl_amd/csrc/$f" > $TMP/csrc/$f; done
-  git -C $ROOT show "$REV:include/gradus_mi355x.h" > $TMP/inc/gradus_mi355x.h
-fi
-mkdir -p $TMP/a/b; mv $TMP/csrc $TMP/a/b/csrc; mkdir -p $TMP/a/include; cp $TMP/inc/gradus_mi355x.h $TMP/a/include/
-# the sources include "../../include/gradus_mi355x.h" relative to csrc
-cd $TMP/a/b/csrc
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -disable-machine-licm $@"
-hipcc $F -c gradus_mi355x.hip -o main.o &
-if [ "${FAST:-0}" = "1" ] && [ -f "$ROOT/gradus.jl_amd/csrc/gradus_mi355x_f32.o" ]; then
-  cp "$ROOT/gradus.jl_amd/csrc/gradus_mi355x_f32.o" f32.o
-else
-  hipcc $F -Xclang -cl-single-precision-constant -c gradus_mi355x_f32.hip -o f32.o &
-fi
-wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/$NAME.so main.o f32.o
-rm -rf $TMP
-echo built $OUT/$NAME.so
+python3 - "$ROOT" "$REV" "$OUT/$NAME.so" "${METRICS:-}" "$@" <<'PY'
+import os, shutil, subprocess, sys, tempfile
+root, rev, out, metrics = sys.argv[1:5]
+extra = sys.argv[5:]
+sys.path.insert(0, root)
+tmp = tempfile.mkdtemp()
+src = os.path.join(tmp, "a", "b", "csrc")          # the sources include "../../include/gradus_mi355x.h" relative to csrc
+os.makedirs(src); os.makedirs(os.path.join(tmp, "a", "include"))
+names = ["gr_device.hpp", "gr_kernels.hpp", "gradus_mi355x.hip", "kernels_tu.hip"]
+if rev == "WORK":
+    for f in names:
+        shutil.copy(os.path.join(root, "gradus.jl_amd", "csrc", f), src)
+    shutil.copy(os.path.join(root, "include", "gradus_mi355x.h"), os.path.join(tmp, "a", "include"))
+else:
+    for f in names:
+        open(os.path.join(src, f), "wb").write(subprocess.check_output(["git", "-C", root, "show", f"{rev}:gradus.jl_amd/csrc/{f}"]))
+    open(os.path.join(tmp, "a", "include", "gradus_mi355x.h"), "wb").write(
+        subprocess.check_output(["git", "-C", root, "show", f"{rev}:include/gradus_mi355x.h"]))
+import __graft_entry__ as g
+units = g.hip_units(extra)
+if metrics and rev == "WORK":
+    keep = {f"kernels_m{m}.o" for m in metrics.split()} | {"gradus_mi355x.o"}
+    for o, _, _ in units:
+        if o not in keep:
+            shutil.copy(os.path.join(root, "gradus.jl_amd", "csrc", o), os.path.join(src, o))
+    units_c = [u for u in units if u[0] in keep]
+else:
+    units_c = units
+g.compile_units(units_c, src, src, force=True)
+subprocess.check_call([g._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [os.path.join(src, o) for o, _, _ in units])
+shutil.rmtree(tmp)
+print("built", out)
+PY
