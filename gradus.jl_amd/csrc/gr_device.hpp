@@ -442,7 +442,7 @@ typedef KerrFamily<true> KerrNewmanMetric;
 // and for f = ΣXW (W = 1/N²): ∂f = (∂Σ X + Σ ∂X) W - 2 f ∂N/N.
 struct JohannsenMetric {
     static constexpr bool kHasForce = false;
-    static constexpr bool kFusedRhs = false;
+    static constexpr bool kFusedRhs = true;                    // rhs() below replaces eval() + the generic contraction
     static constexpr int kMinWavesPerSimd = 2;
     static constexpr int kLaneWavesPerSimd = 2;
     real M, a, a13, a22, a52, e3;
@@ -522,6 +522,94 @@ struct JohannsenMetric {
         gi[2] = iSig;
         gi[3] = g[0] * iD2;
         gi[4] = -g[4] * iD2;
+    }
+
+    // The whole right-hand side in one pass, as KerrFamily::rhs.  With K = (r²+a²)A1, N = K - a²s²A2, F = Σ/N² (Σ incl.
+    // the ϵ3 term) the t-ϕ block is g_tt = -F T, g_tϕ = -a s² F Q, g_ϕϕ = s² F P with T = Δ - a²s²A2², Q = K A2 - Δ,
+    // P = K² - a²s²Δ, and T P + a²s²Q² = Δ N², so det = -Σ² s² Δ/N² and the inverse block needs 1/(ΣΔ) only:
+    //   g^tt = -P/(ΣΔ), g^tϕ = -aQ/(ΣΔ), g^ϕϕ = T/(ΣΔs²)         (eval() spends a second reciprocal on it)
+    // Every θ-derivative carries the factor S2 = 2 sinθ cosθ: ∂_θ(T, s²Q, s²P, N, Σ) = S2 (-a²A2², Q, P - a²s²Δ, -a²A2, -a²).
+    // With ℓ_t = -(T v^t + a s²Q v^ϕ), ℓ_ϕ = s²(P v^ϕ - a Q v^t), Φ = ℓ_t v^t + ℓ_ϕ v^ϕ and κ = ∂ ln F = ∂Σ/Σ - 2∂N/N:
+    //   T_t = F(κ̇ ℓ_t + ℓ̇_t), T_ϕ = F(κ̇ ℓ_ϕ + ℓ̇_ϕ)  (dots: along (v^r, v^θ)),   D_x = F(κ_x Φ + Φ_x) + ∂_x g_rr v_r² + ∂_xΣ v_θ².
+    // One reciprocal for 1/N, 1/(ΔA5), 1/Σ, 1/(Σs²) besides 1/r.  Equal to eval() + the generic contraction to rounding
+    // (tests/test_kernel_logic_host.py::test_fused_rhs_equals_generic_contraction).
+    GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
+                    real& at, real& ar, real& ah, real& ap) const
+    {
+        const real a2 = a * a, tM = 2.0 * M, eM3 = e3 * M * M * M;
+        const real ir = rcp_full(r);
+        const real Mr = M * ir, Mr2 = Mr * Mr, Mr3 = Mr2 * Mr;
+        const real A1 = GR_FMA(a13, Mr3, 1.0), A2 = GR_FMA(a22, Mr2, 1.0), A5 = GR_FMA(a52, Mr2, 1.0);
+        const real A1r = (-3.0 * a13) * Mr3 * ir, A2r = (-2.0 * a22) * Mr2 * ir, A5r = (-2.0 * a52) * Mr2 * ir;
+        const real r2 = r * r, s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
+        const real eir = eM3 * ir;
+        const real Sig = GR_FMA(a2, c * c, r2) + eir;
+        const real Sig_r = GR_FMA(-eir, ir, tr);
+        const real Del = GR_FMA(-tM, r, r2) + a2;
+        const real Del_r = tr - tM;
+        const real rho2 = r2 + a2;
+        const real K = rho2 * A1;
+        const real K_r = GR_FMA(rho2, A1r, tr * A1);
+        const real a2s2 = a2 * s2;
+        const real N = GR_FMA(-a2s2, A2, K);
+        const real N_r = GR_FMA(-a2s2, A2r, K_r);
+        const real DA5 = Del * A5;
+        const real DA5_r = GR_FMA(Del, A5r, Del_r * A5);
+        // reciprocals
+        const real e1 = N * DA5, e2 = Sig * s2;
+        const real R = rcp_full(e1 * e2);
+        const real ie1 = R * e2, ie2 = R * e1;                      // 1/(N ΔA5), 1/(Σ s²)
+        const real iN = ie1 * DA5, iDA5 = ie1 * N, iSig = ie2 * s2;
+        const real iDel = A5 * iDA5;
+        const real c2 = (iN * iN) * iDel;                           // F/(ΣΔ) = 1/(N²Δ)
+        const real c3 = c2 * (ie2 * Sig);                           // F/(ΣΔs²)
+        const real F = Sig * (iN * iN);
+        // the three functions of the t-ϕ block and their r-derivatives
+        const real aA2 = a2s2 * A2;
+        const real T = GR_FMA(-aA2, A2, Del);
+        const real T_r = GR_FMA(-2.0 * aA2, A2r, Del_r);
+        const real Q = GR_FMA(K, A2, -Del);
+        const real Q_r = GR_FMA(K_r, A2, GR_FMA(K, A2r, -Del_r));
+        const real a2s2D = a2s2 * Del;
+        const real P = GR_FMA(K, K, -a2s2D);
+        const real P_r = GR_FMA(2.0 * K, K_r, -(a2s2 * Del_r));
+        const real Pth = P - a2s2D;                                 // ∂_θ(s²P)/S2
+        const real a2A22 = a2 * (A2 * A2);                          // -∂_θT/S2
+        const real aQ = a * Q;
+        // linear and quadratic forms
+        const real lt = -GR_FMA(T, vt, (aQ * s2) * vp);
+        const real lp = s2 * GR_FMA(P, vp, -(aQ * vt));
+        const real Phi = GR_FMA(lt, vt, lp * vp);
+        const real kr = GR_FMA(Sig_r, iSig, -2.0 * (N_r * iN));
+        const real kth = a2 * GR_FMA(2.0 * A2, iN, -iSig);          // κ_θ/S2
+        const real vt2 = vt * vt, vp2 = vp * vp, vtp = vt * vp, vr2 = vr * vr, vh2 = vh * vh, vrvh = vr * vh;
+        const real aQr_s2 = (a * Q_r) * s2;
+        const real Phi_r = GR_FMA(s2 * P_r, vp2, -GR_FMA(T_r, vt2, (2.0 * aQr_s2) * vtp));
+        const real phith = GR_FMA(Pth, vp2, GR_FMA(a2A22, vt2, -(2.0 * aQ) * vtp));
+        // r equation
+        const real grr = Sig * iDA5;
+        const real grr_r = GR_FMA(-grr, DA5_r, Sig_r) * iDA5;
+        const real a2S2 = a2 * S2;
+        const real FDr = F * GR_FMA(kr, Phi, Phi_r);
+        real br = GR_FMA(grr_r, vr2, -GR_FMA(Sig_r, vh2, FDr));     // ∂_r g_rr v_r² - Σ_r v_θ² - F(κ_rΦ + Φ_r)
+        br = GR_FMA(0.5, br, -((a2S2 * iDA5) * vrvh));
+        ar = -((DA5 * iSig) * br);
+        // θ equation
+        const real FDh = GR_FMA(F, GR_FMA(kth, Phi, phith), a2 * GR_FMA(-iDA5, vr2, vh2));
+        ah = -(iSig * GR_FMA(-0.5 * S2, FDh, Sig_r * vrvh));
+        // t and ϕ equations
+        const real S2vh = S2 * vh;
+        const real Td = GR_FMA(T_r, vr, -(a2A22 * S2vh));
+        const real Qsd = GR_FMA(s2 * Q_r, vr, Q * S2vh);
+        const real Psd = GR_FMA(s2 * P_r, vr, Pth * S2vh);
+        const real kd = GR_FMA(kr, vr, kth * S2vh);
+        const real aQsd = a * Qsd;
+        const real ltd = -GR_FMA(Td, vt, aQsd * vp);
+        const real lpd = GR_FMA(Psd, vp, -(aQsd * vt));
+        const real taut = GR_FMA(kd, lt, ltd);
+        const real taup = GR_FMA(kd, lp, lpd);
+        at = c2 * GR_FMA(P, taut, aQ * taup);
+        ap = GR_FMA(c2 * aQ, taut, -((c3 * T) * taup));
     }
 };
 
