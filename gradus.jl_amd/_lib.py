@@ -17,17 +17,22 @@ LIB_PATH = os.environ.get("GRADUS_MI355X_LIB") or os.path.join(_HERE, "csrc", "l
 
 
 def kernel_source_sha16() -> str:
-    """sha256[:16] over the kernel sources of the library in this tree.  rocprofv3 summaries under profiles/ record
-    it, and bench.py refuses to price a launch with counters taken from a different build of the kernels."""
+    """sha256[:16] over the kernel sources of the library in this tree with comments and white space removed (a
+    comment edit is not a different kernel).  rocprofv3 summaries under profiles/ record it, and bench.py refuses to
+    price a launch with counters taken from a different build of the kernels."""
     import hashlib
+    import re
 
     h = hashlib.sha256()
     root = os.path.dirname(_HERE)
     for rel in ("gradus.jl_amd/csrc/gr_device.hpp", "gradus.jl_amd/csrc/gr_kernels.hpp", "gradus.jl_amd/csrc/kernels_tu.hip",
                 "gradus.jl_amd/csrc/gradus_mi355x.hip",
                 "include/gradus_mi355x.h"):
-        with open(os.path.join(root, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(root, rel), "r", encoding="utf-8") as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                    # line comments (no string literal here holds "//")
+        h.update(" ".join(text.split()).encode("utf-8"))
     return h.hexdigest()[:16]
 
 

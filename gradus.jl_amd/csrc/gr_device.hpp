@@ -25,7 +25,7 @@
 
 #include "../../include/gradus_mi355x.h"
 
-// Scalar type of the integrator.  The fp32 build (gradus_mi355x_f32.hip) defines GR_REAL_IS_FLOAT
+// Scalar type of the integrator.  The fp32 build (kernels_tu.hip with -DGR_TU_F32) defines GR_REAL_IS_FLOAT
 // and GR_NS = gr32 and is compiled with -Xclang -cl-single-precision-constant so that every
 // floating literal below is a float there.  All I/O (gr_point, images, tables) stays double.
 #ifndef GR_NS

@@ -1,6 +1,6 @@
 // gr_kernels.hpp -- the trace kernels and their launcher, written against namespace GR_NS and its
 // `real` type.  Included by gradus_mi355x.hip (GR_NS = gr, real = double) and by
-// gradus_mi355x_f32.hip (GR_NS = gr32, real = float, compiled with single-precision constants).
+// the fp32 objects (GR_NS = gr32, real = float, compiled with single-precision constants).
 #pragma once
 
 #include "gr_device.hpp"
