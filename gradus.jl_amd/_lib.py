@@ -25,7 +25,8 @@ def kernel_source_sha16() -> str:
 
     h = hashlib.sha256()
     root = os.path.dirname(_HERE)
-    for rel in ("gradus.jl_amd/csrc/gr_device.hpp", "gradus.jl_amd/csrc/gr_kernels.hpp", "gradus.jl_amd/csrc/kernels_tu.hip",
+    for rel in ("gradus.jl_amd/csrc/gr_device.hpp", "gradus.jl_amd/csrc/gr_kernels.hpp", "gradus.jl_amd/csrc/gr_tangent.hpp",
+                "gradus.jl_amd/csrc/kernels_tu.hip",
                 "gradus.jl_amd/csrc/gradus_mi355x.hip",
                 "include/gradus_mi355x.h"):
         with open(os.path.join(root, rel), "r", encoding="utf-8") as f:
@@ -200,6 +201,8 @@ EXPORTS = [
     "gr_redshift_radius",
     "gr_ray_summary_device",
     "gr_ray_summary",
+    "gr_ray_tangent_device",
+    "gr_ray_tangent",
     "gr_rayset_endpoints_device",
     "gr_rayset_endpoints",
     "gr_apply_pointfunction_device",
@@ -242,6 +245,8 @@ def load():
     L.gr_redshift_radius.argtypes = [vp, cfgp, rsp, pfp, C.c_double, C.c_double, vp, stp]
     L.gr_ray_summary_device.argtypes = [vp, cfgp, rsp, pfp, vp, vp, vp]
     L.gr_ray_summary.argtypes = [vp, cfgp, rsp, pfp, vp, stp]
+    L.gr_ray_tangent_device.argtypes = [vp, cfgp, rsp, pfp, vp, vp, vp]
+    L.gr_ray_tangent.argtypes = [vp, cfgp, rsp, pfp, vp, stp]
     L.gr_rayset_endpoints_device.argtypes = [vp, cfgp, rsp, vp, vp, vp]
     L.gr_rayset_endpoints.argtypes = [vp, cfgp, rsp, vp, stp]
     L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]

@@ -31,7 +31,21 @@
 #ifndef GR_NS
 #define GR_NS gr
 #endif
-#ifdef GR_REAL_IS_FLOAT
+#if defined(GR_REAL_IS_TAN2)
+// third build: real = a forward-mode number with two tangent directions (gr_tangent.hpp)
+#include "gr_tangent.hpp"
+typedef gr_tan2 gr_real_t;
+#define GR_FMA(a, b, c) ((a) * (b) + (c))
+#define GR_FABS gr_t_abs
+#define GR_FMAX gr_t_max
+#define GR_FMIN gr_t_min
+#define GR_RINT gr_t_rint
+#define GR_FLOOR gr_t_floor
+#define GR_SQRT gr_t_sqrt
+#define GR_POW gr_t_pow
+#define GR_ATAN gr_t_atan
+#define GR_EPS 2.220446049250313e-16
+#elif defined(GR_REAL_IS_FLOAT)
 typedef float gr_real_t;
 #define GR_FMA __builtin_fmaf
 #define GR_FABS __builtin_fabsf
@@ -66,14 +80,22 @@ typedef double gr_real_t;
 // the oracle.  Test infrastructure only: the shipped library never defines GR_HOST_HARNESS.
 #include <cmath>
 #define GR_DEV inline
+#ifdef GR_REAL_IS_TAN2
+#define GR_RCP_SEED(x) gr_t_rcp(x)
+#define GR_RSQ_SEED(x) gr_t_rsq(x)
+#else
 #define GR_RCP_SEED(x) (1.0 / (x))
 #define GR_RSQ_SEED(x) (1.0 / std::sqrt(x))
+#endif
 #define GR_LOG2F(x) std::log2((float)(x))
 #define GR_EXP2F(x) std::exp2((float)(x))
 #else
 #include <hip/hip_runtime.h>
 #define GR_DEV __device__ __forceinline__
-#ifdef GR_REAL_IS_FLOAT
+#if defined(GR_REAL_IS_TAN2)
+#define GR_RCP_SEED(x) gr_t_rcp(x)
+#define GR_RSQ_SEED(x) gr_t_rsq(x)
+#elif defined(GR_REAL_IS_FLOAT)
 #define GR_RCP_SEED(x) __builtin_amdgcn_rcpf(x)
 #define GR_RSQ_SEED(x) __builtin_amdgcn_rsqf(x)
 #else
@@ -87,6 +109,11 @@ typedef double gr_real_t;
 namespace GR_NS {
 
 typedef gr_real_t real;
+#ifdef GR_REAL_IS_TAN2
+typedef double creal;     // tableau and other compile-time tables: plain numbers (constants have no tangent)
+#else
+typedef real creal;
+#endif
 
 // ---------------------------------------------------------------------------------------
 // scalar helpers
@@ -182,7 +209,7 @@ GR_DEV void sincos_fast(real x, real& s_out, real& c_out)
 // the 64 lanes is below 2^-5 in 99.05 % and below 2^-4 in all of the wave-steps of the bench image: tests/host_harness.cpp
 // hh_wave_stats) and needs two three-term polynomials (truncation 2.5e-18 / 2.3e-17, below half an ulp) and four
 // FMAs: no range reduction, no quadrant logic.  Larger δ takes the full evaluation.
-constexpr real SINCOS_ROT_MAX = 0.03125;
+constexpr creal SINCOS_ROT_MAX = 0.03125;
 GR_DEV void sincos_rot(real th0, real s0, real c0, real th, real& s_out, real& c_out)
 {
     const real d = th - th0;
@@ -953,7 +980,7 @@ GR_DEV real constrain_time(const real g[5], real vr, real vh, real vp, real mu)
 // Tsit5 tableau, dense output
 // ---------------------------------------------------------------------------------------
 struct Ts {
-    static constexpr real A[7][6] = {
+    static constexpr creal A[7][6] = {
         { 0, 0, 0, 0, 0, 0 },
         { 0.161, 0, 0, 0, 0, 0 },
         { -0.008480655492356989, 0.335480655492357, 0, 0, 0, 0 },
@@ -962,11 +989,11 @@ struct Ts {
         { 5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0 },
         { 0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774 },
     };
-    static constexpr real BT[7] = { -0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+    static constexpr creal BT[7] = { -0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
                                       -0.1447110071732629,     0.5823571654525552,     -0.45808210592918697,
                                       0.015151515151515152 };
     // b_i(Θ) = Σ_m R[i][m] Θ^(m+1)
-    static constexpr real R[7][4] = {
+    static constexpr creal R[7][4] = {
         { 1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216 },
         { 0.0, 0.13169999999999998, -0.2234, 0.1017 },
         { 0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253 },
@@ -984,51 +1011,51 @@ struct Ts {
 // stage ACCELERATIONS A_i are stored (28 doubles instead of 56); results differ from the
 // first-order bookkeeping by rounding only.
 struct TsX {
-    real C[7];       // c_s = Σ_j a_sj
-    real AX[7][7];   // ā_si = Σ_{i<j<s} a_sj a_ji
-    real SBT;        // Σ_j b̃_j (zero up to rounding of the published coefficients)
-    real BTX[7];     // Σ_{j>i} b̃_j a_ji
-    real SR[4];      // Σ_j R[j][m]  (1, ~0, ~0, ~0)
-    real RX[7][4];   // Σ_{j>i} R[j][m] a_ji
-    real K2;         // max_j Σ_i |Σ_m RX[i][m] Θ_j^(m+1)| over the sample points Θ_j = j/7
+    creal C[7];       // c_s = Σ_j a_sj
+    creal AX[7][7];   // ā_si = Σ_{i<j<s} a_sj a_ji
+    creal SBT;        // Σ_j b̃_j (zero up to rounding of the published coefficients)
+    creal BTX[7];     // Σ_{j>i} b̃_j a_ji
+    creal SR[4];      // Σ_j R[j][m]  (1, ~0, ~0, ~0)
+    creal RX[7][4];   // Σ_{j>i} R[j][m] a_ji
+    creal K2;         // max_j Σ_i |Σ_m RX[i][m] Θ_j^(m+1)| over the sample points Θ_j = j/7
 };
 constexpr TsX make_tsx()
 {
     TsX t{};
     for (int s = 0; s < 7; ++s) {
-        real c = 0.0;
+        creal c = 0.0;
         for (int j = 0; j < s && j < 6; ++j) c += Ts::A[s][j];
         t.C[s] = c;
         for (int i = 0; i < 7; ++i) {
-            real a = 0.0;
+            creal a = 0.0;
             for (int j = i + 1; j < s && j < 6; ++j) a += Ts::A[s][j] * Ts::A[j][i];
             t.AX[s][i] = a;
         }
     }
-    real sb = 0.0;
+    creal sb = 0.0;
     for (int j = 0; j < 7; ++j) sb += Ts::BT[j];
     t.SBT = sb;
     for (int i = 0; i < 7; ++i) {
-        real a = 0.0;
+        creal a = 0.0;
         for (int j = i + 1; j < 7; ++j) a += Ts::BT[j] * (i < 6 ? Ts::A[j][i] : 0.0);
         t.BTX[i] = a;
     }
     for (int m = 0; m < 4; ++m) {
-        real sr = 0.0;
+        creal sr = 0.0;
         for (int j = 0; j < 7; ++j) sr += Ts::R[j][m];
         t.SR[m] = sr;
         for (int i = 0; i < 7; ++i) {
-            real a = 0.0;
+            creal a = 0.0;
             for (int j = i + 1; j < 7; ++j) a += Ts::R[j][m] * (i < 6 ? Ts::A[j][i] : 0.0);
             t.RX[i][m] = a;
         }
     }
-    real k2 = 0.0;
+    creal k2 = 0.0;
     for (int jj = 1; jj <= 6; ++jj) {
-        const real th = (real)jj / 7.0;
-        real sum = 0.0;
+        const creal th = (creal)jj / 7.0;
+        creal sum = 0.0;
         for (int i = 0; i < 7; ++i) {
-            const real b = th * (t.RX[i][0] + th * (t.RX[i][1] + th * (t.RX[i][2] + th * t.RX[i][3])));
+            const creal b = th * (t.RX[i][0] + th * (t.RX[i][1] + th * (t.RX[i][2] + th * t.RX[i][3])));
             sum += b < 0.0 ? -b : b;
         }
         if (sum > k2) k2 = sum;
@@ -1041,15 +1068,15 @@ struct TsD {
 };
 
 // PI controller constants (App. A.3)
-constexpr real PI_BETA1 = 7.0 / 50.0;
-constexpr real PI_BETA2 = 2.0 / 25.0;
-constexpr real PI_GAMMA = 0.9;
-constexpr real PI_QMIN = 0.2;
-constexpr real PI_QMAX = 10.0;
-constexpr real LOG2_QOLDINIT = -13.287712379549449;  // log2(1e-4)
+constexpr creal PI_BETA1 = 7.0 / 50.0;
+constexpr creal PI_BETA2 = 2.0 / 25.0;
+constexpr creal PI_GAMMA = 0.9;
+constexpr creal PI_QMIN = 0.2;
+constexpr creal PI_QMAX = 10.0;
+constexpr creal LOG2_QOLDINIT = -13.287712379549449;  // log2(1e-4)
 // bounds used to skip the event sampling (see Ray::sample_event); 1e-6 of slack for rounding
-constexpr real DENSE_K1 = 1.000001;
-constexpr real DENSE_K2 = TsD::X.K2 * 1.000001;
+constexpr creal DENSE_K1 = 1.000001;
+constexpr creal DENSE_K2 = TsD::X.K2 * 1.000001;
 
 // ---------------------------------------------------------------------------------------
 // kernel parameter block (uniform, lives in the kernarg segment / SGPRs)
@@ -1069,7 +1096,7 @@ struct PfDev {
 // live in SGPRs across the hot step loop.
 struct Cold {
     int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays
-    int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs, 4 = (g, ρ, t, status)
+    int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs, 4 = (g, ρ, t, status), 5 = the same with ∂/∂α, ∂/∂β (tangent build only)
     int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
     int32_t idx32;            // 1 = every ray / pixel index fits 31 bits: 32-bit divisions in the index maps
     gr_plane plane;
@@ -1417,7 +1444,13 @@ struct Ray {
             // promote_velfunc: map_impact_parameters(m, x, αs[i], βs[i]) -- no pixel offset
             const real ro = p.plane.x_obs[1];
             const real iro = rcp_full(ro);
-            const real b = p.beta[jl] * iro, a = p.alpha[jl] * iro;
+#ifdef GR_REAL_IS_TAN2
+            // the two tangent directions of this build: ∂/∂α and ∂/∂β of everything downstream
+            const real al(p.alpha[jl], 1.0, 0.0), be(p.beta[jl], 0.0, 1.0);
+#else
+            const real al = p.alpha[jl], be = p.beta[jl];
+#endif
+            const real b = be * iro, a = al * iro;
             const real pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
             const real pb[4] = { 1.0, pr, b * pr, a * pr };
 #pragma unroll
@@ -1458,7 +1491,7 @@ struct Ray {
         constrained_u0(m, p, jl, x, v);
         t = p.cfg.lambda0;
         h = 0.0;
-        lq_old = LOG2_QOLDINIT;
+        lq_old = (float)LOG2_QOLDINIT;
         real s, c;
         accel(m, x[1], x[2], v, A[0], s, c);
         sth = s; cth = c;
@@ -1873,6 +1906,36 @@ struct Ray {
             dense_coeffs(4 + i, h, C);
             ve[i] = dense_eval(v[i], h, C, theta);
         }
+#ifdef GR_REAL_IS_TAN2
+        {
+            // The event time depends on (α, β): c(x(λ*; α, β)) = 0  =>  ∂λ* = -∂c|_λ / (dc/dλ).  xe, ve above carry the
+            // tangents at FIXED λ (Θ is a plain number); the state at the event moves by (ẋ, v̇) ∂λ* on top.  The
+            // reference's ForwardDiff pass through the ContinuousCallback carries the same term (without it the
+            // Jacobian ∂(ρ, g)/∂(α, β) is off by 13-45 % on the rₑ ≈ 5-8 rays checked in tests/test_tangent_host.py).
+            real se, ce;
+            sincos_fast(xe[2], se, ce);
+            const real cv = disc_cond4(p, xe[1], se, ce, xe[3]);
+            // dc/dλ along the ray: the same condition on a state whose first tangent slot holds the velocity
+            const real r1(xe[1].v, ve[1].v, 0.0), t1(xe[2].v, ve[2].v, 0.0), p1(xe[3].v, ve[3].v, 0.0);
+            real s1, c1;
+            sincos_fast(t1, s1, c1);
+            const double cdot = disc_cond4(p, r1, s1, c1, p1).a;
+            if (cdot != 0.0) {
+                const double la = -cv.a / cdot, lb = -cv.b / cdot;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    real C[4];
+                    dense_coeffs(4 + i, h, C);
+                    // v̇ = (1/h) d/dΘ of the velocity interpolant
+                    const double acc = C[0].v + theta.v * (2.0 * C[1].v + theta.v * (3.0 * C[2].v + theta.v * 4.0 * C[3].v));
+                    const double vel = ve[i].v;
+                    xe[i].a += vel * la; xe[i].b += vel * lb;
+                    ve[i].a += acc * la; ve[i].b += acc * lb;
+                }
+                t.a += la; t.b += lb;
+            }
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x[i] = xe[i]; v[i] = ve[i]; }
         t = t + theta * h;
@@ -1903,13 +1966,13 @@ struct Ray {
             o->status = status;
             o->flags = flags;
             o->lambda_min = p.cfg.lambda0;
-            o->lambda_max = t;
+            o->lambda_max = (double)t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                o->x_init[q] = x0[q];
-                o->v_init[q] = v0[q];
-                o->x[q] = x[q];
-                o->v[q] = v[q];
+                o->x_init[q] = (double)x0[q];
+                o->v_init[q] = (double)v0[q];
+                o->x[q] = (double)x[q];
+                o->v[q] = (double)v[q];
             }
         } else if (cd.out_mode >= 2) {
             // lineprofile(bins, ε, m, u, d, BinningMethod()), line-profiles.jl:186-197
@@ -1923,6 +1986,19 @@ struct Ray {
                 constrained_u0(m, p, j, x0, v0);
                 g = redshift_pf(m, p, cd, lds, x0, v0, x, v);
             }
+#ifdef GR_REAL_IS_TAN2
+            if (cd.out_mode == 5) {
+                // ray summary with tangents: (g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status) -- what
+                // jacobian_∂αβ_∂gr reads off its dual numbers (precision-solvers.jl:401-451)
+                double* o = cd.lp_pairs + 8 * j;
+                o[0] = in ? g.v : __builtin_nan("");
+                o[1] = rho.v;
+                o[2] = g.a; o[3] = g.b;
+                o[4] = rho.a; o[5] = rho.b;
+                o[6] = x[0].v;
+                o[7] = (double)status;
+            } else
+#endif
             if (cd.out_mode == 4) {
                 // ray summary for the precision solvers: (g, ρ, t, status) -- 32 B instead of the
                 // 152-B end-point record plus a second pass for the redshift
@@ -1946,7 +2022,7 @@ struct Ray {
                     if (cd.lp_edges[mid] <= g) lo = mid + 1; else hi = mid;
                 }
                 lo = lo > 0 ? lo - 1 : 0;
-                if (f == f) gr_atomic_add((lds.hist ? lds.hist : cd.lp_flux) + lo, f);
+                if (f == f) gr_atomic_add((lds.hist ? lds.hist : cd.lp_flux) + lo, (double)f);
             }
         } else {
             bool pass = true;
@@ -1967,7 +2043,7 @@ struct Ray {
                     val = redshift_pf(m, p, cd, lds, x0, v0, x, v);
                 }
             }
-            cd.image[j] = val;
+            cd.image[j] = (double)val;
         }
     }
 };

@@ -231,10 +231,16 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
     const int block = k.block;
     const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows);
+#ifdef GR_LANE_ONLY
+    {
+#else
     if (k.kernel == 0) {
+#endif
         const int64_t grid = (p.n + block - 1) / block;
         hipLaunchKernelGGL((k_trace_lane<Metric, DISC>), dim3((unsigned)grid), dim3(block), lds, stream, p);
-    } else {
+    }
+#ifndef GR_LANE_ONLY
+    else {
         int per_cu = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persistent<Metric, DISC>, block, lds);
         if (e != hipSuccess) return e;
@@ -252,6 +258,7 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_trace_persistent<Metric, DISC>), dim3((unsigned)grid), dim3(block), lds, stream, p);
     }
+#endif
     return hipGetLastError();
 }
 

@@ -1,0 +1,101 @@
+// gr_tangent.hpp -- forward-mode scalar with two tangent directions, for the third build of the integrator
+// (GR_REAL_IS_TAN2, namespace grt): the SAME source as the fp64 kernels with `real` = a number that carries
+// ∂/∂α and ∂/∂β, i.e. "dual-number state through the integrator", which is how the reference computes the Jacobian
+// ∂(rₑ, g)/∂(α, β) of its Cunningham transfer functions (ForwardDiff.jacobian around tracegeodesics,
+// src/tracing/precision-solvers.jl:401-451).  A Runge-Kutta step commutes with differentiation with respect to the initial
+// state, so this integrates the tangent equations with the very steps the value takes; the step-size controller, the
+// accept test and every branch look at VALUES only (gr_tan2's comparisons and its conversions to float / int), and
+// the event time's dependence on (α, β) is added by implicit differentiation where the event is resolved
+// (Ray::resolve_event).
+#pragma once
+
+#include <cmath>
+
+struct gr_tan2 {
+    double v, a, b;
+    constexpr gr_tan2() : v(0.0), a(0.0), b(0.0) {}
+    constexpr gr_tan2(double x) : v(x), a(0.0), b(0.0) {}          // implicit: literals and plain doubles are constants
+    constexpr gr_tan2(double x, double da, double db) : v(x), a(da), b(db) {}
+    // values only, and only when asked for
+    constexpr explicit operator double() const { return v; }
+    constexpr explicit operator float() const { return (float)v; }
+    constexpr explicit operator int() const { return (int)v; }
+    constexpr explicit operator long long() const { return (long long)v; }
+    constexpr explicit operator long() const { return (long)v; }
+};
+
+#ifdef GR_HOST_HARNESS
+#define GR_TAN_FN inline
+#else
+#define GR_TAN_FN __host__ __device__ __forceinline__
+#endif
+
+GR_TAN_FN constexpr gr_tan2 operator+(gr_tan2 x, gr_tan2 y) { return { x.v + y.v, x.a + y.a, x.b + y.b }; }
+GR_TAN_FN constexpr gr_tan2 operator+(gr_tan2 x, double y) { return { x.v + y, x.a, x.b }; }
+GR_TAN_FN constexpr gr_tan2 operator+(double y, gr_tan2 x) { return { x.v + y, x.a, x.b }; }
+GR_TAN_FN constexpr gr_tan2 operator-(gr_tan2 x, gr_tan2 y) { return { x.v - y.v, x.a - y.a, x.b - y.b }; }
+GR_TAN_FN constexpr gr_tan2 operator-(gr_tan2 x, double y) { return { x.v - y, x.a, x.b }; }
+GR_TAN_FN constexpr gr_tan2 operator-(double y, gr_tan2 x) { return { y - x.v, -x.a, -x.b }; }
+GR_TAN_FN constexpr gr_tan2 operator-(gr_tan2 x) { return { -x.v, -x.a, -x.b }; }
+GR_TAN_FN constexpr gr_tan2 operator*(gr_tan2 x, gr_tan2 y) { return { x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b }; }
+GR_TAN_FN constexpr gr_tan2 operator*(gr_tan2 x, double y) { return { x.v * y, x.a * y, x.b * y }; }
+GR_TAN_FN constexpr gr_tan2 operator*(double y, gr_tan2 x) { return { x.v * y, x.a * y, x.b * y }; }
+GR_TAN_FN constexpr gr_tan2 operator/(gr_tan2 x, gr_tan2 y)
+{
+    const double i = 1.0 / y.v, q = x.v * i;
+    return { q, (x.a - q * y.a) * i, (x.b - q * y.b) * i };
+}
+GR_TAN_FN constexpr gr_tan2 operator/(gr_tan2 x, double y) { return { x.v / y, x.a / y, x.b / y }; }
+GR_TAN_FN constexpr gr_tan2 operator/(double x, gr_tan2 y)
+{
+    const double i = 1.0 / y.v, q = x * i;
+    return { q, -q * y.a * i, -q * y.b * i };
+}
+GR_TAN_FN constexpr gr_tan2& operator+=(gr_tan2& x, gr_tan2 y) { x = x + y; return x; }
+GR_TAN_FN constexpr gr_tan2& operator-=(gr_tan2& x, gr_tan2 y) { x = x - y; return x; }
+GR_TAN_FN constexpr gr_tan2& operator*=(gr_tan2& x, gr_tan2 y) { x = x * y; return x; }
+GR_TAN_FN constexpr gr_tan2& operator+=(gr_tan2& x, double y) { x.v += y; return x; }
+GR_TAN_FN constexpr gr_tan2& operator-=(gr_tan2& x, double y) { x.v -= y; return x; }
+GR_TAN_FN constexpr gr_tan2& operator*=(gr_tan2& x, double y) { x = x * y; return x; }
+
+#define GR_TAN_CMP(op)                                                                      \
+    GR_TAN_FN constexpr bool operator op(gr_tan2 x, gr_tan2 y) { return x.v op y.v; }       \
+    GR_TAN_FN constexpr bool operator op(gr_tan2 x, double y) { return x.v op y; }          \
+    GR_TAN_FN constexpr bool operator op(double x, gr_tan2 y) { return x op y.v; }
+GR_TAN_CMP(<) GR_TAN_CMP(>) GR_TAN_CMP(<=) GR_TAN_CMP(>=) GR_TAN_CMP(==) GR_TAN_CMP(!=)
+#undef GR_TAN_CMP
+
+// elementary functions (plain-double overloads beside them so that one macro serves both)
+GR_TAN_FN double gr_t_abs(double x) { return x < 0.0 ? -x : x; }
+GR_TAN_FN gr_tan2 gr_t_abs(gr_tan2 x) { return x.v < 0.0 ? -x : x; }
+GR_TAN_FN double gr_t_max(double x, double y) { return x > y ? x : y; }
+GR_TAN_FN gr_tan2 gr_t_max(gr_tan2 x, gr_tan2 y) { return x.v > y.v ? x : y; }
+GR_TAN_FN double gr_t_min(double x, double y) { return x < y ? x : y; }
+GR_TAN_FN gr_tan2 gr_t_min(gr_tan2 x, gr_tan2 y) { return x.v < y.v ? x : y; }
+GR_TAN_FN gr_tan2 gr_t_rint(gr_tan2 x) { return gr_tan2(::rint(x.v)); }        // piecewise constant
+GR_TAN_FN gr_tan2 gr_t_floor(gr_tan2 x) { return gr_tan2(::floor(x.v)); }
+GR_TAN_FN gr_tan2 gr_t_sqrt(gr_tan2 x)
+{
+    const double s = ::sqrt(x.v), h = 0.5 / s;
+    return { s, x.a * h, x.b * h };
+}
+GR_TAN_FN gr_tan2 gr_t_rcp(gr_tan2 x)
+{
+    const double i = 1.0 / x.v, m = -i * i;
+    return { i, m * x.a, m * x.b };
+}
+GR_TAN_FN gr_tan2 gr_t_rsq(gr_tan2 x)
+{
+    const double i = 1.0 / ::sqrt(x.v), m = -0.5 * i / x.v;
+    return { i, m * x.a, m * x.b };
+}
+GR_TAN_FN gr_tan2 gr_t_pow(gr_tan2 x, gr_tan2 y)          // y is a constant exponent wherever the integrator calls this
+{
+    const double p = ::pow(x.v, y.v), d = y.v * p / x.v;
+    return { p, d * x.a, d * x.b };
+}
+GR_TAN_FN gr_tan2 gr_t_atan(gr_tan2 x)
+{
+    const double w = 1.0 / (1.0 + x.v * x.v);
+    return { ::atan(x.v), w * x.a, w * x.b };
+}

@@ -28,6 +28,7 @@ using namespace gr;
 #define GR_DECLARE_METRIC(ID)                                                                                          \
     hipError_t gr64_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);             \
     hipError_t gr32_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);             \
+    hipError_t grt_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);              \
     hipError_t gr64_launch_path_m##ID(const void*, double*, int64_t, unsigned long long*, hipStream_t);                \
     hipError_t gr64_launch_apply_m##ID(const void*, const gr_point*, double, double*, hipStream_t);
 GR_DECLARE_METRIC(0) GR_DECLARE_METRIC(1) GR_DECLARE_METRIC(2) GR_DECLARE_METRIC(3) GR_DECLARE_METRIC(4) GR_DECLARE_METRIC(5)
@@ -49,6 +50,7 @@ typedef hipError_t (*apply_fn)(const void*, const gr_point*, double, double*, hi
 #define GR_ROW(F) { F##0, F##1, F##2, F##3, F##4, F##5, F##6, F##7, F##8, F##9, F##10 }
 const trace_fn kTrace64[11] = GR_ROW(gr64_launch_trace_m);
 const trace_fn kTrace32[11] = GR_ROW(gr32_launch_trace_m);
+const trace_fn kTraceTan[11] = GR_ROW(grt_launch_trace_m);      // value + ∂/∂α + ∂/∂β (out_mode 5)
 const path_fn kPath64[11] = GR_ROW(gr64_launch_path_m);
 const apply_fn kApply64[11] = GR_ROW(gr64_launch_apply_m);
 #undef GR_ROW
@@ -351,7 +353,9 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
                        ctx->d_queue + ctx->queue_next };
     ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
     // validate_cfg() has pinned metric_id to [GR_METRIC_KERR, GR_METRIC_NOZ]
-    const trace_fn fn = (ctx->precision == 32 ? kTrace32 : kTrace64)[p.cfg.metric_id];
+    const bool tangent = cold.out_mode == 5;
+    const trace_fn fn = (tangent ? kTraceTan : ctx->precision == 32 ? kTrace32 : kTrace64)[p.cfg.metric_id];
+    if (tangent) { knobs.kernel = 0; knobs.block = 64; }      // the tangent objects carry the one-ray-per-lane kernel only
     const hipError_t le = fn(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
     if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
     if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0) {
@@ -788,6 +792,29 @@ int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     return launch_trace(ctx, p, cd, stream);
 }
 
+int32_t gr_ray_tangent_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                              double* d_out, gr_stats* d_stats, void* hip_stream)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    int32_t rc;
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if (cfg->disc_id == GR_DISC_NONE) return fail(GR_ERR_INVALID_ARGUMENT, "ray tangents are taken where the ray meets the geometry: none given");
+    GR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params p;
+    Cold cd;
+    if ((rc = rays_params(ctx, p, cd, cfg, rays)) != GR_OK) return rc;
+    if (rays->n > 0 && !d_out) return fail(GR_ERR_INVALID_ARGUMENT, "out is null");
+    if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "needs the redshift point function");
+    if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
+    cd.out_mode = 5;
+    cd.lp_rmin = 0.0;
+    cd.lp_rmax = INFINITY;
+    cd.lp_pairs = d_out;
+    p.stats = (unsigned long long*)d_stats;
+    return launch_trace(ctx, p, cd, stream);
+}
+
 int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, gr_point* d_points,
                                    gr_stats* d_stats, void* hip_stream)
 {
@@ -1023,6 +1050,24 @@ int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
     if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
     if ((rc = gr_ray_summary_device(ctx, cfg, &dev, pf, (double*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
+                                    ctx->stream)) != GR_OK) return rc;
+    if (bytes) GR_HIP(hipMemcpyAsync(out, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return end_host_call(ctx, stats);
+}
+
+int32_t gr_ray_tangent(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                       double* out, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (rays && rays->n > 0 && !out) return fail(GR_ERR_INVALID_ARGUMENT, "out is null");
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    gr_rayset dev;
+    if ((rc = stage_rays(ctx, rays, dev, 0, nullptr)) != GR_OK) return rc;
+    const size_t bytes = sizeof(double) * 8 * (size_t)rays->n;
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = gr_ray_tangent_device(ctx, cfg, &dev, pf, (double*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
                                     ctx->stream)) != GR_OK) return rc;
     if (bytes) GR_HIP(hipMemcpyAsync(out, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);

@@ -2,6 +2,7 @@
 //
 //     hipcc ... -DGR_TU_METRIC=<GR_METRIC_* id> -c kernels_tu.hip -o kernels_m<id>.o                       (fp64)
 //     hipcc ... -DGR_TU_METRIC=<id> -DGR_TU_F32 -Xclang -cl-single-precision-constant ... -o kernels32_m<id>.o   (fp32)
+//     hipcc ... -DGR_TU_METRIC=<id> -DGR_TU_TAN -c kernels_tu.hip -o kernelstan_m<id>.o                     (tangent)
 //
 // so that every metric's kernels hold only that metric's component function (gr_device.hpp, GenericMetricT) and the
 // library builds on all cores at once (__graft_entry__.build_hip).  The fp32 objects are the same source with
@@ -11,11 +12,19 @@
 //
 // Exports (plain signatures: the host unit, gradus_mi355x.hip, passes its gr::Params by address -- gr32::Params has the
 // same layout, its fields are double / integer / pointers only):
-//     gr64_launch_trace_m<ID>, gr64_launch_path_m<ID>, gr64_launch_apply_m<ID>      gr32_launch_trace_m<ID>
+//     gr64_launch_trace_m<ID>, gr64_launch_path_m<ID>, gr64_launch_apply_m<ID>      gr32_launch_trace_m<ID>      grt_launch_trace_m<ID>
 #ifndef GR_TU_METRIC
 #error "compile with -DGR_TU_METRIC=<metric id>"
 #endif
-#ifdef GR_TU_F32
+#if defined(GR_TU_TAN)
+// third flavour: real = value + ∂/∂α + ∂/∂β (gr_tangent.hpp), the one-ray-per-lane kernel only, one wave per SIMD (the
+// state is three times as wide; these kernels trace a few thousand rays per call for the transfer-function Jacobians)
+#define GR_REAL_IS_TAN2 1
+#define GR_NS grt
+#define GR_TU_PREFIX grt
+#define GR_LANE_ONLY 1
+#define GR_LANE_MIN_WAVES 1
+#elif defined(GR_TU_F32)
 #define GR_REAL_IS_FLOAT 1
 #define GR_NS gr32
 #define GR_TU_PREFIX gr32
@@ -43,7 +52,7 @@ hipError_t GR_TU_NAME(_launch_trace_m)(int kernel, int block, int n_cu, int wave
     return GR_NS::launch_metric<TuMetric>(k, p, stream);
 }
 
-#ifndef GR_TU_F32
+#if !defined(GR_TU_F32) && !defined(GR_TU_TAN)
 hipError_t GR_TU_NAME(_launch_path_m)(const void* params, double* d_path, int64_t cap, unsigned long long* d_n, hipStream_t stream)
 {
     return GR_NS::launch_path_metric<TuMetric>(*reinterpret_cast<const GR_NS::Params*>(params), d_path, cap, d_n, stream);

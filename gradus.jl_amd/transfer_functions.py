@@ -106,7 +106,16 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
         _lib.check(L.gr_rayset_endpoints(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), pts.ctypes.data, None))
         return pts
 
+    def tangent(α, β, heights=None):
+        """(g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status) per ray: dual numbers through the integrator on the device
+        (`gr_ray_tangent`), what the reference's ForwardDiff.jacobian around tracegeodesics produces."""
+        rs, keep = rayset(α, β, heights)
+        out = np.zeros((rs.n, 8))
+        _lib.check(L.gr_ray_tangent(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, None))
+        return out
+
     trace.endpoints = endpoints
+    trace.tangent = tangent
     return trace
 
 
@@ -115,7 +124,7 @@ def _rho(pts):
 
 
 def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zero_atol=1e-7, max_iter=50, eps=1e-5,
-                            heights=None, x0=None):
+                            heights=None, x0=None, polish=True):
     """_find_offset_for_radius (precision-solvers.jl:135-236) for a batch of (r_target, θ) problems.
 
     Safeguarded Newton on y(r) = ρ(r, θ) - r_target, which is monotonic in r: the start
@@ -176,6 +185,8 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
         # always available there.  Newton squares the error, so three iterations past zero_atol are at the floor.
         n_polish[active] += (hit & (ybest[active] <= zero_atol)).astype(np.int64)
         conv = polished | (n_polish[active] >= 4) | (hit & (np.abs(ya) <= 1e-11 * np.maximum(r_target[active], 1.0)))
+        if not polish:      # the reference's loop: stop at the first iterate with |y| <= zero_atol
+            conv = hit & (np.abs(ya) <= zero_atol)
         # bracket bookkeeping
         # a ray that neither hits nor is captured has left the chart: its offset is too large
         # (the reference projects such an end point onto the equator and gets y > 0)
@@ -203,11 +214,100 @@ def find_offsets_for_radius(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zer
     return r, best_pts, best_g
 
 
-def jacobians(trace, r, θ, *, α0=0.0, β0=0.0, rel_step=3e-4):
-    """|∂(ρ, g)/∂(α, β)|⁻¹ (jacobian_∂αβ_∂gr, precision-solvers.jl:401-451) for a batch, by central
-    differences: four rays per problem in one launch."""
+def find_offsets_for_radius_newton_ad(trace, r_target, θ, *, r_min, α0=0.0, β0=0.0, zero_atol=1e-7, max_iter=50,
+                                      heights=None, contrapoint_bias=2.0):
+    """_find_offset_for_radius (precision-solvers.jl:135-236) restated step for step for a batch of (r_target, θ)
+    problems, with the reference's own ingredients: the derivative dρ/dr of the image-plane map from dual numbers carried
+    through the integrator (`trace.tangent`; _make_image_plane_mapper :70-130 does the same with ForwardDiff), the cold
+    start max(20, r_target), the Newton update, the contrapoint kept from steps that fall short, the biased bisection
+    (2·contra + x)/3 when a step lands below zero or within r_min + 1 of the hole, and -- what matters for parity --
+    the loop's exit at the FIRST iterate with |ρ - r_target| <= zero_atol.
+
+    Why this exists beside `find_offsets_for_radius` (which polishes every root to the integrator's noise floor): the
+    transfer function divides by √(1 - g✶) near the extrema of g, so the 1e-7 residual the reference leaves in ρ is not
+    innocent there -- it biases its recorded statistics upward (tests/test_transfer_functions_host.py).  Reproducing the
+    reference's numbers means reproducing its iterates.  Returns (r, summaries, g) like the other solver."""
+    r_target = np.asarray(r_target, dtype=np.float64)
+    θ = np.asarray(θ, dtype=np.float64)
+    n = r_target.size
+    cθ, sθ = np.cos(θ), np.sin(θ)
+
+    def step(idx, r):
+        α, β = r * cθ[idx] + α0, r * sθ[idx] + β0
+        out = trace.tangent(α, β) if heights is None else trace.tangent(α, β, heights[idx])
+        df = out[:, 4] * cθ[idx] + out[:, 5] * sθ[idx]
+        return out, df, out[:, 1] - r_target[idx]
+
+    x = np.maximum(20.0, r_target)
+    contra = np.zeros(n)
+    all_idx = np.arange(n)
+    point, df, y = step(all_idx, x)
+    Δy = np.zeros(n)
+    previous = np.zeros((n, 6))
+    failed = np.zeros(n, dtype=bool)
+    active = np.abs(y) > zero_atol
+    i = 0
+    while active.any() and i <= max_iter:
+        idx = all_idx[active]
+        with np.errstate(all="ignore"):
+            next_x = x[idx] - y[idx] / df[idx]
+        p2, df2, next_y = step(idx, next_x)
+        short = (next_x < 0) | ((next_y < 0) & (y[idx] > 0))
+        contra[idx] = np.where(short, np.maximum(contra[idx], next_x), contra[idx])
+        bis = short & ((next_x < 0) | (p2[:, 1] < (r_min + 1.0)))
+        if bis.any():
+            jb = idx[bis]
+            nb = (contra[jb] * contrapoint_bias + x[jb]) / (1.0 + contrapoint_bias)
+            p3, df3, y3 = step(jb, nb)
+            next_x[bis], next_y[bis], df2[bis], p2[bis] = nb, y3, df3, p3
+        with np.errstate(all="ignore"):
+            stop = (next_y < 0) & (y[idx] < 0) & ((-y[idx] / df[idx]) < 0)       # "Converge failed": the reference breaks here
+            next_Δy = (y[idx] - next_y) / y[idx]
+            cycle = (y[idx] > 0) & np.any(np.abs(previous[idx] - next_Δy[:, None]) <= zero_atol * 100, axis=1)
+        # a cycle is finished off by bracketing in the reference (Roots.find_zero on (contra, x)); bisection here
+        if cycle.any():
+            jc = idx[cycle]
+            lo_, hi_ = contra[jc].copy(), x[jc].copy()
+            for _ in range(60):
+                mid = 0.5 * (lo_ + hi_)
+                pm, dfm, ym = step(jc, mid)
+                neg = ym < 0
+                lo_, hi_ = np.where(neg, mid, lo_), np.where(neg, hi_, mid)
+                if np.all(np.abs(ym) <= zero_atol):
+                    break
+            next_x[cycle], next_y[cycle], df2[cycle], p2[cycle] = mid, ym, dfm, pm
+        upd = ~stop
+        ju = idx[upd]
+        x[ju], y[ju], df[ju], Δy[ju] = next_x[upd], next_y[upd], df2[upd], next_Δy[upd]
+        point[ju] = p2[upd]
+        previous[ju, i % 6] = next_Δy[upd]
+        failed[idx[stop]] = True
+        active = (np.abs(y) > zero_atol) & ~failed
+        active[idx[cycle]] = False
+        i += 1
+    status = point[:, 7].astype(np.int32)
+    ok = (x >= 0) & (np.abs(y) <= 1e-4 * r_target) & (status == StatusCodes.IntersectedWithGeometry)
+    r = np.where(ok, x, np.nan)
+    pts = np.zeros(n, dtype=SUMMARY_DTYPE)
+    pts["status"] = status
+    pts["x"][:, 0], pts["x"][:, 1], pts["x"][:, 2] = point[:, 6], point[:, 1], math.pi / 2
+    return r, pts, point[:, 0].copy(), point
+
+
+def jacobians(trace, r, θ, *, α0=0.0, β0=0.0, rel_step=3e-4, heights=None):
+    """|∂(ρ, g)/∂(α, β)|⁻¹ (jacobian_∂αβ_∂gr, precision-solvers.jl:401-451) for a batch.
+
+    With a tracer that offers `tangent` (the device tracer: `gr_ray_tangent`) the four partial derivatives come from
+    dual numbers carried through the integrator, one ray per problem, as in the reference (ForwardDiff.jacobian around
+    tracegeodesics).  Otherwise by central differences: four rays per problem in one launch."""
     r, θ = np.asarray(r, dtype=np.float64), np.asarray(θ, dtype=np.float64)
     α, β = r * np.cos(θ) + α0, r * np.sin(θ) + β0
+    if getattr(trace, "tangent", None) is not None:
+        out = trace.tangent(α, β) if heights is None else trace.tangent(α, β, heights)
+        ok = out[:, 7].astype(np.int32) == StatusCodes.IntersectedWithGeometry
+        with np.errstate(all="ignore"):
+            J = np.abs(1.0 / (out[:, 4] * out[:, 3] - out[:, 5] * out[:, 2]))
+        return np.where(ok, J, np.nan)
     δ = rel_step * np.maximum(np.abs(r), 1.0)
     pts, g = trace(np.concatenate([α + δ, α - δ, α, α]), np.concatenate([β, β, β + δ, β - δ]))
     n = r.size
@@ -231,8 +331,20 @@ class _Workhorse:
 
     def __call__(self, rₑ, θ, x0=None):
         s = self.s
+        if s.get("root_finder") == "reference" and getattr(self.trace, "tangent", None) is not None:
+            # the reference's iterates: Newton with the dual-number derivative, exit at the first |y| <= zero_atol; the
+            # Jacobian of the accepted ray comes with it (same ray, same dual numbers)
+            r, pts, g, tan = find_offsets_for_radius_newton_ad(self.trace, rₑ, θ, r_min=self.r_min, α0=s["α0"], β0=s["β0"],
+                                                               zero_atol=s["zero_atol"])
+            self.last_r = r
+            if np.any(np.isnan(r)):
+                k = int(np.nonzero(np.isnan(r))[0][0])
+                raise RuntimeError(f"Transfer function integration failed (rₑ={np.asarray(rₑ)[k]}, θ={np.asarray(θ)[k]}).")
+            with np.errstate(all="ignore"):
+                J = np.abs(1.0 / (tan[:, 4] * tan[:, 3] - tan[:, 5] * tan[:, 2]))
+            return g, J, pts["x"][:, 0].copy()
         r, pts, g = find_offsets_for_radius(self.trace, rₑ, θ, r_min=self.r_min, α0=s["α0"], β0=s["β0"],
-                                            zero_atol=s["zero_atol"], x0=x0)
+                                            zero_atol=s["zero_atol"], x0=x0, polish=s.get("polish", True))
         self.last_r = r
         if np.any(np.isnan(r)):
             k = int(np.nonzero(np.isnan(r))[0][0])
@@ -310,12 +422,20 @@ def _check_gmin_gmax(gmin, gmax, gs):
 
 def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offset=0.3, zero_atol=1e-7, α0=0.0, β0=0.0,
                                   chart=None, max_time=None, redshift_pf=None, ensemble=None, tracer=None,
-                                  thick_tracers=None, **solver_opts):
+                                  thick_tracers=None, polish=True, root_finder="reference", **solver_opts):
     """cunningham_transfer_function (cunningham-transfer-functions.jl:337-387) for every emission
     radius of `radii` at once.  Returns a list of CunninghamTransferData.
 
     `tracer` replaces the device tracer by another `(α, β) -> (points, g)` callable (the CPU tests
-    use it to drive this host logic with oracle-traced rays); the default traces on the MI355X."""
+    use it to drive this host logic with oracle-traced rays); the default traces on the MI355X.
+
+    `root_finder = "reference"` (default; needs a tracer with `.tangent`, which the device tracer has): the offsets are
+    found by the reference's own Newton iteration with the dual-number derivative and its exit at the first
+    |ρ - rₑ| <= zero_atol (`find_offsets_for_radius_newton_ad`), the Jacobian comes from the dual numbers of the
+    accepted ray.  `"polished"` (and any tracer without `.tangent`): safeguarded Newton with a difference quotient,
+    every root polished to the integrator's noise floor, Jacobians by central differences.  The two agree to 1e-3 in
+    the recorded statistics wherever those are well-conditioned; the reference-faithful one reproduces them to
+    1e-5 ... 1e-7 there (tests/test_transfer_functions_host.py)."""
     thick = hasattr(d, "cross_section")
     if not thick and not isinstance(d, (ThinDisc, DatumPlane)):
         raise NotImplementedError(f"transfer functions: no implementation for {type(d).__name__}")
@@ -327,7 +447,7 @@ def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offs
         if redshift_pf is None:
             redshift_pf = ConstPointFunctions.redshift(m, x, **({"ensemble": ensemble} if m.metric_id != 0 else {}))
         tracer = device_tracer(m, x, max_time, chart, redshift_pf, ensemble, **solver_opts)
-    setup = dict(α0=float(α0), β0=float(β0), zero_atol=float(zero_atol))
+    setup = dict(α0=float(α0), β0=float(β0), zero_atol=float(zero_atol), polish=bool(polish), root_finder=root_finder)
     if thick:
         from .tracing import domain_upper_hemisphere
 

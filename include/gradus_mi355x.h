@@ -340,6 +340,18 @@ int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
  * α[i], β[i]), d, ...; ensemble = EnsembleEndpointThreads()) as impact_parameters_for_radius_obscured
  * (src/tracing/precision-solvers.jl:363-372) and the thick-disc transfer-function workhorse
  * (src/transfer-functions/cunningham-transfer-functions.jl:253-300) call it. ---- */
+/* The same rays with DUAL NUMBERS THROUGH THE INTEGRATOR: what jacobian_∂αβ_∂gr obtains from ForwardDiff.jacobian around
+ * tracegeodesics (src/tracing/precision-solvers.jl:401-451) and the Cunningham transfer functions divide by
+ * (src/transfer-functions/cunningham-transfer-functions.jl:337-387).  The integrator is instantiated on a scalar that carries
+ * ∂/∂α and ∂/∂β (gr_tangent.hpp): the tangent equations are integrated with the very Tsit5 steps of the value, the event
+ * time's dependence on (α, β) is added by implicit differentiation at the disc.  out: n x 8 doubles
+ * (g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status); g = NaN unless the ray met the geometry.  cfg->disc_id must not be NONE. */
+int32_t gr_ray_tangent_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                              const gr_pointfunction* pf, double* d_out /* n x 8 */, gr_stats* d_stats,
+                              void* hip_stream);
+int32_t gr_ray_tangent(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
+                       const gr_pointfunction* pf, double* out /* host, n x 8 */, gr_stats* stats);
+
 int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
                                    gr_point* d_points /* n */, gr_stats* d_stats, void* hip_stream);
 int32_t gr_rayset_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
