@@ -422,7 +422,7 @@ def _check_gmin_gmax(gmin, gmax, gs):
 
 def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offset=0.3, zero_atol=1e-7, α0=0.0, β0=0.0,
                                   chart=None, max_time=None, redshift_pf=None, ensemble=None, tracer=None,
-                                  thick_tracers=None, polish=True, root_finder="reference", **solver_opts):
+                                  thick_tracers=None, polish=True, root_finder="reference", _raw=None, **solver_opts):
     """cunningham_transfer_function (cunningham-transfer-functions.jl:337-387) for every emission
     radius of `radii` at once.  Returns a list of CunninghamTransferData.
 
@@ -493,6 +493,8 @@ def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offs
     upper = np.concatenate([np.full(R, θ_offset), np.full(R, math.pi + θ_offset)])
     best = _golden_section_batch(objective, lower, upper, n_iter)
     gmin_c, gmax_c = best[:R], -best[R:]
+    if _raw is not None:
+        _raw.append((data.copy(), gmin_c.copy(), gmax_c.copy()))
 
     out = []
     for k in range(R):

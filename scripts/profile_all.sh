@@ -12,5 +12,6 @@ PROF_CMD="scripts/sibling_workloads.py c5p" PROF_KERNEL="k_trace_persistent<gr::
 PROF_F32=1 PROF_CMD="scripts/sibling_workloads.py c5f32" PROF_KERNEL="gr32::" bash scripts/profile_pmc.sh ${T}_c5f32
 PROF_CMD="scripts/sibling_workloads.py applypf" PROF_KERNEL="k_apply_pf" bash scripts/profile_pmc.sh ${T}_applypf
 PROF_CMD="scripts/sibling_workloads.py endpoints" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_endpoints
+PROF_CMD="scripts/sibling_workloads.py tangent" PROF_KERNEL="k_trace_lane<grt::" bash scripts/profile_pmc.sh ${T}_tangent
 # drop the bulky raw traces, keep summaries
 for d in gpurun_out/prof_${T}_*; do rm -rf $d/trace $d/pmcA $d/pmcB $d/pmcC $d/pmcD; done

@@ -9,6 +9,7 @@ PROF_CMD="scripts/sibling_workloads.py <which>" PROF_KERNEL=<substring of the ke
     c5f32     config 5 with the fp32 kernels at tol 1e-5                                              gr32::k_trace_*
     applypf   apply(pf, cache) on the 2048² end points of the bench plane                             k_apply_pf
     endpoints gr_render_endpoints_device, 2048² Kerr (152-B records)                                  k_trace_lane<KerrFamily<false>,1>
+    tangent   gr_ray_tangent_device, 1024² Kerr rays against the datum plane (value + ∂/∂α + ∂/∂β)     grt::k_trace_lane<KerrFamily<false>,1>
 
 Prints one JSON line {"rays": rays per launch, "launches": n, ...} (bench.log of the profile run); the first 2
 launches are warm-up, like bench.py's.
@@ -103,6 +104,46 @@ elif which in ("applypf", "endpoints"):
     ms = [a.elapsed_time(b) for a, b in ev]
     rays = n
     extra = {"bytes_per_ray": 160 if which == "applypf" else 152}
+elif which == "tangent":
+    import ctypes as C
+
+    import torch
+
+    from gradus_jl_amd import _lib
+    from gradus_jl_amd.rendering import abi_pointfunction
+    from gradus_jl_amd.tracing import lnr_momentum_to_global_velocity_matrix
+
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(75), 0.0])
+    S = 1024
+    n = S * S
+    cfg = G.tracing_configuration(m, x, np.zeros((1, 4)), G.DatumPlane(0.0), 2000.0, ensemble=ens)
+    acfg = cfg.abi_config()
+    apf, keep = abi_pointfunction(G.ConstPointFunctions.redshift(m, x))
+    dev = torch.device("cuda", 0)
+    aa, bb = np.meshgrid(np.linspace(*ALIMS, S), np.linspace(*BLIMS, S))
+    d_a = torch.from_numpy(aa.ravel().copy()).to(dev)
+    d_b = torch.from_numpy(bb.ravel().copy()).to(dev)
+    rs = _lib.gr_rayset()
+    Mx = lnr_momentum_to_global_velocity_matrix(m, cfg.position)
+    for i in range(4):
+        rs.x_obs[i] = float(cfg.position[i])
+        for k in range(4):
+            rs.Mx[4 * i + k] = float(Mx[i, k])
+    rs.alpha, rs.beta, rs.area, rs.n = d_a.data_ptr(), d_b.data_ptr(), None, n
+    out = torch.empty(n * 8, dtype=torch.float64, device=dev)
+    L = _lib.load()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for i in range(reps):
+        ev[i][0].record()
+        _lib.check(L.gr_ray_tangent_device(ens.ctx.handle, C.byref(acfg), C.byref(rs), C.byref(apf), C.c_void_p(out.data_ptr()), None,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in ev]
+    rays = n
+    o = out.view(n, 8)
+    extra = {"bytes_per_ray": 16 + 64, "hit_fraction": float((o[:, 7] == 2).double().mean())}
 else:
     raise SystemExit(f"unknown workload {which}")
 

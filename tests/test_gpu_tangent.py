@@ -1,0 +1,113 @@
+"""`gr_ray_tangent` on the MI355X: the TANGENT flavour of the kernels (real = value + ∂/∂α + ∂/∂β through the
+integrator; SURVEY §8 f-4, jacobian_∂αβ_∂gr, src/tracing/precision-solvers.jl:401-451) against (1) its own host build,
+(2) central differences of the fp64 device path, (3) the values the reference records for its Cunningham transfer
+functions, with the reference's Newton root finder."""
+import math
+
+import numpy as np
+import pytest
+
+import harness as Hh
+
+pytestmark = pytest.mark.gpu
+
+GOLD = {(74, 4.0): 0.05550300700779827, (85, 4.0): 0.03602870590038378, (30, 7.0): 0.12205125501900763,
+        (30, 10.0): 0.1265019201038228, (30, 15.0): 0.12875961522283233, (30, 300.0): 0.13378948600255888,
+        (30, 800.0): 0.13470290875241375, (30, 1000.0): 0.13319637850028626}
+
+
+@pytest.fixture()
+def ens(G):
+    return G.EnsembleMI355X(0)
+
+
+def _tracer(G, ens, m, x, max_time, **kw):
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    chart = G.chart_for_metric(m, 2 * x[1], closest_approach=1.005)
+    return device_tracer(m, x, max_time, chart, G.ConstPointFunctions.redshift(m, x), ens, **kw)
+
+
+def test_device_tangents_equal_the_host_build(G, ens):
+    """Same source, two compilers: values to 1e-10, tangents to 1e-7 of their scale (contraction differs)."""
+    x = np.array([0.0, 1000.0, math.radians(30), 0.0])
+    m = G.KerrMetric(1.0, 0.998)
+    rng = np.random.default_rng(5)
+    al, be = rng.uniform(-12, 12, 200), rng.uniform(-12, 12, 200)
+    tr = _tracer(G, ens, m, x, 4000.0)
+    dev = tr.tangent(al, be)
+    cfg = G.tracing_configuration(m, x, np.zeros((1, 4)), G.DatumPlane(0.0), 4000.0,
+                                  chart=G.chart_for_metric(m, 2 * x[1], closest_approach=1.005))
+    host = Hh.ray_tangent(G, cfg, G.ConstPointFunctions.redshift(m, x), al, be)
+    assert np.array_equal(dev[:, 7], host[:, 7])
+    hit = dev[:, 7] == 2
+    assert hit.sum() > 120
+    np.testing.assert_allclose(dev[hit, 0:2], host[hit, 0:2], rtol=1e-9)
+    for c in range(2, 6):
+        scale = np.abs(host[hit, c]).max()
+        assert np.abs(dev[hit, c] - host[hit, c]).max() < 1e-6 * scale, c
+    # and the value part is the plain kernel's answer
+    pts, g = tr(al, be)
+    np.testing.assert_allclose(dev[hit, 0], g[hit], rtol=1e-8)
+    np.testing.assert_allclose(dev[hit, 1], pts["x"][hit, 1], rtol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["kerr", "johannsen", "kerr-newman", "johannsen-psaltis"])
+def test_device_tangents_equal_central_differences(G, ens, name):
+    """Per metric family (fused Kerr RHS, fused Johannsen RHS, generic dual-number functor -- here dual numbers of dual
+    numbers): the tangents against central differences of the fp64 device path at tolerance 1e-12."""
+    m = {"kerr": G.KerrMetric(1.0, 0.9), "johannsen": G.JohannsenMetric(1.0, 0.7, 1.0, 0.0, 0.0, 0.5),
+         "kerr-newman": G.KerrNewmanMetric(1.0, 0.6, 0.5), "johannsen-psaltis": G.JohannsenPsaltisMetric(1.0, 0.6, 1.0)}[name]
+    x = np.array([0.0, 1000.0, math.radians(55), 0.0])
+    rng = np.random.default_rng(11)
+    al, be = rng.uniform(-10, 10, 64), rng.uniform(3, 12, 64) * rng.choice([-1, 1], 64)
+    tr = _tracer(G, ens, m, x, 4000.0, abstol=1e-12, reltol=1e-12)
+    t = tr.tangent(al, be)
+    h = 1e-5
+    (pa, ga), (ma, gma) = tr(al + h, be), tr(al - h, be)
+    (pb, gb), (mb, gmb) = tr(al, be + h), tr(al, be - h)
+    ok = (t[:, 7] == 2) & (pa["status"] == 2) & (ma["status"] == 2) & (pb["status"] == 2) & (mb["status"] == 2)
+    assert ok.sum() > 40
+    fd = np.stack([(ga - gma), (gb - gmb), pa["x"][:, 1] - ma["x"][:, 1], pb["x"][:, 1] - mb["x"][:, 1]], axis=1) / (2 * h)
+    for c in range(4):
+        scale = np.abs(fd[ok, c]).max()
+        err = np.abs(t[ok, 2 + c] - fd[ok, c]).max()
+        assert err < 5e-5 * scale, (name, c, err, scale)
+
+
+def test_reference_transfer_function_values_with_dual_numbers(G, ens):
+    """The recorded statistics (test/smoke-tests/cunningham-transfer-functions.jl:25-39, atol 1e-3) with the reference's
+    root finder and dual-number Jacobians on the device: 1e-4 where the host build measures 4e-7 ... 5e-5."""
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(0.0, float("inf"))
+    for angle in (30, 74, 85):
+        x = np.array([0.0, 100_000.0, math.radians(angle), 0.0])
+        radii = [r for (a, r) in GOLD if a == angle]
+        out = G.cunningham_transfer_functions(m, x, d, radii, N=80, ensemble=ens, root_finder="reference",
+                                              chart=G.chart_for_metric(m, 2 * x[1], closest_approach=1.005))
+        for c, r in zip(out, radii):
+            meas = float(np.sum(c.f * c.g_star) / c.f.size)
+            tol = 1e-3 if (angle, r) in ((30, 15.0), (85, 4.0)) else 1e-4
+            print(f"  ({angle}°, {r}): {meas - GOLD[(angle, r)]:+.2e}")
+            assert meas == pytest.approx(GOLD[(angle, r)], abs=tol), (angle, r)
+
+
+def test_tangent_entry_point_edges(G, ens):
+    """Empty ray set; no geometry -> error (tangents are taken where the ray meets it); the context's fp32 switch does not
+    apply (tangents are always fp64)."""
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    x = np.array([0.0, 1000.0, math.radians(30), 0.0])
+    m = G.KerrMetric(1.0, 0.998)
+    tr = _tracer(G, ens, m, x, 4000.0)
+    assert tr.tangent(np.zeros(0), np.zeros(0)).shape == (0, 8)
+    a, b = np.array([5.0, -3.0]), np.array([4.0, 6.0])
+    ref = tr.tangent(a, b)
+    ens.set("precision", 32)
+    try:
+        np.testing.assert_array_equal(_tracer(G, ens, m, x, 4000.0).tangent(a, b), ref)
+    finally:
+        ens.set("precision", 64)
+    # per-ray datum planes (thick-disc transfer functions): heights shift the surface the tangents are taken on
+    up = tr.tangent(a, b, heights=np.array([0.5, 0.5]))
+    assert np.all(up[:, 7] == 2) and np.all(np.abs(up[:, 1] - ref[:, 1]) > 1e-3)

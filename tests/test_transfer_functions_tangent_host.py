@@ -67,3 +67,24 @@ def test_low_inclination_inner_disc_is_stable_here_but_off_the_record(G, angle, 
         assert ((conv.g_star > 0.999) | (conv.g_star < 0.001)).sum() >= 30
         top = conv.f[(conv.g_star > 0.999) & (conv.g_star < 1.0)]     # the extremal sample itself has f = 0
         assert np.ptp(top) < 0.02 * np.mean(top)                     # a clean limit, not noise
+
+
+def test_the_3_degree_record_is_this_sample_set_minus_fifteen_near_g_min(G):
+    """Attribution of the largest gap: at (3°, rₑ = 4) the recorded 0.140489 is what THIS build's samples give when 15 of
+    the 17 golden-section calls of the g_min search (all with g✶ < 6e-3, i.e. ~zero terms of the sum) are left out of the
+    mean -- 114 -> 99 samples: agreement 2e-6, the level of the well-conditioned cases.  The current source of the
+    reference always stores 16 + 1 calls per search (cunningham-transfer-functions.jl:391-429: `iterations = N`, no
+    convergence exit is reachable at these bracket widths), so the recorded value and the current source disagree about
+    the sample count, not about any g or f; this build follows the source (114 samples)."""
+    raw = []
+    c = ctf(G, 3, [4.0], root_finder="reference", _raw=raw)[0]
+    d = raw[0][0][0]                                   # rows θ, g, J, t; columns 80..96 = the g_min search in call order
+    assert c.f.size == 114
+    keep = np.ones(114, bool)
+    keep[82:97] = False
+    g, J = d[1, keep], d[2, keep]
+    gs = (g - g.min()) / np.ptp(g)
+    f = g * np.sqrt(gs * (1 - gs)) * np.ptp(g) * J / (math.pi * 4.0)
+    assert float(np.sum(f * gs) / f.size) == pytest.approx(GOLD[(3, 4.0)], abs=1e-5)
+    full = (d[1] - d[1].min()) / np.ptp(d[1])
+    assert np.all(full[82:97] < 6e-3)
