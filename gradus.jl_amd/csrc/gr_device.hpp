@@ -647,12 +647,15 @@ struct JohannsenMetric {
 // step then carried all nine metric bodies -- a 9 600-instruction step loop (57 KB of code against a 64 KB
 // instruction cache), 180 B of scratch per lane and 1.8x the time of Kerr.  ID < 0 keeps the run-time switch
 // (tests/host_harness.cpp traces every metric through one instantiation).
+#ifndef GR_JP_LANE_WAVES
+#define GR_JP_LANE_WAVES 2
+#endif
 template <int ID>
 struct GenericMetricT {
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
-    static constexpr int kLaneWavesPerSimd = GR_GENERIC_MIN_WAVES;
+    static constexpr int kLaneWavesPerSimd = (ID == GR_METRIC_JOHANNSEN_PSALTIS) ? GR_JP_LANE_WAVES : GR_GENERIC_MIN_WAVES;
     static constexpr bool kHasForce = false;
-    static constexpr bool kFusedRhs = false;
+    static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS);      // rhs() below
     int32_t id;
     real P[6];
     GR_DEV void load(const gr_config& c)
@@ -897,6 +900,85 @@ struct GenericMetricT {
     }
 
     GR_DEV void comps(real r, real s, real c, real g[5]) const { components<real>(r, s, c, g); }
+
+    // Johannsen-Psaltis: the whole right-hand side in one pass instead of dual numbers + the generic contraction (the
+    // form KerrFamily::rhs and JohannsenMetric::rhs take).  With w = 2Mr/Σ, h = ϵ3 M³ r/Σ², H = 1 + h, η = hΣ:
+    //   g_tt = H(w - 1), g_tϕ = -H a s² w, g_ϕϕ = H g_ϕϕ^Kerr - η s², g_rr = ΣH/Δ̃, g_θθ = Σ,   Δ̃ = Δ + a² s² h,
+    // the t-ϕ block has determinant -H s² Δ̃ (the Kerr identity (w-1)g_ϕϕ^K - a²s⁴w² = -s²Δ and Σ - 2Mr = Δ - a²s²), so
+    //   a^t = [(ρ² + a²s²w - η/H) T_t + a w T_ϕ]/Δ̃,  a^ϕ = [(w - 1) T_ϕ + a s² w T_t]/(s² Δ̃),         ρ² = r² + a².
+    // With U = v^t - a s² v^ϕ, ℓ = wU - v^t, ℓ_ϕ^K = s²(ρ² v^ϕ - a w U), Φ^K = wU² - (v^t)² + s²ρ²(v^ϕ)² (dots: along
+    // (v^r, v^θ) at fixed velocity; S2 = ∂_θ s² = 2 sinθ cosθ):
+    //   T_t = ḣ ℓ + H(ẇ U - a w (s²)˙ v^ϕ),   T_ϕ = ḣ ℓ_ϕ^K + H ℓ̇_ϕ^K - (η s²)˙ v^ϕ,
+    //   Φ_x = h_x Φ^K + H Φ^K_x - (η s²)_x (v^ϕ)²,   L_x = ∂_x ln g_rr = Σ_x/Σ + h_x/H - Δ̃_x/Δ̃,
+    //   a^r = (Δ̃/(ΣH)) ½(Φ_r + 2r v_θ²) - ½ L_r v_r² - L_θ v_r v_θ,   a^θ = [½Φ_θ + ½ g_rr L_θ v_r² + ½ a² S2 v_θ² - 2r v_r v_θ]/Σ.
+    // Two reciprocals (1/Σ; 1/(H Δ̃ s²) shared by 1/H, 1/Δ̃, 1/(s²Δ̃)).  Equal to eval() + the generic contraction to
+    // rounding (tests/test_kernel_logic_host.py::test_fused_johannsen_psaltis_rhs_equals_generic_contraction).
+    GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
+                    real& at, real& ar, real& ah, real& ap) const
+    {
+        const real M = P[0], a = P[1];
+        const real a2 = a * a, tM = 2.0 * M, eps = P[2] * M * M * M;
+        const real r2 = r * r, s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
+        const real Sig = GR_FMA(a2, c * c, r2);
+        const real iSig = rcp_full(Sig);
+        const real Del = GR_FMA(-tM, r, r2) + a2;
+        const real rho2 = r2 + a2;
+        const real a2S2 = a2 * S2;                         // -Σ_θ
+        const real a2s2 = a2 * s2;
+        // w, h, η and their gradients
+        const real w = (tM * r) * iSig;
+        const real w_r = iSig * GR_FMA(-w, tr, tM);
+        const real w_h = (w * a2S2) * iSig;
+        const real eta = (eps * r) * iSig;                 // h Σ
+        const real h = eta * iSig;
+        const real eta_r = iSig * GR_FMA(-eta, tr, eps);
+        const real eta_h = (eta * a2S2) * iSig;
+        const real h_r = iSig * GR_FMA(-2.0 * h, tr, eps * iSig);
+        const real h_h = 2.0 * ((h * a2S2) * iSig);
+        const real H = 1.0 + h;
+        const real Dt = GR_FMA(a2s2, h, Del);              // Δ̃
+        const real Dt_r = GR_FMA(a2s2, h_r, tr - tM);
+        const real Dt_h = GR_FMA(a2S2, h, a2s2 * h_h);
+        // reciprocals
+        const real HD = H * Dt;
+        const real R = rcp_full(HD * s2);                  // 1/(H Δ̃ s²)
+        const real iH = R * (Dt * s2), iDt = R * (H * s2), is2Dt = R * H;
+        // dots along the ray
+        const real hd = GR_FMA(h_r, vr, h_h * vh);
+        const real wd = GR_FMA(w_r, vr, w_h * vh);
+        const real s2d = S2 * vh;
+        const real es2_r = s2 * eta_r;                      // (η s²)_r
+        const real es2_h = GR_FMA(S2, eta, s2 * eta_h);    // (η s²)_θ
+        const real es2d = GR_FMA(es2_r, vr, es2_h * vh);
+        // linear forms
+        const real avp = a * vp;
+        const real U = GR_FMA(-avp, s2, vt);
+        const real wU = w * U;
+        const real l = wU - vt;
+        const real B = GR_FMA(rho2, vp, -(a * wU));         // ℓ_ϕ^K / s²
+        const real lpK = s2 * B;
+        const real aws2d = (a * w) * s2d;
+        const real Tt = GR_FMA(hd, l, H * GR_FMA(wd, U, -(aws2d * vp)));
+        const real Bd = GR_FMA(tr * vr, vp, GR_FMA(-(a * wd), U, (a * aws2d) * vp));      // Ḃ at fixed velocity
+        const real lpKd = GR_FMA(s2d, B, s2 * Bd);
+        const real Tp = GR_FMA(hd, lpK, GR_FMA(H, lpKd, -(es2d * vp)));
+        at = GR_FMA(GR_FMA(a2s2, w, rho2) - eta * iH, Tt, (a * w) * Tp) * iDt;
+        ap = GR_FMA(w - 1.0, Tp, ((a * s2) * w) * Tt) * is2Dt;
+        // quadratic forms
+        const real vp2 = vp * vp, U2 = U * U;
+        const real PhiK = GR_FMA(wU, U, GR_FMA(s2 * rho2, vp2, -(vt * vt)));
+        const real PhiK_r = GR_FMA(w_r, U2, (tr * s2) * vp2);
+        const real PhiK_h = GR_FMA(w_h, U2, S2 * GR_FMA(rho2, vp2, -2.0 * (wU * avp)));
+        const real Phi_r = GR_FMA(h_r, PhiK, GR_FMA(H, PhiK_r, -(es2_r * vp2)));
+        const real Phi_h = GR_FMA(h_h, PhiK, GR_FMA(H, PhiK_h, -(es2_h * vp2)));
+        const real L_r = GR_FMA(tr, iSig, GR_FMA(h_r, iH, -(Dt_r * iDt)));
+        const real L_h = GR_FMA(-a2S2, iSig, GR_FMA(h_h, iH, -(Dt_h * iDt)));
+        const real vr2 = vr * vr, vh2 = vh * vh, vrh = vr * vh;
+        const real girr = (Dt * iSig) * iH;                 // g^rr
+        ar = GR_FMA(girr, 0.5 * GR_FMA(tr, vh2, Phi_r), -GR_FMA(0.5 * L_r, vr2, L_h * vrh));
+        const real grr = (Sig * H) * iDt;
+        ah = iSig * GR_FMA(0.5, GR_FMA(grr * L_h, vr2, GR_FMA(a2S2, vh2, Phi_h)), -(tr * vrh));
+    }
 
     GR_DEV void eval(real r, real s, real c, real g[5], real gr[5], real gt[5], real gi[5]) const
     {

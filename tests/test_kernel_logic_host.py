@@ -503,3 +503,29 @@ def test_trace_windings_kernel_logic(G, oracle):
     g2 = Hh.render_endpoints(G, cfg2)
     ok = g2["status"] == r2["status"]
     assert (G.winding_number(g2)[ok] != G.winding_number(r2)[ok]).sum() <= 1
+
+
+def test_fused_johannsen_psaltis_rhs_equals_generic_contraction(G, oracle):
+    """GenericMetricT<JOHANNSEN_PSALTIS>::rhs (fused, hand-derived) against the dual-number eval() + the generic
+    contraction and the oracle's dual-number geodesic_equation, random spins and deformations."""
+    import ctypes as C
+
+    rng = np.random.default_rng(13)
+    L = Hh.lib()
+    errs_fg, errs_fo = [], []
+    for _ in range(400):
+        params = (rng.uniform(0.5, 1.5), 0.0, rng.uniform(-1.0, 3.0))
+        params = (params[0], rng.uniform(-0.95, 0.95) * params[0], params[2])
+        m = G.JohannsenPsaltisMetric(*params)
+        r = 1.05 * m.inner_radius() + 10.0 ** rng.uniform(-1, 3)
+        th = rng.uniform(0.02, math.pi - 0.02)
+        v = np.array([rng.uniform(1, 2), rng.uniform(-1, 1), rng.uniform(-1, 1) / r, rng.uniform(-1, 1) / r])
+        cfg = G.tracing_configuration(m, np.array([0.0, r, th, 0.0]), v, None, (0.0, 1.0)).abi_config()
+        fused, generic = np.zeros(4), np.zeros(4)
+        assert L.hh_rhs_both(C.byref(cfg), C.c_double(r), C.c_double(th), v.ctypes.data_as(C.c_void_p),
+                             fused.ctypes.data_as(C.c_void_p), generic.ctypes.data_as(C.c_void_p)) == 0
+        ref = oracle.geodesic_equation(oracle.make_config("johannsen-psaltis", params), np.array([0.0, r, th, 0.0]), v)
+        errs_fg.append(np.abs(fused - generic).max() / np.abs(generic).max())
+        errs_fo.append(np.abs(fused - ref).max() / np.abs(ref).max())
+    assert np.median(errs_fg) < 5e-15 and max(errs_fg) < 5e-12, (np.median(errs_fg), max(errs_fg))
+    assert np.median(errs_fo) < 5e-15 and max(errs_fo) < 5e-12, (np.median(errs_fo), max(errs_fo))
