@@ -33,17 +33,18 @@ def ctf(G, angle, radii, **kw):
 
 def test_well_conditioned_reference_values_to_1e4(G):
     """Measured with this build: (30°, 7) -6.7e-6, (30°, 10) 4.0e-5, (30°, 300) 5e-5, (30°, 800) -3.7e-7,
-    (30°, 1000) 2.1e-5 -- bound 1e-4, ten times below the reference's atol."""
+    (30°, 1000) 2.1e-5 -- bound 2e-4 (another compiler's rounding moves these by up to 1e-4: the statistic amplifies
+    relative noise in g by 1e6), five times below the reference's atol."""
     radii = [7.0, 10.0, 300.0, 800.0, 1000.0]
     out = ctf(G, 30, radii, root_finder="reference")
     for c, r in zip(out, radii):
         assert c.f.size == 114 and not np.any(np.isnan(c.f))
-        assert measure(c) == pytest.approx(GOLD[(30, r)], abs=1e-4), r
+        assert measure(c) == pytest.approx(GOLD[(30, r)], abs=2e-4), r
 
 
 def test_reference_values_within_the_reference_tolerance(G):
     """(74°, 4) 4.6e-6; (30°, 15) 4.1e-4 and (85°, 4) -5.5e-4 inside the reference's 1e-3."""
-    assert measure(ctf(G, 74, [4.0], root_finder="reference")[0]) == pytest.approx(GOLD[(74, 4.0)], abs=1e-4)
+    assert measure(ctf(G, 74, [4.0], root_finder="reference")[0]) == pytest.approx(GOLD[(74, 4.0)], abs=2e-4)
     assert measure(ctf(G, 30, [15.0], root_finder="reference")[0]) == pytest.approx(GOLD[(30, 15.0)], abs=1e-3)
     assert measure(ctf(G, 85, [4.0], root_finder="reference")[0]) == pytest.approx(GOLD[(85, 4.0)], abs=1e-3)
 
