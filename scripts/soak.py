@@ -46,6 +46,7 @@ fam = [
 bad = []
 tot = mis = 0
 worst = 0.0
+unexplained_total = 0
 for case in range(n_scenes):
     name, gen, cls = fam[int(rng.integers(0, len(fam)))]
     params = gen()
@@ -126,7 +127,17 @@ for case in range(n_scenes):
     lim_e = max(1e3 * tol, 1e-6) * (200 if name == "kerr-refractive" else 10 if name == "kerr-dark-matter" else 1)
     worst = max(worst, e2 / lim_e)
     if mism > 8 or e2 >= lim_e:
-        bad.append((case, name, tuple(round(p, 4) for p in params), kind, f"mism={mism} err={e2:.2e} tol={tol} robs={r_obs:.1f} th={math.degrees(th):.1f} gtol={gtol:.4f} hemi={hemi} q={q:.2f}"))
-print(f"scenes={n_scenes} seed={seed} rays={tot} status-mismatches={mis} ({mis / max(tot, 1):.4%}) worst err/limit={worst:.3f} failing={len(bad)}")
+        # conditioning: which of the mismatching rays does the ORACLE classify differently from itself when its tolerance is
+        # nudged by -10 % / +10 %?  Those are rays no two implementations agree on; what is left is unexplained.
+        flips = np.zeros(got.size, dtype=bool)
+        for f in (0.9, 1.1):
+            ocfg2 = oracle.make_config(name, params, disc=od, lambda_max=lam, gtol=gtol, abstol=f * tol, reltol=f * tol, upper_hemisphere=hemi, q=q)
+            ref2 = oracle.trace(ocfg2, x, oracle.render_velocities(ocfg2, x, (-lim, lim), (-lim, lim), W, H), nthreads=16)
+            flips |= ref2["status"] != ref["status"]
+        unexplained = int(((got["status"] != ref["status"]) & ~flips).sum())
+        unexplained_total += unexplained
+        bad.append((case, name, tuple(round(p, 4) for p in params), kind, f"mism={mism} err={e2:.2e} unexplained={unexplained} oracle-self-flips={int(flips.sum())} tol={tol} robs={r_obs:.1f} th={math.degrees(th):.1f} gtol={gtol:.4f} hemi={hemi} q={q:.2f}"))
+print(f"scenes={n_scenes} seed={seed} rays={tot} status-mismatches={mis} ({mis / max(tot, 1):.4%}) worst err/limit={worst:.3f} failing={len(bad)} "
+      f"mismatches in failing scenes the oracle does not flip itself under a 10 % tolerance nudge: {unexplained_total}")
 for b in bad:
     print("  ", b)
