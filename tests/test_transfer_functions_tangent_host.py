@@ -89,3 +89,22 @@ def test_the_3_degree_record_is_this_sample_set_minus_fifteen_near_g_min(G):
     assert float(np.sum(f * gs) / f.size) == pytest.approx(GOLD[(3, 4.0)], abs=1e-5)
     full = (d[1] - d[1].min()) / np.ptp(d[1])
     assert np.all(full[82:97] < 6e-3)
+
+
+def test_problem_cases_with_the_reference_root_finder(G):
+    """'ones that have been problematic in the past' (smoke-tests/cunningham-transfer-functions.jl:41-51,
+    test/transfer-functions/test-problem-cases.jl:20-35) through the Newton iteration with dual-number derivatives:
+    grazing inclinations, retrograde spins, the ISCO itself, a = 1 with the emitter 1 % outside the horizon.  Every root
+    find converges, every sample is finite, and the safeguarded difference-quotient route gives the same statistic."""
+    cases = [(-0.6, 1e5, 88, 784.8253509875607), (-0.998, 1e5, 88, 953.9915665264327), (0.0, 1e5, 88, 631.1007589946363),
+             (0.744, 1e5, 88, 3.1880132176627862), (0.998, 5e5, 88.0, 1.2469706551751847),
+             (0.10324137931034483, 5e5, 82.06896551724138, 21.755193176415617), (0.998, 5e5, 88.0, 1.2369706551751847),
+             (0.9291724137931034, 5e5, 88.0, 2.1204839212537308), (1.0, 1e5, 88, 1.01)]
+    for a, r_obs, angle, r in cases:
+        x = np.array([0.0, r_obs, math.radians(angle), 0.0])
+        m, tr = Hh.tangent_tracer(G, a, x, 2 * r_obs)
+        d = G.ThinDisc(0.0, float("inf"))
+        c = G.transfer_functions.cunningham_transfer_function(m, x, d, r, N=80, tracer=tr, root_finder="reference")
+        p = G.transfer_functions.cunningham_transfer_function(m, x, d, r, N=80, tracer=tr, root_finder="polished")
+        assert c.f.size == 114 and np.all(np.isfinite(c.f)) and 0 < c.gmin < c.gmax < 2.0, (a, angle, r)
+        assert measure(c) == pytest.approx(measure(p), rel=3e-3), (a, angle, r)
