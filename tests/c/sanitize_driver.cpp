@@ -17,6 +17,8 @@
 extern "C" {
 int hh_render_endpoints(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, gr_point* out);
 int hh_render(const gr_config* cfg, const gr_plane* plane, const gr_range* rg, const gr_pointfunction* pf, double* image);
+// tests/host_harness_tangent.cpp: the tangent flavour (value + d/dalpha + d/dbeta through the integrator)
+int hht_ray_tangent(const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf, double* out);
 }
 
 static const double PI = 3.141592653589793;
@@ -85,6 +87,39 @@ int main()
         opf.pf_id = ORC_PF_AFFINE_TIME; opf.filter_id = ORC_FILTER_EARLY_TERM; opf.fill = NAN;
         std::vector<double> oimg(N);
         orc_apply_pf(&c, &opf, ref.data(), N, 200.0, oimg.data(), 2);
+    }
+    {   // dual numbers through the integrator: Kerr and Johannsen-Psaltis rays against the datum plane and a thin disc
+        for (int metric : { (int)GR_METRIC_KERR, (int)GR_METRIC_JOHANNSEN_PSALTIS }) {
+            for (int disc : { (int)GR_DISC_DATUM, (int)GR_DISC_THIN }) {
+                orc_config c;
+                std::memset(&c, 0, sizeof c);
+                c.metric_id = metric; c.params[0] = 1.0; c.params[1] = 0.6; c.params[2] = metric == GR_METRIC_KERR ? 0.0 : 1.0;
+                c.r_inner = 1.01 * (1.0 + std::sqrt(1.0 - 0.36)); c.r_outer = 12000.0;
+                c.gtol = 1e-2; c.lambda0 = 0.0; c.lambda1 = 200.0; c.abstol = c.reltol = 1e-9; c.maxiters = 1000000;
+                c.hemi_delta = 1e-4; c.winding_plane = PI / 2;
+                gr_config g;
+                std::memcpy(&g, &c, sizeof g);
+                g.disc_id = disc; g.disc_r_in = 0.0; g.disc_r_out = disc == GR_DISC_THIN ? 40.0 : INFINITY;
+                gr_rayset rs;
+                std::memset(&rs, 0, sizeof rs);
+                std::memcpy(rs.x_obs, x, sizeof x);
+                orc_lnr_transform(&c, x, rs.Mx);
+                std::vector<double> al(40), be(40), out(8 * 40);
+                for (int i = 0; i < 40; ++i) { al[i] = -8.0 + 0.4 * i; be[i] = 1.0 + 0.1 * i; }
+                rs.alpha = al.data(); rs.beta = be.data(); rs.n = 40;
+                gr_pointfunction pf;
+                std::memset(&pf, 0, sizeof pf);
+                pf.pf_id = GR_PF_REDSHIFT; pf.filter_id = GR_FILTER_NONE; pf.fill = NAN; pf.r_isco = 0.5;   // Keplerian branch everywhere
+                if (hht_ray_tangent(&g, &rs, &pf, out.data()) != 0) { std::printf("hht_ray_tangent failed\n"); ++bad; continue; }
+                int hits = 0, finite = 0;
+                for (int i = 0; i < 40; ++i) {
+                    if (out[8 * i + 7] == 2.0) ++hits;
+                    if (std::isfinite(out[8 * i + 2]) && std::isfinite(out[8 * i + 4])) ++finite;
+                }
+                std::printf("tangent flavour, metric %d disc %d: %d of 40 rays hit, %d with finite tangents\n", metric, disc, hits, finite);
+                if (hits < 10 || finite < hits) ++bad;
+            }
+        }
     }
     {   // plunging table (mu = 1 trace with every step saved)
         orc_config c;
