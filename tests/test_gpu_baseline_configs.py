@@ -1,6 +1,7 @@
 """BASELINE.json configurations at their stated sizes against the CPU oracle, EVERY ray compared.
 
 C2  Kerr a=0.998, 1024 x 1024, ThinDisc(isco, 50), redshift ∘ filter_intersected      
+C3  the same at 2048 x 2048 = the workload bench.py times
 C4  JohannsenMetric(a=0.7, α13=2, ϵ3=1), 1024 x 1024, ThinDisc(isco, 50), interpolated redshift
 C5  Kerr a=0.998, θ=60°, ThinDisc(isco, 250), PolarPlane(GeometricGrid; 4096 x 4096), 180 bins,
     fp64 x {1e-9, 1e-7, 1e-5, 1e-3} and fp32 x {1e-6 ... 1e-3}   (src/line-profiles.jl:152-198)
@@ -114,6 +115,22 @@ def test_config2_kerr_1024_every_pixel(G, oracle, ens):
     rec = _full_image_parity("C2_kerr_1024", img, st, ref, ref2, pts, W, H)
     assert rec["hits_both"] > 300_000
     assert rec["status_flips"] <= C2_MAX_FLIPS
+
+
+def test_config3_bench_workload_2048_every_pixel(G, oracle, ens):
+    """C3 = the workload bench.py times (C2 at 2048 x 2048): all 4 194 304 pixels against the oracle (about a minute of
+    oracle time on the GPU box's host cores), so the headline number is a number for a parity-checked render."""
+    m = G.KerrMetric(1.0, 0.998)
+    isco = m.isco()
+    x = np.array([0.0, 1000.0, math.radians(75), 0.0])
+    W = H = 2048
+    pf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+    _, _, img, st = G.rendergeodesics(m, x, G.ThinDisc(isco, 50.0), 2000.0, image_width=W, image_height=H,
+                                      alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens, stats=True)
+    ref, ref2, pts = _oracle_pair(oracle, "kerr", (1.0, 0.998), x, (isco, 50.0), W, H, r_isco=isco)
+    rec = _full_image_parity("C3_kerr_2048_bench_workload", img, st, ref, ref2, pts, W, H)
+    assert rec["hits_both"] > 1_200_000
+    assert rec["status_flips"] <= 4 * C2_MAX_FLIPS
 
 
 def test_config4_johannsen_1024_every_pixel(G, oracle, ens):
