@@ -74,7 +74,7 @@ def profile_evidence(size, world):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=250)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=2048, help="image is size x size")
     ap.add_argument("--kernel", type=int, default=2, help="0 = one ray per lane, 1 = persistent, 2 = auto by launch depth")
