@@ -336,11 +336,7 @@ int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
 int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
                        const gr_pointfunction* pf, double* out /* host, n x 4 */, gr_stats* stats);
 
-/* ---- end points of an impact-parameter ray set: tracegeodesics(m, x, i -> map_impact_parameters(m, x,
- * α[i], β[i]), d, ...; ensemble = EnsembleEndpointThreads()) as impact_parameters_for_radius_obscured
- * (src/tracing/precision-solvers.jl:363-372) and the thick-disc transfer-function workhorse
- * (src/transfer-functions/cunningham-transfer-functions.jl:253-300) call it. ---- */
-/* The same rays with DUAL NUMBERS THROUGH THE INTEGRATOR: what jacobian_∂αβ_∂gr obtains from ForwardDiff.jacobian around
+/* ---- The same rays with DUAL NUMBERS THROUGH THE INTEGRATOR: what jacobian_∂αβ_∂gr obtains from ForwardDiff.jacobian around
  * tracegeodesics (src/tracing/precision-solvers.jl:401-451) and the Cunningham transfer functions divide by
  * (src/transfer-functions/cunningham-transfer-functions.jl:337-387).  The integrator is instantiated on a scalar that carries
  * ∂/∂α and ∂/∂β (gr_tangent.hpp): the tangent equations are integrated with the very Tsit5 steps of the value, the event
@@ -351,6 +347,11 @@ int32_t gr_ray_tangent_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
                               void* hip_stream);
 int32_t gr_ray_tangent(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
                        const gr_pointfunction* pf, double* out /* host, n x 8 */, gr_stats* stats);
+
+/* ---- end points of an impact-parameter ray set: tracegeodesics(m, x, i -> map_impact_parameters(m, x,
+ * α[i], β[i]), d, ...; ensemble = EnsembleEndpointThreads()) as impact_parameters_for_radius_obscured
+ * (src/tracing/precision-solvers.jl:363-372) and the thick-disc transfer-function workhorse
+ * (src/transfer-functions/cunningham-transfer-functions.jl:253-300) call it. ---- */
 
 int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
                                    gr_point* d_points /* n */, gr_stats* d_stats, void* hip_stream);
