@@ -127,6 +127,13 @@ class gr_rayset(C.Structure):
         ("area", C.c_void_p),
         ("n", C.c_int64),
         ("height", C.c_void_p),
+        ("sep_r", C.c_void_p),
+        ("sep_cos", C.c_void_p),
+        ("sep_sin", C.c_void_p),
+        ("sep_nr", C.c_int64),
+        ("sep_nt", C.c_int64),
+        ("sep_tiled", C.c_int32),
+        ("sep_reserved", C.c_int32),
     ]
 
 

@@ -1199,6 +1199,13 @@ struct Cold {
     const double* beta;       // device, n
     const double* area;       // device, n (unnormalized_areas) or null = 1
     const double* height;     // device, n per-ray DatumPlane heights or null = cfg.disc_params[0]
+    // separable ray set (gr_rayset.sep_*: a PolarPlane as three small tables): α = r_i cos θ_j, β = r_i sin θ_j, area = r_i²
+    const double* sep_r;      // device, sep_nr (null: alpha / beta / area arrays)
+    const double* sep_cos;    // device, sep_nt
+    const double* sep_sin;    // device, sep_nt
+    int64_t sep_nr, sep_nt;
+    int64_t sep_core_rows;    // sep_tiled: rows / columns covered by whole 8 x 8 tiles (0, 0 = column-major order)
+    int64_t sep_core_cols;
     double winding_plane;     // TraceWindings.plane_inc (cfg.count_windings)
     // out_mode 2: BinningMethod line profile (line-profiles.jl:152-198) fused into finalize;
     // out_mode 3: (g, ρ) pairs for a host-side emissivity
@@ -1500,6 +1507,49 @@ struct Ray {
         return term;
     }
 
+    // ray k of a separable set -> (radius index i, angle index j).  Tiled order (lineprofiles._tile_order): whole 8 x 8
+    // tiles first -- tiles down a column strip, lanes column-major inside a tile --, then the rays no whole tile covers in
+    // column-major order; untiled: k = i + nr j.
+    static GR_DEV void sep_index(const Cold& p, int64_t k, int64_t& i, int64_t& j)
+    {
+        const int64_t R = p.sep_core_rows, Cc = p.sep_core_cols, nr = p.sep_nr;
+        const int64_t core = R * Cc;
+        if (k < core) {
+            const int64_t rr = k & 7, cc = (k >> 3) & 7, t = k >> 6;
+            const int64_t tiles_down = R >> 3;
+            const int64_t tcol = t / tiles_down, trow = t - tcol * tiles_down;
+            i = (trow << 3) + rr;
+            j = (tcol << 3) + cc;
+            return;
+        }
+        k -= core;
+        const int64_t tail = nr - R;                       // rows below the tiled block, in each of its Cc columns
+        if (k < Cc * tail) {
+            j = k / tail;
+            i = R + (k - j * tail);
+        } else {
+            k -= Cc * tail;
+            const int64_t jj = k / nr;
+            j = Cc + jj;
+            i = k - jj * nr;
+        }
+    }
+
+    // impact parameters of ray jl of an impact-parameter set (src_mode 2)
+    static GR_DEV void impact_parameters_of(const Cold& p, int64_t jl, double& al, double& be)
+    {
+        if (p.sep_r) {
+            int64_t i, j;
+            sep_index(p, jl, i, j);
+            const double r = p.sep_r[i];
+            al = r * p.sep_cos[j];
+            be = r * p.sep_sin[j];
+        } else {
+            al = p.alpha[jl];
+            be = p.beta[jl];
+        }
+    }
+
     // initial position / unconstrained velocity of local ray jl
     static GR_DEV void initial_conditions(const Params& pp, int64_t jl, real x0[4], real v0[4])
     {
@@ -1526,11 +1576,13 @@ struct Ray {
             // promote_velfunc: map_impact_parameters(m, x, αs[i], βs[i]) -- no pixel offset
             const real ro = p.plane.x_obs[1];
             const real iro = rcp_full(ro);
+            double al_, be_;
+            impact_parameters_of(p, jl, al_, be_);
 #ifdef GR_REAL_IS_TAN2
             // the two tangent directions of this build: ∂/∂α and ∂/∂β of everything downstream
-            const real al(p.alpha[jl], 1.0, 0.0), be(p.beta[jl], 0.0, 1.0);
+            const real al(al_, 1.0, 0.0), be(be_, 0.0, 1.0);
 #else
-            const real al = p.alpha[jl], be = p.beta[jl];
+            const real al = (real)al_, be = (real)be_;
 #endif
             const real b = be * iro, a = al * iro;
             const real pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
@@ -2092,7 +2144,15 @@ struct Ray {
                 cd.lp_pairs[2 * j] = in ? (double)g : __builtin_nan("");
                 cd.lp_pairs[2 * j + 1] = in ? (double)rho : __builtin_nan("");
             } else if (in) {
-                const real area = cd.area ? cd.area[j] : 1.0;
+                real area = 1.0;
+                if (cd.sep_r) {
+                    int64_t ii, jj;
+                    sep_index(cd, j, ii, jj);
+                    const double rr = cd.sep_r[ii];
+                    area = (real)(rr * rr);                    // unnormalized_areas(::PolarPlane) = r_i², planes.jl:127-131
+                } else if (cd.area) {
+                    area = (real)cd.area[j];
+                }
                 // ε(r) g³ area with ε(r) = r^-q
                 const real eps = (cd.lp_q == 3.0) ? rcp_full(rho * rho * rho) : GR_POW(rho, -cd.lp_q);
                 const real f = eps * g * g * g * area;

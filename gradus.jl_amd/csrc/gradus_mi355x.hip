@@ -708,7 +708,13 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
 {
     if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
     if (rays->n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
-    if (rays->n > 0 && (!rays->alpha || !rays->beta)) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
+    if (rays->sep_r) {
+        if (!rays->sep_cos || !rays->sep_sin || rays->sep_nr < 1 || rays->sep_nt < 1)
+            return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: tables missing or empty");
+        if (rays->sep_nr > (int64_t)1 << 31 || rays->sep_nt > (int64_t)1 << 31 || rays->n != rays->sep_nr * rays->sep_nt)
+            return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: n must be sep_nr * sep_nt");
+        if (rays->height) return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: per-ray heights are not supported");
+    } else if (rays->n > 0 && (!rays->alpha || !rays->beta)) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
     std::memset(&p, 0, sizeof p);
     std::memset(&cd, 0, sizeof cd);
     p.cfg = *cfg;
@@ -720,6 +726,15 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
     cd.range = gr_range{ 0, rays->n, rays->n > 0 ? rays->n : 1, 1 };
     cd.alpha = rays->alpha; cd.beta = rays->beta; cd.area = rays->area;
     cd.height = cfg->disc_id == GR_DISC_DATUM ? rays->height : nullptr;
+    if (rays->sep_r) {
+        cd.sep_r = rays->sep_r; cd.sep_cos = rays->sep_cos; cd.sep_sin = rays->sep_sin;
+        cd.sep_nr = rays->sep_nr; cd.sep_nt = rays->sep_nt;
+        const bool tiled = rays->sep_tiled && rays->sep_nr >= 8 && rays->sep_nt >= 8;
+        cd.sep_core_rows = tiled ? (rays->sep_nr / 8) * 8 : 0;
+        cd.sep_core_cols = tiled ? (rays->sep_nt / 8) * 8 : 0;
+        if (!tiled) { cd.sep_core_rows = 0; cd.sep_core_cols = 0; }
+        cd.alpha = cd.beta = cd.area = nullptr;
+    }
     cd.swizzle = 0;
     (void)ctx;
     return GR_OK;
@@ -979,6 +994,23 @@ static int32_t stage_rays(gr_ctx* ctx, const gr_rayset* rays, gr_rayset& dev, si
 {
     if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
     if (rays->n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (rays->sep_r) {
+        // separable set: three small tables instead of 24 B per ray
+        if (!rays->sep_cos || !rays->sep_sin || rays->sep_nr < 1 || rays->sep_nt < 1)
+            return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: tables missing or empty");
+        const size_t nr = (size_t)rays->sep_nr, nt = (size_t)rays->sep_nt;
+        int32_t rcs;
+        if ((rcs = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * (nr + 2 * nt) + extra_bytes + 64)) != GR_OK) return rcs;
+        double* b = (double*)ctx->d_in;
+        dev = *rays;
+        dev.alpha = dev.beta = dev.area = dev.height = nullptr;
+        dev.sep_r = b; dev.sep_cos = b + nr; dev.sep_sin = b + nr + nt;
+        GR_HIP(hipMemcpyAsync(b, rays->sep_r, sizeof(double) * nr, hipMemcpyHostToDevice, ctx->stream));
+        GR_HIP(hipMemcpyAsync(b + nr, rays->sep_cos, sizeof(double) * nt, hipMemcpyHostToDevice, ctx->stream));
+        GR_HIP(hipMemcpyAsync(b + nr + nt, rays->sep_sin, sizeof(double) * nt, hipMemcpyHostToDevice, ctx->stream));
+        if (extra) *extra = (void*)(b + nr + 2 * nt);
+        return GR_OK;
+    }
     if (rays->n > 0 && (!rays->alpha || !rays->beta)) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
     const size_t n = (size_t)rays->n;
     int32_t rc;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GR_ABI_VERSION 3
+#define GR_ABI_VERSION 4
 
 typedef enum {
     GR_OK = 0,
@@ -299,6 +299,19 @@ typedef struct gr_rayset {
                                  (datumplane(d, rₑ), datum-plane.jl:14-17: what the thick-disc
                                  transfer-function solvers trace against, one plane per emission
                                  radius), or NULL for cfg->disc_params[0]                   */
+    /* Separable ray sets (ABI 4): a PolarPlane (src/image-planes/planes.jl:96-131) is the outer product of Nr radii and
+     * Nθ angles -- α = r_i cos θ_j, β = r_i sin θ_j, unnormalized_areas = r_i² -- so its rays need not be materialised:
+     * with sep_r != NULL the library forms them on the device from the three small tables (alpha / beta / area are
+     * ignored, n must be sep_nr * sep_nt; products are plain IEEE multiplies, i.e. bit-identical to the arrays the
+     * reference builds).  Ray k of the set is visited in 8 x 8 tiles of (i, j) (sep_tiled = 1: 64 neighbouring rays per
+     * wave; the order in which a histogram receives its rays is immaterial) or column-major, k = i + sep_nr j
+     * (sep_tiled = 0: the order of vec(αs), for outputs that are indexed by ray). */
+    const double* sep_r;      /* sep_nr radii                                              */
+    const double* sep_cos;    /* sep_nt cosines                                            */
+    const double* sep_sin;    /* sep_nt sines                                              */
+    int64_t sep_nr, sep_nt;
+    int32_t sep_tiled;
+    int32_t sep_reserved;
 } gr_rayset;
 
 typedef struct gr_binning {

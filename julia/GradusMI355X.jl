@@ -37,7 +37,7 @@ import SciMLBase
 export EnsembleMI355X, SampledThickDisc, render_mi355x, winding_numbers
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
-const ABI_VERSION = 3
+const ABI_VERSION = 4
 
 # ---------------------------------------------------------------------------------------------------------------
 # POD mirrors of include/gradus_mi355x.h (field order and types checked by tests/test_julia_binding.py)

@@ -91,6 +91,29 @@ def lib_tangent():
     return _lib_tan
 
 
+def ray_tangent_separable(G, config, pf, r, cos_t, sin_t, tiled):
+    """The same for a separable ray set (gr_rayset.sep_*: α = r_i cos θ_j, β = r_i sin θ_j formed by the kernel code)."""
+    from gradus_jl_amd.rendering import abi_pointfunction
+    from gradus_jl_amd.tracing import lnr_momentum_to_global_velocity_matrix
+
+    L = G._lib
+    cfg = config.abi_config()
+    s, keep = abi_pointfunction(pf)
+    r, cos_t, sin_t = (np.ascontiguousarray(a, dtype=np.float64) for a in (r, cos_t, sin_t))
+    rs = L.gr_rayset()
+    Mx = lnr_momentum_to_global_velocity_matrix(config.metric, config.position)
+    for i in range(4):
+        rs.x_obs[i] = float(config.position[i])
+        for k in range(4):
+            rs.Mx[4 * i + k] = float(Mx[i, k])
+    rs.sep_r, rs.sep_cos, rs.sep_sin = r.ctypes.data, cos_t.ctypes.data, sin_t.ctypes.data
+    rs.sep_nr, rs.sep_nt, rs.sep_tiled, rs.n = r.size, cos_t.size, int(tiled), r.size * cos_t.size
+    out = np.zeros((rs.n, 8))
+    rc = lib_tangent().hht_ray_tangent(C.byref(cfg), C.byref(rs), C.byref(s), C.c_void_p(out.ctypes.data))
+    assert rc == 0, rc
+    return out
+
+
 def ray_tangent(G, config, pf, α, β, heights=None):
     """(g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status) per ray, from the host build of the tangent kernels."""
     from gradus_jl_amd.rendering import abi_pointfunction

@@ -40,6 +40,14 @@ int hht_ray_tangent(const gr_config* cfg, const gr_rayset* rays, const gr_pointf
     c.plane.width = rays->n; c.plane.height = 1;
     c.range = gr_range{ 0, rays->n, rays->n > 0 ? rays->n : 1, 1 };
     c.alpha = rays->alpha; c.beta = rays->beta; c.area = rays->area;
+    if (rays->sep_r) {                                    // as rays_params() of the host unit
+        c.sep_r = rays->sep_r; c.sep_cos = rays->sep_cos; c.sep_sin = rays->sep_sin;
+        c.sep_nr = rays->sep_nr; c.sep_nt = rays->sep_nt;
+        const bool tiled = rays->sep_tiled && rays->sep_nr >= 8 && rays->sep_nt >= 8;
+        c.sep_core_rows = tiled ? (rays->sep_nr / 8) * 8 : 0;
+        c.sep_core_cols = tiled ? (rays->sep_nt / 8) * 8 : 0;
+        c.alpha = c.beta = c.area = nullptr;
+    }
     c.height = cfg->disc_id == GR_DISC_DATUM ? rays->height : nullptr;
     c.lp_rmin = 0.0; c.lp_rmax = INFINITY; c.lp_pairs = out;
     c.pf.pf_id = pf->pf_id; c.pf.filter_id = pf->filter_id; c.pf.fill = pf->fill; c.pf.r_isco = pf->r_isco;

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(G):
     for name in declared:
         assert hasattr(lib, name), name
     lib.gr_abi_version.restype = C.c_int32
-    assert lib.gr_abi_version() == 3
+    assert lib.gr_abi_version() == 4
 
 
 def test_struct_layouts(G):

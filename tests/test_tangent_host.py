@@ -97,3 +97,34 @@ def test_tangent_build_takes_the_steps_of_the_plain_build(G, oracle):
     np.testing.assert_allclose(out[:, 1], rho, rtol=1e-11)
     np.testing.assert_allclose(out[:, 6], pts["x"][:, 0], rtol=1e-11)
     np.testing.assert_array_equal(out[:, 7].astype(int), pts["status"])
+
+
+@pytest.mark.parametrize("nr,nt", [(16, 24), (19, 13), (8, 8), (5, 30)])
+def test_separable_ray_sets_equal_explicit_arrays(G, nr, nt):
+    """gr_rayset.sep_* (a PolarPlane handed over as three small tables): the kernel code's index map `Ray::sep_index`,
+    tiled and column-major, whole tiles and ragged edges, against explicit α / β arrays in the order the Python mirror
+    `lineprofiles._sep_index` states -- bit-identical rays, so bit-identical results."""
+    from gradus_jl_amd.lineprofiles import _sep_index
+
+    m = G.KerrMetric(1.0, 0.9)
+    cfg = G.tracing_configuration(m, X, np.zeros((1, 4)), G.DatumPlane(0.0), 4000.0)
+    pf = G.ConstPointFunctions.redshift(m, X)
+    r = np.geomspace(2.0, 30.0, nr)
+    th = np.linspace(0.0, 2 * math.pi, nt, endpoint=False)
+    cs, sn = np.cos(th), np.sin(th)
+    for tiled in (True, False):
+        sep = Hh.ray_tangent_separable(G, cfg, pf, r, cs, sn, tiled)
+        i, j = _sep_index(np.arange(nr * nt), nr, nt, tiled and nr >= 8 and nt >= 8)
+        assert sorted(zip(i.tolist(), j.tolist())) == [(a, b) for a in range(nr) for b in range(nt)]      # a permutation
+        ref = Hh.ray_tangent(G, cfg, pf, r[i] * cs[j], r[i] * sn[j])
+        assert np.array_equal(np.nan_to_num(sep, nan=-1.0), np.nan_to_num(ref, nan=-1.0)), (nr, nt, tiled)
+    if nr == 16:
+        # the tiled order walks 8 x 8 tiles: the first 64 rays are rows 0..7 of columns 0..7, rows fastest
+        i, j = _sep_index(np.arange(64), nr, nt, True)
+        assert i.tolist() == list(range(8)) * 8 and j.tolist() == [c for c in range(8) for _ in range(8)]
+        # and it is the permutation lineprofiles._tile_order applies to explicit arrays
+        from gradus_jl_amd.lineprofiles import _tile_order
+
+        perm = _tile_order(nr, nt)
+        i, j = _sep_index(np.arange(nr * nt), nr, nt, True)
+        assert np.array_equal(perm, i + nr * j)
