@@ -223,10 +223,13 @@ def find_offsets_for_radius_newton_ad(trace, r_target, θ, *, r_min, α0=0.0, β
     (2·contra + x)/3 when a step lands below zero or within r_min + 1 of the hole, and -- what matters for parity --
     the loop's exit at the FIRST iterate with |ρ - r_target| <= zero_atol.
 
-    Why this exists beside `find_offsets_for_radius` (which polishes every root to the integrator's noise floor): the
-    transfer function divides by √(1 - g✶) near the extrema of g, so the 1e-7 residual the reference leaves in ρ is not
-    innocent there -- it biases its recorded statistics upward (tests/test_transfer_functions_host.py).  Reproducing the
-    reference's numbers means reproducing its iterates.  Returns (r, summaries, g) like the other solver."""
+    Why this exists beside `find_offsets_for_radius` (safeguarded Newton on a difference quotient, every root polished
+    to the integrator's noise floor): it is the reference's iteration, so its roots carry the reference's residuals
+    (anything up to zero_atol), and it needs one ray per problem per iteration instead of two.  With Jacobians from dual
+    numbers the transfer-function statistics do not depend on which of the two finds the roots (agreement 1e-4 or
+    better, tests/test_transfer_functions_tangent_host.py); with difference-quotient Jacobians they do, near the extrema
+    of g.  Returns (r, summaries, g, tangent rows) -- the last so that the caller can take the Jacobian of the accepted
+    ray without tracing it again."""
     r_target = np.asarray(r_target, dtype=np.float64)
     θ = np.asarray(θ, dtype=np.float64)
     n = r_target.size
