@@ -134,6 +134,9 @@ class gr_rayset(C.Structure):
         ("sep_nt", C.c_int64),
         ("sep_tiled", C.c_int32),
         ("sep_reserved", C.c_int32),
+        ("sep_first", C.c_int64),
+        ("sep_block", C.c_int64),
+        ("sep_stride", C.c_int64),
     ]
 
 

@@ -1204,6 +1204,9 @@ struct Cold {
     const double* sep_cos;    // device, sep_nt
     const double* sep_sin;    // device, sep_nt
     int64_t sep_nr, sep_nt;
+    int64_t sep_first;        // local ray jl is ray sep_first + (jl / sep_block) sep_stride + jl % sep_block of the set
+    int64_t sep_block;        // (0: sep_first + jl)
+    int64_t sep_stride;
     int64_t sep_core_rows;    // sep_tiled: rows / columns covered by whole 8 x 8 tiles (0, 0 = column-major order)
     int64_t sep_core_cols;
     double winding_plane;     // TraceWindings.plane_inc (cfg.count_windings)
@@ -1535,12 +1538,20 @@ struct Ray {
         }
     }
 
+    // local ray of a launch -> position in the order of the separable set (gr_rayset.sep_first / sep_block / sep_stride)
+    static GR_DEV int64_t sep_global(const Cold& p, int64_t jl)
+    {
+        if (p.sep_block <= 0) return p.sep_first + jl;
+        const int64_t b = jl / p.sep_block;
+        return p.sep_first + b * p.sep_stride + (jl - b * p.sep_block);
+    }
+
     // impact parameters of ray jl of an impact-parameter set (src_mode 2)
     static GR_DEV void impact_parameters_of(const Cold& p, int64_t jl, double& al, double& be)
     {
         if (p.sep_r) {
             int64_t i, j;
-            sep_index(p, jl, i, j);
+            sep_index(p, sep_global(p, jl), i, j);
             const double r = p.sep_r[i];
             al = r * p.sep_cos[j];
             be = r * p.sep_sin[j];
@@ -2147,7 +2158,7 @@ struct Ray {
                 real area = 1.0;
                 if (cd.sep_r) {
                     int64_t ii, jj;
-                    sep_index(cd, j, ii, jj);
+                    sep_index(cd, sep_global(cd, j), ii, jj);
                     const double rr = cd.sep_r[ii];
                     area = (real)(rr * rr);                    // unnormalized_areas(::PolarPlane) = r_i², planes.jl:127-131
                 } else if (cd.area) {

@@ -711,8 +711,17 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
     if (rays->sep_r) {
         if (!rays->sep_cos || !rays->sep_sin || rays->sep_nr < 1 || rays->sep_nt < 1)
             return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: tables missing or empty");
-        if (rays->sep_nr > (int64_t)1 << 31 || rays->sep_nt > (int64_t)1 << 31 || rays->n != rays->sep_nr * rays->sep_nt)
-            return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: n must be sep_nr * sep_nt");
+        if (rays->sep_nr > (int64_t)1 << 31 || rays->sep_nt > (int64_t)1 << 31 || rays->sep_first < 0 || rays->sep_block < 0
+            || (rays->sep_block > 0 && rays->sep_stride < rays->sep_block))
+            return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: bad sep_first / sep_block / sep_stride");
+        if (rays->n > 0) {
+            const int64_t j = rays->n - 1;
+            const int64_t last = rays->sep_block > 0
+                                     ? rays->sep_first + (j / rays->sep_block) * rays->sep_stride + j % rays->sep_block
+                                     : rays->sep_first + j;
+            if (last >= rays->sep_nr * rays->sep_nt)
+                return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: the launch's rays run past sep_nr * sep_nt");
+        }
         if (rays->height) return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: per-ray heights are not supported");
     } else if (rays->n > 0 && (!rays->alpha || !rays->beta)) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
     std::memset(&p, 0, sizeof p);
@@ -729,6 +738,7 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
     if (rays->sep_r) {
         cd.sep_r = rays->sep_r; cd.sep_cos = rays->sep_cos; cd.sep_sin = rays->sep_sin;
         cd.sep_nr = rays->sep_nr; cd.sep_nt = rays->sep_nt;
+        cd.sep_first = rays->sep_first; cd.sep_block = rays->sep_block; cd.sep_stride = rays->sep_stride;
         const bool tiled = rays->sep_tiled && rays->sep_nr >= 8 && rays->sep_nt >= 8;
         cd.sep_core_rows = tiled ? (rays->sep_nr / 8) * 8 : 0;
         cd.sep_core_cols = tiled ? (rays->sep_nt / 8) * 8 : 0;

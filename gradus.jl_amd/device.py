@@ -70,3 +70,58 @@ def render_endpoints_device(config: TracingConfiguration, out, ray_range=None, s
 
 def points_from_tensor(t, count):
     return np.frombuffer(t.cpu().numpy().tobytes(), dtype=_lib.POINT_DTYPE, count=count)
+
+
+def lineprofile_device(bins, ε, m, u, d, plane, *, shard=None, maxrₑ=50.0, minrₑ=None, λ_max=None, redshift_pf=None,
+                       callback="default", ensemble=None, flux=None, stats=None, **solver_args):
+    """gr_lineprofile_device: the un-normalised BinningMethod histogram of (a shard of) a PolarPlane's rays, accumulated
+    into a float64 CUDA tensor of bins.size entries (`flux` if given, else a new one; the launch zeroes it first).  `shard`: a distributed.RayShard (block-cyclic sub-range of the plane's rays) or None = all of them.
+    Asynchronous on the current stream; power-law emissivities only (the fused route)."""
+    import torch
+
+    from .lineprofiles import PowerLawEmissivity, _rayset
+    from .planes import PolarPlane
+    from .pointfunctions import ConstPointFunctions
+    from .tracing import domain_upper_hemisphere, tracing_configuration
+
+    if not isinstance(ε, PowerLawEmissivity) or not isinstance(plane, PolarPlane):
+        raise NotImplementedError("the device-resident line profile is the fused route: PowerLawEmissivity on a PolarPlane")
+    u = np.asarray(u, dtype=np.float64)
+    bins = np.ascontiguousarray(bins, dtype=np.float64)
+    λ_max = 2.0 * u[1] if λ_max is None else λ_max
+    minrₑ = m.isco() if minrₑ is None else minrₑ
+    if callback == "default":
+        callback = domain_upper_hemisphere()
+    if redshift_pf is None:
+        redshift_pf = ConstPointFunctions.redshift(m, u, **({"ensemble": ensemble} if m.metric_id != 0 else {}))
+    config = tracing_configuration(m, u, np.zeros((1, 4)), d, (0.0, λ_max), callback=callback, ensemble=ensemble, **solver_args)
+    cfg = config.abi_config()
+    ens = config.ensemble
+    dev = torch.device("cuda", ens.device)
+    keep = []
+    rs, _ = _rayset(config, plane, keep)
+    # the three tables and the bin edges live in HBM for the launch (tiny: Nr + 2 Nθ + n_bins doubles)
+    tabs = torch.from_numpy(np.concatenate([keep[0], keep[1], keep[2], bins])).to(dev)
+    nr, nt = plane.Nr, plane.Nθ
+    base = tabs.data_ptr()
+    rs.sep_r, rs.sep_cos, rs.sep_sin = base, base + 8 * nr, base + 8 * (nr + nt)
+    if shard is not None:
+        rs.sep_first, rs.sep_block, rs.sep_stride, rs.n = shard.first, shard.block, shard.stride, shard.count
+    if flux is None:
+        flux = torch.zeros(bins.size, dtype=torch.float64, device=dev)
+    assert flux.is_cuda and flux.dtype == torch.float64 and flux.numel() == bins.size
+    b = _lib.gr_binning(float(minrₑ), float(maxrₑ), ε.q, bins.size, base + 8 * (nr + 2 * nt))
+    pf, keep_pf = abi_pointfunction(redshift_pf)
+    lane = rs._tiled and ens.knobs.get("kernel", 2) == 2 and max(config.abstol, config.reltol) <= 1e-6
+    if lane:
+        ens.ctx.set("kernel", 0)
+    try:
+        if rs.n > 0:
+            _lib.check(_lib.load().gr_lineprofile_device(
+                ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), C.byref(b), C.c_void_p(flux.data_ptr()),
+                C.c_void_p(stats.data_ptr()) if stats is not None else None, _stream_handle()))
+    finally:
+        if lane:
+            ens.ctx.set("kernel", 2)
+    flux._gradus_keep = (tabs, keep_pf)          # the launch reads them asynchronously
+    return flux

@@ -7,6 +7,7 @@ columns so every rank gets a similar mix of short (captured / disc-hit) and long
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 from . import _lib
@@ -128,3 +129,80 @@ def gather_image_async(local, plan: ShardPlan, group=None, dst: int = 0, recv_bu
         bufs = recv_bufs if recv_bufs is not None else [torch.empty_like(local) for _ in range(plan.world)]
     work = dist.gather(local, bufs, dst=dst, group=group, async_op=True)
     return PendingGather(work, bufs, local, plan, dst)
+
+
+# ------------------------------------------------------------------------------------------
+# BinningMethod line profiles (BASELINE config 5) over several GPUs: the rays of one PolarPlane are dealt to the ranks,
+# every rank bins its own, ONE all-reduce of the histogram (n_bins doubles) is the path's only exchange step.
+# ------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class RayShard:
+    """Block-cyclic deal of the rays 0 .. n-1 of a separable ray set (gr_rayset.sep_first / sep_block / sep_stride):
+    rank r takes blocks r, r + world, r + 2 world, ... of `block` consecutive rays; the last block may be short."""
+
+    n: int
+    world: int
+    rank: int
+    block: int
+
+    @property
+    def first(self) -> int:
+        return self.rank * self.block
+
+    @property
+    def stride(self) -> int:
+        return self.world * self.block
+
+    @property
+    def count(self) -> int:
+        nb = -(-self.n // self.block)                       # blocks in the set
+        mine = len(range(self.rank, nb, self.world))
+        if mine == 0:
+            return 0
+        last = self.rank + (mine - 1) * self.world
+        return (mine - 1) * self.block + min(self.block, self.n - last * self.block)
+
+    def global_index(self, j):
+        b = j // self.block
+        return self.first + b * self.stride + (j - b * self.block)
+
+
+def ray_shard(plane, world: int, rank: int) -> RayShard:
+    """One block = one strip of 8 x 8 tiles down the plane (all radii of 8 neighbouring angles): every rank gets every
+    radius and an even sample of the angles, i.e. the same mix of short and long rays."""
+    n = plane.Nr * plane.Nθ
+    block = 8 * ((plane.Nr // 8) * 8) if plane.Nr >= 8 and plane.Nθ >= 8 else max(64, -(-n // (world * 8)))
+    return RayShard(n, world, rank, block)
+
+
+def lineprofile_sharded(bins, ε, m, u, d, plane, *, maxrₑ=50.0, minrₑ=None, λ_max=None, redshift_pf=None, callback="default",
+                        ensemble=None, group=None, shard=None, **solver_args):
+    """lineprofile(bins, ε, m, u, d, BinningMethod(); plane) (src/line-profiles.jl:152-198) with the plane's rays dealt
+    over the ranks of `group` (one process per GPU).  Each rank traces and bins its rays into an un-normalised histogram
+    in HBM (gr_lineprofile_device on a sub-range of the separable ray set), one all-reduce (RCCL) sums the histograms,
+    every rank normalises.  Returns (bins, flux) on every rank.  Without an initialised process group: one rank."""
+    import numpy as np
+    import torch
+
+    from .device import lineprofile_device
+
+    world = rank = None
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+    except ImportError:          # pragma: no cover
+        dist = None
+    if world is None:
+        world, rank = 1, 0
+    if shard is None:                                        # (a given shard: one rank's share timed alone)
+        shard = ray_shard(plane, world, rank)
+    flux = lineprofile_device(bins, ε, m, u, d, plane, shard=shard, maxrₑ=maxrₑ, minrₑ=minrₑ, λ_max=λ_max, redshift_pf=redshift_pf,
+                              callback=callback, ensemble=ensemble, **solver_args)
+    forced = os.environ.get("GRADUS_FORCE_COLLECTIVE") == "1" and dist is not None and dist.is_initialized()
+    if world > 1 or forced:                                  # forced: one rank through RCCL (tests on a 1-GPU box)
+        dist.all_reduce(flux, op=dist.ReduceOp.SUM, group=group)
+    total = flux.sum()
+    out = torch.where(total != 0, flux / total, flux)
+    return np.asarray(bins, dtype=np.float64), out.cpu().numpy()

@@ -302,7 +302,7 @@ typedef struct gr_rayset {
     /* Separable ray sets (ABI 4): a PolarPlane (src/image-planes/planes.jl:96-131) is the outer product of Nr radii and
      * Nθ angles -- α = r_i cos θ_j, β = r_i sin θ_j, unnormalized_areas = r_i² -- so its rays need not be materialised:
      * with sep_r != NULL the library forms them on the device from the three small tables (alpha / beta / area are
-     * ignored, n must be sep_nr * sep_nt; products are plain IEEE multiplies, i.e. bit-identical to the arrays the
+     * ignored; products are plain IEEE multiplies, i.e. bit-identical to the arrays the
      * reference builds).  Ray k of the set is visited in 8 x 8 tiles of (i, j) (sep_tiled = 1: 64 neighbouring rays per
      * wave; the order in which a histogram receives its rays is immaterial) or column-major, k = i + sep_nr j
      * (sep_tiled = 0: the order of vec(αs), for outputs that are indexed by ray). */
@@ -312,6 +312,12 @@ typedef struct gr_rayset {
     int64_t sep_nr, sep_nt;
     int32_t sep_tiled;
     int32_t sep_reserved;
+    /* Which rays of the set's order this launch traces (one plane sharded over devices, each adding its partial
+     * histogram -- gradus.jl_amd/distributed.py): local ray j is ray
+     *     k = sep_first + (j / sep_block) * sep_stride + j % sep_block          (sep_block > 0: a block-cyclic deal)
+     *     k = sep_first + j                                                     (sep_block = 0: a contiguous range)
+     * and every k must be below sep_nr * sep_nt.  All zero and n = sep_nr * sep_nt: the whole plane. */
+    int64_t sep_first, sep_block, sep_stride;
 } gr_rayset;
 
 typedef struct gr_binning {

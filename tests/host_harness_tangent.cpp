@@ -42,7 +42,7 @@ int hht_ray_tangent(const gr_config* cfg, const gr_rayset* rays, const gr_pointf
     c.alpha = rays->alpha; c.beta = rays->beta; c.area = rays->area;
     if (rays->sep_r) {                                    // as rays_params() of the host unit
         c.sep_r = rays->sep_r; c.sep_cos = rays->sep_cos; c.sep_sin = rays->sep_sin;
-        c.sep_nr = rays->sep_nr; c.sep_nt = rays->sep_nt;
+        c.sep_nr = rays->sep_nr; c.sep_nt = rays->sep_nt; c.sep_first = rays->sep_first; c.sep_block = rays->sep_block; c.sep_stride = rays->sep_stride;
         const bool tiled = rays->sep_tiled && rays->sep_nr >= 8 && rays->sep_nt >= 8;
         c.sep_core_rows = tiled ? (rays->sep_nr / 8) * 8 : 0;
         c.sep_core_cols = tiled ? (rays->sep_nt / 8) * 8 : 0;

@@ -88,3 +88,58 @@ def test_shard_plan_covers_image_exactly(G):
         assert np.all(seen == 1)
     with pytest.raises(ValueError):
         G.shard_plan(20, 20, 8, 0)
+
+
+def test_ray_shards_partition_a_polar_plane():
+    """distributed.ray_shard: the block-cyclic deal of a separable ray set's rays over the ranks is a partition, whole and
+    ragged planes, and local -> global is the map the C ABI documents for gr_rayset.sep_first / sep_block / sep_stride."""
+    import gradus_jl_amd as G
+    from gradus_jl_amd.distributed import ray_shard
+
+    for nr, nt in ((64, 48), (100, 77), (4096, 4096), (5, 9), (8, 8)):
+        plane = G.PolarPlane(G.GeometricGrid(), Nr=nr, Nθ=nt)
+        for world in (1, 2, 3, 8):
+            shards = [ray_shard(plane, world, r) for r in range(world)]
+            assert sum(s.count for s in shards) == nr * nt
+            if nr * nt <= 10_000:
+                seen = np.concatenate([[s.global_index(j) for j in range(s.count)] for s in shards]).astype(np.int64)
+                assert np.array_equal(np.sort(seen), np.arange(nr * nt))
+            for s in shards:
+                if s.count:
+                    j = s.count - 1
+                    assert s.global_index(j) == s.first + (j // s.block) * s.stride + j % s.block < nr * nt
+            if nr == 4096:
+                assert shards[0].block == 8 * 4096 and max(s.count for s in shards) - min(s.count for s in shards) <= shards[0].block
+
+
+def _sum_histograms(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(100 + rank)
+        part = torch.from_numpy(rng.uniform(0, 1, 180))
+        total = part.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)           # the one exchange step of the sharded line profile
+        out.put((rank, part.numpy(), total.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_histogram_all_reduce_two_ranks():
+    """The collective of distributed.lineprofile_sharded on gloo: every rank ends with the sum of the partial histograms."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sum_histograms, args=(r, 2, 29611, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    parts = {r: a for r, a, _ in got}
+    for _, _, total in got:
+        np.testing.assert_allclose(total, parts[0] + parts[1], rtol=1e-15)

@@ -445,6 +445,41 @@ def test_separable_polar_plane_equals_explicit_rays(G, ens, monkeypatch, shape):
     np.testing.assert_allclose(out["1"][0], out["1"][1], rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_lineprofile_reassembles(G, ens, world):
+    """distributed.lineprofile_sharded on one GPU: the partial histograms of every rank's shard (block-cyclic strips of
+    the plane's tile order, gr_rayset.sep_first / sep_block / sep_stride) sum to the single-launch histogram, the rays
+    and steps add up exactly, and the one-rank call equals lineprofile(...)."""
+    import torch
+
+    from gradus_jl_amd.device import lineprofile_device, new_stats, stats_dict
+    from gradus_jl_amd.distributed import lineprofile_sharded, ray_shard
+
+    m = G.KerrMetric(1.0, 0.998)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    d = G.ThinDisc(m.isco(), 250.0)
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=200, Nθ=132, r_min=1.0, r_max=250.0)          # ragged: 200 = 25 x 8, 132 = 16.5 x 8
+    bins = np.linspace(0.1, 1.5, 180)
+    eps = G.PowerLawEmissivity(3)
+    st_all = new_stats(torch.device("cuda", 0))
+    whole = lineprofile_device(bins, eps, m, u, d, plane, maxrₑ=250.0, ensemble=ens, stats=st_all)
+    parts, rays, steps = torch.zeros_like(whole), 0, 0
+    for r in range(world):
+        st = new_stats(torch.device("cuda", 0))
+        parts += lineprofile_device(bins, eps, m, u, d, plane, shard=ray_shard(plane, world, r), maxrₑ=250.0, ensemble=ens, stats=st)
+        sd = stats_dict(st)
+        rays += sd["rays"]
+        steps += sd["accepted_steps"]
+    torch.cuda.synchronize()
+    sa = stats_dict(st_all)
+    assert rays == sa["rays"] == 200 * 132 and steps == sa["accepted_steps"]
+    np.testing.assert_allclose(parts.cpu().numpy(), whole.cpu().numpy(), rtol=1e-11, atol=1e-18)
+    if world == 2:
+        _, y = lineprofile_sharded(bins, eps, m, u, d, plane, maxrₑ=250.0, ensemble=ens)
+        _, y_ref = G.lineprofile(bins, eps, m, u, d, G.BinningMethod(), plane=plane, maxrₑ=250.0, ensemble=ens)
+        np.testing.assert_allclose(y, y_ref, rtol=1e-11, atol=1e-18)
+
+
 def test_lineprofile_binning_matches_oracle_and_reference_edges(G, oracle, ens):
     """test/line-profiles/test-binning.jl:5-32 on the device (fused and generic paths) + oracle parity."""
     m = G.KerrMetric(M=1.0, a=0.6)
@@ -1489,6 +1524,26 @@ def test_bench_collective_path_on_one_gpu():
     # launches overlapped pairwise: a launch's own span is longer than the device's busy span per launch (by 1.9x when
     # the Kerr kernel held 2 waves per SIMD; at 3 waves per SIMD a single launch leaves less room beside it: 1.28x)
     assert line["roofline"]["launch_ms"] > 1.15 * line["roofline"]["kernel_ms"]
+
+
+def test_sharded_lineprofile_script_through_rccl_on_one_gpu():
+    """scripts/lineprofile_sharded.py under torch.distributed.run with one rank pushed through the RCCL all-reduce of the
+    histogram (GRADUS_FORCE_COLLECTIVE=1): the launch line an 8-GPU node would use, at 1024² rays."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRADUS_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(root, "scripts", "lineprofile_sharded.py"), "--size", "1024", "--steps", "4",
+           "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["profile_sum"] == pytest.approx(1.0, abs=1e-12)
+    assert line["rays_per_s"] > 5e7
 
 
 def test_c_abi_rejects_bad_input_without_touching_the_device(G, ens):
