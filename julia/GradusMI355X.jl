@@ -34,7 +34,7 @@ using Gradus: TracingConfiguration, EnsembleProblem, GeodesicPoint, StatusCodes,
 using StaticArrays
 import SciMLBase
 
-export EnsembleMI355X, SampledThickDisc, render_mi355x, winding_numbers
+export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, winding_numbers
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
 const ABI_VERSION = 4
@@ -112,6 +112,34 @@ struct GrRange                       # == gr_range
     count::Int64
     block::Int64
     stride_blocks::Int64
+end
+
+struct GrRayset                      # == gr_rayset
+    x_obs::NTuple{4,Float64}
+    Mx::NTuple{16,Float64}
+    alpha::Ptr{Float64}
+    beta::Ptr{Float64}
+    area::Ptr{Float64}
+    n::Int64
+    height::Ptr{Float64}
+    sep_r::Ptr{Float64}              # a PolarPlane as three small tables: the device forms α = r cos θ, β = r sin θ, area = r²
+    sep_cos::Ptr{Float64}
+    sep_sin::Ptr{Float64}
+    sep_nr::Int64
+    sep_nt::Int64
+    sep_tiled::Int32
+    sep_reserved::Int32
+    sep_first::Int64
+    sep_block::Int64
+    sep_stride::Int64
+end
+
+struct GrBinning                     # == gr_binning
+    r_min::Float64
+    r_max::Float64
+    emissivity_index::Float64
+    n_bins::Int64
+    bin_edges::Ptr{Float64}
 end
 
 _check(rc) = rc == 0 || error(unsafe_string(ccall((:gr_last_error, LIB), Cstring, ())))
@@ -521,6 +549,49 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
         ensemble.ctxs, length(ensemble.ctxs), cfg, plane, pfs, 0, image, stats))
     α, β = Gradus.impact_axes(image_width, image_height, αlims, βlims)
     α, β, image
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# lineprofile(bins, ε, m, u, d, BinningMethod(); plane) (src/line-profiles.jl:152-198) fused on the device for a power-law
+# emissivity ε(r) = r^-q on a PolarPlane: the plane crosses the boundary as its radii and the cosines / sines of its
+# angles (src/image-planes/planes.jl:96-131), the device forms the rays, traces them, evaluates redshift and ε g³ area
+# and bins -- BASELINE config 5 (4096² rays) in one call.  The reference's method fixes `ensemble =
+# EnsembleEndpointThreads()` ahead of `solver_args...`, so a maintainer wiring this in adds one branch there:
+#     ensemble isa EnsembleMI355X && ε isa PowerLaw... && plane isa PolarPlane && return lineprofile_mi355x(...)
+# ---------------------------------------------------------------------------------------------------------------
+function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float64}, q::Real, m, u::SVector{4,Float64}, d;
+        plane::Gradus.PolarPlane = Gradus.PolarPlane(Gradus.GeometricGrid(); Nr = 450, Nθ = 1300, r_max = 250.0),
+        λ_max = 2 * u[2], minrₑ = Gradus.isco(m), maxrₑ = 50.0, redshift_pf = ConstPointFunctions.redshift(m, u),
+        gtol = 1e-2, abstol = 1e-9, reltol = 1e-9, chart = Gradus.chart_for_metric(m), upper_hemisphere = true)
+    id, params = _metric(m)
+    did, rin, rout, dparams = _disc(d)
+    r_in, r_out, tab, θ0, θ1 = _chart(chart)
+    dtab = _disc_table(d)
+    cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λ_max),
+        abstol, reltol, 0.0, 1_000_000, Int32(upper_hemisphere), Int32(0), 1e-4, dparams,
+        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, 0.0, Int32(0), Int32(0), π / 2))
+    g = Gradus.metric(m, u)
+    Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
+    rs = collect(Float64, plane.grid(plane.r_min, plane.r_max, plane.Nr))             # planes.jl:110-114
+    δθ = (plane.θ_max - plane.θ_min) / plane.Nθ
+    θs = collect(range(plane.θ_min, plane.θ_max - δθ, plane.Nθ))
+    cs, sn = cos.(θs), sin.(θs)
+    rays = Ref(GrRayset(Tuple(u), Tuple(permutedims(Mx)), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
+        plane.Nr * plane.Nθ, Ptr{Float64}(C_NULL), pointer(rs), pointer(cs), pointer(sn), plane.Nr, plane.Nθ, Int32(1), Int32(0),
+        0, 0, 0))
+    bpf = _builtin_pf(redshift_pf, m)
+    isnothing(bpf) && error("lineprofile_mi355x: `redshift_pf` is not a redshift point function the kernels evaluate")
+    gpf, keep_pf = bpf
+    pfs = Ref(gpf)
+    edges = collect(Float64, bins)
+    binning = Ref(GrBinning(Float64(minrₑ), Float64(maxrₑ), Float64(q), length(edges), pointer(edges)))
+    flux = zeros(Float64, length(edges))
+    stats = Ref{GrStats}()
+    _check(GC.@preserve tab dtab keep_pf rs cs sn edges ccall((:gr_lineprofile, LIB), Int32,
+        (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ref{GrBinning}, Ptr{Float64}, Ref{GrStats}),
+        ensemble.ctxs[1], cfg, rays, pfs, binning, flux, stats))
+    bins, flux ./ sum(flux)                                                            # line-profiles.jl:197
 end
 
 end # module

@@ -150,7 +150,7 @@ def jl_ccalls():
 
 
 JL2C_STRUCT = {"GrConfig": "gr_config", "GrStats": "gr_stats", "GrPlane": "gr_plane", "GrPointFunction": "gr_pointfunction",
-               "GrRange": "gr_range"}
+               "GrRange": "gr_range", "GrRayset": "gr_rayset", "GrBinning": "gr_binning"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -168,7 +168,7 @@ def test_ctypes_structures_match_the_header_field_by_field(G):
 
     cs = c_structs()
     kind_of = {C.c_int32: "i32", C.c_int64: "i64", C.c_double: "f64"}
-    for cname in list(JL2C_STRUCT.values()) + ["gr_rayset", "gr_binning"]:
+    for cname in list(JL2C_STRUCT.values()):
         fields = []
         for name, typ in getattr(_lib, cname)._fields_:
             if typ in kind_of:
@@ -192,7 +192,7 @@ def test_every_ccall_matches_its_c_prototype():
     seen = {c[0] for c in calls}
     # the boundary the binding uses
     assert {"gr_abi_version", "gr_last_error", "gr_ctx_create", "gr_ctx_destroy", "gr_trace_endpoints", "gr_render_endpoints",
-            "gr_render_multi"} <= seen
+            "gr_render_multi", "gr_lineprofile"} <= seen
     for sym, ret, types, nvals in calls:
         assert sym in protos, sym
         want = protos[sym]
@@ -217,7 +217,7 @@ def test_every_ccall_matches_its_c_prototype():
 def test_positional_constructors_pass_one_value_per_field():
     js = jl_structs()
     n_calls = 0
-    for jname in ("GrConfig", "GrPlane", "GrPointFunction", "GrRange"):
+    for jname in ("GrConfig", "GrPlane", "GrPointFunction", "GrRange", "GrRayset", "GrBinning"):
         for m in re.finditer(r"(?<![\w{])" + jname + r"\(", JL):
             args = split_top(balanced(JL, m.end() - 1))
             assert len(args) == len(js[jname]), (jname, len(args), len(js[jname]), args[:3])
