@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define GR_NS gr
@@ -123,6 +124,12 @@ struct gr_ctx {
     hipEvent_t ev_tables = nullptr;
     hipStream_t tables_stream = nullptr;
     bool tables_busy = false;
+    // host-buffer entry points that return 152 B per ray: the result goes back in bands on a second stream while later
+    // bands are still being traced (see copy_back_in_bands)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_band[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    bool lpt_suspend = false;              // banded launches do not learn / use a tile order (their ranges differ)
+    int64_t pipeline = 1;                  // 0: one launch + one copy (diagnostic)
 };
 
 namespace {
@@ -258,7 +265,7 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
     cold.tile_perm = nullptr;
     cold.tile_cost = nullptr;
     const int kern = resolve_kernel(ctx, p.n, cold);
-    if (!ctx->lpt || (kern != 1 && !ctx->lpt_lane) || !cold.swizzle || cold.src_mode != 0) return GR_OK;
+    if (!ctx->lpt || ctx->lpt_suspend || (kern != 1 && !ctx->lpt_lane) || !cold.swizzle || cold.src_mode != 0) return GR_OK;
     const int64_t tiles = p.n >> 6;
     // Measured on MI355X: longest-first pays when a launch is only a few tiles per
     // resident wave deep (the 1/8 shard of a 2048² image: 4.0 -> 3.7 ms on the rank holding the
@@ -509,6 +516,9 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (hipEvent_t e : c->ev_band)
+        if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
     return GR_OK;
 }
@@ -517,6 +527,10 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
 {
     if (!c || !key) return fail(GR_ERR_INVALID_ARGUMENT, "ctx/key is null");
     const std::string k(key);
+    if (k == "pipeline") {
+        c->pipeline = value != 0;
+        return GR_OK;
+    }
     if (k == "kernel") {
         if (value < 0 || value > 2) return fail(GR_ERR_INVALID_ARGUMENT, "kernel must be 0 (lane), 1 (persistent) or 2 (auto)");
         c->kernel = value;
@@ -859,6 +873,44 @@ int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_r
 }
 
 // ---- host-buffer variants: stage through the context, block until done ----
+
+// Touch every page of an output buffer from a few threads (its content is about to be overwritten).  A freshly
+// allocated destination -- numpy's `empty`, Julia's `Vector{GeodesicPoint}(undef, n)` -- is not backed by pages yet, and
+// taking those faults inside the device-to-host copy costs as much again as the copy (637 MB of end points at 2048²:
+// 35 ms into touched memory, 60 ms into fresh memory); taken here they overlap the kernel that is already running.
+static void prefault_output(void* dst, size_t bytes)
+{
+    if (bytes < ((size_t)64 << 20)) return;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 4 : (nt > 8 ? 8 : nt);
+    const size_t page = 4096;
+    char* base = (char*)dst;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([=]() {
+            // every thread sweeps front to back (pages t, t + nt, ...): the first band's pages are ready first
+            for (size_t off = (size_t)t * page; off < bytes; off += (size_t)nt * page) ((volatile char*)base)[off] = 0;
+        });
+    for (auto& x : th) x.join();
+}
+
+static int32_t ensure_copy_stream(gr_ctx* ctx)
+{
+    if (!ctx->copy_stream) GR_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : ctx->ev_band)
+        if (!e) GR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return GR_OK;
+}
+
+// How many bands a result of n records is returned in (1: not worth it), each a multiple of `unit` records.
+static int band_count(const gr_ctx* ctx, int64_t n, int64_t unit)
+{
+    if (!ctx->pipeline || unit <= 0 || n < ((int64_t)1 << 21)) return 1;
+    int nb = 4;
+    while (nb > 1 && (n / nb) < unit) --nb;
+    return nb;
+}
+
 static int32_t begin_host_call(gr_ctx* ctx, gr_stats* stats)
 {
     GR_HIP(hipSetDevice(ctx->device));
@@ -947,10 +999,42 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     int32_t rc;
     const size_t bytes = sizeof(gr_point) * (size_t)(range->count > 0 ? range->count : 0);
     if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
+    // A contiguous range of a large plane goes out in bands of whole 8-column tile strips: band k is copied back on a
+    // second stream while bands k+1.. are traced (2048²: 20 ms of kernel + 15 ms of copy become 25 ms), and the
+    // destination's pages are faulted in by helper threads meanwhile.
+    const bool contiguous = plane && (range->stride_blocks == 1 || range->count <= range->block);
+    const int64_t unit = plane ? 8 * plane->height : 0;
+    const int nb = (contiguous && unit > 0 && range->first % unit == 0) ? band_count(ctx, range->count, unit) : 1;
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
-    if ((rc = gr_render_endpoints_device(ctx, cfg, plane, range, (gr_point*)ctx->d_scratch,
-                                         stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
-    if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (nb <= 1) {
+        if ((rc = gr_render_endpoints_device(ctx, cfg, plane, range, (gr_point*)ctx->d_scratch,
+                                             stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+        prefault_output(points, bytes);
+        if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return end_host_call(ctx, stats);
+    }
+    if ((rc = ensure_copy_stream(ctx)) != GR_OK) return rc;
+    const int64_t per = ((range->count / nb + unit - 1) / unit) * unit;
+    int64_t j0[9];
+    int used = 0;
+    for (int64_t j = 0; j < range->count && used < 8; j += per) j0[used++] = j;
+    j0[used] = range->count;
+    ctx->lpt_suspend = true;
+    for (int k = 0; k < used && rc == GR_OK; ++k) {
+        const gr_range band{ range->first + j0[k], j0[k + 1] - j0[k], j0[k + 1] - j0[k], 1 };
+        rc = gr_render_endpoints_device(ctx, cfg, plane, &band, (gr_point*)ctx->d_scratch + j0[k],
+                                        stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream);
+        if (rc == GR_OK && hipEventRecord(ctx->ev_band[k], ctx->stream) != hipSuccess) rc = fail(GR_ERR_HIP, "hipEventRecord failed");
+    }
+    ctx->lpt_suspend = false;
+    if (rc != GR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    prefault_output(points, bytes);
+    for (int k = 0; k < used; ++k) {
+        GR_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
+        GR_HIP(hipMemcpyAsync(points + j0[k], (gr_point*)ctx->d_scratch + j0[k], sizeof(gr_point) * (size_t)(j0[k + 1] - j0[k]),
+                              hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    GR_HIP(hipStreamSynchronize(ctx->copy_stream));
     return end_host_call(ctx, stats);
 }
 
@@ -976,6 +1060,7 @@ int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, i
     }
     if ((rc = gr_trace_endpoints_device(ctx, cfg, d_x, x_stride, d_v, n, (gr_point*)ctx->d_scratch,
                                         stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    prefault_output(points, out_bytes);
     if (out_bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
 }
@@ -1128,6 +1213,7 @@ int32_t gr_rayset_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* 
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
     if ((rc = gr_rayset_endpoints_device(ctx, cfg, &dev, (gr_point*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
                                          ctx->stream)) != GR_OK) return rc;
+    prefault_output(points, bytes);
     if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
 }

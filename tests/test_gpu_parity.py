@@ -152,6 +152,26 @@ def test_fused_image_equals_endpoints_plus_apply(G, ens):
         np.testing.assert_allclose(img[ok], img2[ok], rtol=1e-12)
 
 
+def test_endpoints_returned_in_bands_equal_one_copy(G, ens):
+    """gr_render_endpoints on a large plane: traced and copied back in bands of whole 8-column strips on two streams
+    (later bands computing while earlier ones travel), the destination pre-faulted by helper threads -- byte for byte
+    the records of the single launch + single copy, also for a width that leaves a ragged last band, and the statistics
+    add up."""
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    for W, H in ((1536, 1536), (1100, 2048)):
+        cfg = G.render_configuration(m, X_FAR, d, 2000.0, image_width=W, image_height=H, alpha_lims=ALIMS, beta_lims=BLIMS, ensemble=ens)
+        out = {}
+        for pipe in (1, 0):
+            ens.set("pipeline", pipe)
+            pts, st = G.ensemble_solve_tracing_problem(ens, cfg, stats=True)
+            out[pipe] = (pts.copy(), st)
+        assert out[1][0].tobytes() == out[0][0].tobytes()
+        for k in ("rays", "accepted_steps", "rejected_steps", "status_count"):
+            assert out[1][1][k] == out[0][1][k]
+        assert out[1][1]["rays"] == W * H
+
+
 def test_kernels_agree_bitwise(G, ens):
     """Wave-ballot refill must not change any ray: persistent == one-ray-per-lane, bit for bit."""
     m = G.KerrMetric(1.0, 0.998)
