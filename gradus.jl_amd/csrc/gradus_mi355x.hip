@@ -657,6 +657,8 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     return GR_OK;
 }
 
+static void prefault_output(void* dst, size_t bytes);
+
 int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64_t x_stride, const double* v, int64_t n,
                        int64_t cap, double* path, int64_t* n_rows, gr_point* endpoints)
 {
@@ -705,6 +707,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     GR_HIP(hipGetLastError());
     if ((p.disc_table || p.chart_table) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters are copied as int64");
+    prefault_output(path, path_bytes);          // while the kernel runs (the path buffer of 16 384 geodesics is 600 MB)
     GR_HIP(hipMemcpyAsync(n_rows, d_n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     GR_HIP(hipMemcpyAsync(path, d_path, path_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (endpoints) GR_HIP(hipMemcpyAsync(endpoints, d_pt, pt_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1093,6 +1096,7 @@ static int32_t stage_rays(gr_ctx* ctx, const gr_rayset* rays, gr_rayset& dev, si
         // separable set: three small tables instead of 24 B per ray
         if (!rays->sep_cos || !rays->sep_sin || rays->sep_nr < 1 || rays->sep_nt < 1)
             return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: tables missing or empty");
+        if (rays->height) return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: per-ray heights are not supported");
         const size_t nr = (size_t)rays->sep_nr, nt = (size_t)rays->sep_nt;
         int32_t rcs;
         if ((rcs = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * (nr + 2 * nt) + extra_bytes + 64)) != GR_OK) return rcs;
