@@ -1606,4 +1606,22 @@ def test_c_abi_rejects_bad_input_without_touching_the_device(G, ens):
     pts = np.zeros(4, dtype=G.POINT_DTYPE)
     assert L.gr_rayset_endpoints(h, C.byref(cfg), C.byref(rs), pts.ctypes.data, None) == -1
     assert L.gr_render(None, C.byref(cfg), C.byref(pl), C.byref(pf), C.byref(rg), img.ctypes.data, None) == -1
+    # separable ray sets (ABI 4): missing tables, rays past the end of the set, a stride below the block, heights
+    r, cs, sn, hs = np.linspace(2.0, 9.0, 8), np.cos(np.linspace(0, 6, 8)), np.sin(np.linspace(0, 6, 8)), np.zeros(64)
+    pts64 = np.zeros(64, dtype=G.POINT_DTYPE)
+
+    def sep(**kw):
+        q = G._lib.gr_rayset()
+        q.sep_r, q.sep_cos, q.sep_sin, q.sep_nr, q.sep_nt, q.sep_tiled, q.n = r.ctypes.data, cs.ctypes.data, sn.ctypes.data, 8, 8, 1, 64
+        for k, v in kw.items():
+            setattr(q, k, v)
+        return L.gr_rayset_endpoints(h, C.byref(cfg), C.byref(q), pts64.ctypes.data, None)
+
+    assert sep() == 0
+    assert sep(sep_cos=None) == -1 and sep(sep_nt=0) == -1
+    assert sep(n=65) == -1 and sep(sep_first=1) == -1 and sep(sep_first=-1) == -1
+    assert sep(sep_block=16, sep_stride=8) == -1
+    assert sep(sep_first=0, sep_block=16, sep_stride=32, n=32) == 0          # blocks 0 and 2 of four
+    assert sep(sep_first=16, sep_block=16, sep_stride=32, n=48) == -1        # a third block would start at ray 80
+    assert sep(height=hs.ctypes.data) == -1
     assert call() == 0 and np.isfinite(img).sum() > 0
