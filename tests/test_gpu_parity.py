@@ -1235,8 +1235,10 @@ def test_thick_disc_transfer_functions_on_device(G, oracle, ens):
     from test_transfer_functions_host import thick_oracle_tracers
 
     ens.set("kernel", 2).set("precision", 64)
-    for a, angle, r_e, edd, gold, tol in ((0.998, 75, 3.0, 0.3, 14.64279128586961, 1.5e-2),
-                                          (0.2, 20, 5.469668466100368, 0.2, 21.581370829241525, 1.8e-2)):
+    # with dual-number Jacobians the device gives 14.64494 / 21.4028 at EVERY tolerance from 1e-9 to 1e-12
+    # (scripts/thick_tf_sums.py): 1.5e-4 and -8.3e-3 relative to the record (the second: one sample's worth of 114)
+    for a, angle, r_e, edd, gold, tol in ((0.998, 75, 3.0, 0.3, 14.64279128586961, 5e-4),
+                                          (0.2, 20, 5.469668466100368, 0.2, 21.581370829241525, 1e-2)):
         m = G.KerrMetric(1.0, a)
         x = np.array([0.0, 10_000.0, math.radians(angle), 0.0])
         d = G.ShakuraSunyaev.for_metric(m, eddington_ratio=edd)
