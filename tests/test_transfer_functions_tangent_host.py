@@ -70,13 +70,14 @@ def test_low_inclination_inner_disc_is_stable_here_but_off_the_record(G, angle, 
         assert np.ptp(top) < 0.02 * np.mean(top)                     # a clean limit, not noise
 
 
-def test_the_3_degree_record_is_this_sample_set_minus_fifteen_near_g_min(G):
-    """Attribution of the largest gap: at (3°, rₑ = 4) the recorded 0.140489 is what THIS build's samples give when 15 of
-    the 17 golden-section calls of the g_min search (all with g✶ < 6e-3, i.e. ~zero terms of the sum) are left out of the
-    mean -- 114 -> 99 samples: agreement 2e-6, the level of the well-conditioned cases.  The current source of the
-    reference always stores 16 + 1 calls per search (cunningham-transfer-functions.jl:391-429: `iterations = N`, no
-    convergence exit is reachable at these bracket widths), so the recorded value and the current source disagree about
-    the sample count, not about any g or f; this build follows the source (114 samples)."""
+def test_the_3_degree_record_coincides_with_this_sample_set_minus_fifteen_near_g_min(G):
+    """A numerical lead on the largest gap, recorded as such: at (3°, rₑ = 4) the recorded 0.140489 is what THIS build's
+    samples give when 15 of the 17 golden-section calls of the g_min search (all with g✶ < 6e-3, i.e. ~zero terms of the
+    sum) are left out of the mean -- 114 -> 99 samples: agreement 2e-6, the level of the well-conditioned cases.  Of the 289
+    (k_min, k_max) truncations of the two searches that were tried, chance alone would produce such a match about once in
+    30, so this is suggestive, not proof.  The current source of the reference always stores 16 + 1 calls per search
+    (cunningham-transfer-functions.jl:391-429: `iterations = N`, no convergence exit is reachable at these bracket
+    widths); this build follows the source (114 samples)."""
     raw = []
     c = ctf(G, 3, [4.0], root_finder="reference", _raw=raw)[0]
     d = raw[0][0][0]                                   # rows θ, g, J, t; columns 80..96 = the g_min search in call order
