@@ -21,7 +21,8 @@ from . import _lib
 from .planes import GeometricGrid, PolarPlane, impact_parameters, unnormalized_areas
 from .pointfunctions import ConstPointFunctions
 from .rendering import abi_pointfunction
-from .tracing import (domain_upper_hemisphere, lnr_momentum_to_global_velocity_matrix, tracing_configuration)
+from .tracing import (domain_upper_hemisphere, lnr_momentum_to_global_velocity_matrix, separable_rayset,
+                      tracing_configuration)
 
 
 class BinningMethod:
@@ -109,22 +110,9 @@ def _rayset(config, plane, keep):
     if isinstance(plane, PolarPlane) and os.environ.get("GRADUS_MI355X_SEPARABLE_RAYS", "1") != "0":
         # α = r_i cos θ_j, β = r_i sin θ_j, area = r_i² (planes.jl:96-131): three small tables cross the boundary and the
         # device forms the rays (for C5, 4096² rays: 100 KB instead of 403 MB, and no 5 s of host-side fancy indexing)
-        r = np.ascontiguousarray(plane.grid(plane.r_min, plane.r_max, plane.Nr), dtype=np.float64)
-        dθ = (plane.θ_max - plane.θ_min) / plane.Nθ
-        θs = np.linspace(plane.θ_min, plane.θ_max - dθ, plane.Nθ)
-        cs, sn = np.ascontiguousarray(np.cos(θs)), np.ascontiguousarray(np.sin(θs))
         tiled = os.environ.get("GRADUS_MI355X_TILE_RAYS", "1") != "0" and plane.Nr >= 8 and plane.Nθ >= 8
+        rs, (r, cs, sn) = separable_rayset(config.metric, config.position, plane, tiled)
         keep += [r, cs, sn]
-        rs = _lib.gr_rayset()
-        for i in range(4):
-            rs.x_obs[i] = float(config.position[i])
-        Mx = lnr_momentum_to_global_velocity_matrix(config.metric, config.position)
-        for i in range(4):
-            for k in range(4):
-                rs.Mx[4 * i + k] = float(Mx[i, k])
-        rs.alpha = rs.beta = rs.area = rs.height = None
-        rs.sep_r, rs.sep_cos, rs.sep_sin = r.ctypes.data, cs.ctypes.data, sn.ctypes.data
-        rs.sep_nr, rs.sep_nt, rs.sep_tiled, rs.n = plane.Nr, plane.Nθ, int(tiled), plane.Nr * plane.Nθ
         rs._tiled = tiled
         return rs, _LazyAreas(r, plane.Nr, plane.Nθ, tiled)
     αs, βs = impact_parameters(plane, config.position)

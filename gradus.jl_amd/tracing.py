@@ -11,6 +11,8 @@ import math
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -229,6 +231,35 @@ class RenderVelocity:
     offset: float = 1e-6
 
 
+@dataclass(frozen=True)
+class PlaneVelocity:
+    """`promote_velfunc(m, x, plane::PolarPlane, _)` (image-planes/planes.jl:180-184) as data: the plane's rays are formed on
+    the device from its radii and angle tables (gr_rayset.sep_*), in the order of vec(αs) -- trajectory i is
+    (r index, θ index) = ((i - 1) % Nr, (i - 1) ÷ Nr)."""
+
+    plane: object
+
+
+def separable_rayset(m, position, plane, tiled: bool):
+    """gr_rayset for a PolarPlane handed over as its three tables (α = r_i cos θ_j, β = r_i sin θ_j, area = r_i²,
+    planes.jl:96-131).  Returns (rayset, (r, cos θ, sin θ)); the arrays must outlive the call that uses the rayset."""
+    r = np.ascontiguousarray(plane.grid(plane.r_min, plane.r_max, plane.Nr), dtype=np.float64)
+    dθ = (plane.θ_max - plane.θ_min) / plane.Nθ
+    θs = np.linspace(plane.θ_min, plane.θ_max - dθ, plane.Nθ)
+    cs, sn = np.ascontiguousarray(np.cos(θs)), np.ascontiguousarray(np.sin(θs))
+    rs = _lib.gr_rayset()
+    position = np.asarray(position, dtype=np.float64)
+    Mx = lnr_momentum_to_global_velocity_matrix(m, position)
+    for i in range(4):
+        rs.x_obs[i] = float(position[i])
+        for k in range(4):
+            rs.Mx[4 * i + k] = float(Mx[i, k])
+    rs.alpha = rs.beta = rs.area = rs.height = None
+    rs.sep_r, rs.sep_cos, rs.sep_sin = r.ctypes.data, cs.ctypes.data, sn.ctypes.data
+    rs.sep_nr, rs.sep_nt, rs.sep_tiled, rs.n = plane.Nr, plane.Nθ, int(bool(tiled)), plane.Nr * plane.Nθ
+    return rs, (r, cs, sn)
+
+
 @dataclass
 class TracingConfiguration:
     """configuration.jl:3-88 flattened; `μ` from TraceGeodesic (tracing.jl:1-7), `gtol` from
@@ -385,7 +416,14 @@ def tracing_configuration(
     from .planes import AbstractImagePlane, impact_parameters
 
     position = np.asarray(position, dtype=np.float64)
-    if isinstance(velocity, AbstractImagePlane):
+    from .planes import PolarPlane
+
+    if isinstance(velocity, PolarPlane) and os.environ.get("GRADUS_MI355X_SEPARABLE_RAYS", "1") != "0":
+        trajectories = velocity.Nr * velocity.Nθ
+        velocity = PlaneVelocity(velocity)
+    elif isinstance(velocity, PlaneVelocity):
+        trajectories = velocity.plane.Nr * velocity.plane.Nθ
+    elif isinstance(velocity, AbstractImagePlane):
         # promote_velfunc, image-planes/planes.jl:180-184
         αs, βs = impact_parameters(velocity, position)
         velocity = map_impact_parameters(m, position, αs, βs)
@@ -427,6 +465,12 @@ def ensemble_solve_tracing_problem(ensemble: EnsembleMI355X, config: TracingConf
         out = np.zeros(n, dtype=_lib.POINT_DTYPE)
         _lib.check(L.gr_render_endpoints(ensemble.ctx.handle, C.byref(cfg), C.byref(pl), C.byref(rg),
                                          out.ctypes.data, C.byref(st)))
+    elif isinstance(config.velocity, PlaneVelocity):
+        # the plane's rays formed on the device, column-major like vec(αs): no (x, v) arrays to build or to send
+        rs, keep = separable_rayset(config.metric, config.position, config.velocity.plane, tiled=False)
+        n = rs.n
+        out = np.zeros(n, dtype=_lib.POINT_DTYPE)
+        _lib.check(L.gr_rayset_endpoints(ensemble.ctx.handle, C.byref(cfg), C.byref(rs), out.ctypes.data, C.byref(st)))
     else:
         v = np.ascontiguousarray(config.velocity, dtype=np.float64)
         x = np.ascontiguousarray(config.position, dtype=np.float64)

@@ -465,6 +465,33 @@ def test_separable_polar_plane_equals_explicit_rays(G, ens, monkeypatch, shape):
     np.testing.assert_allclose(out["1"][0], out["1"][1], rtol=1e-9, atol=1e-13)
 
 
+def test_tracegeodesics_on_a_polar_plane_forms_its_rays_on_the_device(G, ens, monkeypatch):
+    """tracegeodesics(m, u, plane::PolarPlane, d, ...) (the call inside the reference's lineprofile, line-profiles.jl:171-183):
+    the plane goes over as its tables and trajectory i is ray i of vec(αs) -- same statuses and end points as with host-built
+    (x, v) arrays (whose velocities come from a numpy product instead of the kernel's FMAs: agreement to rounding)."""
+    m = G.KerrMetric(1.0, 0.9)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    d = G.ThinDisc(m.isco(), 80.0)
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=37, Nθ=50, r_min=1.0, r_max=120.0)
+    got = {}
+    for sep in ("1", "0"):
+        monkeypatch.setenv("GRADUS_MI355X_SEPARABLE_RAYS", sep)
+        got[sep] = G.tracegeodesics(m, u, plane, d, (0.0, 2000.0), ensemble=ens, callback=G.domain_upper_hemisphere())
+    a, b = got["1"], got["0"]
+    assert a.size == b.size == 37 * 50
+    assert (a["status"] != b["status"]).sum() <= 2
+    same = a["status"] == b["status"]
+    np.testing.assert_allclose(a["v_init"][same], b["v_init"][same], rtol=1e-13, atol=1e-16)
+    hit = same & (a["status"] == 2)
+    assert hit.sum() > 300
+    np.testing.assert_allclose(a["x"][hit], b["x"][hit], rtol=1e-7, atol=1e-9)
+    # vec(αs) order: trajectory k is (r index, θ index) = (k % Nr, k // Nr)
+    αs, βs = G.impact_parameters(plane, u)
+    cfg = G.tracing_configuration(m, u, np.zeros((1, 4)), d, (0.0, 2000.0), ensemble=ens)
+    v = G.map_impact_parameters(m, u, αs[[0, 36, 37, 1849]], βs[[0, 36, 37, 1849]])
+    np.testing.assert_allclose(a["v_init"][[0, 36, 37, 1849], 1:], v[:, 1:], rtol=1e-12, atol=1e-15)
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_lineprofile_reassembles(G, ens, world):
     """distributed.lineprofile_sharded on one GPU: the partial histograms of every rank's shard (block-cyclic strips of
