@@ -10,8 +10,10 @@
 //                           counts differ ~4x between rays.
 // Output is one double per ray (fused PointFunction) or one 152-byte GeodesicPoint per ray.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -129,7 +131,7 @@ struct gr_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_band[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     bool lpt_suspend = false;              // banded launches do not learn / use a tile order (their ranges differ)
-    int64_t pipeline = 1;                  // 0: one launch + one copy (diagnostic)
+    int64_t pipeline = 4;                  // bands of the end-point return (0 / 1: one launch + one copy)
 };
 
 namespace {
@@ -528,7 +530,8 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
     if (!c || !key) return fail(GR_ERR_INVALID_ARGUMENT, "ctx/key is null");
     const std::string k(key);
     if (k == "pipeline") {
-        c->pipeline = value != 0;
+        if (value < 0 || value > 8) return fail(GR_ERR_INVALID_ARGUMENT, "pipeline must be 0..8 bands");
+        c->pipeline = value;
         return GR_OK;
     }
     if (k == "kernel") {
@@ -884,6 +887,12 @@ int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_r
 static void prefault_output(void* dst, size_t bytes)
 {
     if (bytes < ((size_t)64 << 20)) return;
+    {   // ask for transparent huge pages on the 2 MB-aligned interior: 300 faults instead of 155 000 for 637 MB
+        // (measured on the GPU box, THP mode "madvise": 10.7 ms instead of 27-64 ms with 8 threads; errors are ignored)
+        const size_t two = (size_t)2 << 20;
+        const size_t a0 = ((size_t)dst + two - 1) / two * two, a1 = ((size_t)dst + bytes) / two * two;
+        if (a1 > a0) (void)madvise((void*)a0, a1 - a0, MADV_HUGEPAGE);
+    }
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt == 0 ? 4 : (nt > 8 ? 8 : nt);
     const size_t page = 4096;
@@ -897,6 +906,54 @@ static void prefault_output(void* dst, size_t bytes)
     for (auto& x : th) x.join();
 }
 
+// The same sweep in the background: `wait_until(off)` returns once every page below `off` has been touched, so that
+// the first band can travel while the pages of the later ones are still being faulted in.
+struct BackgroundPrefault {
+    static constexpr unsigned kMax = 8;
+    std::atomic<size_t> progress[kMax];
+    std::vector<std::thread> th;
+    unsigned nt = 0;
+    size_t bytes = 0;
+    void start(void* dst, size_t n)
+    {
+        bytes = n;
+        if (n < ((size_t)64 << 20)) return;
+        const size_t two = (size_t)2 << 20;
+        const size_t a0 = ((size_t)dst + two - 1) / two * two, a1 = ((size_t)dst + n) / two * two;
+        if (a1 > a0) (void)madvise((void*)a0, a1 - a0, MADV_HUGEPAGE);
+        nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 4 : (nt > kMax ? kMax : nt);
+        char* base = (char*)dst;
+        const unsigned n_threads = nt;
+        for (unsigned t = 0; t < nt; ++t) {
+            progress[t].store(0, std::memory_order_relaxed);
+            th.emplace_back([this, base, n, t, n_threads]() {
+                const size_t page = 4096;
+                size_t since = 0;
+                for (size_t off = (size_t)t * page; off < n; off += (size_t)n_threads * page) {
+                    ((volatile char*)base)[off] = 0;
+                    if (++since == 256) { progress[t].store(off, std::memory_order_release); since = 0; }
+                }
+                progress[t].store(n, std::memory_order_release);
+            });
+        }
+    }
+    void wait_until(size_t off) const
+    {
+        if (nt == 0) return;
+        if (off > bytes) off = bytes;
+        for (unsigned t = 0; t < nt; ++t)
+            while (progress[t].load(std::memory_order_acquire) < off) std::this_thread::yield();
+    }
+    void finish()
+    {
+        for (auto& x : th) x.join();
+        th.clear();
+        nt = 0;
+    }
+    ~BackgroundPrefault() { finish(); }
+};
+
 static int32_t ensure_copy_stream(gr_ctx* ctx)
 {
     if (!ctx->copy_stream) GR_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -908,8 +965,8 @@ static int32_t ensure_copy_stream(gr_ctx* ctx)
 // How many bands a result of n records is returned in (1: not worth it), each a multiple of `unit` records.
 static int band_count(const gr_ctx* ctx, int64_t n, int64_t unit)
 {
-    if (!ctx->pipeline || unit <= 0 || n < ((int64_t)1 << 21)) return 1;
-    int nb = 4;
+    if (ctx->pipeline <= 1 || unit <= 0 || n < ((int64_t)1 << 21)) return 1;
+    int nb = (int)(ctx->pipeline > 8 ? 8 : ctx->pipeline);
     while (nb > 1 && (n / nb) < unit) --nb;
     return nb;
 }
@@ -1017,7 +1074,8 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
         return end_host_call(ctx, stats);
     }
     if ((rc = ensure_copy_stream(ctx)) != GR_OK) return rc;
-    const int64_t per = ((range->count / nb + unit - 1) / unit) * unit;
+    // equal bands except the last, which is half a band: its copy is the only one nothing overlaps
+    const int64_t per = ((2 * range->count / (2 * nb - 1) + unit - 1) / unit) * unit;
     int64_t j0[9];
     int used = 0;
     for (int64_t j = 0; j < range->count && used < 8; j += per) j0[used++] = j;
@@ -1031,8 +1089,10 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     }
     ctx->lpt_suspend = false;
     if (rc != GR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    prefault_output(points, bytes);
+    BackgroundPrefault pf;
+    pf.start(points, bytes);
     for (int k = 0; k < used; ++k) {
+        pf.wait_until(sizeof(gr_point) * (size_t)j0[k + 1]);
         GR_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
         GR_HIP(hipMemcpyAsync(points + j0[k], (gr_point*)ctx->d_scratch + j0[k], sizeof(gr_point) * (size_t)(j0[k + 1] - j0[k]),
                               hipMemcpyDeviceToHost, ctx->copy_stream));

@@ -26,17 +26,17 @@ for S in (1024, 2048):
         a, b, cache = G.prerendergeodesics(m, x, d, 2000.0, image_width=S, image_height=S, alpha_lims=(-60, 60), beta_lims=(-35, 35),
                                            ensemble=ens)
         ts.append(time.perf_counter() - t0)
-    for pipe in (1, 0):
+    for pipe in (4, 0):
         ens.set("pipeline", pipe)
         tt = []
         for _ in range(5):
             cfg0 = G.render_configuration(m, x, d, 2000.0, image_width=S, image_height=S, alpha_lims=(-60, 60), beta_lims=(-35, 35), ensemble=ens)
             t0 = time.perf_counter()
-            pts0 = G.ensemble_solve_tracing_problem(ens, cfg0)
+            pts0, st0 = G.ensemble_solve_tracing_problem(ens, cfg0, stats=True)
             tt.append(time.perf_counter() - t0)
             del pts0
-        out[f"endpoints_{S}_pipeline{pipe}_ms"] = [round(t * 1e3, 2) for t in tt]
-    ens.set("pipeline", 1)
+        out[f"endpoints_{S}_pipeline{pipe}_ms"] = [round(t * 1e3, 2) for t in tt] + [f"kernels {st0['kernel_ms']:.2f}"]
+    ens.set("pipeline", 4)
     cfg = G.render_configuration(m, x, d, 2000.0, image_width=S, image_height=S, alpha_lims=(-60, 60), beta_lims=(-35, 35), ensemble=ens)
     tr = []
     for _ in range(4):

@@ -162,14 +162,15 @@ def test_endpoints_returned_in_bands_equal_one_copy(G, ens):
     for W, H in ((1536, 1536), (1100, 2048)):
         cfg = G.render_configuration(m, X_FAR, d, 2000.0, image_width=W, image_height=H, alpha_lims=ALIMS, beta_lims=BLIMS, ensemble=ens)
         out = {}
-        for pipe in (1, 0):
+        for pipe in (4, 7, 0):
             ens.set("pipeline", pipe)
             pts, st = G.ensemble_solve_tracing_problem(ens, cfg, stats=True)
             out[pipe] = (pts.copy(), st)
-        assert out[1][0].tobytes() == out[0][0].tobytes()
-        for k in ("rays", "accepted_steps", "rejected_steps", "status_count"):
-            assert out[1][1][k] == out[0][1][k]
-        assert out[1][1]["rays"] == W * H
+        for pipe in (4, 7):
+            assert out[pipe][0].tobytes() == out[0][0].tobytes()
+            for k in ("rays", "accepted_steps", "rejected_steps", "status_count"):
+                assert out[pipe][1][k] == out[0][1][k]
+        assert out[4][1]["rays"] == W * H
 
 
 def test_kernels_agree_bitwise(G, ens):
