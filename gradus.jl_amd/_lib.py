@@ -147,6 +147,9 @@ class gr_binning(C.Structure):
         ("emissivity_index", C.c_double),
         ("n_bins", C.c_int64),
         ("bin_edges", C.c_void_p),
+        ("eps_r", C.c_void_p),
+        ("eps_v", C.c_void_p),
+        ("eps_n", C.c_int64),
     ]
 
 

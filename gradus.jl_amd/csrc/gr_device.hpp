@@ -1214,6 +1214,9 @@ struct Cold {
     // out_mode 3: (g, ρ) pairs for a host-side emissivity
     double lp_rmin, lp_rmax;  // minrₑ, maxrₑ
     double lp_q;              // ε(r) = r^-q
+    const double* lp_eps_r;   // device, lp_eps_n radii of a tabulated emissivity (RadialDiscProfile), or null
+    const double* lp_eps_v;   // device, lp_eps_n values
+    int64_t lp_eps_n;
     int64_t lp_nbins;
     const double* lp_edges;   // device, lp_nbins
     double* lp_flux;          // device, lp_nbins (accumulated with fp64 atomics)
@@ -2165,7 +2168,29 @@ struct Ray {
                     area = (real)cd.area[j];
                 }
                 // ε(r) g³ area with ε(r) = r^-q
-                const real eps = (cd.lp_q == 3.0) ? rcp_full(rho * rho * rho) : GR_POW(rho, -cd.lp_q);
+                real eps;
+                if (cd.lp_eps_n >= 2) {
+                    // emissivity_at(prof::RadialDiscProfile, ρ): clamp, then NaNLinearInterpolator (interpolations.jl:7-26)
+                    const int64_t ne = cd.lp_eps_n;
+                    const double rc = fmin(fmax((double)rho, cd.lp_eps_r[0]), cd.lp_eps_r[ne - 1]);
+                    int64_t a = 0, b = ne;                       // searchsortedlast: last index with eps_r[i] <= rc
+                    while (a < b) {
+                        const int64_t mid = (a + b) >> 1;
+                        if (cd.lp_eps_r[mid] <= rc) a = mid + 1; else b = mid;
+                    }
+                    int64_t i0 = a - 1;
+                    i0 = i0 < 0 ? 0 : (i0 > ne - 2 ? ne - 2 : i0);
+                    const double x1 = cd.lp_eps_r[i0], x2 = cd.lp_eps_r[i0 + 1], y1 = cd.lp_eps_v[i0], y2 = cd.lp_eps_v[i0 + 1];
+                    const double w = (rc - x1) / (x2 - x1);
+                    double y = (1.0 - w) * y1 + w * y2;
+                    if (y != y) {
+                        const double pick = w < 0.5 ? y1 : y2;
+                        y = (pick != pick) ? 0.0 : pick;
+                    }
+                    eps = (real)y;
+                } else {
+                    eps = (cd.lp_q == 3.0) ? rcp_full(rho * rho * rho) : GR_POW(rho, -cd.lp_q);
+                }
                 const real f = eps * g * g * g * area;
                 // bucket(Simple(), g, f, bins): last edge <= g, clamped to the first / last bin
                 // (the convention the reference's emissivity golden pins, test/unit/emissivity.jl:27-48)

@@ -787,7 +787,11 @@ int32_t gr_lineprofile_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     if (!pf || pf->pf_id != GR_PF_REDSHIFT) return fail(GR_ERR_INVALID_ARGUMENT, "line profiles use the redshift point function");
     if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     cd.out_mode = 2;
+    if (b->eps_n != 0 && (b->eps_n < 2 || !b->eps_r || !b->eps_v))
+        return fail(GR_ERR_INVALID_ARGUMENT, "tabulated emissivity: needs eps_n >= 2 radii and values");
     cd.lp_rmin = b->r_min; cd.lp_rmax = b->r_max; cd.lp_q = b->emissivity_index;
+    cd.lp_eps_r = b->eps_n >= 2 ? b->eps_r : nullptr; cd.lp_eps_v = b->eps_n >= 2 ? b->eps_v : nullptr;
+    cd.lp_eps_n = b->eps_n >= 2 ? b->eps_n : 0;
     cd.lp_nbins = b->n_bins; cd.lp_edges = b->bin_edges; cd.lp_flux = d_flux;
     p.stats = (unsigned long long*)d_stats;
     GR_HIP(hipMemsetAsync(d_flux, 0, sizeof(double) * (size_t)b->n_bins, stream));
@@ -1198,12 +1202,20 @@ int32_t gr_lineprofile(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
     gr_rayset dev;
     void* extra = nullptr;
     const size_t nb = (size_t)b->n_bins;
-    if ((rc = stage_rays(ctx, rays, dev, sizeof(double) * 2 * nb, &extra)) != GR_OK) return rc;
+    const size_t ne = (b->eps_n >= 2 && b->eps_r && b->eps_v) ? (size_t)b->eps_n : 0;
+    if ((rc = stage_rays(ctx, rays, dev, sizeof(double) * (2 * nb + 2 * ne), &extra)) != GR_OK) return rc;
     double* d_edges = (double*)extra;
     double* d_flux = d_edges + nb;
     GR_HIP(hipMemcpyAsync(d_edges, b->bin_edges, sizeof(double) * nb, hipMemcpyHostToDevice, ctx->stream));
     gr_binning db = *b;
     db.bin_edges = d_edges;
+    if (ne) {
+        double* d_er = d_flux + nb;
+        GR_HIP(hipMemcpyAsync(d_er, b->eps_r, sizeof(double) * ne, hipMemcpyHostToDevice, ctx->stream));
+        GR_HIP(hipMemcpyAsync(d_er + ne, b->eps_v, sizeof(double) * ne, hipMemcpyHostToDevice, ctx->stream));
+        db.eps_r = d_er;
+        db.eps_v = d_er + ne;
+    }
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
     if ((rc = gr_lineprofile_device(ctx, cfg, &dev, pf, &db, d_flux, stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
     GR_HIP(hipMemcpyAsync(flux, d_flux, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));

@@ -190,9 +190,25 @@ def lineprofile(bins, ε, m, u, d, method=None, *, λ_max=None, redshift_pf=None
             ens.ctx.set("kernel", 2)
 
 
+def _emissivity_table(ε):
+    """(radii, values) of an emissivity given as a RadialDiscProfile (anything with `radii` and `ε` arrays and the
+    reference's `emissivity_at` semantics, src/corona/radial.jl:15-18), else None."""
+    r, v = getattr(ε, "radii", None), getattr(ε, "ε", None)
+    if r is None or v is None or not hasattr(ε, "emissivity_at"):
+        return None
+    r, v = np.ascontiguousarray(r, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
+    if r.ndim != 1 or r.size < 2 or r.shape != v.shape or np.any(np.diff(r) <= 0):
+        return None
+    return r, v
+
+
 def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, stats):
-    if isinstance(ε, PowerLawEmissivity):
-        b = _lib.gr_binning(float(minrₑ), float(maxrₑ), ε.q, bins.size, bins.ctypes.data)
+    table = None if isinstance(ε, PowerLawEmissivity) else _emissivity_table(ε)
+    if isinstance(ε, PowerLawEmissivity) or table is not None:
+        b = _lib.gr_binning(float(minrₑ), float(maxrₑ), ε.q if table is None else 0.0, bins.size, bins.ctypes.data)
+        if table is not None:
+            # an emissivity profile is a table: interpolated on the device like the power law is evaluated there
+            b.eps_r, b.eps_v, b.eps_n = table[0].ctypes.data, table[1].ctypes.data, table[0].size
         flux = np.zeros(bins.size)
         _lib.check(L.gr_lineprofile(h, C.byref(cfg), C.byref(rs), C.byref(pf), C.byref(b), flux.ctypes.data,
                                     C.byref(st)))
@@ -202,7 +218,7 @@ def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, 
                                         pairs.ctypes.data, C.byref(st)))
         I = ~np.isnan(pairs[:, 0])
         g, r = pairs[I, 0], pairs[I, 1]
-        f = ε(r) * g ** 3 * areas[I]
+        f = (ε(r) if callable(ε) else ε.emissivity_at(r)) * g ** 3 * areas[I]
         flux = bucket_simple(g, f, bins)
     total = flux.sum()
     out = flux / total if total != 0 else flux

@@ -325,6 +325,13 @@ typedef struct gr_binning {
     double emissivity_index;  /* ε(r) = r^-q                                               */
     int64_t n_bins;
     const double* bin_edges;  /* n_bins values, ascending (the `bins` argument)            */
+    /* ABI 4: a tabulated emissivity instead of the power law -- emissivity_at(prof::RadialDiscProfile, r)
+     * (src/corona/radial.jl:15-18): r clamped to [eps_r[0], eps_r[eps_n-1]], then the NaNLinearInterpolator of
+     * src/interpolations.jl:1-30 (linear between the neighbouring radii; a NaN node falls back to the nearer finite
+     * neighbour, else 0).  eps_n >= 2 selects it; eps_n = 0: ε(r) = r^-emissivity_index. */
+    const double* eps_r;      /* eps_n radii, ascending                                    */
+    const double* eps_v;      /* eps_n emissivities                                        */
+    int64_t eps_n;
 } gr_binning;
 
 /* flux[k] += ε(ρ) g³ area for every counted hit whose redshift g falls in bin k

@@ -140,6 +140,9 @@ struct GrBinning                     # == gr_binning
     emissivity_index::Float64
     n_bins::Int64
     bin_edges::Ptr{Float64}
+    eps_r::Ptr{Float64}              # a tabulated emissivity (RadialDiscProfile) instead of the power law, or C_NULL / 0
+    eps_v::Ptr{Float64}
+    eps_n::Int64
 end
 
 _check(rc) = rc == 0 || error(unsafe_string(ccall((:gr_last_error, LIB), Cstring, ())))
@@ -585,7 +588,8 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     gpf, keep_pf = bpf
     pfs = Ref(gpf)
     edges = collect(Float64, bins)
-    binning = Ref(GrBinning(Float64(minrₑ), Float64(maxrₑ), Float64(q), length(edges), pointer(edges)))
+    binning = Ref(GrBinning(Float64(minrₑ), Float64(maxrₑ), Float64(q), length(edges), pointer(edges),
+        Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0))
     flux = zeros(Float64, length(edges))
     stats = Ref{GrStats}()
     _check(GC.@preserve tab dtab keep_pf rs cs sn edges ccall((:gr_lineprofile, LIB), Int32,

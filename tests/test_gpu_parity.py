@@ -466,6 +466,33 @@ def test_separable_polar_plane_equals_explicit_rays(G, ens, monkeypatch, shape):
     np.testing.assert_allclose(out["1"][0], out["1"][1], rtol=1e-9, atol=1e-13)
 
 
+def test_lineprofile_with_an_emissivity_profile_is_fused(G, ens, monkeypatch):
+    """lineprofile(bins, prof::RadialDiscProfile, m, u, d, BinningMethod()): the profile's table is interpolated on the
+    device (emissivity_at: clamp to the table's range + NaNLinearInterpolator, src/corona/radial.jl:15-18,
+    src/interpolations.jl:1-30) and binned there.  Same profile as the generic route (pairs back to the host, numpy
+    interpolation and bucketing) -- with a table that has a NaN node, with hits beyond both ends of the table (clamped),
+    and for a lamp-post emissivity profile traced on the device."""
+    from gradus_jl_amd import lineprofiles as LP
+    from gradus_jl_amd.corona import RadialDiscProfile
+
+    m = G.KerrMetric(1.0, 0.9)
+    u = np.array([0.0, 1000.0, math.radians(55), 0.0])
+    d = G.ThinDisc(m.isco(), 200.0)
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=160, Nθ=200, r_min=1.0, r_max=300.0)
+    bins = np.linspace(0.1, 1.6, 120)
+    radii = np.geomspace(4.0, 120.0, 40)                      # the disc extends beyond both ends: clamped there
+    eps = radii ** -2.7 * (1.0 + 0.3 * np.sin(radii))
+    eps[7] = np.nan                                            # a bin no corona ray fell into
+    lamp = G.emissivity_profile(m, d, G.LampPostModel(h=8.0), n_samples=400, ensemble=ens)
+    for prof in (RadialDiscProfile(radii, eps, np.zeros_like(radii)), lamp):
+        _, y_fused, st = G.lineprofile(bins, prof, m, u, d, G.BinningMethod(), plane=plane, maxrₑ=200.0, ensemble=ens, stats=True)
+        monkeypatch.setattr(LP, "_emissivity_table", lambda e: None)        # force the generic route
+        _, y_gen = G.lineprofile(bins, prof, m, u, d, G.BinningMethod(), plane=plane, maxrₑ=200.0, ensemble=ens)
+        monkeypatch.undo()
+        assert st["rays"] == 160 * 200 and y_fused.sum() == pytest.approx(1.0, abs=1e-12) and np.count_nonzero(y_fused) > 40
+        np.testing.assert_allclose(y_fused, y_gen, rtol=1e-10, atol=1e-15)
+
+
 def test_tracegeodesics_on_a_polar_plane_forms_its_rays_on_the_device(G, ens, monkeypatch):
     """tracegeodesics(m, u, plane::PolarPlane, d, ...) (the call inside the reference's lineprofile, line-profiles.jl:171-183):
     the plane goes over as its tables and trajectory i is ray i of vec(αs) -- same statuses and end points as with host-built
