@@ -218,7 +218,7 @@ def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, 
                                         pairs.ctypes.data, C.byref(st)))
         I = ~np.isnan(pairs[:, 0])
         g, r = pairs[I, 0], pairs[I, 1]
-        f = (ε(r) if callable(ε) else ε.emissivity_at(r)) * g ** 3 * areas[I]
+        f = (ε(r) if callable(ε) else ε.emissivity_at(r)) * (g * g * g) * areas[I]
         flux = bucket_simple(g, f, bins)
     total = flux.sum()
     out = flux / total if total != 0 else flux
