@@ -76,16 +76,18 @@ def lineprofile_device(bins, ε, m, u, d, plane, *, shard=None, maxrₑ=50.0, mi
                        callback="default", ensemble=None, flux=None, stats=None, **solver_args):
     """gr_lineprofile_device: the un-normalised BinningMethod histogram of (a shard of) a PolarPlane's rays, accumulated
     into a float64 CUDA tensor of bins.size entries (`flux` if given, else a new one; the launch zeroes it first).  `shard`: a distributed.RayShard (block-cyclic sub-range of the plane's rays) or None = all of them.
-    Asynchronous on the current stream; power-law emissivities only (the fused route)."""
+    Asynchronous on the current stream; the fused route: power laws and emissivity profiles (tables)."""
     import torch
 
-    from .lineprofiles import PowerLawEmissivity, _rayset
+    from .lineprofiles import PowerLawEmissivity, _emissivity_table, _rayset
     from .planes import PolarPlane
     from .pointfunctions import ConstPointFunctions
     from .tracing import domain_upper_hemisphere, tracing_configuration
 
-    if not isinstance(ε, PowerLawEmissivity) or not isinstance(plane, PolarPlane):
-        raise NotImplementedError("the device-resident line profile is the fused route: PowerLawEmissivity on a PolarPlane")
+    table = None if isinstance(ε, PowerLawEmissivity) else _emissivity_table(ε)
+    if not (isinstance(ε, PowerLawEmissivity) or table is not None) or not isinstance(plane, PolarPlane):
+        raise NotImplementedError("the device-resident line profile is the fused route: a PowerLawEmissivity or an emissivity "
+                                  "profile (RadialDiscProfile) on a PolarPlane")
     u = np.asarray(u, dtype=np.float64)
     bins = np.ascontiguousarray(bins, dtype=np.float64)
     λ_max = 2.0 * u[1] if λ_max is None else λ_max
@@ -101,7 +103,8 @@ def lineprofile_device(bins, ε, m, u, d, plane, *, shard=None, maxrₑ=50.0, mi
     keep = []
     rs, _ = _rayset(config, plane, keep)
     # the three tables and the bin edges live in HBM for the launch (tiny: Nr + 2 Nθ + n_bins doubles)
-    tabs = torch.from_numpy(np.concatenate([keep[0], keep[1], keep[2], bins])).to(dev)
+    extra = [] if table is None else [table[0], table[1]]
+    tabs = torch.from_numpy(np.concatenate([keep[0], keep[1], keep[2], bins] + extra)).to(dev)
     nr, nt = plane.Nr, plane.Nθ
     base = tabs.data_ptr()
     rs.sep_r, rs.sep_cos, rs.sep_sin = base, base + 8 * nr, base + 8 * (nr + nt)
@@ -110,7 +113,10 @@ def lineprofile_device(bins, ε, m, u, d, plane, *, shard=None, maxrₑ=50.0, mi
     if flux is None:
         flux = torch.zeros(bins.size, dtype=torch.float64, device=dev)
     assert flux.is_cuda and flux.dtype == torch.float64 and flux.numel() == bins.size
-    b = _lib.gr_binning(float(minrₑ), float(maxrₑ), ε.q, bins.size, base + 8 * (nr + 2 * nt))
+    b = _lib.gr_binning(float(minrₑ), float(maxrₑ), ε.q if table is None else 0.0, bins.size, base + 8 * (nr + 2 * nt))
+    if table is not None:
+        off = base + 8 * (nr + 2 * nt + bins.size)
+        b.eps_r, b.eps_v, b.eps_n = off, off + 8 * table[0].size, table[0].size
     pf, keep_pf = abi_pointfunction(redshift_pf)
     lane = rs._tiled and ens.knobs.get("kernel", 2) == 2 and max(config.abstol, config.reltol) <= 1e-6
     if lane:

@@ -550,6 +550,14 @@ def test_sharded_lineprofile_reassembles(G, ens, world):
     assert rays == sa["rays"] == 200 * 132 and steps == sa["accepted_steps"]
     np.testing.assert_allclose(parts.cpu().numpy(), whole.cpu().numpy(), rtol=1e-11, atol=1e-18)
     if world == 2:
+        # an emissivity profile (table) through the device-resident route equals the host-buffer route
+        from gradus_jl_amd.corona import RadialDiscProfile
+
+        rr = np.geomspace(2.0, 200.0, 30)
+        prof = RadialDiscProfile(rr, rr ** -2.5, np.zeros_like(rr))
+        _, yt = lineprofile_sharded(bins, prof, m, u, d, plane, maxrₑ=250.0, ensemble=ens)
+        _, yt_ref = G.lineprofile(bins, prof, m, u, d, G.BinningMethod(), plane=plane, maxrₑ=250.0, ensemble=ens)
+        np.testing.assert_allclose(yt, yt_ref, rtol=1e-11, atol=1e-18)
         _, y = lineprofile_sharded(bins, eps, m, u, d, plane, maxrₑ=250.0, ensemble=ens)
         _, y_ref = G.lineprofile(bins, eps, m, u, d, G.BinningMethod(), plane=plane, maxrₑ=250.0, ensemble=ens)
         np.testing.assert_allclose(y, y_ref, rtol=1e-11, atol=1e-18)
