@@ -556,13 +556,14 @@ end
 
 # ---------------------------------------------------------------------------------------------------------------
 # lineprofile(bins, ε, m, u, d, BinningMethod(); plane) (src/line-profiles.jl:152-198) fused on the device for a power-law
-# emissivity ε(r) = r^-q on a PolarPlane: the plane crosses the boundary as its radii and the cosines / sines of its
+# emissivity ε(r) = r^-q or an emissivity profile (RadialDiscProfile) on a PolarPlane: the plane crosses the boundary as its radii and the cosines / sines of its
 # angles (src/image-planes/planes.jl:96-131), the device forms the rays, traces them, evaluates redshift and ε g³ area
 # and bins -- BASELINE config 5 (4096² rays) in one call.  The reference's method fixes `ensemble =
 # EnsembleEndpointThreads()` ahead of `solver_args...`, so a maintainer wiring this in adds one branch there:
 #     ensemble isa EnsembleMI355X && ε isa PowerLaw... && plane isa PolarPlane && return lineprofile_mi355x(...)
 # ---------------------------------------------------------------------------------------------------------------
-function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float64}, q::Real, m, u::SVector{4,Float64}, d;
+function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float64}, ε::Union{Real,Gradus.RadialDiscProfile}, m,
+        u::SVector{4,Float64}, d;
         plane::Gradus.PolarPlane = Gradus.PolarPlane(Gradus.GeometricGrid(); Nr = 450, Nθ = 1300, r_max = 250.0),
         λ_max = 2 * u[2], minrₑ = Gradus.isco(m), maxrₑ = 50.0, redshift_pf = ConstPointFunctions.redshift(m, u),
         gtol = 1e-2, abstol = 1e-9, reltol = 1e-9, chart = Gradus.chart_for_metric(m), upper_hemisphere = true)
@@ -588,11 +589,16 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     gpf, keep_pf = bpf
     pfs = Ref(gpf)
     edges = collect(Float64, bins)
-    binning = Ref(GrBinning(Float64(minrₑ), Float64(maxrₑ), Float64(q), length(edges), pointer(edges),
-        Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0))
+    # ε: the exponent q of a power law r^-q, or an emissivity profile whose table the device interpolates like
+    # emissivity_at(prof, r) does (src/corona/radial.jl:15-18)
+    q = ε isa Real ? Float64(ε) : 0.0
+    er = ε isa Real ? Float64[] : collect(Float64, ε.radii)
+    ev = ε isa Real ? Float64[] : collect(Float64, ε.ε)
+    binning = Ref(GrBinning(Float64(minrₑ), Float64(maxrₑ), q, length(edges), pointer(edges),
+        isempty(er) ? Ptr{Float64}(C_NULL) : pointer(er), isempty(ev) ? Ptr{Float64}(C_NULL) : pointer(ev), length(er)))
     flux = zeros(Float64, length(edges))
     stats = Ref{GrStats}()
-    _check(GC.@preserve tab dtab keep_pf rs cs sn edges ccall((:gr_lineprofile, LIB), Int32,
+    _check(GC.@preserve tab dtab keep_pf rs cs sn edges er ev ccall((:gr_lineprofile, LIB), Int32,
         (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ref{GrBinning}, Ptr{Float64}, Ref{GrStats}),
         ensemble.ctxs[1], cfg, rays, pfs, binning, flux, stats))
     bins, flux ./ sum(flux)                                                            # line-profiles.jl:197
