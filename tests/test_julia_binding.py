@@ -324,3 +324,50 @@ def test_reference_facts_the_binding_relies_on():
     body = re.search(r"struct GeodesicPoint\{T,A\} <: AbstractGeodesicPoint\{T\}(.*?)\nend", sp, flags=re.S).group(1)
     order = re.findall(r"^\s{4}(\w+)::", body, flags=re.M)
     assert order == ["status", "λ_min", "λ_max", "x_init", "x", "v_init", "v", "aux"]
+
+
+def test_blocks_and_brackets_balance():
+    """No Julia here to parse the file: at least every block opener has its `end` and every bracket its partner (comments,
+    strings and docstrings removed; `for` / `if` inside brackets are generators / ternaries, `end` inside brackets an index)."""
+    def strip(s):
+        out, i, n = [], 0, len(s)
+        while i < n:
+            if s.startswith('"""', i):
+                j = s.find('"""', i + 3)
+                i = (j + 3) if j >= 0 else n
+                out.append(" ")
+                continue
+            c = s[i]
+            if c == '"':
+                j = i + 1
+                while j < n and s[j] != '"':
+                    if s[j] == "\\":
+                        j += 1
+                    j += 1
+                i = j + 1
+                out.append('""')
+                continue
+            if c == "#":
+                j = s.find("\n", i)
+                i = j if j >= 0 else n
+                continue
+            out.append(c)
+            i += 1
+        return "".join(out)
+
+    toks = re.findall(r"[A-Za-z_][A-Za-z_0-9!]*|\S", strip(JL))
+    openers = {"function", "if", "for", "while", "struct", "begin", "let", "do", "try", "module", "macro", "quote"}
+    depth, brack = 0, []
+    for k, tok in enumerate(toks):
+        if tok in "([{":
+            brack.append(tok)
+        elif tok in ")]}":
+            assert brack and "([{".index(brack.pop()) == ")]}".index(tok), ("bracket mismatch near token", k, toks[max(0, k - 8):k + 3])
+        elif tok in openers:
+            if tok in ("for", "if") and brack:
+                continue
+            depth += 1
+        elif tok == "end" and not brack:
+            depth -= 1
+            assert depth >= 0, ("an `end` without an opener near token", k, toks[max(0, k - 8):k + 3])
+    assert depth == 0 and not brack, (depth, brack)
