@@ -428,6 +428,18 @@ end
 # The generic boundary: same signature as src/tracing/tracing.jl:151-158.  GeodesicPoint{Float64,Nothing} is isbits
 # with the layout of gr_point (152 bytes), so the result vector is filled in place by the library.
 # ---------------------------------------------------------------------------------------------------------------
+"The (αs, βs) an image plane's velocity closure captured, or `nothing` for any other velocity."
+function _plane_rays(config::TracingConfiguration)
+    f = config.velocity
+    f isa Function || return nothing
+    names = fieldnames(typeof(f))
+    (:αs in names && :βs in names) || return nothing
+    αs, βs = getfield(f, :αs), getfield(f, :βs)
+    (αs isa AbstractArray{Float64} && βs isa AbstractArray{Float64}) || return nothing
+    (length(αs) == config.trajectories == length(βs)) || return nothing
+    collect(vec(αs)), collect(vec(βs))
+end
+
 function _cpu_fallback(reason, problem, config; kwargs...)
     @warn "EnsembleMI355X: $reason -- tracing on the CPU with EnsembleEndpointThreads instead"
     Gradus.ensemble_solve_tracing_problem(Gradus.EnsembleEndpointThreads(), problem, config; kwargs...)
@@ -466,6 +478,22 @@ function Gradus.ensemble_solve_tracing_problem(
         _check(GC.@preserve keep out ccall((:gr_render_endpoints, LIB), Int32,
             (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrPlane}, Ref{GrRange}, Ptr{Cvoid}, Ref{GrStats}),
             ensemble.ctxs[1], cfg, pl, rg, out, stats))
+        return out
+    end
+    # the velocity closure of an image plane (promote_velfunc, image-planes/planes.jl:180-184: it captures the plane's impact
+    # parameters αs, βs): 16 B per ray go over and map_impact_parameters runs on the device -- what lineprofile(…,
+    # BinningMethod()) and lagtransfer trace (line-profiles.jl:171-183)
+    pr = _plane_rays(config)
+    if !isnothing(pr) && config.position isa SVector
+        αv, βv = pr
+        g = Gradus.metric(config.metric, config.position)
+        Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
+        rays = Ref(GrRayset(Tuple(SVector{4,Float64}(config.position)), Tuple(permutedims(Mx)), pointer(αv), pointer(βv),
+            Ptr{Float64}(C_NULL), N, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0,
+            Int32(0), Int32(0), 0, 0, 0))
+        _check(GC.@preserve keep αv βv out ccall((:gr_rayset_endpoints, LIB), Int32,
+            (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ptr{Cvoid}, Ref{GrStats}),
+            ensemble.ctxs[1], cfg, rays, out, stats))
         return out
     end
     # arbitrary velocity closures are evaluated on the host (UNCONSTRAINED: constrain_all runs on the device with
