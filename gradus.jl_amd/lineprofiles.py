@@ -98,10 +98,12 @@ class _LazyAreas:
         self.r, self.nr, self.nt, self.tiled, self._a = r, nr, nt, tiled, None
 
     def __getitem__(self, I):
-        if self._a is None:
-            i, _ = _sep_index(np.arange(self.nr * self.nt, dtype=np.int64), self.nr, self.nt, self.tiled)
-            self._a = self.r[i] ** 2
-        return self._a[I]
+        I = np.asarray(I)
+        if I.dtype == bool:
+            I = np.flatnonzero(I)
+        i, _ = _sep_index(I.astype(np.int64, copy=False), self.nr, self.nt, self.tiled)      # only the rays asked for (the hits)
+        r = self.r[i]
+        return r * r
 
 
 def _rayset(config, plane, keep):
@@ -216,7 +218,7 @@ def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, 
         pairs = np.zeros((rs.n, 2))
         _lib.check(L.gr_redshift_radius(h, C.byref(cfg), C.byref(rs), C.byref(pf), float(minrₑ), float(maxrₑ),
                                         pairs.ctypes.data, C.byref(st)))
-        I = ~np.isnan(pairs[:, 0])
+        I = np.flatnonzero(~np.isnan(pairs[:, 0]))
         g, r = pairs[I, 0], pairs[I, 1]
         f = (ε(r) if callable(ε) else ε.emissivity_at(r)) * (g * g * g) * areas[I]
         flux = bucket_simple(g, f, bins)
