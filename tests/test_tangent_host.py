@@ -128,3 +128,35 @@ def test_separable_ray_sets_equal_explicit_arrays(G, nr, nt):
         perm = _tile_order(nr, nt)
         i, j = _sep_index(np.arange(nr * nt), nr, nt, True)
         assert np.array_equal(perm, i + nr * j)
+
+
+@pytest.mark.parametrize("angle", [3, 30, 74])
+def test_jacobians_satisfy_the_area_identity_of_the_ring_image(G, angle):
+    """A check of the dual-number Jacobians that needs neither difference quotients nor the reference: the image of the ring
+    ρ = rₑ encloses the area A(rₑ) = ½∮r(θ)² dθ (from the root finder alone), and dA/drₑ = ∮ds/|∇ρ| = ∮|∂(α,β)/∂(rₑ,g)| |dg|
+    along the ring -- the first form uses (∂ρ/∂α, ∂ρ/∂β), the second is the transfer function's own Jacobian (its
+    normalisation: ∫f/(g√(g✶(1-g✶))) dg✶ over both branches = dA/drₑ / (π rₑ)).  a = 0.998, rₑ = 4, observer at 10⁵."""
+    from gradus_jl_amd import transfer_functions as TF
+
+    x = np.array([0.0, 100_000.0, math.radians(angle), 0.0])
+    m, tr = Hh.tangent_tracer(G, 0.998, x, 2 * x[1])
+    th = np.linspace(0.0, 2 * math.pi, 1441)[:-1]
+
+    def ring(r_e):
+        return TF.find_offsets_for_radius_newton_ad(tr, np.full(th.size, r_e), th, r_min=m.inner_radius())
+
+    def area(r_e):
+        r = ring(r_e)[0]
+        return 0.5 * np.sum(r * r) * (th[1] - th[0])
+
+    dA = (area(4.0 + 1e-3) - area(4.0 - 1e-3)) / 2e-3
+    r, _, g, tan = ring(4.0)
+    ga, gb, ra, rb = tan[:, 2], tan[:, 3], tan[:, 4], tan[:, 5]
+    al, be = r * np.cos(th), r * np.sin(th)
+    ds = np.hypot(np.diff(np.r_[al, al[0]]), np.diff(np.r_[be, be[0]]))
+    grad = np.hypot(ra, rb)
+    assert np.sum(ds / (0.5 * (grad + np.roll(grad, -1)))) == pytest.approx(dA, rel=5e-5)
+    Jinv = 1.0 / np.abs(ra * gb - rb * ga)
+    dg = np.abs(np.diff(np.r_[g, g[0]]))
+    # |J| ~ 1/|θ - θ*| at the two extrema of g, |dg| ~ |θ - θ*| dθ: integrable, the trapezoid sum is good to a per cent
+    assert np.sum(0.5 * (Jinv + np.roll(Jinv, -1)) * dg) == pytest.approx(dA, rel=1.5e-2)
