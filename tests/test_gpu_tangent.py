@@ -117,3 +117,31 @@ def test_tangent_entry_point_edges(G, ens):
     # per-ray datum planes (thick-disc transfer functions): heights shift the surface the tangents are taken on
     up = tr.tangent(a, b, heights=np.array([0.5, 0.5]))
     assert np.all(up[:, 7] == 2) and np.all(np.abs(up[:, 1] - ref[:, 1]) > 1e-3)
+
+
+@pytest.mark.parametrize("angle,re,rel", [(3, 4.0, 2e-4), (30, 4.0, 5e-4), (85, 4.0, 6e-3)])
+def test_device_transfer_functions_satisfy_the_normalisation_identity(G, ens, angle, re, rel):
+    """∮ (f/g) 2 dφ (g✶ = sin²φ, both branches) = (1/π rₑ) dA/drₑ with A(rₑ) the area enclosed by the image of the ring
+    ρ = rₑ -- the transfer function's own normalisation against a number the root finder alone provides; on the device, at
+    the points where the reference's recorded mean(f g✶) is not met (tests/test_transfer_functions_tangent_host.py)."""
+    from gradus_jl_amd import transfer_functions as TF
+
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 100_000.0, math.radians(angle), 0.0])
+    chart = G.chart_for_metric(m, 2 * x[1], closest_approach=1.005)
+    tr = TF.device_tracer(m, x, 2 * x[1], chart, G.ConstPointFunctions.redshift(m, x), ens)
+    th = np.linspace(0.0, 2 * math.pi, 1441)[:-1]
+
+    def area(r_e):
+        r = TF.find_offsets_for_radius_newton_ad(tr, np.full(th.size, r_e), th, r_min=m.inner_radius())[0]
+        return 0.5 * np.sum(r * r) * (th[1] - th[0])
+
+    dA = (area(re + 1e-3) - area(re - 1e-3)) / 2e-3
+    c = G.cunningham_transfer_function(m, x, G.ThinDisc(0.0, float("inf")), re, N=80, chart=chart, ensemble=ens)
+    gs = np.clip(c.g_star, 0.0, 1.0)
+    y = c.f / (c.gmin + gs * (c.gmax - c.gmin))
+    for k in np.flatnonzero(c.f == 0.0):
+        y[k] = 0.5 * (y[k - 1] + y[(k + 1) % y.size])
+    phi = np.arcsin(np.sqrt(gs))
+    total = np.sum(0.5 * (y + np.roll(y, -1)) * 2.0 * np.abs(np.roll(phi, -1) - phi))
+    assert total == pytest.approx(dA / (math.pi * re), rel=rel)
