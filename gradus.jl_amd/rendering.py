@@ -136,15 +136,26 @@ def rendergeodesics(m, position, *args, image_width=375, image_height=250, alpha
     return α, β, res
 
 
-@dataclass
 class EndpointRenderCache:
-    """rendering/cache.jl:40-52"""
+    """rendering/cache.jl:40-52.  `points`: (height, width) GeodesicPoint records on the host.  With
+    `prerendergeodesics(..., keep_on_device=True)` the records stay in HBM as well (`device_points`: a uint8 CUDA tensor of
+    152 B per ray in image order) -- `apply` of a built-in point function then runs on them where they are, and the host
+    copy is made only when `points` is first read."""
 
-    config: TracingConfiguration
-    max_time: float
-    height: int
-    width: int
-    points: np.ndarray   # (height, width) GeodesicPoint records
+    def __init__(self, config, max_time, height, width, points=None, device_points=None):
+        self.config, self.max_time, self.height, self.width = config, max_time, height, width
+        self._points, self.device_points = points, device_points
+
+    @property
+    def points(self):
+        if self._points is None:
+            import torch
+
+            n = self.height * self.width
+            host = np.empty(n, dtype=_lib.POINT_DTYPE)
+            torch.from_numpy(host.view(np.uint8)).copy_(self.device_points[: n * _lib.POINT_DTYPE.itemsize])
+            self._points = host.reshape(self.width, self.height).T
+        return self._points
 
     @property
     def m(self):
@@ -152,13 +163,27 @@ class EndpointRenderCache:
 
 
 def prerendergeodesics(m, position, *args, image_width=375, image_height=250, alpha_lims=(-60, 60),
-                       beta_lims=(-40, 40), ensemble=None, **kwargs):
-    """prerendergeodesics -> (α, β, EndpointRenderCache) -- rendering.jl:56-87,121-138."""
+                       beta_lims=(-40, 40), ensemble=None, keep_on_device=False, **kwargs):
+    """prerendergeodesics -> (α, β, EndpointRenderCache) -- rendering.jl:56-87,121-138.  `keep_on_device`: leave the end
+    points in HBM (152 B per ray) for `apply` of built-in point functions; the host copy is made on first use."""
     kwargs = _unicode_kwargs(kwargs)
     alpha_lims = kwargs.pop("alpha_lims", alpha_lims)
     beta_lims = kwargs.pop("beta_lims", beta_lims)
     config = render_configuration(m, position, *args, image_width=image_width, image_height=image_height,
                                   alpha_lims=alpha_lims, beta_lims=beta_lims, ensemble=ensemble, **kwargs)
+    if keep_on_device:
+        import torch
+
+        from .device import render_endpoints_device
+
+        ens = config.ensemble
+        dev = torch.device("cuda", ens.device)
+        raw = torch.empty(image_width * image_height * _lib.POINT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        render_endpoints_device(config, raw)
+        torch.cuda.synchronize(dev)
+        cache = EndpointRenderCache(config, config.λ_domain[1], image_height, image_width, None, raw)
+        α, β = impact_axes(image_width, image_height, alpha_lims, beta_lims)
+        return α, β, cache
     pts = ensemble_solve_tracing_problem(config.ensemble, config)
     cache = EndpointRenderCache(config, config.λ_domain[1], image_height, image_width,
                                 pts.reshape(image_width, image_height).T)
@@ -168,6 +193,20 @@ def prerendergeodesics(m, position, *args, image_width=375, image_height=250, al
 
 def apply(pf, rc: EndpointRenderCache, **kw):
     """apply(pf, cache) -- point-functions.jl:98-101"""
+    if pf.fusable and rc.device_points is not None:
+        # the records are in HBM already: k_apply_pf reads them there (0.1 ms at 2048² instead of uploading 637 MB)
+        import torch
+
+        from .device import _stream_handle
+
+        n = rc.width * rc.height
+        cfg = rc.config.abi_config()
+        s, keep = abi_pointfunction(pf)
+        out = torch.empty(n, dtype=torch.float64, device=rc.device_points.device)
+        _lib.check(_lib.load().gr_apply_pointfunction_device(
+            rc.config.ensemble.ctx.handle, C.byref(cfg), C.byref(s), C.c_void_p(rc.device_points.data_ptr()), n, float(rc.max_time),
+            C.c_void_p(out.data_ptr()), _stream_handle()))
+        return out.cpu().numpy().reshape(rc.width, rc.height).T
     pts = np.ascontiguousarray(rc.points.T).ravel()
     out = apply_pointfunction(rc.config.ensemble, rc.config, pf, pts, rc.max_time)
     return out.reshape(rc.width, rc.height).T

@@ -173,6 +173,34 @@ def test_endpoints_returned_in_bands_equal_one_copy(G, ens):
         assert out[4][1]["rays"] == W * H
 
 
+def test_endpoint_cache_kept_on_the_device(G, ens):
+    """prerendergeodesics(..., keep_on_device=True): `apply` of built-in point functions runs on the records in HBM
+    (gr_apply_pointfunction_device) and gives the image of the host route bit for bit; the host copy appears on first use
+    and equals the ordinary cache; a Python point function still works (it reads the host copy)."""
+    import time
+
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    kw = dict(image_width=512, image_height=384, alpha_lims=ALIMS, beta_lims=BLIMS, ensemble=ens)
+    _, _, host = G.prerendergeodesics(m, X_FAR, d, 2000.0, **kw)
+    _, _, dev = G.prerendergeodesics(m, X_FAR, d, 2000.0, keep_on_device=True, **kw)
+    assert dev._points is None and dev.device_points is not None
+    for pf in (G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected(), G.ConstPointFunctions.shadow(),
+               G.ConstPointFunctions.affine_time()):
+        a, b = G.apply(pf, dev), G.apply(pf, host)
+        assert a.shape == b.shape == (384, 512) and a.tobytes() == b.tobytes()
+    assert dev._points is None                                   # nothing came back but images
+    assert dev.points.tobytes() == host.points.tobytes()
+    custom = G.PointFunction(lambda mm, gp, t: gp["x"][1])
+    np.testing.assert_array_equal(G.apply(custom, dev), G.apply(custom, host))
+    t0 = time.perf_counter()
+    G.apply(G.ConstPointFunctions.shadow(), dev)
+    t1 = time.perf_counter()
+    G.apply(G.ConstPointFunctions.shadow(), host)
+    t2 = time.perf_counter()
+    print(f"apply(shadow) on a 512x384 cache: {1e3 * (t1 - t0):.2f} ms in HBM, {1e3 * (t2 - t1):.2f} ms from the host")
+
+
 def test_kernels_agree_bitwise(G, ens):
     """Wave-ballot refill must not change any ray: persistent == one-ray-per-lane, bit for bit."""
     m = G.KerrMetric(1.0, 0.998)
