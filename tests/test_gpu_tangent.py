@@ -145,3 +145,37 @@ def test_device_transfer_functions_satisfy_the_normalisation_identity(G, ens, an
     phi = np.arcsin(np.sqrt(gs))
     total = np.sum(0.5 * (y + np.roll(y, -1)) * 2.0 * np.abs(np.roll(phi, -1) - phi))
     assert total == pytest.approx(dA / (math.pi * re), rel=rel)
+
+
+def test_thick_disc_transfer_function_satisfies_the_normalisation_identity(G, ens):
+    """The second recorded case of test/transfer-functions/test-thick-disc.jl (a = 0.2, 20°, ShakuraSunyaev at Ṁ = 0.2,
+    rₑ = 5.47): Σf on the device is 21.4028 at every tolerance, 0.83 % below the recorded 21.5814 -- yet the transfer
+    function is correctly normalised: ∮ (f/g) 2 dφ equals (1/π rₑ) dA/drₑ, with A(rₑ) the area enclosed by the image of the
+    ring ρ = rₑ ON THE DISC'S SURFACE (offsets against datumplane(d, rₑ)), to 2e-4 with 114 samples and 2e-5 with 434."""
+    from gradus_jl_amd import transfer_functions as TF
+
+    m = G.KerrMetric(1.0, 0.2)
+    x = np.array([0.0, 10_000.0, math.radians(20), 0.0])
+    d = G.ShakuraSunyaev.for_metric(m, eddington_ratio=0.2)
+    r_e = 5.469668466100368
+    datum = TF.device_tracer(m, x, 2 * x[1], G.chart_for_metric(m, 2 * x[1]), G.ConstPointFunctions.redshift(m, x), ens)
+    th = np.linspace(0.0, 2 * math.pi, 1441)[:-1]
+
+    def area(r):
+        h = float(d.cross_section(float(r)))
+        rr = TF.find_offsets_for_radius(datum, np.full(th.size, r), th, r_min=m.inner_radius(), β0=2.0, heights=np.full(th.size, h))[0]
+        return 0.5 * np.sum(rr * rr) * (th[1] - th[0])
+
+    dA = (area(r_e + 1e-3) - area(r_e - 1e-3)) / 2e-3
+    for N, rel in ((80, 5e-4), (400, 1e-4)):
+        c = G.cunningham_transfer_function(m, x, d, r_e, β0=2.0, ensemble=ens, N=N)
+        assert np.all(np.isfinite(c.f))
+        gs = np.clip(c.g_star, 0.0, 1.0)
+        y = c.f / (c.gmin + gs * (c.gmax - c.gmin))
+        for k in np.flatnonzero(c.f == 0.0):
+            y[k] = 0.5 * (y[k - 1] + y[(k + 1) % y.size])
+        phi = np.arcsin(np.sqrt(gs))
+        total = np.sum(0.5 * (y + np.roll(y, -1)) * 2.0 * np.abs(np.roll(phi, -1) - phi))
+        assert total == pytest.approx(dA / (math.pi * r_e), rel=rel), N
+        if N == 80:
+            assert float(np.nansum(c.f)) == pytest.approx(21.4028, abs=2e-3)
