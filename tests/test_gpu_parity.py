@@ -494,6 +494,30 @@ def test_separable_polar_plane_equals_explicit_rays(G, ens, monkeypatch, shape):
     np.testing.assert_allclose(out["1"][0], out["1"][1], rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("shape", [(8, 8), (5, 30), (257, 513)])
+def test_separable_rays_across_kernels_and_precisions(G, ens, monkeypatch, shape):
+    """Separable against explicit ray sets for a one-tile plane, an untiled one (fewer than 8 radii) and a ragged one, at a
+    tight tolerance (one ray per lane) and a loose one (persistent kernel with refill), fp64 and fp32: the same rays, so the
+    same number of integration steps and the same profile."""
+    m = G.KerrMetric(1.0, 0.998)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    d = G.ThinDisc(m.isco(), 250.0)
+    bins = np.linspace(0.1, 1.5, 180)
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=shape[0], Nθ=shape[1], r_min=1.0, r_max=250.0)
+    for tol in (1e-9, 1e-4):
+        for prec in (64, 32):
+            ens.set("precision", prec)
+            out = {}
+            for sep in ("1", "0"):
+                monkeypatch.setenv("GRADUS_MI355X_SEPARABLE_RAYS", sep)
+                _, y, st = G.lineprofile(bins, G.PowerLawEmissivity(3), m, u, d, G.BinningMethod(), plane=plane, maxrₑ=250.0,
+                                         ensemble=ens, stats=True, abstol=tol, reltol=tol)
+                out[sep] = (y, st)
+            assert out["1"][1]["rays"] == shape[0] * shape[1]
+            assert out["1"][1]["accepted_steps"] == out["0"][1]["accepted_steps"], (tol, prec)
+            np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-9 if prec == 64 else 1e-4, atol=1e-12)
+
+
 def test_lineprofile_with_an_emissivity_profile_is_fused(G, ens, monkeypatch):
     """lineprofile(bins, prof::RadialDiscProfile, m, u, d, BinningMethod()): the profile's table is interpolated on the
     device (emissivity_at: clamp to the table's range + NaNLinearInterpolator, src/corona/radial.jl:15-18,
