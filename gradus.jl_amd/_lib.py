@@ -38,6 +38,7 @@ def kernel_source_sha16() -> str:
 
 
 GR_OK = 0
+ABI_VERSION = 5      # GR_ABI_VERSION of include/gradus_mi355x.h this module mirrors (checked in load() and tests/test_host_api.py)
 ERROR_NAMES = {
     -1: "GR_ERR_INVALID_ARGUMENT",
     -2: "GR_ERR_UNSUPPORTED",
@@ -161,7 +162,8 @@ class gr_stats(C.Structure):
         ("rhs_evals", C.c_int64),
         ("flagged_rays", C.c_int64),
         ("status_count", C.c_int64 * 4),
-        ("kernel_ms", C.c_double),
+        ("kernel_ms", C.c_double),     # host variants: start of the call's device work -> end of its last trace kernel
+        ("call_ms", C.c_double),       # ... -> end of the last copy into the caller's buffer (ABI 5)
     ]
 
     def asdict(self):
@@ -173,6 +175,7 @@ class gr_stats(C.Structure):
             "flagged_rays": self.flagged_rays,
             "status_count": list(self.status_count),
             "kernel_ms": self.kernel_ms,
+            "call_ms": self.call_ms,
         }
 
 
@@ -199,6 +202,8 @@ EXPORTS = [
     "gr_ctx_create",
     "gr_ctx_destroy",
     "gr_ctx_set",
+    "gr_host_alloc",
+    "gr_host_free",
     "gr_render_device",
     "gr_render",
     "gr_render_multi",
@@ -237,10 +242,16 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.gr_abi_version.restype = i32
+    # the structs below are laid out for ONE version of include/gradus_mi355x.h: a library of another version (an older
+    # build named by GRADUS_MI355X_LIB, a variant of scripts/build_variant.sh) would read them wrongly without any error
+    if L.gr_abi_version() != ABI_VERSION:
+        raise GradusMI355XError(-1, f"{LIB_PATH} has ABI version {L.gr_abi_version()}, this binding is written for {ABI_VERSION}")
     L.gr_last_error.restype = C.c_char_p
     L.gr_ctx_create.argtypes = [i32, C.POINTER(vp)]
     L.gr_ctx_destroy.argtypes = [vp]
     L.gr_ctx_set.argtypes = [vp, C.c_char_p, i64]
+    L.gr_host_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+    L.gr_host_free.argtypes = [vp, vp]
     cfgp, plp, pfp, rgp, stp = (C.POINTER(t) for t in (gr_config, gr_plane, gr_pointfunction, gr_range, gr_stats))
     L.gr_render_device.argtypes = [vp, cfgp, plp, pfp, rgp, vp, vp, vp]
     L.gr_render.argtypes = [vp, cfgp, plp, pfp, rgp, vp, stp]

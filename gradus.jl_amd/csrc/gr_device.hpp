@@ -129,6 +129,20 @@ GR_DEV real rcp_full(real x)
     return r;
 }
 GR_DEV real rcp_raw(real x) { return GR_RCP_SEED(x); }
+GR_DEV real rcp_fast(real x);
+// The reciprocal inside the fused right-hand sides: 1 = seed + one Newton step (2e-15 relative, the rounding level of the ~85
+// operations it feeds), 2 = two steps (<= 1 ulp).
+#ifndef GR_RHS_RCP_STEPS
+#define GR_RHS_RCP_STEPS 1
+#endif
+GR_DEV real rcp_rhs(real x)
+{
+#if GR_RHS_RCP_STEPS == 1
+    return rcp_fast(x);
+#else
+    return rcp_full(x);
+#endif
+}
 GR_DEV real rcp_fast(real x)
 {
     // one Newton step: ~2e-15 relative
@@ -152,6 +166,27 @@ GR_DEV real sqrt_fast(real x)
     return GR_FMA(d, hh, g);
 }
 GR_DEV int sgn(real x) { return (x > 0.0) - (x < 0.0); }
+// max(|a|, |b|) as ONE instruction.  fmax(fabs(a), fabs(b)) compiles to three under IEEE mode (each fabs is made canonical by
+// its own v_max x, |a|, |a| before the real maximum): 15 of the step's FP64 instructions were such canonicalisations (error
+// norm scales, the event pre-filter's max |A^θ|).  The source modifiers of v_max_f64 take the absolute values for free and the
+// instruction's NaN behaviour is fmax's (the other operand is returned).
+#if defined(GR_HOST_HARNESS) || defined(GR_REAL_IS_TAN2)
+GR_DEV real absmax(real a, real b) { return GR_FMAX(GR_FABS(a), GR_FABS(b)); }
+#elif defined(GR_REAL_IS_FLOAT)
+GR_DEV real absmax(real a, real b)
+{
+    real r;
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+GR_DEV real absmax(real a, real b)
+{
+    real r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
 GR_DEV void gr_atomic_add(double* p, double v)
 {
 #ifdef GR_HOST_HARNESS
@@ -210,16 +245,46 @@ GR_DEV void sincos_fast(real x, real& s_out, real& c_out)
 // hh_wave_stats) and needs two three-term polynomials (truncation 2.5e-18 / 2.3e-17, below half an ulp) and four
 // FMAs: no range reduction, no quadrant logic.  Larger δ takes the full evaluation.
 constexpr creal SINCOS_ROT_MAX = 0.03125;
-GR_DEV void sincos_rot(real th0, real s0, real c0, real th, real& s_out, real& c_out)
+// The two polynomials each open with an FMA that has TWO constant operands, and a VALU instruction of this ISA reads at
+// most one scalar / literal operand: the other constant has to sit in a vector register.  Left to itself the compiler
+// rebuilds both (v_mov_b32 pairs + a copy) at each of the six stage points of a step -- 36 of the step's ~130 non-FP64
+// vector instructions.  RotK keeps the two addends in registers for the life of the ray (4 VGPRs), made opaque once in
+// Ray::init so that they are not rematerialised.
+#ifndef GR_ROT_MODE
+#define GR_ROT_MODE 0
+#endif
+struct RotK {
+    real s2, c2;      // 1/120, 1/24 (GR_ROT_MODE 1 only)
+    GR_DEV void load()
+    {
+        s2 = 8.3333333333333333e-03;
+        c2 = 4.1666666666666664e-02;
+#if GR_ROT_MODE == 1 && !defined(GR_HOST_HARNESS) && !defined(GR_REAL_IS_TAN2)
+        asm volatile("" : "+v"(s2), "+v"(c2));
+#endif
+    }
+};
+GR_DEV void sincos_rot(const RotK& k, real th0, real s0, real c0, real th, real& s_out, real& c_out)
 {
     const real d = th - th0;
     if (GR_FABS(d) <= SINCOS_ROT_MAX) {
         const real z = d * d;
-        real ps = GR_FMA(z, -1.9841269841269841e-04, 8.3333333333333333e-03);
+#if GR_ROT_MODE == 2
+        // every FMA with ONE non-inline constant (the second operand is 1.0 or -0.5, which the ISA encodes inline):
+        //   sin δ = δ + δ z S1 (1 + z (S2/S1) (1 + z S3/S2)),   cos δ - 1 = z (-1/2 + z C2 (1 + z C3/C2))
+        // three multiplications more than Horner's form, six register moves fewer per stage point
+        const real u1 = GR_FMA(z, -2.3809523809523808e-02, 1.0);          // S3/S2 = -1/42
+        const real u3 = GR_FMA(z * u1, -5.0e-02, 1.0);                    // S2/S1 = -1/20
+        const real sd = GR_FMA((d * z) * u3, -1.6666666666666666e-01, d); // sin δ
+        const real t1 = GR_FMA(z, -3.3333333333333333e-02, 1.0);          // C3/C2 = -1/30
+        const real pc = GR_FMA(z * t1, 4.1666666666666664e-02, -0.5);
+#else
+        real ps = GR_FMA(z, -1.9841269841269841e-04, k.s2);
         ps = GR_FMA(z, ps, -1.6666666666666666e-01);
         const real sd = GR_FMA(d * z, ps, d);                    // sin δ
-        real pc = GR_FMA(z, -1.3888888888888889e-03, 4.1666666666666664e-02);
+        real pc = GR_FMA(z, -1.3888888888888889e-03, k.c2);
         pc = GR_FMA(z, pc, -0.5);
+#endif
         const real cm1 = z * pc;                                        // cos δ - 1
         s_out = GR_FMA(c0, sd, GR_FMA(s0, cm1, s0));
         c_out = GR_FMA(-s0, sd, GR_FMA(c0, cm1, c0));
@@ -388,7 +453,7 @@ struct KerrFamily {
         real Del = GR_FMA(-tM, r, r2) + a2;
         if (CHARGED) Del += Q2;
         const real Ds2 = Del * s2;
-        const real P = rcp_full(Sig * Ds2);
+        const real P = rcp_rhs(Sig * Ds2);
         const real iSig = P * Ds2;           // 1/Σ
         const real iDs = P * Sig;            // 1/(Δ sin²θ)
         const real iDel = iDs * s2;          // 1/Δ
@@ -1239,7 +1304,20 @@ struct Params {
     int32_t maxiters32;       // cfg.maxiters clamped to int32: the per-step test is one 32-bit compare
     double wedge;             // asin(gtol) with a hair of slack: |θ - π/2| beyond it cannot hit the disc
     double dtmax;             // |λ1 - λ0|, formed once on the host instead of once per step per lane
+    int32_t tangent_norm;     // tangent build only: 1 = the error norm runs over values AND tangents (gr_ctx_set "tangent_norm")
+    int32_t _pad_tn;
 };
+
+// the derived fields of Params, from cfg (host side; one place for the library and the two host harnesses)
+static inline void derive_params(Params& p)
+{
+    const double g = p.cfg.gtol < 1.0 ? p.cfg.gtol : 1.0;
+    p.wedge = ::asin(g) * (1.0 + 1e-9) + 1e-12;
+    const double span = p.cfg.lambda1 - p.cfg.lambda0;
+    p.dtmax = span < 0.0 ? -span : span;
+    int64_t mi = p.cfg.maxiters < 0 ? 0 : p.cfg.maxiters;
+    p.maxiters32 = (int32_t)(mi > 0x7fffffff ? 0x7fffffff : mi);
+}
 
 // Small read-mostly tables staged in LDS by the kernel prologue (null = use the global copy):
 // the PlungingInterpolation table of the non-Kerr redshift and the per-workgroup private copy of
@@ -1405,6 +1483,7 @@ struct Ray {
     real t, dt, h;    // affine time, proposed step, last used step
     real cprev;       // disc condition at x
     real sth, cth;    // sin θ, cos θ at x (base of the stage rotations)
+    RotK rotk;        // register-resident constants of the stage rotations
 #ifdef GR_CONTROLLER_F64
     double lq_old;      // log2(qold)
 #else
@@ -1636,6 +1715,7 @@ struct Ray {
         j = jl;
         status = GR_STATUS_NO_STATUS;
         flags = 0; nacc = 0; nrej = 0; ev_top = 0;
+        rotk.load();
         constrained_u0(m, p, jl, x, v);
         t = p.cfg.lambda0;
         h = 0.0;
@@ -1750,7 +1830,7 @@ struct Ray {
             rs = GR_FMA(h2, ar, rs);                                                           \
             ts = GR_FMA(h2, at, ts);                                                           \
         }                                                                                             \
-        sincos_rot(x[2], sth, cth, ts, s, c);                                                         \
+        sincos_rot(rotk, x[2], sth, cth, ts, s, c);                                                   \
         GR_DBG_BIT((GR_FABS(ts - x[2]) <= SINCOS_ROT_MAX) ? 0 : (1 << S));                                    \
         GR_DBG_DMAX(GR_FABS(ts - x[2]));                                                              \
         geodesic_rhs_sc(m, rs, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
@@ -1781,7 +1861,7 @@ struct Ray {
 #ifndef GR_NO_ROT_FINAL
         GR_DBG_DMAX(GR_FABS(xn[2] - x[2]));
         if ((nacc & 63) == 63) sincos_fast(xn[2], sn, cn);
-        else sincos_rot(x[2], sth, cth, xn[2], sn, cn);
+        else sincos_rot(rotk, x[2], sth, cth, xn[2], sn, cn);
         geodesic_rhs_sc(m, xn[1], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);
 #else
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);
@@ -1798,6 +1878,9 @@ struct Ray {
         // 4.3e-11 with it, 1.0e-10 without (tests/test_gpu_baseline_configs.py).
         const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
         real e2 = 0.0;
+#ifdef GR_REAL_IS_TAN2
+        double e2n = 0.0;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             real ev = Ts::BT[0] * A[0][i];
@@ -1807,8 +1890,24 @@ struct Ray {
 #pragma unroll
             for (int q = 1; q < 6; ++q) ex = GR_FMA(TsD::X.BTX[q], A[q][i], ex);
             ex = GR_FMA(hh, ex, TsD::X.SBT * v[i]);
-            const real skv = GR_FMA(GR_FMAX(GR_FABS(v[i]), GR_FABS(vn[i])), reltol, abstol);
-            const real skx = GR_FMA(GR_FMAX(GR_FABS(x[i]), GR_FABS(xn[i])), reltol, abstol);
+#ifdef GR_REAL_IS_TAN2
+            if (p.tangent_norm) {
+                // The reference integrates Dual state through OrdinaryDiffEq (precision-solvers.jl:73-131,401-451) and
+                // DiffEqBase's ForwardDiff extension (third party; as published) lets the partials into the controller:
+                //   internalnorm(u::Dual) = sqrt(value² + Σ partials²),   internalnorm(array) = sqrt(Σ sse / (N (1 + P))),
+                // so the residual of component i is ũ_i / (abstol + reltol max(|u0_i|_D, |u1_i|_D)) as a Dual and EEst² is
+                // the mean over all 8 x 3 entries.  Steps shorten where the tangents are the stiffer part.
+                const double nv0 = ::sqrt(v[i].v * v[i].v + v[i].a * v[i].a + v[i].b * v[i].b);
+                const double nv1 = ::sqrt(vn[i].v * vn[i].v + vn[i].a * vn[i].a + vn[i].b * vn[i].b);
+                const double nx0 = ::sqrt(x[i].v * x[i].v + x[i].a * x[i].a + x[i].b * x[i].b);
+                const double nx1 = ::sqrt(xn[i].v * xn[i].v + xn[i].a * xn[i].a + xn[i].b * xn[i].b);
+                const double sv = abstol.v + reltol.v * (nv0 > nv1 ? nv0 : nv1), sx = abstol.v + reltol.v * (nx0 > nx1 ? nx0 : nx1);
+                e2n += (ev.v * ev.v + ev.a * ev.a + ev.b * ev.b) / (sv * sv) + (ex.v * ex.v + ex.a * ex.a + ex.b * ex.b) / (sx * sx);
+                continue;
+            }
+#endif
+            const real skv = GR_FMA(absmax(v[i], vn[i]), reltol, abstol);
+            const real skx = GR_FMA(absmax(x[i], xn[i]), reltol, abstol);
             // the bare v_rcp_f64 seed is good to 4.6e-8 (measured, scripts/rcp_accuracy.hip): ample for
             // a quantity that only feeds the step-size controller and the accept test
             const real av = ev * rcp_raw(skv);
@@ -1816,6 +1915,9 @@ struct Ray {
             e2 = GR_FMA(av, av, e2);
             e2 = GR_FMA(ax, ax, e2);
         }
+#ifdef GR_REAL_IS_TAN2
+        if (p.tangent_norm) e2 = real(e2n * (1.0 / 3.0));
+#endif
         e2 *= 0.125 * h2;   // EEst² ; accept iff EEst <= 1
 #ifdef GR_HOST_HARNESS
         dbg_e2 = e2;
@@ -1841,21 +1943,27 @@ struct Ray {
 #endif
         const ctl_t lE = (ctl_t)0.5 * GR_CTL_LOG2(e2);       // log2(EEst); -inf when e2 underflows
         if (e2 <= 1.0) {
-            ctl_t qf = GR_CTL_EXP2((ctl_t)PI_BETA1 * lE - (ctl_t)PI_BETA2 * (ctl_t)lq_old) * (ctl_t)(1.0 / PI_GAMMA);
-            qf = GR_CTL_MAX((ctl_t)(1.0 / PI_QMAX), GR_CTL_MIN((ctl_t)(1.0 / PI_QMIN), qf));   // e2 == 0 -> 1/qmax
+            // dt_next = dt / q with q = clamp(EEst^β1 / qold^β2 / γ, 1/qmax, 1/qmin): formed directly as the growth factor
+            // 1/q = clamp(γ 2^(β2 log2 qold - β1 log2 EEst), qmin, qmax), so the accepted step needs no reciprocal
+            // (round 2 clamped q and then divided: one v_rcp_f64, four Newton FMAs and a conversion more per step)
+            ctl_t gf = GR_CTL_EXP2((ctl_t)PI_BETA2 * (ctl_t)lq_old - (ctl_t)PI_BETA1 * lE) * (ctl_t)PI_GAMMA;
+            gf = GR_CTL_MIN((ctl_t)PI_QMAX, GR_CTL_MAX((ctl_t)PI_QMIN, gf));   // e2 == 0 -> lE = -inf -> qmax
             nacc++;
             lq_old = GR_CTL_MAX(lE, (ctl_t)LOG2_QOLDINIT);
-            const real dtnew = hh * rcp_full((real)qf);
+            const real dtnew = hh * (real)gf;
             real tnew = t + hh;
             if (GR_FABS(tnew - tend) < 100.0 * GR_EPS * GR_FMAX(GR_FABS(tnew), GR_FABS(tend))) tnew = tend;
 
             if (DISC) {
                 const real cnext = disc_cond4(p, xn[1], sn, cn, xn[3]);
-                const int ps = sgn(cprev);
+                // prev = sign(c(u_prev)), event at the step's end iff prev != 0 and prev * sign(c(u_new)) <= 0 (a NaN
+                // condition has sign 0 and counts as a crossing): four comparisons, no integer sign arithmetic
+                const bool pos = cprev > 0.0, neg = cprev < 0.0;
                 int top = 0;
-                if (ps != 0) {
-                    if (ps * sgn(cnext) <= 0) top = 7;
-                    else top = sample_event(p, ps, hh);
+                if (pos || neg) {
+                    const bool crossed = pos ? !(cnext > 0.0) : !(cnext < 0.0);
+                    if (crossed) top = 7;
+                    else top = sample_event(p, pos ? 1 : -1, hh);
                 }
                 if (top) {
                     // leave (x, v, A, h) in place; finalize() root-finds on the dense output
@@ -1931,9 +2039,9 @@ struct Ray {
         constexpr bool thin = (DISC == GR_DISC_THIN);
         if (thin && ps > 0) {
             // |θ(Θ_j) - θ_0| <= h (Θ_j |v^θ| + h Σ_i |RXΣ_i(Θ_j)| |A_i^θ|) <= h (|v^θ| + K h max_i |A_i^θ|)
-            real amax = GR_FABS(A[0][2]);
+            real amax = absmax(A[0][2], A[1][2]);
 #pragma unroll
-            for (int i = 1; i < 6; ++i) amax = GR_FMAX(amax, GR_FABS(A[i][2]));
+            for (int i = 2; i < 6; ++i) amax = absmax(amax, A[i][2]);
             const real reach = hh * (GR_FABS(v[2]) * DENSE_K1 + DENSE_K2 * hh * amax);
             // distance of θ from the equatorial plane (mod π) is asin|cosθ| >= |cosθ|, and cosθ of the step's base
             // is at hand: |cosθ| - reach > wedge rules every sample out

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -112,6 +113,9 @@ struct gr_ctx {
     int64_t lds = 1;                       // stage the plunging table / line-profile histogram in LDS
     int64_t lpt = 1;                       // longest-first tile order learned from the previous render
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_k = nullptr;             // end of the last trace kernel of a host call (gr_stats.kernel_ms vs call_ms)
+    int64_t hugepages = 1;                 // madvise(MADV_HUGEPAGE) on large caller-owned result buffers before pre-faulting
+    int64_t tangent_norm = 0;              // tangent kernels: fold the tangents into the error norm (DiffEqBase on Dual state)
     // LPT state for one (config, plane, range) key
     std::vector<unsigned char> lpt_key;
     uint32_t* d_tile_cost = nullptr;
@@ -343,8 +347,10 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
         if (trc != GR_OK) return trc;
     }
     p.refill_threshold = (int32_t)ctx->refill_threshold;
-    const int kern_sel = resolve_kernel(ctx, p.n, cold);
-    const int block_sel = resolve_block(ctx, kern_sel);
+    // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
+    const bool tangent = cold.out_mode == 5;
+    const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold);
+    const int block_sel = tangent ? 64 : resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
     // A table is staged per workgroup: with one-wave workgroups a CU holds 8 copies, so it is staged
     // only while those fit the 160 KB of LDS without capping the occupancy (<= 640 rows of 32 B).
@@ -355,18 +361,16 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
                          && cold_in.pf.n_plunge > 0
                          && cold_in.pf.n_plunge <= lds_rows_max) ? (int32_t)cold_in.pf.n_plunge : 0;
     p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
-    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
-    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
+    derive_params(p);
     LaunchKnobs knobs{ kern_sel, block_sel, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
     ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
     // validate_cfg() has pinned metric_id to [GR_METRIC_KERR, GR_METRIC_NOZ]
-    const bool tangent = cold.out_mode == 5;
     const trace_fn fn = (tangent ? kTraceTan : ctx->precision == 32 ? kTrace32 : kTrace64)[p.cfg.metric_id];
-    if (tangent) { knobs.kernel = 0; knobs.block = 64; }      // the tangent objects carry the one-ray-per-lane kernel only
+    p.tangent_norm = (tangent && ctx->tangent_norm) ? 1 : 0;
     const hipError_t le = fn(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
     if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    if (stream == ctx->stream) GR_HIP(hipEventRecord(ctx->ev_k, stream));      // host variants: where the kernel ends
     if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0) {
         const int32_t trc = tables_release(ctx, stream);
         if (trc != GR_OK) return trc;
@@ -486,7 +490,7 @@ int32_t gr_ctx_create(int32_t device, gr_ctx** out)
         if (hipMalloc((void**)&c->d_queue, sizeof(unsigned long long) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"); break; }
         if (hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * N_STAT) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(stats) failed"); break; }
         if (hipMalloc((void**)&c->d_cold, sizeof(Cold) * c->queue_slots) != hipSuccess) { rc = fail(GR_ERR_OUT_OF_MEMORY, "hipMalloc(cold) failed"); break; }
-        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_k) != hipSuccess
             || hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming) != hipSuccess
             || hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming) != hipSuccess) { rc = fail(GR_ERR_HIP, "hipEventCreate failed"); break; }
     } while (0);
@@ -517,6 +521,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_k) (void)hipEventDestroy(c->ev_k);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (hipEvent_t e : c->ev_band)
         if (e) (void)hipEventDestroy(e);
@@ -560,10 +565,63 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         if (value < 0 || value > 2) return fail(GR_ERR_INVALID_ARGUMENT, "lpt must be 0 (off), 1 (auto) or 2 (always)");
         c->lpt = value;
         c->lpt_key.clear();
+    } else if (k == "hugepages") {
+        c->hugepages = value ? 1 : 0;
+    } else if (k == "tangent_norm") {
+        c->tangent_norm = value ? 1 : 0;
     } else {
         return fail(GR_ERR_INVALID_ARGUMENT, "unknown knob '" + k + "'");
     }
     return GR_OK;
+}
+
+// Pinned result blocks are registered process-wide, not per context: the caller's array (a Julia Vector with a finalizer)
+// may outlive the context that allocated it, and finalizers run in no particular order.
+namespace {
+std::mutex g_pinned_mutex;
+std::vector<std::pair<void*, size_t>> g_pinned;
+}  // namespace
+
+int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out)
+{
+    if (!ctx || !out) return fail(GR_ERR_INVALID_ARGUMENT, "ctx/out is null");
+    *out = nullptr;
+    if (bytes < 0) return fail(GR_ERR_INVALID_ARGUMENT, "bytes must be non-negative");
+    GR_HIP(hipSetDevice(ctx->device));
+    void* p = nullptr;
+    // page-locked and mapped for every device (hipHostMallocPortable): a multi-device render may copy into one block
+    GR_HIP(hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocPortable));
+    try {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        g_pinned.emplace_back(p, (size_t)(bytes > 0 ? bytes : 1));
+    } catch (...) {
+        (void)hipHostFree(p);
+        return fail(GR_ERR_OUT_OF_MEMORY, "gr_host_alloc: registry");
+    }
+    *out = p;
+    return GR_OK;
+}
+
+int32_t gr_host_free(gr_ctx* /* may be NULL or already destroyed: not dereferenced */, void* p)
+{
+    if (!p) return GR_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const std::pair<void*, size_t>& q) { return q.first == p; });
+        if (it == g_pinned.end()) return fail(GR_ERR_INVALID_ARGUMENT, "pointer was not allocated by gr_host_alloc");
+        g_pinned.erase(it);
+    }
+    GR_HIP(hipHostFree(p));      // waits for work that still targets the block
+    return GR_OK;
+}
+
+// a result buffer the library pinned itself: no page faults to prepare, no huge-page advice to give
+static bool is_pinned(const gr_ctx*, const void* p)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (const auto& q : g_pinned)
+        if ((const char*)p >= (const char*)q.first && (const char*)p < (const char*)q.first + q.second) return true;
+    return false;
 }
 
 int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,
@@ -660,7 +718,7 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     return GR_OK;
 }
 
-static void prefault_output(void* dst, size_t bytes);
+static void prefault_output(void* dst, size_t bytes, bool huge);
 
 int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64_t x_stride, const double* v, int64_t n,
                        int64_t cap, double* path, int64_t* n_rows, gr_point* endpoints)
@@ -690,9 +748,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     std::memset(&cd, 0, sizeof cd);
     p.cfg = *cfg;
     p.n = n;
-    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
-    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
+    derive_params(p);
     cd.src_mode = 1;
     cd.out_mode = 1;
     cd.winding_plane = p.cfg.winding_plane;
@@ -710,7 +766,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     GR_HIP(hipGetLastError());
     if ((p.disc_table || p.chart_table) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters are copied as int64");
-    prefault_output(path, path_bytes);          // while the kernel runs (the path buffer of 16 384 geodesics is 600 MB)
+    if (!is_pinned(ctx, path)) prefault_output(path, path_bytes, ctx->hugepages != 0);          // while the kernel runs (the path buffer of 16 384 geodesics is 600 MB)
     GR_HIP(hipMemcpyAsync(n_rows, d_n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     GR_HIP(hipMemcpyAsync(path, d_path, path_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (endpoints) GR_HIP(hipMemcpyAsync(endpoints, d_pt, pt_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -888,11 +944,12 @@ int32_t gr_rayset_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_r
 // allocated destination -- numpy's `empty`, Julia's `Vector{GeodesicPoint}(undef, n)` -- is not backed by pages yet, and
 // taking those faults inside the device-to-host copy costs as much again as the copy (637 MB of end points at 2048²:
 // 35 ms into touched memory, 60 ms into fresh memory); taken here they overlap the kernel that is already running.
-static void prefault_output(void* dst, size_t bytes)
+static void prefault_output(void* dst, size_t bytes, bool huge)
 {
     if (bytes < ((size_t)64 << 20)) return;
-    {   // ask for transparent huge pages on the 2 MB-aligned interior: 300 faults instead of 155 000 for 637 MB
-        // (measured on the GPU box, THP mode "madvise": 10.7 ms instead of 27-64 ms with 8 threads; errors are ignored)
+    if (huge) {   // ask for transparent huge pages on the 2 MB-aligned interior: 300 faults instead of 155 000 for 637 MB
+        // (measured on the GPU box, THP mode "madvise": 10.7 ms instead of 27-64 ms with 8 threads; errors are ignored;
+        // gr_ctx_set(ctx, "hugepages", 0) leaves the caller's mapping alone)
         const size_t two = (size_t)2 << 20;
         const size_t a0 = ((size_t)dst + two - 1) / two * two, a1 = ((size_t)dst + bytes) / two * two;
         if (a1 > a0) (void)madvise((void*)a0, a1 - a0, MADV_HUGEPAGE);
@@ -902,44 +959,54 @@ static void prefault_output(void* dst, size_t bytes)
     const size_t page = 4096;
     char* base = (char*)dst;
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([=]() {
-            // every thread sweeps front to back (pages t, t + nt, ...): the first band's pages are ready first
-            for (size_t off = (size_t)t * page; off < bytes; off += (size_t)nt * page) ((volatile char*)base)[off] = 0;
-        });
+    // thread creation can throw (std::system_error: out of threads) and nothing may unwind through the C ABI: pre-faulting
+    // is an optimisation, so whatever threads exist do their stripes and the copy faults the rest in itself
+    try {
+        th.reserve(nt);
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([=]() {
+                // every thread sweeps front to back (pages t, t + nt, ...): the first band's pages are ready first
+                for (size_t off = (size_t)t * page; off < bytes; off += (size_t)nt * page) ((volatile char*)base)[off] = 0;
+            });
+    } catch (...) {
+    }
     for (auto& x : th) x.join();
 }
-
-// The same sweep in the background: `wait_until(off)` returns once every page below `off` has been touched, so that
-// the first band can travel while the pages of the later ones are still being faulted in.
 struct BackgroundPrefault {
     static constexpr unsigned kMax = 8;
     std::atomic<size_t> progress[kMax];
     std::vector<std::thread> th;
     unsigned nt = 0;
     size_t bytes = 0;
-    void start(void* dst, size_t n)
+    void start(void* dst, size_t n, bool huge)
     {
         bytes = n;
         if (n < ((size_t)64 << 20)) return;
         const size_t two = (size_t)2 << 20;
         const size_t a0 = ((size_t)dst + two - 1) / two * two, a1 = ((size_t)dst + n) / two * two;
-        if (a1 > a0) (void)madvise((void*)a0, a1 - a0, MADV_HUGEPAGE);
-        nt = std::thread::hardware_concurrency();
-        nt = nt == 0 ? 4 : (nt > kMax ? kMax : nt);
+        if (huge && a1 > a0) (void)madvise((void*)a0, a1 - a0, MADV_HUGEPAGE);
+        unsigned want = std::thread::hardware_concurrency();
+        want = want == 0 ? 4 : (want > kMax ? kMax : want);
         char* base = (char*)dst;
-        const unsigned n_threads = nt;
-        for (unsigned t = 0; t < nt; ++t) {
-            progress[t].store(0, std::memory_order_relaxed);
-            th.emplace_back([this, base, n, t, n_threads]() {
-                const size_t page = 4096;
-                size_t since = 0;
-                for (size_t off = (size_t)t * page; off < n; off += (size_t)n_threads * page) {
-                    ((volatile char*)base)[off] = 0;
-                    if (++since == 256) { progress[t].store(off, std::memory_order_release); since = 0; }
-                }
-                progress[t].store(n, std::memory_order_release);
-            });
+        const unsigned n_threads = want;
+        for (unsigned t = 0; t < kMax; ++t) progress[t].store(0, std::memory_order_relaxed);
+        // no exception may cross the C ABI: if a thread cannot be created, the ones that exist sweep their stripes and
+        // wait_until() waits for those only (nt counts the threads that really run)
+        try {
+            th.reserve(want);
+            for (unsigned t = 0; t < want; ++t) {
+                th.emplace_back([this, base, n, t, n_threads]() {
+                    const size_t page = 4096;
+                    size_t since = 0;
+                    for (size_t off = (size_t)t * page; off < n; off += (size_t)n_threads * page) {
+                        ((volatile char*)base)[off] = 0;
+                        if (++since == 256) { progress[t].store(off, std::memory_order_release); since = 0; }
+                    }
+                    progress[t].store(n, std::memory_order_release);
+                });
+                nt = t + 1;
+            }
+        } catch (...) {
         }
     }
     void wait_until(size_t off) const
@@ -980,6 +1047,7 @@ static int32_t begin_host_call(gr_ctx* ctx, gr_stats* stats)
     GR_HIP(hipSetDevice(ctx->device));
     if (stats) GR_HIP(hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * N_STAT, ctx->stream));
     GR_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    GR_HIP(hipEventRecord(ctx->ev_k, ctx->stream));      // re-recorded behind every trace kernel of the call (launch_trace)
     return GR_OK;
 }
 
@@ -993,8 +1061,10 @@ static int32_t end_host_call(gr_ctx* ctx, gr_stats* stats)
     if (stats) {
         stats_to_host(h, stats);
         float ms = 0.f;
+        GR_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_k));
+        stats->kernel_ms = ms;      // start of the call's device work -> end of its last trace kernel (input staging included)
         GR_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        stats->kernel_ms = ms;
+        stats->call_ms = ms;        // ... -> end of the last copy back to the caller's buffer
     }
     return GR_OK;
 }
@@ -1073,7 +1143,7 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     if (nb <= 1) {
         if ((rc = gr_render_endpoints_device(ctx, cfg, plane, range, (gr_point*)ctx->d_scratch,
                                              stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
-        prefault_output(points, bytes);
+        if (!is_pinned(ctx, points)) prefault_output(points, bytes, ctx->hugepages != 0);
         if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
         return end_host_call(ctx, stats);
     }
@@ -1094,14 +1164,31 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     ctx->lpt_suspend = false;
     if (rc != GR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     BackgroundPrefault pf;
-    pf.start(points, bytes);
-    for (int k = 0; k < used; ++k) {
+    if (!is_pinned(ctx, points)) pf.start(points, bytes, ctx->hugepages != 0);
+    hipError_t ce = hipSuccess;
+    const char* what = "";
+    for (int k = 0; k < used && ce == hipSuccess; ++k) {
         pf.wait_until(sizeof(gr_point) * (size_t)j0[k + 1]);
-        GR_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
-        GR_HIP(hipMemcpyAsync(points + j0[k], (gr_point*)ctx->d_scratch + j0[k], sizeof(gr_point) * (size_t)(j0[k + 1] - j0[k]),
-                              hipMemcpyDeviceToHost, ctx->copy_stream));
+        ce = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0);
+        what = "hipStreamWaitEvent";
+        if (ce != hipSuccess) break;
+        ce = hipMemcpyAsync(points + j0[k], (gr_point*)ctx->d_scratch + j0[k], sizeof(gr_point) * (size_t)(j0[k + 1] - j0[k]),
+                            hipMemcpyDeviceToHost, ctx->copy_stream);
+        what = "hipMemcpyAsync (band)";
     }
-    GR_HIP(hipStreamSynchronize(ctx->copy_stream));
+    if (ce != hipSuccess) {
+        // bands already queued are still writing into the caller's memory: nothing may be in flight when the call returns
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        return fail(GR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(ce));
+    }
+    {
+        const hipError_t se = hipStreamSynchronize(ctx->copy_stream);
+        if (se != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return fail(GR_ERR_HIP, std::string("hipStreamSynchronize(copy_stream): ") + hipGetErrorString(se));
+        }
+    }
     return end_host_call(ctx, stats);
 }
 
@@ -1127,7 +1214,7 @@ int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, i
     }
     if ((rc = gr_trace_endpoints_device(ctx, cfg, d_x, x_stride, d_v, n, (gr_point*)ctx->d_scratch,
                                         stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
-    prefault_output(points, out_bytes);
+    if (!is_pinned(ctx, points)) prefault_output(points, out_bytes, ctx->hugepages != 0);
     if (out_bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
 }
@@ -1289,7 +1376,7 @@ int32_t gr_rayset_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* 
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
     if ((rc = gr_rayset_endpoints_device(ctx, cfg, &dev, (gr_point*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
                                          ctx->stream)) != GR_OK) return rc;
-    prefault_output(points, bytes);
+    if (!is_pinned(ctx, points)) prefault_output(points, bytes, ctx->hugepages != 0);
     if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
 }

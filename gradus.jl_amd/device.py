@@ -4,6 +4,7 @@ compute is in libgradus_mi355x.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -21,7 +22,7 @@ def _stream_handle():
 def new_stats(device):
     import torch
 
-    return torch.zeros(10, dtype=torch.int64, device=device)   # gr_stats: 9 counters + kernel_ms slot
+    return torch.zeros(11, dtype=torch.int64, device=device)   # gr_stats: 9 counters + kernel_ms + call_ms slots
 
 
 def stats_dict(t):
@@ -79,10 +80,10 @@ def lineprofile_device(bins, ε, m, u, d, plane, *, shard=None, maxrₑ=50.0, mi
     Asynchronous on the current stream; the fused route: power laws and emissivity profiles (tables)."""
     import torch
 
-    from .lineprofiles import PowerLawEmissivity, _emissivity_table, _rayset
+    from .lineprofiles import PowerLawEmissivity, _emissivity_table
     from .planes import PolarPlane
     from .pointfunctions import ConstPointFunctions
-    from .tracing import domain_upper_hemisphere, tracing_configuration
+    from .tracing import domain_upper_hemisphere, separable_rayset, tracing_configuration
 
     table = None if isinstance(ε, PowerLawEmissivity) else _emissivity_table(ε)
     if not (isinstance(ε, PowerLawEmissivity) or table is not None) or not isinstance(plane, PolarPlane):
@@ -100,8 +101,11 @@ def lineprofile_device(bins, ε, m, u, d, plane, *, shard=None, maxrₑ=50.0, mi
     cfg = config.abi_config()
     ens = config.ensemble
     dev = torch.device("cuda", ens.device)
-    keep = []
-    rs, _ = _rayset(config, plane, keep)
+    # always the separable form here (three device-resident tables), whatever GRADUS_MI355X_SEPARABLE_RAYS says for
+    # the host route: the pointers set below are only meaningful for it
+    tiled = os.environ.get("GRADUS_MI355X_TILE_RAYS", "1") != "0" and plane.Nr >= 8 and plane.Nθ >= 8
+    rs, keep = separable_rayset(config.metric, config.position, plane, tiled)
+    rs._tiled = tiled
     # the three tables and the bin edges live in HBM for the launch (tiny: Nr + 2 Nθ + n_bins doubles)
     extra = [] if table is None else [table[0], table[1]]
     tabs = torch.from_numpy(np.concatenate([keep[0], keep[1], keep[2], bins] + extra)).to(dev)

@@ -249,6 +249,21 @@ def find_offsets_for_radius_newton_ad(trace, r_target, θ, *, r_min, α0=0.0, β
     previous = np.zeros((n, 6))
     failed = np.zeros(n, dtype=bool)
     active = np.abs(y) > zero_atol
+
+    def bracket(jc):
+        """Roots.find_zero(i -> step(i)[end], (contra, x), atol = zero_atol): bisection on the bracket, finished when
+        |y| <= zero_atol; then the reference re-evaluates `step(x)` -- the last midpoint's values here."""
+        lo_, hi_ = contra[jc].copy(), x[jc].copy()
+        mid, pm, dfm, ym = hi_, point[jc], df[jc], y[jc]
+        for _ in range(60):
+            mid = 0.5 * (lo_ + hi_)
+            pm, dfm, ym = step(jc, mid)
+            neg = ym < 0
+            lo_, hi_ = np.where(neg, mid, lo_), np.where(neg, hi_, mid)
+            if np.all(np.abs(ym) <= zero_atol):
+                break
+        x[jc], y[jc], df[jc], point[jc] = mid, ym, dfm, pm
+
     i = 0
     while active.any() and i <= max_iter:
         idx = all_idx[active]
@@ -264,30 +279,31 @@ def find_offsets_for_radius_newton_ad(trace, r_target, θ, *, r_min, α0=0.0, β
             p3, df3, y3 = step(jb, nb)
             next_x[bis], next_y[bis], df2[bis], p2[bis] = nb, y3, df3, p3
         with np.errstate(all="ignore"):
-            stop = (next_y < 0) & (y[idx] < 0) & ((-y[idx] / df[idx]) < 0)       # "Converge failed": the reference breaks here
+            # "Converge failed": `point, df, next_y = step(next_x)` has overwritten df by now (precision-solvers.jl:176-193),
+            # so the test reads the derivative at next_x -- after the bisection step where one was taken.  The loop breaks
+            # with x and y as they were and `point` the NEW one (the pair the reference returns if |y| passes worst_accuracy)
+            stop = (next_y < 0) & (y[idx] < 0) & ((-y[idx] / df2) < 0)
             next_Δy = (y[idx] - next_y) / y[idx]
-            cycle = (y[idx] > 0) & np.any(np.abs(previous[idx] - next_Δy[:, None]) <= zero_atol * 100, axis=1)
-        # a cycle is finished off by bracketing in the reference (Roots.find_zero on (contra, x)); bisection here
+            cycle = ~stop & (y[idx] > 0) & np.any(np.abs(previous[idx] - next_Δy[:, None]) <= zero_atol * 100, axis=1)
+        point[idx[stop]] = p2[stop]
+        df[idx[stop]] = df2[stop]
+        # a cycle is finished off by bracketing (Roots.find_zero on (contra, x)) and the loop is left
         if cycle.any():
-            jc = idx[cycle]
-            lo_, hi_ = contra[jc].copy(), x[jc].copy()
-            for _ in range(60):
-                mid = 0.5 * (lo_ + hi_)
-                pm, dfm, ym = step(jc, mid)
-                neg = ym < 0
-                lo_, hi_ = np.where(neg, mid, lo_), np.where(neg, hi_, mid)
-                if np.all(np.abs(ym) <= zero_atol):
-                    break
-            next_x[cycle], next_y[cycle], df2[cycle], p2[cycle] = mid, ym, dfm, pm
-        upd = ~stop
+            bracket(idx[cycle])
+        upd = ~stop & ~cycle
         ju = idx[upd]
         x[ju], y[ju], df[ju], Δy[ju] = next_x[upd], next_y[upd], df2[upd], next_Δy[upd]
         point[ju] = p2[upd]
         previous[ju, i % 6] = next_Δy[upd]
         failed[idx[stop]] = True
+        failed[idx[cycle]] = True          # left the loop: not iterated further
         active = (np.abs(y) > zero_atol) & ~failed
-        active[idx[cycle]] = False
         i += 1
+    if i >= max_iter:
+        # "Exceeded max iter": the problems still iterating are bracketed if they are far off (y > 10)
+        late = active & (y > 10.0)
+        if late.any():
+            bracket(all_idx[late])
     status = point[:, 7].astype(np.int32)
     ok = (x >= 0) & (np.abs(y) <= 1e-4 * r_target) & (status == StatusCodes.IntersectedWithGeometry)
     r = np.where(ok, x, np.nan)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GR_ABI_VERSION 4
+#define GR_ABI_VERSION 5
 
 typedef enum {
     GR_OK = 0,
@@ -206,7 +206,12 @@ typedef struct gr_stats {
     int64_t rhs_evals;
     int64_t flagged_rays;     /* rays with a GR_FLAG_* bit set                           */
     int64_t status_count[4];  /* histogram over StatusCodes                              */
-    double kernel_ms;         /* host variants only: device time of the trace kernel     */
+    /* host variants only (ABI 5 tells the two apart): device time from the start of the call's work on the context's
+     * stream to the end of its LAST TRACE KERNEL (staging of inputs and tables included) ...                            */
+    double kernel_ms;
+    /* ... and to the end of the last copy back into the caller's buffer: kernel_ms plus the D2H part.  The wall time
+     * of the blocking call is this plus the launch / synchronisation latency of the host side.                        */
+    double call_ms;
 } gr_stats;
 
 typedef struct gr_ctx gr_ctx;
@@ -222,8 +227,24 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * line profiles and caller-ordered ray arrays -> persistent); ("block", threads per workgroup,
  * 0 = auto [default]: 64 for kernel 0, 256 for kernel 1); ("refill_threshold", idle lanes that
  * trigger a refill, default 16); ("waves_per_simd"), ("swizzle"), ("lpt"), ("lpt_lane"), ("lds"),
- * ("precision", 64 | 32). */
+ * ("precision", 64 | 32); ("pipeline", bands of the end-point return); ("hugepages", 1 [default] = large caller-owned
+ * result buffers are madvise(MADV_HUGEPAGE)d before they are pre-faulted, 0 = the caller's mapping is left alone);
+ * ("tangent_norm", 1 = gr_ray_tangent's step-size controller sees values AND tangents -- DiffEqBase's norm on Dual state,
+ * what the reference's solves under ForwardDiff use (src/tracing/precision-solvers.jl:73-131,401-451) --, 0 [default] =
+ * values only: the tangents ride on the very steps of the plain trace). */
 int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
+
+/* ---- pinned result buffers (ABI 5).  The reference allocates the result of ensemble_solve_tracing_problem itself
+ * (`Vector{GeodesicPoint{T}}(undef, n)`, src/tracing/tracing.jl:179-183): pageable memory, which the D2H copy crosses at
+ * ~30 GB/s after its pages have been faulted in.  A binding that lets the LIBRARY allocate that block (page-locked, mapped
+ * for DMA once) and wraps it as its array -- Julia: unsafe_wrap(Array, Ptr{GeodesicPoint}(p), n) + a finalizer calling
+ * gr_host_free -- gets the copy at the link's rate and entirely under the trace of the later bands.  Any host entry point
+ * accepts such a pointer wherever it takes a caller-owned output buffer; callers that bring their own memory are served as
+ * before.  Blocks are registered process-wide: gr_host_free does not look at `ctx` (it may be NULL, or a context that has
+ * been destroyed meanwhile -- finalizers of a garbage-collected host language run in no particular order), and destroying a
+ * context does not free them.  gr_host_free(ctx, NULL) is a no-op. */
+int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out);
+int32_t gr_host_free(gr_ctx* ctx, void* p);
 
 /* ---- fused render: rendergeodesics / render_into_image! (rendering.jl:28-54,89-107) ----
  * image[j] (j local, see gr_range) = pf(m, trace(ray i), λ_max). */

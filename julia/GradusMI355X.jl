@@ -37,7 +37,7 @@ import SciMLBase
 export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, winding_numbers
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
-const ABI_VERSION = 4
+const ABI_VERSION = 5
 
 # ---------------------------------------------------------------------------------------------------------------
 # POD mirrors of include/gradus_mi355x.h (field order and types checked by tests/test_julia_binding.py)
@@ -80,7 +80,8 @@ struct GrStats                       # == gr_stats
     rhs_evals::Int64
     flagged_rays::Int64
     status_count::NTuple{4,Int64}
-    kernel_ms::Float64
+    kernel_ms::Float64               # start of the call's device work -> end of its last trace kernel
+    call_ms::Float64                 # ... -> end of the last copy into the caller's buffer (ABI 5)
 end
 
 struct GrPlane                       # == gr_plane
@@ -440,6 +441,28 @@ function _plane_rays(config::TracingConfiguration)
     collect(vec(αs)), collect(vec(βs))
 end
 
+# The result of ensemble_solve_tracing_problem -- the reference allocates `Vector{GeodesicPoint{T}}(undef, n)` itself
+# (tracing/tracing.jl:179-183) -- in memory the LIBRARY page-locked (gr_host_alloc, ABI 5): 152 B per ray come back by DMA
+# at the link's rate, band by band under the trace of the later bands, instead of through the pageable path (page faults,
+# then ~30 GB/s).  Julia owns the wrapper; its finalizer hands the block back (gr_host_free does not need the context, so
+# the order in which the ensemble and the array are collected does not matter).  Small results and a refused allocation
+# (RLIMIT_MEMLOCK) take an ordinary Vector.
+const PINNED_RESULT_MIN_BYTES = 64 << 20
+
+function _result_vector(ensemble::EnsembleMI355X, N::Integer)
+    bytes = Int64(N) * 152
+    if bytes >= PINNED_RESULT_MIN_BYTES
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:gr_host_alloc, LIB), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ensemble.ctxs[1], bytes, ref)
+        if rc == 0 && ref[] != C_NULL
+            out = unsafe_wrap(Array, Ptr{GeodesicPoint{Float64,Nothing}}(ref[]), Int(N); own = false)
+            finalizer(a -> ccall((:gr_host_free, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, pointer(a)), out)
+            return out
+        end
+    end
+    Vector{GeodesicPoint{Float64,Nothing}}(undef, N)
+end
+
 function _cpu_fallback(reason, problem, config; kwargs...)
     @warn "EnsembleMI355X: $reason -- tracing on the CPU with EnsembleEndpointThreads instead"
     Gradus.ensemble_solve_tracing_problem(Gradus.EnsembleEndpointThreads(), problem, config; kwargs...)
@@ -467,8 +490,8 @@ function Gradus.ensemble_solve_tracing_problem(
         return _cpu_fallback(e.msg, problem, config; progress_bar, save_on, maxiters, solver_opts...)
     end
     cfg = Ref(cfg_val)
-    out = Vector{GeodesicPoint{Float64,Nothing}}(undef, N)
-    @assert sizeof(eltype(out)) == 152
+    @assert sizeof(GeodesicPoint{Float64,Nothing}) == 152
+    out = _result_vector(ensemble, N)
     stats = Ref{GrStats}()
     plane = _render_plane(config)
     if !isnothing(plane)

@@ -508,12 +508,31 @@ static void interpolate(const double u[8], const double k[7][8], double dt, doub
 }
 
 /* ODE_DEFAULT_NORM on an 8-vector: sqrt(sum(abs2)/length) [3P] */
+#ifdef ORC_TANGENT_BUILD
+/* tangent_oracle.cpp only (this translation unit compiled on a value + 2 tangents scalar): with the switch on, the norms
+ * are DiffEqBase's ForwardDiff-extension ones [3P]: |u|_D = sqrt(value² + Σ partials²) for a scalar and
+ * sqrt(Σ sse / (N (1 + P))) for an array.  Off (default), and in the plain build, values only. */
+#define ORC_ABS(x) (g_norm_with_tangents ? T2(sqrt(orct_sse(x))) : fabs(x))
+static double rms8(const double x[8])
+{
+    if (g_norm_with_tangents) {
+        T2 s = 0.0;
+        for (int i = 0; i < 8; ++i) s += T2(orct_sse(x[i]));
+        return sqrt(s / 24.0);
+    }
+    double s = 0.0;
+    for (int i = 0; i < 8; ++i) s += x[i] * x[i];
+    return sqrt(s / 8.0);
+}
+#else
+#define ORC_ABS(x) fabs(x)
 static double rms8(const double x[8])
 {
     double s = 0.0;
     for (int i = 0; i < 8; ++i) s += x[i] * x[i];
     return sqrt(s / 8.0);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------
  * callbacks
@@ -663,7 +682,7 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
     /* ---- initial dt: ode_determine_initdt (App. A.4) ---- */
     double f0[8], sk[8];
     rhs(c, u, f0); n_rhs++;
-    for (int i = 0; i < 8; ++i) sk[i] = abstol + fabs(u[i]) * reltol;
+    for (int i = 0; i < 8; ++i) sk[i] = abstol + ORC_ABS(u[i]) * reltol;
     for (int i = 0; i < 8; ++i) tmp[i] = u[i] / sk[i];
     const double d0 = rms8(tmp);
     for (int i = 0; i < 8; ++i) tmp[i] = f0[i] / sk[i];
@@ -715,7 +734,7 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
             double acc = 0.0;
             for (int j = 0; j < 7; ++j) acc += TS_BT[j] * k[j][i];
             const double ut = dt * acc;
-            et[i] = ut / (abstol + fmax(fabs(u[i]), fabs(unew[i])) * reltol);
+            et[i] = ut / (abstol + fmax(ORC_ABS(u[i]), ORC_ABS(unew[i])) * reltol);
         }
         const double EEst = rms8(et);
 

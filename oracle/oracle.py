@@ -398,3 +398,41 @@ def shakura_sunyaev(cfg, eddington_ratio=0.3):
     r_isco = isco(cfg)
     eta = 1.0 - circular_energy(cfg, r_isco)
     return {"mdot": eddington_ratio, "inv_eta": 1.0 / eta, "inner_radius": r_isco}
+
+
+# ---- the oracle on a value + two tangents scalar (oracle/tangent_oracle.cpp): per-ray pin of the tangent kernels ----
+_TAN_LIB_PATH = os.path.join(_HERE, "libgradus_oracle_tangent.so")
+_tan_lib = None
+
+
+def build_tangent(force: bool = False) -> str:
+    if force or not os.path.exists(_TAN_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_TAN_LIB_PATH)
+        for f in ("tangent_oracle.cpp", "gradus_oracle.c", "gradus_oracle.h", "metrics_tmpl.h")
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "tangent"])
+    return _TAN_LIB_PATH
+
+
+def ray_tangent(cfg, x_obs, alpha, beta, *, r_isco, max_time, heights=None, norm_with_tangents=False):
+    """(g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status) per ray from the oracle integrated on dual numbers -- what
+    jacobian_∂αβ_∂gr reads off ForwardDiff.jacobian around tracegeodesics (precision-solvers.jl:401-451).
+    `norm_with_tangents`: the step-size controller sees the tangents too (DiffEqBase's norm on Dual state)."""
+    global _tan_lib
+    if _tan_lib is None:
+        _tan_lib = C.CDLL(build_tangent())
+        _tan_lib.orct_ray_tangent.restype = C.c_int
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    x_obs = np.ascontiguousarray(x_obs, dtype=np.float64)
+    out = np.zeros((alpha.size, 8))
+    pf = PF()
+    pf.pf_id, pf.filter_id, pf.fill, pf.r_isco, pf.n_plunge = PF_REDSHIFT, FILTER_NONE, float("nan"), float(r_isco), 0
+    h = None if heights is None else np.ascontiguousarray(np.broadcast_to(heights, alpha.shape), dtype=np.float64)
+    _tan_lib.orct_set_norm(C.c_int(1 if norm_with_tangents else 0))
+    rc = _tan_lib.orct_ray_tangent(C.byref(cfg), C.byref(pf), _dp(x_obs), _dp(alpha), _dp(beta),
+                                   _dp(h) if h is not None else None, C.c_int64(alpha.size), C.c_double(max_time), _dp(out))
+    _tan_lib.orct_set_norm(C.c_int(0))
+    if rc != 0:
+        raise RuntimeError(f"orct_ray_tangent failed: {rc}")
+    return out

@@ -49,16 +49,24 @@ for path in args.libs:
         k, v = kv.split("=")
         assert lib.gr_ctx_set(h, k.encode(), int(v)) == 0
     lib.gr_render.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p, C.c_void_p]
-    libs.append((path, lib, h))
+    lib.gr_abi_version.restype = C.c_int32
+    libs.append((path, lib, h, lib.gr_abi_version()))
 
-times = {p: [] for p, _, _ in libs}
+# ABI <= 4: gr_stats.kernel_ms spans kernel + D2H; ABI 5 splits it into kernel_ms (kernel) and call_ms (kernel + D2H).
+# The column compared across builds is kernel + D2H; the kernel alone is listed for ABI-5 builds.
+times = {p: [] for p, _, _, _ in libs}
+ktimes = {p: [] for p, _, _, _ in libs}
 st = L.gr_stats()
 for rnd in range(args.rounds + 2):
-    for path, lib, h in libs:
+    for path, lib, h, abi in libs:
         rc = lib.gr_render(h, C.byref(cfg), C.byref(pl), C.byref(s), C.byref(rg), img.ctypes.data, C.byref(st))
         assert rc == 0, rc
         if rnd >= 2:
-            times[path].append(st.kernel_ms)
+            times[path].append(st.call_ms if abi >= 5 else st.kernel_ms)
+            if abi >= 5:
+                ktimes[path].append(st.kernel_ms)
 for path in times:
     t = np.array(times[path])
-    print(f"{os.path.basename(path):40s} median {np.median(t):8.4f} ms  min {t.min():8.4f}  max {t.max():8.4f}  (n={t.size})")
+    k = np.array(ktimes[path]) if ktimes[path] else None
+    extra = f"  kernel alone median {np.median(k):8.4f} min {k.min():8.4f}" if k is not None else ""
+    print(f"{os.path.basename(path):40s} kernel+D2H median {np.median(t):8.4f} ms  min {t.min():8.4f}  max {t.max():8.4f}  (n={t.size}){extra}")

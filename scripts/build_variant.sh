@@ -8,7 +8,7 @@
 set -e
 REV=$1; NAME=$2; shift 2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/ab; mkdir -p $OUT
+OUT=${AB_DIR:-$ROOT/ab}; mkdir -p $OUT
 python3 - "$ROOT" "$REV" "$OUT/$NAME.so" "${METRICS:-}" "$@" <<'PY'
 import os, shutil, subprocess, sys, tempfile
 root, rev, out, metrics = sys.argv[1:5]

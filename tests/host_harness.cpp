@@ -34,9 +34,7 @@ static void run(const Params& p, int64_t n, double* tlog, double* hlog, int64_t 
 
 static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t* nlog)
 {
-    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
-    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
+    derive_params(p);
     p.disc_table = p.cfg.disc_table;      // host pointer is directly usable here
     p.cfg.upper_hemisphere = (p.cfg.upper_hemisphere ? 1 : 0) | (p.cfg.count_windings ? 4 : 0);   // as stage_disc_table does
     const int disc = p.cfg.disc_id;
@@ -111,9 +109,7 @@ int hh_wave_stats(const gr_config* cfg, const gr_plane* plane, const int64_t* ti
     const int64_t n = plane->width * plane->height;
     p.cfg = *cfg; p.n = n; p.cold = &c; c.winding_plane = cfg->winding_plane;
     c.src_mode = 0; c.out_mode = 0; c.plane = *plane; c.range = gr_range{ 0, n, n, 1 };
-    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
-    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
+    derive_params(p);
     p.cfg.upper_hemisphere = 0;
     for (int i = 0; i < 34; ++i) out[i] = 0.0;
     if (cfg->metric_id != GR_METRIC_KERR || cfg->disc_id != GR_DISC_THIN) return -1;

@@ -26,7 +26,12 @@ static void run(const Params& p)
     }
 }
 
+static int g_tangent_norm = 0;
+
 extern "C" {
+
+// 1 = the error norm over values and tangents (what gr_ctx_set(ctx, "tangent_norm", 1) selects in the library)
+void hht_set_tangent_norm(int on) { g_tangent_norm = on ? 1 : 0; }
 
 // rays given by impact parameters; out: n x 8 = (g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status)
 int hht_ray_tangent(const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf, double* out)
@@ -54,9 +59,8 @@ int hht_ray_tangent(const gr_config* cfg, const gr_rayset* rays, const gr_pointf
     c.pf.n_plunge = pf->n_plunge; c.pf.plunge_r = pf->plunge_r; c.pf.plunge_vt = pf->plunge_vt;
     c.pf.plunge_vr = pf->plunge_vr; c.pf.plunge_vphi = pf->plunge_vphi;
     c.winding_plane = cfg->winding_plane;
-    p.wedge = std::asin(std::fmin(p.cfg.gtol, 1.0)) * (1.0 + 1e-9) + 1e-12;
-    p.dtmax = std::fabs(p.cfg.lambda1 - p.cfg.lambda0);
-    p.maxiters32 = (int32_t)std::min<int64_t>(std::max<int64_t>(p.cfg.maxiters, 0), 0x7fffffff);
+    derive_params(p);
+    p.tangent_norm = g_tangent_norm;
     p.disc_table = p.cfg.disc_table;
     p.cfg.upper_hemisphere = (p.cfg.upper_hemisphere ? 1 : 0);
     const int disc = p.cfg.disc_id;

@@ -61,9 +61,10 @@ def _worker(rank, world, port, W, H, tmp, use_async=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,use_async", [(2, False), (4, False), (2, True), (4, 2)])
+@pytest.mark.parametrize("world,use_async", [(2, False), (4, False), (2, True), (4, 2), (8, 2)])
 def test_sharded_render_equals_single(oracle, G, tmp_path, world, use_async):
-    W = H = 16
+    # world 8 = the node the driver scales to (1 -> 8 MI355X): the same deal, gather and reassembly on gloo
+    W = H = 16 if world < 8 else 32
     mp.spawn(_worker, args=(world, _free_port(), W, H, str(tmp_path), use_async), nprocs=world, join=True)
     img = np.load(tmp_path / "img.npy")
     x = np.array([0.0, 100.0, math.radians(85), 0.0])

@@ -57,7 +57,7 @@ def c_structs():
 
 
 def c_prototypes():
-    """{name: [arg kind]} with kinds ctx / ctxs / struct:<name> / f64p / i64p / i64 / i32 / f64 / voidp / charp."""
+    """{name: [arg kind]} with kinds ctx / ctxs / struct:<name> / f64p / i64p / i64 / i32 / f64 / voidp / voidpp / charp."""
     out = {}
     for m in re.finditer(r"(?:int32_t|const char\*)\s+(gr_\w+)\(([^;{]*?)\);", strip_c_comments(HDR), flags=re.S):
         args = " ".join(m.group(2).split())
@@ -75,7 +75,7 @@ def c_prototypes():
                     kinds.append("struct:" + t[:-1])
                 else:
                     kinds.append({"double*": "f64p", "int64_t*": "i64p", "int64_t": "i64", "int32_t": "i32", "double": "f64",
-                                  "void*": "voidp", "char*": "charp"}[t])
+                                  "void*": "voidp", "void**": "voidpp", "char*": "charp"}[t])
         out[m.group(1)] = kinds
     return out
 
@@ -210,6 +210,10 @@ def test_every_ccall_matches_its_c_prototype():
                 else:
                     jname = {v: k for k, v in JL2C_STRUCT.items()}[cname]
                     assert t in (f"Ref{{{jname}}}", f"Ptr{{{jname}}}"), (sym, t, w)
+            elif w == "voidpp":
+                assert t == "Ref{Ptr{Cvoid}}", (sym, t, w)            # gr_host_alloc's out parameter
+            elif w == "voidp":
+                assert t == "Ptr{Cvoid}", (sym, t, w)
             else:
                 assert t == {"f64p": "Ptr{Float64}", "i64": "Int64", "i32": "Int32", "f64": "Float64"}[w], (sym, t, w)
 

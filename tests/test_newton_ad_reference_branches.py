@@ -1,0 +1,134 @@
+"""`find_offsets_for_radius_newton_ad` against a literal, one-problem-at-a-time transcription of the reference's loop
+(src/tracing/precision-solvers.jl:135-236) on SYNTHETIC image-plane maps ρ(r) -- no ray tracing: the point is the control
+flow.  The maps are chosen so that every branch of the reference is taken by some problem: plain Newton convergence, the
+contrapoint + biased bisection (a step that lands below zero or within r_min + 1 of the hole), "Converge failed" (two
+negative residuals in a row with the derivative AT THE NEW POINT pointing away: the loop is left with the OLD x, y and
+the NEW point -- ADVICE r2: the batch version used the stale derivative and kept the old point), the cycle detector
+with its bracketing finish, and the post-loop bracket for y > 10 after max_iter."""
+import math
+
+import numpy as np
+import pytest
+
+from gradus_jl_amd import transfer_functions as TF
+
+
+def make_map(kind, k):
+    """(F, F') of a synthetic map ρ = F(r)."""
+    if kind == "smooth":            # monotone, convex: Newton converges
+        return (lambda r: r - 1.0 + 2.0 / (1.0 + r * r)), (lambda r: 1.0 - 4.0 * r / (1.0 + r * r) ** 2)
+    if kind == "well":              # a shelf at large r, then a well with a negative slope on its left flank
+        c, d, a = 6.0 + 0.3 * k, 0.02 + 0.01 * k, 3.0 + 0.1 * k
+        return (lambda r: np.where(r >= 12.0, r, a + d * (r - c) ** 2 * np.sign(r - c) * -1.0 + 0.9 * np.tanh(r - c))), \
+               (lambda r: np.where(r >= 12.0, 1.0, -2.0 * d * np.abs(r - c) + 0.9 / np.cosh(r - c) ** 2))
+    if kind == "hole":              # steep near a "horizon": steps fall below zero / inside r_min + 1
+        return (lambda r: np.where(r > 0.0, 0.05 * r * r + 0.2 * r, -1.0 + 0.0 * r)), (lambda r: np.where(r > 0.0, 0.1 * r + 0.2, 1.0 + 0.0 * r))
+    if kind == "flat":              # nearly flat far out: Newton overshoots hugely, stays > 10 away -> max_iter + bracket
+        return (lambda r: 40.0 + 0.5 * np.sin(r) + 1e-3 * r), (lambda r: 0.5 * np.cos(r) + 1e-3)
+    raise ValueError(kind)
+
+
+class FakeTrace:
+    """a tracer with only `.tangent`, for rays on the α axis (θ = 0): out = (g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status)"""
+
+    def __init__(self, F, dF):
+        self.F, self.dF, self.calls = F, dF, 0
+
+    def tangent(self, α, β, heights=None):
+        self.calls += α.size
+        out = np.zeros((α.size, 8))
+        out[:, 0] = 0.5 + 1e-3 * α
+        out[:, 1] = self.F(α)
+        out[:, 4] = self.dF(α)
+        out[:, 6] = α
+        out[:, 7] = 2.0
+        return out
+
+
+def reference_loop(F, dF, r_target, r_min, zero_atol=1e-7, max_iter=50, bias=2.0):
+    """precision-solvers.jl:152-233 statement by statement for one problem; returns (x, ρ of `point`, y, branches)."""
+    seen = set()
+
+    def step(r):
+        return float(F(np.float64(r))), float(dF(np.float64(r))), float(F(np.float64(r))) - r_target
+
+    def find_zero(lo, hi):
+        mid = hi
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            ym = step(mid)[2]
+            if ym < 0:
+                lo = mid
+            else:
+                hi = mid
+            if abs(ym) <= zero_atol:
+                break
+        return mid
+
+    x = max(20.0, r_target)
+    contra = 0.0
+    point, df, y = step(x)
+    previous = [0.0] * 6
+    i = 0
+    while abs(y) > zero_atol and i <= max_iter:
+        with np.errstate(all="ignore"):
+            next_x = x - y / df
+        point, df, next_y = step(next_x)
+        if next_x < 0 or (next_y < 0 and y > 0):
+            contra = max(contra, next_x)
+            if next_x < 0 or point < r_min + 1:
+                seen.add("bisect")
+                next_x = (contra * bias + x) / (1 + bias)
+                point, df, next_y = step(next_x)
+        if next_y < 0 and y < 0 and (-y / df) < 0:
+            seen.add("converge_failed")
+            break
+        next_Δy = (y - next_y) / y
+        if y > 0 and any(abs(next_Δy - q) <= zero_atol * 100 for q in previous):
+            seen.add("cycle")
+            x = find_zero(contra, x)
+            point, df, y = step(x)
+            break
+        x, y = next_x, next_y
+        previous[i % 6] = next_Δy
+        i += 1
+    if i >= max_iter:
+        seen.add("max_iter")
+        if y > 10.0:
+            seen.add("late_bracket")
+            x = find_zero(contra, x)
+            point, df, y = step(x)
+    return x, point, y, seen
+
+
+CASES = [("smooth", 0, 4.0, 0.5), ("smooth", 0, 12.0, 0.5), ("hole", 0, 4.0, 1.5), ("hole", 0, 1.0, 2.5), ("flat", 0, 4.0, 0.5)] \
+        + [("well", k, re, 0.2) for k in range(6) for re in (2.5, 3.2, 3.6)]
+
+
+def test_batch_newton_follows_the_reference_statement_by_statement():
+    branches = set()
+    for kind, k, re, r_min in CASES:
+        F, dF = make_map(kind, k)
+        xr, pr, yr, seen = reference_loop(F, dF, re, r_min)
+        branches |= seen
+        tr = FakeTrace(F, dF)
+        r, pts, g, point = TF.find_offsets_for_radius_newton_ad(tr, np.array([re]), np.array([0.0]), r_min=r_min)
+        ok_ref = (xr >= 0) and abs(yr) <= 1e-4 * re
+        assert np.isnan(r[0]) == (not ok_ref), (kind, k, re, xr, yr, r)
+        if ok_ref:
+            assert r[0] == pytest.approx(xr, rel=1e-12, abs=1e-12), (kind, k, re)
+        # the point handed back is the reference's `point` (on "Converge failed": the NEW one, not x's)
+        assert point[0, 1] == pytest.approx(pr, rel=1e-12, abs=1e-12), (kind, k, re, seen)
+    assert {"bisect", "converge_failed", "cycle", "max_iter", "late_bracket"} <= branches, branches
+
+
+def test_batch_of_mixed_problems_equals_the_problems_one_by_one():
+    """lock-step batching must not couple the problems: the same maps solved together and alone give the same roots"""
+    F, dF = make_map("well", 2)
+    res = np.array([2.5, 3.2, 3.6, 3.9, 12.5, 15.0])
+    tr = FakeTrace(F, dF)
+    r_all, _, _, p_all = TF.find_offsets_for_radius_newton_ad(tr, res, np.zeros(res.size), r_min=0.2)
+    for k, re in enumerate(res):
+        r1, _, _, p1 = TF.find_offsets_for_radius_newton_ad(FakeTrace(F, dF), np.array([re]), np.array([0.0]), r_min=0.2)
+        assert (np.isnan(r1[0]) and np.isnan(r_all[k])) or r1[0] == r_all[k]
+        assert p1[0, 1] == p_all[k, 1]
