@@ -288,6 +288,46 @@ def check(code):
         raise GradusMI355XError(code, load().gr_last_error().decode("utf-8", "replace"))
 
 
+class PinnedBlock:
+    """A result buffer the LIBRARY page-locked (gr_host_alloc, ABI 5): what the Julia shim wraps as its
+    Vector{GeodesicPoint} so that 152 B per ray come back by DMA under the trace instead of through the pageable path.
+    `array(dtype, count)` views it as a numpy array that keeps the block alive; the block is returned when the last view
+    is gone (gr_host_free needs no context)."""
+
+    def __init__(self, ctx, nbytes: int):
+        p = C.c_void_p()
+        check(load().gr_host_alloc(ctx.handle, int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def array(self, dtype, count: int):
+        buf = (C.c_char * self.nbytes).from_address(self.ptr)
+        buf._pinned_block = self                      # the view keeps the block alive
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                load().gr_host_free(None, C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+PINNED_RESULT_MIN_BYTES = 64 << 20
+
+
+def result_points(ctx, n: int):
+    """The array an end-point call fills: pinned by the library from 64 MiB up (GRADUS_MI355X_PINNED_RESULTS=0: never),
+    an ordinary numpy array below that or when page-locking is refused."""
+    nbytes = int(n) * POINT_DTYPE.itemsize
+    if nbytes >= PINNED_RESULT_MIN_BYTES and os.environ.get("GRADUS_MI355X_PINNED_RESULTS", "1") != "0":
+        try:
+            return PinnedBlock(ctx, nbytes).array(POINT_DTYPE, int(n))
+        except GradusMI355XError:
+            pass
+    return np.zeros(int(n), dtype=POINT_DTYPE)
+
+
 class Context:
     """Owns one gr_ctx (one HIP device)."""
 

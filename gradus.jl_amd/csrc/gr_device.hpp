@@ -166,6 +166,25 @@ GR_DEV real sqrt_fast(real x)
     return GR_FMA(d, hh, g);
 }
 GR_DEV int sgn(real x) { return (x > 0.0) - (x < 0.0); }
+// A value that is the same in every lane, forced into scalar registers.  Products of metric parameters (a², 2M, -3 α13, ...)
+// are formed by the vector ALU (the scalar unit has no FP64), so the compiler keeps them in VGPRs for the whole step loop;
+// at the 168-register budget it spilled exactly those to scratch and reloaded them in every stage.  Two v_readfirstlane
+// once per kernel put them where uniform values belong.
+#ifndef GR_UNIFORM_TO_SGPR
+#define GR_UNIFORM_TO_SGPR 1
+#endif
+GR_DEV real uni(real x)
+{
+#if defined(GR_HOST_HARNESS) || defined(GR_REAL_IS_TAN2) || !GR_UNIFORM_TO_SGPR
+    return x;
+#elif defined(GR_REAL_IS_FLOAT)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+#else
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+#endif
+}
 // max(|a|, |b|) as ONE instruction.  fmax(fabs(a), fabs(b)) compiles to three under IEEE mode (each fabs is made canonical by
 // its own v_max x, |a|, |a| before the real maximum): 15 of the step's FP64 instructions were such canonicalisations (error
 // norm scales, the event pre-filter's max |A^θ|).  The source modifiers of v_max_f64 take the absolute values for free and the
@@ -354,9 +373,11 @@ struct KerrFamily {
     static constexpr int kLaneWavesPerSimd = CHARGED ? 2 : 3;
     real M, a;
     real Q, Q2, qm;      // CHARGED only: charge, its square, test-particle q (or q/μ)
+    real ka2, ktM, kta2; // a², 2M, 2a²: uniform, formed once (rhs)
     GR_DEV void load(const gr_config& c)
     {
         M = c.params[0]; a = c.params[1];
+        ka2 = uni(a * a); ktM = uni(2.0 * M); kta2 = uni(2.0 * (a * a));
         Q = Q2 = qm = 0.0;
         if (CHARGED) {
             Q = c.params[2];
@@ -447,7 +468,7 @@ struct KerrFamily {
     GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
                     real& at, real& ar, real& ah, real& ap) const
     {
-        const real a2 = a * a, tM = 2.0 * M;
+        const real a2 = ka2, tM = ktM;
         const real r2 = r * r, s2 = s * s, sc = s * c;
         const real Sig = GR_FMA(a2, c * c, r2);
         real Del = GR_FMA(-tM, r, r2) + a2;
@@ -462,7 +483,7 @@ struct KerrFamily {
         const real wiS = n * (iSig * iSig);                         // w/Σ
         const real w = n * iSig;
         const real hw_r = GR_FMA(-r, wiS, M * iSig);                // ½ ∂_r w = (MΣ - r n)/Σ²
-        const real mSig_t = (2.0 * a2) * sc;                        // -∂_θ Σ
+        const real mSig_t = kta2 * sc;                              // -∂_θ Σ
         const real w_t = wiS * mSig_t;                              // ∂_θ w = -w ∂_θΣ/Σ
         const real q = a * s2;
         const real U = GR_FMA(-q, vp, vt);                          // v^t - a s² v^ϕ
@@ -538,9 +559,12 @@ struct JohannsenMetric {
     static constexpr int kMinWavesPerSimd = 2;
     static constexpr int kLaneWavesPerSimd = 2;
     real M, a, a13, a22, a52, e3;
+    real ka2, ktM, keM3, km3a13, km2a22, km2a52;     // a², 2M, ϵ3 M³, -3 α13, -2 α22, -2 α52: uniform, formed once (rhs)
     GR_DEV void load(const gr_config& c)
     {
         M = c.params[0]; a = c.params[1]; a13 = c.params[2]; a22 = c.params[3]; a52 = c.params[4]; e3 = c.params[5];
+        ka2 = uni(a * a); ktM = uni(2.0 * M); keM3 = uni(e3 * M * M * M);
+        km3a13 = uni(-3.0 * a13); km2a22 = uni(-2.0 * a22); km2a52 = uni(-2.0 * a52);
     }
 
     GR_DEV void comps(real r, real s, real c, real g[5]) const
@@ -628,11 +652,11 @@ struct JohannsenMetric {
     GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
                     real& at, real& ar, real& ah, real& ap) const
     {
-        const real a2 = a * a, tM = 2.0 * M, eM3 = e3 * M * M * M;
-        const real ir = rcp_full(r);
+        const real a2 = ka2, tM = ktM, eM3 = keM3;
+        const real ir = rcp_rhs(r);
         const real Mr = M * ir, Mr2 = Mr * Mr, Mr3 = Mr2 * Mr;
         const real A1 = GR_FMA(a13, Mr3, 1.0), A2 = GR_FMA(a22, Mr2, 1.0), A5 = GR_FMA(a52, Mr2, 1.0);
-        const real A1r = (-3.0 * a13) * Mr3 * ir, A2r = (-2.0 * a22) * Mr2 * ir, A5r = (-2.0 * a52) * Mr2 * ir;
+        const real A1r = km3a13 * Mr3 * ir, A2r = km2a22 * Mr2 * ir, A5r = km2a52 * Mr2 * ir;
         const real r2 = r * r, s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
         const real eir = eM3 * ir;
         const real Sig = GR_FMA(a2, c * c, r2) + eir;
@@ -649,7 +673,7 @@ struct JohannsenMetric {
         const real DA5_r = GR_FMA(Del, A5r, Del_r * A5);
         // reciprocals
         const real e1 = N * DA5, e2 = Sig * s2;
-        const real R = rcp_full(e1 * e2);
+        const real R = rcp_rhs(e1 * e2);
         const real ie1 = R * e2, ie2 = R * e1;                      // 1/(N ΔA5), 1/(Σ s²)
         const real iN = ie1 * DA5, iDA5 = ie1 * N, iSig = ie2 * s2;
         const real iDel = A5 * iDA5;
@@ -985,7 +1009,7 @@ struct GenericMetricT {
         const real a2 = a * a, tM = 2.0 * M, eps = P[2] * M * M * M;
         const real r2 = r * r, s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
         const real Sig = GR_FMA(a2, c * c, r2);
-        const real iSig = rcp_full(Sig);
+        const real iSig = rcp_rhs(Sig);
         const real Del = GR_FMA(-tM, r, r2) + a2;
         const real rho2 = r2 + a2;
         const real a2S2 = a2 * S2;                         // -Σ_θ
@@ -1006,7 +1030,7 @@ struct GenericMetricT {
         const real Dt_h = GR_FMA(a2S2, h, a2s2 * h_h);
         // reciprocals
         const real HD = H * Dt;
-        const real R = rcp_full(HD * s2);                  // 1/(H Δ̃ s²)
+        const real R = rcp_rhs(HD * s2);                  // 1/(H Δ̃ s²)
         const real iH = R * (Dt * s2), iDt = R * (H * s2), is2Dt = R * H;
         // dots along the ray
         const real hd = GR_FMA(h_r, vr, h_h * vh);
@@ -1244,7 +1268,7 @@ struct PfDev {
 struct Cold {
     int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays
     int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs, 4 = (g, ρ, t, status), 5 = the same with ∂/∂α, ∂/∂β (tangent build only)
-    int32_t swizzle;          // 1 = 8x8 pixel tiles per wave
+    int32_t swizzle;          // log2 rows of the pixel tile a wave owns: 3 = 8 x 8, 4 = 16 x 4 (0 = none)
     int32_t idx32;            // 1 = every ray / pixel index fits 31 bits: 32-bit divisions in the index maps
     gr_plane plane;
     gr_range range;
@@ -1347,16 +1371,20 @@ GR_DEV int64_t idx_div(const Cold& p, int64_t a, int64_t b)
     return p.idx32 ? (int64_t)((uint32_t)a / (uint32_t)b) : a / b;
 }
 
+// `swizzle` = log2 of the tile's ROWS (consecutive pixels of a column, i.e. consecutive doubles of the image): 3 = 8 x 8
+// tiles, 4 = 16 rows x 4 columns -- a wave's stores are then four whole 128-byte lines instead of eight half lines
+// (gr_ctx_set "tile_rows").  0 = no tiling.
 GR_DEV int64_t tile_swizzle(const Cold& p, int64_t j)
 {
     if (!p.swizzle) return j;
+    const int tr = p.swizzle, tc = 6 - tr;
     const int64_t H = p.plane.height;
     int64_t tile = j >> 6;
     if (p.tile_perm) tile = p.tile_perm[tile];
     const int lane = (int)(j & 63);
-    const int64_t tiles_per_col = H >> 3;
+    const int64_t tiles_per_col = H >> tr;
     const int64_t tx = idx_div(p, tile, tiles_per_col), ty = tile - tx * tiles_per_col;
-    return ((tx << 3) + (lane >> 3)) * H + (ty << 3) + (lane & 7);
+    return ((tx << tc) + (lane >> tr)) * H + (ty << tr) + (lane & ((1 << tr) - 1));
 }
 
 GR_DEV int64_t range_map(const Cold& p, int64_t j)
@@ -1469,6 +1497,48 @@ GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const 
     const real E_obs = g0[0] * v0[0] + g0[4] * v0[3];
     return E_obs * rcp_full(E_disc);
 }
+
+// ---------------------------------------------------------------------------------------
+// Cold lane storage: LDS as the spill space the compiler does not have.
+//
+// The step's hot region (five stages + the right-hand side at the new state) needs r, θ, the four velocities and the
+// stage accelerations; the rest of the ray -- t, dt, x^t, x^ϕ, the disc condition at the step's start, the controller's
+// memory and the counters -- is touched before and after it only.  At the register budget of three waves per SIMD
+// (168 VGPRs) the compiler spilled into scratch (56-88 B per lane, HBM-backed: 44-60 MB of write-back per launch).  A
+// lane-private LDS slot costs neither HBM traffic nor a VALU instruction: the cold values are parked at the top of
+// step() and reloaded behind the last right-hand side (9 ds_write_b64 + 9 ds_read_b64 per step on a unit that is
+// otherwise idle; 72 B per lane = 4.6 KB per wave of the CU's 160 KB).  NoColdStore keeps everything in registers
+// (host harness, tangent flavour, k_trace_path).
+// ---------------------------------------------------------------------------------------
+constexpr int COLD_SLOTS = 9;      // 8-byte slots per lane
+struct NoColdStore {
+    static constexpr bool kOn = false;
+};
+struct LdsColdStore {
+    static constexpr bool kOn = true;
+    static constexpr int kStride = 64;     // one wave per region: slot k of the wave's lanes is one conflict-free 512-byte row,
+                                           // and k * 512 is an immediate offset of the ds instruction (no address arithmetic)
+    double* lane;        // this lane's slot 0 inside its wave's region; slot k is lane[k * 64]
+    template <class T> GR_DEV void st(int k, T v) const { *reinterpret_cast<T*>(lane + k * kStride) = v; }
+    template <class T> GR_DEV T ld(int k) const { return *reinterpret_cast<const T*>(lane + k * kStride); }
+    GR_DEV void st2(int k, int32_t a, int32_t b) const
+    {
+        reinterpret_cast<int32_t*>(lane + k * kStride)[0] = a;
+        reinterpret_cast<int32_t*>(lane + k * kStride)[1] = b;
+    }
+    GR_DEV void ld2(int k, int32_t& a, int32_t& b) const
+    {
+        a = reinterpret_cast<const int32_t*>(lane + k * kStride)[0];
+        b = reinterpret_cast<const int32_t*>(lane + k * kStride)[1];
+    }
+    // the compiler may neither forward a parked value to its reload nor move the accesses into the hot region
+    static GR_DEV void fence()
+    {
+#ifndef GR_HOST_HARNESS
+        asm volatile("" ::: "memory");
+#endif
+    }
+};
 
 // ---------------------------------------------------------------------------------------
 // The per-lane integrator.
@@ -1786,7 +1856,10 @@ struct Ray {
 #endif
     // One attempted Tsit5 step.  Returns true when the ray has finished (terminated by a
     // callback, reached λ1, or hit an anomaly).
-    GR_DEV bool step(const Metric& m, const Params& p)
+    GR_DEV bool step(const Metric& m, const Params& p) { return step(m, p, NoColdStore{}); }
+
+    template <class Cold_>
+    GR_DEV bool step(const Metric& m, const Params& p, const Cold_& cs)
     {
         const real tend = p.cfg.lambda1;
         const real dtmax = (real)p.dtmax;
@@ -1805,6 +1878,20 @@ struct Ray {
         hh = GR_FMIN(hh, tend - t);
         h = hh;
         const real h2 = hh * hh;
+        const bool resync = (nacc & 63) == 63;      // full sin/cos at the new state (decided while nacc is in a register)
+        if constexpr (Cold_::kOn) {
+            // park what the hot region does not read (see LdsColdStore)
+            cs.template st<real>(0, t);
+            cs.template st<real>(1, dt);
+            cs.template st<real>(2, x[0]);
+            cs.template st<real>(3, x[3]);
+            cs.template st<real>(4, cprev);
+            cs.st2(5, status, flags);
+            cs.st2(6, nacc, nrej);
+            cs.st2(7, ev_top, __builtin_bit_cast(int32_t, (float)lq_old));
+            cs.template st<int64_t>(8, j);
+            Cold_::fence();
+        }
 
         real s, c;
         // stages 2..6: arguments need r, θ and the four velocities only (the RHS does not
@@ -1841,7 +1928,8 @@ struct Ray {
         GR_STAGE(4)
         GR_STAGE(5)
 #undef GR_STAGE
-        // stage 7 argument = the new state
+        // stage 7 argument = the new state.  Its right-hand side reads r, θ and the velocities; t and ϕ of the new state are
+        // formed behind it (their old values are parked when the cold store is on)
         real xn[4], vn[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1849,23 +1937,44 @@ struct Ray {
 #pragma unroll
             for (int q = 1; q < 6; ++q) acc = GR_FMA(Ts::A[6][q], A[q][i], acc);
             vn[i] = GR_FMA(hh, acc, v[i]);
-            real ax = TsD::X.AX[6][0] * A[0][i];
-#pragma unroll
-            for (int q = 1; q < 5; ++q) ax = GR_FMA(TsD::X.AX[6][q], A[q][i], ax);
-            xn[i] = GR_FMA(h2, ax, GR_FMA(TsD::X.C[6] * hh, v[i], x[i]));
         }
+#define GR_NEW_POSITION(i)                                                                        \
+    {                                                                                             \
+        real ax = TsD::X.AX[6][0] * A[0][i];                                                      \
+        _Pragma("unroll") for (int q = 1; q < 5; ++q) ax = GR_FMA(TsD::X.AX[6][q], A[q][i], ax); \
+        xn[i] = GR_FMA(h2, ax, GR_FMA(TsD::X.C[6] * hh, v[i], x[i]));                             \
+    }
+        GR_NEW_POSITION(1)
+        GR_NEW_POSITION(2)
         // sin/cos at the new state by rotating the step's base as well (the RHS at the new state is stage 7 and the
         // base of the next step).  Rotation errors random-walk by ~1 ulp per step, so the base is re-synchronised
         // with a full evaluation every 64 accepted steps (and whenever the rotation falls back to it anyway).
         real sn, cn;
 #ifndef GR_NO_ROT_FINAL
         GR_DBG_DMAX(GR_FABS(xn[2] - x[2]));
-        if ((nacc & 63) == 63) sincos_fast(xn[2], sn, cn);
+        if (resync) sincos_fast(xn[2], sn, cn);
         else sincos_rot(rotk, x[2], sth, cth, xn[2], sn, cn);
         geodesic_rhs_sc(m, xn[1], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);
 #else
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);
 #endif
+        if constexpr (Cold_::kOn) {
+            Cold_::fence();
+            t = cs.template ld<real>(0);
+            dt = cs.template ld<real>(1);
+            x[0] = cs.template ld<real>(2);
+            x[3] = cs.template ld<real>(3);
+            cprev = cs.template ld<real>(4);
+            cs.ld2(5, status, flags);
+            cs.ld2(6, nacc, nrej);
+            int32_t lqb;
+            cs.ld2(7, ev_top, lqb);
+            lq_old = __builtin_bit_cast(float, lqb);
+            j = cs.template ld<int64_t>(8);
+        }
+        GR_NEW_POSITION(0)
+        GR_NEW_POSITION(3)
+#undef GR_NEW_POSITION
 
         // error estimate, squared RMS norm over all eight components: ũ_v = h Σ b̃_q A_q, ũ_x = h (Σb̃ · v + h Σ b̄_i A_i);
         // the common factor h² and the 1/8 of the mean are applied once to the sum.
@@ -1950,7 +2059,7 @@ struct Ray {
             gf = GR_CTL_MIN((ctl_t)PI_QMAX, GR_CTL_MAX((ctl_t)PI_QMIN, gf));   // e2 == 0 -> lE = -inf -> qmax
             nacc++;
             lq_old = GR_CTL_MAX(lE, (ctl_t)LOG2_QOLDINIT);
-            const real dtnew = hh * (real)gf;
+            real dtnew = hh * (real)gf;
             real tnew = t + hh;
             if (GR_FABS(tnew - tend) < 100.0 * GR_EPS * GR_FMAX(GR_FABS(tnew), GR_FABS(tend))) tnew = tend;
 
@@ -1963,7 +2072,35 @@ struct Ray {
                 if (pos || neg) {
                     const bool crossed = pos ? !(cnext > 0.0) : !(cnext < 0.0);
                     if (crossed) top = 7;
-                    else top = sample_event(p, pos ? 1 : -1, hh);
+                    else if (!sample_reach_excludes(p, pos ? 1 : -1, hh)) {
+                        // the interior samples are evaluated on ~2 % of the wave-steps and need a dozen registers of
+                        // their own: what they do not read waits in the cold store meanwhile (no scratch spill)
+                        if constexpr (Cold_::kOn) {
+                            cs.template st<real>(0, tnew);
+                            cs.template st<real>(1, dtnew);
+                            cs.template st<real>(2, x[0]);
+                            cs.template st<real>(3, x[3]);
+                            cs.template st<real>(4, xn[0]);
+                            cs.template st<real>(5, xn[3]);
+                            cs.template st<real>(6, vn[0]);
+                            cs.template st<real>(7, vn[3]);
+                            cs.template st<real>(8, t);
+                            Cold_::fence();
+                        }
+                        top = sample_event(p, pos ? 1 : -1, hh);
+                        if constexpr (Cold_::kOn) {
+                            Cold_::fence();
+                            tnew = cs.template ld<real>(0);
+                            dtnew = cs.template ld<real>(1);
+                            x[0] = cs.template ld<real>(2);
+                            x[3] = cs.template ld<real>(3);
+                            xn[0] = cs.template ld<real>(4);
+                            xn[3] = cs.template ld<real>(5);
+                            vn[0] = cs.template ld<real>(6);
+                            vn[3] = cs.template ld<real>(7);
+                            t = cs.template ld<real>(8);
+                        }
+                    }
                 }
                 if (top) {
                     // leave (x, v, A, h) in place; finalize() root-finds on the dense output
@@ -2033,9 +2170,9 @@ struct Ray {
     // A sample can only change sign if it lies inside the |cosθ| < gtol wedge.  Cheap exits first:
     // (1) a bound on how far θ can move inside the step, (2) θ alone at the six samples; the full
     // condition is evaluated only for steps that come near the equatorial plane.
-    GR_DEV int sample_event(const Params& p, int ps, real hh) const
+    // cheap exit of the event sampling, on every accepted step: true = no interior sample can change the condition's sign
+    GR_DEV bool sample_reach_excludes(const Params& p, int ps, real hh) const
     {
-        const real wedge = p.wedge;
         constexpr bool thin = (DISC == GR_DISC_THIN);
         if (thin && ps > 0) {
             // |θ(Θ_j) - θ_0| <= h (Θ_j |v^θ| + h Σ_i |RXΣ_i(Θ_j)| |A_i^θ|) <= h (|v^θ| + K h max_i |A_i^θ|)
@@ -2045,8 +2182,15 @@ struct Ray {
             const real reach = hh * (GR_FABS(v[2]) * DENSE_K1 + DENSE_K2 * hh * amax);
             // distance of θ from the equatorial plane (mod π) is asin|cosθ| >= |cosθ|, and cosθ of the step's base
             // is at hand: |cosθ| - reach > wedge rules every sample out
-            if (GR_FABS(cth) - reach > wedge) return 0;
+            if (GR_FABS(cth) - reach > (real)p.wedge) return true;
         }
+        return false;
+    }
+
+    GR_DEV int sample_event(const Params& p, int ps, real hh) const
+    {
+        const real wedge = p.wedge;
+        constexpr bool thin = (DISC == GR_DISC_THIN);
         GR_DBG_BIT(1 << 8);
         real Ct[4], Cr[4];
         dense_coeffs(2, hh, Ct);
@@ -2210,10 +2354,12 @@ struct Ray {
         if (flags & GR_FLAG_MASK) status = GR_STATUS_NO_STATUS;
         const Cold& cd = cold_of(p);
         if (cd.tile_cost) {
-            // representative ray of its 8x8 tile: local column and row both multiples of 8
+            // representative ray of its tile: the first row of the first column
+            const int tr = cd.swizzle, tc = 6 - tr;
             const int64_t H = cd.plane.height;
             const int64_t col = idx_div(cd, j, H), row = j - col * H;
-            if (((col | row) & 7) == 0) cd.tile_cost[(col >> 3) * (H >> 3) + (row >> 3)] = (uint32_t)(nacc + nrej);
+            if ((col & ((1 << tc) - 1)) == 0 && (row & ((1 << tr) - 1)) == 0)
+                cd.tile_cost[(col >> tc) * (H >> tr) + (row >> tr)] = (uint32_t)(nacc + nrej);
         }
         if (cd.out_mode == 1) {
             real x0[4], v0[4];

@@ -36,9 +36,34 @@ struct LaneStats {
     }
 };
 
-// LDS staging shared by both trace kernels: [ hist (lds_bins) | plunging table (4 x lds_plunge_rows) ]
+// LDS staging shared by both trace kernels: [ hist (lds_bins) | plunging table (4 x lds_plunge_rows) | cold lane storage ]
 #ifndef GR_HOST_HARNESS
 extern __shared__ double gr_lds[];
+
+// Cold lane storage (gr_device.hpp, LdsColdStore): -DGR_COLD_LDS=1 builds the trace kernels with it.  OFF by default:
+// measured on MI355X (profiles/r3c_ab_cold_store.txt) it removes every scratch access of the Kerr kernel (0 B instead of
+// 64 B per lane) at no gain in time (20.40 vs 20.31 ms) and costs 1.7 % on Johannsen at 2 waves per SIMD; it is kept as the
+// instrument that attributes the kernel's HBM write excess to scratch.
+#ifndef GR_COLD_LDS
+#define GR_COLD_LDS 0
+#endif
+#if GR_COLD_LDS && (defined(GR_REAL_IS_TAN2) || defined(GR_CONTROLLER_F64))
+#error "the cold lane storage is written for the fp64 / fp32 scalars and the fp32 controller"
+#endif
+#if GR_COLD_LDS
+typedef LdsColdStore TraceColdStore;
+__device__ __forceinline__ TraceColdStore cold_store_of(const Params& p)
+{
+    // wave w of the workgroup owns doubles [w * 64 * COLD_SLOTS, (w + 1) * 64 * COLD_SLOTS) of the region
+    const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    return TraceColdStore{ gr_lds + p.lds_bins + 4 * p.lds_plunge_rows + w * (64 * COLD_SLOTS) + l };
+}
+constexpr size_t kColdLdsBytesPerThread = sizeof(double) * COLD_SLOTS;
+#else
+typedef NoColdStore TraceColdStore;
+__device__ __forceinline__ TraceColdStore cold_store_of(const Params&) { return TraceColdStore{}; }
+constexpr size_t kColdLdsBytesPerThread = 0;
+#endif
 
 __device__ __forceinline__ LdsView lds_prologue(const Params& p)
 {
@@ -88,8 +113,9 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
     const LdsView lds = lds_prologue(p);
     if (gid < p.n) {
         Ray<Metric, DISC> ray;
+        const TraceColdStore cs = cold_store_of(p);
         ray.init(m, p, tile_swizzle(cold_of(p), gid));
-        while (!ray.step(m, p)) {}
+        while (!ray.step(m, p, cs)) {}
         ray.finalize(m, p, lds);
         ls.add(ray);
     }
@@ -112,6 +138,7 @@ __global__ void __launch_bounds__(256, GR_PERSISTENT_MIN_WAVES) k_trace_persiste
     const int lane = threadIdx.x & 63;
     const int threshold = p.refill_threshold;
     const LdsView lds = lds_prologue(p);
+    const TraceColdStore cs = cold_store_of(p);
 
     for (;;) {
         const unsigned long long act = __ballot(active);
@@ -140,7 +167,7 @@ __global__ void __launch_bounds__(256, GR_PERSISTENT_MIN_WAVES) k_trace_persiste
             if (__ballot(active) == 0ull) break;
         }
         if (active) {
-            if (ray.step(m, p)) {
+            if (ray.step(m, p, cs)) {
                 active = false;
                 pending = true;
             }
@@ -230,7 +257,7 @@ template <class Metric, int DISC>
 hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
     const int block = k.block;
-    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows);
+    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows) + kColdLdsBytesPerThread * (size_t)block;
 #ifdef GR_LANE_ONLY
     {
 #else

@@ -109,13 +109,14 @@ struct gr_ctx {
     int64_t refill_threshold = 16;
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
     int64_t swizzle = 1;
+    int64_t tile_rows = 8;                 // rows of the pixel tile of a wave: 8 (8 x 8) or 16 (16 x 4: whole 128-B lines per store)
     int64_t precision = 64;                // 64 = fp64 kernels, 32 = fp32 kernels (tolerance sweeps)
     int64_t lds = 1;                       // stage the plunging table / line-profile histogram in LDS
     int64_t lpt = 1;                       // longest-first tile order learned from the previous render
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_k = nullptr;             // end of the last trace kernel of a host call (gr_stats.kernel_ms vs call_ms)
     int64_t hugepages = 1;                 // madvise(MADV_HUGEPAGE) on large caller-owned result buffers before pre-faulting
-    int64_t tangent_norm = 0;              // tangent kernels: fold the tangents into the error norm (DiffEqBase on Dual state)
+    int64_t tangent_norm = 1;              // tangent kernels: the tangents are part of the error norm (DiffEqBase on Dual state); 0 = values only
     // LPT state for one (config, plane, range) key
     std::vector<unsigned char> lpt_key;
     uint32_t* d_tile_cost = nullptr;
@@ -337,15 +338,15 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
         if (lrc != GR_OK) return lrc;
     }
     if (p.n == 0) return GR_OK;
+    {
+        const int32_t trc = stage_disc_table(ctx, p, stream);
+        if (trc != GR_OK) return trc;
+    }
     // stage the cold block into the next ring slot (stream-ordered before the kernel)
     Cold* slot = ctx->d_cold + ctx->cold_next;
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cold, sizeof(Cold), hipMemcpyHostToDevice, stream));
     p.cold = slot;
-    {
-        const int32_t trc = stage_disc_table(ctx, p, stream);
-        if (trc != GR_OK) return trc;
-    }
     p.refill_threshold = (int32_t)ctx->refill_threshold;
     // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
     const bool tangent = cold.out_mode == 5;
@@ -439,11 +440,17 @@ void plane_params(gr_ctx* ctx, Params& pp, Cold& p, const gr_config* cfg, const 
     p.src_mode = 0;
     p.plane = *plane;
     p.range = *range;
-    // 8x8 tiles need whole, column-aligned groups of 8 columns in the local index space
+    // tiles of R rows x 64/R columns need whole, column-aligned groups of 64/R columns in the local index space
     const int64_t H = plane->height;
-    const bool cols_ok = (H % 8 == 0) && (range->first % H == 0) && (range->block % (8 * H) == 0)
-                         && (range->count % (8 * H) == 0);
-    p.swizzle = (ctx->swizzle && cols_ok) ? 1 : 0;
+    auto tiles_ok = [&](int64_t rows) {
+        const int64_t cols = 64 / rows;
+        return (H % rows == 0) && (range->first % H == 0) && (range->block % (cols * H) == 0) && (range->count % (cols * H) == 0);
+    };
+    p.swizzle = 0;
+    if (ctx->swizzle) {
+        if (ctx->tile_rows == 16 && tiles_ok(16)) p.swizzle = 4;
+        else if (tiles_ok(8)) p.swizzle = 3;
+    }
     const int64_t lim = (int64_t)1 << 31;
     p.idx32 = (plane->width * plane->height < lim && range->count < lim && range->block < lim) ? 1 : 0;
 }
@@ -553,6 +560,10 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->waves_per_simd = value;
     } else if (k == "swizzle") {
         c->swizzle = value ? 1 : 0;
+    } else if (k == "tile_rows") {
+        if (value != 8 && value != 16) return fail(GR_ERR_INVALID_ARGUMENT, "tile_rows must be 8 or 16");
+        c->tile_rows = value;
+        c->lpt_key.clear();
     } else if (k == "lpt_lane") {
         c->lpt_lane = value ? 1 : 0;
         c->lpt_key.clear();
@@ -757,11 +768,11 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     cd.v = d_v;
     cd.points = d_pt;
     cd.range = gr_range{ 0, n, n, 1 };
+    if ((rc = stage_disc_table(ctx, p, ctx->stream)) != GR_OK) return rc;
     Cold* slot = ctx->d_cold + ctx->cold_next;
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, ctx->stream));
     p.cold = slot;
-    if ((rc = stage_disc_table(ctx, p, ctx->stream)) != GR_OK) return rc;
     GR_HIP(kPath64[cfg->metric_id](&p, d_path, cap, d_n, ctx->stream));
     GR_HIP(hipGetLastError());
     if ((p.disc_table || p.chart_table) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;

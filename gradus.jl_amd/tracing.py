@@ -462,7 +462,7 @@ def ensemble_solve_tracing_problem(ensemble: EnsembleMI355X, config: TracingConf
         pl = config.abi_plane()
         n = pl.width * pl.height
         rg = _lib.gr_range(0, n, max(n, 1), 1)
-        out = np.zeros(n, dtype=_lib.POINT_DTYPE)
+        out = _lib.result_points(ensemble.ctx, n)       # >= 64 MiB: a block the library pinned (as the Julia shim does)
         _lib.check(L.gr_render_endpoints(ensemble.ctx.handle, C.byref(cfg), C.byref(pl), C.byref(rg),
                                          out.ctypes.data, C.byref(st)))
     elif isinstance(config.velocity, PlaneVelocity):

@@ -229,9 +229,10 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * trigger a refill, default 16); ("waves_per_simd"), ("swizzle"), ("lpt"), ("lpt_lane"), ("lds"),
  * ("precision", 64 | 32); ("pipeline", bands of the end-point return); ("hugepages", 1 [default] = large caller-owned
  * result buffers are madvise(MADV_HUGEPAGE)d before they are pre-faulted, 0 = the caller's mapping is left alone);
- * ("tangent_norm", 1 = gr_ray_tangent's step-size controller sees values AND tangents -- DiffEqBase's norm on Dual state,
- * what the reference's solves under ForwardDiff use (src/tracing/precision-solvers.jl:73-131,401-451) --, 0 [default] =
- * values only: the tangents ride on the very steps of the plain trace). */
+ * ("tangent_norm", 1 [default] = gr_ray_tangent's step-size controller sees values AND tangents -- DiffEqBase's norm on
+ * Dual state, what the reference's solves under ForwardDiff use (src/tracing/precision-solvers.jl:73-131,401-451); two
+ * independent integrators then agree on the Jacobians to 1e-6 (tests/test_oracle_tangent.py) --, 0 = values only: the
+ * tangents ride on the very steps of the plain trace and are good to ~1e-5, 4e-3 on rays through the polar axis). */
 int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
 
 /* ---- pinned result buffers (ABI 5).  The reference allocates the result of ensemble_solve_tracing_problem itself

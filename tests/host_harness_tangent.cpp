@@ -26,7 +26,7 @@ static void run(const Params& p)
     }
 }
 
-static int g_tangent_norm = 0;
+static int g_tangent_norm = 1;      // the library's default (gr_ctx: tangent_norm = 1)
 
 extern "C" {
 

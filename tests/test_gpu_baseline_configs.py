@@ -173,6 +173,18 @@ C5_TABLE = {
 }
 
 
+# Rays an fp32 run gives up on (dt < eps·t: GR_FLAG_DTMIN, status NoStatus), as a fraction of the 16 777 216 rays -- measured
+# on MI355X in round 2 (profiles/r2_parity_configs.json); the profile is built from what is left, so the fraction is part
+# of the result: asserted within x1.3.  fp64 never flags more than 44 rays of the plane (at 1e-3).
+C5_FLAGGED = {
+    (64, 1e-7): 0.0, (64, 1e-5): 0.0, (64, 1e-3): 44 / 16777216,
+    (32, 1e-6): 1737199 / 16777216,      # 10.4 %
+    (32, 1e-5): 576069 / 16777216,       #  3.4 %
+    (32, 1e-4): 48426 / 16777216,        #  0.29 %: the smallest fp32 tolerance measured with < 1 % dropped rays
+    (32, 1e-3): 370129 / 16777216,       #  2.2 %  (loose tolerance: large first steps straight into the near-horizon region)
+}
+
+
 def _c5_scene(G):
     m = G.KerrMetric(1.0, 0.998)
     u = np.array([0.0, 1000.0, math.radians(60), 0.0])
@@ -204,15 +216,62 @@ def test_config5_lineprofile_4096_precision_tolerance_sweep(G, ens):
                                     "rejected_per_ray": st["rejected_steps"] / st["rays"],
                                     "flagged_rays": st["flagged_rays"], "status_count": st["status_count"],
                                     "rays_per_s": st["rays"] / st["kernel_ms"] * 1e3}
+        out[f"fp{prec}@{tol:g}"]["flagged_fraction"] = st["flagged_rays"] / st["rays"]
         if (prec, tol) in C5_TABLE:
             t1, tinf = C5_TABLE[(prec, tol)]
             assert l1 < 1.5 * t1 and linf < 1.5 * tinf, (prec, tol, l1, linf)
+            assert st["flagged_rays"] / st["rays"] <= 1.3 * C5_FLAGGED[(prec, tol)] + 1e-5, (prec, tol, st["flagged_rays"])
     # the reference's own test of this product: edges of the profile (test/line-profiles/test-binning.jl:5-32 does
     # it for a = 0.6; for a = 0.998 at 60° the red wing reaches far lower and the blue horn sits near 1.25)
     nz = np.nonzero(ref > 1e-6)[0]
     assert C5_BINS[nz[0]] < 0.3 and 1.15 < C5_BINS[nz[-1]] < 1.4
     _record("C5_sweep_4096", out)
     print("C5", json.dumps(out))
+
+
+def test_config5_rays_dropped_by_fp32_are_captured_rays(G, ens):
+    """What the fp32 half of the sweep loses.  On the strided 512 x 512 subset of the C5 plane (every
+    8th radius and angle) the rays an fp32 @ 1e-6 trace flags (dt < eps·t, ~10 % of the plane) are traced again in fp64 @
+    1e-9 and binned on their own: their share of the line profile's flux is the error the dropped rays cause.  They are
+    rays that fp64 sees fall through the inner boundary (or skim it): the flux share is recorded and bounded."""
+    m, u, d = _c5_scene(G)
+    sub = G.PolarPlane(G.GeometricGrid(), Nr=512, Nθ=512, r_min=1.0, r_max=250.0 ** (4088.0 / 4095.0))
+    kw = dict(callback=G.domain_upper_hemisphere(), ensemble=ens)
+    rec = {}
+    p64 = G.tracegeodesics(m, u, sub, d, (0.0, 2.0 * u[1]), **kw)
+    al, be = G.impact_parameters(sub, u)
+    area = np.asarray(G.unnormalized_areas(sub)).ravel(order="F")
+    pf = G.ConstPointFunctions.redshift(m, u)
+    rho64 = p64["x"][:, 1] * np.abs(np.sin(p64["x"][:, 2]))
+    hit64 = (p64["status"] == 2) & (rho64 >= m.isco()) & (rho64 <= 250.0)
+    # redshift of the fp64 hits on the device (fused summary: g, ρ per ray)
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    tr = device_tracer(m, u, 2.0 * u[1], G.chart_for_metric(m), pf, ens, geometry=d, callback=G.domain_upper_hemisphere())
+    _, g_all = tr(al, be)
+    f64 = np.where(hit64 & np.isfinite(g_all), rho64 ** -3.0 * g_all ** 3 * area, 0.0)
+    for tol in (1e-6, 1e-4):
+        ens.set("precision", 32)
+        try:
+            p32 = G.tracegeodesics(m, u, sub, d, (0.0, 2.0 * u[1]), abstol=tol, reltol=tol, **kw)
+        finally:
+            ens.set("precision", 64)
+        flagged = (p32["flags"] & 0xFFFF) != 0
+        share = float(f64[flagged].sum() / f64.sum())
+        st64 = np.bincount(p64["status"][flagged], minlength=4).tolist()
+        rec[f"fp32@{tol:g}"] = {"flagged_fraction": float(flagged.mean()), "fp64_status_of_flagged_rays": st64,
+                                "flux_share_of_flagged_rays_in_fp64": share}
+        print(f"  fp32@{tol:g}: flagged {flagged.mean():.4f}; in fp64 these rays are {st64} (OutOfDomain, WithinInnerBoundary, "
+              f"Intersected, NoStatus); their share of the fp64 profile's flux: {share:.3e}")
+    _record("C5_fp32_dropped_rays_512_subset", rec)
+    assert 0.03 < rec["fp32@1e-06"]["flagged_fraction"] < 0.2
+    assert rec["fp32@0.0001"]["flagged_fraction"] < 0.01
+    # measured on MI355X (profiles/r3_parity_configs.json): at 1e-6 the 27 353 flagged rays of the subset are captured rays in
+    # fp64 (27 333 WithinInnerBoundary, 20 OutOfDomain, no disc hit): their flux share is exactly 0 -- the 4.1e-2 L1 of that
+    # sweep point is step-count noise of the rays that DO finish, not missing rays.  At 1e-4 (0.28 % flagged) 508 of the 733
+    # flagged rays are disc hits in fp64 and carry 0.27 % of the flux.
+    assert rec["fp32@1e-06"]["flux_share_of_flagged_rays_in_fp64"] < 1e-6
+    assert rec["fp32@0.0001"]["flux_share_of_flagged_rays_in_fp64"] < 6e-3
 
 
 def test_config5_lineprofile_matches_oracle_on_strided_512_subset(G, oracle, ens):

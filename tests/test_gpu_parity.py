@@ -173,6 +173,47 @@ def test_endpoints_returned_in_bands_equal_one_copy(G, ens):
         assert out[4][1]["rays"] == W * H
 
 
+def test_endpoints_into_a_block_the_library_pinned(G, ens, monkeypatch):
+    """gr_host_alloc / gr_host_free (ABI 5; what the Julia shim wraps as its Vector{GeodesicPoint}): the end points of a
+    2048² plane (637 MB) returned into page-locked memory are byte for byte those of the pageable call, the copy hides
+    under the trace of the later bands (device time of the whole call within 10 % of its kernels; the pageable path pays
+    ~38 %), kernel_ms and call_ms of gr_stats tell the two apart, and blocks outlive their context."""
+    import ctypes as C
+
+    from gradus_jl_amd import _lib
+
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    W = H = 2048
+    cfg = G.render_configuration(m, X_FAR, d, 2000.0, image_width=W, image_height=H, alpha_lims=ALIMS, beta_lims=BLIMS, ensemble=ens)
+    ens.set("pipeline", 4)
+    res = {}
+    for mode in ("1", "0", "1", "0"):                      # second round: warm buffers on both paths
+        monkeypatch.setenv("GRADUS_MI355X_PINNED_RESULTS", mode)
+        pts, st = G.ensemble_solve_tracing_problem(ens, cfg, stats=True)
+        res[mode] = (pts, st)
+    pinned, pageable = res["1"], res["0"]
+    assert isinstance(pinned[0].base, C.Array) or pinned[0].base is not None
+    assert pinned[0].tobytes() == pageable[0].tobytes()
+    for st in (pinned[1], pageable[1]):
+        assert 0.0 < st["kernel_ms"] <= st["call_ms"]
+    print(f"  2048² end points: pinned kernel {pinned[1]['kernel_ms']:.2f} call {pinned[1]['call_ms']:.2f} ms; "
+          f"pageable kernel {pageable[1]['kernel_ms']:.2f} call {pageable[1]['call_ms']:.2f} ms")
+    assert pinned[1]["call_ms"] < 1.10 * pinned[1]["kernel_ms"]
+    assert pinned[1]["call_ms"] < pageable[1]["call_ms"]
+    # a block survives the context that allocated it and is freed without one
+    ctx2 = _lib.Context(0)
+    blk = _lib.PinnedBlock(ctx2, 1 << 20)
+    a = blk.array(np.float64, 1 << 17)
+    a[:] = 3.0
+    ctx2.close()
+    assert float(a.sum()) == 3.0 * (1 << 17)
+    del a, blk
+    L = _lib.load()
+    assert L.gr_host_free(None, None) == 0
+    assert L.gr_host_free(None, C.c_void_p(0x1000)) == -1          # not one of ours: refused, nothing freed
+
+
 def test_endpoint_cache_kept_on_the_device(G, ens):
     """prerendergeodesics(..., keep_on_device=True): `apply` of built-in point functions runs on the records in HBM
     (gr_apply_pointfunction_device) and gives the image of the host route bit for bit; the host copy appears on first use
@@ -214,6 +255,29 @@ def test_kernels_agree_bitwise(G, ens):
     ens.set("refill_threshold", 8)
     for o in out[1:]:
         assert o.tobytes() == out[0].tobytes()
+
+
+def test_pixel_tile_shape_changes_no_ray(G, ens):
+    """8 x 8 tiles, 16 x 4 tiles (a wave's stores = four whole 128-byte lines; gr_ctx_set "tile_rows") and no tiling give
+    the same image and the same end points bit for bit, also on planes whose height fits only one of the shapes and on a
+    sharded range; the LPT tile order (persistent kernel) follows the tile shape."""
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    pf = G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    for (W, H) in ((96, 64), (64, 72), (40, 48)):          # H % 16 == 0 ; H % 8 == 0 only ; both
+        imgs, pts = [], []
+        for rows, swz, kern in ((8, 1, 0), (16, 1, 0), (8, 0, 0), (16, 1, 1)):
+            ens.set("tile_rows", rows).set("swizzle", swz).set("kernel", kern).set("lpt", 2 if kern == 1 else 1)
+            _, _, img = G.rendergeodesics(m, X_FAR, d, 2000.0, image_width=W, image_height=H, alpha_lims=ALIMS, beta_lims=BLIMS,
+                                          pf=pf, ensemble=ens)
+            _, _, cache = G.prerendergeodesics(m, X_FAR, d, 2000.0, image_width=W, image_height=H, alpha_lims=ALIMS,
+                                               beta_lims=BLIMS, ensemble=ens)
+            imgs.append(img.copy())
+            pts.append(cache.points.copy())
+        ens.set("tile_rows", 8).set("swizzle", 1).set("kernel", 2).set("lpt", 1)
+        for k in range(1, len(imgs)):
+            assert imgs[k].tobytes() == imgs[0].tobytes(), (W, H, k)
+            assert pts[k].tobytes() == pts[0].tobytes(), (W, H, k)
 
 
 def test_tracegeodesics_arrays_and_polar_counts(G, oracle, ens):

@@ -11,9 +11,13 @@ import harness as Hh
 
 pytestmark = pytest.mark.gpu
 
-GOLD = {(74, 4.0): 0.05550300700779827, (85, 4.0): 0.03602870590038378, (30, 7.0): 0.12205125501900763,
+GOLD = {(3, 4.0): 0.14048899037409682, (35, 4.0): 0.10846177995555085, (74, 4.0): 0.05550300700779827,
+        (85, 4.0): 0.03602870590038378, (30, 4.0): 0.11958152396826184, (30, 7.0): 0.12205125501900763,
         (30, 10.0): 0.1265019201038228, (30, 15.0): 0.12875961522283233, (30, 300.0): 0.13378948600255888,
         (30, 800.0): 0.13470290875241375, (30, 1000.0): 0.13319637850028626}
+# the three recorded statistics this build does not reproduce (f-4): kept in the table as STRICT xfails so that the gap is
+# visible in every GPU test record; scripts/tf_truncation_scan.py has the lead on their origin
+UNMET = {(3, 4.0), (30, 4.0), (35, 4.0)}
 
 
 @pytest.fixture()
@@ -38,7 +42,7 @@ def test_device_tangents_equal_the_host_build(G, ens):
     dev = tr.tangent(al, be)
     cfg = G.tracing_configuration(m, x, np.zeros((1, 4)), G.DatumPlane(0.0), 4000.0,
                                   chart=G.chart_for_metric(m, 2 * x[1], closest_approach=1.005))
-    host = Hh.ray_tangent(G, cfg, G.ConstPointFunctions.redshift(m, x), al, be)
+    host = Hh.ray_tangent(G, cfg, G.ConstPointFunctions.redshift(m, x), al, be)      # both sides: tangents in the norm (default)
     assert np.array_equal(dev[:, 7], host[:, 7])
     hit = dev[:, 7] == 2
     assert hit.sum() > 120
@@ -46,10 +50,18 @@ def test_device_tangents_equal_the_host_build(G, ens):
     for c in range(2, 6):
         scale = np.abs(host[hit, c]).max()
         assert np.abs(dev[hit, c] - host[hit, c]).max() < 1e-6 * scale, c
-    # and the value part is the plain kernel's answer
+    # and the value part is the plain kernel's answer: to rounding when the controller looks at values only (same steps),
+    # to the tolerance level with the tangents in the norm (the default: shorter steps where the tangents are stiff)
     pts, g = tr(al, be)
-    np.testing.assert_allclose(dev[hit, 0], g[hit], rtol=1e-8)
-    np.testing.assert_allclose(dev[hit, 1], pts["x"][hit, 1], rtol=1e-8)
+    np.testing.assert_allclose(dev[hit, 0], g[hit], rtol=1e-5)
+    np.testing.assert_allclose(dev[hit, 1], pts["x"][hit, 1], rtol=1e-5)
+    ens.set("tangent_norm", 0)
+    try:
+        same = _tracer(G, ens, m, x, 4000.0).tangent(al, be)
+    finally:
+        ens.set("tangent_norm", 1)
+    np.testing.assert_allclose(same[hit, 0], g[hit], rtol=1e-8)
+    np.testing.assert_allclose(same[hit, 1], pts["x"][hit, 1], rtol=1e-8)
 
 
 @pytest.mark.parametrize("name", ["kerr", "johannsen", "kerr-newman", "johannsen-psaltis"])
@@ -77,25 +89,78 @@ def test_device_tangents_equal_central_differences(G, ens, name):
         assert err < 5e-5 * scale, (name, c, err, scale)
 
 
-def test_reference_transfer_function_values_with_dual_numbers(G, ens):
-    """The recorded statistics (test/smoke-tests/cunningham-transfer-functions.jl:25-39, atol 1e-3) with the reference's
-    root finder and dual-number Jacobians on the device."""
+def _gold_params():
+    out = []
+    for (angle, r) in sorted(GOLD):
+        marks = [pytest.mark.xfail(strict=True, reason="recorded statistic not reproduced with the 114 samples the reference's "
+                                   "current source stores (f-4)")] if (angle, r) in UNMET else []
+        out.append(pytest.param(angle, r, marks=marks, id=f"{angle}deg-re{r:g}"))
+    return out
+
+
+@pytest.mark.parametrize("angle,r", _gold_params())
+def test_reference_transfer_function_values_with_dual_numbers(G, ens, angle, r):
+    """ALL ELEVEN recorded statistics (test/smoke-tests/cunningham-transfer-functions.jl:25-39; atol 1e-3, rtol 1e-2 for the
+    three large radii) with the reference's root finder and dual-number Jacobians on the device.  Eight are met -- six of
+    them two to four digits inside the reference's tolerance --, three are strict xfails."""
     m = G.KerrMetric(1.0, 0.998)
-    d = G.ThinDisc(0.0, float("inf"))
-    errs = {}
-    for angle in (30, 74, 85):
-        x = np.array([0.0, 100_000.0, math.radians(angle), 0.0])
-        radii = [r for (a, r) in GOLD if a == angle]
-        out = G.cunningham_transfer_functions(m, x, d, radii, N=80, ensemble=ens, root_finder="reference",
-                                              chart=G.chart_for_metric(m, 2 * x[1], closest_approach=1.005))
-        for c, r in zip(out, radii):
-            meas = float(np.sum(c.f * c.g_star) / c.f.size)
-            # the statistic moves by 1e-4 ... 3e-4 per 1e-10 of relative noise in g (its extremal samples), so two builds
-            # of the same integrator (host g++ / device hipcc contraction) differ at the 1e-4 level: 3e-4 here
-            tol = 1e-3 if (angle, r) in ((30, 15.0), (85, 4.0)) else 3e-4
-            errs[(angle, r)] = (meas - GOLD[(angle, r)], tol)
-            print(f"  ({angle}°, {r}): {meas - GOLD[(angle, r)]:+.2e}")
-    assert all(abs(e) < t for e, t in errs.values()), errs
+    x = np.array([0.0, 100_000.0, math.radians(angle), 0.0])
+    c = G.cunningham_transfer_function(m, x, G.ThinDisc(0.0, float("inf")), r, N=80, ensemble=ens, root_finder="reference",
+                                       chart=G.chart_for_metric(m, 2 * x[1], closest_approach=1.005))
+    assert c.f.size == 114 and np.all(np.isfinite(c.f))
+    meas = float(np.sum(c.f * c.g_star) / c.f.size)
+    print(f"  ({angle}°, {r}): {meas - GOLD[(angle, r)]:+.2e}")
+    if (angle, r) in UNMET:
+        assert meas == pytest.approx(GOLD[(angle, r)], abs=1e-3)          # the reference's own bound: expected to fail
+        return
+    # the statistic moves by 1e-4 ... 3e-4 per 1e-10 of relative noise in g (its extremal samples), so two builds
+    # of the same integrator (host g++ / device hipcc contraction) differ at the 1e-4 level: 3e-4 where the host build is
+    # within 1e-4, the reference's 1e-3 for (30°, 15) [+4.1e-4] and (85°, 4) [-5.5e-4]
+    tol = 1e-3 if (angle, r) in ((30, 15.0), (85, 4.0)) else 3e-4
+    assert meas == pytest.approx(GOLD[(angle, r)], abs=tol)
+
+
+def test_device_tangents_equal_the_tangent_oracle_ray_by_ray(G, ens, oracle):
+    """gr_ray_tangent pinned PER RAY against the oracle's dual-number mode (oracle/tangent_oracle.cpp: the unchanged oracle
+    source on a value + ∂/∂α + ∂/∂β scalar -- a second integrator: first-order form, library sin/cos, true divisions, its
+    own event root find and its own event-time term).  With the tangents in the error norm (default; DiffEqBase's norm on
+    Dual state) values agree to 1e-5 (5e-6 measured) and Jacobian entries to 1e-5 of their scale (1e-6 measured) on 300 rays of the transfer-function
+    geometry; with values-only control (knob 0) ordinary rays agree to 1e-4 and the Jacobian is unprotected near the
+    polar axis."""
+    a = 0.998
+    m = G.KerrMetric(1.0, a)
+    x = np.array([0.0, 100_000.0, math.radians(30), 0.0])
+    rng = np.random.default_rng(2026)
+    rr, th = rng.uniform(2.5, 14.0, 300), rng.uniform(0.0, 2 * math.pi, 300)
+    th[:4] = [math.pi / 2, math.pi / 2 + 1e-3, 3 * math.pi / 2, 0.0]         # through / next to the polar axis, and the α axis
+    al, be = rr * np.cos(th), rr * np.sin(th)
+    cfg = oracle.make_config("kerr", (1.0, a), disc={"datum": 0.0}, lambda_max=2 * x[1], closest_approach=1.005,
+                             outer_radius=2 * x[1])
+
+    def rel(dev, orc):
+        out = np.zeros(dev.shape[0])
+        for lo in (2, 4):
+            scale = np.maximum(np.abs(orc[:, lo]), np.abs(orc[:, lo + 1]))
+            out = np.maximum(out, np.max(np.abs(dev[:, lo:lo + 2] - orc[:, lo:lo + 2]), axis=1) / scale)
+        return out
+
+    res = {}
+    for norm in (1, 0):
+        ens.set("tangent_norm", norm)
+        try:
+            dev = _tracer(G, ens, m, x, 2 * x[1]).tangent(al, be)
+        finally:
+            ens.set("tangent_norm", 1)
+        orc = oracle.ray_tangent(cfg, x, al, be, r_isco=m.isco(), max_time=2 * x[1], norm_with_tangents=bool(norm))
+        assert np.array_equal(dev[:, 7], orc[:, 7])
+        hit = dev[:, 7] == 2
+        assert hit.sum() > 250
+        np.testing.assert_allclose(dev[hit, 0:2], orc[hit, 0:2], rtol=1e-5)
+        res[norm] = rel(dev[hit], orc[hit])
+    print(f"  per-ray Jacobian deviation from the tangent oracle: norm on max {res[1].max():.2e} median {np.median(res[1]):.2e}; "
+          f"values-only max {res[0].max():.2e} median {np.median(res[0]):.2e}")
+    assert res[1].max() < 1e-5 and np.median(res[1]) < 2e-6
+    assert np.median(res[0]) < 1e-4
 
 
 def test_tangent_entry_point_edges(G, ens):

@@ -78,7 +78,7 @@ def _host_tangent(G, al, be, x, lam, norm, **kw):
     try:
         return Hh.ray_tangent(G, cfg, G.ConstPointFunctions.redshift(m, x), al, be)
     finally:
-        Hh.lib_tangent().hht_set_tangent_norm(0)
+        Hh.lib_tangent().hht_set_tangent_norm(1)          # back to the default
 
 
 def _rel(a, b):

@@ -6,8 +6,9 @@ What this pins: with the reference's Newton iteration (dual-number derivative, e
 src/transfer-functions/cunningham-transfer-functions.jl:72-117 via src/tracing/precision-solvers.jl:230-330) and Jacobians
 from dual numbers through the integrator (precision-solvers.jl:401-451), the recorded statistics are reproduced to 1e-5
 ... 1e-7 wherever they are well-conditioned -- two to four digits below the reference's own tolerance.  The rₑ = 4
-values at low inclination (3°, 30°, 35°) are the ones still outside 1e-3 (by 1.85e-2, 9.5e-3, 2.1e-3); what this build
-gives there does not depend on the root finder (last test)."""
+values at low inclination (3°, 30°, 35°) are the ones still outside 1e-3 (by 1.85e-2, 9.5e-3, 2.1e-3): strict xfails
+below; what this build gives there depends neither on the root finder nor on whether the tangents enter the error norm
+(round 3: DiffEqBase's norm on Dual state, now the default, moved no statistic by more than 1e-5)."""
 import math
 
 import numpy as np
@@ -70,26 +71,43 @@ def test_low_inclination_inner_disc_is_stable_here_but_off_the_record(G, angle, 
         assert np.ptp(top) < 0.02 * np.mean(top)                     # a clean limit, not noise
 
 
-def test_the_3_degree_record_coincides_with_this_sample_set_minus_fifteen_near_g_min(G):
-    """A numerical lead on the largest gap, recorded as such: at (3°, rₑ = 4) the recorded 0.140489 is what THIS build's
-    samples give when 15 of the 17 golden-section calls of the g_min search (all with g✶ < 6e-3, i.e. ~zero terms of the
-    sum) are left out of the mean -- 114 -> 99 samples: agreement 2e-6, the level of the well-conditioned cases.  Of the 289
-    (k_min, k_max) truncations of the two searches that were tried, chance alone would produce such a match about once in
-    30, so this is suggestive, not proof.  The current source of the reference always stores 16 + 1 calls per search
-    (cunningham-transfer-functions.jl:391-429: `iterations = N`, no convergence exit is reachable at these bracket
-    widths); this build follows the source (114 samples)."""
+UNMET = [(3, 4.0), (30, 4.0), (35, 4.0)]
+
+
+@pytest.mark.parametrize("angle,re", [pytest.param(a, r, marks=pytest.mark.xfail(strict=True, reason="recorded statistic not reproduced "
+                                                   "with the 114 samples the reference's current source stores (f-4, VERDICT r2)"))
+                                      for a, r in UNMET])
+def test_unmet_reference_values_stay_visible(G, angle, re):
+    """The three recorded statistics this build does not reproduce, inside the reference's own tolerance (atol 1e-3):
+    strict xfails, so the gap shows in every test record and closing it turns the suite red until the marks go."""
+    assert measure(ctf(G, angle, [re], root_finder="reference")[0]) == pytest.approx(GOLD[(angle, re)], abs=1e-3)
+
+
+@pytest.mark.parametrize("angle,re,k_min,bound", [(3, 4.0, 2, 1e-4), (30, 4.0, 8, 1e-4), (35, 4.0, 15, 5e-4), (74, 4.0, 17, 1e-4)])
+def test_the_unmet_records_are_this_sample_set_with_a_shortened_g_min_search(G, angle, re, k_min, bound):
+    """A numerical lead, recorded as such (scripts/tf_truncation_scan.py -> profiles/r3_tf_truncation.json).  The three unmet
+    records equal THIS build's statistic when only the first k_min stored calls of the g_min golden-section search enter the
+    mean -- k_min = 2 at 3°, 8 at 30°, 15 at 35° (agreement 1e-5, 2e-5, 2e-4), 17 = all of them at 74° (4e-6) -- i.e.
+    `N = count(data.mask)` samples with N = 99, 105, 112, 114 (cunningham-transfer-functions.jl:303-334 truncates its
+    accumulator to the calls Optim's search really made).  Monotonic in the inclination, the g_max search complete in
+    every case, all three inside the reference's tolerance: a difference in HOW MANY samples the search stores, not in any
+    g or f (the f values satisfy their normalisation identity below).  The current source of the reference and Optim's
+    GoldenSection as published give 17 calls per search (`iterations = N`, no convergence exit reachable at these bracket
+    widths); what shortened the searches of the recorded run cannot be told without running it.  This build follows the
+    source: 114 samples."""
     raw = []
-    c = ctf(G, 3, [4.0], root_finder="reference", _raw=raw)[0]
-    d = raw[0][0][0]                                   # rows θ, g, J, t; columns 80..96 = the g_min search in call order
+    c = ctf(G, angle, [re], root_finder="reference", _raw=raw)[0]
     assert c.f.size == 114
+    th, g, J, t = raw[0][0][0]                          # columns 80..96 = the g_min search in call order
     keep = np.ones(114, bool)
-    keep[82:97] = False
-    g, J = d[1, keep], d[2, keep]
-    gs = (g - g.min()) / np.ptp(g)
-    f = g * np.sqrt(gs * (1 - gs)) * np.ptp(g) * J / (math.pi * 4.0)
-    assert float(np.sum(f * gs) / f.size) == pytest.approx(GOLD[(3, 4.0)], abs=1e-5)
-    full = (d[1] - d[1].min()) / np.ptp(d[1])
-    assert np.all(full[82:97] < 6e-3)
+    keep[80 + k_min:97] = False
+    gg, JJ = g[keep], J[keep]
+    gs = (gg - gg.min()) / np.ptp(gg)
+    f = gg * np.sqrt(gs * (1 - gs)) * np.ptp(gg) * JJ / (math.pi * re)
+    assert float(np.mean(f * gs)) == pytest.approx(GOLD[(angle, re)], abs=bound)
+    # the calls left out all sit at g✶ ~ 0: zero terms of the sum, only the sample count changes
+    full = (g - g.min()) / np.ptp(g)
+    assert np.all(full[80 + max(k_min, 3):97] < 6e-3)
 
 
 def test_problem_cases_with_the_reference_root_finder(G):
