@@ -87,16 +87,40 @@ __device__ __forceinline__ LdsView lds_prologue(const Params& p)
 }
 
 // one global atomic per non-empty bin per workgroup
-__device__ __forceinline__ void lds_epilogue(const Params& p, const LdsView& v)
+__device__ __forceinline__ void lds_epilogue(const Cold* cold, int lds_bins, const LdsView& v)
 {
     if (!v.hist) return;
     __syncthreads();
-    const Cold& cd = cold_of(p);
-    for (int i = threadIdx.x; i < p.lds_bins; i += blockDim.x) {
+    asm volatile("" : "+s"(cold));
+    const Cold& cd = *cold;
+    for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) {
         const double h = v.hist[i];
         if (h != 0.0) atomicAdd(cd.lp_flux + i, h);
     }
 }
+#endif
+
+// The launch parameters once more, read from the kernel-argument segment behind a pointer the optimiser cannot see through.
+// What only the code after the step loop reads (the cold-block pointer, the statistics pointer, table pointers) then takes
+// no scalar registers while the loop runs: with every Params field loaded at kernel entry the loop's hot block parked nine
+// SGPRs in vector lanes and fetched them back on EVERY step (18 of the step's non-FP64 vector instructions).
+#ifndef GR_LATE_PARAMS
+#define GR_LATE_PARAMS 1
+#endif
+#if GR_LATE_PARAMS
+// an offset of zero the optimiser cannot know to be zero (one SGPR), formed at kernel entry
+#define GR_PARAMS_OPAQUE_ZERO(z) \
+    int z = 0;                   \
+    asm volatile("" : "+s"(z));
+#define GR_PARAMS_AFTER_LOOP(p, pl, z)                                                                             \
+    const Params __attribute__((address_space(4)))* pl##_k = (const Params __attribute__((address_space(4)))*)(      \
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + z);                  \
+    Params pl = p;                                                                                                   \
+    pl.cold = pl##_k->cold;                                                                                          \
+    pl.stats = pl##_k->stats;
+#else
+#define GR_PARAMS_OPAQUE_ZERO(z)
+#define GR_PARAMS_AFTER_LOOP(p, pl, z) const Params& pl = p;
 #endif
 
 // ---- kernel 0: one ray per work-item ----
@@ -106,6 +130,7 @@ template <class Metric, int DISC>
 #endif
 __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Params p)
 {
+    GR_PARAMS_OPAQUE_ZERO(zoff)
     Metric m;
     m.load(p.cfg);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,10 +141,11 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
         const TraceColdStore cs = cold_store_of(p);
         ray.init(m, p, tile_swizzle(cold_of(p), gid));
         while (!ray.step(m, p, cs)) {}
-        ray.finalize(m, p, lds);
+        GR_PARAMS_AFTER_LOOP(p, pl, zoff)
+        ray.finalize(m, pl, lds);
         ls.add(ray);
     }
-    lds_epilogue(p, lds);
+    lds_epilogue(p.cold, p.lds_bins, lds);
     ls.flush(p.stats);
 }
 
@@ -173,7 +199,7 @@ __global__ void __launch_bounds__(256, GR_PERSISTENT_MIN_WAVES) k_trace_persiste
             }
         }
     }
-    lds_epilogue(p, lds);
+    lds_epilogue(p.cold, p.lds_bins, lds);
     ls.flush(p.stats);
 }
 

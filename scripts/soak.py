@@ -47,6 +47,7 @@ bad = []
 tot = mis = 0
 worst = 0.0
 unexplained_total = 0
+unexplained_err_scenes = 0
 for case in range(n_scenes):
     name, gen, cls = fam[int(rng.integers(0, len(fam)))]
     params = gen()
@@ -127,17 +128,27 @@ for case in range(n_scenes):
     lim_e = max(1e3 * tol, 1e-6) * (200 if name == "kerr-refractive" else 10 if name == "kerr-dark-matter" else 1)
     worst = max(worst, e2 / lim_e)
     if mism > 8 or e2 >= lim_e:
-        # conditioning: which of the mismatching rays does the ORACLE classify differently from itself when its tolerance is
-        # nudged by -10 % / +10 %?  Those are rays no two implementations agree on; what is left is unexplained.
+        # conditioning: which of the differing rays does the ORACLE trace differently from itself when its tolerance is
+        # nudged (x0.5, x0.9, x1.1, x2)?  Either the class changes, or -- rays grazing the rim of the disc -- the class stays
+        # "disc" and the crossing jumps from the rim to the far side (a position difference of order one).  Those are rays no
+        # two implementations agree on; what is left is unexplained.
         flips = np.zeros(got.size, dtype=bool)
-        for f in (0.9, 1.1):
+        for f in (0.5, 0.9, 1.1, 2.0):
             ocfg2 = oracle.make_config(name, params, disc=od, lambda_max=lam, gtol=gtol, abstol=f * tol, reltol=f * tol, upper_hemisphere=hemi, q=q)
             ref2 = oracle.trace(ocfg2, x, oracle.render_velocities(ocfg2, x, (-lim, lim), (-lim, lim), W, H), nthreads=16)
             flips |= ref2["status"] != ref["status"]
+            flips |= (np.abs(ref2["x"] - ref["x"]) / np.maximum(np.abs(ref["x"]), 1.0)).max(axis=1) > 1e-3
         unexplained = int(((got["status"] != ref["status"]) & ~flips).sum())
         unexplained_total += unexplained
-        bad.append((case, name, tuple(round(p, 4) for p in params), kind, f"mism={mism} err={e2:.2e} unexplained={unexplained} oracle-self-flips={int(flips.sum())} tol={tol} robs={r_obs:.1f} th={math.degrees(th):.1f} gtol={gtol:.4f} hemi={hemi} q={q:.2f}"))
+        okx = ok & ~flips
+        e_un = 0.0
+        if okx.any():
+            e_un = float((np.abs(got["x"][okx] - ref["x"][okx]) / np.maximum(np.abs(ref["x"][okx]), 1.0)).max())
+        if e_un >= lim_e:
+            unexplained_err_scenes += 1
+        bad.append((case, name, tuple(round(p, 4) for p in params), kind, f"mism={mism} err={e2:.2e} unexplained={unexplained} err-outside-oracle-flips={e_un:.2e} oracle-self-flips={int(flips.sum())} tol={tol} robs={r_obs:.1f} th={math.degrees(th):.1f} gtol={gtol:.4f} hemi={hemi} q={q:.2f}"))
 print(f"scenes={n_scenes} seed={seed} rays={tot} status-mismatches={mis} ({mis / max(tot, 1):.4%}) worst err/limit={worst:.3f} failing={len(bad)} "
-      f"mismatches in failing scenes the oracle does not flip itself under a 10 % tolerance nudge: {unexplained_total}")
+      f"mismatches in failing scenes the oracle does not flip itself under a tolerance nudge: {unexplained_total}; "
+      f"failing scenes whose largest end-point difference outside the oracle's own flips exceeds the limit: {unexplained_err_scenes}")
 for b in bad:
     print("  ", b)
