@@ -496,8 +496,9 @@ struct KerrFamily {
     {
         const real a2 = ka2, tM = ktM;
         const real r2 = r * r, s2 = s * s, sc = s * c;
-        const real Sig = GR_FMA(a2, c * c, r2);
-        real Del = GR_FMA(-tM, r, r2) + a2;
+        const real ra2 = r2 + a2;                                   // shared by Σ, Δ and B
+        const real Sig = GR_FMA(-a2, s2, ra2);                      // r² + a² cos²θ = (r² + a²) - a² sin²θ (no cancellation: Σ >= r²)
+        real Del = GR_FMA(-tM, r, ra2);
         if (CHARGED) Del += Q2;
         const real Ds2 = Del * s2;
         const real P = rcp_rhs(Sig * Ds2);
@@ -518,9 +519,10 @@ struct KerrFamily {
         // t-ϕ block:  T_t = ġ_tt v^t + ġ_tϕ v^ϕ = ẇ U - (a (s²)˙ w) v^ϕ ,  T_ϕ = ġ_tϕ U + ((s²)˙ B + 2 r s² v^r) v^ϕ
         const real wd = GR_FMA(2.0 * hw_r, vr, w_t * vh);           // ẇ
         const real s2d = (2.0 * sc) * vh;                           // (s²)˙
-        const real z1 = (a * s2d) * w;
+        const real aw = a * w;
+        const real z1 = aw * s2d;
         const real gtp = -(q * w);                                  // g_tϕ
-        const real B = GR_FMA(-a, gtp, r2 + a2);
+        const real B = GR_FMA(-a, gtp, ra2);
         const real gtpd = -GR_FMA(q, wd, z1);                       // ġ_tϕ
         const real Tt = GR_FMA(wd, U, -(z1 * vp));
         const real Tp = GR_FMA(gtpd, U, GR_FMA(s2d, B, (tr * s2) * vr) * vp);
@@ -537,7 +539,7 @@ struct KerrFamily {
         ar = GR_FMA(girr, in, GR_FMA(k1, vrvh, crr * vr2));
         // θ equation: -(1/Σ)(2 r v^r v^θ - sc X),  X = a²(v_θ² - v_r²/Δ + w U²/Σ) + B v_ϕ² + a w v^ϕ (a s² v^ϕ - 2 v^t)
         const real W1 = GR_FMA(-2.0, vt, q * vp);
-        real X = GR_FMA((a * w) * vp, W1, B * vp2);
+        real X = GR_FMA(aw * vp, W1, B * vp2);
         X = GR_FMA(a2, GR_FMA(wiS, U2, GR_FMA(-vr2, iDel, vh2)), X);
         ah = iSig * GR_FMA(sc, X, -(tr * vrvh));
         if (CHARGED) {
@@ -585,12 +587,14 @@ struct JohannsenMetric {
     static constexpr int kMinWavesPerSimd = 2;
     static constexpr int kLaneWavesPerSimd = 2;
     real M, a, a13, a22, a52, e3;
-    real ka2, ktM, keM3, km3a13, km2a22, km2a52;     // a², 2M, ϵ3 M³, -3 α13, -2 α22, -2 α52: uniform, formed once (rhs)
+    real ka2, ktM, keM3;                             // a², 2M, ϵ3 M³: uniform, formed once (rhs)
+    real kA1, kA2, kA5, kA1r, kA2r, kA5r;            // α13 M³, α22 M², α52 M² and -3, -2, -2 times them: A_i = 1 + kA_i / r^n
     GR_DEV void load(const gr_config& c)
     {
         M = c.params[0]; a = c.params[1]; a13 = c.params[2]; a22 = c.params[3]; a52 = c.params[4]; e3 = c.params[5];
         ka2 = uni(a * a); ktM = uni(2.0 * M); keM3 = uni(e3 * M * M * M);
-        km3a13 = uni(-3.0 * a13); km2a22 = uni(-2.0 * a22); km2a52 = uni(-2.0 * a52);
+        kA1 = uni(a13 * (M * M * M)); kA2 = uni(a22 * (M * M)); kA5 = uni(a52 * (M * M));
+        kA1r = uni(-3.0 * (a13 * (M * M * M))); kA2r = uni(-2.0 * (a22 * (M * M))); kA5r = uni(-2.0 * (a52 * (M * M)));
     }
 
     GR_DEV void comps(real r, real s, real c, real g[5]) const
@@ -679,11 +683,13 @@ struct JohannsenMetric {
                     real& at, real& ar, real& ah, real& ap) const
     {
         const real a2 = ka2, tM = ktM, eM3 = keM3;
+        // A_i = 1 + α (M/r)^n with the powers of M folded into uniform factors: nine instructions for the three functions
+        // and their r-derivatives (twelve when (M/r)^n is formed first)
         const real ir = rcp_rhs(r);
-        const real Mr = M * ir, Mr2 = Mr * Mr, Mr3 = Mr2 * Mr;
-        const real A1 = GR_FMA(a13, Mr3, 1.0), A2 = GR_FMA(a22, Mr2, 1.0), A5 = GR_FMA(a52, Mr2, 1.0);
-        const real A1r = km3a13 * Mr3 * ir, A2r = km2a22 * Mr2 * ir, A5r = km2a52 * Mr2 * ir;
-        const real r2 = r * r, s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
+        const real ir2 = ir * ir, ir3 = ir2 * ir, ir4 = ir2 * ir2;
+        const real A1 = GR_FMA(kA1, ir3, 1.0), A2 = GR_FMA(kA2, ir2, 1.0), A5 = GR_FMA(kA5, ir2, 1.0);
+        const real A1r = kA1r * ir4, A2r = kA2r * ir3, A5r = kA5r * ir3;
+        const real r2 = r * r, s2 = s * s, sc = s * c, S2 = 2.0 * sc, tr = 2.0 * r;
         const real eir = eM3 * ir;
         const real Sig = GR_FMA(a2, c * c, r2) + eir;
         const real Sig_r = GR_FMA(-eir, ir, tr);
@@ -704,7 +710,7 @@ struct JohannsenMetric {
         const real iN = ie1 * DA5, iDA5 = ie1 * N, iSig = ie2 * s2;
         const real iDel = A5 * iDA5;
         const real c2 = (iN * iN) * iDel;                           // F/(ΣΔ) = 1/(N²Δ)
-        const real c3 = c2 * (ie2 * Sig);                           // F/(ΣΔs²)
+        const real is2 = ie2 * Sig;                                 // 1/s²
         const real F = Sig * (iN * iN);
         // the three functions of the t-ϕ block and their r-derivatives
         const real aA2 = a2s2 * A2;
@@ -722,12 +728,13 @@ struct JohannsenMetric {
         const real lt = -GR_FMA(T, vt, (aQ * s2) * vp);
         const real lp = s2 * GR_FMA(P, vp, -(aQ * vt));
         const real Phi = GR_FMA(lt, vt, lp * vp);
-        const real kr = GR_FMA(Sig_r, iSig, -2.0 * (N_r * iN));
-        const real kth = a2 * GR_FMA(2.0 * A2, iN, -iSig);          // κ_θ/S2
-        const real vt2 = vt * vt, vp2 = vp * vp, vtp = vt * vp, vr2 = vr * vr, vh2 = vh * vh, vrvh = vr * vh;
+        const real iN2 = iN + iN;
+        const real kr = GR_FMA(-N_r, iN2, Sig_r * iSig);
+        const real kth = a2 * GR_FMA(A2, iN2, -iSig);               // κ_θ/S2
+        const real vt2 = vt * vt, vp2 = vp * vp, tvtp = (vt + vt) * vp, vr2 = vr * vr, vh2 = vh * vh, vrvh = vr * vh;
         const real aQr_s2 = (a * Q_r) * s2;
-        const real Phi_r = GR_FMA(s2 * P_r, vp2, -GR_FMA(T_r, vt2, (2.0 * aQr_s2) * vtp));
-        const real phith = GR_FMA(Pth, vp2, GR_FMA(a2A22, vt2, -(2.0 * aQ) * vtp));
+        const real Phi_r = GR_FMA(s2 * P_r, vp2, -GR_FMA(T_r, vt2, aQr_s2 * tvtp));
+        const real phith = GR_FMA(Pth, vp2, GR_FMA(a2A22, vt2, -(aQ * tvtp)));
         // r equation
         const real grr = Sig * iDA5;
         const real grr_r = GR_FMA(-grr, DA5_r, Sig_r) * iDA5;
@@ -738,7 +745,7 @@ struct JohannsenMetric {
         ar = -((DA5 * iSig) * br);
         // θ equation
         const real FDh = GR_FMA(F, GR_FMA(kth, Phi, phith), a2 * GR_FMA(-iDA5, vr2, vh2));
-        ah = -(iSig * GR_FMA(-0.5 * S2, FDh, Sig_r * vrvh));
+        ah = -(iSig * GR_FMA(-sc, FDh, Sig_r * vrvh));
         // t and ϕ equations
         const real S2vh = S2 * vh;
         const real Td = GR_FMA(T_r, vr, -(a2A22 * S2vh));
@@ -751,7 +758,7 @@ struct JohannsenMetric {
         const real taut = GR_FMA(kd, lt, ltd);
         const real taup = GR_FMA(kd, lp, lpd);
         at = c2 * GR_FMA(P, taut, aQ * taup);
-        ap = GR_FMA(c2 * aQ, taut, -((c3 * T) * taup));
+        ap = c2 * GR_FMA(aQ, taut, -((T * is2) * taup));             // g^ϕϕ = T/(ΣΔs²)
     }
 };
 
@@ -773,11 +780,13 @@ struct GenericMetricT {
     static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS);      // rhs() below
     int32_t id;
     real P[6];
+    real ka2, ktM, keps;      // Johannsen-Psaltis rhs(): a², 2M, ϵ3 M³ -- uniform, formed once
     GR_DEV void load(const gr_config& c)
     {
         id = ID >= 0 ? ID : c.metric_id;
 #pragma unroll
         for (int i = 0; i < 6; ++i) P[i] = c.params[i];
+        ka2 = uni(P[1] * P[1]); ktM = uni(2.0 * P[0]); keps = uni(P[2] * P[0] * P[0] * P[0]);
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
     static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
@@ -1031,15 +1040,15 @@ struct GenericMetricT {
     GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
                     real& at, real& ar, real& ah, real& ap) const
     {
-        const real M = P[0], a = P[1];
-        const real a2 = a * a, tM = 2.0 * M, eps = P[2] * M * M * M;
+        const real a = P[1];
+        const real a2 = ka2, tM = ktM, eps = keps;
         const real r2 = r * r, s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
-        const real Sig = GR_FMA(a2, c * c, r2);
-        const real iSig = rcp_rhs(Sig);
-        const real Del = GR_FMA(-tM, r, r2) + a2;
         const real rho2 = r2 + a2;
         const real a2S2 = a2 * S2;                         // -Σ_θ
         const real a2s2 = a2 * s2;
+        const real Sig = rho2 - a2s2;                      // r² + a² cos²θ (Σ >= r²: no cancellation)
+        const real iSig = rcp_rhs(Sig);
+        const real Del = GR_FMA(-tM, r, rho2);
         // w, h, η and their gradients
         const real w = (tM * r) * iSig;
         const real w_r = iSig * GR_FMA(-w, tr, tM);
@@ -1370,7 +1379,8 @@ struct Params {
     double wedge;             // asin(gtol) with a hair of slack: |θ - π/2| beyond it cannot hit the disc
     double dtmax;             // |λ1 - λ0|, formed once on the host instead of once per step per lane
     int32_t tangent_norm;     // tangent build only: 1 = the error norm runs over values AND tangents (gr_ctx_set "tangent_norm")
-    int32_t _pad_tn;
+    int32_t lds_points;       // one-ray-per-lane kernel, end-point output: 1 = a wave's 152-B records leave through LDS as whole
+                              // runs (POINT_UNITS doubles + one address slot per lane behind the other LDS regions)
 };
 
 // the derived fields of Params, from cfg (host side; one place for the library and the two host harnesses)
@@ -1393,7 +1403,11 @@ struct LdsView {
     const double* pl_vr;
     const double* pl_vp;
     double* hist;
+    double* point;            // this lane's record inside its wave's region (POINT_UNITS doubles), or null: direct stores
+    uint64_t* point_addr;     // this lane's slot for the record's destination address (0 = nothing to store)
 };
+constexpr int POINT_UNITS = 19;     // sizeof(gr_point) / 8
+static_assert(sizeof(gr_point) == 8 * POINT_UNITS, "gr_point is 19 eight-byte units");
 
 // read the cold block through a pointer the optimiser cannot hoist loads from
 GR_DEV const Cold& cold_of(const Params& p)
@@ -1554,9 +1568,12 @@ GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const 
 constexpr int COLD_SLOTS = 9;      // 8-byte slots per lane
 struct NoColdStore {
     static constexpr bool kOn = false;
+    static constexpr bool kHead = false;
 };
-struct LdsColdStore {
-    static constexpr bool kOn = true;
+template <bool HEAD>
+struct LdsColdStoreT {
+    static constexpr bool kOn = true;       // parked around the event sampling (the rarely taken branch)
+    static constexpr bool kHead = HEAD;     // ... and across the whole hot region of every step
     static constexpr int kStride = 64;     // one wave per region: slot k of the wave's lanes is one conflict-free 512-byte row,
                                            // and k * 512 is an immediate offset of the ds instruction (no address arithmetic)
     double* lane;        // this lane's slot 0 inside its wave's region; slot k is lane[k * 64]
@@ -1580,6 +1597,8 @@ struct LdsColdStore {
 #endif
     }
 };
+typedef LdsColdStoreT<true> LdsColdStore;
+typedef LdsColdStoreT<false> LdsColdStoreRare;
 
 // ---------------------------------------------------------------------------------------
 // The per-lane integrator.
@@ -1920,7 +1939,7 @@ struct Ray {
         h = hh;
         const real h2 = hh * hh;
         const bool resync = (nacc & 63) == 63;      // full sin/cos at the new state (decided while nacc is in a register)
-        if constexpr (Cold_::kOn) {
+        if constexpr (Cold_::kHead) {
             // park what the hot region does not read (see LdsColdStore)
             cs.template st<real>(0, t);
             cs.template st<real>(1, dt);
@@ -2002,7 +2021,7 @@ struct Ray {
 #else
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);
 #endif
-        if constexpr (Cold_::kOn) {
+        if constexpr (Cold_::kHead) {
             Cold_::fence();
             t = cs.template ld<real>(0);
             dt = cs.template ld<real>(1);
@@ -2413,7 +2432,10 @@ struct Ray {
         if (cd.out_mode == 1) {
             real x0[4], v0[4];
             constrained_u0(m, p, j, x0, v0);
-            gr_point* o = cd.points + j;
+            // with lds.point the record is laid down in LDS and the wave sends all 64 as runs of consecutive
+            // addresses afterwards (gr_kernels.hpp, points_epilogue); without it each lane stores its own 152 bytes
+            gr_point* o = lds.point ? reinterpret_cast<gr_point*>(lds.point) : cd.points + j;
+            if (lds.point) *lds.point_addr = (uint64_t)(cd.points + j);
             o->status = status;
             o->flags = flags;
             o->lambda_min = p.cfg.lambda0;

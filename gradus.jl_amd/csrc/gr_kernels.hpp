@@ -51,7 +51,11 @@ extern __shared__ double gr_lds[];
 #error "the cold lane storage is written for the fp64 / fp32 scalars and the fp32 controller"
 #endif
 #if GR_COLD_LDS
+#if GR_COLD_LDS == 2
+typedef LdsColdStoreRare TraceColdStore;      // parked around the event sampling only: nothing on the path of every step
+#else
 typedef LdsColdStore TraceColdStore;
+#endif
 __device__ __forceinline__ TraceColdStore cold_store_of(const Params& p)
 {
     // wave w of the workgroup owns doubles [w * 64 * COLD_SLOTS, (w + 1) * 64 * COLD_SLOTS) of the region
@@ -65,10 +69,22 @@ __device__ __forceinline__ TraceColdStore cold_store_of(const Params&) { return 
 constexpr size_t kColdLdsBytesPerThread = 0;
 #endif
 
+// bytes of LDS per work-item of the end-point region: its record and its address slot
+constexpr size_t kPointLdsBytesPerThread = sizeof(double) * (POINT_UNITS + 1);
+
 __device__ __forceinline__ LdsView lds_prologue(const Params& p)
 {
-    LdsView v{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    LdsView v{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     const int bins = p.lds_bins, rows = p.lds_plunge_rows;
+    if (p.lds_points) {
+        // wave w owns (POINT_UNITS + 1) * 64 doubles: 64 records back to back (lane stride 19 doubles = 38 banks: the
+        // 64-bit accesses of a half wave fall on 32 distinct bank pairs), then the 64 address slots
+        const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        double* reg = gr_lds + bins + 4 * rows + (kColdLdsBytesPerThread / sizeof(double)) * blockDim.x + w * (64 * (POINT_UNITS + 1));
+        v.point = reg + l * POINT_UNITS;
+        v.point_addr = reinterpret_cast<uint64_t*>(reg + 64 * POINT_UNITS + l);
+        *v.point_addr = 0;
+    }
     if (bins == 0 && rows == 0) return v;
     const Cold& cd = cold_of(p);
     double* hist = gr_lds;
@@ -84,6 +100,29 @@ __device__ __forceinline__ LdsView lds_prologue(const Params& p)
     if (bins) v.hist = hist;
     if (rows) { v.pl_r = tab; v.pl_vt = tab + rows; v.pl_vr = tab + 2 * rows; v.pl_vp = tab + 3 * rows; }
     return v;
+}
+
+// The wave's 64 end-point records, written to LDS by finalize(), leave as 19 store instructions of 64 consecutive 8-byte
+// units each: unit u of the region belongs to record u / 19, and wherever neighbouring lanes hold neighbouring rays (eight
+// rows of a column in an 8 x 8 tile = 1216 bytes, the whole 9.7 KB in ray order) consecutive units are consecutive
+// addresses -- whole 64- and 128-byte segments instead of 64 eight-byte pieces 152 bytes apart per instruction.  That is
+// what makes a destination in pinned HOST memory practical (the stores cross PCIe as full-size packets) and takes the
+// write excess out of the HBM path.  Every lane of the workgroup calls this (uniform control flow).
+__device__ __forceinline__ void points_epilogue(const LdsView& v)
+{
+    if (!v.point) return;
+    __syncthreads();
+    const unsigned l = threadIdx.x & 63;
+    const double* reg = v.point - l * POINT_UNITS;
+    const uint64_t* addr = reinterpret_cast<const uint64_t*>(reg + 64 * POINT_UNITS);
+#pragma unroll
+    for (int t = 0; t < POINT_UNITS; ++t) {
+        const unsigned u = l + 64u * t;
+        const unsigned rec = (u * 3450u) >> 16;          // u / 19 for u < 1216 (checked exhaustively, tests/test_host_api.py)
+        const unsigned f = u - rec * POINT_UNITS;
+        const uint64_t base = addr[rec];
+        if (base) reinterpret_cast<double*>(base)[f] = reg[u];
+    }
 }
 
 // one global atomic per non-empty bin per workgroup
@@ -145,6 +184,7 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
         ray.finalize(m, pl, lds);
         ls.add(ray);
     }
+    points_epilogue(lds);
     lds_epilogue(p.cold, p.lds_bins, lds);
     ls.flush(p.stats);
 }
@@ -283,7 +323,9 @@ template <class Metric, int DISC>
 hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
     const int block = k.block;
-    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows) + kColdLdsBytesPerThread * (size_t)block;
+    if (k.kernel != 0) p.lds_points = 0;     // the persistent kernel refills lanes one by one: no wave-wide moment to send records
+    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows) + kColdLdsBytesPerThread * (size_t)block
+                       + (p.lds_points ? kPointLdsBytesPerThread * (size_t)block : 0);
 #ifdef GR_LANE_ONLY
     {
 #else

@@ -116,6 +116,8 @@ struct gr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_k = nullptr;             // end of the last trace kernel of a host call (gr_stats.kernel_ms vs call_ms)
     int64_t hugepages = 1;                 // madvise(MADV_HUGEPAGE) on large caller-owned result buffers before pre-faulting
+    int64_t lds_points = 1;                // one-ray-per-lane kernel: a wave's end-point records leave through LDS as whole runs
+    int64_t direct_host = 1;               // gr_render_endpoints into a gr_host_alloc block: the kernel stores across the link itself
     int64_t tangent_norm = 1;              // tangent kernels: the tangents are part of the error norm (DiffEqBase on Dual state); 0 = values only
     // LPT state for one (config, plane, range) key
     std::vector<unsigned char> lpt_key;
@@ -365,6 +367,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
                          && cold_in.pf.n_plunge > 0
                          && cold_in.pf.n_plunge <= lds_rows_max) ? (int32_t)cold_in.pf.n_plunge : 0;
     p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
+    p.lds_points = (ctx->lds_points && cold.out_mode == 1 && kern_sel == 0) ? 1 : 0;
     derive_params(p);
     LaunchKnobs knobs{ kern_sel, block_sel, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
@@ -585,6 +588,10 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->hugepages = value ? 1 : 0;
     } else if (k == "tangent_norm") {
         c->tangent_norm = value ? 1 : 0;
+    } else if (k == "lds_points") {
+        c->lds_points = value ? 1 : 0;
+    } else if (k == "direct_host") {
+        c->direct_host = value ? 1 : 0;
     } else {
         return fail(GR_ERR_INVALID_ARGUMENT, "unknown knob '" + k + "'");
     }
@@ -1144,6 +1151,17 @@ int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, co
     return GR_OK;
 }
 
+// would this end-point render run on the one-ray-per-lane kernel (the one whose waves send whole runs of records)?
+static bool endpoints_on_lane_kernel(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range)
+{
+    if (validate_cfg(cfg) != GR_OK || validate_plane(plane, range) != GR_OK) return false;   // the regular path reports it
+    Params p;
+    Cold cd;
+    plane_params(ctx, p, cd, cfg, plane, range);
+    cd.out_mode = 1;
+    return resolve_kernel(ctx, range->count, cd) == 0;
+}
+
 int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
                             gr_point* points, gr_stats* stats)
 {
@@ -1157,6 +1175,19 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     // A contiguous range of a large plane goes out in bands of whole 8-column tile strips: band k is copied back on a
     // second stream while bands k+1.. are traced (2048²: 20 ms of kernel + 15 ms of copy become 25 ms), and the
     // destination's pages are faulted in by helper threads meanwhile.
+    // Into a block the library pinned (gr_host_alloc) the kernel stores the records itself: one launch, no staging copy in
+    // HBM, no copy engine.  The wave-transposed stores (points_epilogue) cross the link as full-size packets, 637 MB spread
+    // over the 20 ms of the 2048² trace is about half the link's rate, and the call ends when the kernel does.
+    if (ctx->direct_host && ctx->lds_points && bytes && is_pinned(ctx, points) && endpoints_on_lane_kernel(ctx, cfg, plane, range)) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, points, 0) == hipSuccess && dp) {
+            if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+            if ((rc = gr_render_endpoints_device(ctx, cfg, plane, range, (gr_point*)dp,
+                                                 stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+            return end_host_call(ctx, stats);
+        }
+        (void)hipGetLastError();
+    }
     const bool contiguous = plane && (range->stride_blocks == 1 || range->count <= range->block);
     const int64_t unit = plane ? 8 * plane->height : 0;
     const int nb = (contiguous && unit > 0 && range->first % unit == 0) ? band_count(ctx, range->count, unit, is_pinned(ctx, points)) : 1;

@@ -232,7 +232,11 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * ("tangent_norm", 1 [default] = gr_ray_tangent's step-size controller sees values AND tangents -- DiffEqBase's norm on
  * Dual state, what the reference's solves under ForwardDiff use (src/tracing/precision-solvers.jl:73-131,401-451); two
  * independent integrators then agree on the Jacobians to 1e-6 (tests/test_oracle_tangent.py) --, 0 = values only: the
- * tangents ride on the very steps of the plain trace and are good to ~1e-5, 4e-3 on rays through the polar axis). */
+ * tangents ride on the very steps of the plain trace and are good to ~1e-5, 4e-3 on rays through the polar axis);
+ * ("lds_points", 1 [default] = the one-ray-per-lane kernel sends a wave's 64 end-point records through LDS as runs of
+ * consecutive addresses, 0 = every lane stores its own 152 bytes; same bytes either way); ("direct_host", 1 [default] =
+ * gr_render_endpoints into a gr_host_alloc block lets the kernel store across the link itself -- no staging buffer, no
+ * copy --, 0 = staged in HBM and copied in bands as for caller-owned memory). */
 int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
 
 /* ---- pinned result buffers (ABI 5).  The reference allocates the result of ensemble_solve_tracing_problem itself

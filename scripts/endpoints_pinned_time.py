@@ -33,14 +33,24 @@ out = {"size": N, "bytes": n * 152}
 call(np.zeros(n, dtype=_lib.POINT_DTYPE))                  # context warm-up (allocations, first launch)
 blk = _lib.PinnedBlock(ens.ctx, n * 152)
 pinned = blk.array(_lib.POINT_DTYPE, n)
-out["pinned"] = [call(pinned) for _ in range(5)]
+out["pinned"] = [call(pinned) for _ in range(5)]                   # the kernel stores across the link itself (direct_host, default)
+ens.set("direct_host", 0)
+pinned2 = _lib.PinnedBlock(ens.ctx, n * 152)
+banded = pinned2.array(_lib.POINT_DTYPE, n)
+out["pinned_banded"] = [call(banded) for _ in range(5)]            # staging buffer in HBM, bands on two streams, copy engine
+assert pinned.tobytes() == banded.tobytes()
+ens.set("lds_points", 0)
+out["pinned_banded_lane_stores"] = [call(banded) for _ in range(5)]   # ... with each lane storing its own 152 bytes
+assert pinned.tobytes() == banded.tobytes()
+ens.set("lds_points", 1)
+ens.set("direct_host", 1)
 warm = np.zeros(n, dtype=_lib.POINT_DTYPE)
 warm[:] = 0                                                   # pages exist
 out["pageable_warm"] = [call(warm) for _ in range(5)]
 out["pageable_fresh"] = [call(np.empty(n, dtype=_lib.POINT_DTYPE)) for _ in range(5)]
 ref = warm.copy()
 assert pinned.tobytes() == ref.tobytes()
-for k in ("pinned", "pageable_warm", "pageable_fresh"):
+for k in ("pinned", "pinned_banded", "pinned_banded_lane_stores", "pageable_warm", "pageable_fresh"):
     a = np.array(out[k])
-    print(f"{k:15s} wall {np.median(a[:, 0]):7.2f} ms   kernel_ms {np.median(a[:, 1]):7.2f}   call_ms {np.median(a[:, 2]):7.2f}")
+    print(f"{k:26s} wall {np.median(a[:, 0]):7.2f} ms   kernel_ms {np.median(a[:, 1]):7.2f}   call_ms {np.median(a[:, 2]):7.2f}")
 print(json.dumps(out))

@@ -214,6 +214,88 @@ def test_endpoints_into_a_block_the_library_pinned(G, ens, monkeypatch):
     assert L.gr_host_free(None, C.c_void_p(0x1000)) == -1          # not one of ours: refused, nothing freed
 
 
+def _render_points(G, ens, cfg, first=0, count=None, into=None):
+    """gr_render_endpoints on a range of the plane, as records (optionally into a caller-supplied array)"""
+    import ctypes as C
+
+    from gradus_jl_amd import _lib
+
+    acfg, pl = cfg.abi_config(), cfg.abi_plane()
+    n = pl.width * pl.height
+    count = n - first if count is None else count
+    rg = _lib.gr_range(first, count, max(count, 1), 1)
+    pts = np.zeros(count, dtype=_lib.POINT_DTYPE) if into is None else into
+    st = _lib.gr_stats()
+    _lib.check(_lib.load().gr_render_endpoints(ens.ctx.handle, C.byref(acfg), C.byref(pl), C.byref(rg), pts.ctypes.data, C.byref(st)))
+    return pts, st
+
+
+def _trace_points(G, ens, cfg, xs, vs):
+    """array inputs through gr_trace_endpoints, as records"""
+    import ctypes as C
+
+    from gradus_jl_amd import _lib
+
+    acfg = cfg.abi_config()
+    n = vs.shape[0]
+    pts = np.zeros(n, dtype=_lib.POINT_DTYPE)
+    xs, vs = np.ascontiguousarray(xs), np.ascontiguousarray(vs)
+    _lib.check(_lib.load().gr_trace_endpoints(ens.ctx.handle, C.byref(acfg), xs.ctypes.data, 4, vs.ctypes.data, n, pts.ctypes.data, None))
+    return pts
+
+
+def test_endpoint_records_sent_by_the_wave_equal_per_lane_stores(G, ens):
+    """End-point records of the one-ray-per-lane kernel leave through LDS, a wave's 64 records as runs of consecutive
+    addresses (gr_kernels.hpp points_epilogue; gr_ctx_set "lds_points", default 1) -- byte for byte what each lane storing its
+    own 152 bytes produces: tiled planes, planes whose height is no multiple of 8, a ragged last wave, a range that starts
+    inside the plane, array inputs; and into a block the library pinned the kernel's own stores across the link
+    ("direct_host", default 1) equal the staged, banded copy."""
+    from gradus_jl_amd import _lib
+
+    m = G.KerrMetric(1.0, 0.9)
+    d = G.ThinDisc(m.isco(), 40.0)
+    x = np.array([0.0, 800.0, math.radians(70), 0.0])
+    kw = dict(alpha_lims=(-30, 30), beta_lims=(-20, 20), ensemble=ens)
+
+    def both(fn):
+        out = []
+        for v in (1, 0):
+            ens.set("lds_points", v)
+            out.append(fn())
+        ens.set("lds_points", 1)
+        assert out[0].tobytes() == out[1].tobytes()
+        return out[0]
+
+    for (W, H) in ((96, 80), (37, 29), (64, 1), (1, 200)):
+        cfg = G.render_configuration(m, x, d, 1600.0, image_width=W, image_height=H, **kw)
+        pts = both(lambda: _render_points(G, ens, cfg)[0])
+        assert pts.size == W * H and (pts["status"] > 0).all()
+        n0 = (W * H) // 3
+        sub = both(lambda: _render_points(G, ens, cfg, first=n0)[0])
+        assert sub.tobytes() == pts[n0:].tobytes()
+    # array inputs, n not a multiple of 64: the directions of a 40 x 25 plane, ray by ray
+    cfga = G.render_configuration(m, x, d, 1600.0, image_width=40, image_height=25, **kw)
+    ref = _render_points(G, ens, cfga)[0]
+    got = both(lambda: _trace_points(G, ens, cfga, ref["x_init"], ref["v_init"]))
+    assert got.size == 1000
+    np.testing.assert_array_equal(got["status"], ref["status"])
+    np.testing.assert_allclose(got["x"], ref["x"], rtol=1e-9, atol=1e-9)
+    # pinned destination: the kernel's own stores across the link against staged bands
+    Wb = Hb = 1536
+    cfgb = G.render_configuration(m, x, d, 1600.0, image_width=Wb, image_height=Hb, **kw)
+    nb = Wb * Hb
+    res = []
+    for v in (1, 0):
+        ens.set("direct_host", v)
+        blk = _lib.PinnedBlock(ens.ctx, nb * 152)
+        a, st = _render_points(G, ens, cfgb, into=blk.array(_lib.POINT_DTYPE, nb))
+        res.append((blk, a, st.kernel_ms, st.call_ms))
+    ens.set("direct_host", 1)
+    assert res[0][1].tobytes() == res[1][1].tobytes()
+    print(f"  {Wb}² end points into pinned memory: direct kernel {res[0][2]:.2f} call {res[0][3]:.2f} ms; "
+          f"banded kernel {res[1][2]:.2f} call {res[1][3]:.2f} ms")
+
+
 def test_endpoint_cache_kept_on_the_device(G, ens):
     """prerendergeodesics(..., keep_on_device=True): `apply` of built-in point functions runs on the records in HBM
     (gr_apply_pointfunction_device) and gives the image of the host route bit for bit; the host copy appears on first use

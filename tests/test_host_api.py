@@ -167,3 +167,12 @@ def test_header_is_plain_c_and_library_refuses_without_a_device(G, tmp_path):
         assert rc.returncode == 0, rc.stdout + rc.stderr
     else:
         assert rc.returncode == 3 and "no HIP device" in rc.stdout, rc.stdout + rc.stderr
+
+
+def test_record_index_of_an_lds_unit():
+    """points_epilogue (gr_kernels.hpp) maps unit u of a wave's 64 x 19 end-point units to its record with (u * 3450) >> 16:
+    exact for every unit, and sizeof(gr_point) is 19 eight-byte units."""
+    from gradus_jl_amd import _lib
+
+    assert _lib.POINT_DTYPE.itemsize == 19 * 8
+    assert all((u * 3450) >> 16 == u // 19 for u in range(64 * 19))
