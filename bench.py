@@ -282,6 +282,25 @@ def main():
                      "definition": "SURVEY §8(d): rays completed / wall time of the blocking ABI call, H2D/D2H included, "
                                    "ctx creation excluded",
                      "kernel_ms_last": hst.kernel_ms, "kernel_plus_copy_ms_last": hst.call_ms}
+        # the same call into an image the library pinned (gr_host_alloc): the kernel stores across the link itself
+        blk = _lib.PinnedBlock(ens.ctx, 8 * n_all)
+        pin_img = blk.array(np.float64, n_all)
+
+        def pinned_step():
+            _lib.check(L.gr_render(ens.ctx.handle, C.byref(acfg), C.byref(apl), C.byref(apf), C.byref(arg_rg),
+                                   pin_img.ctypes.data, C.byref(hst)))
+
+        pinned_step()
+        assert pin_img.tobytes() == host_img.tobytes()
+        psteps = max(args.steps // 5, 1)
+        tp0 = time.perf_counter()
+        for _ in range(psteps):
+            pinned_step()
+        tp = time.perf_counter() - tp0
+        host_call["into_pinned_image"] = {"value": n_all * psteps / tp, "ms_per_step": tp / psteps * 1e3, "steps": psteps,
+                                          "entry": "gr_render into a gr_host_alloc block: no staging image, no copy",
+                                          "kernel_ms_last": hst.kernel_ms, "call_ms_last": hst.call_ms}
+        del pin_img, blk
 
     launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # start -> end of one launch on its own stream
     # with two renders in flight consecutive launches overlap pairwise: the duration that prices a launch is then

@@ -397,6 +397,7 @@ struct KerrFamily {
     // the rarely executed event-sampling blocks, none on the step's main path; the third wave hides the dependent
     // FP64 chains that two waves leave exposed: 22.95 -> 21.97 ms on the 2048² image (profiles/r2_ab_variants.txt)
     static constexpr int kLaneWavesPerSimd = CHARGED ? 2 : 3;
+    static constexpr bool kColdRare = !CHARGED;                // at the register cap: the event sampling parks in LDS (gr_kernels.hpp)
     real M, a;
     real Q, Q2, qm;      // CHARGED only: charge, its square, test-particle q (or q/μ)
     real ka2, ktM, kta2; // a², 2M, 2a²: uniform, formed once (rhs)
@@ -495,8 +496,8 @@ struct KerrFamily {
                     real& at, real& ar, real& ah, real& ap) const
     {
         const real a2 = ka2, tM = ktM;
-        const real r2 = r * r, s2 = s * s, sc = s * c;
-        const real ra2 = r2 + a2;                                   // shared by Σ, Δ and B
+        const real s2 = s * s, sc = s * c;
+        const real ra2 = GR_FMA(r, r, a2);                          // r² + a²: shared by Σ, Δ and B
         const real Sig = GR_FMA(-a2, s2, ra2);                      // r² + a² cos²θ = (r² + a²) - a² sin²θ (no cancellation: Σ >= r²)
         real Del = GR_FMA(-tM, r, ra2);
         if (CHARGED) Del += Q2;
@@ -689,16 +690,16 @@ struct JohannsenMetric {
         const real ir2 = ir * ir, ir3 = ir2 * ir, ir4 = ir2 * ir2;
         const real A1 = GR_FMA(kA1, ir3, 1.0), A2 = GR_FMA(kA2, ir2, 1.0), A5 = GR_FMA(kA5, ir2, 1.0);
         const real A1r = kA1r * ir4, A2r = kA2r * ir3, A5r = kA5r * ir3;
-        const real r2 = r * r, s2 = s * s, sc = s * c, S2 = 2.0 * sc, tr = 2.0 * r;
+        const real s2 = s * s, sc = s * c, S2 = 2.0 * sc, tr = 2.0 * r;
         const real eir = eM3 * ir;
-        const real Sig = GR_FMA(a2, c * c, r2) + eir;
+        const real rho2 = GR_FMA(r, r, a2);                         // r² + a²: shared by Σ, Δ and K
+        const real a2s2 = a2 * s2;
+        const real Sig = (rho2 - a2s2) + eir;                       // r² + a² cos²θ + ϵ3 M³/r
         const real Sig_r = GR_FMA(-eir, ir, tr);
-        const real Del = GR_FMA(-tM, r, r2) + a2;
+        const real Del = GR_FMA(-tM, r, rho2);
         const real Del_r = tr - tM;
-        const real rho2 = r2 + a2;
         const real K = rho2 * A1;
         const real K_r = GR_FMA(rho2, A1r, tr * A1);
-        const real a2s2 = a2 * s2;
         const real N = GR_FMA(-a2s2, A2, K);
         const real N_r = GR_FMA(-a2s2, A2r, K_r);
         const real DA5 = Del * A5;
@@ -1042,8 +1043,8 @@ struct GenericMetricT {
     {
         const real a = P[1];
         const real a2 = ka2, tM = ktM, eps = keps;
-        const real r2 = r * r, s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
-        const real rho2 = r2 + a2;
+        const real s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;
+        const real rho2 = GR_FMA(r, r, a2);
         const real a2S2 = a2 * S2;                         // -Σ_θ
         const real a2s2 = a2 * s2;
         const real Sig = rho2 - a2s2;                      // r² + a² cos²θ (Σ >= r²: no cancellation)

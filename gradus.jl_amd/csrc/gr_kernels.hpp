@@ -4,6 +4,7 @@
 #pragma once
 
 #include "gr_device.hpp"
+#include <type_traits>
 
 namespace GR_NS {
 namespace {
@@ -40,38 +41,59 @@ struct LaneStats {
 #ifndef GR_HOST_HARNESS
 extern __shared__ double gr_lds[];
 
-// Cold lane storage (gr_device.hpp, LdsColdStore): -DGR_COLD_LDS=1 builds the trace kernels with it.  OFF by default:
-// measured on MI355X (profiles/r3c_ab_cold_store.txt) it removes every scratch access of the Kerr kernel (0 B instead of
-// 64 B per lane) at no gain in time (20.40 vs 20.31 ms) and costs 1.7 % on Johannsen at 2 waves per SIMD; it is kept as the
-// instrument that attributes the kernel's HBM write excess to scratch.
+// Cold lane storage (gr_device.hpp, LdsColdStoreT): LDS as the place for what a block of the step does not read.
+//   GR_COLD_LDS = 3 (default): around the EVENT SAMPLING only (taken in ~2 % of the wave-steps), for the metrics that run at
+//                 the 168-register cap (Metric::kColdRare: Kerr).  The sampling block needs a dozen registers of its own; left to
+//                 the compiler they are made by spilling to scratch, whose write-back was 113 of the 147 MB the bench kernel
+//                 sent to HBM per launch.  Parked in LDS instead: 50.7 MB written (1.5 x the 33.6 MB image), same time
+//                 (19.22 vs 19.19 ms, profiles/r3h_*).
+//   GR_COLD_LDS = 2: the same for every metric;  1: additionally across the hot region of EVERY step (the round-3 instrument
+//                 that attributed the write excess: no scratch at all, +1.3 % time, 1.7 % on Johannsen);  0: off.
+// The tangent scalar and the fp64-controller build do not fit the 8-byte slots: off there.
 #ifndef GR_COLD_LDS
+#if defined(GR_REAL_IS_TAN2) || defined(GR_CONTROLLER_F64)
 #define GR_COLD_LDS 0
+#else
+#define GR_COLD_LDS 3
+#endif
 #endif
 #if GR_COLD_LDS && (defined(GR_REAL_IS_TAN2) || defined(GR_CONTROLLER_F64))
 #error "the cold lane storage is written for the fp64 / fp32 scalars and the fp32 controller"
 #endif
-#if GR_COLD_LDS
-#if GR_COLD_LDS == 2
-typedef LdsColdStoreRare TraceColdStore;      // parked around the event sampling only: nothing on the path of every step
+template <class Metric, class = void>
+struct ColdRareOf { static constexpr bool value = false; };
+template <class Metric>
+struct ColdRareOf<Metric, decltype((void)Metric::kColdRare)> { static constexpr bool value = Metric::kColdRare; };
+
+template <class Metric, bool LANE_KERNEL = true>      // the persistent kernel runs below the register cap: nothing to park
+struct ColdSel {
+#if GR_COLD_LDS == 1
+    typedef LdsColdStore type;
+#elif GR_COLD_LDS == 2
+    typedef LdsColdStoreRare type;
+#elif GR_COLD_LDS == 3
+    typedef typename std::conditional<LANE_KERNEL && ColdRareOf<Metric>::value, LdsColdStoreRare, NoColdStore>::type type;
 #else
-typedef LdsColdStore TraceColdStore;
+    typedef NoColdStore type;
 #endif
-__device__ __forceinline__ TraceColdStore cold_store_of(const Params& p)
+    static constexpr size_t kBytesPerThread = type::kOn ? sizeof(double) * COLD_SLOTS : 0;
+};
+template <class Store>
+__device__ __forceinline__ Store cold_store_of(const Params& p)
 {
-    // wave w of the workgroup owns doubles [w * 64 * COLD_SLOTS, (w + 1) * 64 * COLD_SLOTS) of the region
-    const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    return TraceColdStore{ gr_lds + p.lds_bins + 4 * p.lds_plunge_rows + w * (64 * COLD_SLOTS) + l };
+    if constexpr (Store::kOn) {
+        // wave w of the workgroup owns doubles [w * 64 * COLD_SLOTS, (w + 1) * 64 * COLD_SLOTS) of the region
+        const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        return Store{ gr_lds + p.lds_bins + 4 * p.lds_plunge_rows + w * (64 * COLD_SLOTS) + l };
+    } else {
+        return Store{};
+    }
 }
-constexpr size_t kColdLdsBytesPerThread = sizeof(double) * COLD_SLOTS;
-#else
-typedef NoColdStore TraceColdStore;
-__device__ __forceinline__ TraceColdStore cold_store_of(const Params&) { return TraceColdStore{}; }
-constexpr size_t kColdLdsBytesPerThread = 0;
-#endif
 
 // bytes of LDS per work-item of the end-point region: its record and its address slot
 constexpr size_t kPointLdsBytesPerThread = sizeof(double) * (POINT_UNITS + 1);
 
+template <size_t COLD_BYTES_PER_THREAD>
 __device__ __forceinline__ LdsView lds_prologue(const Params& p)
 {
     LdsView v{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -80,7 +102,10 @@ __device__ __forceinline__ LdsView lds_prologue(const Params& p)
         // wave w owns (POINT_UNITS + 1) * 64 doubles: 64 records back to back (lane stride 19 doubles = 38 banks: the
         // 64-bit accesses of a half wave fall on 32 distinct bank pairs), then the 64 address slots
         const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
-        double* reg = gr_lds + bins + 4 * rows + (kColdLdsBytesPerThread / sizeof(double)) * blockDim.x + w * (64 * (POINT_UNITS + 1));
+        // a one-wave workgroup reuses the cold lane storage's bytes (that is dead once the step loop has ended); with
+        // several waves per workgroup another wave may still be stepping, so the records get their own region
+        const unsigned cold_doubles = blockDim.x == 64 ? 0u : (unsigned)(COLD_BYTES_PER_THREAD / sizeof(double)) * blockDim.x;
+        double* reg = gr_lds + bins + 4 * rows + cold_doubles + w * (64 * (POINT_UNITS + 1));
         v.point = reg + l * POINT_UNITS;
         v.point_addr = reinterpret_cast<uint64_t*>(reg + 64 * POINT_UNITS + l);
         *v.point_addr = 0;
@@ -174,10 +199,10 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
     m.load(p.cfg);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     LaneStats<Metric, DISC> ls;
-    const LdsView lds = lds_prologue(p);
+    const LdsView lds = lds_prologue<ColdSel<Metric>::kBytesPerThread>(p);
     if (gid < p.n) {
         Ray<Metric, DISC> ray;
-        const TraceColdStore cs = cold_store_of(p);
+        const typename ColdSel<Metric>::type cs = cold_store_of<typename ColdSel<Metric>::type>(p);
         ray.init(m, p, tile_swizzle(cold_of(p), gid));
         while (!ray.step(m, p, cs)) {}
         GR_PARAMS_AFTER_LOOP(p, pl, zoff)
@@ -203,8 +228,8 @@ __global__ void __launch_bounds__(256, GR_PERSISTENT_MIN_WAVES) k_trace_persiste
     bool active = false, pending = false, queue_empty = false;
     const int lane = threadIdx.x & 63;
     const int threshold = p.refill_threshold;
-    const LdsView lds = lds_prologue(p);
-    const TraceColdStore cs = cold_store_of(p);
+    const LdsView lds = lds_prologue<ColdSel<Metric, false>::kBytesPerThread>(p);
+    const typename ColdSel<Metric, false>::type cs = cold_store_of<typename ColdSel<Metric, false>::type>(p);
 
     for (;;) {
         const unsigned long long act = __ballot(active);
@@ -324,8 +349,11 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
     const int block = k.block;
     if (k.kernel != 0) p.lds_points = 0;     // the persistent kernel refills lanes one by one: no wave-wide moment to send records
-    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows) + kColdLdsBytesPerThread * (size_t)block
-                       + (p.lds_points ? kPointLdsBytesPerThread * (size_t)block : 0);
+    const size_t cold_b = (k.kernel == 0 ? ColdSel<Metric, true>::kBytesPerThread : ColdSel<Metric, false>::kBytesPerThread) * (size_t)block;
+    const size_t point_b = p.lds_points ? kPointLdsBytesPerThread * (size_t)block : 0;
+    // one-wave workgroups: the end-point records reuse the cold lane storage (lds_prologue)
+    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows)
+                       + (block == 64 ? (cold_b > point_b ? cold_b : point_b) : cold_b + point_b);
 #ifdef GR_LANE_ONLY
     {
 #else

@@ -1097,6 +1097,18 @@ static int32_t end_host_call(gr_ctx* ctx, gr_stats* stats)
     return GR_OK;
 }
 
+// would this render of a plane run on the one-ray-per-lane kernel (whose waves store whole runs: 64-byte image segments of an
+// 8 x 8 tile, 1216-byte runs of end-point records)?  Only those stores are worth sending across the link directly.
+static bool plane_on_lane_kernel(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range, int out_mode)
+{
+    if (validate_cfg(cfg) != GR_OK || validate_plane(plane, range) != GR_OK) return false;   // the regular path reports it
+    Params p;
+    Cold cd;
+    plane_params(ctx, p, cd, cfg, plane, range);
+    cd.out_mode = out_mode;
+    return resolve_kernel(ctx, range->count, cd) == 0;
+}
+
 int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,
                   const gr_range* range, double* image, gr_stats* stats)
 {
@@ -1106,6 +1118,17 @@ int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, cons
     GR_HIP(hipSetDevice(ctx->device));      // before any allocation: ensure() mallocs on the current device
     int32_t rc;
     const size_t bytes = sizeof(double) * (size_t)(range->count > 0 ? range->count : 0);
+    // an image in a block the library pinned is written by the kernel itself (as gr_render_endpoints does): no D2H copy
+    if (ctx->direct_host && bytes && is_pinned(ctx, image) && plane_on_lane_kernel(ctx, cfg, plane, range, 0)) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, image, 0) == hipSuccess && dp) {
+            if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+            if ((rc = gr_render_device(ctx, cfg, plane, pf, range, (double*)dp,
+                                       stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+            return end_host_call(ctx, stats);
+        }
+        (void)hipGetLastError();
+    }
     if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
     if ((rc = gr_render_device(ctx, cfg, plane, pf, range, (double*)ctx->d_scratch,
@@ -1151,17 +1174,6 @@ int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, co
     return GR_OK;
 }
 
-// would this end-point render run on the one-ray-per-lane kernel (the one whose waves send whole runs of records)?
-static bool endpoints_on_lane_kernel(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range)
-{
-    if (validate_cfg(cfg) != GR_OK || validate_plane(plane, range) != GR_OK) return false;   // the regular path reports it
-    Params p;
-    Cold cd;
-    plane_params(ctx, p, cd, cfg, plane, range);
-    cd.out_mode = 1;
-    return resolve_kernel(ctx, range->count, cd) == 0;
-}
-
 int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
                             gr_point* points, gr_stats* stats)
 {
@@ -1178,7 +1190,7 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     // Into a block the library pinned (gr_host_alloc) the kernel stores the records itself: one launch, no staging copy in
     // HBM, no copy engine.  The wave-transposed stores (points_epilogue) cross the link as full-size packets, 637 MB spread
     // over the 20 ms of the 2048² trace is about half the link's rate, and the call ends when the kernel does.
-    if (ctx->direct_host && ctx->lds_points && bytes && is_pinned(ctx, points) && endpoints_on_lane_kernel(ctx, cfg, plane, range)) {
+    if (ctx->direct_host && ctx->lds_points && bytes && is_pinned(ctx, points) && plane_on_lane_kernel(ctx, cfg, plane, range, 1)) {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, points, 0) == hipSuccess && dp) {
             if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;

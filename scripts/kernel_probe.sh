@@ -15,7 +15,7 @@ cat > /tmp/probe/probe.hip <<EOT
 using namespace gr;
 template __global__ void gr::$K<$M, $D>(const Params);
 EOT
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -disable-machine-licm -S --cuda-device-only "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -disable-machine-licm -ffp-contract=on -S --cuda-device-only "$@" \
       -o /tmp/probe/probe.s /tmp/probe/probe.hip 2>&1 | grep -v "hip-link" || true
 grep -E "amdhsa_next_free_vgpr|amdhsa_next_free_sgpr|amdhsa_private_segment_fixed_size" /tmp/probe/probe.s | tr -s '\t ' ' ' | paste -sd' '
 python3 "$ROOT/scripts/asm_blocks.py" /tmp/probe/probe.s

@@ -214,6 +214,38 @@ def test_endpoints_into_a_block_the_library_pinned(G, ens, monkeypatch):
     assert L.gr_host_free(None, C.c_void_p(0x1000)) == -1          # not one of ours: refused, nothing freed
 
 
+def test_image_into_a_block_the_library_pinned(G, ens):
+    """gr_render into an image allocated with gr_host_alloc: the kernel stores the pixels across the link itself (no
+    staging image, no copy; "direct_host") -- the bytes of the staged call, for a whole plane and for a range of it."""
+    import ctypes as C
+
+    from gradus_jl_amd import _lib
+    from gradus_jl_amd.rendering import abi_pointfunction
+
+    m = G.KerrMetric(1.0, 0.9)
+    x = np.array([0.0, 800.0, math.radians(70), 0.0])
+    W, H = 264, 200
+    cfg = G.render_configuration(m, x, G.ThinDisc(m.isco(), 40.0), 1600.0, image_width=W, image_height=H,
+                                 alpha_lims=(-30, 30), beta_lims=(-20, 20), ensemble=ens)
+    pf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+    acfg, apl = cfg.abi_config(), cfg.abi_plane()
+    apf, keep = abi_pointfunction(pf)
+    L = _lib.load()
+    for first, count in ((0, W * H), (8 * H, 40 * H)):
+        rg = _lib.gr_range(first, count, count, 1)
+        plain = np.full(count, -7.0)
+        blk = _lib.PinnedBlock(ens.ctx, 8 * count)
+        pinned = blk.array(np.float64, count)
+        pinned[:] = -7.0
+        st = _lib.gr_stats()
+        _lib.check(L.gr_render(ens.ctx.handle, C.byref(acfg), C.byref(apl), C.byref(apf), C.byref(rg), plain.ctypes.data, C.byref(st)))
+        _lib.check(L.gr_render(ens.ctx.handle, C.byref(acfg), C.byref(apl), C.byref(apf), C.byref(rg), pinned.ctypes.data, C.byref(st)))
+        assert st.rays == count
+        assert pinned.tobytes() == plain.tobytes()
+        assert np.isfinite(plain).sum() > 0.05 * count
+        del pinned, blk
+
+
 def _render_points(G, ens, cfg, first=0, count=None, into=None):
     """gr_render_endpoints on a range of the plane, as records (optionally into a caller-supplied array)"""
     import ctypes as C
@@ -1410,6 +1442,8 @@ def test_batched_saved_paths(G, oracle, ens):
         assert abs((paths[j].λ.size - 2) - int(st["accepted"][0])) <= 2
     for j, p in enumerate(paths):
         assert p.point["status"] == ends["status"][j]
+        # the path kernel and the end-point kernel are two instantiations of one source, built with -ffp-contract=on: the
+        # same roundings, bit for bit
         np.testing.assert_array_equal(p.x[-1], ends["x"][j])
         np.testing.assert_array_equal(p.v[-1], ends["v"][j])
         assert p.λ[0] == 0.0 and np.all(np.diff(p.λ) > 0) and p.λ[-1] == ends["lambda_max"][j]
