@@ -337,6 +337,14 @@ def main():
                         "profile": src, "profile_kernel": summ["kernel"], "profile_source_sha16": summ["source_sha16"],
                         "profile_avg_ms": summ["avg_ms"], "profile_timed_calls": summ.get("timed_calls"),
                         "traffic": traffic or None}
+            # the FP64 pipe's own currency: FP64 wave-instructions issued per second against the bare pure-FMA stream of the
+            # calibration (the resource that saturates here; a flop-based fraction falls when executed flops are REMOVED)
+            cnt = summ.get("counters", {})
+            n64 = sum(cnt.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64",
+                                                "SQ_INSTS_VALU_TRANS_F64"))
+            if n64:
+                per_ray64 = n64 / summ["rays_per_launch"]
+                executed["fp64_wave_insts_per_s"] = rays_launch * per_ray64 / (kernel_ms * 1e-3)
         else:
             sys.stderr.write(f"bench.py: roofline.frac withheld: {src}\n")
             executed = {"achieved": None, "frac": None, "traffic": None, "profile": None, "profile_error": src}
@@ -357,7 +365,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r3_valu_calib.json")) as f:
                 cal = json.load(f)["calib_fma_f64"]
-            sustained = {"tflops": cal["bare_wave_inst_per_s"] * 128.0 / 1e12, "clock_ghz_under_counters": cal["clock_ghz"],
+            sustained = {"tflops": cal["bare_wave_inst_per_s"] * 128.0 / 1e12, "bare_wave_insts_per_s": cal["bare_wave_inst_per_s"],
+                         "clock_ghz_under_counters": cal["clock_ghz"],
                          "simd_cycles_per_inst_under_counters": cal["simd_cycles_per_valu_inst"],
                          "source": "profiles/r3_valu_calib.json (calib_fma_f64)"}
         except Exception:      # noqa: BLE001
@@ -407,6 +416,12 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": executed["frac"],
                 "sustained_fma_stream": sustained,
+                "fp64_issue": ({"achieved": executed.get("fp64_wave_insts_per_s"), "sustained_pure_fma_stream": sustained.get("bare_wave_insts_per_s"),
+                                "frac": executed["fp64_wave_insts_per_s"] / sustained["bare_wave_insts_per_s"],
+                                "unit": "FP64 wave-instructions/s",
+                                "note": "how busy the FP64 pipe is in its own currency: instructions, not flops (49 % of the kernel's FP64 "
+                                        "instructions are multiplies / adds / reciprocals worth one flop)"}
+                               if (sustained and sustained.get("bare_wave_insts_per_s") and executed.get("fp64_wave_insts_per_s")) else None),
                 "frac_of_sustained_fma_stream": (executed["achieved"] / sustained["tflops"]) if (sustained and executed["achieved"]) else None,
                 "kernel_ms": kernel_ms,
                 "launch_ms": launch_ms,

@@ -508,8 +508,8 @@ struct KerrFamily {
         const real iDel = iDs * s2;          // 1/Δ
         const real tr = 2.0 * r;
         const real n = CHARGED ? GR_FMA(tM, r, -Q2) : tM * r;       // 2Mr - Q²
-        const real wiS = n * (iSig * iSig);                         // w/Σ
         const real w = n * iSig;
+        const real wiS = w * iSig;                                  // w/Σ
         const real hw_r = GR_FMA(-r, wiS, M * iSig);                // ½ ∂_r w = (MΣ - r n)/Σ²
         const real mSig_t = kta2 * sc;                              // -∂_θ Σ
         const real w_t = wiS * mSig_t;                              // ∂_θ w = -w ∂_θΣ/Σ
@@ -527,24 +527,21 @@ struct KerrFamily {
         const real gtpd = -GR_FMA(q, wd, z1);                       // ġ_tϕ
         const real Tt = GR_FMA(wd, U, -(z1 * vp));
         const real Tp = GR_FMA(gtpd, U, GR_FMA(s2d, B, (tr * s2) * vr) * vp);
-        const real gitp = gtp * iDs;                                // g^tϕ
-        const real gipp = (1.0 - w) * iDs;                          // g^ϕϕ
-        const real BiD = B * iDel;                                  // -g^tt
-        at = GR_FMA(BiD, Tt, -(gitp * Tp));                         // -(g^tt T_t + g^tϕ T_ϕ)
-        ap = -GR_FMA(gitp, Tt, gipp * Tp);
+        // the inverse t-ϕ block is (-B s², g_tϕ; g_tϕ, 1 - w) / (Δ s²): the common factor is applied once per component
+        at = iDs * GR_FMA(B * s2, Tt, -(gtp * Tp));                 // -(g^tt T_t + g^tϕ T_ϕ)
+        ap = -(iDs * GR_FMA(gtp, Tt, GR_FMA(-w, Tp, Tp)));          // -(g^tϕ T_t + g^ϕϕ T_ϕ)
         // r equation: -g^rr (ġ_rr v^r - ½ D_r) with g^rr ½∂_r g_rr = r/Σ - (r - M)/Δ and ∂_θ g_rr = ∂_θΣ/Δ
-        const real girr = Del * iSig;
-        const real crr = GR_FMA(-r, iSig, (r - M) * iDel);
-        const real k1 = mSig_t * iSig;
+        // = (1/Σ)(Δ in - ∂_θΣ v^r v^θ - r v_r²) + (r - M) v_r²/Δ: 1/Σ applied once, v_r²/Δ shared with the θ equation
+        const real vr2iD = vr2 * iDel;
         const real in = GR_FMA(hw_r, U2, r * GR_FMA(s2, vp2, vh2));
-        ar = GR_FMA(girr, in, GR_FMA(k1, vrvh, crr * vr2));
+        ar = GR_FMA(iSig, GR_FMA(Del, in, GR_FMA(mSig_t, vrvh, -(r * vr2))), (r - M) * vr2iD);
         // θ equation: -(1/Σ)(2 r v^r v^θ - sc X),  X = a²(v_θ² - v_r²/Δ + w U²/Σ) + B v_ϕ² + a w v^ϕ (a s² v^ϕ - 2 v^t)
-        const real W1 = GR_FMA(-2.0, vt, q * vp);
-        real X = GR_FMA(aw * vp, W1, B * vp2);
-        X = GR_FMA(a2, GR_FMA(wiS, U2, GR_FMA(-vr2, iDel, vh2)), X);
+        const real W1n = U + vt;                                    // -(a s² v^ϕ - 2 v^t) = U + v^t
+        real X = GR_FMA(-(aw * vp), W1n, B * vp2);
+        X = GR_FMA(a2, GR_FMA(wiS, U2, vh2 - vr2iD), X);
         ah = iSig * GR_FMA(sc, X, -(tr * vrvh));
         if (CHARGED) {
-            real gi[5] = { -BiD, girr, iSig, gipp, gitp };
+            real gi[5] = { -(B * iDel), Del * iSig, iSig, ((real)1.0 - w) * iDs, gtp * iDs };      // g^tt, g^rr, g^θθ, g^ϕϕ, g^tϕ
             add_force(r, s, c, gi, vt, vr, vh, vp, at, ar, ah, ap);
         }
     }
