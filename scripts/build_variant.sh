@@ -30,7 +30,7 @@ else:
 import __graft_entry__ as g
 units = g.hip_units(extra)
 if metrics and rev == "WORK":
-    keep = {f"kernels_m{m}.o" for m in metrics.split()} | {"gradus_mi355x.o"}
+    keep = {f"kernels_m{m}.o" for m in metrics.split()} | {f"kernels32_m{m}.o" for m in metrics.split()} | {"gradus_mi355x.o"}
     for o, _, _ in units:
         if o not in keep:
             shutil.copy(os.path.join(root, "gradus.jl_amd", "csrc", o), os.path.join(src, o))
@@ -38,7 +38,7 @@ if metrics and rev == "WORK":
 else:
     units_c = units
 g.compile_units(units_c, src, src, force=True)
-subprocess.check_call([g._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [os.path.join(src, o) for o, _, _ in units])
+subprocess.check_call([g._hipcc(), "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-o", out] + [os.path.join(src, o) for o, _, _ in units])
 shutil.rmtree(tmp)
 print("built", out)
 PY
