@@ -545,6 +545,37 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     return GR_OK;
 }
 
+// Pinned result blocks are registered process-wide, not per context: the caller's array (a Julia Vector with a finalizer)
+// may outlive the context that allocated it, and finalizers run in no particular order.
+//
+// Page-locking is expensive -- hipHostMalloc of the 608 MiB end-point block of a 2048² plane takes 113-365 ms and hipHostFree
+// 75 ms (scripts/host_alloc_time.py), ten times the call the block serves -- so freed blocks go to a small process-wide POOL and
+// the next gr_host_alloc of a similar size takes one from there: a caller that renders repeatedly and lets go of the previous
+// result pays the page-locking once.  Bounded (4 blocks, 4 GiB in all by default: gr_ctx_set(ctx, "pinned_pool_mib", MiB); 0
+// empties and disables it); a pooled block is handed out for requests between half its size and its size.
+namespace {
+std::mutex g_pinned_mutex;
+std::vector<std::pair<void*, size_t>> g_pinned;      // blocks handed out: base, true size
+std::vector<std::pair<void*, size_t>> g_pool;        // page-locked blocks waiting for the next gr_host_alloc
+size_t g_pool_cap = (size_t)4 << 30;
+constexpr size_t kPoolBlocks = 4;
+
+size_t pool_bytes_locked()
+{
+    size_t t = 0;
+    for (const auto& q : g_pool) t += q.second;
+    return t;
+}
+// release pooled blocks until the pool fits `cap` (call with g_pinned_mutex held; hipHostFree outside would be nicer but trims are rare)
+void pool_trim_locked(size_t cap)
+{
+    while (!g_pool.empty() && (pool_bytes_locked() > cap || g_pool.size() > kPoolBlocks)) {
+        (void)hipHostFree(g_pool.front().first);
+        g_pool.erase(g_pool.begin());
+    }
+}
+}
+
 int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
 {
     if (!c || !key) return fail(GR_ERR_INVALID_ARGUMENT, "ctx/key is null");
@@ -592,31 +623,45 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->lds_points = value ? 1 : 0;
     } else if (k == "direct_host") {
         c->direct_host = value ? 1 : 0;
+    } else if (k == "pinned_pool_mib") {
+        if (value < 0) return fail(GR_ERR_INVALID_ARGUMENT, "pinned_pool_mib must be non-negative");
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        g_pool_cap = (size_t)value << 20;          // process-wide, like the blocks themselves
+        pool_trim_locked(g_pool_cap);
     } else {
         return fail(GR_ERR_INVALID_ARGUMENT, "unknown knob '" + k + "'");
     }
     return GR_OK;
 }
 
-// Pinned result blocks are registered process-wide, not per context: the caller's array (a Julia Vector with a finalizer)
-// may outlive the context that allocated it, and finalizers run in no particular order.
-namespace {
-std::mutex g_pinned_mutex;
-std::vector<std::pair<void*, size_t>> g_pinned;
-}  // namespace
-
 int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out)
 {
     if (!ctx || !out) return fail(GR_ERR_INVALID_ARGUMENT, "ctx/out is null");
     *out = nullptr;
     if (bytes < 0) return fail(GR_ERR_INVALID_ARGUMENT, "bytes must be non-negative");
+    const size_t want = (size_t)(bytes > 0 ? bytes : 1);
+    try {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        // best fit among the pooled blocks that are large enough and not more than twice as large
+        auto best = g_pool.end();
+        for (auto it = g_pool.begin(); it != g_pool.end(); ++it)
+            if (it->second >= want && it->second / 2 <= want && (best == g_pool.end() || it->second < best->second)) best = it;
+        if (best != g_pool.end()) {
+            g_pinned.push_back(*best);
+            *out = best->first;
+            g_pool.erase(best);
+            return GR_OK;
+        }
+    } catch (...) {
+        return fail(GR_ERR_OUT_OF_MEMORY, "gr_host_alloc: registry");
+    }
     GR_HIP(hipSetDevice(ctx->device));
     void* p = nullptr;
     // page-locked and mapped for every device (hipHostMallocPortable): a multi-device render may copy into one block
-    GR_HIP(hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocPortable));
+    GR_HIP(hipHostMalloc(&p, want, hipHostMallocPortable));
     try {
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
-        g_pinned.emplace_back(p, (size_t)(bytes > 0 ? bytes : 1));
+        g_pinned.emplace_back(p, want);
     } catch (...) {
         (void)hipHostFree(p);
         return fail(GR_ERR_OUT_OF_MEMORY, "gr_host_alloc: registry");
@@ -628,11 +673,26 @@ int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out)
 int32_t gr_host_free(gr_ctx* /* may be NULL or already destroyed: not dereferenced */, void* p)
 {
     if (!p) return GR_OK;
+    size_t size = 0;
     {
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
         auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const std::pair<void*, size_t>& q) { return q.first == p; });
         if (it == g_pinned.end()) return fail(GR_ERR_INVALID_ARGUMENT, "pointer was not allocated by gr_host_alloc");
+        size = it->second;
         g_pinned.erase(it);
+        // every entry point that writes a block is blocking, so nothing targets it any more: it can wait for the next request
+        if (size <= g_pool_cap) {
+            // the newest block is the likeliest to be asked for again: older ones make room (least recently freed first)
+            while (!g_pool.empty() && (g_pool.size() >= kPoolBlocks || pool_bytes_locked() + size > g_pool_cap)) {
+                (void)hipHostFree(g_pool.front().first);
+                g_pool.erase(g_pool.begin());
+            }
+            try {
+                g_pool.emplace_back(p, size);
+                return GR_OK;
+            } catch (...) {
+            }
+        }
     }
     GR_HIP(hipHostFree(p));      // waits for work that still targets the block
     return GR_OK;

