@@ -548,29 +548,74 @@ int32_t gr_ctx_destroy(gr_ctx* c)
 // Pinned result blocks are registered process-wide, not per context: the caller's array (a Julia Vector with a finalizer)
 // may outlive the context that allocated it, and finalizers run in no particular order.
 //
-// Page-locking is expensive -- hipHostMalloc of the 608 MiB end-point block of a 2048² plane takes 113-365 ms and hipHostFree
-// 75 ms (scripts/host_alloc_time.py), ten times the call the block serves -- so freed blocks go to a small process-wide POOL and
-// the next gr_host_alloc of a similar size takes one from there: a caller that renders repeatedly and lets go of the previous
-// result pays the page-locking once.  Bounded (4 blocks, 4 GiB in all by default: gr_ctx_set(ctx, "pinned_pool_mib", MiB); 0
-// empties and disables it); a pooled block is handed out for requests between half its size and its size.
+// How a block is made (round 3, scripts/microbench/host_register_thp.hip on the GPU box, 608 MiB = the end points of a 2048² plane):
+//   hipHostMalloc 122-365 ms, hipHostFree 82-97 ms -- page-locking 155 000 4-KiB pages, ten times the call the block serves;
+//   mmap + MADV_HUGEPAGE + first touch from 8 threads 11-12 ms, hipHostRegister (Portable | Mapped) of those 304 huge pages
+//   1.3 ms, hipHostUnregister 0.0 ms, munmap 28-42 ms; device-to-host copies and the kernel's own stores reach the same
+//   56 GB/s either way.
+// So blocks of 8 MiB and more are anonymous mappings on transparent huge pages that the library registers (13 ms instead of
+// 122-365); smaller ones, and any block for which one of those steps fails, come from hipHostMalloc as before.
+// Freed blocks still go to a small process-wide POOL first and the next gr_host_alloc of a similar size takes one from there
+// (no cost at all).  Bounded (4 blocks, 4 GiB in all by default: gr_ctx_set(ctx, "pinned_pool_mib", MiB); 0 empties and
+// disables it); a pooled block is handed out for requests between half its size and its size.
 namespace {
+struct PinnedMem {
+    void* p;          // what the caller holds
+    size_t size;      // usable bytes
+    void* map;        // base of the anonymous mapping (null: the block came from hipHostMalloc)
+    size_t map_len;
+};
 std::mutex g_pinned_mutex;
-std::vector<std::pair<void*, size_t>> g_pinned;      // blocks handed out: base, true size
-std::vector<std::pair<void*, size_t>> g_pool;        // page-locked blocks waiting for the next gr_host_alloc
+std::vector<PinnedMem> g_pinned;      // blocks handed out
+std::vector<PinnedMem> g_pool;        // page-locked blocks waiting for the next gr_host_alloc
 size_t g_pool_cap = (size_t)4 << 30;
 constexpr size_t kPoolBlocks = 4;
+constexpr size_t kHugeMin = (size_t)8 << 20;
+
+void prefault_threads(char* base, size_t bytes);     // below: first touch from up to 8 threads
+
+bool pinned_make(size_t want, PinnedMem& out)
+{
+    if (want >= kHugeMin) {
+        const size_t two = (size_t)2 << 20, len = (want + two - 1) / two * two;
+        void* m = mmap(nullptr, len + two, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            char* al = (char*)(((size_t)m + two - 1) / two * two);
+            (void)madvise(al, len, MADV_HUGEPAGE);          // refused or unavailable: 4-KiB pages, a slower registration, same result
+            prefault_threads(al, len);
+            if (hipHostRegister(al, len, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
+                out = PinnedMem{ al, len, m, len + two };
+                return true;
+            }
+            (void)hipGetLastError();
+            (void)munmap(m, len + two);
+        }
+    }
+    void* p = nullptr;
+    // page-locked and mapped for every device (hipHostMallocPortable): a multi-device render may write into one block
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) return false;
+    out = PinnedMem{ p, want, nullptr, 0 };
+    return true;
+}
+hipError_t pinned_release(const PinnedMem& b)
+{
+    if (!b.map) return hipHostFree(b.p);      // waits for work that still targets the block
+    const hipError_t e = hipHostUnregister(b.p);
+    (void)munmap(b.map, b.map_len);
+    return e;
+}
 
 size_t pool_bytes_locked()
 {
     size_t t = 0;
-    for (const auto& q : g_pool) t += q.second;
+    for (const auto& q : g_pool) t += q.size;
     return t;
 }
-// release pooled blocks until the pool fits `cap` (call with g_pinned_mutex held; hipHostFree outside would be nicer but trims are rare)
+// release pooled blocks until the pool fits `cap` (call with g_pinned_mutex held; trims are rare)
 void pool_trim_locked(size_t cap)
 {
     while (!g_pool.empty() && (pool_bytes_locked() > cap || g_pool.size() > kPoolBlocks)) {
-        (void)hipHostFree(g_pool.front().first);
+        (void)pinned_release(g_pool.front());
         g_pool.erase(g_pool.begin());
     }
 }
@@ -645,10 +690,10 @@ int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out)
         // best fit among the pooled blocks that are large enough and not more than twice as large
         auto best = g_pool.end();
         for (auto it = g_pool.begin(); it != g_pool.end(); ++it)
-            if (it->second >= want && it->second / 2 <= want && (best == g_pool.end() || it->second < best->second)) best = it;
+            if (it->size >= want && it->size / 2 <= want && (best == g_pool.end() || it->size < best->size)) best = it;
         if (best != g_pool.end()) {
             g_pinned.push_back(*best);
-            *out = best->first;
+            *out = best->p;
             g_pool.erase(best);
             return GR_OK;
         }
@@ -656,45 +701,47 @@ int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out)
         return fail(GR_ERR_OUT_OF_MEMORY, "gr_host_alloc: registry");
     }
     GR_HIP(hipSetDevice(ctx->device));
-    void* p = nullptr;
-    // page-locked and mapped for every device (hipHostMallocPortable): a multi-device render may copy into one block
-    GR_HIP(hipHostMalloc(&p, want, hipHostMallocPortable));
+    PinnedMem b{};
+    if (!pinned_make(want, b)) {
+        const hipError_t e = hipGetLastError();
+        return fail(GR_ERR_OUT_OF_MEMORY, std::string("gr_host_alloc: ") + hipGetErrorString(e));
+    }
     try {
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
-        g_pinned.emplace_back(p, want);
+        g_pinned.push_back(b);
     } catch (...) {
-        (void)hipHostFree(p);
+        (void)pinned_release(b);
         return fail(GR_ERR_OUT_OF_MEMORY, "gr_host_alloc: registry");
     }
-    *out = p;
+    *out = b.p;
     return GR_OK;
 }
 
 int32_t gr_host_free(gr_ctx* /* may be NULL or already destroyed: not dereferenced */, void* p)
 {
     if (!p) return GR_OK;
-    size_t size = 0;
+    PinnedMem b{};
     {
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
-        auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const std::pair<void*, size_t>& q) { return q.first == p; });
+        auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const PinnedMem& q) { return q.p == p; });
         if (it == g_pinned.end()) return fail(GR_ERR_INVALID_ARGUMENT, "pointer was not allocated by gr_host_alloc");
-        size = it->second;
+        b = *it;
         g_pinned.erase(it);
         // every entry point that writes a block is blocking, so nothing targets it any more: it can wait for the next request
-        if (size <= g_pool_cap) {
+        if (b.size <= g_pool_cap) {
             // the newest block is the likeliest to be asked for again: older ones make room (least recently freed first)
-            while (!g_pool.empty() && (g_pool.size() >= kPoolBlocks || pool_bytes_locked() + size > g_pool_cap)) {
-                (void)hipHostFree(g_pool.front().first);
+            while (!g_pool.empty() && (g_pool.size() >= kPoolBlocks || pool_bytes_locked() + b.size > g_pool_cap)) {
+                (void)pinned_release(g_pool.front());
                 g_pool.erase(g_pool.begin());
             }
             try {
-                g_pool.emplace_back(p, size);
+                g_pool.push_back(b);
                 return GR_OK;
             } catch (...) {
             }
         }
     }
-    GR_HIP(hipHostFree(p));      // waits for work that still targets the block
+    GR_HIP(pinned_release(b));
     return GR_OK;
 }
 
@@ -703,7 +750,7 @@ static bool is_pinned(const gr_ctx*, const void* p)
 {
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
     for (const auto& q : g_pinned)
-        if ((const char*)p >= (const char*)q.first && (const char*)p < (const char*)q.first + q.second) return true;
+        if ((const char*)p >= (const char*)q.p && (const char*)p < (const char*)q.p + q.size) return true;
     return false;
 }
 
@@ -1054,6 +1101,24 @@ static void prefault_output(void* dst, size_t bytes, bool huge)
     } catch (...) {
     }
     for (auto& x : th) x.join();
+}
+namespace {
+void prefault_threads(char* base, size_t bytes)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 4 : (nt > 8 ? 8 : nt);
+    const size_t page = 4096;
+    std::vector<std::thread> th;
+    try {       // nothing may unwind through the C ABI: whatever threads exist do their stripes, the registration faults in the rest
+        th.reserve(nt);
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([=]() {
+                for (size_t off = (size_t)t * page; off < bytes; off += (size_t)nt * page) ((volatile char*)base)[off] = 0;
+            });
+    } catch (...) {
+    }
+    for (auto& x : th) x.join();
+}
 }
 struct BackgroundPrefault {
     static constexpr unsigned kMax = 8;

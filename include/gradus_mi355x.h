@@ -249,9 +249,10 @@ int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
  * caller-owned output buffer; callers that bring their own memory are served as before.  Blocks are registered
  * process-wide: gr_host_free does not look at `ctx` (it may be NULL, or a context that has been destroyed meanwhile --
  * finalizers of a garbage-collected host language run in no particular order), and destroying a context does not free them.
- * gr_host_free(ctx, NULL) is a no-op.  Page-locking is slow (608 MiB: 113-365 ms to lock, 75 ms to unlock), so freed blocks
- * wait in a bounded process-wide pool for the next request of a similar size (gr_ctx_set "pinned_pool_mib"): a caller that
- * renders repeatedly and lets go of the previous result pays for the locking once.  The memory of a reused block holds the
+ * gr_host_free(ctx, NULL) is a no-op.  Blocks of 8 MiB and more are anonymous mappings on transparent huge pages that the
+ * library registers with the runtime (608 MiB: 13 ms; hipHostMalloc takes 122-365 ms for the same block), and freed blocks
+ * wait in a bounded process-wide pool for the next request of a similar size (gr_ctx_set "pinned_pool_mib"), which then
+ * costs nothing.  The memory of a reused block holds the
  * previous result until the next call overwrites it. */
 int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out);
 int32_t gr_host_free(gr_ctx* ctx, void* p);

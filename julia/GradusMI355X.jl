@@ -447,9 +447,9 @@ end
 # then ~30 GB/s).  Julia owns the wrapper; its finalizer hands the block back (gr_host_free does not need the context, so
 # the order in which the ensemble and the array are collected does not matter).  Small results and a refused allocation
 # (RLIMIT_MEMLOCK) take an ordinary Vector.
-# Page-locking is slow (608 MiB: 113-365 ms, unlocking 75 ms): the library keeps freed blocks in a small pool and hands them out again,
-# so only the first render of a session pays it -- provided the previous result has been finalized by the time of the next call
-# (`finalize(prev)` in a loop that keeps only the latest result).
+# The library builds the block on transparent huge pages and registers it (13 ms for 608 MiB) and keeps freed blocks in a small pool:
+# a render whose previous result has been finalized by then (`finalize(prev)` in a loop that keeps only the latest result) gets
+# its block for nothing.
 const PINNED_RESULT_MIN_BYTES = 64 << 20
 
 function _result_vector(ensemble::EnsembleMI355X, N::Integer)
