@@ -571,12 +571,13 @@ std::vector<PinnedMem> g_pool;        // page-locked blocks waiting for the next
 size_t g_pool_cap = (size_t)4 << 30;
 constexpr size_t kPoolBlocks = 4;
 constexpr size_t kHugeMin = (size_t)8 << 20;
+bool g_pinned_huge = true;            // gr_ctx_set(ctx, "pinned_huge", 0): every block from hipHostMalloc (process-wide)
 
 void prefault_threads(char* base, size_t bytes);     // below: first touch from up to 8 threads
 
 bool pinned_make(size_t want, PinnedMem& out)
 {
-    if (want >= kHugeMin) {
+    if (g_pinned_huge && want >= kHugeMin) {
         const size_t two = (size_t)2 << 20, len = (want + two - 1) / two * two;
         void* m = mmap(nullptr, len + two, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m != MAP_FAILED) {
@@ -668,6 +669,9 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->lds_points = value ? 1 : 0;
     } else if (k == "direct_host") {
         c->direct_host = value ? 1 : 0;
+    } else if (k == "pinned_huge") {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        g_pinned_huge = value != 0;
     } else if (k == "pinned_pool_mib") {
         if (value < 0) return fail(GR_ERR_INVALID_ARGUMENT, "pinned_pool_mib must be non-negative");
         std::lock_guard<std::mutex> lock(g_pinned_mutex);

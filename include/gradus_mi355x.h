@@ -237,7 +237,9 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * consecutive addresses, 0 = every lane stores its own 152 bytes; same bytes either way); ("direct_host", 1 [default] =
  * gr_render_endpoints into a gr_host_alloc block lets the kernel store across the link itself -- no staging buffer, no
  * copy --, 0 = staged in HBM and copied in bands as for caller-owned memory); ("pinned_pool_mib", process-wide: bytes of freed
- * gr_host_alloc blocks kept page-locked for the next request, default 4096 in at most 4 blocks, 0 = empty the pool and keep nothing). */
+ * gr_host_alloc blocks kept page-locked for the next request, default 4096 in at most 4 blocks, 0 = empty the pool and keep nothing);
+ * ("pinned_huge", process-wide: 1 [default] = gr_host_alloc blocks of 8 MiB and more are mappings on transparent huge pages
+ * registered with the runtime (13 ms for 608 MiB), 0 = every block from hipHostMalloc (122-365 ms)). */
 int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
 
 /* ---- pinned result buffers (ABI 5).  The reference allocates the result of ensemble_solve_tracing_problem itself

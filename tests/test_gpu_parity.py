@@ -247,6 +247,15 @@ def test_freed_pinned_blocks_are_reused(G, ens):
     assert f.ptr != pd or True                               # (the runtime may reuse the address; what counts: no error, memory usable)
     f.array(np.float64, 16)[:] = 1.0
     del e, f
+    # blocks of 8 MiB and more are mappings on transparent huge pages registered with the runtime; "pinned_huge" 0 takes
+    # every block from hipHostMalloc instead -- both are ordinary host memory the kernels can store into
+    for huge in (0, 1):
+        ens.set("pinned_huge", huge)
+        g = _lib.PinnedBlock(ens.ctx, 24 << 20)
+        w = g.array(np.float64, (24 << 20) // 8)
+        w[:] = 3.0
+        assert float(w[::4096].sum()) == 3.0 * len(w[::4096])
+        del w, g
     ens.set("pinned_pool_mib", 4096)
 
 
