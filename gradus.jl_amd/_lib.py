@@ -328,6 +328,22 @@ def result_points(ctx, n: int):
     return np.zeros(int(n), dtype=POINT_DTYPE)
 
 
+PINNED_IMAGE_MIN_BYTES = 8 << 20
+
+
+def result_image(ctx, n: int):
+    """The image a fused render fills: from 8 MiB up a block the library page-locked (registered huge pages, taken from the
+    pool of freed blocks when one fits), which the kernel writes across the link itself -- no staging image in HBM, no copy;
+    below that, or when page-locking is refused (or GRADUS_MI355X_PINNED_RESULTS=0), an ordinary numpy array."""
+    nbytes = int(n) * 8
+    if nbytes >= PINNED_IMAGE_MIN_BYTES and os.environ.get("GRADUS_MI355X_PINNED_RESULTS", "1") != "0":
+        try:
+            return PinnedBlock(ctx, nbytes).array(np.float64, int(n))
+        except GradusMI355XError:
+            pass
+    return np.zeros(int(n))
+
+
 class Context:
     """Owns one gr_ctx (one HIP device)."""
 

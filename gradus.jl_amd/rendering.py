@@ -93,8 +93,9 @@ def render_into_image(config: TracingConfiguration, pf=None, stats=False):
     if pf.fusable:
         cfg, pl = config.abi_config(), config.abi_plane()
         s, keep = abi_pointfunction(pf)
-        img = np.zeros(n)
-        if ens.devices is not None and len(ens.devices) > 1:
+        multi = ens.devices is not None and len(ens.devices) > 1
+        img = np.zeros(n) if multi else _lib.result_image(ens.ctx, n)      # >= 8 MiB: written by the kernel across the link
+        if multi:
             ctxs = ens.contexts
             arr = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
             sts = (_lib.gr_stats * len(ctxs))()
