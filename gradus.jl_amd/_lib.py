@@ -38,7 +38,7 @@ def kernel_source_sha16() -> str:
 
 
 GR_OK = 0
-ABI_VERSION = 5      # GR_ABI_VERSION of include/gradus_mi355x.h this module mirrors (checked in load() and tests/test_host_api.py)
+ABI_VERSION = 6      # GR_ABI_VERSION of include/gradus_mi355x.h this module mirrors (checked in load() and tests/test_host_api.py)
 ERROR_NAMES = {
     -1: "GR_ERR_INVALID_ARGUMENT",
     -2: "GR_ERR_UNSUPPORTED",
@@ -164,6 +164,7 @@ class gr_stats(C.Structure):
         ("status_count", C.c_int64 * 4),
         ("kernel_ms", C.c_double),     # host variants: start of the call's device work -> end of its last trace kernel
         ("call_ms", C.c_double),       # ... -> end of the last copy into the caller's buffer (ABI 5)
+        ("enqueue_ms", C.c_double),    # *_multi: host time spent enqueueing this context's share (ABI 6); 0 elsewhere
     ]
 
     def asdict(self):
@@ -176,6 +177,7 @@ class gr_stats(C.Structure):
             "status_count": list(self.status_count),
             "kernel_ms": self.kernel_ms,
             "call_ms": self.call_ms,
+            "enqueue_ms": self.enqueue_ms,
         }
 
 
@@ -225,6 +227,13 @@ EXPORTS = [
     "gr_rayset_endpoints",
     "gr_apply_pointfunction_device",
     "gr_apply_pointfunction",
+    "gr_render_endpoints_multi",
+    "gr_trace_endpoints_multi",
+    "gr_rayset_endpoints_multi",
+    "gr_ray_summary_multi",
+    "gr_ray_tangent_multi",
+    "gr_redshift_radius_multi",
+    "gr_lineprofile_multi",
 ]
 
 _lib = None
@@ -275,6 +284,14 @@ def load():
     L.gr_rayset_endpoints.argtypes = [vp, cfgp, rsp, vp, stp]
     L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]
     L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
+    ctxa = C.POINTER(vp)
+    L.gr_render_endpoints_multi.argtypes = [ctxa, i32, cfgp, plp, i64, vp, vp]
+    L.gr_trace_endpoints_multi.argtypes = [ctxa, i32, cfgp, vp, i64, vp, i64, vp, vp]
+    L.gr_rayset_endpoints_multi.argtypes = [ctxa, i32, cfgp, rsp, vp, vp]
+    L.gr_ray_summary_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, vp, vp]
+    L.gr_ray_tangent_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, vp, vp]
+    L.gr_redshift_radius_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, C.c_double, C.c_double, vp, vp]
+    L.gr_lineprofile_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, bnp, vp, vp]
     for name in EXPORTS:
         if name not in ("gr_last_error",):
             getattr(L, name).restype = i32
@@ -286,6 +303,26 @@ def load():
 def check(code):
     if code != GR_OK:
         raise GradusMI355XError(code, load().gr_last_error().decode("utf-8", "replace"))
+
+
+def ctx_array(ctxs):
+    """(ctypes array of the contexts' handles, array of gr_stats, one per context) for a *_multi call."""
+    arr = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+    return arr, (gr_stats * len(ctxs))()
+
+
+def merge_stats(sts) -> gr_stats:
+    """One gr_stats for a *_multi call: counters summed over the contexts, times = the slowest context
+    (they run side by side), enqueue_ms = the sum (the host enqueues them one after another)."""
+    st = gr_stats()
+    for f in ("rays", "accepted_steps", "rejected_steps", "rhs_evals", "flagged_rays"):
+        setattr(st, f, sum(getattr(x, f) for x in sts))
+    for q in range(4):
+        st.status_count[q] = sum(x.status_count[q] for x in sts)
+    st.kernel_ms = max(x.kernel_ms for x in sts)
+    st.call_ms = max(x.call_ms for x in sts)
+    st.enqueue_ms = sum(x.enqueue_ms for x in sts)
+    return st
 
 
 class PinnedBlock:

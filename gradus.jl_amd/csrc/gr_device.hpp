@@ -1404,6 +1404,10 @@ struct Cold {
     const double* lp_edges;   // device, lp_nbins
     double* lp_flux;          // device, lp_nbins (accumulated with fp64 atomics)
     double* lp_pairs;         // device, n x 2
+    // out_mode 0 / 1 of an image plane: 1 = ray j's pixel / record goes to index range_map(j) -- its place in the WHOLE image --
+    // instead of to local index j (several devices storing one plane into one page-locked host block, gr_*_multi)
+    int32_t out_global;
+    int32_t out_reserved;
 };
 
 constexpr int N_STAT = 9;   // statistics counters of a launch: rays, accepted, rejected, rhs, flagged, status[4]
@@ -2476,10 +2480,11 @@ struct Ray {
         if (cd.out_mode == 1) {
             real x0[4], v0[4];
             constrained_u0(m, p, j, x0, v0);
+            const int64_t oj = cd.out_global ? range_map(cd, j) : j;
             // with lds.point the record is laid down in LDS and the wave sends all 64 as runs of consecutive
             // addresses afterwards (gr_kernels.hpp, points_epilogue); without it each lane stores its own 152 bytes
-            gr_point* o = lds.point ? reinterpret_cast<gr_point*>(lds.point) : cd.points + j;
-            if (lds.point) *lds.point_addr = (uint64_t)(cd.points + j);
+            gr_point* o = lds.point ? reinterpret_cast<gr_point*>(lds.point) : cd.points + oj;
+            if (lds.point) *lds.point_addr = (uint64_t)(cd.points + oj);
             o->status = status;
             o->flags = flags;
             o->lambda_min = p.cfg.lambda0;
@@ -2590,7 +2595,7 @@ struct Ray {
                     val = redshift_pf(m, p, cd, lds, x0, v0, x, v);
                 }
             }
-            cd.image[j] = (double)val;
+            cd.image[cd.out_global ? range_map(cd, j) : j] = (double)val;
         }
     }
 };

@@ -205,6 +205,11 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
         const typename ColdSel<Metric>::type cs = cold_store_of<typename ColdSel<Metric>::type>(p);
         ray.init(m, p, tile_swizzle(cold_of(p), gid));
         while (!ray.step(m, p, cs)) {}
+        // In a one-wave workgroup finalize() lays the end-point record down in the LDS bytes other lanes of this wave use as
+        // cold storage inside step() (lds_prologue): every lane must have LEFT the loop before any lane stores.  The
+        // structured loop exit guarantees that today; the barrier states it, so that no later pass may sink finalize() into a
+        // per-lane exit block.  It emits no instruction.
+        __builtin_amdgcn_wave_barrier();
         GR_PARAMS_AFTER_LOOP(p, pl, zoff)
         ray.finalize(m, pl, lds);
         ls.add(ray);

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +64,7 @@ const apply_fn kApply64[11] = GR_ROW(gr64_launch_apply_m);
 namespace {
 
 thread_local std::string g_last_error;
+std::atomic<int> g_live_ctx{ 0 };     // contexts alive: the pool of page-locked blocks is emptied when the last one goes
 
 int32_t fail(int32_t code, const std::string& msg)
 {
@@ -142,6 +144,8 @@ struct gr_ctx {
     hipEvent_t ev_band[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     bool lpt_suspend = false;              // banded launches do not learn / use a tile order (their ranges differ)
     int64_t pipeline = 4;                  // bands of the end-point return (0 / 1: one launch + one copy)
+    bool counted = false;                  // this context is in g_live_ctx
+    bool multi_direct = false;             // *_multi: this context's kernel stores into the caller's pinned block itself (no copy in phase 2)
 };
 
 namespace {
@@ -511,13 +515,20 @@ int32_t gr_ctx_create(int32_t device, gr_ctx** out)
         gr_ctx_destroy(c);
         return rc;
     }
+    c->counted = true;
+    g_live_ctx.fetch_add(1);
     *out = c;
     return GR_OK;
 }
 
+static void pool_drop_all();
+
 int32_t gr_ctx_destroy(gr_ctx* c)
 {
     if (!c) return GR_OK;
+    // the last context takes the pool of page-locked blocks with it (blocks still HELD by the caller stay: their finalizers
+    // may run later, gr_host_free needs no context)
+    if (c->counted && g_live_ctx.fetch_sub(1) == 1) pool_drop_all();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_queue) (void)hipFree(c->d_queue);
@@ -568,16 +579,22 @@ struct PinnedMem {
 std::mutex g_pinned_mutex;
 std::vector<PinnedMem> g_pinned;      // blocks handed out
 std::vector<PinnedMem> g_pool;        // page-locked blocks waiting for the next gr_host_alloc
-size_t g_pool_cap = (size_t)4 << 30;
+size_t g_pool_cap = (size_t)1 << 30;  // freed blocks kept page-locked: 1 GiB (one 2048² end-point block and change); "pinned_pool_mib"
 constexpr size_t kPoolBlocks = 4;
 constexpr size_t kHugeMin = (size_t)8 << 20;
-bool g_pinned_huge = true;            // gr_ctx_set(ctx, "pinned_huge", 0): every block from hipHostMalloc (process-wide)
+std::atomic<bool> g_pinned_huge{ true };   // gr_ctx_set(ctx, "pinned_huge", 0): every block from hipHostMalloc (process-wide)
+// A garbage-collected caller (Julia, Python) sees a 100-byte wrapper, not the block behind it, and may pile up page-locked
+// memory long before a collection runs: the bytes handed out and not yet freed are counted, and gr_host_alloc REFUSES
+// (GR_ERR_OUT_OF_MEMORY) a request that would take them past this cap -- the bindings then collect and retry, or fall back to
+// an ordinary pageable array.  gr_ctx_set(ctx, "pinned_max_mib", MiB), default 8 GiB.
+size_t g_pinned_max = (size_t)8 << 30;
+size_t g_pinned_out = 0;              // bytes of g_pinned (under g_pinned_mutex)
 
 void prefault_threads(char* base, size_t bytes);     // below: first touch from up to 8 threads
 
 bool pinned_make(size_t want, PinnedMem& out)
 {
-    if (g_pinned_huge && want >= kHugeMin) {
+    if (g_pinned_huge.load(std::memory_order_relaxed) && want >= kHugeMin) {
         const size_t two = (size_t)2 << 20, len = (want + two - 1) / two * two;
         void* m = mmap(nullptr, len + two, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m != MAP_FAILED) {
@@ -620,6 +637,12 @@ void pool_trim_locked(size_t cap)
         g_pool.erase(g_pool.begin());
     }
 }
+}
+
+static void pool_drop_all()
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    pool_trim_locked(0);
 }
 
 int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
@@ -670,8 +693,11 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
     } else if (k == "direct_host") {
         c->direct_host = value ? 1 : 0;
     } else if (k == "pinned_huge") {
+        g_pinned_huge.store(value != 0);
+    } else if (k == "pinned_max_mib") {
+        if (value < 0) return fail(GR_ERR_INVALID_ARGUMENT, "pinned_max_mib must be non-negative");
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
-        g_pinned_huge = value != 0;
+        g_pinned_max = (size_t)value << 20;        // process-wide: bytes of gr_host_alloc blocks that may be outstanding at once
     } else if (k == "pinned_pool_mib") {
         if (value < 0) return fail(GR_ERR_INVALID_ARGUMENT, "pinned_pool_mib must be non-negative");
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
@@ -691,12 +717,16 @@ int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out)
     const size_t want = (size_t)(bytes > 0 ? bytes : 1);
     try {
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        if (g_pinned_out + want > g_pinned_max)
+            return fail(GR_ERR_OUT_OF_MEMORY, "gr_host_alloc: " + std::to_string((g_pinned_out + want) >> 20) + " MiB of page-locked results would be "
+                        "outstanding (cap " + std::to_string(g_pinned_max >> 20) + " MiB, gr_ctx_set \"pinned_max_mib\"): free or finalize earlier results");
         // best fit among the pooled blocks that are large enough and not more than twice as large
         auto best = g_pool.end();
         for (auto it = g_pool.begin(); it != g_pool.end(); ++it)
             if (it->size >= want && it->size / 2 <= want && (best == g_pool.end() || it->size < best->size)) best = it;
         if (best != g_pool.end()) {
             g_pinned.push_back(*best);
+            g_pinned_out += best->size;
             *out = best->p;
             g_pool.erase(best);
             return GR_OK;
@@ -713,6 +743,7 @@ int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out)
     try {
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
         g_pinned.push_back(b);
+        g_pinned_out += b.size;
     } catch (...) {
         (void)pinned_release(b);
         return fail(GR_ERR_OUT_OF_MEMORY, "gr_host_alloc: registry");
@@ -731,8 +762,9 @@ int32_t gr_host_free(gr_ctx* /* may be NULL or already destroyed: not dereferenc
         if (it == g_pinned.end()) return fail(GR_ERR_INVALID_ARGUMENT, "pointer was not allocated by gr_host_alloc");
         b = *it;
         g_pinned.erase(it);
+        g_pinned_out -= b.size <= g_pinned_out ? b.size : g_pinned_out;
         // every entry point that writes a block is blocking, so nothing targets it any more: it can wait for the next request
-        if (b.size <= g_pool_cap) {
+        if (b.size <= g_pool_cap && g_live_ctx.load() > 0) {      // no context left: nobody to hand the block to
             // the newest block is the likeliest to be asked for again: older ones make room (least recently freed first)
             while (!g_pool.empty() && (g_pool.size() >= kPoolBlocks || pool_bytes_locked() + b.size > g_pool_cap)) {
                 (void)pinned_release(g_pool.front());
@@ -749,17 +781,22 @@ int32_t gr_host_free(gr_ctx* /* may be NULL or already destroyed: not dereferenc
     return GR_OK;
 }
 
-// a result buffer the library pinned itself: no page faults to prepare, no huge-page advice to give
-static bool is_pinned(const gr_ctx*, const void* p)
+// Do the `bytes` bytes at p lie inside ONE block the library pinned itself?  (No page faults to prepare, no huge-page advice to
+// give -- and the only memory a kernel may store into across the link: the whole extent is checked, a pointer near the end of a
+// block or a pooled block handed out for a smaller request must not send the GPU past the registered mapping.)
+static bool is_pinned(const void* p, size_t bytes)
 {
+    if (!p) return false;
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
     for (const auto& q : g_pinned)
-        if ((const char*)p >= (const char*)q.p && (const char*)p < (const char*)q.p + q.size) return true;
+        if ((const char*)p >= (const char*)q.p && (const char*)p + (bytes ? bytes : 1) <= (const char*)q.p + q.size) return true;
     return false;
 }
 
-int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,
-                         const gr_range* range, double* d_image, gr_stats* d_stats, void* hip_stream)
+// out_global: pixel / record of local ray j goes to index range_map(j) of d_image / d_points (the whole plane's buffer, which
+// several devices fill together) instead of to index j of a buffer holding this range only
+static int32_t render_device_impl(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,
+                                  const gr_range* range, double* d_image, gr_stats* d_stats, void* hip_stream, bool out_global)
 {
     if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
     int32_t rc;
@@ -774,12 +811,19 @@ int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plan
     if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     cd.out_mode = 0;
     cd.image = d_image;
+    cd.out_global = out_global ? 1 : 0;
     p.stats = (unsigned long long*)d_stats;   // same layout: 9 x 64-bit counters then kernel_ms
     return launch_trace(ctx, p, cd, stream);
 }
 
-int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
-                                   gr_point* d_points, gr_stats* d_stats, void* hip_stream)
+int32_t gr_render_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,
+                         const gr_range* range, double* d_image, gr_stats* d_stats, void* hip_stream)
+{
+    return render_device_impl(ctx, cfg, plane, pf, range, d_image, d_stats, hip_stream, false);
+}
+
+static int32_t render_endpoints_device_impl(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
+                                            gr_point* d_points, gr_stats* d_stats, void* hip_stream, bool out_global)
 {
     if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
     int32_t rc;
@@ -792,8 +836,15 @@ int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_p
     plane_params(ctx, p, cd, cfg, plane, range);
     cd.out_mode = 1;
     cd.points = d_points;
+    cd.out_global = out_global ? 1 : 0;
     p.stats = (unsigned long long*)d_stats;
     return launch_trace(ctx, p, cd, (hipStream_t)hip_stream);
+}
+
+int32_t gr_render_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
+                                   gr_point* d_points, gr_stats* d_stats, void* hip_stream)
+{
+    return render_endpoints_device_impl(ctx, cfg, plane, range, d_points, d_stats, hip_stream, false);
 }
 
 int32_t gr_trace_endpoints_device(gr_ctx* ctx, const gr_config* cfg, const double* d_x, int64_t x_stride,
@@ -900,7 +951,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     GR_HIP(hipGetLastError());
     if ((p.disc_table || p.chart_table) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters are copied as int64");
-    if (!is_pinned(ctx, path)) prefault_output(path, path_bytes, ctx->hugepages != 0);          // while the kernel runs (the path buffer of 16 384 geodesics is 600 MB)
+    if (!is_pinned(path, path_bytes)) prefault_output(path, path_bytes, ctx->hugepages != 0);          // while the kernel runs (the path buffer of 16 384 geodesics is 600 MB)
     GR_HIP(hipMemcpyAsync(n_rows, d_n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     GR_HIP(hipMemcpyAsync(path, d_path, path_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (endpoints) GR_HIP(hipMemcpyAsync(endpoints, d_pt, pt_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1222,6 +1273,7 @@ static int32_t end_host_call(gr_ctx* ctx, gr_stats* stats)
         stats->kernel_ms = ms;      // start of the call's device work -> end of its last trace kernel (input staging included)
         GR_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         stats->call_ms = ms;        // ... -> end of the last copy back to the caller's buffer
+        stats->enqueue_ms = 0.0;    // the *_multi entry points fill it in
     }
     return GR_OK;
 }
@@ -1248,7 +1300,7 @@ int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, cons
     int32_t rc;
     const size_t bytes = sizeof(double) * (size_t)(range->count > 0 ? range->count : 0);
     // an image in a block the library pinned is written by the kernel itself (as gr_render_endpoints does): no D2H copy
-    if (ctx->direct_host && bytes && is_pinned(ctx, image) && plane_on_lane_kernel(ctx, cfg, plane, range, 0)) {
+    if (ctx->direct_host && bytes && is_pinned(image, bytes) && plane_on_lane_kernel(ctx, cfg, plane, range, 0)) {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, image, 0) == hipSuccess && dp) {
             if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
@@ -1266,41 +1318,194 @@ int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, cons
     return end_host_call(ctx, stats);
 }
 
-int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_plane* plane,
-                        const gr_pointfunction* pf, int64_t block_cols, double* image, gr_stats* stats)
+// ---------------------------------------------------------------------------------------
+// ONE host thread, SEVERAL devices (include/gradus_mi355x.h, "*_multi"): enqueue on every context, queue the copies home,
+// wait for all.
+// ---------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int32_t validate_ctxs(gr_ctx* const* ctxs, int32_t n)
 {
     if (!ctxs || n < 1) return fail(GR_ERR_INVALID_ARGUMENT, "no contexts");
-    for (int k = 0; k < n; ++k)
+    for (int k = 0; k < n; ++k) {
         if (!ctxs[k]) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (!plane || !image) return fail(GR_ERR_INVALID_ARGUMENT, "plane/image is null");
+        for (int q = 0; q < k; ++q)
+            if (ctxs[q] == ctxs[k]) return fail(GR_ERR_INVALID_ARGUMENT, "the same context twice: every share needs its own stream and staging buffers");
+    }
+    return GR_OK;
+}
+
+// enq(k): stage and launch context k's share (begins with begin_host_call); copy(k): queue its copy home.
+// Whatever was started is waited for before the call returns, also on an error: the buffers belong to the caller.
+template <class Enqueue, class CopyBack>
+int32_t multi_drive(gr_ctx* const* ctxs, int32_t n, gr_stats* stats, Enqueue enq, CopyBack copy)
+{
+    double t_enq[64];
+    int32_t rc = GR_OK;
+    int started = 0;
+    for (int k = 0; k < n && rc == GR_OK; ++k) {
+        const double t0 = now_ms();
+        rc = enq(k);
+        if (k < 64) t_enq[k] = now_ms() - t0;
+        started = k + 1;      // begin_host_call may have queued work even if a later step of enq failed
+    }
+    for (int k = 0; k < n && rc == GR_OK; ++k) rc = copy(k);
+    for (int k = 0; k < started; ++k) {
+        gr_stats* st = stats ? &stats[k] : nullptr;
+        int32_t e;
+        if (rc == GR_OK) {
+            e = end_host_call(ctxs[k], st);
+        } else {
+            // an earlier failure: keep its message, just make sure nothing of this call is still in flight
+            const std::string keep = g_last_error;
+            (void)hipSetDevice(ctxs[k]->device);
+            (void)hipStreamSynchronize(ctxs[k]->stream);
+            g_last_error = keep;
+            e = GR_OK;
+        }
+        if (rc == GR_OK) rc = e;
+        if (st && rc == GR_OK) st->enqueue_ms = k < 64 ? t_enq[k] : 0.0;
+    }
+    return rc;
+}
+
+// the block-cyclic deal of an image's columns over n contexts: `block` rays per block, `n_blocks` blocks = `count` rays each
+int32_t plane_deal(const gr_plane* plane, int32_t n, int64_t block_cols, int64_t* block, int64_t* n_blocks, int64_t* count)
+{
+    if (!plane) return fail(GR_ERR_INVALID_ARGUMENT, "plane is null");
     const int64_t W = plane->width, H = plane->height;
     if (W <= 0 || H <= 0) return fail(GR_ERR_INVALID_ARGUMENT, "image dimensions must be positive");
     int64_t bc = block_cols > 0 ? block_cols : 8;
     while (bc > 1 && W % (bc * n) != 0) bc /= 2;
     if (W % (bc * n) != 0) return fail(GR_ERR_INVALID_ARGUMENT, "image width cannot be dealt in column blocks over the contexts");
-    const int64_t block = bc * H;                 // rays per block
-    const int64_t n_blocks = W / (bc * n);        // blocks per context
-    const int64_t count = n_blocks * block;
+    *block = bc * H;
+    *n_blocks = W / (bc * n);
+    *count = *n_blocks * *block;
+    return GR_OK;
+}
+
+// the device-side address of a block the library pinned, as the CURRENT device sees it (blocks are registered portable)
+void* pinned_device_pointer(void* host)
+{
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, host, 0) == hipSuccess && dp) return dp;
+    (void)hipGetLastError();
+    return nullptr;
+}
+
+// contiguous shares of n_rays rays over n contexts, in multiples of 64 rays (the last may be short or empty)
+void contiguous_share(int64_t n_rays, int32_t n, int k, int64_t* off, int64_t* cnt)
+{
+    int64_t per = (n_rays + n - 1) / n;
+    per = (per + 63) / 64 * 64;
+    int64_t a = (int64_t)k * per, b = a + per;
+    if (a > n_rays) a = n_rays;
+    if (b > n_rays) b = n_rays;
+    *off = a;
+    *cnt = b - a;
+}
+}  // namespace
+}  // extern "C++"
+
+int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_plane* plane,
+                        const gr_pointfunction* pf, int64_t block_cols, double* image, gr_stats* stats)
+{
     int32_t rc;
-    // phase 1: enqueue every device's trace and its strided copy home; nothing blocks here
-    for (int k = 0; k < n; ++k) {
-        gr_ctx* c = ctxs[k];
-        const size_t bytes = sizeof(double) * (size_t)count;
-        GR_HIP(hipSetDevice(c->device));      // context k's scratch image must live on device k
-        if ((rc = ensure(&c->d_scratch, &c->scratch_bytes, bytes)) != GR_OK) return rc;
-        if ((rc = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return rc;
+    if ((rc = validate_ctxs(ctxs, n)) != GR_OK) return rc;
+    if (n > 64) return fail(GR_ERR_INVALID_ARGUMENT, "at most 64 contexts");
+    if (!image) return fail(GR_ERR_INVALID_ARGUMENT, "image is null");
+    int64_t block, n_blocks, count;
+    if ((rc = plane_deal(plane, n, block_cols, &block, &n_blocks, &count)) != GR_OK) return rc;
+    const size_t bytes = sizeof(double) * (size_t)count;
+    // An image in a block the library pinned: every device's kernel stores its pixels at their final place, across the link
+    // (what gr_render does for one device) -- no staging image, no copy, nothing for the host to wait on but the kernels.
+    bool direct = is_pinned(image, sizeof(double) * (size_t)(plane->width * plane->height));
+    for (int k = 0; k < n && direct; ++k) {
         const gr_range rg{ (int64_t)k * block, count, block, (int64_t)n };
-        if ((rc = gr_render_device(c, cfg, plane, pf, &rg, (double*)c->d_scratch,
-                                   stats ? (gr_stats*)c->d_stats : nullptr, c->stream)) != GR_OK) return rc;
+        direct = ctxs[k]->direct_host && plane_on_lane_kernel(ctxs[k], cfg, plane, &rg, 0);
+    }
+    auto enq = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        int32_t r;
+        GR_HIP(hipSetDevice(c->device));      // context k's scratch image must live on device k
+        double* dst = nullptr;
+        if (direct) dst = (double*)pinned_device_pointer(image);
+        const bool global = dst != nullptr;
+        if (!global) {
+            if ((r = ensure(&c->d_scratch, &c->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return r;
+            dst = (double*)c->d_scratch;
+        }
+        c->multi_direct = global;
+        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
+        const gr_range rg{ (int64_t)k * block, count, block, (int64_t)n };
+        return render_device_impl(c, cfg, plane, pf, &rg, dst, stats ? (gr_stats*)c->d_stats : nullptr, c->stream, global);
+    };
+    auto copy = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        if (c->multi_direct || count == 0) return GR_OK;
+        GR_HIP(hipSetDevice(c->device));
         // local block b of context k is image block b*n + k: one 2-D copy places all of them
         GR_HIP(hipMemcpy2DAsync(image + (size_t)k * block, sizeof(double) * (size_t)(n * block), c->d_scratch,
                                 sizeof(double) * (size_t)block, sizeof(double) * (size_t)block, (size_t)n_blocks,
                                 hipMemcpyDeviceToHost, c->stream));
+        return GR_OK;
+    };
+    return multi_drive(ctxs, n, stats, enq, copy);
+}
+
+int32_t gr_render_endpoints_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_plane* plane,
+                                  int64_t block_cols, gr_point* points, gr_stats* stats)
+{
+    int32_t rc;
+    if ((rc = validate_ctxs(ctxs, n)) != GR_OK) return rc;
+    if (n > 64) return fail(GR_ERR_INVALID_ARGUMENT, "at most 64 contexts");
+    if (!points) return fail(GR_ERR_INVALID_ARGUMENT, "points is null");
+    int64_t block, n_blocks, count;
+    if ((rc = plane_deal(plane, n, block_cols, &block, &n_blocks, &count)) != GR_OK) return rc;
+    const size_t bytes = sizeof(gr_point) * (size_t)count;
+    const size_t total = sizeof(gr_point) * (size_t)(plane->width * plane->height);
+    bool direct = is_pinned(points, total);
+    for (int k = 0; k < n && direct; ++k) {
+        const gr_range rg{ (int64_t)k * block, count, block, (int64_t)n };
+        direct = ctxs[k]->direct_host && ctxs[k]->lds_points && plane_on_lane_kernel(ctxs[k], cfg, plane, &rg, 1);
     }
-    // phase 2: wait for all of them
-    for (int k = 0; k < n; ++k)
-        if ((rc = end_host_call(ctxs[k], stats ? &stats[k] : nullptr)) != GR_OK) return rc;
-    return GR_OK;
+    const bool pinned = direct || is_pinned(points, total);
+    auto enq = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        int32_t r;
+        GR_HIP(hipSetDevice(c->device));
+        gr_point* dst = nullptr;
+        if (direct) dst = (gr_point*)pinned_device_pointer(points);
+        const bool global = dst != nullptr;
+        if (!global) {
+            if ((r = ensure(&c->d_scratch, &c->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return r;
+            dst = (gr_point*)c->d_scratch;
+        }
+        c->multi_direct = global;
+        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
+        const gr_range rg{ (int64_t)k * block, count, block, (int64_t)n };
+        return render_endpoints_device_impl(c, cfg, plane, &rg, dst, stats ? (gr_stats*)c->d_stats : nullptr, c->stream, global);
+    };
+    bool faulted = false;
+    auto copy = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        if (c->multi_direct || count == 0) return GR_OK;
+        // every kernel is running by now: the pages of a fresh pageable destination are faulted in under them, once
+        if (!faulted && !pinned) prefault_output(points, total, c->hugepages != 0);
+        faulted = true;
+        GR_HIP(hipSetDevice(c->device));
+        GR_HIP(hipMemcpy2DAsync(points + (size_t)k * block, sizeof(gr_point) * (size_t)(n * block), c->d_scratch,
+                                sizeof(gr_point) * (size_t)block, sizeof(gr_point) * (size_t)block, (size_t)n_blocks,
+                                hipMemcpyDeviceToHost, c->stream));
+        return GR_OK;
+    };
+    return multi_drive(ctxs, n, stats, enq, copy);
 }
 
 int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_range* range,
@@ -1312,14 +1517,13 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     GR_HIP(hipSetDevice(ctx->device));      // before any allocation: ensure() mallocs on the current device
     int32_t rc;
     const size_t bytes = sizeof(gr_point) * (size_t)(range->count > 0 ? range->count : 0);
-    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
     // A contiguous range of a large plane goes out in bands of whole 8-column tile strips: band k is copied back on a
     // second stream while bands k+1.. are traced (2048²: 20 ms of kernel + 15 ms of copy become 25 ms), and the
     // destination's pages are faulted in by helper threads meanwhile.
     // Into a block the library pinned (gr_host_alloc) the kernel stores the records itself: one launch, no staging copy in
     // HBM, no copy engine.  The wave-transposed stores (points_epilogue) cross the link as full-size packets, 637 MB spread
     // over the 20 ms of the 2048² trace is about half the link's rate, and the call ends when the kernel does.
-    if (ctx->direct_host && ctx->lds_points && bytes && is_pinned(ctx, points) && plane_on_lane_kernel(ctx, cfg, plane, range, 1)) {
+    if (ctx->direct_host && ctx->lds_points && bytes && is_pinned(points, bytes) && plane_on_lane_kernel(ctx, cfg, plane, range, 1)) {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, points, 0) == hipSuccess && dp) {
             if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
@@ -1329,14 +1533,16 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
         }
         (void)hipGetLastError();
     }
+    // only the staged routes need the copy of the records in HBM (637 MB at 2048²)
+    if ((rc = ensure(&ctx->d_scratch, &ctx->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return rc;
     const bool contiguous = plane && (range->stride_blocks == 1 || range->count <= range->block);
     const int64_t unit = plane ? 8 * plane->height : 0;
-    const int nb = (contiguous && unit > 0 && range->first % unit == 0) ? band_count(ctx, range->count, unit, is_pinned(ctx, points)) : 1;
+    const int nb = (contiguous && unit > 0 && range->first % unit == 0) ? band_count(ctx, range->count, unit, is_pinned(points, bytes)) : 1;
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
     if (nb <= 1) {
         if ((rc = gr_render_endpoints_device(ctx, cfg, plane, range, (gr_point*)ctx->d_scratch,
                                              stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
-        if (!is_pinned(ctx, points)) prefault_output(points, bytes, ctx->hugepages != 0);
+        if (!is_pinned(points, bytes)) prefault_output(points, bytes, ctx->hugepages != 0);
         if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
         return end_host_call(ctx, stats);
     }
@@ -1371,7 +1577,7 @@ int32_t gr_render_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_plane* p
     if (rc == GR_OK && hipEventRecord(ctx->ev_k, ctx->stream) != hipSuccess) rc = fail(GR_ERR_HIP, "hipEventRecord failed");
     if (rc != GR_OK) { (void)hipStreamSynchronize(ctx->band_stream); (void)hipStreamSynchronize(ctx->stream); return rc; }
     BackgroundPrefault pf;
-    if (!is_pinned(ctx, points)) pf.start(points, bytes, ctx->hugepages != 0);
+    if (!is_pinned(points, bytes)) pf.start(points, bytes, ctx->hugepages != 0);
     hipError_t ce = hipSuccess;
     const char* what = "";
     for (int k = 0; k < used && ce == hipSuccess; ++k) {
@@ -1423,7 +1629,7 @@ int32_t gr_trace_endpoints(gr_ctx* ctx, const gr_config* cfg, const double* x, i
     }
     if ((rc = gr_trace_endpoints_device(ctx, cfg, d_x, x_stride, d_v, n, (gr_point*)ctx->d_scratch,
                                         stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
-    if (!is_pinned(ctx, points)) prefault_output(points, out_bytes, ctx->hugepages != 0);
+    if (!is_pinned(points, out_bytes)) prefault_output(points, out_bytes, ctx->hugepages != 0);
     if (out_bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
 }
@@ -1585,9 +1791,257 @@ int32_t gr_rayset_endpoints(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* 
     if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
     if ((rc = gr_rayset_endpoints_device(ctx, cfg, &dev, (gr_point*)ctx->d_scratch, stats ? (gr_stats*)ctx->d_stats : nullptr,
                                          ctx->stream)) != GR_OK) return rc;
-    if (!is_pinned(ctx, points)) prefault_output(points, bytes, ctx->hugepages != 0);
+    if (!is_pinned(points, bytes)) prefault_output(points, bytes, ctx->hugepages != 0);
     if (bytes) GR_HIP(hipMemcpyAsync(points, ctx->d_scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return end_host_call(ctx, stats);
+}
+
+// ---- *_multi on ray arrays and ray sets ----
+
+int32_t gr_trace_endpoints_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const double* x, int64_t x_stride,
+                                 const double* v, int64_t n_rays, gr_point* points, gr_stats* stats)
+{
+    int32_t rc;
+    if ((rc = validate_ctxs(ctxs, n)) != GR_OK) return rc;
+    if (n > 64) return fail(GR_ERR_INVALID_ARGUMENT, "at most 64 contexts");
+    if (n_rays < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (x_stride != 0 && x_stride != 4) return fail(GR_ERR_INVALID_ARGUMENT, "x_stride must be 0 or 4");
+    if (n_rays > 0 && (!x || !v || !points)) return fail(GR_ERR_INVALID_ARGUMENT, "x/v/points is null");
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    const bool pinned = is_pinned(points, sizeof(gr_point) * (size_t)n_rays);
+    auto enq = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        int64_t off, cnt;
+        contiguous_share(n_rays, n, k, &off, &cnt);
+        int32_t r;
+        GR_HIP(hipSetDevice(c->device));
+        const size_t nx = (size_t)(x_stride == 0 ? 4 : 4 * cnt), nv = (size_t)(4 * cnt);
+        const size_t out_bytes = sizeof(gr_point) * (size_t)cnt;
+        if ((r = ensure(&c->d_scratch, &c->scratch_bytes, out_bytes ? out_bytes : 8)) != GR_OK) return r;
+        if ((r = ensure(&c->d_in, &c->in_bytes, sizeof(double) * (nx + nv) + 8)) != GR_OK) return r;
+        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
+        if (cnt == 0) return GR_OK;
+        double* d_x = (double*)c->d_in;
+        double* d_v = d_x + nx;
+        GR_HIP(hipMemcpyAsync(d_x, x_stride == 0 ? x : x + 4 * off, sizeof(double) * nx, hipMemcpyHostToDevice, c->stream));
+        GR_HIP(hipMemcpyAsync(d_v, v + 4 * off, sizeof(double) * nv, hipMemcpyHostToDevice, c->stream));
+        return gr_trace_endpoints_device(c, cfg, d_x, x_stride, d_v, cnt, (gr_point*)c->d_scratch,
+                                         stats ? (gr_stats*)c->d_stats : nullptr, c->stream);
+    };
+    bool faulted = false;
+    auto copy = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        int64_t off, cnt;
+        contiguous_share(n_rays, n, k, &off, &cnt);
+        if (cnt == 0) return GR_OK;
+        if (!faulted && !pinned) prefault_output(points, sizeof(gr_point) * (size_t)n_rays, c->hugepages != 0);
+        faulted = true;
+        GR_HIP(hipSetDevice(c->device));
+        GR_HIP(hipMemcpyAsync(points + off, c->d_scratch, sizeof(gr_point) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+        return GR_OK;
+    };
+    return multi_drive(ctxs, n, stats, enq, copy);
+}
+
+extern "C++" {
+namespace {
+// context k's contiguous share of a ray set (host pointers)
+int32_t rayset_share(const gr_rayset* rays, int32_t n, int k, gr_rayset& out, int64_t* off_out)
+{
+    if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
+    if (rays->n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (rays->sep_r && (rays->sep_block != 0 || rays->sep_tiled))
+        return fail(GR_ERR_INVALID_ARGUMENT, "*_multi: a separable ray set with one output row per ray must come whole and in ray order "
+                                             "(sep_block = 0, sep_tiled = 0)");
+    int64_t off, cnt;
+    contiguous_share(rays->n, n, k, &off, &cnt);
+    out = *rays;
+    out.n = cnt;
+    if (rays->sep_r) {
+        out.sep_first = rays->sep_first + off;
+    } else if (rays->n > 0) {
+        if (!rays->alpha || !rays->beta) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");
+        out.alpha = rays->alpha + off;
+        out.beta = rays->beta + off;
+        out.area = rays->area ? rays->area + off : nullptr;
+        out.height = rays->height ? rays->height + off : nullptr;
+    }
+    *off_out = off;
+    return GR_OK;
+}
+
+// One output row of `row_bytes` per ray: context k stages its share of the rays, `launch(ctx, device rayset, d_out, d_stats)`
+// queues the kernel, the rows go home with one contiguous copy.
+template <class Launch>
+int32_t rayset_rows_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays, size_t row_bytes,
+                          void* out, gr_stats* stats, Launch launch)
+{
+    int32_t rc;
+    if ((rc = validate_ctxs(ctxs, n)) != GR_OK) return rc;
+    if (n > 64) return fail(GR_ERR_INVALID_ARGUMENT, "at most 64 contexts");
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
+    if (rays->n > 0 && !out) return fail(GR_ERR_INVALID_ARGUMENT, "output is null");
+    {
+        gr_rayset probe;
+        int64_t o;
+        if ((rc = rayset_share(rays, n, 0, probe, &o)) != GR_OK) return rc;
+    }
+    const size_t total = row_bytes * (size_t)(rays->n > 0 ? rays->n : 0);
+    const bool pinned = is_pinned(out, total);
+    auto enq = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        gr_rayset share, dev;
+        int64_t off;
+        int32_t r;
+        if ((r = rayset_share(rays, n, k, share, &off)) != GR_OK) return r;
+        GR_HIP(hipSetDevice(c->device));
+        if ((r = stage_rays(c, &share, dev, 0, nullptr)) != GR_OK) return r;
+        const size_t bytes = row_bytes * (size_t)share.n;
+        if ((r = ensure(&c->d_scratch, &c->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return r;
+        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
+        if (share.n == 0) return GR_OK;
+        return launch(c, &dev, c->d_scratch, stats ? (gr_stats*)c->d_stats : nullptr);
+    };
+    bool faulted = false;
+    auto copy = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        int64_t off, cnt;
+        contiguous_share(rays->n, n, k, &off, &cnt);
+        if (cnt == 0) return GR_OK;
+        if (!faulted && !pinned) prefault_output(out, total, c->hugepages != 0);
+        faulted = true;
+        GR_HIP(hipSetDevice(c->device));
+        GR_HIP(hipMemcpyAsync((char*)out + row_bytes * (size_t)off, c->d_scratch, row_bytes * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+        return GR_OK;
+    };
+    return multi_drive(ctxs, n, stats, enq, copy);
+}
+}  // namespace
+}  // extern "C++"
+
+int32_t gr_rayset_endpoints_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays, gr_point* points,
+                                  gr_stats* stats)
+{
+    return rayset_rows_multi(ctxs, n, cfg, rays, sizeof(gr_point), points, stats,
+                             [&](gr_ctx* c, const gr_rayset* dev, void* d_out, gr_stats* d_st) {
+                                 return gr_rayset_endpoints_device(c, cfg, dev, (gr_point*)d_out, d_st, c->stream);
+                             });
+}
+
+int32_t gr_ray_summary_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                             double* out, gr_stats* stats)
+{
+    return rayset_rows_multi(ctxs, n, cfg, rays, sizeof(double) * 4, out, stats,
+                             [&](gr_ctx* c, const gr_rayset* dev, void* d_out, gr_stats* d_st) {
+                                 return gr_ray_summary_device(c, cfg, dev, pf, (double*)d_out, d_st, c->stream);
+                             });
+}
+
+int32_t gr_ray_tangent_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                             double* out, gr_stats* stats)
+{
+    return rayset_rows_multi(ctxs, n, cfg, rays, sizeof(double) * 8, out, stats,
+                             [&](gr_ctx* c, const gr_rayset* dev, void* d_out, gr_stats* d_st) {
+                                 return gr_ray_tangent_device(c, cfg, dev, pf, (double*)d_out, d_st, c->stream);
+                             });
+}
+
+int32_t gr_redshift_radius_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays,
+                                 const gr_pointfunction* pf, double r_min, double r_max, double* pairs, gr_stats* stats)
+{
+    return rayset_rows_multi(ctxs, n, cfg, rays, sizeof(double) * 2, pairs, stats,
+                             [&](gr_ctx* c, const gr_rayset* dev, void* d_out, gr_stats* d_st) {
+                                 return gr_redshift_radius_device(c, cfg, dev, pf, r_min, r_max, (double*)d_out, d_st, c->stream);
+                             });
+}
+
+int32_t gr_lineprofile_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                             const gr_binning* b, double* flux, gr_stats* stats)
+{
+    int32_t rc;
+    if ((rc = validate_ctxs(ctxs, n)) != GR_OK) return rc;
+    if (n > 64) return fail(GR_ERR_INVALID_ARGUMENT, "at most 64 contexts");
+    if ((rc = validate_cfg(cfg)) != GR_OK) return rc;
+    if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
+    if (!b || b->n_bins < 1 || !b->bin_edges || !flux) return fail(GR_ERR_INVALID_ARGUMENT, "binning/flux is null or empty");
+    if (rays->sep_r && rays->sep_block != 0)
+        return fail(GR_ERR_INVALID_ARGUMENT, "gr_lineprofile_multi: a separable ray set must come whole (sep_block = 0): the call deals it itself");
+    const size_t nb = (size_t)b->n_bins;
+    const size_t ne = (b->eps_n >= 2 && b->eps_r && b->eps_v) ? (size_t)b->eps_n : 0;
+    // the deal of a separable plane: blocks of one strip of 8 x 8 tiles (all radii of 8 neighbouring angles) in the set's
+    // visiting order, block k, k + n, ... to context k -- every context sees every radius and an even sample of the angles
+    // (gradus.jl_amd/distributed.py: ray_shard does the same across processes)
+    const int64_t N = rays->n;
+    int64_t sep_blk = 0;
+    if (rays->sep_r) {
+        const int64_t nr = rays->sep_nr, nt = rays->sep_nt;
+        sep_blk = (nr >= 8 && nt >= 8) ? 8 * ((nr / 8) * 8) : std::max<int64_t>(64, (N + (int64_t)n * 8 - 1) / ((int64_t)n * 8));
+    }
+    std::vector<double> part;
+    try {
+        part.assign(nb * (size_t)n, 0.0);
+    } catch (...) {
+        return fail(GR_ERR_OUT_OF_MEMORY, "gr_lineprofile_multi: partial histograms");
+    }
+    auto share_of = [&](int k, gr_rayset& sh) -> int32_t {
+        if (!rays->sep_r) {
+            int64_t off;
+            return rayset_share(rays, n, k, sh, &off);
+        }
+        sh = *rays;
+        const int64_t blocks = (N + sep_blk - 1) / sep_blk;
+        const int64_t mine = k < blocks ? (blocks - 1 - k) / n + 1 : 0;
+        int64_t cnt = 0;
+        if (mine > 0) {
+            const int64_t last = k + (mine - 1) * n;
+            cnt = (mine - 1) * sep_blk + std::min<int64_t>(sep_blk, N - last * sep_blk);
+        }
+        sh.n = cnt;
+        sh.sep_first = rays->sep_first + (int64_t)k * sep_blk;
+        sh.sep_block = sep_blk;
+        sh.sep_stride = (int64_t)n * sep_blk;
+        return GR_OK;
+    };
+    std::vector<double*> d_part((size_t)n, nullptr);
+    auto enq = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        gr_rayset sh, dev;
+        int32_t r;
+        if ((r = share_of(k, sh)) != GR_OK) return r;
+        GR_HIP(hipSetDevice(c->device));
+        void* extra = nullptr;
+        if ((r = stage_rays(c, &sh, dev, sizeof(double) * (2 * nb + 2 * ne), &extra)) != GR_OK) return r;
+        double* d_edges = (double*)extra;
+        double* d_flux = d_edges + nb;
+        GR_HIP(hipMemcpyAsync(d_edges, b->bin_edges, sizeof(double) * nb, hipMemcpyHostToDevice, c->stream));
+        gr_binning db = *b;
+        db.bin_edges = d_edges;
+        if (ne) {
+            double* d_er = d_flux + nb;
+            GR_HIP(hipMemcpyAsync(d_er, b->eps_r, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+            GR_HIP(hipMemcpyAsync(d_er + ne, b->eps_v, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+            db.eps_r = d_er;
+            db.eps_v = d_er + ne;
+        }
+        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
+        d_part[(size_t)k] = d_flux;
+        // (a context without rays still zeroes its histogram: gr_lineprofile_device does so before it looks at n)
+        return gr_lineprofile_device(c, cfg, &dev, pf, &db, d_flux, stats ? (gr_stats*)c->d_stats : nullptr, c->stream);
+    };
+    auto copy = [&](int k) -> int32_t {
+        gr_ctx* c = ctxs[k];
+        GR_HIP(hipSetDevice(c->device));
+        GR_HIP(hipMemcpyAsync(part.data() + nb * (size_t)k, d_part[(size_t)k], sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+        return GR_OK;
+    };
+    if ((rc = multi_drive(ctxs, n, stats, enq, copy)) != GR_OK) return rc;
+    for (size_t i = 0; i < nb; ++i) {
+        double sum = 0.0;
+        for (int k = 0; k < n; ++k) sum += part[nb * (size_t)k + i];     // context order: the same bytes run after run
+        flux[i] = sum;
+    }
+    return GR_OK;
 }
 
 }  // extern "C"

@@ -183,13 +183,17 @@ def lineprofile(bins, ε, m, u, d, method=None, *, λ_max=None, redshift_pf=None
     # steps per ray the per-workgroup histogram flush decides).
     ens = config.ensemble
     lane = getattr(rs, "_tiled", False) and ens.knobs.get("kernel", 2) == 2 and max(config.abstol, config.reltol) <= 1e-6
+    fused = isinstance(ε, PowerLawEmissivity) or _emissivity_table(ε) is not None
+    ctxs = ens.contexts if (ens.multi and fused) else [ens.ctx]       # the (g, ρ) route for callable emissivities: one device
     if lane:
-        ens.ctx.set("kernel", 0)
+        for c in ctxs:
+            c.set("kernel", 0)
     try:
-        return _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, stats)
+        return _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, stats, ctxs=ctxs)
     finally:
         if lane:
-            ens.ctx.set("kernel", 2)
+            for c in ctxs:
+                c.set("kernel", 2)
 
 
 def _emissivity_table(ε):
@@ -204,7 +208,7 @@ def _emissivity_table(ε):
     return r, v
 
 
-def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, stats):
+def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, stats, ctxs=None):
     table = None if isinstance(ε, PowerLawEmissivity) else _emissivity_table(ε)
     if isinstance(ε, PowerLawEmissivity) or table is not None:
         b = _lib.gr_binning(float(minrₑ), float(maxrₑ), ε.q if table is None else 0.0, bins.size, bins.ctypes.data)
@@ -212,8 +216,15 @@ def _lineprofile_call(L, h, cfg, rs, pf, st, ε, bins, minrₑ, maxrₑ, areas, 
             # an emissivity profile is a table: interpolated on the device like the power law is evaluated there
             b.eps_r, b.eps_v, b.eps_n = table[0].ctypes.data, table[1].ctypes.data, table[0].size
         flux = np.zeros(bins.size)
-        _lib.check(L.gr_lineprofile(h, C.byref(cfg), C.byref(rs), C.byref(pf), C.byref(b), flux.ctypes.data,
-                                    C.byref(st)))
+        if ctxs is not None and len(ctxs) > 1:
+            # the plane's rays dealt over the devices, one histogram each, added by the host (gr_lineprofile_multi)
+            arr, sts = _lib.ctx_array(ctxs)
+            _lib.check(L.gr_lineprofile_multi(arr, len(ctxs), C.byref(cfg), C.byref(rs), C.byref(pf), C.byref(b),
+                                              flux.ctypes.data, sts))
+            st = _lib.merge_stats(sts)
+        else:
+            _lib.check(L.gr_lineprofile(h, C.byref(cfg), C.byref(rs), C.byref(pf), C.byref(b), flux.ctypes.data,
+                                        C.byref(st)))
     else:
         pairs = np.zeros((rs.n, 2))
         _lib.check(L.gr_redshift_radius(h, C.byref(cfg), C.byref(rs), C.byref(pf), float(minrₑ), float(maxrₑ),

@@ -93,22 +93,14 @@ def render_into_image(config: TracingConfiguration, pf=None, stats=False):
     if pf.fusable:
         cfg, pl = config.abi_config(), config.abi_plane()
         s, keep = abi_pointfunction(pf)
-        multi = ens.devices is not None and len(ens.devices) > 1
-        img = np.zeros(n) if multi else _lib.result_image(ens.ctx, n)      # >= 8 MiB: written by the kernel across the link
+        multi = ens.multi
+        img = _lib.result_image(ens.ctx, n)      # >= 8 MiB: written by the kernel(s) across the link, each pixel at its place
         if multi:
             ctxs = ens.contexts
-            arr = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
-            sts = (_lib.gr_stats * len(ctxs))()
+            arr, sts = _lib.ctx_array(ctxs)
             _lib.check(_lib.load().gr_render_multi(arr, len(ctxs), C.byref(cfg), C.byref(pl), C.byref(s), 0,
                                                    img.ctypes.data, sts))
-            st.rays = sum(x.rays for x in sts)
-            st.accepted_steps = sum(x.accepted_steps for x in sts)
-            st.rejected_steps = sum(x.rejected_steps for x in sts)
-            st.rhs_evals = sum(x.rhs_evals for x in sts)
-            st.flagged_rays = sum(x.flagged_rays for x in sts)
-            for q in range(4):
-                st.status_count[q] = sum(x.status_count[q] for x in sts)
-            st.kernel_ms = max(x.kernel_ms for x in sts)
+            st = _lib.merge_stats(sts)
         else:
             rg = _lib.gr_range(0, n, max(n, 1), 1)
             _lib.check(_lib.load().gr_render(ens.ctx.handle, C.byref(cfg), C.byref(pl), C.byref(s), C.byref(rg),

@@ -176,15 +176,18 @@ def map_impact_parameters(m: AbstractMetric, x, α, β):
 
 # ---- Gradus.jl:412 / ext/GradusDiffEqGPUExt: the ensemble type selects the backend ----
 class EnsembleMI355X:
-    """Ensemble algorithm that runs the trace on one MI355X through libgradus_mi355x.so.
+    """Ensemble algorithm that runs the trace on one MI355X -- or, with `devices=[...]`, on several from this one process
+    -- through libgradus_mi355x.so.
 
     Passing it as `ensemble=` is the drop-in point (dispatch of
     `ensemble_solve_tracing_problem`, src/tracing/tracing.jl:113-196).
     """
 
     def __init__(self, device: int = 0, devices=None, **knobs):
-        """`devices=[0, 1, ...]` renders images on several GPUs from this one process
-        (gr_render_multi: columns dealt block-cyclically, strided D2H straight into the image)."""
+        """`devices=[0, 1, ...]`: every entry of the boundary (rendergeodesics, prerendergeodesics, tracegeodesics,
+        lineprofile(BinningMethod)) spreads its rays over these GPUs through the library's *_multi entry points: the host
+        enqueues every device's share, then collects them -- no exchange between devices.  An entry may repeat (two
+        contexts on one device: testing)."""
         self.device = device if devices is None else list(devices)[0]
         self.devices = None if devices is None else [int(d) for d in devices]
         self.knobs = dict(knobs)
@@ -210,6 +213,10 @@ class EnsembleMI355X:
             for k, v in self.knobs.items():
                 self._ctx.set(k, v)
         return self._ctx
+
+    @property
+    def multi(self) -> bool:
+        return self.devices is not None and len(self.devices) > 1
 
     def set(self, key, value):
         self.knobs[key] = value
@@ -458,6 +465,31 @@ def ensemble_solve_tracing_problem(ensemble: EnsembleMI355X, config: TracingConf
     L = _lib.load()
     cfg = config.abi_config()
     st = _lib.gr_stats()
+    if ensemble.multi:
+        # several devices, one host thread: the same three input shapes through the *_multi entry points
+        ctxs = ensemble.contexts
+        arr, sts = _lib.ctx_array(ctxs)
+        if isinstance(config.velocity, RenderVelocity):
+            pl = config.abi_plane()
+            n = pl.width * pl.height
+            out = _lib.result_points(ensemble.ctx, n)   # pinned from 64 MiB up: every device's kernel stores its records there itself
+            _lib.check(L.gr_render_endpoints_multi(arr, len(ctxs), C.byref(cfg), C.byref(pl), 0, out.ctypes.data, sts))
+        elif isinstance(config.velocity, PlaneVelocity):
+            rs, keep = separable_rayset(config.metric, config.position, config.velocity.plane, tiled=False)
+            out = np.zeros(rs.n, dtype=_lib.POINT_DTYPE)
+            _lib.check(L.gr_rayset_endpoints_multi(arr, len(ctxs), C.byref(cfg), C.byref(rs), out.ctypes.data, sts))
+        else:
+            v = np.ascontiguousarray(config.velocity, dtype=np.float64)
+            x = np.ascontiguousarray(config.position, dtype=np.float64)
+            n = v.shape[0]
+            stride = 0 if x.ndim == 1 else 4
+            if stride == 4 and x.shape[0] != n:
+                raise ValueError("positions and velocities must have the same length")
+            out = np.zeros(n, dtype=_lib.POINT_DTYPE)
+            _lib.check(L.gr_trace_endpoints_multi(arr, len(ctxs), C.byref(cfg), x.ctypes.data, stride, v.ctypes.data, n,
+                                                  out.ctypes.data, sts))
+        st = _lib.merge_stats(sts)
+        return (out, st.asdict()) if stats else out
     if isinstance(config.velocity, RenderVelocity):
         pl = config.abi_plane()
         n = pl.width * pl.height

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GR_ABI_VERSION 5
+#define GR_ABI_VERSION 6
 
 typedef enum {
     GR_OK = 0,
@@ -212,6 +212,11 @@ typedef struct gr_stats {
     /* ... and to the end of the last copy back into the caller's buffer: kernel_ms plus the D2H part.  The wall time
      * of the blocking call is this plus the launch / synchronisation latency of the host side.                        */
     double call_ms;
+    /* *_multi entry points only (ABI 6; 0 from every other call): host wall-clock time the calling thread spent ENQUEUEING
+     * this context's share -- staging its inputs and launching its kernel, before it moved on to the next context.  Small
+     * against kernel_ms means the devices ran side by side; comparable to kernel_ms would mean the call had waited for
+     * device k before it started device k+1 (tests/test_gpu_multi.py asserts the former, for pageable and pinned results). */
+    double enqueue_ms;
 } gr_stats;
 
 typedef struct gr_ctx gr_ctx;
@@ -269,16 +274,37 @@ int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane,
                   const gr_pointfunction* pf, const gr_range* range,
                   double* image /* host, range->count doubles */, gr_stats* stats /* host, may be NULL */);
 
-/* ---- the same render spread over several devices from ONE host thread (what a Julia caller of
- * rendergeodesics(...; ensemble = EnsembleMI355X(devices)) uses; bench.py uses one process per GPU
- * and an RCCL gather instead).  The image's columns are dealt to the n contexts block-cyclically in
- * groups of `block_cols` columns (0 = default 8); each device traces its share asynchronously and
- * copies it with one strided D2H copy straight into its place in `image`, so there is no exchange
- * between devices at all.  ctxs may live on different devices or (for testing) on the same one.
- * stats[k] receives the counters of ctxs[k] (may be NULL). */
+/* ---- ONE host thread, SEVERAL devices: what a Julia caller gets from `ensemble = EnsembleMI355X(devices)` at every entry
+ * of the boundary (bench.py uses one process per GPU and an RCCL gather instead).  Every *_multi call has the same shape:
+ *   phase 1  for each context: stage its inputs, launch its kernel on its own stream -- nothing here waits for a device
+ *            (gr_stats.enqueue_ms records the host time each context took);
+ *   phase 2  for each context: queue the copy of its share into its place in the caller's buffer (a copy into pageable memory
+ *            may block the host until THAT device's kernel has finished -- every other device is already running);
+ *   phase 3  wait for all of them.
+ * There is no exchange between devices at all.  ctxs must be distinct contexts; they may live on different devices or (for
+ * testing) on the same one.  stats[k] receives the counters of ctxs[k] (may be NULL).  With n = 1 a call is equivalent to its
+ * single-context entry point and produces the same bytes.
+ *
+ * Image planes (gr_render_multi, gr_render_endpoints_multi): the columns are dealt to the n contexts block-cyclically in
+ * groups of `block_cols` columns (0 = default 8, halved until it divides width / n) -- centre columns hold the long rays, so
+ * a contiguous split would leave the middle devices working after the outer ones have finished.  Into caller-owned (pageable)
+ * memory each device's share goes home with one strided D2H copy; into a block from gr_host_alloc every device's KERNEL
+ * stores its pixels / records at their final place across the link (no staging buffer, no copy). */
 int32_t gr_render_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_plane* plane,
                         const gr_pointfunction* pf, int64_t block_cols,
                         double* image /* host, width*height doubles */, gr_stats* stats /* n entries or NULL */);
+/* prerendergeodesics / ensemble_solve_tracing_problem on the render closure (src/rendering/rendering.jl:56-87,
+ * src/tracing/tracing.jl:151-196): the whole plane's end points, 152 B per ray in image order. */
+int32_t gr_render_endpoints_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_plane* plane,
+                                  int64_t block_cols, gr_point* points /* host, width*height */,
+                                  gr_stats* stats /* n entries or NULL */);
+/* tracegeodesics(m, xs, vs, ...) (tracing.jl:151-196 on the array inputs of geodesic-problem.jl:121-150): context k takes
+ * the k-th contiguous share of the rays (shares are multiples of 64 rays, the last may be short or empty). */
+int32_t gr_trace_endpoints_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const double* x, int64_t x_stride,
+                                 const double* v, int64_t n_rays, gr_point* points /* host, n_rays */,
+                                 gr_stats* stats /* n entries or NULL */);
+/* (the ray-set entry points -- gr_rayset_endpoints_multi, gr_ray_summary_multi, gr_ray_tangent_multi,
+ * gr_redshift_radius_multi, gr_lineprofile_multi -- are declared at the end of this header, behind gr_rayset) */
 
 /* ---- endpoints of an image plane: prerendergeodesics / EndpointRenderCache
  * (rendering.jl:56-87,121-138) ---- */
@@ -425,6 +451,27 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
                                       double* d_out, void* hip_stream);
 int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,
                                const gr_point* points, int64_t n, double max_time, double* out);
+
+/* ---- ONE host thread, SEVERAL devices, ray sets (see gr_render_multi for the shape every *_multi call has) ---- */
+/* Ray sets with one output row per ray (gr_rayset_endpoints, gr_ray_summary, gr_ray_tangent, gr_redshift_radius): contiguous
+ * shares as above.  A separable ray set must come whole and in ray order (sep_block = 0, sep_tiled = 0). */
+int32_t gr_rayset_endpoints_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays,
+                                  gr_point* points /* host, rays->n */, gr_stats* stats);
+int32_t gr_ray_summary_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays,
+                             const gr_pointfunction* pf, double* out /* host, rays->n x 4 */, gr_stats* stats);
+int32_t gr_ray_tangent_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays,
+                             const gr_pointfunction* pf, double* out /* host, rays->n x 8 */, gr_stats* stats);
+int32_t gr_redshift_radius_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays,
+                                 const gr_pointfunction* pf, double r_min, double r_max,
+                                 double* pairs /* host, rays->n x 2 */, gr_stats* stats);
+/* lineprofile(bins, ε, m, x, d, BinningMethod(); plane) (src/line-profiles.jl:152-198): the rays are dealt block-cyclically
+ * (a separable plane: one block = one strip of 8 x 8 tiles, all radii of 8 neighbouring angles, so every device sees every
+ * radius; ray arrays: contiguous shares), each device bins its own rays into its own histogram and the host adds the n
+ * histograms in context order.  The order in which a bin receives its rays differs from the one-context call, so the sums
+ * agree to rounding (1e-13 relative), not bit for bit.  A separable ray set must come whole (sep_block = 0). */
+int32_t gr_lineprofile_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays,
+                             const gr_pointfunction* pf, const gr_binning* b, double* flux /* host, n_bins */,
+                             gr_stats* stats);
 
 #ifdef __cplusplus
 }

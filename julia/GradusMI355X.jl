@@ -37,7 +37,7 @@ import SciMLBase
 export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, winding_numbers
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
-const ABI_VERSION = 5
+const ABI_VERSION = 6
 
 # ---------------------------------------------------------------------------------------------------------------
 # POD mirrors of include/gradus_mi355x.h (field order and types checked by tests/test_julia_binding.py)
@@ -82,6 +82,7 @@ struct GrStats                       # == gr_stats
     status_count::NTuple{4,Int64}
     kernel_ms::Float64               # start of the call's device work -> end of its last trace kernel
     call_ms::Float64                 # ... -> end of the last copy into the caller's buffer (ABI 5)
+    enqueue_ms::Float64              # *_multi: host time spent enqueueing this context's share (ABI 6); 0 elsewhere
 end
 
 struct GrPlane                       # == gr_plane
@@ -156,8 +157,12 @@ end
 """
     EnsembleMI355X(devices = [0])
 
-One `gr_ctx` per listed HIP device, all driven from the calling Julia task.  With several devices
-`rendergeodesics` deals the image's columns to them (`gr_render_multi`).
+One `gr_ctx` per listed HIP device, all driven from the calling Julia task.  With several devices every entry of the
+boundary spreads its rays over them through the library's `*_multi` entry points: `rendergeodesics` and
+`prerendergeodesics` deal the image's columns block-cyclically (`gr_render_multi`, `gr_render_endpoints_multi`),
+`tracegeodesics` on arrays and image planes takes contiguous shares (`gr_trace_endpoints_multi`,
+`gr_rayset_endpoints_multi`), `lineprofile_mi355x` adds one histogram per device (`gr_lineprofile_multi`).  The host
+enqueues every device's share before it waits for any of them; there is no exchange between devices.
 """
 mutable struct EnsembleMI355X
     devices::Vector{Int32}
@@ -451,14 +456,36 @@ end
 # a render whose previous result has been finalized by then (`finalize(prev)` in a loop that keeps only the latest result) gets
 # its block for nothing.
 const PINNED_RESULT_MIN_BYTES = 64 << 20
+const PINNED_IMAGE_MIN_BYTES = 8 << 20
+
+# Julia's GC sees the ~100-byte wrapper of such an array, not the hundreds of MiB of page-locked memory behind it, and a render
+# loop that drops its results without `finalize` could pile those up long before a collection runs.  So:
+#   * ENV["GRADUS_MI355X_PINNED_RESULTS"] = "0" turns pinned results off altogether (ordinary Vectors / Matrices, as the
+#     reference allocates them; the Python binding has the same switch);
+#   * the LIBRARY counts the bytes it has handed out and refuses a request that would take them past its cap
+#     (gr_ctx_set "pinned_max_mib", default 8 GiB).  On a refusal the shim runs an incremental collection -- which finalizes
+#     the dropped results and returns their blocks -- and asks once more; a second refusal means the caller really HOLDS that
+#     much, and the result is an ordinary pageable array (slower copy home, nothing else changes);
+#   * freed blocks wait in a pool of at most 1 GiB ("pinned_pool_mib") that is emptied when the last context is destroyed.
+_pinned_results_enabled() = get(ENV, "GRADUS_MI355X_PINNED_RESULTS", "1") != "0"
+
+function _pinned_block(ensemble::EnsembleMI355X, bytes::Int64)
+    _pinned_results_enabled() || return C_NULL
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    for attempt = 1:2
+        rc = ccall((:gr_host_alloc, LIB), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ensemble.ctxs[1], bytes, ref)
+        (rc == 0 && ref[] != C_NULL) && return ref[]
+        attempt == 1 && GC.gc(false)          # finalizers of dropped results hand their blocks back
+    end
+    C_NULL
+end
 
 function _result_vector(ensemble::EnsembleMI355X, N::Integer)
     bytes = Int64(N) * 152
     if bytes >= PINNED_RESULT_MIN_BYTES
-        ref = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:gr_host_alloc, LIB), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ensemble.ctxs[1], bytes, ref)
-        if rc == 0 && ref[] != C_NULL
-            out = unsafe_wrap(Array, Ptr{GeodesicPoint{Float64,Nothing}}(ref[]), Int(N); own = false)
+        p = _pinned_block(ensemble, bytes)
+        if p != C_NULL
+            out = unsafe_wrap(Array, Ptr{GeodesicPoint{Float64,Nothing}}(p), Int(N); own = false)
             finalizer(a -> ccall((:gr_host_free, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, pointer(a)), out)
             return out
         end
@@ -466,16 +493,13 @@ function _result_vector(ensemble::EnsembleMI355X, N::Integer)
     Vector{GeodesicPoint{Float64,Nothing}}(undef, N)
 end
 
-const PINNED_IMAGE_MIN_BYTES = 8 << 20
-
 # the H x W image of a fused render: page-locked by the library from 8 MiB up, an ordinary Matrix below that or when refused
 function _result_matrix(ensemble::EnsembleMI355X, H::Integer, W::Integer)
     bytes = Int64(H) * Int64(W) * 8
     if bytes >= PINNED_IMAGE_MIN_BYTES
-        ref = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:gr_host_alloc, LIB), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), ensemble.ctxs[1], bytes, ref)
-        if rc == 0 && ref[] != C_NULL
-            out = unsafe_wrap(Array, Ptr{Float64}(ref[]), (Int(H), Int(W)); own = false)
+        p = _pinned_block(ensemble, bytes)
+        if p != C_NULL
+            out = unsafe_wrap(Array, Ptr{Float64}(p), (Int(H), Int(W)); own = false)
             finalizer(a -> ccall((:gr_host_free, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, pointer(a)), out)
             return out
         end
@@ -513,10 +537,19 @@ function Gradus.ensemble_solve_tracing_problem(
     @assert sizeof(GeodesicPoint{Float64,Nothing}) == 152
     out = _result_vector(ensemble, N)
     stats = Ref{GrStats}()
+    nctx = length(ensemble.ctxs)
+    mstats = Vector{GrStats}(undef, nctx)           # the *_multi entry points report per context
     plane = _render_plane(config)
     if !isnothing(plane)
         # the pixel -> velocity closure of rendergeodesics / prerendergeodesics: rays are made on the device
         pl = Ref(plane)
+        if nctx > 1 && plane.width % nctx == 0
+            # columns dealt over the devices; into a pinned `out` every device's kernel stores its records at their place
+            _check(GC.@preserve keep out ccall((:gr_render_endpoints_multi, LIB), Int32,
+                (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Int64, Ptr{Cvoid}, Ptr{GrStats}),
+                ensemble.ctxs, nctx, cfg, pl, 0, out, mstats))
+            return out
+        end
         rg = Ref(GrRange(0, N, max(N, 1), 1))
         _check(GC.@preserve keep out ccall((:gr_render_endpoints, LIB), Int32,
             (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrPlane}, Ref{GrRange}, Ptr{Cvoid}, Ref{GrStats}),
@@ -534,6 +567,12 @@ function Gradus.ensemble_solve_tracing_problem(
         rays = Ref(GrRayset(Tuple(SVector{4,Float64}(config.position)), Tuple(permutedims(Mx)), pointer(αv), pointer(βv),
             Ptr{Float64}(C_NULL), N, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0,
             Int32(0), Int32(0), 0, 0, 0))
+        if nctx > 1
+            _check(GC.@preserve keep αv βv out ccall((:gr_rayset_endpoints_multi, LIB), Int32,
+                (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ptr{Cvoid}, Ptr{GrStats}),
+                ensemble.ctxs, nctx, cfg, rays, out, mstats))
+            return out
+        end
         _check(GC.@preserve keep αv βv out ccall((:gr_rayset_endpoints, LIB), Int32,
             (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ptr{Cvoid}, Ref{GrStats}),
             ensemble.ctxs[1], cfg, rays, out, stats))
@@ -544,6 +583,12 @@ function Gradus.ensemble_solve_tracing_problem(
     xs = config.position isa SVector ? [SVector{4,Float64}(config.position)] : Vector{SVector{4,Float64}}(config.position)
     vs = config.velocity isa Function ? SVector{4,Float64}[config.velocity(i) for i = 1:N] :
          Vector{SVector{4,Float64}}(config.velocity)
+    if nctx > 1
+        _check(GC.@preserve keep xs vs out ccall((:gr_trace_endpoints_multi, LIB), Int32,
+            (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}, Ptr{GrStats}),
+            ensemble.ctxs, nctx, cfg, reinterpret(Float64, xs), length(xs) == 1 ? 0 : 4, reinterpret(Float64, vs), N, out, mstats))
+        return out
+    end
     _check(GC.@preserve keep xs vs out ccall((:gr_trace_endpoints, LIB), Int32,
         (Ptr{Cvoid}, Ref{GrConfig}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}, Ref{GrStats}),
         ensemble.ctxs[1], cfg, reinterpret(Float64, xs), length(xs) == 1 ? 0 : 4, reinterpret(Float64, vs), N, out, stats))
@@ -627,8 +672,9 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
             (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Ref{GrRange}, Ptr{Float64}, Ptr{GrStats}),
             ensemble.ctxs[1], cfg, plane, pfs, rg, image, stats))
     else
-        image = zeros(Float64, (image_height, image_width))         # rendering.jl:50, column-major H x W
-        _check(GC.@preserve tab dtab keep_pf ccall((:gr_render_multi, LIB), Int32,
+        # several devices: the same pinned block, every device's kernel stores its columns at their place (no copies at all)
+        image = _result_matrix(ensemble, image_height, image_width)
+        _check(GC.@preserve tab dtab keep_pf image ccall((:gr_render_multi, LIB), Int32,
             (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Int64, Ptr{Float64}, Ptr{GrStats}),
             ensemble.ctxs, length(ensemble.ctxs), cfg, plane, pfs, 0, image, stats))
     end
@@ -679,6 +725,14 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     binning = Ref(GrBinning(Float64(minrₑ), Float64(maxrₑ), q, length(edges), pointer(edges),
         isempty(er) ? Ptr{Float64}(C_NULL) : pointer(er), isempty(ev) ? Ptr{Float64}(C_NULL) : pointer(ev), length(er)))
     flux = zeros(Float64, length(edges))
+    if length(ensemble.ctxs) > 1
+        # the plane's rays dealt over the devices, one histogram per device, added by the library on the host
+        mstats = Vector{GrStats}(undef, length(ensemble.ctxs))
+        _check(GC.@preserve tab dtab keep_pf rs cs sn edges er ev ccall((:gr_lineprofile_multi, LIB), Int32,
+            (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ref{GrBinning}, Ptr{Float64}, Ptr{GrStats}),
+            ensemble.ctxs, length(ensemble.ctxs), cfg, rays, pfs, binning, flux, mstats))
+        return bins, flux ./ sum(flux)                                                     # line-profiles.jl:197
+    end
     stats = Ref{GrStats}()
     _check(GC.@preserve tab dtab keep_pf rs cs sn edges er ev ccall((:gr_lineprofile, LIB), Int32,
         (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ref{GrBinning}, Ptr{Float64}, Ref{GrStats}),

@@ -15,7 +15,7 @@
 _Static_assert(sizeof(gr_point) == 152, "GeodesicPoint layout");
 _Static_assert(sizeof(gr_range) == 32, "gr_range");
 _Static_assert(sizeof(gr_plane) == 8 * (4 + 16 + 4) + 16 + 8, "gr_plane");
-_Static_assert(sizeof(gr_stats) == 88, "gr_stats");
+_Static_assert(sizeof(gr_stats) == 96, "gr_stats");
 
 typedef int32_t (*ctx_create_t)(int32_t, gr_ctx**);
 typedef int32_t (*ctx_destroy_t)(gr_ctx*);

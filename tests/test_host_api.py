@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(G):
     for name in declared:
         assert hasattr(lib, name), name
     lib.gr_abi_version.restype = C.c_int32
-    assert lib.gr_abi_version() == G._lib.ABI_VERSION == 5
+    assert lib.gr_abi_version() == G._lib.ABI_VERSION == 6
 
 
 def test_struct_layouts(G):
@@ -29,7 +29,7 @@ def test_struct_layouts(G):
     assert C.sizeof(L.gr_config) == 8 + 64 + 8 * 10 + 8 + 8 + 8 + 32 + 16 + 32 + 8 + 16
     assert C.sizeof(L.gr_plane) == 8 * (4 + 16 + 4) + 16 + 8
     assert C.sizeof(L.gr_range) == 32
-    assert C.sizeof(L.gr_stats) == 88
+    assert C.sizeof(L.gr_stats) == 96            # ABI 6: + enqueue_ms
     assert C.sizeof(L.gr_pointfunction) == 8 + 16 + 8 + 32
 
 
