@@ -1563,12 +1563,36 @@ def test_rayset_endpoints_with_one_datum_plane_per_ray(G, oracle, ens):
     assert trace.endpoints(np.zeros(0), np.zeros(0), np.zeros(0)).size == 0
 
 
+THICK_GOLD = [(0.998, 75, 3.0, 0.3, 14.64279128586961, 1e-4), (0.2, 20, 5.469668466100368, 0.2, 21.581370829241525, 1e-2)]
+
+
+@pytest.mark.parametrize("a,angle,r_e,edd,gold,atol", [
+    pytest.param(*THICK_GOLD[0], id="a0.998-75deg", marks=pytest.mark.xfail(
+        strict=True, reason="recorded thick-disc sum 14.64279 not reproduced at the reference's atol 1e-4: 14.64494 here (f-4)")),
+    pytest.param(*THICK_GOLD[1], id="a0.2-20deg", marks=pytest.mark.xfail(
+        strict=True, reason="recorded thick-disc sum 21.5814 not reproduced at the reference's atol 1e-2: 21.4028 here (f-4)")),
+])
+def test_thick_disc_recorded_sums_at_the_reference_tolerance(G, ens, a, angle, r_e, edd, gold, atol):
+    """test/transfer-functions/test-thick-disc.jl:9-11,17-19 at the tolerances the REFERENCE asserts.  Not met (2.2e-3 and 0.18
+    absolute: sums over 114 samples, i.e. a sample-set question like the three thin-disc records of tests/test_gpu_tangent.py):
+    strict xfails, so that every GPU test record shows 5 unmet of the 13 recorded transfer-function statistics.  The looser
+    bounds of the next test are this build's own band around the record, not parity."""
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(1.0, a)
+    x = np.array([0.0, 10_000.0, math.radians(angle), 0.0])
+    d = G.ShakuraSunyaev.for_metric(m, eddington_ratio=edd)
+    tf = G.cunningham_transfer_function(m, x, d, r_e, β0=2.0, ensemble=ens)
+    total = float(np.nansum(tf.f))
+    print(f"  thick disc a={a} {angle}°: {total:.6f} vs {gold:.6f} ({total - gold:+.2e}, atol {atol:g})")
+    assert total == pytest.approx(gold, abs=atol)
+
+
 def test_thick_disc_transfer_functions_on_device(G, oracle, ens):
     """test/transfer-functions/test-thick-disc.jl through the device tracer: the datum-plane offsets
     (one plane per emission radius), the visibility re-trace against the ShakuraSunyaev surface and the
-    thick-surface Jacobians, several radii in the same launches.  Recorded sums to the 1-2 % their
-    extremal samples allow (see tests/test_transfer_functions_host.py); the well-conditioned samples
-    agree with the same host logic driven by oracle-traced rays."""
+    thick-surface Jacobians, several radii in the same launches.  The recorded sums are NOT met at the reference's tolerances
+    (strict xfails above); here they are held to this build's own band (5e-4 / 1e-2 relative) so that a regression shows,
+    and the well-conditioned samples agree with the same host logic driven by oracle-traced rays."""
     import sys, os
 
     sys.path.insert(0, os.path.dirname(__file__))

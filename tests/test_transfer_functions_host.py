@@ -234,6 +234,22 @@ def test_thick_disc_reference_values(G, oracle):
     assert float(np.nansum(tf.f)) == pytest.approx(14.64279128586961, rel=1.5e-3)
 
 
+# The two sums AT THE REFERENCE'S OWN TOLERANCES (test/transfer-functions/test-thick-disc.jl:11,19: atol 1e-4 and 1e-2).  Neither
+# is met -- the oracle-driven host build is 1.0 % / 1.3 % off (difference-quotient Jacobians), the device's dual-number build
+# 2.2e-3 / 0.18 absolute -- and the bounds above are this build's own, not the reference's.  Strict xfails, so every test record
+# counts them among the unmet goldens (5 of the 13 recorded transfer-function statistics) and meeting one turns the
+# suite red until the mark goes.
+@pytest.mark.parametrize("a,angle,r_e,edd,gold,atol", [
+    pytest.param(0.998, 75, 3.0, 0.3, 14.64279128586961, 1e-4, id="a0.998-75deg", marks=pytest.mark.xfail(
+        strict=True, reason="recorded thick-disc sum not reproduced at the reference's atol 1e-4 (f-4)")),
+    pytest.param(0.2, 20, 5.469668466100368, 0.2, 21.581370829241525, 1e-2, id="a0.2-20deg", marks=pytest.mark.xfail(
+        strict=True, reason="recorded thick-disc sum not reproduced at the reference's atol 1e-2 (f-4)")),
+])
+def test_thick_disc_recorded_sums_at_the_reference_tolerance(G, oracle, a, angle, r_e, edd, gold, atol):
+    tf = thick_ctf(G, oracle, a, angle, r_e, edd, 2.0)
+    assert float(np.nansum(tf.f)) == pytest.approx(gold, abs=atol)
+
+
 def test_thick_disc_problem_cases_do_not_raise(G, oracle):
     """test-thick-disc.jl:23-60: cases that only have to run (inner edge of the disc, where the surface
     has zero height and most of the ring is hidden; large radii; steep inclinations)."""

@@ -94,7 +94,13 @@ def test_the_unmet_records_are_this_sample_set_with_a_shortened_g_min_search(G, 
     g or f (the f values satisfy their normalisation identity below).  The current source of the reference and Optim's
     GoldenSection as published give 17 calls per search (`iterations = N`, no convergence exit reachable at these bracket
     widths); what shortened the searches of the recorded run cannot be told without running it.  This build follows the
-    source: 114 samples."""
+    source: 114 samples.
+
+    WHAT THIS TEST IS NOT: parity.  It is a one-integer fit per record -- k_min is chosen from 1..17 so that the statistic lands
+    on the record, and 17 candidates spanning ~2e-2 make a hit inside 2e-4 close to chance for ONE record (probability ~0.2);
+    three records whose fitted k_min rise monotonically with the inclination, plus the control at 74°, are less likely by
+    accident (~1e-2) but still a conjecture about a run nobody here can repeat.  The three records stay strict xfails at
+    the reference's tolerance (above, and tests/test_gpu_tangent.py); this test only keeps the lead reproducible."""
     raw = []
     c = ctf(G, angle, [re], root_finder="reference", _raw=raw)[0]
     assert c.f.size == 114
