@@ -35,7 +35,7 @@
 // third build: real = a forward-mode number with two tangent directions (gr_tangent.hpp)
 #include "gr_tangent.hpp"
 typedef gr_tan2 gr_real_t;
-#define GR_FMA(a, b, c) ((a) * (b) + (c))
+#define GR_FMA(a, b, c) gr_t_fma((a), (b), (c))
 #define GR_FABS gr_t_abs
 #define GR_FMAX gr_t_max
 #define GR_FMIN gr_t_min
@@ -120,6 +120,9 @@ typedef real creal;
 // ---------------------------------------------------------------------------------------
 GR_DEV real rcp_full(real x)
 {
+#if defined(GR_REAL_IS_TAN2) && !defined(GR_TAN_OLD_RCP)
+    return gr_t_rcp(x);      // value: seed + two Newton steps on the plain double; tangents: -x' / x² (no Newton steps on tangents)
+#else
     // v_rcp_f64 seed (4.6e-8 relative, measured) + two Newton steps: <= 1 ulp for normal, finite x
     real r = GR_RCP_SEED(x);
     real e = GR_FMA(-x, r, 1.0);
@@ -127,6 +130,7 @@ GR_DEV real rcp_full(real x)
     e = GR_FMA(-x, r, 1.0);
     r = GR_FMA(r, e, r);
     return r;
+#endif
 }
 GR_DEV real rcp_raw(real x) { return GR_RCP_SEED(x); }
 GR_DEV real rcp_fast(real x);
@@ -145,13 +149,20 @@ GR_DEV real rcp_rhs(real x)
 }
 GR_DEV real rcp_fast(real x)
 {
+#if defined(GR_REAL_IS_TAN2) && !defined(GR_TAN_OLD_RCP)
+    return gr_t_rcp(x);
+#else
     // one Newton step: ~2e-15 relative
     real r = GR_RCP_SEED(x);
     real e = GR_FMA(-x, r, 1.0);
     return GR_FMA(r, e, r);
+#endif
 }
 GR_DEV real sqrt_fast(real x)
 {
+#if defined(GR_REAL_IS_TAN2) && !defined(GR_TAN_OLD_RCP)
+    return gr_t_sqrt(x);
+#else
     // x > 0, normal range.  rsq seed + two coupled Newton steps (Goldschmidt): <= 1 ulp
     if (!(x > 0.0)) return (x == 0.0) ? 0.0 : GR_SQRT(x);
     real y = GR_RSQ_SEED(x);
@@ -164,6 +175,7 @@ GR_DEV real sqrt_fast(real x)
     hh = GR_FMA(hh, r, hh);
     const real d = GR_FMA(-g, g, x);
     return GR_FMA(d, hh, g);
+#endif
 }
 GR_DEV int sgn(real x) { return (x > 0.0) - (x < 0.0); }
 // A value that is the same in every lane, forced into scalar registers.  Products of metric parameters (a², 2M, -3 α13, ...)
@@ -210,7 +222,8 @@ GR_DEV real absmax(real a, real b)
 // addend is a constant and has to build that constant in the destination VECTOR registers first (two v_mov_b32 per use);
 // the three-address form reads it from an SGPR pair filled by the scalar unit, which has issue slots to spare here.
 #if defined(GR_HOST_HARNESS) || defined(GR_REAL_IS_TAN2) || defined(GR_REAL_IS_FLOAT)
-GR_DEV real fma_sk(real a, real b, creal k) { return GR_FMA(a, b, (real)k); }
+template <class T>
+GR_DEV T fma_sk(T a, T b, creal k) { return GR_FMA(a, b, (T)k); }
 #else
 GR_DEV real fma_sk(real a, real b, creal k)
 {
@@ -230,46 +243,69 @@ GR_DEV void gr_atomic_add(double* p, double v)
 GR_DEV float fast_log2f(float x) { return GR_LOG2F(x); }
 GR_DEV float fast_exp2f(float x) { return GR_EXP2F(x); }
 
+// The full evaluation behind a rotation that is out of range is taken in 1-2 % of the wave-steps.  On plain doubles (the value
+// part of the tangent build) it is cheap enough for the optimiser to if-convert -- compute both, select -- which fused the six
+// stages of a step into one 3000-instruction block, evaluated the full sin/cos at EVERY stage and spilled 900 bytes per lane
+// to scratch (90 ms instead of 50 for 1024² rays).  An empty volatile asm cannot be speculated: the branch stays a branch.
+#if defined(GR_REAL_IS_TAN2) && !defined(GR_HOST_HARNESS)
+#define GR_NO_SPECULATION() asm volatile("")
+#else
+#define GR_NO_SPECULATION()
+#endif
+
 // sin and cos of x for moderate |x| (|x| < ~1e5): two-term Cody-Waite reduction by pi/2 with
 // exact-product FMAs, then the fdlibm minimax kernels on [-pi/4, pi/4].  < 1 ulp each.
-GR_DEV void sincos_fast(real x, real& s_out, real& c_out)
+template <class T>
+GR_DEV void sincos_fast_impl(T x, T& s_out, T& c_out)
 {
-    const real TWO_OVER_PI = 6.36619772367581382433e-01;
-    const real PIO2_HI = 1.57079632679489655800e+00;
-    const real PIO2_LO = 6.12323399573676603587e-17;
-    const real kf = GR_RINT(x * TWO_OVER_PI);
-    real y = GR_FMA(-kf, PIO2_HI, x);
+    const T TWO_OVER_PI = 6.36619772367581382433e-01;
+    const T PIO2_HI = 1.57079632679489655800e+00;
+    const T PIO2_LO = 6.12323399573676603587e-17;
+    const T kf = GR_RINT(x * TWO_OVER_PI);
+    T y = GR_FMA(-kf, PIO2_HI, x);
     y = GR_FMA(-kf, PIO2_LO, y);
     const int q = (int)kf;
-    const real z = y * y;
+    const T z = y * y;
     // __kernel_sin
-    const real S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+    const T S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    real ps = GR_FMA(z, S6, S5);
+    T ps = GR_FMA(z, S6, S5);
     ps = GR_FMA(z, ps, S4);
     ps = GR_FMA(z, ps, S3);
     ps = GR_FMA(z, ps, S2);
     ps = GR_FMA(z, ps, S1);
-    const real sn = GR_FMA(y * z, ps, y);
+    const T sn = GR_FMA(y * z, ps, y);
     // __kernel_cos
-    const real C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+    const T C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    real pc = GR_FMA(z, C6, C5);
+    T pc = GR_FMA(z, C6, C5);
     pc = GR_FMA(z, pc, C4);
     pc = GR_FMA(z, pc, C3);
     pc = GR_FMA(z, pc, C2);
     pc = GR_FMA(z, pc, C1);
-    const real hz = 0.5 * z;
-    const real w = 1.0 - hz;
-    const real cs = w + (((1.0 - w) - hz) + z * (z * pc));
+    const T hz = 0.5 * z;
+    const T w = 1.0 - hz;
+    const T cs = w + (((1.0 - w) - hz) + z * (z * pc));
     // quadrant
-    const real s0 = (q & 1) ? cs : sn;
-    const real c0 = (q & 1) ? sn : cs;
+    const T s0 = (q & 1) ? cs : sn;
+    const T c0 = (q & 1) ? sn : cs;
     s_out = (q & 2) ? -s0 : s0;
     c_out = ((q + 1) & 2) ? -c0 : c0;
 }
+
+#if defined(GR_REAL_IS_TAN2) && !defined(GR_TAN_OLD_SINCOS)
+// the polynomials run on the VALUE; the tangents are cos θ θ' and -sin θ θ'
+GR_DEV void sincos_fast(real x, real& s_out, real& c_out)
+{
+    double sv, cv;
+    sincos_fast_impl<double>(x.v, sv, cv);
+    gr_t_sincos_lift(x, sv, cv, s_out, c_out);
+}
+#else
+GR_DEV void sincos_fast(real x, real& s_out, real& c_out) { sincos_fast_impl<real>(x, s_out, c_out); }
+#endif
 
 // sin and cos of θ0 + δ from (sin θ0, cos θ0) by rotation, for the Runge-Kutta stage points of
 // one step.  |δ| <= 1/32 covers every stage of 99 % of the steps of a WAVE at tolerance 1e-9 (the largest |δ| over
@@ -296,23 +332,24 @@ struct RotK {
 #endif
     }
 };
-GR_DEV void sincos_rot(const RotK& k, real th0, real s0, real c0, real th, real& s_out, real& c_out)
+template <class T>
+GR_DEV void sincos_rot_impl(const RotK& k, T th0, T s0, T c0, T th, T& s_out, T& c_out)
 {
-    const real d = th - th0;
+    const T d = th - th0;
     if (GR_FABS(d) <= SINCOS_ROT_MAX) {
-        const real z = d * d;
+        const T z = d * d;
 #if GR_ROT_MODE == 2
         // every FMA with ONE non-inline constant (the second operand is 1.0 or -0.5, which the ISA encodes inline):
         //   sin δ = δ + δ z S1 (1 + z (S2/S1) (1 + z S3/S2)),   cos δ - 1 = z (-1/2 + z C2 (1 + z C3/C2))
         // three multiplications more than Horner's form, six register moves fewer per stage point
-        const real u1 = GR_FMA(z, -2.3809523809523808e-02, 1.0);          // S3/S2 = -1/42
-        const real u3 = GR_FMA(z * u1, -5.0e-02, 1.0);                    // S2/S1 = -1/20
-        const real sd = GR_FMA((d * z) * u3, -1.6666666666666666e-01, d); // sin δ
-        const real t1 = GR_FMA(z, -3.3333333333333333e-02, 1.0);          // C3/C2 = -1/30
-        const real pc = GR_FMA(z * t1, 4.1666666666666664e-02, -0.5);
+        const T u1 = GR_FMA(z, -2.3809523809523808e-02, 1.0);          // S3/S2 = -1/42
+        const T u3 = GR_FMA(z * u1, -5.0e-02, 1.0);                    // S2/S1 = -1/20
+        const T sd = GR_FMA((d * z) * u3, -1.6666666666666666e-01, d); // sin δ
+        const T t1 = GR_FMA(z, -3.3333333333333333e-02, 1.0);          // C3/C2 = -1/30
+        const T pc = GR_FMA(z * t1, 4.1666666666666664e-02, -0.5);
 #elif GR_ROT_MODE == 3
         // the two-constant FMA opened as a product and a sum (one scalar operand each)
-        real ps, pc;
+        T ps, pc;
         {
 #pragma clang fp contract(off)
             ps = z * -1.9841269841269841e-04;
@@ -321,22 +358,38 @@ GR_DEV void sincos_rot(const RotK& k, real th0, real s0, real c0, real th, real&
             pc = pc + 4.1666666666666664e-02;
         }
         ps = fma_sk(z, ps, -1.6666666666666666e-01);
-        const real sd = GR_FMA(d * z, ps, d);                    // sin δ
+        const T sd = GR_FMA(d * z, ps, d);                    // sin δ
         pc = GR_FMA(z, pc, -0.5);
 #else
-        real ps = GR_FMA(z, -1.9841269841269841e-04, k.s2);
+        T ps = GR_FMA(z, -1.9841269841269841e-04, (T)k.s2);
         ps = GR_FMA(z, ps, -1.6666666666666666e-01);
-        const real sd = GR_FMA(d * z, ps, d);                    // sin δ
-        real pc = GR_FMA(z, -1.3888888888888889e-03, k.c2);
+        const T sd = GR_FMA(d * z, ps, d);                    // sin δ
+        T pc = GR_FMA(z, -1.3888888888888889e-03, (T)k.c2);
         pc = GR_FMA(z, pc, -0.5);
 #endif
-        const real cm1 = z * pc;                                        // cos δ - 1
+        const T cm1 = z * pc;                                        // cos δ - 1
         s_out = GR_FMA(c0, sd, GR_FMA(s0, cm1, s0));
         c_out = GR_FMA(-s0, sd, GR_FMA(c0, cm1, c0));
     } else {
-        sincos_fast(th, s_out, c_out);
+        GR_NO_SPECULATION();
+        sincos_fast_impl<T>(th, s_out, c_out);
     }
 }
+
+#if defined(GR_REAL_IS_TAN2) && !defined(GR_TAN_OLD_SINCOS)
+// rotation on the VALUES (the tangents of sin θ0, cos θ0 are not needed: d sin θ = cos θ θ', d cos θ = -sin θ θ')
+GR_DEV void sincos_rot(const RotK& k, real th0, real s0, real c0, real th, real& s_out, real& c_out)
+{
+    double sv, cv;
+    sincos_rot_impl<double>(k, th0.v, s0.v, c0.v, th.v, sv, cv);
+    gr_t_sincos_lift(th, sv, cv, s_out, c_out);
+}
+#else
+GR_DEV void sincos_rot(const RotK& k, real th0, real s0, real c0, real th, real& s_out, real& c_out)
+{
+    sincos_rot_impl<real>(k, th0, s0, c0, th, s_out, c_out);
+}
+#endif
 
 // The same rotation for the five INTERIOR stage points of a step, with two-term polynomials: sin δ = δ (1 + z (S1 + z S2)),
 // cos δ - 1 = z (-1/2 + z C2).  Truncation δ⁶/5040 resp. δ⁶/720 of the leading term: 1.8e-13 / 1.3e-12 at the bound |δ| = 1/32,
@@ -348,30 +401,46 @@ GR_DEV void sincos_rot(const RotK& k, real th0, real s0, real c0, real th, real&
 #ifndef GR_ROT_STAGE_TERMS
 #define GR_ROT_STAGE_TERMS 2
 #endif
-GR_DEV void sincos_rot_stage(const RotK& k, real th0, real s0, real c0, real th, real& s_out, real& c_out)
+template <class T>
+GR_DEV void sincos_rot_stage_impl(const RotK& k, T th0, T s0, T c0, T th, T& s_out, T& c_out)
 {
 #if GR_ROT_STAGE_TERMS == 2 && GR_ROT_MODE == 3
-    const real d = th - th0;
+    const T d = th - th0;
     if (GR_FABS(d) <= SINCOS_ROT_MAX) {
-        const real z = d * d;
-        real ps;
+        const T z = d * d;
+        T ps;
         {
 #pragma clang fp contract(off)
             ps = z * 8.3333333333333333e-03;
             ps = ps + -1.6666666666666666e-01;
         }
-        const real sd = GR_FMA(d * z, ps, d);                         // sin δ
-        const real pc = GR_FMA(z, 4.1666666666666664e-02, -0.5);        // one scalar constant, one inline constant
-        const real cm1 = z * pc;                                        // cos δ - 1
+        const T sd = GR_FMA(d * z, ps, d);                         // sin δ
+        const T pc = GR_FMA(z, 4.1666666666666664e-02, -0.5);        // one scalar constant, one inline constant
+        const T cm1 = z * pc;                                        // cos δ - 1
         s_out = GR_FMA(c0, sd, GR_FMA(s0, cm1, s0));
         c_out = GR_FMA(-s0, sd, GR_FMA(c0, cm1, c0));
     } else {
-        sincos_fast(th, s_out, c_out);
+        GR_NO_SPECULATION();
+        sincos_fast_impl<T>(th, s_out, c_out);
     }
 #else
-    sincos_rot(k, th0, s0, c0, th, s_out, c_out);
+    sincos_rot_impl<T>(k, th0, s0, c0, th, s_out, c_out);
 #endif
 }
+
+#if defined(GR_REAL_IS_TAN2) && !defined(GR_TAN_OLD_SINCOS)
+GR_DEV void sincos_rot_stage(const RotK& k, real th0, real s0, real c0, real th, real& s_out, real& c_out)
+{
+    double sv, cv;
+    sincos_rot_stage_impl<double>(k, th0.v, s0.v, c0.v, th.v, sv, cv);
+    gr_t_sincos_lift(th, sv, cv, s_out, c_out);
+}
+#else
+GR_DEV void sincos_rot_stage(const RotK& k, real th0, real s0, real c0, real th, real& s_out, real& c_out)
+{
+    sincos_rot_stage_impl<real>(k, th0, s0, c0, th, s_out, c_out);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Forward-mode dual number with two partials, for metrics without hand-written derivatives
@@ -1429,6 +1498,8 @@ struct Params {
     int32_t tangent_norm;     // tangent build only: 1 = the error norm runs over values AND tangents (gr_ctx_set "tangent_norm")
     int32_t lds_points;       // one-ray-per-lane kernel, end-point output: 1 = a wave's 152-B records leave through LDS as whole
                               // runs (POINT_UNITS doubles + one address slot per lane behind the other LDS regions)
+    int32_t xcd_spread;       // one-ray-per-lane kernel on rays in CALLER order: 1 = workgroup b traces chunk xcd_chunk(b) of the
+    int32_t reserved0;        // rays instead of chunk b (gr_kernels.hpp)
 };
 
 // the derived fields of Params, from cfg (host side; one place for the library and the two host harnesses)
@@ -1456,6 +1527,16 @@ struct LdsView {
 };
 constexpr int POINT_UNITS = 19;     // sizeof(gr_point) / 8
 static_assert(sizeof(gr_point) == 8 * POINT_UNITS, "gr_point is 19 eight-byte units");
+
+// Lanes per ray and this lane's tangent direction.  GR_TAN_W = 1 on the device: rays are traced by PAIRS of neighbouring
+// lanes (gr_tangent.hpp), the even lane carries ∂/∂α, the odd one ∂/∂β; local ray index = global work-item index >> 1.
+#if defined(GR_REAL_IS_TAN2) && GR_TAN_W == 1 && !defined(GR_HOST_HARNESS)
+constexpr int LANES_PER_RAY_LOG2 = 1;
+GR_DEV int tan_dir() { return (int)(threadIdx.x & 1u); }
+#else
+constexpr int LANES_PER_RAY_LOG2 = 0;
+GR_DEV int tan_dir() { return 0; }
+#endif
 
 // read the cold block through a pointer the optimiser cannot hoist loads from
 GR_DEV const Cold& cold_of(const Params& p)
@@ -1617,11 +1698,13 @@ constexpr int COLD_SLOTS = 9;      // 8-byte slots per lane
 struct NoColdStore {
     static constexpr bool kOn = false;
     static constexpr bool kHead = false;
+    static constexpr int kParkA = 0;
 };
 template <bool HEAD>
 struct LdsColdStoreT {
     static constexpr bool kOn = true;       // parked around the event sampling (the rarely taken branch)
     static constexpr bool kHead = HEAD;     // ... and across the whole hot region of every step
+    static constexpr int kParkA = 0;        // (stage accelerations: ParkA below)
     static constexpr int kStride = 64;     // one wave per region: slot k of the wave's lanes is one conflict-free 512-byte row,
                                            // and k * 512 is an immediate offset of the ds instruction (no address arithmetic)
     double* lane;        // this lane's slot 0 inside its wave's region; slot k is lane[k * 64]
@@ -1647,6 +1730,27 @@ struct LdsColdStoreT {
 };
 typedef LdsColdStoreT<true> LdsColdStore;
 typedef LdsColdStoreT<false> LdsColdStoreRare;
+
+// STAGE ACCELERATIONS PARKED IN LDS (round 4).  A[1..5] are written once per stage and read only by the sums of the later
+// stages, the error estimate and the dense output -- never inside a right-hand side, which is where the register pressure
+// peaks.  With ParkA<Base, N> the accelerations of stages 1..N leave for LDS as soon as they are formed (Ray::step, GR_PARK) and
+// come back, behind a compiler fence, where a sum is about to read them (GR_UNPARK): no value of A[1..N] is alive across a
+// right-hand side.  N x 4 scalars per lane: 32 B per stage for the fp64 kernels (Johannsen: 3 stages = 6 KB per wave, 72 KB per
+// CU at three waves per SIMD), 64 B for the tangent build's (value, ∂) pairs (4 stages = 16 KB per wave, 128 KB at two).
+// Element (q, i) of the wave is 64 consecutive scalars: one conflict-free ds_read / ds_write per element.
+template <class Base, int NPARK>
+struct ParkA : Base {
+    static constexpr int kParkA = NPARK;
+    real* park;          // this lane's element (1, 0); element (q, i) is park[((q - 1) * 4 + i) * 64]
+    GR_DEV void stA(int q, int i, real v) const { park[((q - 1) * 4 + i) * 64] = v; }
+    GR_DEV real ldA(int q, int i) const { return park[((q - 1) * 4 + i) * 64]; }
+    static GR_DEV void park_fence()
+    {
+#ifndef GR_HOST_HARNESS
+        asm volatile("" ::: "memory");      // no forwarding of a parked value to its reload, no reload hoisted above a right-hand side
+#endif
+    }
+};
 
 // ---------------------------------------------------------------------------------------
 // The per-lane integrator.
@@ -1850,8 +1954,8 @@ struct Ray {
             double al_, be_;
             impact_parameters_of(p, jl, al_, be_);
 #ifdef GR_REAL_IS_TAN2
-            // the two tangent directions of this build: ∂/∂α and ∂/∂β of everything downstream
-            const real al(al_, 1.0, 0.0), be(be_, 0.0, 1.0);
+            // the tangent directions of this build: ∂/∂α and ∂/∂β of everything downstream (GR_TAN_W = 1: this lane's one)
+            const real al = gr_t_seed(al_, 0, tan_dir()), be = gr_t_seed(be_, 1, tan_dir());
 #else
             const real al = (real)al_, be = (real)be_;
 #endif
@@ -2002,10 +2106,28 @@ struct Ray {
         }
 
         real s, c;
+        // stage accelerations parked in LDS (ParkA): store A[S] behind its right-hand side, reload A[1..UPTO] where sums read them
+#define GR_PARK(S)                                                                             \
+    if constexpr (Cold_::kParkA >= (S)) {                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) cs.stA((S), i_, A[(S)][i_]);          \
+        Cold_::park_fence();                                                                   \
+    }
+#define GR_UNPARK(UPTO)                                                                        \
+    if constexpr (Cold_::kParkA > 0) {                                                         \
+        Cold_::park_fence();                                                                   \
+        _Pragma("unroll") for (int q_ = 1; q_ <= ((UPTO) < Cold_::kParkA ? (UPTO) : Cold_::kParkA); ++q_)   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) A[q_][i_] = cs.ldA(q_, i_);       \
+    }
+#ifdef GR_REAL_IS_TAN2
+#define GR_PIN4(a) { gr_t_pin((a)[0]); gr_t_pin((a)[1]); gr_t_pin((a)[2]); gr_t_pin((a)[3]); }     // see gr_t_pin
+#else
+#define GR_PIN4(a)
+#endif
         // stages 2..6: arguments need r, θ and the four velocities only (the RHS does not
         // depend on t or ϕ)
 #define GR_STAGE(S)                                                                                   \
     {                                                                                                 \
+        GR_UNPARK((S) - 1)                                                                            \
         real vs[4];                                                                                 \
         const real ha = Ts::A[S][0] * hh;                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
@@ -2031,6 +2153,8 @@ struct Ray {
         GR_DBG_BIT((GR_FABS(ts - x[2]) <= SINCOS_ROT_MAX) ? 0 : (1 << S));                                    \
         GR_DBG_DMAX(GR_FABS(ts - x[2]));                                                              \
         geodesic_rhs_sc(m, rs, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
+        GR_PIN4(A[S]);                                                                                \
+        GR_PARK(S)                                                                                    \
     }
         GR_STAGE(1)
         GR_STAGE(2)
@@ -2041,6 +2165,7 @@ struct Ray {
         // stage 7 argument = the new state.  Its right-hand side reads r, θ and the velocities; t and ϕ of the new state are
         // formed behind it (their old values are parked when the cold store is on)
         real xn[4], vn[4];
+        GR_UNPARK(5)
         const real ha6 = Ts::A[6][0] * hh, hc6 = TsD::X.C[6] * hh, h2a6 = TsD::X.AX[6][0] * h2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -2057,6 +2182,10 @@ struct Ray {
     }
         GR_NEW_POSITION(1)
         GR_NEW_POSITION(2)
+        if constexpr (Cold_::kParkA > 0) {      // t and ϕ of the new state while the parked accelerations are here
+            GR_NEW_POSITION(0)
+            GR_NEW_POSITION(3)
+        }
         // sin/cos at the new state by rotating the step's base as well (the RHS at the new state is stage 7 and the
         // base of the next step).  Rotation errors random-walk by ~1 ulp per step, so the base is re-synchronised
         // with a full evaluation every 64 accepted steps (and whenever the rotation falls back to it anyway).
@@ -2066,6 +2195,7 @@ struct Ray {
         if (resync) sincos_fast(xn[2], sn, cn);
         else sincos_rot(rotk, x[2], sth, cth, xn[2], sn, cn);
         geodesic_rhs_sc(m, xn[1], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);
+        GR_PIN4(A[6]);
 #else
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);
 #endif
@@ -2083,9 +2213,12 @@ struct Ray {
             lq_old = __builtin_bit_cast(float, lqb);
             j = cs.template ld<int64_t>(8);
         }
-        GR_NEW_POSITION(0)
-        GR_NEW_POSITION(3)
+        if constexpr (Cold_::kParkA == 0) {
+            GR_NEW_POSITION(0)
+            GR_NEW_POSITION(3)
+        }
 #undef GR_NEW_POSITION
+        GR_UNPARK(5)          // the error estimate reads every stage
 
         // error estimate, squared RMS norm over all eight components: ũ_v = h Σ b̃_q A_q, ũ_x = h (Σb̃ · v + h Σ b̄_i A_i);
         // the common factor h² and the 1/8 of the mean are applied once to the sum.
@@ -2119,14 +2252,14 @@ struct Ray {
                 // so the residual of component i is ũ_i / (abstol + reltol max(|u0_i|_D, |u1_i|_D)) as a Dual and EEst² is
                 // the mean over all 8 x 3 entries.  Steps shorten where the tangents are the stiffer part.
                 // max(‖u0‖_D, ‖u1‖_D) = sqrt(max of the squares): one square root per scale
-                const double qv0 = v[i].v * v[i].v + v[i].a * v[i].a + v[i].b * v[i].b;
-                const double qv1 = vn[i].v * vn[i].v + vn[i].a * vn[i].a + vn[i].b * vn[i].b;
-                const double qx0 = x[i].v * x[i].v + x[i].a * x[i].a + x[i].b * x[i].b;
-                const double qx1 = xn[i].v * xn[i].v + xn[i].a * xn[i].a + xn[i].b * xn[i].b;
+                const double qv0 = __builtin_fma(v[i].v, v[i].v, gr_t_tan_sq(v[i]));
+                const double qv1 = __builtin_fma(vn[i].v, vn[i].v, gr_t_tan_sq(vn[i]));
+                const double qx0 = __builtin_fma(x[i].v, x[i].v, gr_t_tan_sq(x[i]));
+                const double qx1 = __builtin_fma(xn[i].v, xn[i].v, gr_t_tan_sq(xn[i]));
                 const double sv = abstol.v + reltol.v * gr_d_sqrt(qv0 > qv1 ? qv0 : qv1);
                 const double sx = abstol.v + reltol.v * gr_d_sqrt(qx0 > qx1 ? qx0 : qx1);
                 const double iv = gr_d_rcp(sv) * (double)Ts::BT[0], ix = gr_d_rcp(sx);
-                e2n += (ev.v * ev.v + ev.a * ev.a + ev.b * ev.b) * (iv * iv) + (ex.v * ex.v + ex.a * ex.a + ex.b * ex.b) * (ix * ix);
+                e2n += __builtin_fma(ev.v, ev.v, gr_t_tan_sq(ev)) * (iv * iv) + __builtin_fma(ex.v, ex.v, gr_t_tan_sq(ex)) * (ix * ix);
                 continue;
             }
 #endif
@@ -2203,6 +2336,7 @@ struct Ray {
                             cs.template st<real>(8, t);
                             Cold_::fence();
                         }
+                        GR_UNPARK(5)          // the dense output reads the member array
                         top = sample_event(p, pos ? 1 : -1, hh);
                         if constexpr (Cold_::kOn) {
                             Cold_::fence();
@@ -2248,6 +2382,8 @@ struct Ray {
 #undef GR_CTL_EXP2
 #undef GR_CTL_MIN
 #undef GR_CTL_MAX
+#undef GR_PARK
+#undef GR_UNPARK
     }
 
     // dense-output polynomial coefficients of component `comp` (0..3 position, 4..7 velocity):
@@ -2432,12 +2568,13 @@ struct Ray {
             sincos_fast(xe[2], se, ce);
             const real cv = disc_cond4(p, xe[1], se, ce, xe[3]);
             // dc/dλ along the ray: the same condition on a state whose first tangent slot holds the velocity
-            const real r1(xe[1].v, ve[1].v, 0.0), t1(xe[2].v, ve[2].v, 0.0), p1(xe[3].v, ve[3].v, 0.0);
+            const real r1 = gr_t_along(xe[1].v, ve[1].v), t1 = gr_t_along(xe[2].v, ve[2].v), p1 = gr_t_along(xe[3].v, ve[3].v);
             real s1, c1;
             sincos_fast(t1, s1, c1);
             const double cdot = disc_cond4(p, r1, s1, c1, p1).a;
             if (cdot != 0.0) {
-                const double la = -cv.a / cdot, lb = -cv.b / cdot;
+                const double la = -cv.a / cdot;
+                GR_TAN_B(const double lb = -cv.b / cdot;)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     real C[4];
@@ -2445,10 +2582,11 @@ struct Ray {
                     // v̇ = (1/h) d/dΘ of the velocity interpolant
                     const double acc = C[0].v + theta.v * (2.0 * C[1].v + theta.v * (3.0 * C[2].v + theta.v * 4.0 * C[3].v));
                     const double vel = ve[i].v;
-                    xe[i].a += vel * la; xe[i].b += vel * lb;
-                    ve[i].a += acc * la; ve[i].b += acc * lb;
+                    xe[i].a += vel * la; ve[i].a += acc * la;
+                    GR_TAN_B(xe[i].b += vel * lb; ve[i].b += acc * lb;)
                 }
-                t.a += la; t.b += lb;
+                t.a += la;
+                GR_TAN_B(t.b += lb;)
             }
         }
 #endif
@@ -2461,9 +2599,20 @@ struct Ray {
     }
 
     // unpack_solution + apply_to_image!
-    GR_DEV void finalize(const Metric& m, const Params& p, const LdsView& lds)
+    GR_DEV void finalize(const Metric& m, const Params& p, const LdsView& lds) { finalize(m, p, lds, NoColdStore{}); }
+
+    template <class Cold_>
+    GR_DEV void finalize(const Metric& m, const Params& p, const LdsView& lds, const Cold_& cs)
     {
         if (DISC && (flags & RAY_EVENT)) {
+            if constexpr (Cold_::kParkA > 0) {
+                // the event step's accelerations of stages 1..kParkA are still where step() parked them
+                Cold_::park_fence();
+#pragma unroll
+                for (int q_ = 1; q_ <= Cold_::kParkA; ++q_)
+#pragma unroll
+                    for (int i_ = 0; i_ < 4; ++i_) A[q_][i_] = cs.ldA(q_, i_);
+            }
             resolve_event(p);
             flags &= ~RAY_EVENT;
         }
@@ -2513,12 +2662,25 @@ struct Ray {
                 // ray summary with tangents: (g, ρ, ∂g/∂α, ∂g/∂β, ∂ρ/∂α, ∂ρ/∂β, t, status) -- what
                 // jacobian_∂αβ_∂gr reads off its dual numbers (precision-solvers.jl:401-451)
                 double* o = cd.lp_pairs + 8 * j;
+#if GR_TAN_W == 1
+                // a pair of lanes per ray: the even lane carries ∂/∂α and writes the value columns, the odd one ∂/∂β
+                const int dir = tan_dir();
+                if (dir == 0) {
+                    o[0] = in ? g.v : __builtin_nan("");
+                    o[1] = rho.v;
+                    o[6] = x[0].v;
+                    o[7] = (double)status;
+                }
+                o[2 + dir] = g.a;
+                o[4 + dir] = rho.a;
+#else
                 o[0] = in ? g.v : __builtin_nan("");
                 o[1] = rho.v;
                 o[2] = g.a; o[3] = g.b;
                 o[4] = rho.a; o[5] = rho.b;
                 o[6] = x[0].v;
                 o[7] = (double)status;
+#endif
             } else
 #endif
             if (cd.out_mode == 4) {

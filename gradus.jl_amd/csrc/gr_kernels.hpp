@@ -65,29 +65,48 @@ struct ColdRareOf { static constexpr bool value = false; };
 template <class Metric>
 struct ColdRareOf<Metric, decltype((void)Metric::kColdRare)> { static constexpr bool value = Metric::kColdRare; };
 
+// How many stage accelerations the one-ray-per-lane kernel of a metric parks in LDS (ParkA, gr_device.hpp): Metric::kParkStages,
+// GR_PARK_STAGES overrides it for every metric of a build (the tangent objects: 4)
+template <class Metric, class = void>
+struct ParkStagesOf { static constexpr int value = 0; };
+template <class Metric>
+struct ParkStagesOf<Metric, decltype((void)Metric::kParkStages)> { static constexpr int value = Metric::kParkStages; };
+
 template <class Metric, bool LANE_KERNEL = true>      // the persistent kernel runs below the register cap: nothing to park
 struct ColdSel {
 #if GR_COLD_LDS == 1
-    typedef LdsColdStore type;
+    typedef LdsColdStore base;
 #elif GR_COLD_LDS == 2
-    typedef LdsColdStoreRare type;
+    typedef LdsColdStoreRare base;
 #elif GR_COLD_LDS == 3
-    typedef typename std::conditional<LANE_KERNEL && ColdRareOf<Metric>::value, LdsColdStoreRare, NoColdStore>::type type;
+    typedef typename std::conditional<LANE_KERNEL && ColdRareOf<Metric>::value, LdsColdStoreRare, NoColdStore>::type base;
 #else
-    typedef NoColdStore type;
+    typedef NoColdStore base;
 #endif
-    static constexpr size_t kBytesPerThread = type::kOn ? sizeof(double) * COLD_SLOTS : 0;
+#ifdef GR_PARK_STAGES
+    static constexpr int kPark = LANE_KERNEL ? GR_PARK_STAGES : 0;
+#else
+    static constexpr int kPark = LANE_KERNEL ? ParkStagesOf<Metric>::value : 0;
+#endif
+    typedef typename std::conditional<(kPark > 0), ParkA<base, kPark>, base>::type type;
+    static constexpr size_t kColdBytes = base::kOn ? sizeof(double) * COLD_SLOTS : 0;
+    static constexpr size_t kParkBytes = sizeof(real) * 4 * (size_t)kPark;
+    static constexpr size_t kBytesPerThread = kColdBytes + kParkBytes;
 };
-template <class Store>
-__device__ __forceinline__ Store cold_store_of(const Params& p)
+// wave w of the workgroup owns bytes [w * 64 * kBytesPerThread, (w + 1) * 64 * kBytesPerThread) of the region behind the
+// histogram and the plunging table: its cold slots first (64 lanes x COLD_SLOTS doubles), then its parked accelerations
+template <class Sel>
+__device__ __forceinline__ typename Sel::type cold_store_of(const Params& p)
 {
-    if constexpr (Store::kOn) {
-        // wave w of the workgroup owns doubles [w * 64 * COLD_SLOTS, (w + 1) * 64 * COLD_SLOTS) of the region
+    typedef typename Sel::type Store;
+    Store st{};
+    if constexpr (Store::kOn || Store::kParkA > 0) {
         const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
-        return Store{ gr_lds + p.lds_bins + 4 * p.lds_plunge_rows + w * (64 * COLD_SLOTS) + l };
-    } else {
-        return Store{};
+        char* region = reinterpret_cast<char*>(gr_lds + p.lds_bins + 4 * p.lds_plunge_rows) + (size_t)w * (64 * Sel::kBytesPerThread);
+        if constexpr (Store::kOn) st.lane = reinterpret_cast<double*>(region) + l;
+        if constexpr (Store::kParkA > 0) st.park = reinterpret_cast<real*>(region + 64 * Sel::kColdBytes) + l;
     }
+    return st;
 }
 
 // bytes of LDS per work-item of the end-point region: its record and its address slot
@@ -187,6 +206,22 @@ __device__ __forceinline__ void lds_epilogue(const Cold* cold, int lds_bins, con
 #define GR_PARAMS_AFTER_LOOP(p, pl, z) const Params& pl = p;
 #endif
 
+// Which chunk of the rays workgroup b traces when the rays come in CALLER order (ray arrays, impact-parameter sets).
+// Workgroups go to the 8 XCDs round-robin (b mod 8), so with chunk = b every ray pattern whose period is a multiple of 8
+// chunks lands on the same XCDs: the α ≈ 0 column of a 1024-wide grid of impact parameters -- the rays that pass the polar
+// axis and take five times the steps -- is chunk 7 / 8 of every 16, i.e. XCD 7 and XCD 0 only; those two ran for 38 ms while
+// the other six had finished after 16 (measured wave by wave, scripts/wave_timeline.py -> profiles/r4_tangent_timeline.txt).
+// The map below keeps b's group of 8 (so neighbouring chunks still run at about the same time) but rotates the chunk within
+// the group by the base-8 digit sum of the group's index: periodic patterns of any period 8^k and clustered ones are both
+// dealt to all eight XCDs.  A bijection on [0, 8 ceil(W / 8)); the launcher rounds the grid up to a multiple of 8.
+__device__ __forceinline__ unsigned xcd_chunk(unsigned b)
+{
+    const unsigned r = b >> 3;
+    unsigned sum = 0;
+    for (unsigned t = r; t; t >>= 3) sum += t & 7u;
+    return (r << 3) | ((b - sum) & 7u);
+}
+
 // ---- kernel 0: one ray per work-item ----
 template <class Metric, int DISC>
 #ifndef GR_LANE_MIN_WAVES
@@ -195,14 +230,20 @@ template <class Metric, int DISC>
 __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Params p)
 {
     GR_PARAMS_OPAQUE_ZERO(zoff)
+#ifdef GR_WAVE_TIMELINE      // debug builds only (scripts/wave_timeline.py): when did this wave run, where, and how long was its longest ray
+    const unsigned long long tl0 = wall_clock64();
+    int tl_steps = 0;
+#endif
     Metric m;
     m.load(p.cfg);
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (the tangent build traces a ray with a PAIR of lanes, one per direction of the Jacobian: LANES_PER_RAY_LOG2 = 1)
+    const unsigned chunk = p.xcd_spread ? xcd_chunk(blockIdx.x) : blockIdx.x;
+    const int64_t gid = ((int64_t)chunk * blockDim.x + threadIdx.x) >> LANES_PER_RAY_LOG2;
     LaneStats<Metric, DISC> ls;
     const LdsView lds = lds_prologue<ColdSel<Metric>::kBytesPerThread>(p);
     if (gid < p.n) {
         Ray<Metric, DISC> ray;
-        const typename ColdSel<Metric>::type cs = cold_store_of<typename ColdSel<Metric>::type>(p);
+        const typename ColdSel<Metric>::type cs = cold_store_of<ColdSel<Metric>>(p);
         ray.init(m, p, tile_swizzle(cold_of(p), gid));
         while (!ray.step(m, p, cs)) {}
         // In a one-wave workgroup finalize() lays the end-point record down in the LDS bytes other lanes of this wave use as
@@ -211,9 +252,25 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
         // per-lane exit block.  It emits no instruction.
         __builtin_amdgcn_wave_barrier();
         GR_PARAMS_AFTER_LOOP(p, pl, zoff)
-        ray.finalize(m, pl, lds);
-        ls.add(ray);
+        ray.finalize(m, pl, lds, cs);
+        if (LANES_PER_RAY_LOG2 == 0 || tan_dir() == 0) ls.add(ray);      // a ray is counted once
+#ifdef GR_WAVE_TIMELINE
+        tl_steps = ray.nacc + ray.nrej;
+#endif
     }
+#ifdef GR_WAVE_TIMELINE
+    if (p.queue) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(tl_steps, off, 64); tl_steps = o > tl_steps ? o : tl_steps; }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned hw = 0, xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = p.queue + 4ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+            o[0] = tl0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = (unsigned long long)tl_steps;
+        }
+    }
+#endif
     points_epilogue(lds);
     lds_epilogue(p.cold, p.lds_bins, lds);
     ls.flush(p.stats);
@@ -234,7 +291,7 @@ __global__ void __launch_bounds__(256, GR_PERSISTENT_MIN_WAVES) k_trace_persiste
     const int lane = threadIdx.x & 63;
     const int threshold = p.refill_threshold;
     const LdsView lds = lds_prologue<ColdSel<Metric, false>::kBytesPerThread>(p);
-    const typename ColdSel<Metric, false>::type cs = cold_store_of<typename ColdSel<Metric, false>::type>(p);
+    const typename ColdSel<Metric, false>::type cs = cold_store_of<ColdSel<Metric, false>>(p);
 
     for (;;) {
         const unsigned long long act = __ballot(active);
@@ -364,7 +421,8 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 #else
     if (k.kernel == 0) {
 #endif
-        const int64_t grid = (p.n + block - 1) / block;
+        int64_t grid = ((p.n << LANES_PER_RAY_LOG2) + block - 1) / block;
+        if (p.xcd_spread) grid = (grid + 7) / 8 * 8;       // xcd_chunk permutes whole groups of 8 workgroups
         hipLaunchKernelGGL((k_trace_lane<Metric, DISC>), dim3((unsigned)grid), dim3(block), lds, stream, p);
     }
 #ifndef GR_LANE_ONLY

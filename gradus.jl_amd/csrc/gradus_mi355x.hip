@@ -120,6 +120,7 @@ struct gr_ctx {
     int64_t hugepages = 1;                 // madvise(MADV_HUGEPAGE) on large caller-owned result buffers before pre-faulting
     int64_t lds_points = 1;                // one-ray-per-lane kernel: a wave's end-point records leave through LDS as whole runs
     int64_t direct_host = 1;               // gr_render_endpoints into a gr_host_alloc block: the kernel stores across the link itself
+    int64_t xcd_spread = 1;                // one-ray-per-lane kernel, rays in caller order: chunks dealt over the XCDs by digit sum
     int64_t tangent_norm = 1;              // tangent kernels: the tangents are part of the error norm (DiffEqBase on Dual state); 0 = values only
     // LPT state for one (config, plane, range) key
     std::vector<unsigned char> lpt_key;
@@ -337,6 +338,10 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
     return GR_OK;
 }
 
+#ifdef GR_WAVE_TIMELINE
+unsigned long long* g_debug_timeline = nullptr;
+#endif
+
 int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t stream)
 {
     Cold cold = cold_in;
@@ -360,7 +365,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
     const bool tangent = cold.out_mode == 5;
     const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold);
-    const int block_sel = tangent ? 64 : resolve_block(ctx, kern_sel);
+    const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
     // A table is staged per workgroup: with one-wave workgroups a CU holds 8 copies, so it is staged
     // only while those fit the 160 KB of LDS without capping the occupancy (<= 640 rows of 32 B).
@@ -372,6 +377,9 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
                          && cold_in.pf.n_plunge <= lds_rows_max) ? (int32_t)cold_in.pf.n_plunge : 0;
     p.lds_bins = (ctx->lds && cold_in.out_mode == 2 && cold_in.lp_nbins <= 4096) ? (int32_t)cold_in.lp_nbins : 0;
     p.lds_points = (ctx->lds_points && cold.out_mode == 1 && kern_sel == 0) ? 1 : 0;
+    // rays in caller order on the one-ray-per-lane kernel: deal the chunks of 64 rays over the XCDs (gr_kernels.hpp, xcd_chunk);
+    // image planes are tiled and their tile order already mixes (gr_ctx_set "xcd_spread" 0 switches it off)
+    p.xcd_spread = (ctx->xcd_spread && kern_sel == 0 && cold.src_mode != 0) ? 1 : 0;
     derive_params(p);
     LaunchKnobs knobs{ kern_sel, block_sel, ctx->n_cu, (int)ctx->waves_per_simd,
                        ctx->d_queue + ctx->queue_next };
@@ -379,6 +387,9 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     // validate_cfg() has pinned metric_id to [GR_METRIC_KERR, GR_METRIC_NOZ]
     const trace_fn fn = (tangent ? kTraceTan : ctx->precision == 32 ? kTrace32 : kTrace64)[p.cfg.metric_id];
     p.tangent_norm = (tangent && ctx->tangent_norm) ? 1 : 0;
+#ifdef GR_WAVE_TIMELINE
+    p.queue = g_debug_timeline;      // debug builds: 4 x u64 per wave of a one-ray-per-lane launch (gr_kernels.hpp)
+#endif
     const hipError_t le = fn(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
     if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
     if (stream == ctx->stream) GR_HIP(hipEventRecord(ctx->ev_k, stream));      // host variants: where the kernel ends
@@ -483,6 +494,11 @@ void stats_to_host(const unsigned long long* h, gr_stats* s)
 extern "C" {
 
 int32_t gr_abi_version(void) { return GR_ABI_VERSION; }
+
+#ifdef GR_WAVE_TIMELINE
+// debug builds only (not in the header): device buffer of 4 x u64 per wave for the next launches, or NULL
+void gr_debug_set_timeline(void* device_buffer) { g_debug_timeline = (unsigned long long*)device_buffer; }
+#endif
 
 const char* gr_last_error(void) { return g_last_error.c_str(); }
 
@@ -688,6 +704,8 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->hugepages = value ? 1 : 0;
     } else if (k == "tangent_norm") {
         c->tangent_norm = value ? 1 : 0;
+    } else if (k == "xcd_spread") {
+        c->xcd_spread = value ? 1 : 0;
     } else if (k == "lds_points") {
         c->lds_points = value ? 1 : 0;
     } else if (k == "direct_host") {

@@ -17,13 +17,28 @@
 #error "compile with -DGR_TU_METRIC=<metric id>"
 #endif
 #if defined(GR_TU_TAN)
-// third flavour: real = value + ∂/∂α + ∂/∂β (gr_tangent.hpp), the one-ray-per-lane kernel only, one wave per SIMD (the
-// state is three times as wide; these kernels trace a few thousand rays per call for the transfer-function Jacobians)
+// third flavour: real = value + tangents (gr_tangent.hpp), the one-ray-per-lane kernel only.  Shipped shape, measured on the
+// 1024² profile launch (scripts/wave_timeline.py, profiles/r4_tangent_*): GR_TAN_W = 2 -- one lane carries a ray with both
+// directions of the Jacobian --, one wave per SIMD (455 registers, no scratch): 20.9 ms.  The alternative that fits 256
+// registers -- GR_TAN_W = 1, a PAIR of lanes per ray, two waves per SIMD, stage accelerations parked in LDS (GR_PARK_STAGES 4) --
+// runs the same launch in 24.5 ms: a step of a wave is a long dependent chain (10.3 µs with both directions, 8.8 µs with one;
+// 2900 against 1750 vector instructions), so halving the work of a lane buys 15 % per step while the value part is computed
+// twice.  Both shapes build from this source and pass the same tests (scripts/build_variant.sh ... -DGR_TAN_W=1 -DGR_TAN_MIN_WAVES=2
+// -DGR_PARK_STAGES=4).
 #define GR_REAL_IS_TAN2 1
+#ifndef GR_TAN_W
+#define GR_TAN_W 2
+#endif
 #define GR_NS grt
 #define GR_TU_PREFIX grt
 #define GR_LANE_ONLY 1
-#define GR_LANE_MIN_WAVES 1
+#ifndef GR_TAN_MIN_WAVES
+#define GR_TAN_MIN_WAVES 1  // waves per SIMD the tangent kernels are compiled for
+#endif
+#define GR_LANE_MIN_WAVES GR_TAN_MIN_WAVES
+#ifndef GR_PARK_STAGES
+#define GR_PARK_STAGES 0    // stage accelerations parked in LDS while a right-hand side runs (ParkA, gr_device.hpp)
+#endif
 #elif defined(GR_TU_F32)
 #define GR_REAL_IS_FLOAT 1
 #define GR_NS gr32

@@ -30,7 +30,13 @@ else:
 import __graft_entry__ as g
 units = g.hip_units(extra)
 if metrics and rev == "WORK":
-    keep = {f"kernels_m{m}.o" for m in metrics.split()} | {f"kernels32_m{m}.o" for m in metrics.split()} | {"gradus_mi355x.o"}
+    # "t0" = only the TANGENT object of metric 0 (kernelstan_m0.o); "0" = that metric's fp64, fp32 and tangent objects
+    keep = {"gradus_mi355x.o"}
+    for m in metrics.split():
+        if m.startswith("t"):
+            keep.add(f"kernelstan_m{m[1:]}.o")
+        else:
+            keep |= {f"kernels_m{m}.o", f"kernels32_m{m}.o", f"kernelstan_m{m}.o"}
     for o, _, _ in units:
         if o not in keep:
             shutil.copy(os.path.join(root, "gradus.jl_amd", "csrc", o), os.path.join(src, o))

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""When did every wave of one gr_ray_tangent_device launch run?  Needs a library built with -DGR_WAVE_TIMELINE
+(scripts/build_variant.sh WORK <name> -DGR_WAVE_TIMELINE; GRADUS_MI355X_LIB=ab/<name>.so): every wave of the one-ray-per-lane
+kernel writes (start, end [100 MHz clock], hardware id, steps of its longest ray).  Prints the distribution of wave lifetimes,
+the number of waves resident over time and where the launch's tail comes from.
+    python scripts/wave_timeline.py [S=1024] [order=grid|lpt]"""
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import gradus_jl_amd as G
+from gradus_jl_amd import _lib
+from gradus_jl_amd.rendering import abi_pointfunction
+from gradus_jl_amd.tracing import lnr_momentum_to_global_velocity_matrix
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+order = sys.argv[2] if len(sys.argv) > 2 else "grid"
+ens = G.EnsembleMI355X(0)
+m = G.KerrMetric(1.0, 0.998)
+x = np.array([0.0, 1000.0, math.radians(75), 0.0])
+cfg = G.tracing_configuration(m, x, np.zeros((1, 4)), G.DatumPlane(0.0), 2000.0, ensemble=ens)
+acfg = cfg.abi_config()
+apf, keep = abi_pointfunction(G.ConstPointFunctions.redshift(m, x))
+dev = torch.device("cuda", 0)
+L = _lib.load()
+L.gr_debug_set_timeline.argtypes = [C.c_void_p]
+Mx = lnr_momentum_to_global_velocity_matrix(m, cfg.position)
+aa, bb = np.meshgrid(np.linspace(-60.0, 60.0, S), np.linspace(-35.0, 35.0, S))
+a, b = aa.ravel().copy(), bb.ravel().copy()
+if order == "lpt":        # rays closest to the polar axis / the photon ring first
+    k = np.argsort(np.minimum(np.abs(a), np.hypot(a - 2.5, b)), kind="stable")
+    a, b = a[k], b[k]
+d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+n = S * S
+rs = _lib.gr_rayset()
+for i in range(4):
+    rs.x_obs[i] = float(cfg.position[i])
+    for q in range(4):
+        rs.Mx[4 * i + q] = float(Mx[i, q])
+rs.alpha, rs.beta, rs.area, rs.n = d_a.data_ptr(), d_b.data_ptr(), None, n
+o = torch.empty(n * 8, dtype=torch.float64, device=dev)
+waves_max = 2 * n // 64 + 8
+tl = torch.zeros(4 * waves_max, dtype=torch.int64, device=dev)
+for rep in range(2):
+    tl.zero_()
+    L.gr_debug_set_timeline(C.c_void_p(tl.data_ptr()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(L.gr_ray_tangent_device(ens.ctx.handle, C.byref(acfg), C.byref(rs), C.byref(apf), C.c_void_p(o.data_ptr()), None,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    e1.record()
+    torch.cuda.synchronize()
+L.gr_debug_set_timeline(None)
+ms = e0.elapsed_time(e1)
+t = tl.cpu().numpy().reshape(-1, 4)
+t = t[t[:, 1] != 0]
+t0, t1, hw, steps = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+base = t0.min()
+st, en = (t0 - base) / 1e5, (t1 - base) / 1e5          # ms (100 MHz clock)
+life = en - st
+print(f"launch {ms:.2f} ms, {t.shape[0]} waves; wave lifetime ms: mean {life.mean():.3f} median {np.median(life):.3f} p90 {np.percentile(life, 90):.3f} "
+      f"p99 {np.percentile(life, 99):.3f} max {life.max():.3f}; longest ray of a wave, steps: median {np.median(steps):.0f} p99 {np.percentile(steps, 99):.0f} max {steps.max()}")
+print(f"last wave starts at {st.max():.2f} ms, last wave ends at {en.max():.2f} ms; sum of lifetimes / launch = {life.sum() / en.max():.1f} waves resident on average")
+edges = np.linspace(0, en.max(), 21)
+res = [(int(((st < hi) & (en > lo)).sum())) for lo, hi in zip(edges[:-1], edges[1:])]
+print("waves resident per 5 % slice of the launch:", res)
+late = np.argsort(en)[-8:]
+print("the waves that end last (start, end, steps of longest ray):", [(round(float(st[i]), 2), round(float(en[i]), 2), int(steps[i])) for i in late])
+per_step = life * 1e3 / np.maximum(steps, 1)
+print(f"µs per step of a wave's longest ray: median {np.median(per_step):.2f} p10 {np.percentile(per_step, 10):.2f} p90 {np.percentile(per_step, 90):.2f}; "
+      f"for the 1 % longest waves {np.median(per_step[np.argsort(life)[-len(life) // 100:]]):.2f}")
+print(json.dumps({"launch_ms": ms, "waves": int(t.shape[0]), "lifetime_ms": {"mean": float(life.mean()), "p99": float(np.percentile(life, 99)), "max": float(life.max())},
+                  "steps_longest": {"median": float(np.median(steps)), "max": int(steps.max())}, "last_start_ms": float(st.max()), "resident_per_slice": res}))

@@ -12,6 +12,8 @@
 
 using namespace grt;
 
+static int32_t* g_steps = nullptr;      // per-ray attempted steps of the next run (hht_set_steps_out), or null
+
 template <class Metric, int DISC>
 static void run(const Params& p)
 {
@@ -23,12 +25,16 @@ static void run(const Params& p)
         ray.init(m, p, j);
         while (!ray.step(m, p)) {}
         ray.finalize(m, p, no_lds);
+        if (g_steps) g_steps[j] = ray.nacc + ray.nrej;
     }
 }
 
 static int g_tangent_norm = 1;      // the library's default (gr_ctx: tangent_norm = 1)
 
 extern "C" {
+
+// where the next hht_ray_tangent writes every ray's number of attempted steps (n int32; null = nowhere)
+void hht_set_steps_out(int32_t* steps) { g_steps = steps; }
 
 // 1 = the error norm over values and tangents (what gr_ctx_set(ctx, "tangent_norm", 1) selects in the library)
 void hht_set_tangent_norm(int on) { g_tangent_norm = on ? 1 : 0; }
