@@ -74,6 +74,16 @@ typedef double gr_real_t;
 #ifndef GR_GENERIC_MIN_WAVES
 #define GR_GENERIC_MIN_WAVES 2
 #endif
+// Stages of the Tsit5 step whose accelerations the one-ray-per-lane kernels of the non-Kerr metrics park in LDS (ParkA below)
+// to run three waves per SIMD instead of two.  MEASURED in round 4 and left OFF: with -DGR_PARK_DEFAULT=5 every such kernel fits
+// 142-168 registers without scratch (205 -> 157 for Johannsen) and 2.4 waves are resident per SIMD instead of 1.7 -- and the
+// issue rate does not move (0.850 against 0.847 per 4 clocks, FP64 pipe 0.77 against 0.75 busy; profiles/r4e_c4_*): Johannsen
+// 1024² 8.44 against 8.07 ms, 2048² 27.8 against 28.5; Bumblebee 2048² 22.9 against 22.4; dilaton-axion 38.5 against 39.2.  The
+// slots two waves leave empty are not waiting for a third wave: 89 % of these kernels' instructions are FP64 (Kerr: 85 %), which
+// the pipe takes at 0.77 per 4 clocks at best.  The fp32 kernels have registers to spare and never park.
+#ifndef GR_PARK_DEFAULT
+#define GR_PARK_DEFAULT 0
+#endif
 
 #ifdef GR_HOST_HARNESS
 // tests/host_harness.cpp compiles this header with g++ to trace single rays on the CPU next to
@@ -500,7 +510,10 @@ struct KerrFamily {
     // one-ray-per-lane kernel: capped at 168 VGPRs = 3 waves/SIMD.  The few spilled values (36-68 B of scratch) live in
     // the rarely executed event-sampling blocks, none on the step's main path; the third wave hides the dependent
     // FP64 chains that two waves leave exposed: 22.95 -> 21.97 ms on the 2048² image (profiles/r2_ab_variants.txt)
-    static constexpr int kLaneWavesPerSimd = CHARGED ? 2 : 3;
+    // Kerr-Newman (and every metric below) since round 4: three waves as well, made to fit by parking the stage accelerations
+    // in LDS (ParkA: 197 -> 163 registers, no scratch)
+    static constexpr int kLaneWavesPerSimd = (CHARGED && GR_PARK_DEFAULT == 0) ? 2 : 3;
+    static constexpr int kParkStages = CHARGED ? GR_PARK_DEFAULT : 0;
     static constexpr bool kColdRare = !CHARGED;                // at the register cap: the event sampling parks in LDS (gr_kernels.hpp)
     real M, a;
     real Q, Q2, qm;      // CHARGED only: charge, its square, test-particle q (or q/μ)
@@ -698,7 +711,10 @@ struct JohannsenMetric {
     static constexpr bool kHasForce = false;
     static constexpr bool kFusedRhs = true;                    // rhs() below replaces eval() + the generic contraction
     static constexpr int kMinWavesPerSimd = 2;
-    static constexpr int kLaneWavesPerSimd = 2;
+    // one-ray-per-lane kernel: 205 registers and two waves per SIMD left 17 % of the issue slots empty (profiles/r3zz_c4: issue
+    // 0.83); with A[1..5] parked in LDS (ParkA, 10 KB per wave) the kernel needs 157 and runs three
+    static constexpr int kLaneWavesPerSimd = GR_PARK_DEFAULT > 0 ? 3 : 2;      // (-DGR_PARK_DEFAULT=0: the round-3 shape, for A/B)
+    static constexpr int kParkStages = GR_PARK_DEFAULT;
     real M, a, a13, a22, a52, e3;
     real ka2, ktM, keM3;                             // a², 2M, ϵ3 M³: uniform, formed once (rhs)
     real kA1, kA2, kA5, kA1r, kA2r, kA5r;            // α13 M³, α22 M², α52 M² and -3, -2, -2 times them: A_i = 1 + kA_i / r^n
@@ -883,23 +899,41 @@ struct JohannsenMetric {
 // instruction cache), 180 B of scratch per lane and 1.8x the time of Kerr.  ID < 0 keeps the run-time switch
 // (tests/host_harness.cpp traces every metric through one instantiation).
 #ifndef GR_JP_LANE_WAVES
-#define GR_JP_LANE_WAVES 2
+#define GR_JP_LANE_WAVES (GR_PARK_DEFAULT > 0 ? 3 : 2)
+#endif
+#ifndef GR_GENERIC_LANE_WAVES
+#define GR_GENERIC_LANE_WAVES (GR_PARK_DEFAULT > 0 ? 3 : 2)
+#endif
+#ifndef GR_FUSED23_LANE_WAVES
+#define GR_FUSED23_LANE_WAVES 3
 #endif
 template <int ID>
 struct GenericMetricT {
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
-    static constexpr int kLaneWavesPerSimd = (ID == GR_METRIC_JOHANNSEN_PSALTIS) ? GR_JP_LANE_WAVES : GR_GENERIC_MIN_WAVES;
+    // one-ray-per-lane kernel: three waves per SIMD with the stage accelerations parked in LDS (181-228 registers without,
+    // 142-168 with, no scratch: scripts/kernel_probe.sh "GenericMetricT<id>")
+    // Bumblebee and Morris-Thorne with their fused right-hand sides need 167 registers (Bumblebee: with the event sampling's
+    // registers parked in LDS like Kerr's, kColdRare): three waves per SIMD (GR_FUSED23_LANE_WAVES=2: the two-wave shape, A/B)
+    static constexpr bool kSlimFused = (ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE);
+    static constexpr int kLaneWavesPerSimd = kSlimFused ? GR_FUSED23_LANE_WAVES
+                                             : (ID == GR_METRIC_JOHANNSEN_PSALTIS) ? GR_JP_LANE_WAVES : GR_GENERIC_LANE_WAVES;
+    static constexpr bool kColdRare = (ID == GR_METRIC_BUMBLEBEE) && kLaneWavesPerSimd >= 3;
+    static constexpr int kParkStages = (!kSlimFused && kLaneWavesPerSimd >= 3) ? GR_PARK_DEFAULT : 0;
     static constexpr bool kHasForce = false;
-    static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS);      // rhs() below
+    // rhs() below: hand-derived for Johannsen-Psaltis (round 3) and for Bumblebee and Morris-Thorne (round 4) -- the other
+    // five dual-number metrics take eval() + the generic contraction
+    static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS || ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE);
     int32_t id;
     real P[6];
     real ka2, ktM, keps;      // Johannsen-Psaltis rhs(): a², 2M, ϵ3 M³ -- uniform, formed once
+    real kik;                 // Bumblebee rhs(): 1/(1 + l)
     GR_DEV void load(const gr_config& c)
     {
         id = ID >= 0 ? ID : c.metric_id;
 #pragma unroll
         for (int i = 0; i < 6; ++i) P[i] = c.params[i];
         ka2 = uni(P[1] * P[1]); ktM = uni(2.0 * P[0]); keps = uni(P[2] * P[0] * P[0] * P[0]);
+        kik = (ID == GR_METRIC_BUMBLEBEE) ? uni(rcp_full(1.0 + P[2])) : (real)0.0;
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
     static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
@@ -1150,9 +1184,72 @@ struct GenericMetricT {
     //   a^r = (Δ̃/(ΣH)) ½(Φ_r + 2r v_θ²) - ½ L_r v_r² - L_θ v_r v_θ,   a^θ = [½Φ_θ + ½ g_rr L_θ v_r² + ½ a² S2 v_θ² - 2r v_r v_θ]/Σ.
     // Two reciprocals (1/Σ; 1/(H Δ̃ s²) shared by 1/H, 1/Δ̃, 1/(s²Δ̃)).  Equal to eval() + the generic contraction to
     // rounding (tests/test_kernel_logic_host.py::test_fused_johannsen_psaltis_rhs_equals_generic_contraction).
+    //
+    // Morris-Thorne (morris-thorne-ad.jl:4-15; coordinate l, w = l² + b²; g_ϕϕ = w sinθ to the FIRST power as in the
+    // reference): g_tt = -1, g_rr = 1, g_θθ = w, g_ϕϕ = w s, no t-ϕ term, so
+    //   a^t = 0,  a^l = l (v_θ² + s v_ϕ²),  a^θ = -2 l v_l v_θ / w + ½ c v_ϕ²,  a^ϕ = -(2 l v_l / w + (c/s) v_θ) v_ϕ.
+    // One reciprocal, 1/(w s), shared by 1/w and 1/s.
+    //
+    // Bumblebee (bumblebee-ad.jl:6-21; k = 1 + l, u = 2M/r, K = 2Ma): g_tt = u - 1, g_rr = k r/(r - 2M), g_θθ = r²,
+    // g_ϕϕ = r² s², g_tϕ = -K s²/r.  The t-ϕ block has determinant s² D', D' = (u - 1) r² - K² s²/r², so
+    //   a^t = -(r² T_t + (K/r) T_ϕ)/D',   a^ϕ = -((K/r) T_t + ((u - 1)/s²) T_ϕ)/D',
+    //   T_t = ġ_tt v^t + ġ_tϕ v^ϕ,  T_ϕ = ġ_tϕ v^t + ġ_ϕϕ v^ϕ,  ġ_tt = -(u/r) v_r,  ġ_tϕ = (K s²/r²) v_r - (K S2/r) v_θ,
+    //   ġ_ϕϕ = 2 r s² v_r + r² S2 v_θ   (S2 = 2 sinθ cosθ),
+    //   a^r = ½ [2M v_r²/(r (r - 2M)) + ((r - 2M)/(k r)) (g_tt,r v_t² + 2 r v_θ² + 2 r s² v_ϕ² + 2 g_tϕ,r v_t v_ϕ)],
+    //   a^θ = -2 v_r v_θ / r + ½ (r² S2 v_ϕ² - 2 (K S2 / r) v_t v_ϕ)/r².
+    // Two reciprocals: 1/(r (r - 2M)) shared by 1/r and 1/(r - 2M); 1/(D' s²) shared by 1/D' and 1/(s² D').
+    // All three equal eval() + the generic contraction to rounding (tests/test_kernel_logic_host.py).
     GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
                     real& at, real& ar, real& ah, real& ap) const
     {
+        if constexpr (ID == GR_METRIC_MORRIS_THORNE) {
+            const real l = r;
+            const real w = GR_FMA(l, l, P[0] * P[0]);
+            const real R = rcp_rhs(w * s);                   // 1/(w s)
+            const real iw = R * s, is = R * w;
+            const real vp2 = vp * vp;
+            const real tl = 2.0 * l;
+            at = 0.0;
+            ar = l * GR_FMA(s, vp2, vh * vh);
+            ah = GR_FMA(-(tl * iw), vr * vh, (0.5 * c) * vp2);
+            ap = -(GR_FMA(tl * iw, vr, (c * is) * vh) * vp);
+            return;
+        } else if constexpr (ID == GR_METRIC_BUMBLEBEE) {
+            const real tM = ktM, K = ktM * P[1];
+            const real rm = r - tM;
+            const real Q = rcp_rhs(r * rm);                  // 1/(r (r - 2M))
+            const real ir = Q * rm, irm = Q * r;
+            const real s2 = s * s, S2 = 2.0 * (s * c);
+            const real u = tM * ir, ir2 = ir * ir;
+            const real Kir = K * ir;                         // -g_tϕ / s²
+            const real r2 = r * r;
+            const real Dp = GR_FMA(u - 1.0, r2, -((K * Kir) * (s2 * ir)));       // D' = (u - 1) r² - K² s²/r²
+            const real R = rcp_rhs(Dp * s2);                 // 1/(D' s²)
+            const real iDp = R * s2, is2Dp = R;
+            // metric gradients
+            const real gtt_r = -(u * ir);
+            const real gtp_r = (Kir * ir) * s2;              // K s²/r²
+            const real gtp_h = -(Kir * S2);
+            const real gpp_r = (2.0 * r) * s2;
+            const real gpp_h = r2 * S2;
+            // dots along the ray and the linear forms
+            const real gtt_d = gtt_r * vr;
+            const real gtp_d = GR_FMA(gtp_r, vr, gtp_h * vh);
+            const real gpp_d = GR_FMA(gpp_r, vr, gpp_h * vh);
+            const real Tt = GR_FMA(gtt_d, vt, gtp_d * vp);
+            const real Tp = GR_FMA(gtp_d, vt, gpp_d * vp);
+            at = -(GR_FMA(r2, Tt, Kir * Tp) * iDp);
+            ap = -GR_FMA(Kir * iDp, Tt, ((u - 1.0) * is2Dp) * Tp);
+            // quadratic forms
+            const real vt2 = vt * vt, vp2 = vp * vp, vtp = vt * vp, vh2 = vh * vh;
+            const real tr = 2.0 * r;
+            const real Dr = GR_FMA(gtt_r, vt2, GR_FMA(tr, vh2, GR_FMA(gpp_r, vp2, (2.0 * gtp_r) * vtp)));     // without the g_rr term
+            const real girr = (rm * ir) * kik;                 // g^rr = (r - 2M)/(k r)
+            ar = 0.5 * GR_FMA((tM * ir) * irm, vr * vr, girr * Dr);
+            const real Dh = GR_FMA(gpp_h, vp2, (2.0 * gtp_h) * vtp);
+            ah = GR_FMA(-(2.0 * ir), vr * vh, (0.5 * ir2) * Dh);
+            return;
+        }
         const real a = P[1];
         const real a2 = ka2, tM = ktM, eps = keps;
         const real s2 = s * s, S2 = 2.0 * (s * c), tr = 2.0 * r;

@@ -411,6 +411,9 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 {
     const int block = k.block;
     if (k.kernel != 0) p.lds_points = 0;     // the persistent kernel refills lanes one by one: no wave-wide moment to send records
+    // a kernel that parks its stage accelerations in LDS (10 KB per wave) leaves the plunging table in L2: twelve one-wave
+    // workgroups per CU cannot each hold a copy as well (staged and L2-served look-ups measured equal, gradus_mi355x.hip)
+    if (k.kernel == 0 && ColdSel<Metric, true>::kPark > 0) p.lds_plunge_rows = 0;
     const size_t cold_b = (k.kernel == 0 ? ColdSel<Metric, true>::kBytesPerThread : ColdSel<Metric, false>::kBytesPerThread) * (size_t)block;
     const size_t point_b = p.lds_points ? kPointLdsBytesPerThread * (size_t)block : 0;
     // one-wave workgroups: the end-point records reuse the cold lane storage (lds_prologue)

@@ -3,7 +3,10 @@
 PROF_CMD="scripts/sibling_workloads.py <which>" PROF_KERNEL=<substring of the kernel name>):
 
     c4        JohannsenMetric(a=0.7, α13=2, ϵ3=1) 1024², ThinDisc(isco, 50), interpolated redshift   k_trace_lane<JohannsenMetric,1>
-    generic   JohannsenPsaltisMetric(a=0.7, ϵ3=1) 1024², ThinDisc, shadow (dual-number functor)       k_trace_lane<GenericMetric,1>
+    generic   JohannsenPsaltisMetric(a=0.7, ϵ3=1) 1024², ThinDisc, shadow (hand-fused right-hand side)    k_trace_lane<GenericMetricT<5>,1>
+    dual      BumblebeeMetric(a=0.25, l=0.5) 1024², ThinDisc, shadow -- a TRUE dual-number metric          k_trace_lane<GenericMetricT<3>,1>
+    dual2     MorrisThorneWormhole(b=1) 1024², ThinDisc, shadow (hand-fused since round 4)                k_trace_lane<GenericMetricT<2>,1>
+    dual6     DilatonAxion(a=0.5, β=0.3, b=1) 1024², ThinDisc, shadow -- the heaviest dual-number metric k_trace_lane<GenericMetricT<6>,1>
     c5        BASELINE config 5 line profile, 4096² polar-plane rays, fp64 tol 1e-9                  k_trace_lane<KerrFamily<false>,1> (tiled rays)
     c5p       the same through the persistent kernel                                                  k_trace_persistent<...>
     c5f32     config 5 with the fp32 kernels at tol 1e-5                                              gr32::k_trace_*
@@ -32,8 +35,20 @@ ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
 ms = []
 extra = {}
 
-if which in ("c4", "generic"):
-    if which == "c4":
+if which in ("c4", "generic", "dual", "dual6", "dual2"):
+    if which == "dual2":
+        m = G.MorrisThorneWormhole(1.0)
+        x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+        pf = G.ConstPointFunctions.shadow()
+    elif which == "dual":
+        m = G.BumblebeeMetric(1.0, 0.25, 0.5)
+        x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+        pf = G.ConstPointFunctions.shadow()
+    elif which == "dual6":
+        m = G.DilatonAxion(1.0, 0.5, 0.3, 1.0)
+        x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+        pf = G.ConstPointFunctions.shadow()
+    elif which == "c4":
         m = G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0)
         x = np.array([0.0, 1000.0, math.radians(70), 0.0])
         pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
@@ -41,9 +56,10 @@ if which in ("c4", "generic"):
         m = G.JohannsenPsaltisMetric(1.0, 0.7, 1.0)
         x = np.array([0.0, 1000.0, math.radians(70), 0.0])
         pf = G.ConstPointFunctions.shadow()
-    S = 1024
+    S = int(os.environ.get("SIB_SIZE", "1024"))          # (2048: a launch deep enough that its tail does not decide)
     for _ in range(reps):
-        _, _, img, st = G.rendergeodesics(m, x, G.ThinDisc(m.isco(), 50.0), 2000.0, image_width=S, image_height=S,
+        disc = G.ThinDisc(5.0, 50.0) if which == "dual2" else G.ThinDisc(m.isco(), 50.0)        # (a wormhole has no ISCO)
+        _, _, img, st = G.rendergeodesics(m, x, disc, 2000.0, image_width=S, image_height=S,
                                           alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens, stats=True)
         ms.append(st["kernel_ms"])
     rays = S * S

@@ -529,3 +529,35 @@ def test_fused_johannsen_psaltis_rhs_equals_generic_contraction(G, oracle):
         errs_fo.append(np.abs(fused - ref).max() / np.abs(ref).max())
     assert np.median(errs_fg) < 5e-15 and max(errs_fg) < 5e-12, (np.median(errs_fg), max(errs_fg))
     assert np.median(errs_fo) < 5e-15 and max(errs_fo) < 5e-12, (np.median(errs_fo), max(errs_fo))
+
+
+@pytest.mark.parametrize("name", ["bumblebee", "morris-thorne"])
+def test_fused_bumblebee_and_morris_thorne_rhs_equal_generic_contraction(G, oracle, name):
+    """GenericMetricT<BUMBLEBEE>::rhs and GenericMetricT<MORRIS_THORNE>::rhs (round 4: hand-derived, gr_device.hpp) against the
+    dual-number eval() + the generic contraction of the same functor and against the oracle's dual-number geodesic_equation
+    (src/metrics/bumblebee-ad.jl:6-21, morris-thorne-ad.jl:4-15 through auto-diff.jl:115-141,206-226)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(17)
+    L = Hh.lib()
+    errs_fg, errs_fo = [], []
+    for _ in range(400):
+        if name == "bumblebee":
+            params = (rng.uniform(0.5, 1.5), rng.uniform(-0.29, 0.29), rng.uniform(-0.5, 2.0))
+            m = G.BumblebeeMetric(*params)
+            r = 1.05 * m.inner_radius() + 10.0 ** rng.uniform(-1, 3)
+        else:
+            params = (rng.uniform(0.3, 3.0),)
+            m = G.MorrisThorneWormhole(*params)
+            r = rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-2, 3)          # the coordinate l runs through the throat
+        th = rng.uniform(0.02, math.pi - 0.02)
+        v = np.array([rng.uniform(1, 2), rng.uniform(-1, 1), rng.uniform(-1, 1) / abs(r), rng.uniform(-1, 1) / abs(r)])
+        cfg = G.tracing_configuration(m, np.array([0.0, r, th, 0.0]), v, None, (0.0, 1.0)).abi_config()
+        fused, generic = np.zeros(4), np.zeros(4)
+        assert L.hh_rhs_both(C.byref(cfg), C.c_double(r), C.c_double(th), v.ctypes.data_as(C.c_void_p),
+                             fused.ctypes.data_as(C.c_void_p), generic.ctypes.data_as(C.c_void_p)) == 0
+        ref = oracle.geodesic_equation(oracle.make_config(name, params), np.array([0.0, r, th, 0.0]), v)
+        errs_fg.append(np.abs(fused - generic).max() / np.abs(generic).max())
+        errs_fo.append(np.abs(fused - ref).max() / np.abs(ref).max())
+    assert np.median(errs_fg) < 5e-15 and max(errs_fg) < 5e-12, (np.median(errs_fg), max(errs_fg))
+    assert np.median(errs_fo) < 5e-15 and max(errs_fo) < 5e-12, (np.median(errs_fo), max(errs_fo))
