@@ -99,6 +99,7 @@ typedef double gr_real_t;
 #endif
 #define GR_LOG2F(x) std::log2((float)(x))
 #define GR_EXP2F(x) std::exp2((float)(x))
+#define GR_RCPF(x) (1.0f / (x))
 #else
 #include <hip/hip_runtime.h>
 #define GR_DEV __device__ __forceinline__
@@ -114,6 +115,7 @@ typedef double gr_real_t;
 #endif
 #define GR_LOG2F(x) __builtin_amdgcn_logf(x)     // v_log_f32
 #define GR_EXP2F(x) __builtin_amdgcn_exp2f(x)    // v_exp_f32
+#define GR_RCPF(x) __builtin_amdgcn_rcpf(x)      // v_rcp_f32
 #endif
 
 namespace GR_NS {
@@ -1576,6 +1578,16 @@ struct Cold {
     int32_t out_reserved;
 };
 
+// the error norm's scaled residuals in single precision: the fp64 device kernels only (see Ray::step)
+#ifndef GR_NORM_F32
+#define GR_NORM_F32 1
+#endif
+#if GR_NORM_F32 && !defined(GR_REAL_IS_FLOAT) && !defined(GR_REAL_IS_TAN2)
+#define GR_NORM_F32_ON 1
+#else
+#define GR_NORM_F32_ON 0
+#endif
+
 constexpr int N_STAT = 9;   // statistics counters of a launch: rays, accepted, rejected, rhs, flagged, status[4]
 
 struct Params {
@@ -2328,6 +2340,9 @@ struct Ray {
         // 4.3e-11 with it, 1.0e-10 without (tests/test_gpu_baseline_configs.py).
         const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
         real e2v = 0.0, e2x = 0.0;        // Σ (ũ_v / b̃_0 / scale)², Σ (ũ_x / scale)² (before the common h² / 8)
+#if GR_NORM_F32_ON
+        float e2vf = 0.f, e2xf = 0.f;
+#endif
 #ifdef GR_REAL_IS_TAN2
         double e2n = 0.0;
 #endif
@@ -2360,6 +2375,21 @@ struct Ray {
                 continue;
             }
 #endif
+#if GR_NORM_F32_ON
+            // The scaled residuals in SINGLE precision (round 4; -DGR_NORM_F32=0 restores the FP64 form): one v_cvt_f32_f64 per
+            // operand, then v_fma_f32 / v_rcp_f32 / v_mul_f32 instead of 2 FMA + 2 quarter-rate v_rcp_f64 + 2 MUL + 2 FMA in FP64
+            // per component -- 809 -> 776 FP64 instructions per step, 18.20 -> 17.93 ms interleaved on one box
+            // (profiles/r4h_ab_normf32.txt).  The quotient feeds a controller that works in single precision anyway (and whose
+            // FP64 form used the bare 4.6e-8 reciprocal seed): on C2 every pixel keeps its class (814 flips against the oracle
+            // with either form, 0 between them), steps per ray agree to 1e-8, the soak's classes are unchanged.
+            {
+                const float smv = (float)absmax(v[i], vn[i]), smx = (float)absmax(x[i], xn[i]);
+                const float avf = (float)ev * GR_RCPF(__builtin_fmaf(smv, (float)reltol, (float)abstol));
+                const float axf = (float)ex * GR_RCPF(__builtin_fmaf(smx, (float)reltol, (float)abstol));
+                e2vf = __builtin_fmaf(avf, avf, e2vf);
+                e2xf = __builtin_fmaf(axf, axf, e2xf);
+            }
+#else
             const real skv = GR_FMA(absmax(v[i], vn[i]), reltol, abstol);
             const real skx = GR_FMA(absmax(x[i], xn[i]), reltol, abstol);
             // the bare v_rcp_f64 seed is good to 4.6e-8 (measured, scripts/rcp_accuracy.hip): ample for
@@ -2368,8 +2398,13 @@ struct Ray {
             const real ax = ex * rcp_raw(skx);
             e2v = GR_FMA(av, av, e2v);
             e2x = GR_FMA(ax, ax, e2x);
+#endif
         }
+#if GR_NORM_F32_ON
+        real e2 = (real)__builtin_fmaf((float)(Ts::BT[0] * Ts::BT[0]), e2vf, e2xf);
+#else
         real e2 = GR_FMA((real)(Ts::BT[0] * Ts::BT[0]), e2v, e2x);
+#endif
 #ifdef GR_REAL_IS_TAN2
         if (p.tangent_norm) e2 = real(e2n * (1.0 / 3.0));
 #endif
@@ -2470,7 +2505,21 @@ struct Ray {
             // 1/qmin, so the step size would stay finite and the ray would be rejected ~25 times down to
             // dt < dtmin: test for it here (rejected steps only, so the accepted path pays nothing)
             nrej++;
-            if (!(e2 == e2)) { flags |= GR_FLAG_NAN; return true; }
+            if (!(e2 == e2)) {
+#if GR_NORM_F32_ON
+                // The single-precision norm also turns NaN when a trial state is astronomically far off (tolerance 1e-3 next to
+                // the hole: v_new ~ 1e44 overflows the scale to inf, inf x 1/inf): that is a step to reject, not a NaN state --
+                // the FP64 norm called it 1e160 and rejected it.  A state that really holds a NaN shows it in (x_new, v_new) or
+                // in the right-hand side there; only then is the ray flagged.  (fminf below returns 1/qmin for the NaN factor.)
+                bool state_nan = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) state_nan |= !(xn[i] == xn[i]) || !(vn[i] == vn[i]) || !(A[6][i] == A[6][i]);
+                if (state_nan) { flags |= GR_FLAG_NAN; return true; }
+#else
+                flags |= GR_FLAG_NAN;
+                return true;
+#endif
+            }
             const ctl_t q11 = GR_CTL_EXP2((ctl_t)PI_BETA1 * lE);
             dt = hh / (real)GR_CTL_MIN((ctl_t)(1.0 / PI_QMIN), q11 * (ctl_t)(1.0 / PI_GAMMA));
             return false;

@@ -71,6 +71,30 @@ def gather_image(local, plan: ShardPlan, group=None, dst: int = 0):
     return full.view(plan.width, plan.height).t()
 
 
+def gather_points(local, plan: ShardPlan, group=None, dst: int = 0):
+    """The end points of a sharded plane (prerendergeodesics / the generic boundary with one process per GPU): every rank
+    holds its `plan.count` GeodesicPoint records in local ray order as a uint8 tensor of 152 bytes per ray; ONE gather brings
+    them to `dst`, one permute undoes the block-cyclic deal.  Returns a uint8 tensor of 152 * W * H bytes in image order
+    (ray i = x H + y, the order of gr_render_endpoints) on `dst`, None elsewhere.  RCCL on GPU tensors, gloo on CPU ones.
+
+    This is the one exchange of the whole path whose size matters: 637 MB for a 2048² plane, 7/8 of it crossing xGMI into
+    rank 0 over seven point-to-point links at ≈153 GB/s each: ≈ 0.5 ms if the seven senders arrive together, against ≈ 18 / 8 ms
+    of tracing per rank."""
+    import torch
+    import torch.distributed as dist
+
+    rec = _lib.POINT_DTYPE.itemsize
+    assert local.dtype == torch.uint8 and local.numel() == plan.count * rec
+    if plan.world == 1:
+        return local
+    bufs = [torch.empty_like(local) for _ in range(plan.world)] if plan.rank == dst else None
+    dist.gather(local, bufs, dst=dst, group=group)
+    if plan.rank != dst:
+        return None
+    full = torch.stack(bufs)                                   # [world, n_blocks * block * 152]
+    return full.view(plan.world, plan.n_blocks, plan.block * rec).permute(1, 0, 2).reshape(-1)
+
+
 class PendingGather:
     """Handle of an in-flight gather started by `gather_image_async`.  `result()` waits for the
     collective (making the current stream wait, for RCCL) and returns the (H, W) image on `dst`."""

@@ -75,6 +75,50 @@ def test_sharded_render_equals_single(oracle, G, tmp_path, world, use_async):
     np.testing.assert_array_equal(img[~np.isnan(img)], ref[~np.isnan(ref)])
 
 
+def _points_worker(rank, world, port, W, H, tmp):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gradus_jl_amd as G
+    from oracle import oracle as O
+
+    plan = G.shard_plan(W, H, world, rank)
+    gi = np.array([plan.global_index(int(k)) for k in range(plan.count)])
+    x = np.array([0.0, 100.0, math.radians(85), 0.0])
+    cfg = O.make_config("kerr", (1.0, 0.0), disc=(0.0, 40.0), lambda_max=200.0)
+    v = np.concatenate([O.render_velocities(cfg, x, (-9.5, 9.5), (-9.5, 9.5), W, H, i0=int(i), n=1) for i in gi])
+    pts = np.ascontiguousarray(O.trace(cfg, x, v, nthreads=1))
+    assert pts.dtype.itemsize == 152
+    local = torch.from_numpy(pts.view(np.uint8).copy())
+    full = G.gather_points(local, plan)
+    if rank == 0:
+        np.save(os.path.join(tmp, "pts.npy"), full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8])
+def test_sharded_endpoints_gather_equals_single(oracle, G, tmp_path, world):
+    """The one exchange of the path whose size matters (637 MB at 2048²): every rank's 152-byte records in
+    local order -> ONE gather -> image order on rank 0.  World size 8 = the node the driver scales to, on gloo."""
+    W, H = 16, 8
+    mp.spawn(_points_worker, args=(world, _free_port(), W, H, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "pts.npy").view(oracle.POINT_DTYPE if hasattr(oracle, "POINT_DTYPE") else G._lib.POINT_DTYPE)
+    x = np.array([0.0, 100.0, math.radians(85), 0.0])
+    cfg = oracle.make_config("kerr", (1.0, 0.0), disc=(0.0, 40.0), lambda_max=200.0)
+    v = oracle.render_velocities(cfg, x, (-9.5, 9.5), (-9.5, 9.5), W, H, i0=0, n=W * H)
+    ref = oracle.trace(cfg, x, v, nthreads=2)
+    assert got.size == W * H
+    for f in ("status", "lambda_max", "x", "v", "x_init", "v_init"):
+        np.testing.assert_array_equal(got[f], ref[f], err_msg=f)
+
+
 def test_shard_plan_covers_image_exactly(G):
     for W, H, world in ((2048, 2048, 8), (2048, 2048, 4), (1024, 1024, 2), (96, 40, 3), (20, 20, 1)):
         seen = np.zeros(W * H, dtype=np.int32)
