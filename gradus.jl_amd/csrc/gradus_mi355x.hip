@@ -34,6 +34,7 @@ using namespace gr;
     hipError_t gr64_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);             \
     hipError_t gr32_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);             \
     hipError_t grt_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);              \
+    hipError_t grt1_launch_trace_m##ID(int, int, int, int, unsigned long long*, const void*, hipStream_t);             \
     hipError_t gr64_launch_path_m##ID(const void*, double*, int64_t, unsigned long long*, hipStream_t);                \
     hipError_t gr64_launch_apply_m##ID(const void*, const gr_point*, double, double*, hipStream_t);
 GR_DECLARE_METRIC(0) GR_DECLARE_METRIC(1) GR_DECLARE_METRIC(2) GR_DECLARE_METRIC(3) GR_DECLARE_METRIC(4) GR_DECLARE_METRIC(5)
@@ -55,7 +56,8 @@ typedef hipError_t (*apply_fn)(const void*, const gr_point*, double, double*, hi
 #define GR_ROW(F) { F##0, F##1, F##2, F##3, F##4, F##5, F##6, F##7, F##8, F##9, F##10 }
 const trace_fn kTrace64[11] = GR_ROW(gr64_launch_trace_m);
 const trace_fn kTrace32[11] = GR_ROW(gr32_launch_trace_m);
-const trace_fn kTraceTan[11] = GR_ROW(grt_launch_trace_m);      // value + ∂/∂α + ∂/∂β (out_mode 5)
+const trace_fn kTraceTan[11] = GR_ROW(grt_launch_trace_m);      // value + ∂/∂α + ∂/∂β (out_mode 5): one lane per ray
+const trace_fn kTraceTan1[11] = GR_ROW(grt1_launch_trace_m);    // the same with a PAIR of lanes per ray (kernels_tu.hip)
 const path_fn kPath64[11] = GR_ROW(gr64_launch_path_m);
 const apply_fn kApply64[11] = GR_ROW(gr64_launch_apply_m);
 #undef GR_ROW
@@ -120,6 +122,7 @@ struct gr_ctx {
     int64_t hugepages = 1;                 // madvise(MADV_HUGEPAGE) on large caller-owned result buffers before pre-faulting
     int64_t lds_points = 1;                // one-ray-per-lane kernel: a wave's end-point records leave through LDS as whole runs
     int64_t direct_host = 1;               // gr_render_endpoints into a gr_host_alloc block: the kernel stores across the link itself
+    int64_t tangent_pairs = 2;             // tangent kernels: 0 = one lane per ray, 1 = a pair of lanes per ray, 2 = by launch size
     int64_t xcd_spread = 1;                // one-ray-per-lane kernel, rays in caller order: chunks dealt over the XCDs by digit sum
     int64_t tangent_norm = 1;              // tangent kernels: the tangents are part of the error norm (DiffEqBase on Dual state); 0 = values only
     // LPT state for one (config, plane, range) key
@@ -385,7 +388,11 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
                        ctx->d_queue + ctx->queue_next };
     ctx->queue_next = (ctx->queue_next + 1) % ctx->queue_slots;
     // validate_cfg() has pinned metric_id to [GR_METRIC_KERR, GR_METRIC_NOZ]
-    const trace_fn fn = (tangent ? kTraceTan : ctx->precision == 32 ? kTrace32 : kTrace64)[p.cfg.metric_id];
+    // Tangent launches come in two shapes (kernels_tu.hip): a pair of lanes per ray has the shorter step (latency), one lane
+    // per ray does less work in all (throughput).  A launch whose pairs fit the machine at one wave per SIMD -- 2 n / 64 waves
+    // on 4 SIMDs per CU -- cannot keep the SIMDs busy either way and is as long as its longest ray: it takes the pairs.
+    const bool pairs = tangent && (ctx->tangent_pairs == 1 || (ctx->tangent_pairs == 2 && 2 * p.n <= (int64_t)ctx->n_cu * 4 * 64));
+    const trace_fn fn = (tangent ? (pairs ? kTraceTan1 : kTraceTan) : ctx->precision == 32 ? kTrace32 : kTrace64)[p.cfg.metric_id];
     p.tangent_norm = (tangent && ctx->tangent_norm) ? 1 : 0;
 #ifdef GR_WAVE_TIMELINE
     p.queue = g_debug_timeline;      // debug builds: 4 x u64 per wave of a one-ray-per-lane launch (gr_kernels.hpp)
@@ -704,6 +711,9 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->hugepages = value ? 1 : 0;
     } else if (k == "tangent_norm") {
         c->tangent_norm = value ? 1 : 0;
+    } else if (k == "tangent_pairs") {
+        if (value < 0 || value > 2) return fail(GR_ERR_INVALID_ARGUMENT, "tangent_pairs must be 0 (one lane per ray), 1 (a pair of lanes per ray) or 2 (by launch size)");
+        c->tangent_pairs = value;
     } else if (k == "xcd_spread") {
         c->xcd_spread = value ? 1 : 0;
     } else if (k == "lds_points") {

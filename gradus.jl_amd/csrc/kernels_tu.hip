@@ -2,7 +2,8 @@
 //
 //     hipcc ... -DGR_TU_METRIC=<GR_METRIC_* id> -c kernels_tu.hip -o kernels_m<id>.o                       (fp64)
 //     hipcc ... -DGR_TU_METRIC=<id> -DGR_TU_F32 -Xclang -cl-single-precision-constant ... -o kernels32_m<id>.o   (fp32)
-//     hipcc ... -DGR_TU_METRIC=<id> -DGR_TU_TAN -c kernels_tu.hip -o kernelstan_m<id>.o                     (tangent)
+//     hipcc ... -DGR_TU_METRIC=<id> -DGR_TU_TAN -c kernels_tu.hip -o kernelstan_m<id>.o                     (tangent, one lane per ray)
+//     hipcc ... -DGR_TU_METRIC=<id> -DGR_TU_TAN1 -c kernels_tu.hip -o kernelstan1_m<id>.o                   (tangent, a pair of lanes per ray)
 //
 // so that every metric's kernels hold only that metric's component function (gr_device.hpp, GenericMetricT) and the
 // library builds on all cores at once (__graft_entry__.build_hip).  The fp32 objects are the same source with
@@ -12,25 +13,34 @@
 //
 // Exports (plain signatures: the host unit, gradus_mi355x.hip, passes its gr::Params by address -- gr32::Params has the
 // same layout, its fields are double / integer / pointers only):
-//     gr64_launch_trace_m<ID>, gr64_launch_path_m<ID>, gr64_launch_apply_m<ID>      gr32_launch_trace_m<ID>      grt_launch_trace_m<ID>
+//     gr64_launch_trace_m<ID>, gr64_launch_path_m<ID>, gr64_launch_apply_m<ID>      gr32_launch_trace_m<ID>      grt_launch_trace_m<ID>      grt1_launch_trace_m<ID>
 #ifndef GR_TU_METRIC
 #error "compile with -DGR_TU_METRIC=<metric id>"
 #endif
-#if defined(GR_TU_TAN)
-// third flavour: real = value + tangents (gr_tangent.hpp), the one-ray-per-lane kernel only.  Shipped shape, measured on the
-// 1024² profile launch (scripts/wave_timeline.py, profiles/r4_tangent_*): GR_TAN_W = 2 -- one lane carries a ray with both
-// directions of the Jacobian --, one wave per SIMD (455 registers, no scratch): 20.9 ms.  The alternative that fits 256
-// registers -- GR_TAN_W = 1, a PAIR of lanes per ray, two waves per SIMD, stage accelerations parked in LDS (GR_PARK_STAGES 4) --
-// runs the same launch in 24.5 ms: a step of a wave is a long dependent chain (10.3 µs with both directions, 8.8 µs with one;
-// 2900 against 1750 vector instructions), so halving the work of a lane buys 15 % per step while the value part is computed
-// twice.  Both shapes build from this source and pass the same tests (scripts/build_variant.sh ... -DGR_TAN_W=1 -DGR_TAN_MIN_WAVES=2
-// -DGR_PARK_STAGES=4).
+#if defined(GR_TU_TAN) || defined(GR_TU_TAN1)
+// third flavour: real = value + tangents (gr_tangent.hpp), the one-ray-per-lane kernel only, one wave per SIMD, in TWO shapes
+// (round 4; measured with scripts/wave_timeline.py, scripts/lineprofile_tf_time.py; profiles/r4_tangent_*):
+//   GR_TU_TAN   namespace grt,  GR_TAN_W = 2: one lane carries a ray with both directions of the Jacobian (455 registers, no
+//               scratch).  The THROUGHPUT shape: 1024² rays in 20.9 ms.
+//   GR_TU_TAN1  namespace grt1, GR_TAN_W = 1: a PAIR of lanes per ray, one direction each (299 registers, no scratch).  A
+//               wave's step is a long dependent chain and a lane with one direction has 1750 instead of 2900 vector
+//               instructions in it: 8.8 instead of 10.3 µs per step.  The LATENCY shape: the default line profile of the
+//               reference (TransferFunctionMethod: 909 launches of ~126 rays, each as long as its longest ray) takes 1.16 s
+//               with it against 1.55 s -- and 24.5 ms against 20.9 for the 1024² launch, where the value part computed
+//               twice costs more than the shorter chain saves.
+// The host unit picks per launch (gr_ctx_set "tangent_pairs": launches that cannot fill the SIMDs anyway take the pairs).
+// A 256-register variant of the pair shape (two waves per SIMD, stage accelerations parked in LDS: -DGR_TAN_MIN_WAVES=2
+// -DGR_PARK_STAGES=4) was measured and lost to both (24.5 ms; 1.31 s).
 #define GR_REAL_IS_TAN2 1
-#ifndef GR_TAN_W
+#if defined(GR_TU_TAN1)
+#define GR_TAN_W 1
+#define GR_NS grt1
+#define GR_TU_PREFIX grt1
+#else
 #define GR_TAN_W 2
-#endif
 #define GR_NS grt
 #define GR_TU_PREFIX grt
+#endif
 #define GR_LANE_ONLY 1
 #ifndef GR_TAN_MIN_WAVES
 #define GR_TAN_MIN_WAVES 1  // waves per SIMD the tangent kernels are compiled for
@@ -67,7 +77,7 @@ hipError_t GR_TU_NAME(_launch_trace_m)(int kernel, int block, int n_cu, int wave
     return GR_NS::launch_metric<TuMetric>(k, p, stream);
 }
 
-#if !defined(GR_TU_F32) && !defined(GR_TU_TAN)
+#if !defined(GR_TU_F32) && !defined(GR_TU_TAN) && !defined(GR_TU_TAN1)
 hipError_t GR_TU_NAME(_launch_path_m)(const void* params, double* d_path, int64_t cap, unsigned long long* d_n, hipStream_t stream)
 {
     return GR_NS::launch_path_metric<TuMetric>(*reinterpret_cast<const GR_NS::Params*>(params), d_path, cap, d_n, stream);

@@ -51,6 +51,21 @@ class CunninghamTransferData:
 SUMMARY_DTYPE = np.dtype([("status", np.int32), ("x", np.float64, (4,))])
 
 
+# scripts/lineprofile_tf_time.py sets this to a list: every launch of a device tracer then appends (entry point, rays, kernel ms,
+# call ms) so that a product's wall time can be split into launches and host work
+LAUNCH_LOG = None
+
+
+def _logged(name, n):
+    """(gr_stats to pass to the call or None, function to call after it)"""
+    from . import _lib
+
+    if LAUNCH_LOG is None:
+        return None, lambda: None
+    st = _lib.gr_stats()
+    return st, lambda: LAUNCH_LOG.append((name, int(n), st.kernel_ms, st.call_ms))
+
+
 def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, callback=None, **solver_opts):
     """(α, β[, heights]) arrays -> (ray summaries, g): every ray against `geometry` (default
     DatumPlane(0); with `heights`, one DatumPlane per ray -- datumplane(d, rₑ), datum-plane.jl:14-17)
@@ -91,10 +106,23 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
             keep += (h,)
         return rs, keep
 
+    # an ensemble over several devices: the same launches through the *_multi entry points (contiguous shares of the rays)
+    ens_ = config.ensemble
+    many = ens_.multi
+    if many:
+        ctx_arr, ctx_stats = _lib.ctx_array(ens_.contexts)
+        n_ctx = len(ens_.contexts)
+
     def trace(α, β, heights=None):
         rs, keep = rayset(α, β, heights)
         out = np.zeros((rs.n, 4))
-        _lib.check(L.gr_ray_summary(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, None))
+        if many:
+            _lib.check(L.gr_ray_summary_multi(ctx_arr, n_ctx, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, ctx_stats))
+        else:
+            st, done = _logged("gr_ray_summary", rs.n)
+            _lib.check(L.gr_ray_summary(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data,
+                                        C.byref(st) if st is not None else None))
+            done()
         pts = np.zeros(rs.n, dtype=SUMMARY_DTYPE)
         pts["status"] = out[:, 3].astype(np.int32)
         pts["x"][:, 0], pts["x"][:, 1], pts["x"][:, 2] = out[:, 2], out[:, 1], math.pi / 2
@@ -103,7 +131,13 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
     def endpoints(α, β, heights=None):
         rs, keep = rayset(α, β, heights)
         pts = np.zeros(rs.n, dtype=_lib.POINT_DTYPE)
-        _lib.check(L.gr_rayset_endpoints(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), pts.ctypes.data, None))
+        if many:
+            _lib.check(L.gr_rayset_endpoints_multi(ctx_arr, n_ctx, C.byref(cfg), C.byref(rs), pts.ctypes.data, ctx_stats))
+            return pts
+        st, done = _logged("gr_rayset_endpoints", rs.n)
+        _lib.check(L.gr_rayset_endpoints(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), pts.ctypes.data,
+                                         C.byref(st) if st is not None else None))
+        done()
         return pts
 
     def tangent(α, β, heights=None):
@@ -111,7 +145,13 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
         (`gr_ray_tangent`), what the reference's ForwardDiff.jacobian around tracegeodesics produces."""
         rs, keep = rayset(α, β, heights)
         out = np.zeros((rs.n, 8))
-        _lib.check(L.gr_ray_tangent(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, None))
+        if many:
+            _lib.check(L.gr_ray_tangent_multi(ctx_arr, n_ctx, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, ctx_stats))
+        else:
+            st, done = _logged("gr_ray_tangent", rs.n)
+            _lib.check(L.gr_ray_tangent(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data,
+                                        C.byref(st) if st is not None else None))
+            done()
         return out
 
     trace.endpoints = endpoints

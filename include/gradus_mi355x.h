@@ -238,11 +238,21 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * Dual state, what the reference's solves under ForwardDiff use (src/tracing/precision-solvers.jl:73-131,401-451); two
  * independent integrators then agree on the Jacobians to 1e-6 (tests/test_oracle_tangent.py) --, 0 = values only: the
  * tangents ride on the very steps of the plain trace and are good to ~1e-5, 4e-3 on rays through the polar axis);
+ * ("tangent_pairs", gr_ray_tangent's kernel shape: 0 = one lane carries a ray with both directions of the Jacobian (least work:
+ * 1024² rays in 20.9 ms), 1 = a PAIR of lanes per ray, one direction each (shortest step: the reference's default line profile,
+ * 909 launches of ~126 rays, in 1.16 s against 1.55 s), 2 [default] = pairs for launches that cannot fill the SIMDs anyway
+ * (2 n lanes <= one wave per SIMD), one lane per ray beyond; same results to rounding either way);
+ * ("xcd_spread", 1 [default] = rays in caller order on the one-ray-per-lane kernel are dealt to the 8 XCDs by the digit sum of
+ * their chunk index instead of round-robin -- a periodic pattern in the rays, such as the polar-axis column of a 1024-wide grid of
+ * impact parameters, otherwise lands on one or two XCDs (38 against 21 ms) --, 0 = chunk b to workgroup b);
  * ("lds_points", 1 [default] = the one-ray-per-lane kernel sends a wave's 64 end-point records through LDS as runs of
  * consecutive addresses, 0 = every lane stores its own 152 bytes; same bytes either way); ("direct_host", 1 [default] =
  * gr_render_endpoints into a gr_host_alloc block lets the kernel store across the link itself -- no staging buffer, no
  * copy --, 0 = staged in HBM and copied in bands as for caller-owned memory); ("pinned_pool_mib", process-wide: bytes of freed
- * gr_host_alloc blocks kept page-locked for the next request, default 4096 in at most 4 blocks, 0 = empty the pool and keep nothing);
+ * gr_host_alloc blocks kept page-locked for the next request, default 1024 in at most 4 blocks, 0 = empty the pool and keep nothing;
+ * the pool is emptied when the last context is destroyed); ("pinned_max_mib", process-wide: bytes of gr_host_alloc blocks that may
+ * be outstanding at once, default 8192 -- a request beyond it is refused with GR_ERR_OUT_OF_MEMORY and the caller falls back to
+ * pageable memory: a garbage-collected caller sees a 100-byte wrapper, not the block behind it);
  * ("pinned_huge", process-wide: 1 [default] = gr_host_alloc blocks of 8 MiB and more are mappings on transparent huge pages
  * registered with the runtime (13 ms for 608 MiB), 0 = every block from hipHostMalloc (122-365 ms)). */
 int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
@@ -259,8 +269,15 @@ int32_t gr_ctx_set(gr_ctx* ctx, const char* key, int64_t value);
  * gr_host_free(ctx, NULL) is a no-op.  Blocks of 8 MiB and more are anonymous mappings on transparent huge pages that the
  * library registers with the runtime (608 MiB: 13 ms; hipHostMalloc takes 122-365 ms for the same block), and freed blocks
  * wait in a bounded process-wide pool for the next request of a similar size (gr_ctx_set "pinned_pool_mib"), which then
- * costs nothing.  The memory of a reused block holds the
- * previous result until the next call overwrites it. */
+ * costs nothing.  The memory of a reused block holds the previous result until the next call overwrites it -- a call that
+ * writes only PART of a block (a gr_range that is not the whole plane) leaves the rest as it found it.
+ * PROCESS-WIDE STATE, the one exception to "no global state but the context handle" (SURVEY §8b): the registry of blocks, the
+ * pool and its two limits ("pinned_pool_mib", "pinned_max_mib": set through any context, they apply to all) belong to the
+ * process because the blocks must outlive contexts.  The library counts the bytes it has handed out and REFUSES
+ * (GR_ERR_OUT_OF_MEMORY) a request that would take them past "pinned_max_mib" (default 8 GiB): bindings for garbage-collected
+ * languages collect and retry, or fall back to pageable memory.  The pool is emptied when the last context is destroyed.
+ * Only a destination that lies ENTIRELY inside one block is written by a kernel directly; anything else -- a pointer near the end
+ * of a block, a block too small for the result -- takes the staged copy like caller-owned memory. */
 int32_t gr_host_alloc(gr_ctx* ctx, int64_t bytes, void** out);
 int32_t gr_host_free(gr_ctx* ctx, void* p);
 

@@ -225,6 +225,18 @@ def test_lineprofile_multi_equals_one_context(G, ens, multi4):
     np.testing.assert_allclose(g1, f1, rtol=1e-11, atol=1e-15)
 
 
+def test_transfer_function_through_a_multi_ensemble(G, ens, multi4):
+    """The Cunningham transfer function's launches (gr_ray_tangent / gr_ray_summary on a few hundred rays each) through an
+    ensemble of four contexts: the same numbers as on one (contiguous shares, same kernels, same bytes per ray)."""
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 100_000.0, math.radians(60), 0.0])
+    kw = dict(N=40, chart=G.chart_for_metric(m, 2 * x[1], closest_approach=1.005))
+    one = G.cunningham_transfer_function(m, x, G.ThinDisc(0.0, float("inf")), 7.0, ensemble=ens, **kw)
+    many = G.cunningham_transfer_function(m, x, G.ThinDisc(0.0, float("inf")), 7.0, ensemble=multi4, **kw)
+    assert one.f.size == many.f.size and np.all(np.isfinite(one.f))
+    assert many.f.tobytes() == one.f.tobytes() and many.g_star.tobytes() == one.g_star.tobytes()
+
+
 def test_multi_argument_errors(G, ens, multi4):
     from gradus_jl_amd import _lib
     from gradus_jl_amd.tracing import separable_rayset, tracing_configuration

@@ -20,9 +20,31 @@ GOLD = {(3, 4.0): 0.14048899037409682, (35, 4.0): 0.10846177995555085, (74, 4.0)
 UNMET = {(3, 4.0), (30, 4.0), (35, 4.0)}
 
 
-@pytest.fixture()
-def ens(G):
-    return G.EnsembleMI355X(0)
+# Both shapes of the tangent kernels (kernels_tu.hip): "lane" = one lane carries a ray with both directions of the Jacobian
+# (the throughput shape), "pairs" = a pair of neighbouring lanes per ray, one direction each (the latency shape; the Dual
+# norm's sums cross the pair).  Every test of this file runs on both; by default the library picks by launch size.
+@pytest.fixture(params=[0, 1], ids=["lane", "pairs"])
+def ens(G, request):
+    return G.EnsembleMI355X(0, tangent_pairs=request.param)
+
+
+def test_the_two_tangent_shapes_agree(G):
+    """Same rays through both shapes and through the library's own choice: values, tangents and status agree to rounding
+    (the value part is the same arithmetic; the tangents are the same formulas on one or two members)."""
+    x = np.array([0.0, 1000.0, math.radians(30), 0.0])
+    m = G.KerrMetric(1.0, 0.998)
+    rng = np.random.default_rng(3)
+    al, be = rng.uniform(-12, 12, 1000), rng.uniform(-12, 12, 1000)
+    out = {}
+    for shape in (0, 1, 2):
+        out[shape] = _tracer(G, G.EnsembleMI355X(0, tangent_pairs=shape), m, x, 4000.0).tangent(al, be)
+    hit = out[0][:, 7] == 2
+    assert hit.sum() > 600 and np.array_equal(out[0][:, 7], out[1][:, 7])
+    np.testing.assert_allclose(out[1][hit, 0:2], out[0][hit, 0:2], rtol=1e-11)
+    for c in range(2, 6):
+        scale = np.abs(out[0][hit, c]).max()
+        assert np.abs(out[1][hit, c] - out[0][hit, c]).max() < 1e-9 * scale, c
+    assert out[2].tobytes() == out[1].tobytes()          # 1000 rays: the library takes the pairs
 
 
 def _tracer(G, ens, m, x, max_time, **kw):
