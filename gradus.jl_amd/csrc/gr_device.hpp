@@ -126,6 +126,10 @@ typedef double creal;     // tableau and other compile-time tables: plain number
 #else
 typedef real creal;
 #endif
+// The step size and everything formed from it alone: a PLAIN number in every build.  The reference's dt has the type of its
+// time span (Float64) also when the state carries dual numbers, and a tangent build that lets h be a (value, 0, 0) triple pays
+// one dead FMA per tangent member in every weighted sum of a step.
+typedef creal hreal;
 
 // ---------------------------------------------------------------------------------------
 // scalar helpers
@@ -1871,7 +1875,8 @@ struct Ray {
     real x[4];        // (t, r, θ, ϕ) at the start of the current step
     real v[4];        // (v^t, v^r, v^θ, v^ϕ)
     real A[7][4];     // stage accelerations; A[0] is FSAL
-    real t, dt, h;    // affine time, proposed step, last used step
+    real t;           // affine time
+    hreal dt, h;      // proposed step, last used step
     real cprev;       // disc condition at x
     real sth, cth;    // sin θ, cos θ at x (base of the stage rotations)
     RotK rotk;        // register-resident constants of the stage rotations
@@ -2164,7 +2169,7 @@ struct Ray {
             const real dt1 = (dm <= 1e-15) ? GR_FMAX(1e-6, dt0 * 1e-3)
                                              : 0.39810717055349726 * (real)fast_exp2f(-0.2f * fast_log2f((float)dm));
 #endif
-            dt = GR_FMIN(GR_FMIN(100.0 * dt0, dt1), dtmax);
+            dt = (hreal)GR_FMIN(GR_FMIN(100.0 * dt0, dt1), dtmax);
         }
     }
 
@@ -2183,22 +2188,22 @@ struct Ray {
     GR_DEV bool step(const Metric& m, const Params& p, const Cold_& cs)
     {
         const real tend = p.cfg.lambda1;
-        const real dtmax = (real)p.dtmax;
+        const hreal dtmax = (hreal)p.dtmax;
         GR_DBG_BIT(0);
 #ifdef GR_HOST_HARNESS
         dbg_bits = 0;
         dbg_dmax = 0.0;
 #endif
         if (nacc + nrej >= p.maxiters32) { flags |= GR_FLAG_MAXITERS; return true; }
-        real hh = GR_FMIN(dt, dtmax);
+        hreal hh = GR_FMIN(dt, dtmax);
         // one comparison on the common path: a NaN step size fails it as well and is told apart inside
-        if (!(hh >= 4.0 * GR_EPS * GR_FMAX(GR_FABS(t), 1.0))) {
+        if (!(hh >= (hreal)(4.0 * GR_EPS * GR_FMAX(GR_FABS(t), 1.0)))) {
             flags |= (hh == hh) ? GR_FLAG_DTMIN : GR_FLAG_NAN;
             return true;
         }
-        hh = GR_FMIN(hh, tend - t);
+        hh = GR_FMIN(hh, (hreal)(tend - t));
         h = hh;
-        const real h2 = hh * hh;
+        const hreal h2 = hh * hh;
         const bool resync = (nacc & 63) == 63;      // full sin/cos at the new state (decided while nacc is in a register)
         if constexpr (Cold_::kHead) {
             // park what the hot region does not read (see LdsColdStore)
@@ -2238,7 +2243,7 @@ struct Ray {
     {                                                                                                 \
         GR_UNPARK((S) - 1)                                                                            \
         real vs[4];                                                                                 \
-        const real ha = Ts::A[S][0] * hh;                                                           \
+        const hreal ha = Ts::A[S][0] * hh;                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
         {                                                                                             \
             real acc = A[0][i];                                                                     \
@@ -2254,7 +2259,7 @@ struct Ray {
                 ar = GR_FMA(TsD::X.AXR[S][q], A[q][1], ar);                                         \
                 at = GR_FMA(TsD::X.AXR[S][q], A[q][2], at);                                         \
             }                                                                                         \
-            const real h2a = TsD::X.AX[S][0] * h2;                                                  \
+            const hreal h2a = TsD::X.AX[S][0] * h2;                                                 \
             rs = GR_FMA(h2a, ar, rs);                                                          \
             ts = GR_FMA(h2a, at, ts);                                                          \
         }                                                                                             \
@@ -2275,7 +2280,7 @@ struct Ray {
         // formed behind it (their old values are parked when the cold store is on)
         real xn[4], vn[4];
         GR_UNPARK(5)
-        const real ha6 = Ts::A[6][0] * hh, hc6 = TsD::X.C[6] * hh, h2a6 = TsD::X.AX[6][0] * h2;
+        const hreal ha6 = Ts::A[6][0] * hh, hc6 = TsD::X.C[6] * hh, h2a6 = TsD::X.AX[6][0] * h2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             real acc = A[0][i];
@@ -2346,7 +2351,7 @@ struct Ray {
 #ifdef GR_REAL_IS_TAN2
         double e2n = 0.0;
 #endif
-        const real hbx = TsD::X.BTX[0] * hh;
+        const hreal hbx = TsD::X.BTX[0] * hh;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             real ev = A[0][i];               // ũ_v / (h b̃_0)
@@ -2440,7 +2445,7 @@ struct Ray {
             gf = GR_CTL_MIN((ctl_t)PI_QMAX, GR_CTL_MAX((ctl_t)PI_QMIN, gf));   // e2 == 0 -> lE = -inf -> qmax
             nacc++;
             lq_old = GR_CTL_MAX(lE, (ctl_t)LOG2_QOLDINIT);
-            real dtnew = hh * (real)gf;
+            hreal dtnew = hh * (hreal)gf;
             real tnew = t + hh;
             if (GR_FABS(tnew - tend) < 100.0 * GR_EPS * GR_FMAX(GR_FABS(tnew), GR_FABS(tend))) tnew = tend;
 
@@ -2521,7 +2526,7 @@ struct Ray {
 #endif
             }
             const ctl_t q11 = GR_CTL_EXP2((ctl_t)PI_BETA1 * lE);
-            dt = hh / (real)GR_CTL_MIN((ctl_t)(1.0 / PI_QMIN), q11 * (ctl_t)(1.0 / PI_GAMMA));
+            dt = hh / (hreal)GR_CTL_MIN((ctl_t)(1.0 / PI_QMIN), q11 * (ctl_t)(1.0 / PI_GAMMA));
             return false;
         }
 #undef GR_CTL_LOG2

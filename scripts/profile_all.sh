@@ -13,5 +13,8 @@ PROF_F32=1 PROF_CMD="scripts/sibling_workloads.py c5f32" PROF_KERNEL="gr32::" ba
 PROF_CMD="scripts/sibling_workloads.py applypf" PROF_KERNEL="k_apply_pf" bash scripts/profile_pmc.sh ${T}_applypf
 PROF_CMD="scripts/sibling_workloads.py endpoints" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_endpoints
 PROF_CMD="scripts/sibling_workloads.py tangent" PROF_KERNEL="k_trace_lane<grt::" bash scripts/profile_pmc.sh ${T}_tangent
+PROF_CMD="scripts/sibling_workloads.py dual" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<3>" bash scripts/profile_pmc.sh ${T}_bumblebee
+PROF_CMD="scripts/sibling_workloads.py dual2" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<2>" bash scripts/profile_pmc.sh ${T}_morristhorne
+PROF_CMD="scripts/sibling_workloads.py dual6" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<6>" bash scripts/profile_pmc.sh ${T}_dilatonaxion
 # drop the bulky raw traces, keep summaries
 for d in gpurun_out/prof_${T}_*; do rm -rf $d/trace $d/pmcA $d/pmcB $d/pmcC $d/pmcD; done
