@@ -54,6 +54,14 @@ class GradusMI355XError(RuntimeError):
         self.code = code
 
 
+class gr_disc_component(C.Structure):
+    _fields_ = [("disc_id", C.c_int32), ("_pad", C.c_int32), ("disc_r_in", C.c_double), ("disc_r_out", C.c_double),
+                ("disc_params", C.c_double * 4)]
+
+
+GR_COMP_MAX = 4
+
+
 class gr_config(C.Structure):
     _fields_ = [
         ("metric_id", C.c_int32),
@@ -84,6 +92,9 @@ class gr_config(C.Structure):
         ("count_windings", C.c_int32),
         ("_pad2", C.c_int32),
         ("winding_plane", C.c_double),
+        ("comp_n", C.c_int32),
+        ("_pad3", C.c_int32),
+        ("comp", gr_disc_component * GR_COMP_MAX),
     ]
 
 

@@ -1890,6 +1890,10 @@ struct Ray {
     int32_t status, flags;      // flags: GR_FLAG_* | RAY_EVENT in bits 0..15, TraceWindings count in bits 16..31
     int32_t nacc, nrej;
     real hdat;          // GR_DISC_DATUM: this ray's plane height (dead in every other instantiation)
+    // GR_DISC_COMPOSITE (dead in every other instantiation): the conditions of components 1.. at x (component 0's is cprev) and
+    // which components the pending event belongs to
+    real cprev_more[GR_COMP_MAX - 1];
+    int32_t ev_mask;
 #ifdef GR_HOST_HARNESS
     real dbg_e2;
     real dbg_dmax;          // per attempted step: largest |θ_stage - θ_base| (harness statistics)
@@ -1949,6 +1953,97 @@ struct Ray {
         const real v1 = s * sp, v2 = s * cp;
         const real x2 = cb * v2 - sb * c, x3 = sb * v2 + cb * c;     // R = [1 0 0; 0 cβ -sβ; 0 sβ cβ]
         return disc_cond(p, r, sqrt_fast(GR_FMA(v1, v1, x2 * x2)), x3);
+    }
+
+    // ---- CompositeGeometry (src/geometry/composite.jl; geometry_collision_callback(::CompositeGeometry), bootstrap.jl:76-110):
+    // a VectorContinuousCallback whose k-th condition is component k's distance_to_disc and whose every affect terminates with
+    // IntersectedWithGeometry.  DiffEqBase (third party, as published: determine_event_occurance / find_callback_time for
+    // VectorContinuousCallback): sign(c_k) at the step's start is remembered per component; a component has an event at the
+    // step's end if its sign changed (or hit zero); unless EVERY component has one, the seven interior samples of the dense
+    // output are scanned in order and the first sample at which any component's sign differs from its start decides: the
+    // components that changed THERE are the candidates and that sample the bracket's top (no interior change: the end-of-step
+    // candidates stand).  Each candidate's root is found on the bracket, the earliest one is the event.
+    // Components: thin disc, Shakura-Sunyaev, elliptical disc, datum plane (formulas of disc_cond above, per-component fields).
+    GR_DEV real comp_cond(const Params& p, int k, real r, real s, real c) const
+    {
+        const gr_disc_component& g = p.cfg.comp[k];
+        if (g.disc_id == GR_DISC_DATUM) return r * c - (real)g.disc_params[0];
+        if (g.disc_id == GR_DISC_ELLIPTICAL) {
+            const real a = g.disc_params[0], b = g.disc_params[1];
+            if (a < r || r < (real)g.disc_r_in) return 1.0;
+            const real q = r * rcp_full(a);
+            const real y = sqrt_fast(GR_FMAX((1.0 - q * q) * b * b, 0.0));
+            return GR_FABS(r * c) - y - p.cfg.gtol * GR_FABS(r);
+        }
+        const real rho = r * GR_FABS(s);
+        if (g.disc_id == GR_DISC_THIN) {
+            if (rho < g.disc_r_in || rho > g.disc_r_out) return 1.0;
+            return r * GR_FABS(c) - p.cfg.gtol * GR_FABS(r);
+        }
+        const real rin = g.disc_r_in;                       // GR_DISC_SHAKURA_SUNYAEV
+        if (rho < rin) return 1.0;
+        const real height = 3.0 * (real)g.disc_params[1] * (real)g.disc_params[0] * (1.0 - sqrt_fast(rin * rcp_full(rho)));
+        if (height <= 0.0) return 1.0;
+        return r * GR_FABS(c) - height;
+    }
+    GR_DEV real& comp_prev(int k) { return k == 0 ? cprev : cprev_more[k > 0 ? k - 1 : 0]; }
+    GR_DEV real comp_prev(int k) const { return k == 0 ? cprev : cprev_more[k > 0 ? k - 1 : 0]; }
+
+    // the interior samples Θ = 1/7 .. 6/7: first sample at which a component's sign differs from its sign at the step's start;
+    // returns that sample's index (0: none) and the components that changed there
+    GR_DEV int sample_event_composite(const Params& p, real hh, int32_t& mask) const
+    {
+        real Ct[4], Cr[4];
+        dense_coeffs(2, hh, Ct);
+        dense_coeffs(1, hh, Cr);
+        const int K = p.cfg.comp_n;
+        for (int jj = 1; jj <= 6; ++jj) {
+            const real th = (real)jj / 7.0;
+            real s, c;
+            sincos_fast(dense_eval(x[2], hh, Ct, th), s, c);
+            const real rr = dense_eval(x[1], hh, Cr, th);
+            int32_t mk = 0;
+#pragma unroll
+            for (int k = 0; k < GR_COMP_MAX; ++k) {       // (constant indices: the per-component state stays in registers)
+                if (k >= K) continue;
+                const int ps = sgn(comp_prev(k));
+                if (ps != 0 && (real)ps * comp_cond(p, k, rr, s, c) <= 0.0) mk |= 1 << k;   // (<=: findall_events! of the vector callback)
+            }
+            if (mk) { mask = mk; return jj; }
+        }
+        mask = 0;
+        return 0;
+    }
+
+    // left-biased root of a condition on the dense output inside Θ in [0, hi] (the bracketing of resolve_event below, for a
+    // condition given as a functor): sign(f(0)) = ps
+    template <class F>
+    GR_DEV real root_on_dense(F f, int ps, real flo, real hi) const
+    {
+        real lo = 0.0, fhi = f(hi);
+        if (fhi == 0.0) return hi;
+        int side = 0;
+        for (int it = 0; it < 48; ++it) {
+            const real w = hi - lo;
+            if (w <= 1.0e-13) break;
+            real mid = lo - flo * w / (fhi - flo);
+            const bool plateau = (flo == 1.0) || (fhi == 1.0);
+            if (plateau || !(mid > lo && mid < hi)) {
+                mid = lo + 0.5 * w;
+                if (!(mid > lo && mid < hi)) break;
+            }
+            const real fm = f(mid);
+            if (sgn(fm) == ps) {
+                lo = mid; flo = fm;
+                if (side < 0) fhi *= 0.5;
+                side = -1;
+            } else {
+                hi = mid; fhi = fm;
+                if (side > 0) flo *= 0.5;
+                side = 1;
+            }
+        }
+        return lo;
     }
 
     // DiscreteCallbacks in CallbackSet order: domain_upper_hemisphere, then the chart
@@ -2125,6 +2220,12 @@ struct Ray {
             hdat = (cd.src_mode == 2 && cd.height) ? (real)cd.height[jl] : (real)p.cfg.disc_params[0];
         }
         cprev = DISC ? disc_cond4(p, x[1], s, c, x[3]) : 1.0;
+        ev_mask = 0;
+        if constexpr (DISC == GR_DISC_COMPOSITE) {
+#pragma unroll
+            for (int k = 0; k < GR_COMP_MAX; ++k)
+                if (k < p.cfg.comp_n) comp_prev(k) = comp_cond(p, k, x[1], s, c);
+        }
 
         const real abstol = p.cfg.abstol, reltol = p.cfg.reltol;
         const real dtmax = (real)p.dtmax;
@@ -2449,7 +2550,36 @@ struct Ray {
             real tnew = t + hh;
             if (GR_FABS(tnew - tend) < 100.0 * GR_EPS * GR_FMAX(GR_FABS(tnew), GR_FABS(tend))) tnew = tend;
 
-            if (DISC) {
+            if constexpr (DISC == GR_DISC_COMPOSITE) {
+                const int K = p.cfg.comp_n;
+                real cnx[GR_COMP_MAX];
+                int32_t mask_end = 0;
+#pragma unroll
+                for (int k = 0; k < GR_COMP_MAX; ++k) {
+                    if (k >= K) continue;
+                    cnx[k] = comp_cond(p, k, xn[1], sn, cn);
+                    const real cp = comp_prev(k);
+                    const bool pos = cp > 0.0, neg = cp < 0.0;
+                    if ((pos && !(cnx[k] > 0.0)) || (neg && !(cnx[k] < 0.0))) mask_end |= 1 << k;
+                }
+                int top = 0;
+                int32_t mask = 0;
+                if (__builtin_popcount((unsigned)mask_end) != K) {
+                    GR_UNPARK(5)
+                    top = sample_event_composite(p, hh, mask);
+                }
+                if (!top && mask_end) { top = 7; mask = mask_end; }
+                if (top) {
+                    flags |= RAY_EVENT;
+                    ev_top = top;
+                    ev_mask = mask;
+                    status = GR_STATUS_INTERSECTED_WITH_GEOMETRY;
+                    return true;
+                }
+#pragma unroll
+                for (int k = 0; k < GR_COMP_MAX; ++k)
+                    if (k < K) comp_prev(k) = cnx[k];
+            } else if (DISC) {
                 const real cnext = disc_cond4(p, xn[1], sn, cn, xn[3]);
                 // prev = sign(c(u_prev)), event at the step's end iff prev != 0 and prev * sign(c(u_new)) <= 0 (a NaN
                 // condition has sign 0 and counts as a crossing): four comparisons, no integer sign arithmetic
@@ -2656,13 +2786,30 @@ struct Ray {
         dbg_e2 = 0.0;
 #endif
         real lo = 0.0, hi = (ev_top >= 7) ? 1.0 : (real)ev_top / 7.0;
-        real flo = cprev, fhi;
+        real flo = cprev, fhi = 0.0;
+        real theta = hi;
+        int kbest = 0;           // GR_DISC_COMPOSITE: the component whose root is the event
+        if constexpr (DISC == GR_DISC_COMPOSITE) {
+            // every candidate component's root on [0, hi]; the earliest is the event (find_callback_time, VectorContinuousCallback)
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < GR_COMP_MAX; ++k) {
+                if (k >= p.cfg.comp_n || !((ev_mask >> k) & 1)) continue;
+                auto f = [&](real th) {
+                    real s, c;
+                    sincos_fast(dense_eval(x[2], h, Ct, th), s, c);
+                    return comp_cond(p, k, dense_eval(x[1], h, Cr, th), s, c);
+                };
+                const real thk = root_on_dense(f, sgn(comp_prev(k)), comp_prev(k), hi);
+                if (first || thk < theta) { theta = thk; kbest = k; }
+                first = false;
+            }
+        } else {
         {
             real s, c;
             sincos_fast(dense_eval(x[2], h, Ct, hi), s, c);
             fhi = disc_cond4(p, dense_eval(x[1], h, Cr, hi), s, c, DISC == GR_DISC_PRECESSING_THIN ? dense_eval(x[3], h, Cp, hi) : (real)0.0);
         }
-        real theta = hi;
         if (fhi != 0.0) {
             // Illinois regula falsi: brackets [lo, hi] with sign(f(lo)) == ps throughout, superlinear on
             // the smooth part of the condition and still convergent across its jump at the disc rim
@@ -2699,6 +2846,8 @@ struct Ray {
             }
             theta = lo;
         }
+        }
+        (void)kbest;
         // change_t_via_interpolation!: every component from the interpolant
         real xe[4], ve[4];
 #pragma unroll
@@ -2717,12 +2866,12 @@ struct Ray {
             // Jacobian ∂(ρ, g)/∂(α, β) is off by 13-45 % on the rₑ ≈ 5-8 rays checked in tests/test_tangent_host.py).
             real se, ce;
             sincos_fast(xe[2], se, ce);
-            const real cv = disc_cond4(p, xe[1], se, ce, xe[3]);
+            const real cv = (DISC == GR_DISC_COMPOSITE) ? comp_cond(p, kbest, xe[1], se, ce) : disc_cond4(p, xe[1], se, ce, xe[3]);
             // dc/dλ along the ray: the same condition on a state whose first tangent slot holds the velocity
             const real r1 = gr_t_along(xe[1].v, ve[1].v), t1 = gr_t_along(xe[2].v, ve[2].v), p1 = gr_t_along(xe[3].v, ve[3].v);
             real s1, c1;
             sincos_fast(t1, s1, c1);
-            const double cdot = disc_cond4(p, r1, s1, c1, p1).a;
+            const double cdot = ((DISC == GR_DISC_COMPOSITE) ? comp_cond(p, kbest, r1, s1, c1) : disc_cond4(p, r1, s1, c1, p1)).a;
             if (cdot != 0.0) {
                 const double la = -cv.a / cdot;
                 GR_TAN_B(const double lb = -cv.b / cdot;)

@@ -225,7 +225,8 @@ __device__ __forceinline__ unsigned xcd_chunk(unsigned b)
 // ---- kernel 0: one ray per work-item ----
 template <class Metric, int DISC>
 #ifndef GR_LANE_MIN_WAVES
-#define GR_LANE_MIN_WAVES Metric::kLaneWavesPerSimd
+// (a composite geometry samples several conditions on every step: two waves per SIMD at most, no spills on its main path)
+#define GR_LANE_MIN_WAVES (DISC == GR_DISC_COMPOSITE && Metric::kLaneWavesPerSimd > 2 ? 2 : Metric::kLaneWavesPerSimd)
 #endif
 __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Params p)
 {
@@ -462,6 +463,7 @@ hipError_t launch_metric(const LaunchKnobs& k, Params& p, hipStream_t stream)
     case GR_DISC_DATUM: return launch_tmpl<Metric, GR_DISC_DATUM>(k, p, stream);
     case GR_DISC_ELLIPTICAL: return launch_tmpl<Metric, GR_DISC_ELLIPTICAL>(k, p, stream);
     case GR_DISC_PRECESSING_THIN: return launch_tmpl<Metric, GR_DISC_PRECESSING_THIN>(k, p, stream);
+    case GR_DISC_COMPOSITE: return launch_tmpl<Metric, GR_DISC_COMPOSITE>(k, p, stream);
     default: return launch_tmpl<Metric, GR_DISC_NONE>(k, p, stream);
     }
 }
@@ -478,6 +480,7 @@ hipError_t launch_path_metric(const Params& p, double* d_path, int64_t cap, unsi
     case GR_DISC_DATUM: GR_PATH_LAUNCH(GR_DISC_DATUM); break;
     case GR_DISC_ELLIPTICAL: GR_PATH_LAUNCH(GR_DISC_ELLIPTICAL); break;
     case GR_DISC_PRECESSING_THIN: GR_PATH_LAUNCH(GR_DISC_PRECESSING_THIN); break;
+    case GR_DISC_COMPOSITE: GR_PATH_LAUNCH(GR_DISC_COMPOSITE); break;
     default: GR_PATH_LAUNCH(GR_DISC_NONE); break;
     }
 #undef GR_PATH_LAUNCH

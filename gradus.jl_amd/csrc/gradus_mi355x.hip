@@ -185,8 +185,20 @@ int32_t validate_cfg(const gr_config* cfg)
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
     if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_NOZ)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
-    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_PRECESSING_THIN)
+    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_COMPOSITE)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
+    if (cfg->disc_id == GR_DISC_COMPOSITE) {
+        if (cfg->comp_n < 2 || cfg->comp_n > GR_COMP_MAX)
+            return fail(GR_ERR_INVALID_ARGUMENT, "a composite geometry has 2.." + std::to_string(GR_COMP_MAX) + " components");
+        for (int k = 0; k < cfg->comp_n; ++k) {
+            const int id = cfg->comp[k].disc_id;
+            if (id != GR_DISC_THIN && id != GR_DISC_SHAKURA_SUNYAEV && id != GR_DISC_ELLIPTICAL && id != GR_DISC_DATUM)
+                return fail(GR_ERR_UNSUPPORTED, "composite geometry: component " + std::to_string(k) + " must be a thin disc, a Shakura-Sunyaev "
+                                                "disc, an elliptical disc or a datum plane");
+            if (id == GR_DISC_THIN && !(cfg->comp[k].disc_r_out >= cfg->comp[k].disc_r_in))
+                return fail(GR_ERR_INVALID_ARGUMENT, "composite geometry: disc outer radius below inner radius");
+        }
+    }
     if (!(cfg->abstol > 0.0) || !(cfg->reltol > 0.0))
         return fail(GR_ERR_INVALID_ARGUMENT, "abstol and reltol must be positive");
     if (!(cfg->lambda1 > cfg->lambda0))

@@ -6,11 +6,17 @@ from dataclasses import dataclass
 import numpy as np
 
 GR_DISC_NONE, GR_DISC_THIN, GR_DISC_SHAKURA_SUNYAEV, GR_DISC_TABULATED, GR_DISC_DATUM = 0, 1, 2, 3, 4
-GR_DISC_ELLIPTICAL, GR_DISC_PRECESSING_THIN = 5, 6
+GR_DISC_ELLIPTICAL, GR_DISC_PRECESSING_THIN, GR_DISC_COMPOSITE = 5, 6, 7
 
 
 class AbstractAccretionGeometry:
-    pass
+    def __matmul__(self, other):
+        """d1 @ d2 = the reference's d1 ∘ d2 = CompositeGeometry(d1, d2) (src/geometry/composite.jl:24-25)."""
+        if not isinstance(other, AbstractAccretionGeometry):
+            return NotImplemented
+        mine = self.geometry if isinstance(self, CompositeGeometry) else (self,)
+        theirs = other.geometry if isinstance(other, CompositeGeometry) else (other,)
+        return CompositeGeometry(*mine, *theirs)
 
 
 @dataclass(frozen=True)
@@ -122,3 +128,26 @@ class WarpedThinDisc(AbstractAccretionGeometry):
         self.ρ_range = (self.inner_radius, self.outer_radius)
         ρ = np.linspace(self.ρ_range[0], self.ρ_range[1], int(samples))
         self.table = np.ascontiguousarray([float(f(r)) for r in ρ], dtype=np.float64)
+
+
+class CompositeGeometry(AbstractAccretionGeometry):
+    """CompositeGeometry(d1, d2, ...) = d1 ∘ d2 ∘ ... -- src/geometry/composite.jl:1-26.  A ray ends at the earliest
+    intersection with any of its geometries (the VectorContinuousCallback of geometry/bootstrap.jl:76-110).  On the device:
+    2 to 4 components, each a ThinDisc, ShakuraSunyaev, EllipticalDisc or DatumPlane."""
+
+    disc_id = GR_DISC_COMPOSITE
+
+    def __init__(self, *geometry):
+        if not geometry:
+            raise ValueError("Must provide at least one disc as argument to constructor")      # composite.jl:1-3
+        self.geometry = tuple(geometry)
+
+    def __len__(self):
+        return len(self.geometry)
+
+    def __iter__(self):
+        return iter(self.geometry)
+
+    @property
+    def inner_radius(self):
+        return min(getattr(g, "inner_radius", 0.0) for g in self.geometry)

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import dataclasses
 from dataclasses import dataclass
 from typing import Optional
 
@@ -16,7 +17,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .geometry import (GR_DISC_NONE, AbstractAccretionGeometry, DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev,
+from .geometry import (GR_DISC_NONE, AbstractAccretionGeometry, CompositeGeometry, DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev,
                        ThickDisc, ThinDisc, WarpedThinDisc)
 from .metrics import AbstractMetric
 from .orthonormalization import lnrbasis
@@ -306,6 +307,21 @@ class TracingConfiguration:
             c.r_inner, c.r_outer = float(self.chart.inner_radius), float(self.chart.outer_radius)
         if self.geometry is None:
             c.disc_id = GR_DISC_NONE
+        elif isinstance(self.geometry, CompositeGeometry):
+            comps = self.geometry.geometry
+            if not 2 <= len(comps) <= _lib.GR_COMP_MAX:
+                raise NotImplementedError(f"a composite geometry runs on the device with 2..{_lib.GR_COMP_MAX} components")
+            c.disc_id = self.geometry.disc_id
+            c.comp_n = len(comps)
+            for k, g in enumerate(comps):
+                if not isinstance(g, (ThinDisc, ShakuraSunyaev, EllipticalDisc, DatumPlane)):
+                    raise NotImplementedError(f"{type(g).__name__} cannot be a component of a composite geometry on the device")
+                # every component through the single-geometry branches below, then copied into its slot
+                one = dataclasses.replace(self, geometry=g).abi_config()
+                c.comp[k].disc_id = one.disc_id
+                c.comp[k].disc_r_in, c.comp[k].disc_r_out = one.disc_r_in, one.disc_r_out
+                for q in range(4):
+                    c.comp[k].disc_params[q] = one.disc_params[q]
         elif isinstance(self.geometry, ThinDisc):
             c.disc_id = self.geometry.disc_id
             c.disc_r_in, c.disc_r_out = float(self.geometry.inner_radius), float(self.geometry.outer_radius)

@@ -88,9 +88,22 @@ enum {
  *   ELLIPTICAL       EllipticalDisc  src/geometry/discs.jl:57-72: disc_r_in = inner_radius, disc_params = {semi_major,
  *                    semi_minor}; |z| < sqrt((1 - (r/a)²) b²) + gtol |r| for inner_radius <= r <= semi_major
  *   PRECESSING_THIN  PrecessingDisc(ThinDisc(r_in, r_out), β, γ)  src/geometry/discs.jl:74-96: the thin disc tilted by β
- *                    about the x axis and turned by γ about the spin axis; disc_params = {β, γ, cos β, sin β} */
+ *                    about the x axis and turned by γ about the spin axis; disc_params = {β, γ, cos β, sin β}
+ *   COMPOSITE        CompositeGeometry(d1, d2, ...) = d1 ∘ d2  src/geometry/composite.jl:1-26, the VectorContinuousCallback of
+ *                    src/geometry/bootstrap.jl:76-110: comp_n (2..GR_COMP_MAX) components in gr_config.comp[], each a THIN,
+ *                    SHAKURA_SUNYAEV, ELLIPTICAL or DATUM geometry with its own radii and parameters (gtol is shared, as in the
+ *                    reference); the ray ends at the EARLIEST intersection with any of them */
 enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_TABULATED = 3, GR_DISC_DATUM = 4,
-       GR_DISC_ELLIPTICAL = 5, GR_DISC_PRECESSING_THIN = 6 };
+       GR_DISC_ELLIPTICAL = 5, GR_DISC_PRECESSING_THIN = 6, GR_DISC_COMPOSITE = 7 };
+#define GR_COMP_MAX 4
+
+/* one component of a GR_DISC_COMPOSITE geometry: the fields of gr_config with the same names, per component */
+typedef struct gr_disc_component {
+    int32_t disc_id;          /* GR_DISC_THIN | SHAKURA_SUNYAEV | ELLIPTICAL | DATUM               */
+    int32_t _pad;
+    double disc_r_in, disc_r_out;
+    double disc_params[4];
+} gr_disc_component;
 
 /* per-ray anomaly bits written next to the status (SciML retcodes MaxIters /
  * DtLessThanMin / Unstable, which EnsembleEndpointThreads discards, tracing.jl:250) */
@@ -133,6 +146,9 @@ typedef struct gr_config {
                                  gr_point.flags and by GR_PF_WINDING                                  */
     int32_t _pad2;
     double winding_plane;     /* TraceWindings.plane_inc, default π/2                                */
+    int32_t comp_n;           /* GR_DISC_COMPOSITE: number of components (2..GR_COMP_MAX), else 0    */
+    int32_t _pad3;
+    gr_disc_component comp[GR_COMP_MAX];
 } gr_config;
 
 /* GeodesicPoint{Float64,Nothing} -- src/solution-processing.jl:15-32.  152 bytes, same

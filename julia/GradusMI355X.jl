@@ -42,6 +42,16 @@ const ABI_VERSION = 6
 # ---------------------------------------------------------------------------------------------------------------
 # POD mirrors of include/gradus_mi355x.h (field order and types checked by tests/test_julia_binding.py)
 # ---------------------------------------------------------------------------------------------------------------
+struct GrDiscComponent               # == gr_disc_component: one geometry of a CompositeGeometry
+    disc_id::Int32
+    _pad::Int32
+    disc_r_in::Float64
+    disc_r_out::Float64
+    disc_params::NTuple{4,Float64}
+end
+const _NO_COMPONENT = GrDiscComponent(Int32(0), Int32(0), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
+const _NO_COMPONENTS = (_NO_COMPONENT, _NO_COMPONENT, _NO_COMPONENT, _NO_COMPONENT)
+
 struct GrConfig                      # == gr_config
     metric_id::Int32
     disc_id::Int32
@@ -71,6 +81,9 @@ struct GrConfig                      # == gr_config
     count_windings::Int32            # TraceWindings (tracing/photon-rings.jl): count in bits 16..31 of GeodesicPoint padding
     _pad2::Int32
     winding_plane::Float64
+    comp_n::Int32                    # CompositeGeometry (geometry/composite.jl): its geometries, 2..4 of them
+    _pad3::Int32
+    comp::NTuple{4,GrDiscComponent}
 end
 
 struct GrStats                       # == gr_stats
@@ -207,7 +220,23 @@ _disc(d::DatumPlane) = (Int32(4), 0.0, 0.0, (Float64(d.height), 0.0, 0.0, 0.0))
 _disc(d::EllipticalDisc) = (Int32(5), Float64(d.inner_radius), Inf, (Float64(d.semi_major), Float64(d.semi_minor), 0.0, 0.0))
 _disc(d::PrecessingDisc{T,<:ThinDisc}) where {T} =
     (Int32(6), Float64(d.disc.inner_radius), Float64(d.disc.outer_radius), (Float64(d.β), Float64(d.γ), cos(d.β), sin(d.β)))
+# CompositeGeometry(d1, d2, ...) = d1 ∘ d2 (geometry/composite.jl): the components cross as gr_config.comp[]
+_disc(d::Gradus.CompositeGeometry) = (Int32(7), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
 _disc(d) = throw(UnsupportedOnDevice("geometry $(typeof(d)) has no device implementation"))
+
+# (comp_n, comp[4]) of gr_config
+_components(d) = (Int32(0), _NO_COMPONENTS)
+function _components(d::Gradus.CompositeGeometry)
+    n = length(d.geometry)
+    2 <= n <= 4 || throw(UnsupportedOnDevice("a composite geometry of $n components (the device takes 2..4)"))
+    comps = map(d.geometry) do g
+        g isa Union{ThinDisc,Gradus.ShakuraSunyaev,Gradus.EllipticalDisc,Gradus.DatumPlane} ||
+            throw(UnsupportedOnDevice("$(typeof(g)) as a component of a composite geometry"))
+        did, rin, rout, dparams = _disc(g)
+        GrDiscComponent(did, Int32(0), rin, rout, dparams)
+    end
+    (Int32(n), ntuple(k -> k <= n ? comps[k] : _NO_COMPONENT, 4))
+end
 
 """
     SampledThickDisc(d::AbstractThickAccretionDisc, ρ_min, ρ_max; samples = 16384)
@@ -275,19 +304,32 @@ function _callbacks(config::TracingConfiguration)
     isnothing(cb) && return (gtol, δ)
     conts, discs = if cb isa SciMLBase.CallbackSet
         (cb.continuous_callbacks, cb.discrete_callbacks)
-    elseif cb isa SciMLBase.ContinuousCallback
+    elseif cb isa Union{SciMLBase.ContinuousCallback,SciMLBase.VectorContinuousCallback}
         ((cb,), ())
     elseif cb isa SciMLBase.DiscreteCallback
         ((), (cb,))
     elseif cb isa Tuple
-        (filter(c -> c isa SciMLBase.ContinuousCallback, cb), filter(c -> c isa SciMLBase.DiscreteCallback, cb))
+        (filter(c -> c isa Union{SciMLBase.ContinuousCallback,SciMLBase.VectorContinuousCallback}, cb),
+            filter(c -> c isa SciMLBase.DiscreteCallback, cb))
     else
         throw(UnsupportedOnDevice("callback of type $(typeof(cb))"))
     end
     seen_geometry = false
     for c in conts
         cond = c.condition
-        if !seen_geometry && !isnothing(config.geometry) && hasproperty(cond, :g) && hasproperty(cond, :gtol) &&
+        if !seen_geometry && config.geometry isa Gradus.CompositeGeometry && c isa SciMLBase.VectorContinuousCallback &&
+           hasproperty(cond, :callbacks)
+            # geometry_collision_callback(::CompositeGeometry) (bootstrap.jl:76-110): `_composite_condition` closes over
+            # `callbacks`, one (condition, affect) pair per geometry, every condition over its own (g, gtol)
+            cbs = cond.callbacks
+            ok = length(cbs) == length(config.geometry.geometry) && all(1:length(cbs)) do k
+                ck = cbs[k][1]
+                hasproperty(ck, :g) && hasproperty(ck, :gtol) && ck.g === config.geometry.geometry[k]
+            end
+            ok || throw(UnsupportedOnDevice("the composite geometry's callback does not match config.geometry"))
+            gtol = Float64(cbs[1][1].gtol)
+            seen_geometry = true
+        elseif !seen_geometry && !isnothing(config.geometry) && hasproperty(cond, :g) && hasproperty(cond, :gtol) &&
            cond.g === config.geometry
             gtol = Float64(cond.gtol)
             seen_geometry = true
@@ -303,7 +345,7 @@ function _callbacks(config::TracingConfiguration)
             throw(UnsupportedOnDevice("a user DiscreteCallback ($(_closure_name(cond))); only domain_upper_hemisphere runs on the device"))
         end
     end
-    !isnothing(config.geometry) && config.geometry isa Gradus.AbstractAccretionDisc && !seen_geometry &&
+    !isnothing(config.geometry) && config.geometry isa Union{Gradus.AbstractAccretionDisc,Gradus.CompositeGeometry} && !seen_geometry &&
         throw(UnsupportedOnDevice("the geometry's collision callback was not found in config.callback"))
     (gtol, δ)
 end
@@ -332,6 +374,7 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; maxiters = 
     did, rin, rout, dparams = _disc(config.geometry)
     r_in, r_out, tab, θ0, θ1 = _chart(config.chart)
     dtab = _disc_table(config.geometry)
+    comp_n, comps = _components(config.geometry)
     gtol, δ = _callbacks(config)
     windings = trace isa Gradus.TraceWindings
     q = hasproperty(trace, :q) ? Float64(trace.q) : 0.0
@@ -342,7 +385,8 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; maxiters = 
         isnothing(δ) ? Int32(0) : Int32(1), Int32(0), isnothing(δ) ? 1e-4 : δ, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1,
-        q, windings ? Int32(1) : Int32(0), Int32(0), windings ? Float64(trace.plane_inc) : π / 2)
+        q, windings ? Int32(1) : Int32(0), Int32(0), windings ? Float64(trace.plane_inc) : π / 2,
+        comp_n, Int32(0), comps)
     cfg, (tab, dtab)
 end
 
@@ -652,7 +696,8 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
         abstol, reltol, Float64(μ), 1_000_000, Int32(0), Int32(0), 1e-4, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
-        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q), Int32(0), Int32(0), π / 2))
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q), Int32(0), Int32(0), π / 2,
+        _components(d)[1], Int32(0), _components(d)[2]))
     g = Gradus.metric(m, x)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
     plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), Float64(αlims[1]), Float64(αlims[2]), Float64(βlims[1]),
@@ -702,7 +747,8 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λ_max),
         abstol, reltol, 0.0, 1_000_000, Int32(upper_hemisphere), Int32(0), 1e-4, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
-        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, 0.0, Int32(0), Int32(0), π / 2))
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, 0.0, Int32(0), Int32(0), π / 2,
+        _components(d)[1], Int32(0), _components(d)[2]))
     g = Gradus.metric(m, u)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
     rs = collect(Float64, plane.grid(plane.r_min, plane.r_max, plane.Nr))             # planes.jl:110-114

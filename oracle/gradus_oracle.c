@@ -613,6 +613,18 @@ static double disc_condition(const orc_config* c, const double u[8])
     return r * fabs(cos(th)) - c->gtol * fabs(r);
 }
 
+/* condition k of a CompositeGeometry: the distance_to_disc of its k-th geometry (bootstrap.jl:86-99 maps
+ * intersection_callbacks over cg.geometry, all with the same gtol) */
+static double component_condition(const orc_config* c, int k, const double u[8])
+{
+    orc_config one = *c;
+    one.disc_id = c->comp[k].disc_id;
+    one.disc_r_in = c->comp[k].disc_r_in;
+    one.disc_r_out = c->comp[k].disc_r_out;
+    memcpy(one.disc_params, c->comp[k].disc_params, sizeof one.disc_params);
+    return disc_condition(&one, u);
+}
+
 static int sgn(double x) { return (x > 0.0) - (x < 0.0); }
 
 /* DiscreteCallbacks, in CallbackSet order: user callbacks (domain_upper_hemisphere,
@@ -760,7 +772,72 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
 
             /* ---- handle_callbacks!: continuous first (App. A.5) ---- */
             int event = 0;
-            if (c->disc_id != ORC_DISC_NONE) {
+            if (c->disc_id == ORC_DISC_COMPOSITE) {
+                /* geometry_collision_callback(::CompositeGeometry), geometry/bootstrap.jl:76-110: a VectorContinuousCallback,
+                 * component k = distance_to_disc of the k-th geometry, every affect = terminate_with_status!(IntersectedWithGeometry).
+                 * [3P] DiffEqBase determine_event_occurance / find_callback_time for VectorContinuousCallback, as published:
+                 * prev_sign_k = sign(c_k(u_prev)); a component has an event at the step's end iff prev_sign_k != 0 and
+                 * prev_sign_k c_k(u_new) <= 0; unless every component has one, the samples ts = range(tprev, t, length = 8)
+                 * are scanned in order with the same test and the first sample with any event decides (its components are the
+                 * candidates, it is the bracket's top); each candidate's root is bracketed, the earliest root is the event. */
+                const int K = c->comp_n;
+                double cp[ORC_COMP_MAX], cn_[ORC_COMP_MAX];
+                int psk[ORC_COMP_MAX], mask_end = 0, n_end = 0;
+                for (int q = 0; q < K; ++q) {
+                    cp[q] = component_condition(c, q, u); cn_[q] = component_condition(c, q, unew); n_cond += 2;
+                    psk[q] = sgn(cp[q]);
+                    if (psk[q] != 0 && (double)psk[q] * cn_[q] <= 0.0) { mask_end |= 1 << q; n_end++; }
+                }
+                int mask = 0;
+                double th_top = 0.0;
+                if (n_end != K) {
+                    for (int j = 1; j <= 6 && !mask; ++j) {
+                        const double th = (double)j / 7.0;
+                        double uj[8];
+                        interpolate(u, k, dt, th, uj);
+                        for (int q = 0; q < K; ++q) {
+                            const double cj = component_condition(c, q, uj); n_cond++;
+                            if (psk[q] != 0 && (double)psk[q] * cj <= 0.0) mask |= 1 << q;
+                        }
+                        if (mask) th_top = th;
+                    }
+                }
+                if (!mask && mask_end) { mask = mask_end; th_top = 1.0; }
+                if (mask) {
+                    /* every candidate's root with the bracketing of the scalar callback below (absolute time, left-biased),
+                     * so that a composite ends bit for bit where the earlier of its components' own events ends */
+                    double best = 2.0;
+                    const double top_t0 = (th_top == 1.0) ? tnew : t + th_top * (tnew - t);
+                    for (int q = 0; q < K; ++q) {
+                        if (!((mask >> q) & 1)) continue;
+                        double ev_u[8], ctop, theta_q;
+                        if (th_top == 1.0) ctop = component_condition(c, q, unew);
+                        else { interpolate(u, k, dt, (top_t0 - t) / dt, ev_u); ctop = component_condition(c, q, ev_u); }
+                        n_cond++;
+                        if (ctop == 0.0) theta_q = (top_t0 - t) / dt;
+                        else {
+                            double lo = t, hi = top_t0;
+                            for (int it = 0; it < 200; ++it) {
+                                const double mid = lo + 0.5 * (hi - lo);
+                                if (!(mid > lo && mid < hi)) break;
+                                interpolate(u, k, dt, (mid - t) / dt, ev_u);
+                                const double cm = component_condition(c, q, ev_u); n_cond++;
+                                if (sgn(cm) == psk[q]) lo = mid; else hi = mid;
+                            }
+                            theta_q = (lo - t) / dt;
+                        }
+                        if (theta_q < best) best = theta_q;
+                    }
+                    double ev_u[8];
+                    if (best >= 1.0 && th_top == 1.0) memcpy(ev_u, unew, sizeof ev_u);
+                    else interpolate(u, k, dt, best, ev_u);
+                    memcpy(unew, ev_u, sizeof unew);
+                    tnew = t + best * dt;
+                    status = ORC_INTERSECTED_WITH_GEOMETRY;
+                    terminated = 1;
+                    event = 1;
+                }
+            } else if (c->disc_id != ORC_DISC_NONE) {
                 const double cprev = disc_condition(c, u); n_cond++;
                 const double cnext = disc_condition(c, unew); n_cond++;
                 const int ps = sgn(cprev);

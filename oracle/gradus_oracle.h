@@ -47,7 +47,15 @@ enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE =
  * pin the thick-disc golden value. */
 enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1, ORC_DISC_SHAKURA_SUNYAEV = 2, ORC_DISC_TABULATED = 3, ORC_DISC_TORUS = 4,
        ORC_DISC_DATUM = 5 /* DatumPlane(height = disc_params[0]), datum-plane.jl:1-10 */,
-       ORC_DISC_ELLIPTICAL = 6, ORC_DISC_PRECESSING_THIN = 7 /* geometry/discs.jl:57-96 */ };
+       ORC_DISC_ELLIPTICAL = 6, ORC_DISC_PRECESSING_THIN = 7 /* geometry/discs.jl:57-96 */,
+       ORC_DISC_COMPOSITE = 8 /* CompositeGeometry, geometry/composite.jl + bootstrap.jl:76-110: comp_n components in comp[] */ };
+#define ORC_COMP_MAX 4
+typedef struct {
+    int32_t disc_id;        /* ORC_DISC_THIN | SHAKURA_SUNYAEV | ELLIPTICAL | DATUM */
+    int32_t _pad;
+    double disc_r_in, disc_r_out;
+    double disc_params[4];
+} orc_disc_component;
 
 /* per-ray anomaly flags (SciML retcodes that EnsembleEndpointThreads swallows) */
 enum { ORC_FLAG_MAXITERS = 1, ORC_FLAG_DTMIN = 2, ORC_FLAG_NAN = 4 };
@@ -76,6 +84,9 @@ typedef struct {
     int32_t count_windings; /* TraceWindings (tracing/photon-rings.jl): the count lands in bits 16..31 of orc_point.flags */
     int32_t _pad2;
     double winding_plane;   /* TraceWindings.plane_inc */
+    int32_t comp_n;         /* ORC_DISC_COMPOSITE: number of components */
+    int32_t _pad3;
+    orc_disc_component comp[ORC_COMP_MAX];
 } orc_config;
 
 /* GeodesicPoint{Float64,Nothing}, src/solution-processing.jl:15-32; 152 bytes */

@@ -23,8 +23,14 @@ METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "ke
               "kerr-refractive": 9, "noz": 10}
 DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS, DISC_DATUM = 0, 1, 2, 3, 4, 5
 DISC_ELLIPTICAL, DISC_PRECESSING_THIN = 6, 7
+DISC_COMPOSITE = 8
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
+
+
+class DiscComponent(C.Structure):
+    _fields_ = [("disc_id", C.c_int32), ("_pad", C.c_int32), ("disc_r_in", C.c_double), ("disc_r_out", C.c_double),
+                ("disc_params", C.c_double * 4)]
 
 
 class Config(C.Structure):
@@ -57,6 +63,9 @@ class Config(C.Structure):
         ("count_windings", C.c_int32),
         ("_pad2", C.c_int32),
         ("winding_plane", C.c_double),
+        ("comp_n", C.c_int32),           # DISC_COMPOSITE: the geometries of a CompositeGeometry
+        ("_pad3", C.c_int32),
+        ("comp", DiscComponent * 4),
     ]
 
 
@@ -192,6 +201,18 @@ def make_config(
     c.r_outer = outer_radius
     if disc is None:
         c.disc_id = DISC_NONE
+    elif isinstance(disc, dict) and "composite" in disc:
+        # CompositeGeometry(d1, d2, ...): {"composite": [component, ...]}, each component in one of the forms below
+        # (thin disc tuple, {"datum": h}, {"ellipse": ...}, Shakura-Sunyaev dict)
+        c.disc_id = DISC_COMPOSITE
+        comps = disc["composite"]
+        c.comp_n = len(comps)
+        for k, d in enumerate(comps):
+            one = make_config(metric, params, disc=d)
+            c.comp[k].disc_id = one.disc_id
+            c.comp[k].disc_r_in, c.comp[k].disc_r_out = one.disc_r_in, one.disc_r_out
+            for i_par in range(4):          # (not `q`: that is the test particle's charge, an argument of this function)
+                c.comp[k].disc_params[i_par] = one.disc_params[i_par]
     elif isinstance(disc, dict) and "datum" in disc:     # DatumPlane(height)
         c.disc_id = DISC_DATUM
         c.disc_params[0] = float(disc["datum"])

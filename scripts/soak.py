@@ -93,6 +93,14 @@ for case in range(n_scenes):
         f = lambda ρ, r0=r0, w=w, hh=hh: hh * math.sqrt(max(0.0, 1 - ((ρ - r0) / w) ** 2)) if abs(ρ - r0) < w else -1.0
         d = G.ThickDisc(f, ρ_range=(max(r0 - w, 0.0), r0 + w), samples=4096)
         od = {"table": d.table, "range": d.ρ_range}
+    if os.environ.get("SOAK_COMPOSITE") == "1" and kind in ("thin", "datum", "ss", "ellipse"):
+        # the same scenes (same random stream) with a second geometry composed onto the first -- CompositeGeometry(d, ring):
+        # an outer thin ring beyond the first geometry's extent, and for every third scene a datum plane below it as well
+        ring = (rout + 5.0, rout + 60.0)
+        comps_d, comps_o = [d, G.ThinDisc(*ring)], [od, ring]
+        if case % 3 == 0:
+            comps_d.append(G.DatumPlane(-3.0)); comps_o.append({"datum": -3.0})
+        d, od, kind = G.CompositeGeometry(*comps_d), {"composite": comps_o}, kind + "+composite"
     if only is not None and case != only:
         continue
     if tol_override is not None:

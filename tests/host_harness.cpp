@@ -45,6 +45,7 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
          else if (disc == GR_DISC_DATUM) run<M, GR_DISC_DATUM>(p, p.n, tlog, hlog, cap, nlog); \
          else if (disc == GR_DISC_ELLIPTICAL) run<M, GR_DISC_ELLIPTICAL>(p, p.n, tlog, hlog, cap, nlog); \
          else if (disc == GR_DISC_PRECESSING_THIN) run<M, GR_DISC_PRECESSING_THIN>(p, p.n, tlog, hlog, cap, nlog); \
+         else if (disc == GR_DISC_COMPOSITE) run<M, GR_DISC_COMPOSITE>(p, p.n, tlog, hlog, cap, nlog); \
          else run<M, GR_DISC_NONE>(p, p.n, tlog, hlog, cap, nlog); } while (0)
     if (p.cfg.metric_id == GR_METRIC_KERR) HH_RUN(KerrMetric);
     else if (p.cfg.metric_id == GR_METRIC_KERR_NEWMAN) HH_RUN(KerrNewmanMetric);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(G):
 def test_struct_layouts(G):
     L = G._lib
     assert L.POINT_DTYPE.itemsize == 152            # GeodesicPoint{Float64,Nothing}
-    assert C.sizeof(L.gr_config) == 8 + 64 + 8 * 10 + 8 + 8 + 8 + 32 + 16 + 32 + 8 + 16
+    assert C.sizeof(L.gr_config) == 8 + 64 + 8 * 10 + 8 + 8 + 8 + 32 + 16 + 32 + 8 + 16 + 8 + 4 * 56        # + comp_n, comp[4]
     assert C.sizeof(L.gr_plane) == 8 * (4 + 16 + 4) + 16 + 8
     assert C.sizeof(L.gr_range) == 32
     assert C.sizeof(L.gr_stats) == 96            # ABI 6: + enqueue_ms

@@ -37,21 +37,25 @@ def strip_c_comments(s):
 def c_structs():
     """{name: [(field, kind, n)]} with kind in i32 / i64 / f64 / ptr and n = array length (1 = scalar)."""
     out = {}
-    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} (\w+);", strip_c_comments(HDR), flags=re.S):
+    hdr = strip_c_comments(HDR)
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (\w+) (\d+)\s", hdr)}
+    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} (\w+);", hdr, flags=re.S):
         assert m.group(1) == m.group(3)
         fields = []
         for decl in m.group(2).split(";"):
             decl = " ".join(decl.split())
             if not decl:
                 continue
-            mm = re.match(r"(const )?(int32_t|int64_t|double)\s*(\*)?\s*(.*)", decl)
+            mm = re.match(r"(const )?(int32_t|int64_t|double|gr_\w+)\s*(\*)?\s*(.*)", decl)
             assert mm, decl
             base, ptr, names = mm.group(2), mm.group(3), mm.group(4)
             for nm in names.split(","):
                 nm = nm.strip()
-                am = re.match(r"(\w+)\[(\d+)\]", nm)
-                kind = "ptr" if ptr else {"int32_t": "i32", "int64_t": "i64", "double": "f64"}[base]
-                fields.append((am.group(1), kind, int(am.group(2))) if am else (nm, kind, 1))
+                am = re.match(r"(\w+)\[(\w+)\]", nm)
+                # an embedded struct (gr_config.comp[]: the components of a composite geometry) is kind "struct:<name>"
+                kind = "ptr" if ptr else {"int32_t": "i32", "int64_t": "i64", "double": "f64"}.get(base, "struct:" + base)
+                n = (int(am.group(2)) if am.group(2).isdigit() else macros[am.group(2)]) if am else 1
+                fields.append((am.group(1) if am else nm, kind, n))
         out[m.group(1)] = fields
     return out
 
@@ -95,7 +99,7 @@ def jl_structs():
             typ = typ.strip()
             nt = re.match(r"NTuple\{(\d+),(\w+)\}", typ)
             if nt:
-                fields.append((name, JL_SCALAR[nt.group(2)], int(nt.group(1))))
+                fields.append((name, JL_SCALAR.get(nt.group(2)) or "struct:" + JL2C_STRUCT[nt.group(2)], int(nt.group(1))))
             elif typ.startswith("Ptr{"):
                 fields.append((name, "ptr", 1))
             else:
@@ -150,7 +154,7 @@ def jl_ccalls():
 
 
 JL2C_STRUCT = {"GrConfig": "gr_config", "GrStats": "gr_stats", "GrPlane": "gr_plane", "GrPointFunction": "gr_pointfunction",
-               "GrRange": "gr_range", "GrRayset": "gr_rayset", "GrBinning": "gr_binning"}
+               "GrRange": "gr_range", "GrRayset": "gr_rayset", "GrBinning": "gr_binning", "GrDiscComponent": "gr_disc_component"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -174,7 +178,7 @@ def test_ctypes_structures_match_the_header_field_by_field(G):
             if typ in kind_of:
                 fields.append((name, kind_of[typ], 1))
             elif hasattr(typ, "_length_"):
-                fields.append((name, kind_of[typ._type_], typ._length_))
+                fields.append((name, kind_of.get(typ._type_) or "struct:" + typ._type_.__name__, typ._length_))
             else:
                 assert typ is C.c_void_p or issubclass(typ, C._Pointer), (cname, name, typ)
                 fields.append((name, "ptr", 1))
@@ -240,7 +244,8 @@ def test_gr_config_arguments_are_in_field_order():
               "reltol": "reltol", "mu": "trace.μ", "maxiters": "maxiters", "upper_hemisphere": "δ", "_pad": "Int32(0)",
               "hemi_delta": "δ", "disc_params": "dparams", "disc_table": "dtab", "disc_table_n": "length(dtab)",
               "chart_table": "tab", "chart_table_n": "length(tab)", "chart_theta0": "θ0", "chart_theta1": "θ1", "q": "q",
-              "count_windings": "windings", "_pad2": "Int32(0)", "winding_plane": "plane_inc"}
+              "count_windings": "windings", "_pad2": "Int32(0)", "winding_plane": "plane_inc", "comp_n": "comp_n",
+              "_pad3": "Int32(0)", "comp": "comps"}
     assert len(args) == len(fields)
     for f, a in zip(fields, args):
         assert expect[f] in a, (f, a)
