@@ -24,6 +24,7 @@ with the reference's forward-mode ones to ~1e-6.  Pinned on the reference's reco
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -50,6 +51,11 @@ class CunninghamTransferData:
 
 SUMMARY_DTYPE = np.dtype([("status", np.int32), ("x", np.float64, (4,))])
 
+
+# levels of the bisection tree the reference root finder's bracketing traces per launch (1 = one midpoint per launch, the
+# sequential loop; results are identical for every depth: tests/test_newton_ad_reference_branches.py)
+BRACKET_DEPTH = int(os.environ.get("GRADUS_MI355X_BRACKET_DEPTH", "4"))
+BRACKET_RAYS = 16384        # ... and more levels for small groups, while a launch stays below this many rays
 
 # scripts/lineprofile_tf_time.py sets this to a list: every launch of a device tracer then appends (entry point, rays, kernel ms,
 # call ms) so that a product's wall time can be split into launches and host work
@@ -292,16 +298,48 @@ def find_offsets_for_radius_newton_ad(trace, r_target, θ, *, r_min, α0=0.0, β
 
     def bracket(jc):
         """Roots.find_zero(i -> step(i)[end], (contra, x), atol = zero_atol): bisection on the bracket, finished when
-        |y| <= zero_atol; then the reference re-evaluates `step(x)` -- the last midpoint's values here."""
+        |y| <= zero_atol; then the reference re-evaluates `step(x)` -- the last midpoint's values here.
+
+        Bisection is one ray per problem per round and 20-26 rounds long, and a round is a launch as long as one ray: these
+        loops were 60 % of the launches of a transfer-function table.  The midpoints a bisection can visit form a binary tree
+        that depends on nothing but the bracket, so BRACKET_DEPTH levels of it (2^D - 1 midpoints per problem, formed with the
+        very expression the sequential loop uses) are traced in ONE launch and the loop then walks down by the signs it
+        finds: the same midpoints, the same exit level, the same numbers -- a third (D = 3) or a quarter of the rounds."""
         lo_, hi_ = contra[jc].copy(), x[jc].copy()
         mid, pm, dfm, ym = hi_, point[jc], df[jc], y[jc]
-        for _ in range(60):
-            mid = 0.5 * (lo_ + hi_)
-            pm, dfm, ym = step(jc, mid)
-            neg = ym < 0
-            lo_, hi_ = np.where(neg, mid, lo_), np.where(neg, hi_, mid)
-            if np.all(np.abs(ym) <= zero_atol):
-                break
+        k = jc.size
+        it, done = 0, False
+        while it < 60 and not done:
+            # (small groups go deeper: up to BRACKET_RAYS rays per launch, at most 8 levels)
+            D = int(BRACKET_DEPTH)
+            while D > 1 and D < 8 and k * ((1 << (D + 1)) - 1) <= BRACKET_RAYS:
+                D += 1
+            D = max(1, min(D, 60 - it))
+            # level l holds 2^l intervals per problem: node (l, q) = the midpoint of interval q of level l
+            los, his, mids = [lo_[:, None]], [hi_[:, None]], []
+            for l in range(D):
+                m_l = 0.5 * (los[l] + his[l])
+                mids.append(m_l)
+                if l + 1 < D:
+                    # children of interval q: (lo, mid) = 2q [y >= 0: the root lies below mid], (mid, hi) = 2q + 1 [y < 0]
+                    los.append(np.stack([los[l], m_l], axis=2).reshape(k, -1))
+                    his.append(np.stack([m_l, his[l]], axis=2).reshape(k, -1))
+            flat = np.concatenate([m.ravel() for m in mids])
+            idx = np.concatenate([np.repeat(jc, m.shape[1]) for m in mids])
+            p_all, df_all, y_all = step(idx, flat)
+            off, q = 0, np.zeros(k, dtype=np.int64)
+            for l in range(D):
+                w = mids[l].shape[1]
+                sel = off + np.arange(k) * w + q
+                mid, pm, dfm, ym = flat[sel], p_all[sel], df_all[sel], y_all[sel]
+                neg = ym < 0
+                lo_, hi_ = np.where(neg, mid, lo_), np.where(neg, hi_, mid)
+                q = 2 * q + neg.astype(np.int64)
+                off += k * w
+                it += 1
+                if np.all(np.abs(ym) <= zero_atol) or it >= 60:
+                    done = True
+                    break
         x[jc], y[jc], df[jc], point[jc] = mid, ym, dfm, pm
 
     i = 0

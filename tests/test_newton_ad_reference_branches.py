@@ -132,3 +132,36 @@ def test_batch_of_mixed_problems_equals_the_problems_one_by_one():
         r1, _, _, p1 = TF.find_offsets_for_radius_newton_ad(FakeTrace(F, dF), np.array([re]), np.array([0.0]), r_min=0.2)
         assert (np.isnan(r1[0]) and np.isnan(r_all[k])) or r1[0] == r_all[k]
         assert p1[0, 1] == p_all[k, 1]
+
+
+def test_tree_bisection_gives_the_sequential_bisection_bit_for_bit():
+    """The bracketing finish traces BRACKET_DEPTH levels of the bisection tree per launch (round 4).  For every depth the
+    midpoints visited, the exit level and therefore every returned number equal the one-midpoint-per-launch loop's --
+    singly and in a mixed batch whose problems leave the bracket at different levels -- and the launches shrink."""
+    probs = [(kind, k, re, r_min) for kind, k, re, r_min in CASES if kind in ("well", "flat")]
+    outs, calls, launches = {}, {}, {}
+    for depth in (1, 2, 3, 4, 7):
+        TF.BRACKET_DEPTH = depth
+        try:
+            res = []
+            n_launch = 0
+            for kind, k, re, r_min in probs:
+                F, dF = make_map(kind, k)
+                tr = FakeTrace(F, dF)
+                orig = tr.tangent
+
+                def counted(α, β, heights=None, orig=orig):
+                    nonlocal n_launch
+                    n_launch += 1
+                    return orig(α, β, heights)
+
+                tr.tangent = counted
+                r, pts, g, point = TF.find_offsets_for_radius_newton_ad(tr, np.array([re, re * 1.01, re * 0.99]), np.zeros(3), r_min=r_min)
+                res.append((r.copy(), point.copy()))
+            outs[depth], launches[depth] = res, n_launch
+        finally:
+            TF.BRACKET_DEPTH = 4
+    for depth in (2, 3, 4, 7):
+        for (r1, p1), (rd, pd) in zip(outs[1], outs[depth]):
+            assert r1.tobytes() == rd.tobytes() and p1.tobytes() == pd.tobytes(), depth
+    assert max(launches[d] for d in (2, 3, 4, 7)) < 0.75 * launches[1], launches          # (the rest are Newton iterations)
