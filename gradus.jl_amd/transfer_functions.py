@@ -304,42 +304,56 @@ def find_offsets_for_radius_newton_ad(trace, r_target, θ, *, r_min, α0=0.0, β
         loops were 60 % of the launches of a transfer-function table.  The midpoints a bisection can visit form a binary tree
         that depends on nothing but the bracket, so BRACKET_DEPTH levels of it (2^D - 1 midpoints per problem, formed with the
         very expression the sequential loop uses) are traced in ONE launch and the loop then walks down by the signs it
-        finds: the same midpoints, the same exit level, the same numbers -- a third (D = 3) or a quarter of the rounds."""
+        finds: the same midpoints, the same exit level, the same numbers -- a third (D = 3) or a quarter of the rounds.
+        Every problem leaves at ITS first midpoint with |y| <= zero_atol, like the reference's find_zero on one problem
+        (until round 4 a group of problems bisected on until all of them were there): what a problem returns does not
+        depend on which other problems share its launches."""
         lo_, hi_ = contra[jc].copy(), x[jc].copy()
-        mid, pm, dfm, ym = hi_, point[jc], df[jc], y[jc]
+        mid, pm, dfm, ym = hi_.copy(), point[jc].copy(), df[jc].copy(), y[jc].copy()
         k = jc.size
-        it, done = 0, False
-        while it < 60 and not done:
+        live = np.ones(k, dtype=bool)          # problems still bisecting: each stops at ITS first |y| <= zero_atol, as find_zero does
+        it = 0
+        while it < 60 and live.any():
             # (small groups go deeper: up to BRACKET_RAYS rays per launch, at most 8 levels)
+            kl = int(live.sum())
             D = int(BRACKET_DEPTH)
-            while D > 1 and D < 8 and k * ((1 << (D + 1)) - 1) <= BRACKET_RAYS:
+            while D > 1 and D < 8 and kl * ((1 << (D + 1)) - 1) <= BRACKET_RAYS:
                 D += 1
             D = max(1, min(D, 60 - it))
+            jl = np.flatnonzero(live)
             # level l holds 2^l intervals per problem: node (l, q) = the midpoint of interval q of level l
-            los, his, mids = [lo_[:, None]], [hi_[:, None]], []
+            los, his, mids = [lo_[jl, None]], [hi_[jl, None]], []
             for l in range(D):
                 m_l = 0.5 * (los[l] + his[l])
                 mids.append(m_l)
                 if l + 1 < D:
                     # children of interval q: (lo, mid) = 2q [y >= 0: the root lies below mid], (mid, hi) = 2q + 1 [y < 0]
-                    los.append(np.stack([los[l], m_l], axis=2).reshape(k, -1))
-                    his.append(np.stack([m_l, his[l]], axis=2).reshape(k, -1))
+                    los.append(np.stack([los[l], m_l], axis=2).reshape(kl, -1))
+                    his.append(np.stack([m_l, his[l]], axis=2).reshape(kl, -1))
             flat = np.concatenate([m.ravel() for m in mids])
-            idx = np.concatenate([np.repeat(jc, m.shape[1]) for m in mids])
+            idx = np.concatenate([np.repeat(jc[jl], m.shape[1]) for m in mids])
             p_all, df_all, y_all = step(idx, flat)
-            off, q = 0, np.zeros(k, dtype=np.int64)
+            off, q = 0, np.zeros(kl, dtype=np.int64)
+            going = np.ones(kl, dtype=bool)      # of this launch's problems: not yet at their exit level
             for l in range(D):
                 w = mids[l].shape[1]
-                sel = off + np.arange(k) * w + q
-                mid, pm, dfm, ym = flat[sel], p_all[sel], df_all[sel], y_all[sel]
-                neg = ym < 0
-                lo_, hi_ = np.where(neg, mid, lo_), np.where(neg, hi_, mid)
-                q = 2 * q + neg.astype(np.int64)
-                off += k * w
+                sel = (off + np.arange(kl) * w + q)[going]
+                g_ = jl[going]
+                mid[g_], pm[g_], dfm[g_], ym[g_] = flat[sel], p_all[sel], df_all[sel], y_all[sel]
+                neg = ym[g_] < 0
+                lo_[g_], hi_[g_] = np.where(neg, mid[g_], lo_[g_]), np.where(neg, hi_[g_], mid[g_])
+                qn = q.copy()
+                qn[going] = 2 * q[going] + neg.astype(np.int64)
+                q = np.where(going, qn, 2 * q)
+                off += kl * w
                 it += 1
-                if np.all(np.abs(ym) <= zero_atol) or it >= 60:
-                    done = True
+                fin = np.abs(ym[g_]) <= zero_atol
+                live[g_[fin]] = False
+                going[np.flatnonzero(going)[fin]] = False
+                if not going.any() or it >= 60:
                     break
+            if it >= 60:
+                break
         x[jc], y[jc], df[jc], point[jc] = mid, ym, dfm, pm
 
     i = 0
