@@ -162,6 +162,9 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
 
     trace.endpoints = endpoints
     trace.tangent = tangent
+    # rays are nearly free next to a launch's latency here: the solvers may trace points they might not need
+    # (BRACKET_DEPTH, GOLDEN_DEPTH); tracers without this mark (the CPU tests' oracle-driven ones) get one level at a time
+    trace.speculate = True
     return trace
 
 
@@ -316,7 +319,7 @@ def find_offsets_for_radius_newton_ad(trace, r_target, θ, *, r_min, α0=0.0, β
         while it < 60 and live.any():
             # (small groups go deeper: up to BRACKET_RAYS rays per launch, at most 8 levels)
             kl = int(live.sum())
-            D = int(BRACKET_DEPTH)
+            D = int(BRACKET_DEPTH) if getattr(trace, "speculate", False) or getattr(trace, "speculate_test", False) else 1
             while D > 1 and D < 8 and kl * ((1 << (D + 1)) - 1) <= BRACKET_RAYS:
                 D += 1
             D = max(1, min(D, 60 - it))
@@ -498,23 +501,65 @@ class _ThickWorkhorse:
         return g, np.where(visible, J, np.nan), gp["x"][:, 0].copy()
 
 
-def _golden_section_batch(f, lower, upper, iterations):
-    """Optim.optimize(f, lower, upper, GoldenSection(); iterations) for a batch of independent
-    one-dimensional problems advanced in lock-step; `f(θ_array)` evaluates all of them at once.
-    Returns the minima found (Optim.minimum)."""
+# iterations of the golden-section searches that one round of root finds advances: the points a search can visit next form a
+# binary tree that depends on the bracket alone (not on the function values), so GOLDEN_DEPTH levels of it -- 2^D - 1 points per
+# search -- are evaluated together and the search then walks down by the comparisons it makes: the same points, the same minima.
+GOLDEN_DEPTH = int(os.environ.get("GRADUS_MI355X_GOLDEN_DEPTH", "2"))
+
+
+def _golden_section_batch(evaluate, record, lower, upper, iterations, depth=None):
+    """Optim.optimize(f, lower, upper, GoldenSection(); iterations) for a batch of independent one-dimensional problems.
+    `evaluate(idx, x)` evaluates problem idx[k] at x[k] (any number of points per problem in one call) and returns whatever
+    `record` needs; `record(x, values)` -- called once per iteration with one point per problem, in problem order -- stores
+    the evaluation the search really made and returns f.  Returns the minima found (Optim.minimum)."""
+    depth = GOLDEN_DEPTH if depth is None else depth
     lower, upper = np.array(lower, dtype=np.float64), np.array(upper, dtype=np.float64)
+    n = lower.size
+    every = np.arange(n)
     xmin = lower + GOLDEN * (upper - lower)
-    fmin = f(xmin)
-    for _ in range(iterations):
-        right = (upper - xmin) > (xmin - lower)
-        new_x = np.where(right, xmin + GOLDEN * (upper - xmin), xmin - GOLDEN * (xmin - lower))
-        new_f = f(new_x)
-        better = new_f < fmin
-        # right step:  better -> lower = xmin ; else upper = new_x ;  left step mirrored
-        lower = np.where(right & better, xmin, np.where(~right & ~better, new_x, lower))
-        upper = np.where(right & ~better, new_x, np.where(~right & better, xmin, upper))
-        xmin = np.where(better, new_x, xmin)
-        fmin = np.where(better, new_f, fmin)
+    fmin = record(xmin, evaluate(every, xmin))
+    it = 0
+    while it < iterations:
+        D = max(1, min(int(depth), iterations - it))
+        # level l: 2^l possible states per problem; child 2q = "the new point was not better", 2q + 1 = "better"
+        states, level_pts = [(lower, upper, xmin)], []
+        for l in range(D):
+            pts, nxt = [], []
+            for lo, up, xm in states:
+                right = (up - xm) > (xm - lo)
+                nx = np.where(right, xm + GOLDEN * (up - xm), xm - GOLDEN * (xm - lo))
+                pts.append(nx)
+                if l + 1 < D:
+                    nxt.append((np.where(~right, nx, lo), np.where(right, nx, up), xm))          # not better
+                    nxt.append((np.where(right, xm, lo), np.where(~right, xm, up), nx))          # better
+            level_pts.append(pts)
+            states = nxt
+        flat_x = np.concatenate([p for pts in level_pts for p in pts])
+        flat_i = np.tile(every, len(flat_x) // n)
+        try:
+            vals = evaluate(flat_i, flat_x)
+        except RuntimeError:
+            # a point the search would not have visited has no solution: go on one level at a time (the on-path point
+            # raises as before if it is the one)
+            if D == 1:
+                raise
+            depth = 1
+            continue
+        off, q = 0, np.zeros(n, dtype=np.int64)
+        for l in range(D):
+            sel = off + q * n + every                    # problem k's point at node q[k] of this level
+            new_x = flat_x[sel]
+            new_f = record(new_x, tuple(v[sel] for v in vals))
+            right = (upper - xmin) > (xmin - lower)
+            better = new_f < fmin
+            # right step:  better -> lower = xmin ; else upper = new_x ;  left step mirrored
+            lower = np.where(right & better, xmin, np.where(~right & ~better, new_x, lower))
+            upper = np.where(right & ~better, new_x, np.where(~right & better, xmin, upper))
+            xmin = np.where(better, new_x, xmin)
+            fmin = np.where(better, new_f, fmin)
+            q = 2 * q + better.astype(np.int64)
+            off += n * (1 << l)
+            it += 1
     return fmin
 
 
@@ -589,11 +634,17 @@ def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offs
     rr2 = np.concatenate([radii, radii])
     sign = np.concatenate([np.ones(R), -np.ones(R)])
 
-    def objective(θ2):
+    def evaluate(idx, θ2):
+        """(θ after the pole nudge, g, J, t) at θ2[k] for search idx[k] (searches 0..R-1: g_min, R..2R-1: g_max of radius idx - R)"""
         θ2 = np.array(θ2, dtype=np.float64)
         pole = (np.abs(θ2) < 1e-4) | (np.abs(np.abs(θ2) - math.pi) < 1e-4)
         θ2 = np.where(pole, θ2 + 1e-4, θ2)
-        g, J, t = work(rr2, θ2)
+        g, J, t = work(rr2[idx], θ2)
+        return θ2, g, J, t
+
+    def record(_, vals):
+        """one stored call per search and iteration (utils.jl:8-30: the accumulator keeps every point the search evaluated)"""
+        θ2, g, J, t = vals
         i = slot[0]
         for half, col in ((slice(0, R), i), (slice(R, 2 * R), M - 1 - (i - N))):
             data[:, 0, col], data[:, 1, col], data[:, 2, col], data[:, 3, col] = θ2[half], g[half], J[half], t[half]
@@ -602,7 +653,8 @@ def cunningham_transfer_functions(m, x, d, radii, *, N=80, N_extrema=17, θ_offs
 
     lower = np.concatenate([np.full(R, -θ_offset), np.full(R, math.pi - θ_offset)])
     upper = np.concatenate([np.full(R, θ_offset), np.full(R, math.pi + θ_offset)])
-    best = _golden_section_batch(objective, lower, upper, n_iter)
+    best = _golden_section_batch(evaluate, record, lower, upper, n_iter,
+                                 depth=GOLDEN_DEPTH if getattr(tracer, "speculate", False) else 1)
     gmin_c, gmax_c = best[:R], -best[R:]
     if _raw is not None:
         _raw.append((data.copy(), gmin_c.copy(), gmax_c.copy()))

@@ -148,6 +148,7 @@ def test_tree_bisection_gives_the_sequential_bisection_bit_for_bit():
             for kind, k, re, r_min in probs:
                 F, dF = make_map(kind, k)
                 tr = FakeTrace(F, dF)
+                tr.speculate_test = True          # (only the device tracer speculates by default: its rays are nearly free)
                 orig = tr.tangent
 
                 def counted(α, β, heights=None, orig=orig):

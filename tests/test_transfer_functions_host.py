@@ -48,18 +48,31 @@ def test_datum_plane_is_hit_from_above_only(G, oracle):
 
 
 def test_golden_section_restatement():
+    """Optim's GoldenSection restated; with `depth` levels of its decision tree evaluated per round (round 4) the points the
+    search RECORDS -- one per search and iteration -- and the minima are the same for every depth, bit for bit."""
     from gradus_jl_amd.transfer_functions import _golden_section_batch
 
-    seen = []
+    c, off = np.array([0.1, -0.2]), np.array([1.0, 2.0])
+    out = {}
+    for depth in (1, 2, 3, 5):
+        seen, rounds = [], [0]
 
-    def f(x):
-        seen.append(np.array(x))
-        return (np.asarray(x) - np.array([0.1, -0.2])) ** 2 + np.array([1.0, 2.0])
+        def evaluate(idx, x):
+            rounds[0] += 1
+            return ((np.asarray(x) - c[idx]) ** 2 + off[idx],)
 
-    best = _golden_section_batch(f, [-0.3, -0.3], [0.3, 0.3], 16)
-    assert len(seen) == 17                                  # f_calls = iterations + 1 = N_extrema
-    np.testing.assert_allclose(best, [1.0, 2.0], atol=1e-7)
-    np.testing.assert_allclose(seen[0], -0.3 + 0.5 * (3 - math.sqrt(5)) * 0.6)
+        def record(x, vals):
+            seen.append(np.array(x))
+            return vals[0]
+
+        best = _golden_section_batch(evaluate, record, [-0.3, -0.3], [0.3, 0.3], 16, depth=depth)
+        assert len(seen) == 17                                  # f_calls = iterations + 1 = N_extrema
+        assert rounds[0] == 1 + -(-16 // depth)
+        np.testing.assert_allclose(best, [1.0, 2.0], atol=1e-7)
+        np.testing.assert_allclose(seen[0], -0.3 + 0.5 * (3 - math.sqrt(5)) * 0.6)
+        out[depth] = (best.copy(), np.array(seen))
+    for depth in (2, 3, 5):
+        assert out[depth][0].tobytes() == out[1][0].tobytes() and out[depth][1].tobytes() == out[1][1].tobytes()
 
 
 def test_reference_values_large_radii(G, oracle):
