@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(shutil.which("g++") is None or shutil.which("make") is None, reason="needs g++ and make")
 def test_oracle_and_host_kernel_logic_are_clean_under_asan_and_ubsan():
-    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "asan"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "tests", "c"), "asan"], capture_output=True, text=True, timeout=900)
     tail = (out.stdout + out.stderr)[-3000:]
     assert out.returncode == 0, tail
     assert "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail, tail
