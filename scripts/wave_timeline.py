@@ -3,7 +3,9 @@
 (scripts/build_variant.sh WORK <name> -DGR_WAVE_TIMELINE; GRADUS_MI355X_LIB=ab/<name>.so): every wave of the one-ray-per-lane
 kernel writes (start, end [100 MHz clock], hardware id, steps of its longest ray).  Prints the distribution of wave lifetimes,
 the number of waves resident over time and where the launch's tail comes from.
-    python scripts/wave_timeline.py [S=1024] [order=grid|lpt]"""
+    python scripts/wave_timeline.py [S=1024] [order=grid|lpt|plane]
+order = plane: the bench workload (fused image of an S x S plane, the plain fp64 lane kernel) instead of the tangent launch;
+WT_KNOBS="lpt=2,lpt_lane=1" sets context knobs first"""
 import ctypes as C
 import json
 import math
@@ -23,38 +25,57 @@ from gradus_jl_amd.tracing import lnr_momentum_to_global_velocity_matrix
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 order = sys.argv[2] if len(sys.argv) > 2 else "grid"
 ens = G.EnsembleMI355X(0)
+for kv in filter(None, os.environ.get("WT_KNOBS", "").split(",")):
+    k_, v_ = kv.split("=")
+    ens.set(k_, int(v_))
 m = G.KerrMetric(1.0, 0.998)
 x = np.array([0.0, 1000.0, math.radians(75), 0.0])
-cfg = G.tracing_configuration(m, x, np.zeros((1, 4)), G.DatumPlane(0.0), 2000.0, ensemble=ens)
-acfg = cfg.abi_config()
-apf, keep = abi_pointfunction(G.ConstPointFunctions.redshift(m, x))
 dev = torch.device("cuda", 0)
 L = _lib.load()
 L.gr_debug_set_timeline.argtypes = [C.c_void_p]
-Mx = lnr_momentum_to_global_velocity_matrix(m, cfg.position)
-aa, bb = np.meshgrid(np.linspace(-60.0, 60.0, S), np.linspace(-35.0, 35.0, S))
-a, b = aa.ravel().copy(), bb.ravel().copy()
-if order == "lpt":        # rays closest to the polar axis / the photon ring first
-    k = np.argsort(np.minimum(np.abs(a), np.hypot(a - 2.5, b)), kind="stable")
-    a, b = a[k], b[k]
-d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
 n = S * S
-rs = _lib.gr_rayset()
-for i in range(4):
-    rs.x_obs[i] = float(cfg.position[i])
-    for q in range(4):
-        rs.Mx[4 * i + q] = float(Mx[i, q])
-rs.alpha, rs.beta, rs.area, rs.n = d_a.data_ptr(), d_b.data_ptr(), None, n
-o = torch.empty(n * 8, dtype=torch.float64, device=dev)
+if order == "plane":
+    from gradus_jl_amd import device as gdev
+
+    pcfg = G.render_configuration(m, x, G.ThinDisc(m.isco(), 50.0), 2000.0, image_width=S, image_height=S, alpha_lims=(-60.0, 60.0),
+                                  beta_lims=(-35.0, 35.0), ensemble=ens)
+    ppf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+    img = torch.empty(n, dtype=torch.float64, device=dev)
+
+    def launch():
+        gdev.render_device(pcfg, ppf, img)
+    reps = 4          # (a learned tile order needs a recording launch and a sorting one first)
+else:
+    cfg = G.tracing_configuration(m, x, np.zeros((1, 4)), G.DatumPlane(0.0), 2000.0, ensemble=ens)
+    acfg = cfg.abi_config()
+    apf, keep = abi_pointfunction(G.ConstPointFunctions.redshift(m, x))
+    Mx = lnr_momentum_to_global_velocity_matrix(m, cfg.position)
+    aa, bb = np.meshgrid(np.linspace(-60.0, 60.0, S), np.linspace(-35.0, 35.0, S))
+    a, b = aa.ravel().copy(), bb.ravel().copy()
+    if order == "lpt":        # rays closest to the polar axis / the photon ring first
+        k = np.argsort(np.minimum(np.abs(a), np.hypot(a - 2.5, b)), kind="stable")
+        a, b = a[k], b[k]
+    d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    rs = _lib.gr_rayset()
+    for i in range(4):
+        rs.x_obs[i] = float(cfg.position[i])
+        for q in range(4):
+            rs.Mx[4 * i + q] = float(Mx[i, q])
+    rs.alpha, rs.beta, rs.area, rs.n = d_a.data_ptr(), d_b.data_ptr(), None, n
+    o = torch.empty(n * 8, dtype=torch.float64, device=dev)
+
+    def launch():
+        _lib.check(L.gr_ray_tangent_device(ens.ctx.handle, C.byref(acfg), C.byref(rs), C.byref(apf), C.c_void_p(o.data_ptr()), None,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    reps = 2
 waves_max = 2 * n // 64 + 8
 tl = torch.zeros(4 * waves_max, dtype=torch.int64, device=dev)
-for rep in range(2):
+for rep in range(reps):
     tl.zero_()
     L.gr_debug_set_timeline(C.c_void_p(tl.data_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(L.gr_ray_tangent_device(ens.ctx.handle, C.byref(acfg), C.byref(rs), C.byref(apf), C.c_void_p(o.data_ptr()), None,
-                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    launch()
     e1.record()
     torch.cuda.synchronize()
 L.gr_debug_set_timeline(None)
