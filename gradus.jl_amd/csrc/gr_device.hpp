@@ -462,30 +462,58 @@ GR_DEV void sincos_rot_stage(const RotK& k, real th0, real s0, real c0, real th,
 // Forward-mode dual number with two partials, for metrics without hand-written derivatives
 // (the reference differentiates every metric this way, auto-diff.jl:206-211).
 // ---------------------------------------------------------------------------------------
-struct Dual2 {
-    real v, a, b;
+// Typed since round 4: every metric of the catalogue is built from functions of r alone and of θ alone (Δ(r), sin²θ, ...) that
+// meet in a few products (Σ, A); a sub-expression that depends on one coordinate carries ONE partial, the other is absent from
+// the type instead of being a zero that is multiplied and added through (x·0 cannot be folded under IEEE rules).  The values
+// are those of the untyped form (a term a·0 + b is b); DualR = ∂_r only, DualT = ∂_θ only, Dual2 = both.
+template <bool HA, bool HB>
+struct DualP {
+    real v, a, b;          // a = ∂_r (read only where HA), b = ∂_θ (only where HB)
 };
-GR_DEV Dual2 dconst(real x) { return { x, 0.0, 0.0 }; }
-GR_DEV Dual2 operator+(Dual2 x, Dual2 y) { return { x.v + y.v, x.a + y.a, x.b + y.b }; }
-GR_DEV Dual2 operator-(Dual2 x, Dual2 y) { return { x.v - y.v, x.a - y.a, x.b - y.b }; }
-GR_DEV Dual2 operator-(Dual2 x) { return { -x.v, -x.a, -x.b }; }
-GR_DEV Dual2 operator+(Dual2 x, real y) { return { x.v + y, x.a, x.b }; }
-GR_DEV Dual2 operator+(real y, Dual2 x) { return { x.v + y, x.a, x.b }; }
-GR_DEV Dual2 operator-(Dual2 x, real y) { return { x.v - y, x.a, x.b }; }
-GR_DEV Dual2 operator-(real y, Dual2 x) { return { y - x.v, -x.a, -x.b }; }
-GR_DEV Dual2 operator*(real s, Dual2 x) { return { s * x.v, s * x.a, s * x.b }; }
-GR_DEV Dual2 operator*(Dual2 x, real s) { return { s * x.v, s * x.a, s * x.b }; }
-GR_DEV Dual2 operator*(Dual2 x, Dual2 y)
+typedef DualP<true, true> Dual2;
+typedef DualP<true, false> DualR;
+typedef DualP<false, true> DualT;
+template <bool A1, bool B1, bool A2, bool B2>
+GR_DEV DualP<A1 || A2, B1 || B2> operator+(DualP<A1, B1> x, DualP<A2, B2> y)
 {
-    return { x.v * y.v, GR_FMA(x.a, y.v, x.v * y.a), GR_FMA(x.b, y.v, x.v * y.b) };
+    DualP<A1 || A2, B1 || B2> z{ x.v + y.v, 0.0, 0.0 };
+    if constexpr (A1 && A2) z.a = x.a + y.a; else if constexpr (A1) z.a = x.a; else if constexpr (A2) z.a = y.a;
+    if constexpr (B1 && B2) z.b = x.b + y.b; else if constexpr (B1) z.b = x.b; else if constexpr (B2) z.b = y.b;
+    return z;
 }
-GR_DEV Dual2 dinv(Dual2 y)
+template <bool A1, bool B1, bool A2, bool B2>
+GR_DEV DualP<A1 || A2, B1 || B2> operator-(DualP<A1, B1> x, DualP<A2, B2> y)
+{
+    DualP<A1 || A2, B1 || B2> z{ x.v - y.v, 0.0, 0.0 };
+    if constexpr (A1 && A2) z.a = x.a - y.a; else if constexpr (A1) z.a = x.a; else if constexpr (A2) z.a = -y.a;
+    if constexpr (B1 && B2) z.b = x.b - y.b; else if constexpr (B1) z.b = x.b; else if constexpr (B2) z.b = -y.b;
+    return z;
+}
+template <bool A1, bool B1, bool A2, bool B2>
+GR_DEV DualP<A1 || A2, B1 || B2> operator*(DualP<A1, B1> x, DualP<A2, B2> y)
+{
+    DualP<A1 || A2, B1 || B2> z{ x.v * y.v, 0.0, 0.0 };
+    if constexpr (A1 && A2) z.a = GR_FMA(x.a, y.v, x.v * y.a); else if constexpr (A1) z.a = x.a * y.v; else if constexpr (A2) z.a = x.v * y.a;
+    if constexpr (B1 && B2) z.b = GR_FMA(x.b, y.v, x.v * y.b); else if constexpr (B1) z.b = x.b * y.v; else if constexpr (B2) z.b = x.v * y.b;
+    return z;
+}
+template <bool A, bool B> GR_DEV DualP<A, B> operator-(DualP<A, B> x) { return { -x.v, -x.a, -x.b }; }
+template <bool A, bool B> GR_DEV DualP<A, B> operator+(DualP<A, B> x, real y) { return { x.v + y, x.a, x.b }; }
+template <bool A, bool B> GR_DEV DualP<A, B> operator+(real y, DualP<A, B> x) { return { x.v + y, x.a, x.b }; }
+template <bool A, bool B> GR_DEV DualP<A, B> operator-(DualP<A, B> x, real y) { return { x.v - y, x.a, x.b }; }
+template <bool A, bool B> GR_DEV DualP<A, B> operator-(real y, DualP<A, B> x) { return { y - x.v, -x.a, -x.b }; }
+template <bool A, bool B> GR_DEV DualP<A, B> operator*(real s, DualP<A, B> x) { return { s * x.v, A ? s * x.a : x.a, B ? s * x.b : x.b }; }
+template <bool A, bool B> GR_DEV DualP<A, B> operator*(DualP<A, B> x, real s) { return s * x; }
+template <bool A, bool B>
+GR_DEV DualP<A, B> dinv(DualP<A, B> y)
 {
     const real i = rcp_full(y.v);
     const real m = -i * i;
-    return { i, m * y.a, m * y.b };
+    return { i, A ? m * y.a : y.a, B ? m * y.b : y.b };
 }
-GR_DEV Dual2 operator/(Dual2 x, Dual2 y) { return x * dinv(y); }
+// what a metric's component function stores: a typed dual widens to the full one (absent partial = 0), a plain value stays
+template <bool A, bool B> GR_DEV void dput(Dual2& d, DualP<A, B> x) { d.v = x.v; d.a = A ? x.a : (real)0.0; d.b = B ? x.b : (real)0.0; }
+GR_DEV void dput(real& d, real x) { d = x; }
 
 // ---------------------------------------------------------------------------------------
 // Metrics.  eval() returns, for the block form (tt, rr, θθ, ϕϕ, tϕ):
@@ -942,241 +970,241 @@ struct GenericMetricT {
         kik = (ID == GR_METRIC_BUMBLEBEE) ? uni(rcp_full(1.0 + P[2])) : (real)0.0;
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
-    static GR_DEV Dual2 inv_(Dual2 x) { return dinv(x); }
+    template <bool A, bool B> static GR_DEV DualP<A, B> inv_(DualP<A, B> x) { return dinv(x); }
     static GR_DEV real val_(real x) { return x; }
-    static GR_DEV real val_(Dual2 x) { return x.v; }
+    template <bool A, bool B> static GR_DEV real val_(DualP<A, B> x) { return x.v; }
     static GR_DEV real atan_(real x) { return GR_ATAN(x); }
-    static GR_DEV Dual2 atan_(Dual2 x)
+    template <bool A, bool B> static GR_DEV DualP<A, B> atan_(DualP<A, B> x)
     {
         const real w = rcp_full(GR_FMA(x.v, x.v, 1.0));
-        return { GR_ATAN(x.v), w * x.a, w * x.b };
+        return { GR_ATAN(x.v), A ? w * x.a : x.a, B ? w * x.b : x.b };
     }
 
     // __JohannsenAD.metric_components, johannsen-ad.jl:12-34 ; P = M, a, α13, α22, α52, ϵ3
-    template <class T>
-    GR_DEV void johannsen(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void johannsen(TR r, TT s, TT c, TG g[5]) const
     {
         const real M = P[0], a = P[1], a13 = P[2], a22 = P[3], a52 = P[4], e3 = P[5];
         const real a2 = a * a;
-        T Mr = M * inv_(r);
-        T Mr2 = Mr * Mr;
-        T A1 = 1.0 + a13 * (Mr2 * Mr);
-        T A2 = 1.0 + a22 * Mr2;
-        T A5 = 1.0 + a52 * Mr2;
-        T r2 = r * r;
-        T Sig = r2 + a2 * (c * c) + (e3 * M * M * M) * inv_(r);
-        T Del = r2 - (2.0 * M) * r + a2;
-        T r2a2 = r2 + a2;
-        T s2 = s * s;
-        T dn = r2a2 * A1 - a2 * (A2 * s2);
-        T idenom = inv_(dn * dn);
-        T tt = -(Sig * (Del - a2 * (A2 * A2 * s2)));
-        T pp = (Sig * s2) * ((r2a2 * r2a2) * (A1 * A1) - a2 * (Del * s2));
-        T tp = -(a * ((Sig * s2) * (r2a2 * A1 * A2 - Del)));
-        g[0] = tt * idenom;
-        g[1] = Sig * inv_(Del * A5);
-        g[2] = Sig;
-        g[3] = pp * idenom;
-        g[4] = tp * idenom;
+        auto Mr = M * inv_(r);
+        auto Mr2 = Mr * Mr;
+        auto A1 = 1.0 + a13 * (Mr2 * Mr);
+        auto A2 = 1.0 + a22 * Mr2;
+        auto A5 = 1.0 + a52 * Mr2;
+        auto r2 = r * r;
+        auto Sig = r2 + a2 * (c * c) + (e3 * M * M * M) * inv_(r);
+        auto Del = r2 - (2.0 * M) * r + a2;
+        auto r2a2 = r2 + a2;
+        auto s2 = s * s;
+        auto dn = r2a2 * A1 - a2 * (A2 * s2);
+        auto idenom = inv_(dn * dn);
+        auto tt = -(Sig * (Del - a2 * (A2 * A2 * s2)));
+        auto pp = (Sig * s2) * ((r2a2 * r2a2) * (A1 * A1) - a2 * (Del * s2));
+        auto tp = -(a * ((Sig * s2) * (r2a2 * A1 * A2 - Del)));
+        dput(g[0], tt * idenom);
+        dput(g[1], Sig * inv_(Del * A5));
+        dput(g[2], Sig);
+        dput(g[3], pp * idenom);
+        dput(g[4], tp * idenom);
     }
     // __MorrisThorneAD.metric_components, morris-thorne-ad.jl:4-15 ; P = b.  (ϕϕ carries sinθ to
     // the FIRST power in the reference; reproduced as is.)
-    template <class T>
-    GR_DEV void morris_thorne(T l, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void morris_thorne(TR l, TT s, TT c, TG g[5]) const
     {
         const real b2 = P[0] * P[0];
-        T w = l * l + b2;
-        g[0] = (l - l) - 1.0;
-        g[1] = (l - l) + 1.0;
-        g[2] = w;
-        g[3] = w * s;
-        g[4] = l - l;
+        auto w = l * l + b2;
+        dput(g[0], (l - l) - 1.0);
+        dput(g[1], (l - l) + 1.0);
+        dput(g[2], w);
+        dput(g[3], w * s);
+        dput(g[4], l - l);
         (void)c;
     }
     // __BumblebeeAD.metric_components, bumblebee-ad.jl:6-21 ; P = M, a, l
-    template <class T>
-    GR_DEV void bumblebee(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void bumblebee(TR r, TT s, TT c, TG g[5]) const
     {
         const real M = P[0], a = P[1], lsb = P[2];
-        T s2 = s * s;
-        T r2 = r * r;
-        T ir = inv_(r);
-        T Del = (r2 - (2.0 * M) * r) * (1.0 / (lsb + 1.0));
-        g[0] = -(1.0 - (2.0 * M) * ir);
-        g[1] = r2 * inv_(Del);
-        g[2] = r2;
-        g[3] = r2 * s2;
-        g[4] = -((2.0 * M * a) * (s2 * ir));
+        auto s2 = s * s;
+        auto r2 = r * r;
+        auto ir = inv_(r);
+        auto Del = (r2 - (2.0 * M) * r) * (1.0 / (lsb + 1.0));
+        dput(g[0], -(1.0 - (2.0 * M) * ir));
+        dput(g[1], r2 * inv_(Del));
+        dput(g[2], r2);
+        dput(g[3], r2 * s2);
+        dput(g[4], -((2.0 * M * a) * (s2 * ir)));
         (void)c;
     }
     // __JohannsenPsaltisAD.metric_components, johannsen-psaltis-ad.jl:4-27 ; P = M, a, ϵ3
-    template <class T>
-    GR_DEV void johannsen_psaltis(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void johannsen_psaltis(TR r, TT s, TT c, TG g[5]) const
     {
         const real M = P[0], a = P[1], e3 = P[2];
         const real a2 = a * a;
-        T r2 = r * r;
-        T Sig = r2 + a2 * (c * c);
-        T iSig = inv_(Sig);
-        T h = (e3 * M * M * M) * (r * (iSig * iSig));
-        T s2 = s * s;
-        T Del = r2 - (2.0 * M) * r + a2;
-        T tMr = (2.0 * M) * r;
-        T hp1 = 1.0 + h;
-        g[0] = -(hp1 * (1.0 - tMr * iSig));
-        g[1] = (Sig * hp1) * inv_(Del + a2 * (s2 * h));
-        g[2] = Sig;
-        T term1 = s2 * (r2 + a2 + (a2 * (tMr * s2)) * iSig);
-        T term2 = (h * a2) * ((Sig + tMr) * ((s2 * s2) * iSig));
-        g[3] = term1 + term2;
-        g[4] = -((a * tMr) * ((s2 * hp1) * iSig));
+        auto r2 = r * r;
+        auto Sig = r2 + a2 * (c * c);
+        auto iSig = inv_(Sig);
+        auto h = (e3 * M * M * M) * (r * (iSig * iSig));
+        auto s2 = s * s;
+        auto Del = r2 - (2.0 * M) * r + a2;
+        auto tMr = (2.0 * M) * r;
+        auto hp1 = 1.0 + h;
+        dput(g[0], -(hp1 * (1.0 - tMr * iSig)));
+        dput(g[1], (Sig * hp1) * inv_(Del + a2 * (s2 * h)));
+        dput(g[2], Sig);
+        auto term1 = s2 * (r2 + a2 + (a2 * (tMr * s2)) * iSig);
+        auto term2 = (h * a2) * ((Sig + tMr) * ((s2 * s2) * iSig));
+        dput(g[3], term1 + term2);
+        dput(g[4], -((a * tMr) * ((s2 * hp1) * iSig)));
     }
 
     // __DilatonAxionAD.metric_components, dilaton-axion-ad.jl:8-46 ; P = M, a, β, b
-    template <class T>
-    GR_DEV void dilaton_axion(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void dilaton_axion(TR r, TT s, TT c, TG g[5]) const
     {
         const real M = P[0], a = P[1], be = P[2], b = P[3];
         const real R = M, a2 = a * a;
         const bool z = (be == 0.0);
         const real bb = z ? 0.0 : be * rcp_full(b), ba = z ? 0.0 : be * rcp_full(a), bab = z ? 0.0 : be * rcp_full(a * b);
-        T s2 = s * s;
-        T r2 = r * r;
-        T Sig = r2 + a2 * (c * c);
-        T Del = r2 + a2 - (2.0 * R) * r;
-        T bt = (2.0 * b) * r + be * be;
-        T Delh = Del - bt - (R * (R + 2.0 * b) * bb * bb);
-        T Sigh = Sig - bt + (R * R * bb) * (bb - (2.0 * a) * c);
-        T del = r2 - (2.0 * b) * r + a2;
-        T W = 1.0 + (bab * (2.0 * c - bab) + ba * ba) * inv_(s2);
-        T Was = W * (a * s);
-        T A = del * del - Delh * (Was * Was);
-        T iSigh = inv_(Sigh);
-        g[0] = -((Delh - a2 * s2) * iSigh);
-        g[1] = Sigh * inv_(Delh);
-        g[2] = Sigh;
-        g[3] = (A * s2) * iSigh;
-        g[4] = -((a * (del - Delh * W)) * (s2 * iSigh));
+        auto s2 = s * s;
+        auto r2 = r * r;
+        auto Sig = r2 + a2 * (c * c);
+        auto Del = r2 + a2 - (2.0 * R) * r;
+        auto bt = (2.0 * b) * r + be * be;
+        auto Delh = Del - bt - (R * (R + 2.0 * b) * bb * bb);
+        auto Sigh = Sig - bt + (R * R * bb) * (bb - (2.0 * a) * c);
+        auto del = r2 - (2.0 * b) * r + a2;
+        auto W = 1.0 + (bab * (2.0 * c - bab) + ba * ba) * inv_(s2);
+        auto Was = W * (a * s);
+        auto A = del * del - Delh * (Was * Was);
+        auto iSigh = inv_(Sigh);
+        dput(g[0], -((Delh - a2 * s2) * iSigh));
+        dput(g[1], Sigh * inv_(Delh));
+        dput(g[2], Sigh);
+        dput(g[3], (A * s2) * iSigh);
+        dput(g[4], -((a * (del - Delh * W)) * (s2 * iSigh)));
     }
 
     // SphericalMetric (flat space in spherical coordinates), minkowski.jl:4-13
-    template <class T>
-    GR_DEV void spherical(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void spherical(TR r, TT s, TT c, TG g[5]) const
     {
-        T r2 = r * r;
-        g[0] = (r - r) - 1.0;
-        g[1] = (r - r) + 1.0;
-        g[2] = r2;
-        g[3] = r2 * (s * s);
-        g[4] = r - r;
+        auto r2 = r * r;
+        dput(g[0], (r - r) - 1.0);
+        dput(g[1], (r - r) + 1.0);
+        dput(g[2], r2);
+        dput(g[3], r2 * (s * s));
+        dput(g[4], r - r);
         (void)c;
     }
     // __KerrDarkMatter.metric_components, kerr-dark-matter.jl:6-49 ; P = M_bh, a, M_dm, Δr, rₛ: Kerr with
     // the mass M_bh + M_dm G((r - rₛ)/Δr), G(x) = (3 - 2x) x², switched on between rₛ and rₛ + Δr
-    template <class T>
-    GR_DEV void kerr_dark_matter(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void kerr_dark_matter(TR r, TT s, TT c, TG g[5]) const
     {
         const real Mbh = P[0], a = P[1], Mdm = P[2], dR = P[3], rs = P[4];
         const real a2 = a * a;
         const real rv = val_(r);
-        T M = (r - r) + Mbh;
+        auto M = (r - r) + Mbh;
         if (rv >= rs + dR) {
             M = M + Mdm;
         } else if (rv >= rs) {
-            T dr = (r - rs) * rcp_full(dR);
+            auto dr = (r - rs) * rcp_full(dR);
             M = M + Mdm * ((3.0 - 2.0 * dr) * (dr * dr));
         }
-        T R = 2.0 * M;
-        T s2 = s * s;
-        T r2 = r * r;
-        T Sig = r2 + a2 * (1.0 - s2);
-        T iSig = inv_(Sig);
-        T Rr = R * r;
-        g[0] = -(1.0 - Rr * iSig);
-        g[1] = Sig * inv_(r2 + a2 - Rr);
-        g[2] = Sig;
-        g[3] = s2 * (r2 + a2 + (a2 * (s2 * Rr)) * iSig);
-        g[4] = -((a * (Rr * s2)) * iSig);
+        auto R = 2.0 * M;
+        auto s2 = s * s;
+        auto r2 = r * r;
+        auto Sig = r2 + a2 * (1.0 - s2);
+        auto iSig = inv_(Sig);
+        auto Rr = R * r;
+        dput(g[0], -(1.0 - Rr * iSig));
+        dput(g[1], Sig * inv_(r2 + a2 - Rr));
+        dput(g[2], Sig);
+        dput(g[3], s2 * (r2 + a2 + (a2 * (s2 * Rr)) * iSig));
+        dput(g[4], -((a * (Rr * s2)) * iSig));
         (void)c;
     }
     // __KerrRefractiveAD.metric_components, kerr-refractive-ad.jl:8-33 ; P = M, a, n, corona_radius: Kerr
     // with tt / n², tϕ / n inside the corona; the boundary is the smooth step of utils.jl:158-168
     // (δx = 2.5, atan(1e4 t)/π), whose gradient the rays must see
-    template <class T>
-    GR_DEV void kerr_refractive(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void kerr_refractive(TR r, TT s, TT c, TG g[5]) const
     {
         const real M = P[0], a = P[1], n0 = P[2], rc = P[3];
         const real a2 = a * a, R = 2.0 * M;
-        T r2 = r * r;
-        T Sig = r2 + a2 * (c * c);
-        T iSig = inv_(Sig);
-        T s2 = s * s;
-        T Rr = R * r;
+        auto r2 = r * r;
+        auto Sig = r2 + a2 * (c * c);
+        auto iSig = inv_(Sig);
+        auto s2 = s * s;
+        auto Rr = R * r;
         const real rv = val_(r);
-        T t = (r - r) + ((rv <= rc - 1.25) ? 1.0 : 0.0);
+        auto t = (r - r) + ((rv <= rc - 1.25) ? 1.0 : 0.0);
         if (rv > rc - 1.25 && rv <= rc + 1.25)
             t = 0.5 - 0.3183098861837907 * atan_(1e4 * ((r - rc) * 0.4));
-        T n = t + n0 * (1.0 - t);
-        T in = inv_(n);
-        g[0] = -(1.0 - Rr * iSig) * (in * in);
-        g[1] = Sig * inv_(r2 - Rr + a2);
-        g[2] = Sig;
-        g[3] = s2 * (r2 + a2 + (a2 * (s2 * Rr)) * iSig);
-        g[4] = -((a * (Rr * s2)) * iSig) * in;
+        auto n = t + n0 * (1.0 - t);
+        auto in = inv_(n);
+        dput(g[0], -(1.0 - Rr * iSig) * (in * in));
+        dput(g[1], Sig * inv_(r2 - Rr + a2));
+        dput(g[2], Sig);
+        dput(g[3], s2 * (r2 + a2 + (a2 * (s2 * Rr)) * iSig));
+        dput(g[4], -((a * (Rr * s2)) * iSig) * in);
     }
     // __NoZMetric.metric_components, noz-metric.jl:7-47 ; P = M, a, ϵ (y = cosθ; the θθ component carries
     // the dy² = sin²θ dθ² factor as written there)
-    template <class T>
-    GR_DEV void noz(T r, T s, T y, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void noz(TR r, TT s, TT y, TG g[5]) const
     {
         const real M = P[0], a = P[1], e = P[2];
         const real a2 = a * a;
-        T s2 = s * s;
-        T y2 = y * y;
-        T eps = (e * M * a) * y;
-        T r2 = r * r;
-        T a2y2 = a2 * y2;
-        T S = r2 + a2y2;
-        T tMr = (2.0 * M) * r;
-        T iD = inv_(S * S + (r2 - tMr + a2y2) * eps);
-        T Se = S + eps;
-        T omy2 = 1.0 - y2;
-        T big = r2 * r2 + (a2 * a2) * y2 + r2 * (a2 + a2y2 + eps) + a2 * eps + tMr * (a2 - a2y2 - eps);
-        g[0] = (tMr * S) * iD - 1.0;
-        g[1] = Se * inv_(r2 - tMr + a2);
-        g[2] = (Se * inv_(omy2)) * s2;
-        g[3] = ((omy2 * Se) * big) * iD;
-        g[4] = -(((a * tMr) * (omy2 * Se)) * iD);
+        auto s2 = s * s;
+        auto y2 = y * y;
+        auto eps = (e * M * a) * y;
+        auto r2 = r * r;
+        auto a2y2 = a2 * y2;
+        auto S = r2 + a2y2;
+        auto tMr = (2.0 * M) * r;
+        auto iD = inv_(S * S + (r2 - tMr + a2y2) * eps);
+        auto Se = S + eps;
+        auto omy2 = 1.0 - y2;
+        auto big = r2 * r2 + (a2 * a2) * y2 + r2 * (a2 + a2y2 + eps) + a2 * eps + tMr * (a2 - a2y2 - eps);
+        dput(g[0], (tMr * S) * iD - 1.0);
+        dput(g[1], Se * inv_(r2 - tMr + a2));
+        dput(g[2], (Se * inv_(omy2)) * s2);
+        dput(g[3], ((omy2 * Se) * big) * iD);
+        dput(g[4], -(((a * tMr) * (omy2 * Se)) * iD));
     }
 
-    template <class T>
-    GR_DEV void components(T r, T s, T c, T g[5]) const
+    template <class TR, class TT, class TG>
+    GR_DEV void components(TR r, TT s, TT c, TG g[5]) const
     {
-        if constexpr (ID == GR_METRIC_SPHERICAL) spherical<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_KERR_DARK_MATTER) kerr_dark_matter<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_KERR_REFRACTIVE) kerr_refractive<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_NOZ) noz<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_DILATON_AXION) dilaton_axion<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_MORRIS_THORNE) morris_thorne<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_BUMBLEBEE) bumblebee<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_JOHANNSEN_PSALTIS) johannsen_psaltis<T>(r, s, c, g);
-        else if constexpr (ID == GR_METRIC_JOHANNSEN) johannsen<T>(r, s, c, g);
+        if constexpr (ID == GR_METRIC_SPHERICAL) spherical(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_KERR_DARK_MATTER) kerr_dark_matter(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_KERR_REFRACTIVE) kerr_refractive(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_NOZ) noz(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_DILATON_AXION) dilaton_axion(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_MORRIS_THORNE) morris_thorne(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_BUMBLEBEE) bumblebee(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_JOHANNSEN_PSALTIS) johannsen_psaltis(r, s, c, g);
+        else if constexpr (ID == GR_METRIC_JOHANNSEN) johannsen(r, s, c, g);
         else {
             switch (id) {
-            case GR_METRIC_SPHERICAL: spherical<T>(r, s, c, g); break;
-            case GR_METRIC_KERR_DARK_MATTER: kerr_dark_matter<T>(r, s, c, g); break;
-            case GR_METRIC_KERR_REFRACTIVE: kerr_refractive<T>(r, s, c, g); break;
-            case GR_METRIC_NOZ: noz<T>(r, s, c, g); break;
-            case GR_METRIC_DILATON_AXION: dilaton_axion<T>(r, s, c, g); break;
-            case GR_METRIC_MORRIS_THORNE: morris_thorne<T>(r, s, c, g); break;
-            case GR_METRIC_BUMBLEBEE: bumblebee<T>(r, s, c, g); break;
-            case GR_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis<T>(r, s, c, g); break;
-            default: johannsen<T>(r, s, c, g); break;
+            case GR_METRIC_SPHERICAL: spherical(r, s, c, g); break;
+            case GR_METRIC_KERR_DARK_MATTER: kerr_dark_matter(r, s, c, g); break;
+            case GR_METRIC_KERR_REFRACTIVE: kerr_refractive(r, s, c, g); break;
+            case GR_METRIC_NOZ: noz(r, s, c, g); break;
+            case GR_METRIC_DILATON_AXION: dilaton_axion(r, s, c, g); break;
+            case GR_METRIC_MORRIS_THORNE: morris_thorne(r, s, c, g); break;
+            case GR_METRIC_BUMBLEBEE: bumblebee(r, s, c, g); break;
+            case GR_METRIC_JOHANNSEN_PSALTIS: johannsen_psaltis(r, s, c, g); break;
+            default: johannsen(r, s, c, g); break;
             }
         }
     }
 
-    GR_DEV void comps(real r, real s, real c, real g[5]) const { components<real>(r, s, c, g); }
+    GR_DEV void comps(real r, real s, real c, real g[5]) const { components(r, s, c, g); }
 
     // Johannsen-Psaltis: the whole right-hand side in one pass instead of dual numbers + the generic contraction (the
     // form KerrFamily::rhs and JohannsenMetric::rhs take).  With w = 2Mr/Σ, h = ϵ3 M³ r/Σ², H = 1 + h, η = hΣ:
@@ -1323,8 +1351,8 @@ struct GenericMetricT {
     GR_DEV void eval(real r, real s, real c, real g[5], real gr[5], real gt[5], real gi[5]) const
     {
         Dual2 gd[5];
-        // seeds: r = (r;1,0), sinθ = (s;0,c), cosθ = (c;0,-s)
-        components<Dual2>(Dual2{ r, 1.0, 0.0 }, Dual2{ s, 0.0, c }, Dual2{ c, 0.0, -s }, gd);
+        // seeds: r = (r;1,·), sinθ = (s;·,c), cosθ = (c;·,-s)
+        components(DualR{ r, 1.0, 0.0 }, DualT{ s, 0.0, c }, DualT{ c, 0.0, -s }, gd);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             g[i] = gd[i].v;

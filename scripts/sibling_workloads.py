@@ -7,6 +7,7 @@ PROF_CMD="scripts/sibling_workloads.py <which>" PROF_KERNEL=<substring of the ke
     dual      BumblebeeMetric(a=0.25, l=0.5) 1024², ThinDisc, shadow -- a TRUE dual-number metric          k_trace_lane<GenericMetricT<3>,1>
     dual2     MorrisThorneWormhole(b=1) 1024², ThinDisc, shadow (hand-fused since round 4)                k_trace_lane<GenericMetricT<2>,1>
     dual6     DilatonAxion(a=0.5, β=0.3, b=1) 1024², ThinDisc, shadow -- the heaviest dual-number metric k_trace_lane<GenericMetricT<6>,1>
+    dual8 / dual9 / dual10   KerrDarkMatter(a=0.5, 2, 20, 10) / KerrRefractive(a=0.5, n=1.1, 20) / NoZMetric(a=0.5, ϵ=0.5), ThinDisc(6, 50), shadow
     c5        BASELINE config 5 line profile, 4096² polar-plane rays, fp64 tol 1e-9                  k_trace_lane<KerrFamily<false>,1> (tiled rays)
     c5p       the same through the persistent kernel                                                  k_trace_persistent<...>
     c5f32     config 5 with the fp32 kernels at tol 1e-5                                              gr32::k_trace_*
@@ -35,7 +36,7 @@ ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
 ms = []
 extra = {}
 
-if which in ("c4", "generic", "dual", "dual6", "dual2"):
+if which in ("c4", "generic", "dual", "dual6", "dual2", "dual8", "dual9", "dual10"):
     if which == "dual2":
         m = G.MorrisThorneWormhole(1.0)
         x = np.array([0.0, 1000.0, math.radians(70), 0.0])
@@ -48,6 +49,11 @@ if which in ("c4", "generic", "dual", "dual6", "dual2"):
         m = G.DilatonAxion(1.0, 0.5, 0.3, 1.0)
         x = np.array([0.0, 1000.0, math.radians(70), 0.0])
         pf = G.ConstPointFunctions.shadow()
+    elif which in ("dual8", "dual9", "dual10"):
+        m = {"dual8": G.KerrDarkMatter(1.0, 0.5, 2.0, 20.0, 10.0), "dual9": G.KerrRefractive(1.0, 0.5, 1.1, 20.0),
+             "dual10": G.NoZMetric(1.0, 0.5, 0.5)}[which]
+        x = np.array([0.0, 1000.0, math.radians(70), 0.0])
+        pf = G.ConstPointFunctions.shadow()
     elif which == "c4":
         m = G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0)
         x = np.array([0.0, 1000.0, math.radians(70), 0.0])
@@ -58,7 +64,8 @@ if which in ("c4", "generic", "dual", "dual6", "dual2"):
         pf = G.ConstPointFunctions.shadow()
     S = int(os.environ.get("SIB_SIZE", "1024"))          # (2048: a launch deep enough that its tail does not decide)
     for _ in range(reps):
-        disc = G.ThinDisc(5.0, 50.0) if which == "dual2" else G.ThinDisc(m.isco(), 50.0)        # (a wormhole has no ISCO)
+        disc = (G.ThinDisc(5.0, 50.0) if which == "dual2" else G.ThinDisc(6.0, 50.0) if which in ("dual8", "dual9", "dual10")
+                else G.ThinDisc(m.isco(), 50.0))        # (a wormhole has no ISCO; the last three: no isco() on this side)
         _, _, img, st = G.rendergeodesics(m, x, disc, 2000.0, image_width=S, image_height=S,
                                           alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens, stats=True)
         ms.append(st["kernel_ms"])
