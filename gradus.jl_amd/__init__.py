@@ -14,7 +14,8 @@ from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGe
                      RandomGenerator, WeierstrassSampler, coordtime_at, emissivity_at, emissivity_profile,
                      energy_ratio, lorentz_factor, sky_angles_to_velocity, tetradframe_matrix, tracecorona)
 from .distributed import gather_buffers, gather_image, gather_image_async, gather_points, shard_plan
-from .geometry import CompositeGeometry, DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev, ThickDisc, ThinDisc, WarpedThinDisc
+from .geometry import (CompositeGeometry, DatumPlane, EllipticalDisc, MeshAccretionGeometry, PrecessingDisc, ShakuraSunyaev, ThickDisc,
+                       ThinDisc, WarpedThinDisc, bounding_box)
 from .polish_doughnut import PolishDoughnut
 from .lineprofiles import BinningMethod, PowerLawEmissivity, TransferFunctionMethod, bucket_simple, lineprofile
 from .metrics import (BumblebeeMetric, DilatonAxion, JohannsenMetric, JohannsenPsaltisMetric, KerrDarkMatter, KerrMetric,

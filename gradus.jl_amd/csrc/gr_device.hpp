@@ -84,6 +84,13 @@ typedef double gr_real_t;
 #ifndef GR_PARK_DEFAULT
 #define GR_PARK_DEFAULT 0
 #endif
+// MeshAccretionGeometry (GR_DISC_MESH) exists in the fp64 kernels only (and in the host harness); the fp32 and tangent flavours
+// do not instantiate it and the host unit refuses the combination
+#if defined(GR_REAL_IS_TAN2) || defined(GR_REAL_IS_FLOAT)
+#define GR_HAS_MESH 0
+#else
+#define GR_HAS_MESH 1
+#endif
 
 #ifdef GR_HOST_HARNESS
 // tests/host_harness.cpp compiles this header with g++ to trace single rays on the CPU next to
@@ -1928,6 +1935,114 @@ struct Ray {
     mutable int dbg_bits;   // per attempted step: bit s = stage s took the full sincos; 8 = event sampling past the reach bound; 9 = past the θ samples
 #endif
 
+    // a geometry with a ContinuousCallback (distance_to_disc); a mesh is a DiscreteCallback on the step's line element instead
+    static constexpr bool kContinuous = (DISC != GR_DISC_NONE && DISC != GR_DISC_MESH);
+
+#if GR_HAS_MESH
+    // ---- MeshAccretionGeometry (geometry/meshes.jl:1-80): after every accepted step the Cartesian line element
+    // (to_cartesian(u_prev), to_cartesian(u)) (geometry.jl:13-16,38-40) is tested against the triangles -- intersects_geometry
+    // (intersections.jl:7-16) = in_nearby_region && has_intersect; the ray ends AT the step's end (no root finding) with
+    // IntersectedWithGeometry.  The triangles sit in HBM behind p.disc_table, sorted into a uniform grid (gr_mesh_grid.hpp).
+    static GR_DEV void to_cartesian3(real r, real s, real c, real ph, real q[3])
+    {
+        real sp, cp;
+        sincos_fast(ph, sp, cp);
+        const real rs = r * s;
+        q[0] = rs * cp;
+        q[1] = rs * sp;
+        q[2] = r * c;
+    }
+    static GR_DEV void cross3(const real a[3], const real b[3], real o[3])
+    {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = a[2] * b[0] - a[0] * b[2];
+        o[2] = a[0] * b[1] - a[1] * b[0];
+    }
+    static GR_DEV real dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+    // jsf_algorithm (intersections.jl:58-101; Jiménez, Segura & Feito 2010), ϵ = 1e-8: does the segment Q1 -> Q2 pass through the
+    // triangle from its front side (w > 0: Q1 in front of the plane, Q2 not); a segment that starts behind the plane never hits
+    static GR_DEV bool jsf_hit(const real V1[3], const real V2[3], const real V3[3], const real Q1[3], const real Q2[3])
+    {
+        const real eps = 1e-8;
+        real A[3], B[3], C[3], D[3], W1[3], W2[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { A[i] = Q1[i] - V3[i]; B[i] = V1[i] - V3[i]; C[i] = V2[i] - V3[i]; D[i] = Q2[i] - V3[i]; }
+        cross3(B, C, W1);
+        const real w = dot3(A, W1);
+        if (w > eps) {
+            const real sg = dot3(D, W1);
+            if (sg > eps) return false;
+            cross3(A, D, W2);
+            const real tt = dot3(W2, C);
+            if (tt < -eps) return false;
+            const real uu = -dot3(W2, B);
+            if (uu < -eps) return false;
+            if (w < sg + tt + uu) return false;
+            return true;
+        } else if (w < -eps) {
+            return false;
+        }
+        const real sg = dot3(D, W1);       // Q1 in the triangle's plane
+        if (sg > eps) return false;
+        if (sg < -eps) {
+            cross3(D, A, W2);
+            const real tt = dot3(W2, C);
+            if (tt > eps) return false;
+            const real uu = -dot3(W2, B);
+            if (uu > eps) return false;
+            if (-sg > tt + uu) return false;
+            return true;
+        }
+        return false;
+    }
+    // p.disc_table: the table gr_mesh_grid.hpp builds -- the bounding box, a uniform grid over the triangles' first vertices
+    // with cells of (just over) 3, the triangles sorted by cell
+    static GR_DEV bool mesh_hit(const Params& p, real r0, real s0, real c0, real ph0, real r1, real s1, real c1, real ph1)
+    {
+        const double* tb = p.disc_table;
+        real Q2[3];
+        to_cartesian3(r1, s1, c1, ph1, Q2);
+        // in_nearby_region (meshes.jl:46-51): the step's END strictly inside the bounding box
+        if (!((real)tb[0] < Q2[0] && Q2[0] < (real)tb[1] && (real)tb[2] < Q2[1] && Q2[1] < (real)tb[3] && (real)tb[4] < Q2[2] && Q2[2] < (real)tb[5]))
+            return false;
+        real Q1[3];
+        to_cartesian3(r0, s0, c0, ph0, Q1);
+        // has_intersect (meshes.jl:53-64): the triangles whose FIRST vertex is within 3 of the step's end.  They sit in the
+        // point's grid cell or one of its 26 neighbours; per (y, z) neighbour the three x-cells are one run of triangles
+        const real icell = (real)tb[9];
+        const int nx = (int)tb[10], ny = (int)tb[11], nz = (int)tb[12];
+        const uint32_t* cs = reinterpret_cast<const uint32_t*>(tb + 16);
+        const double* T0 = tb + (int64_t)tb[13];
+        int lo[3], hi[3];
+        const int dim[3] = { nx, ny, nz };
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            real f = GR_FLOOR((Q2[a] - (real)tb[6 + a]) * icell);
+            f = GR_FMAX((real)-2.0, GR_FMIN(f, (real)dim[a] + (real)1.0));        // (the box may reach beyond the grid of first vertices)
+            const int i = (int)f;
+            lo[a] = i - 1 < 0 ? 0 : i - 1;
+            hi[a] = i + 1 > dim[a] - 1 ? dim[a] - 1 : i + 1;
+        }
+        if (hi[0] < lo[0]) return false;
+        for (int iz = lo[2]; iz <= hi[2]; ++iz)
+            for (int iy = lo[1]; iy <= hi[1]; ++iy) {
+                const int64_t row = ((int64_t)iz * ny + iy) * nx;
+                const uint32_t k1 = cs[row + hi[0] + 1];
+                for (uint32_t k = cs[row + lo[0]]; k < k1; ++k) {
+                    const double* T = T0 + 9 * (int64_t)k;
+                    const real V1[3] = { (real)T[0], (real)T[1], (real)T[2] };
+                    const real dx = V1[0] - Q2[0], dy = V1[1] - Q2[1], dz = V1[2] - Q2[2];
+                    if (dx * dx + dy * dy + dz * dz < 9.0) {
+                        const real V2[3] = { (real)T[3], (real)T[4], (real)T[5] };
+                        const real V3[3] = { (real)T[6], (real)T[7], (real)T[8] };
+                        if (jsf_hit(V1, V2, V3, Q1, Q2)) return true;
+                    }
+                }
+            }
+        return false;
+    }
+#endif
+
     // distance_to_disc(::DatumPlane), datum-plane.jl:6-10 ; distance_to_disc(::ThinDisc), thin-disc.jl:20-26 ; distance_to_disc(::AbstractThickAccretionDisc),
     // thick-disc.jl:60-66 with cross_section(::ShakuraSunyaev), shakura-sunyaev.jl:28-33
     GR_DEV real disc_cond(const Params& p, real r, real s, real c) const
@@ -2247,7 +2362,7 @@ struct Ray {
             const Cold& cd = cold_of(p);
             hdat = (cd.src_mode == 2 && cd.height) ? (real)cd.height[jl] : (real)p.cfg.disc_params[0];
         }
-        cprev = DISC ? disc_cond4(p, x[1], s, c, x[3]) : 1.0;
+        cprev = kContinuous ? disc_cond4(p, x[1], s, c, x[3]) : 1.0;
         ev_mask = 0;
         if constexpr (DISC == GR_DISC_COMPOSITE) {
 #pragma unroll
@@ -2607,7 +2722,7 @@ struct Ray {
 #pragma unroll
                 for (int k = 0; k < GR_COMP_MAX; ++k)
                     if (k < K) comp_prev(k) = cnx[k];
-            } else if (DISC) {
+            } else if (kContinuous) {
                 const real cnext = disc_cond4(p, xn[1], sn, cn, xn[3]);
                 // prev = sign(c(u_prev)), event at the step's end iff prev != 0 and prev * sign(c(u_new)) <= 0 (a NaN
                 // condition has sign 0 and counts as a crossing): four comparisons, no integer sign arithmetic
@@ -2656,7 +2771,15 @@ struct Ray {
                 }
                 cprev = cnext;
             }
-            const bool term = discrete_cb(p, xn[1], xn[2], cn, status, flags);
+            // the discrete callbacks in CallbackSet order (callbacks.jl:19-38, bootstrap.jl:11-21): the geometry's, the user's,
+            // the chart's -- each one whose condition holds applies its affect!, so a later one's status stands [3P]
+            bool term = false;
+#if GR_HAS_MESH
+            if constexpr (DISC == GR_DISC_MESH) {
+                if (mesh_hit(p, x[1], sth, cth, x[3], xn[1], sn, cn, xn[3])) { status = GR_STATUS_INTERSECTED_WITH_GEOMETRY; term = true; }
+            }
+#endif
+            term |= discrete_cb(p, xn[1], xn[2], cn, status, flags);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[i] = xn[i]; v[i] = vn[i]; A[0][i] = A[6][i]; }
             sth = sn; cth = cn;
@@ -2932,7 +3055,7 @@ struct Ray {
     template <class Cold_>
     GR_DEV void finalize(const Metric& m, const Params& p, const LdsView& lds, const Cold_& cs)
     {
-        if (DISC && (flags & RAY_EVENT)) {
+        if (kContinuous && (flags & RAY_EVENT)) {
             if constexpr (Cold_::kParkA > 0) {
                 // the event step's accelerations of stages 1..kParkA are still where step() parked them
                 Cold_::park_fence();

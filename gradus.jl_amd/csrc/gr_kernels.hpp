@@ -226,7 +226,7 @@ __device__ __forceinline__ unsigned xcd_chunk(unsigned b)
 template <class Metric, int DISC>
 #ifndef GR_LANE_MIN_WAVES
 // (a composite geometry samples several conditions on every step: two waves per SIMD at most, no spills on its main path)
-#define GR_LANE_MIN_WAVES (DISC == GR_DISC_COMPOSITE && Metric::kLaneWavesPerSimd > 2 ? 2 : Metric::kLaneWavesPerSimd)
+#define GR_LANE_MIN_WAVES ((DISC == GR_DISC_COMPOSITE || DISC == GR_DISC_MESH) && Metric::kLaneWavesPerSimd > 2 ? 2 : Metric::kLaneWavesPerSimd)
 #endif
 __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Params p)
 {
@@ -464,6 +464,9 @@ hipError_t launch_metric(const LaunchKnobs& k, Params& p, hipStream_t stream)
     case GR_DISC_ELLIPTICAL: return launch_tmpl<Metric, GR_DISC_ELLIPTICAL>(k, p, stream);
     case GR_DISC_PRECESSING_THIN: return launch_tmpl<Metric, GR_DISC_PRECESSING_THIN>(k, p, stream);
     case GR_DISC_COMPOSITE: return launch_tmpl<Metric, GR_DISC_COMPOSITE>(k, p, stream);
+#if GR_HAS_MESH
+    case GR_DISC_MESH: return launch_tmpl<Metric, GR_DISC_MESH>(k, p, stream);
+#endif
     default: return launch_tmpl<Metric, GR_DISC_NONE>(k, p, stream);
     }
 }
@@ -481,6 +484,9 @@ hipError_t launch_path_metric(const Params& p, double* d_path, int64_t cap, unsi
     case GR_DISC_ELLIPTICAL: GR_PATH_LAUNCH(GR_DISC_ELLIPTICAL); break;
     case GR_DISC_PRECESSING_THIN: GR_PATH_LAUNCH(GR_DISC_PRECESSING_THIN); break;
     case GR_DISC_COMPOSITE: GR_PATH_LAUNCH(GR_DISC_COMPOSITE); break;
+#if GR_HAS_MESH
+    case GR_DISC_MESH: GR_PATH_LAUNCH(GR_DISC_MESH); break;
+#endif
     default: GR_PATH_LAUNCH(GR_DISC_NONE); break;
     }
 #undef GR_PATH_LAUNCH

@@ -26,6 +26,7 @@
 
 #define GR_NS gr
 #include "gr_device.hpp"
+#include "gr_mesh_grid.hpp"
 
 using namespace gr;
 
@@ -96,6 +97,11 @@ struct gr_ctx {
     unsigned long long* d_stats = nullptr; // for host-buffer entry points
     double* d_disc_table = nullptr;        // device copy of a tabulated disc profile
     size_t disc_table_bytes = 0;
+    double* d_mesh = nullptr;              // GR_DISC_MESH: the grid-sorted triangle table (gr_mesh_grid.hpp), kept while the
+    size_t mesh_bytes = 0;                 //   caller passes the same mesh (fingerprint of its table)
+    uint64_t mesh_fp = 0;
+    int64_t mesh_n = -1;
+    std::vector<double> mesh_host;
     double* d_chart_table = nullptr;       // device copy of a PoloidalShapeChart table
     size_t chart_table_bytes = 0;
     Cold* d_cold = nullptr;                // ring of per-launch cold blocks
@@ -185,7 +191,7 @@ int32_t validate_cfg(const gr_config* cfg)
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
     if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_NOZ)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
-    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_COMPOSITE)
+    if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_MESH)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
     if (cfg->disc_id == GR_DISC_COMPOSITE) {
         if (cfg->comp_n < 2 || cfg->comp_n > GR_COMP_MAX)
@@ -206,6 +212,8 @@ int32_t validate_cfg(const gr_config* cfg)
     if (cfg->maxiters <= 0) return fail(GR_ERR_INVALID_ARGUMENT, "maxiters must be positive");
     if (cfg->disc_id == GR_DISC_TABULATED && (!cfg->disc_table || cfg->disc_table_n < 2 || !(cfg->disc_params[1] > cfg->disc_params[0])))
         return fail(GR_ERR_INVALID_ARGUMENT, "tabulated disc needs >= 2 samples on an increasing ρ grid");
+    if (cfg->disc_id == GR_DISC_MESH && (!cfg->disc_table || cfg->disc_table_n < 1 || cfg->disc_table_n > (int64_t)1 << 24))
+        return fail(GR_ERR_INVALID_ARGUMENT, "a mesh geometry needs its bounding box and 1 .. 2^24 triangles in disc_table");
     if (cfg->chart_table_n < 0 || cfg->chart_table_n == 1 || (cfg->chart_table_n > 1 && (!cfg->chart_table || !(cfg->chart_theta1 > cfg->chart_theta0))))
         return fail(GR_ERR_INVALID_ARGUMENT, "chart table needs >= 2 samples on an increasing θ grid");
     if (cfg->disc_id == GR_DISC_THIN && !(cfg->disc_r_out >= cfg->disc_r_in))
@@ -238,7 +246,7 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 {
     p.chart_table = nullptr;
     p.cfg.upper_hemisphere = p.cfg.upper_hemisphere ? 1 : 0;
-    if (p.cfg.chart_table_n > 1 || p.cfg.disc_id == GR_DISC_TABULATED) {
+    if (p.cfg.chart_table_n > 1 || p.cfg.disc_id == GR_DISC_TABULATED || p.cfg.disc_id == GR_DISC_MESH) {
         const int32_t arc = tables_acquire(ctx, stream);
         if (arc != GR_OK) return arc;
     }
@@ -252,6 +260,23 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
     }
     if (p.cfg.count_windings) p.cfg.upper_hemisphere |= 4;     // TraceWindings: bit 2
     p.disc_table = nullptr;
+    if (p.cfg.disc_id == GR_DISC_MESH) {
+        // the caller's triangles -> the grid-sorted table the kernels walk; rebuilt only when the mesh changes
+        const int64_t n = p.cfg.disc_table_n;
+        const uint64_t fp = gr_mesh::fingerprint(p.cfg.disc_table, n);
+        if (ctx->mesh_n != n || ctx->mesh_fp != fp || !ctx->d_mesh) {
+            gr_mesh::build_table(p.cfg.disc_table, n, ctx->mesh_host);
+            const size_t mb = sizeof(double) * ctx->mesh_host.size();
+            ctx->mesh_n = -1;
+            const int32_t mrc = ensure((void**)&ctx->d_mesh, &ctx->mesh_bytes, mb);
+            if (mrc != GR_OK) return mrc;
+            GR_HIP(hipMemcpyAsync(ctx->d_mesh, ctx->mesh_host.data(), mb, hipMemcpyHostToDevice, stream));
+            ctx->mesh_n = n;
+            ctx->mesh_fp = fp;
+        }
+        p.disc_table = ctx->d_mesh;
+        return GR_OK;
+    }
     if (p.cfg.disc_id != GR_DISC_TABULATED) return GR_OK;
     const size_t tb = sizeof(double) * (size_t)p.cfg.disc_table_n;
     int32_t rc = ensure((void**)&ctx->d_disc_table, &ctx->disc_table_bytes, tb);
@@ -379,6 +404,8 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     p.refill_threshold = (int32_t)ctx->refill_threshold;
     // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
     const bool tangent = cold.out_mode == 5;
+    if (p.cfg.disc_id == GR_DISC_MESH && (tangent || ctx->precision == 32))
+        return fail(GR_ERR_UNSUPPORTED, "a mesh geometry is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
     const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold);
     const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
@@ -570,6 +597,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_disc_table) (void)hipFree(c->d_disc_table);
+    if (c->d_mesh) (void)hipFree(c->d_mesh);
     if (c->d_chart_table) (void)hipFree(c->d_chart_table);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);

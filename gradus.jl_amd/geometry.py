@@ -6,7 +6,7 @@ from dataclasses import dataclass
 import numpy as np
 
 GR_DISC_NONE, GR_DISC_THIN, GR_DISC_SHAKURA_SUNYAEV, GR_DISC_TABULATED, GR_DISC_DATUM = 0, 1, 2, 3, 4
-GR_DISC_ELLIPTICAL, GR_DISC_PRECESSING_THIN, GR_DISC_COMPOSITE = 5, 6, 7
+GR_DISC_ELLIPTICAL, GR_DISC_PRECESSING_THIN, GR_DISC_COMPOSITE, GR_DISC_MESH = 5, 6, 7, 8
 
 
 class AbstractAccretionGeometry:
@@ -151,3 +151,37 @@ class CompositeGeometry(AbstractAccretionGeometry):
     @property
     def inner_radius(self):
         return min(getattr(g, "inner_radius", 0.0) for g in self.geometry)
+
+
+def bounding_box(mesh):
+    """bounding_box(mesh) -- src/geometry/meshes.jl:24-44: ((x_min, x_max), (y_min, y_max), (z_min, z_max)) over every vertex."""
+    pts = np.asarray(mesh, dtype=np.float64).reshape(-1, 3)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    return (float(lo[0]), float(hi[0])), (float(lo[1]), float(hi[1])), (float(lo[2]), float(hi[2]))
+
+
+class MeshAccretionGeometry(AbstractAccretionGeometry):
+    """MeshAccretionGeometry(mesh) -- src/geometry/meshes.jl:1-80.  `mesh`: triangles as an (n, 3, 3) array (or any nesting
+    of n triangles x 3 vertices x (x, y, z)) in the Cartesian coordinates (r sinθ cosϕ, r sinθ sinϕ, r cosθ) of geometry.jl:13-16.
+    Fields as in the reference: `mesh`, `x_extent`, `y_extent`, `z_extent` (the bounding box of the constructor; pass your own
+    extents to narrow the region in which the triangles are tested at all).  A DiscreteCallback: after every accepted step the
+    segment from the previous position to the new one is tested with the Jiménez-Segura-Feito algorithm (intersections.jl:58-101)
+    against the triangles whose first vertex is within 3 of the new position; the ray ends at the step's end, front faces only.
+    On the device the triangle list is walked once per wave and accepted step inside the box (fp64 kernels only)."""
+
+    disc_id = GR_DISC_MESH
+
+    def __init__(self, mesh, x_extent=None, y_extent=None, z_extent=None):
+        tri = np.ascontiguousarray(mesh, dtype=np.float64).reshape(-1, 3, 3)
+        if tri.shape[0] < 1:
+            raise ValueError("a mesh needs at least one triangle")
+        self.mesh = tri
+        bx, by, bz = bounding_box(tri)
+        self.x_extent = tuple(map(float, x_extent)) if x_extent is not None else bx
+        self.y_extent = tuple(map(float, y_extent)) if y_extent is not None else by
+        self.z_extent = tuple(map(float, z_extent)) if z_extent is not None else bz
+        # what crosses the ABI (gr_config.disc_table): the six extents, then 9 doubles per triangle
+        self.table = np.ascontiguousarray(np.concatenate([[*self.x_extent, *self.y_extent, *self.z_extent], tri.ravel()]), dtype=np.float64)
+
+    def __len__(self):
+        return self.mesh.shape[0]

@@ -17,8 +17,8 @@ import os
 import numpy as np
 
 from . import _lib
-from .geometry import (GR_DISC_NONE, AbstractAccretionGeometry, CompositeGeometry, DatumPlane, EllipticalDisc, PrecessingDisc, ShakuraSunyaev,
-                       ThickDisc, ThinDisc, WarpedThinDisc)
+from .geometry import (GR_DISC_NONE, AbstractAccretionGeometry, CompositeGeometry, DatumPlane, EllipticalDisc, MeshAccretionGeometry,
+                       PrecessingDisc, ShakuraSunyaev, ThickDisc, ThinDisc, WarpedThinDisc)
 from .metrics import AbstractMetric
 from .orthonormalization import lnrbasis
 
@@ -350,6 +350,10 @@ class TracingConfiguration:
             c.disc_params[0], c.disc_params[1] = g.ρ_range[0], g.ρ_range[1]
             c.disc_params[2], c.disc_params[3] = float(np.abs(g.table).max()), 1.0
             c.disc_table, c.disc_table_n = g.table.ctypes.data, g.table.size     # g keeps the array alive
+        elif isinstance(self.geometry, MeshAccretionGeometry):
+            g = self.geometry
+            c.disc_id = g.disc_id
+            c.disc_table, c.disc_table_n = g.table.ctypes.data, len(g)            # g keeps the array alive
         elif isinstance(self.geometry, ThickDisc):
             g = self.geometry
             c.disc_id = g.disc_id

@@ -92,9 +92,19 @@ enum {
  *   COMPOSITE        CompositeGeometry(d1, d2, ...) = d1 ∘ d2  src/geometry/composite.jl:1-26, the VectorContinuousCallback of
  *                    src/geometry/bootstrap.jl:76-110: comp_n (2..GR_COMP_MAX) components in gr_config.comp[], each a THIN,
  *                    SHAKURA_SUNYAEV, ELLIPTICAL or DATUM geometry with its own radii and parameters (gtol is shared, as in the
- *                    reference); the ray ends at the EARLIEST intersection with any of them */
+ *                    reference); the ray ends at the EARLIEST intersection with any of them
+ *   MESH             MeshAccretionGeometry(mesh)  src/geometry/meshes.jl:1-80: a triangle mesh in Cartesian coordinates
+ *                    (x, y, z) = (r sinθ cosϕ, r sinθ sinϕ, r cosθ), tested with a DiscreteCallback: after every accepted step the
+ *                    segment from the previous to the new position is tested (jsf_algorithm, src/geometry/intersections.jl:58-101,
+ *                    ϵ = 1e-8, front faces only) against the triangles whose first vertex lies within 3 of the new position, when
+ *                    the new position is strictly inside the bounding box; the ray ends AT the step's end (no root finding) with
+ *                    IntersectedWithGeometry.  disc_table = x_min, x_max, y_min, y_max, z_min, z_max (the x/y/z_extent fields of
+ *                    the reference's struct), then 9 doubles V1 V2 V3 per triangle; disc_table_n = number of triangles (>= 1);
+ *                    gtol and the other disc fields are not read.  fp64 only: GR_ERR_UNSUPPORTED with "precision" 32 and in
+ *                    the tangent entry points (gr_ray_tangent*).  Cost per accepted step inside the box: one pass over the
+ *                    triangle list per wave (the reference's "naive implementation" loop, meshes.jl:53-64) */
 enum { GR_DISC_NONE = 0, GR_DISC_THIN = 1, GR_DISC_SHAKURA_SUNYAEV = 2, GR_DISC_TABULATED = 3, GR_DISC_DATUM = 4,
-       GR_DISC_ELLIPTICAL = 5, GR_DISC_PRECESSING_THIN = 6, GR_DISC_COMPOSITE = 7 };
+       GR_DISC_ELLIPTICAL = 5, GR_DISC_PRECESSING_THIN = 6, GR_DISC_COMPOSITE = 7, GR_DISC_MESH = 8 };
 #define GR_COMP_MAX 4
 
 /* one component of a GR_DISC_COMPOSITE geometry: the fields of gr_config with the same names, per component */
@@ -129,8 +139,8 @@ typedef struct gr_config {
     int32_t _pad;
     double hemi_delta;        /* its δ, default 1e-4                                     */
     double disc_params[4];    /* extra geometry parameters, see GR_DISC_*                */
-    const double* disc_table; /* GR_DISC_TABULATED: HOST pointer in every entry point    */
-    int64_t disc_table_n;     /*   (copied into the context); NULL / 0 otherwise         */
+    const double* disc_table; /* GR_DISC_TABULATED (disc_table_n samples) / GR_DISC_MESH (6 + 9 disc_table_n doubles): HOST */
+    int64_t disc_table_n;     /*   pointer in every entry point (copied into the context); NULL / 0 otherwise            */
     /* PoloidalShapeChart (charts.jl:26-48, event_horizon_chart :61-70): inner boundary r_min(θ),
      * chart_table[k] = r_min(θ_k) on the uniform grid θ_k = chart_theta0 + k (chart_theta1 -
      * chart_theta0)/(n-1), already scaled by closest_approach; linear interpolation (end intervals

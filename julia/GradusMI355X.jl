@@ -222,6 +222,8 @@ _disc(d::PrecessingDisc{T,<:ThinDisc}) where {T} =
     (Int32(6), Float64(d.disc.inner_radius), Float64(d.disc.outer_radius), (Float64(d.β), Float64(d.γ), cos(d.β), sin(d.β)))
 # CompositeGeometry(d1, d2, ...) = d1 ∘ d2 (geometry/composite.jl): the components cross as gr_config.comp[]
 _disc(d::Gradus.CompositeGeometry) = (Int32(7), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
+# MeshAccretionGeometry (src/geometry/meshes.jl:1-22): the triangles and the bounding box travel in the disc table
+_disc(d::Gradus.MeshAccretionGeometry) = (Int32(8), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
 _disc(d) = throw(UnsupportedOnDevice("geometry $(typeof(d)) has no device implementation"))
 
 # (comp_n, comp[4]) of gr_config
@@ -268,6 +270,18 @@ end
 _disc(d::SampledThickDisc) = (Int32(3), 0.0, Inf, (d.ρ_min, d.ρ_max, maximum(d.table), 0.0))
 _disc_table(d) = Float64[]
 _disc_table(d::SampledThickDisc) = d.table
+# GR_DISC_MESH: x_extent, y_extent, z_extent (meshes.jl:5-7), then V1 V2 V3 of every triangle (9 doubles)
+function _disc_table(d::Gradus.MeshAccretionGeometry)
+    tab = Float64[d.x_extent[1], d.x_extent[2], d.y_extent[1], d.y_extent[2], d.z_extent[1], d.z_extent[2]]
+    sizehint!(tab, 6 + 9 * length(d.mesh))
+    for tri in d.mesh, vert in tri, c in vert
+        push!(tab, Float64(c))
+    end
+    tab
+end
+# gr_config.disc_table_n: samples of a tabulated profile, TRIANGLES of a mesh
+_disc_table_n(d, dtab) = length(dtab)
+_disc_table_n(d::Gradus.MeshAccretionGeometry, dtab) = length(d.mesh)
 
 # chart -> (r_inner, r_outer, table, θ_first, θ_last).  A PoloidalShapeChart built by
 # event_horizon_chart wraps LinearInterpolation(r_min(θ_k), θ_k) on a uniform θ range (charts.jl:61-70).
@@ -339,13 +353,17 @@ function _callbacks(config::TracingConfiguration)
     end
     for c in discs
         cond = c.condition
-        if occursin("_domain_upper_hemisphere_check", _closure_name(cond)) && hasproperty(cond, :δ)
+        if !seen_geometry && config.geometry isa Gradus.MeshAccretionGeometry && hasproperty(cond, :g) && cond.g === config.geometry
+            # geometry_collision_callback(::MeshAccretionGeometry) (meshes.jl:67-78): a DiscreteCallback whose condition closes
+            # over the mesh `g`; the device tests the same line element itself (GR_DISC_MESH)
+            seen_geometry = true
+        elseif occursin("_domain_upper_hemisphere_check", _closure_name(cond)) && hasproperty(cond, :δ)
             δ = Float64(cond.δ)
         else
             throw(UnsupportedOnDevice("a user DiscreteCallback ($(_closure_name(cond))); only domain_upper_hemisphere runs on the device"))
         end
     end
-    !isnothing(config.geometry) && config.geometry isa Union{Gradus.AbstractAccretionDisc,Gradus.CompositeGeometry} && !seen_geometry &&
+    !isnothing(config.geometry) && config.geometry isa Union{Gradus.AbstractAccretionDisc,Gradus.CompositeGeometry,Gradus.MeshAccretionGeometry} && !seen_geometry &&
         throw(UnsupportedOnDevice("the geometry's collision callback was not found in config.callback"))
     (gtol, δ)
 end
@@ -383,7 +401,7 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; maxiters = 
         Float64(config.λ_domain[1]), Float64(config.λ_domain[2]), Float64(config.abstol), Float64(config.reltol),
         Float64(trace.μ), maxiters,
         isnothing(δ) ? Int32(0) : Int32(1), Int32(0), isnothing(δ) ? 1e-4 : δ, dparams,
-        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
+        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), _disc_table_n(config.geometry, dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1,
         q, windings ? Int32(1) : Int32(0), Int32(0), windings ? Float64(trace.plane_inc) : π / 2,
         comp_n, Int32(0), comps)
@@ -695,7 +713,7 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     dtab = _disc_table(d)
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
         abstol, reltol, Float64(μ), 1_000_000, Int32(0), Int32(0), 1e-4, dparams,
-        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
+        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), _disc_table_n(d, dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q), Int32(0), Int32(0), π / 2,
         _components(d)[1], Int32(0), _components(d)[2]))
     g = Gradus.metric(m, x)
@@ -746,7 +764,7 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     dtab = _disc_table(d)
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λ_max),
         abstol, reltol, 0.0, 1_000_000, Int32(upper_hemisphere), Int32(0), 1e-4, dparams,
-        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), length(dtab),
+        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), _disc_table_n(d, dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, 0.0, Int32(0), Int32(0), π / 2,
         _components(d)[1], Int32(0), _components(d)[2]))
     g = Gradus.metric(m, u)

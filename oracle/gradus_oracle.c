@@ -627,6 +627,81 @@ static double component_condition(const orc_config* c, int k, const double u[8])
 
 static int sgn(double x) { return (x > 0.0) - (x < 0.0); }
 
+/* ---- MeshAccretionGeometry (geometry/meshes.jl) ------------------------------------------------------------ */
+/* to_cartesian, geometry/geometry.jl:1-3,13-16 */
+static void to_cartesian3(const double u[8], double q[3])
+{
+    const double sth = sin(u[2]);
+    q[0] = u[1] * sth * cos(u[3]);
+    q[1] = u[1] * sth * sin(u[3]);
+    q[2] = u[1] * cos(u[2]);
+}
+static void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+/* jsf_algorithm, geometry/intersections.jl:58-101 (Jiménez, Segura & Feito 2010), ϵ = 1e-8.  Returns whether the segment
+ * Q1 -> Q2 meets the triangle; *tpar = w / (s - w) as there (the callers on this path use only the boolean). */
+int orc_jsf(const double V1[3], const double V2[3], const double V3[3], const double Q1[3], const double Q2[3], double* tpar)
+{
+    const double eps = 1e-8;
+    double A[3], B[3], C[3], D[3], W1[3], W2[3], s, t, u;
+    for (int i = 0; i < 3; ++i) { A[i] = Q1[i] - V3[i]; B[i] = V1[i] - V3[i]; C[i] = V2[i] - V3[i]; }
+    cross3(B, C, W1);
+    const double w = dot3(A, W1);
+    if (tpar) *tpar = 0.0;
+    if (w > eps) {
+        for (int i = 0; i < 3; ++i) D[i] = Q2[i] - V3[i];
+        s = dot3(D, W1);
+        if (s > eps) return 0;
+        cross3(A, D, W2);
+        t = dot3(W2, C);
+        if (t < -eps) return 0;
+        u = -dot3(W2, B);
+        if (u < -eps) return 0;
+        if (w < s + t + u) return 0;
+    } else if (w < -eps) {
+        return 0;
+    } else {
+        for (int i = 0; i < 3; ++i) D[i] = Q2[i] - V3[i];
+        s = dot3(D, W1);
+        if (s > eps) {
+            return 0;
+        } else if (s < -eps) {
+            cross3(D, A, W2);
+            t = dot3(W2, C);
+            if (t > eps) return 0;
+            u = -dot3(W2, B);
+            if (u > eps) return 0;
+            if (-s > t + u) return 0;
+        } else {
+            return 0;
+        }
+    }
+    if (tpar) *tpar = w / (s - w);
+    return 1;
+}
+/* intersects_geometry (intersections.jl:7-16) = in_nearby_region (meshes.jl:46-51: the step's end strictly inside the bounding
+ * box) && has_intersect (meshes.jl:53-64: the triangles whose first vertex is within 3 of the step's end, in mesh order) on
+ * cartesian_line_element (geometry.jl:38-40) = (to_cartesian(uprev), to_cartesian(u)) */
+static int mesh_intersects(const orc_config* c, const double uprev[8], const double u[8])
+{
+    const double* tb = c->disc_table;
+    double Q1[3], Q2[3];
+    to_cartesian3(uprev, Q1);
+    to_cartesian3(u, Q2);
+    if (!(tb[0] < Q2[0] && Q2[0] < tb[1] && tb[2] < Q2[1] && Q2[1] < tb[3] && tb[4] < Q2[2] && Q2[2] < tb[5])) return 0;
+    for (int64_t k = 0; k < c->disc_table_n; ++k) {
+        const double* T = tb + 6 + 9 * k;
+        const double dx = T[0] - Q2[0], dy = T[1] - Q2[1], dz = T[2] - Q2[2];
+        if (dx * dx + dy * dy + dz * dz < 9.0 && orc_jsf(T, T + 3, T + 6, Q1, Q2, NULL)) return 1;
+    }
+    return 0;
+}
+
 /* DiscreteCallbacks, in CallbackSet order: user callbacks (domain_upper_hemisphere,
  * callbacks.jl:31-40) then the chart (charts.jl:9-23); every callback whose condition holds
  * has its affect! applied, so a later one overrides the status of an earlier one [3P]. */
@@ -837,7 +912,7 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
                     terminated = 1;
                     event = 1;
                 }
-            } else if (c->disc_id != ORC_DISC_NONE) {
+            } else if (c->disc_id != ORC_DISC_NONE && c->disc_id != ORC_DISC_MESH) {
                 const double cprev = disc_condition(c, u); n_cond++;
                 const double cnext = disc_condition(c, unew); n_cond++;
                 const int ps = sgn(cprev);
@@ -888,7 +963,9 @@ static void integrate(const orc_config* c, const double u0[8], orc_point* out, o
                     terminated = 1;
                 }
             }
-            /* ---- then the discrete callbacks, on the (possibly moved) state ---- */
+            /* ---- then the discrete callbacks, on the (possibly moved) state: the geometry's first (merge_callbacks puts it
+             * ahead of the user's and the chart's, callbacks.jl:19-38 with bootstrap.jl:11-21; meshes.jl:67-78) ---- */
+            if (c->disc_id == ORC_DISC_MESH && mesh_intersects(c, u, unew)) { status = ORC_INTERSECTED_WITH_GEOMETRY; terminated = 1; }
             if (discrete_callbacks(c, unew, &status)) terminated = 1;
             /* winding_callback of TraceWindings, photon-rings.jl:1-15 (a DiscreteCallback merged into the set) */
             if (c->count_windings && ((winding % 2 == 0) ? unew[2] > c->winding_plane : unew[2] < c->winding_plane)) winding++;

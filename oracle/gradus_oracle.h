@@ -48,7 +48,9 @@ enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE =
 enum { ORC_DISC_NONE = 0, ORC_DISC_THIN = 1, ORC_DISC_SHAKURA_SUNYAEV = 2, ORC_DISC_TABULATED = 3, ORC_DISC_TORUS = 4,
        ORC_DISC_DATUM = 5 /* DatumPlane(height = disc_params[0]), datum-plane.jl:1-10 */,
        ORC_DISC_ELLIPTICAL = 6, ORC_DISC_PRECESSING_THIN = 7 /* geometry/discs.jl:57-96 */,
-       ORC_DISC_COMPOSITE = 8 /* CompositeGeometry, geometry/composite.jl + bootstrap.jl:76-110: comp_n components in comp[] */ };
+       ORC_DISC_COMPOSITE = 8 /* CompositeGeometry, geometry/composite.jl + bootstrap.jl:76-110: comp_n components in comp[] */,
+       ORC_DISC_MESH = 9 /* MeshAccretionGeometry, geometry/meshes.jl: disc_table = x/y/z extents (6) + 9 doubles per triangle,
+                            disc_table_n = number of triangles; a DiscreteCallback on the step's Cartesian line element */ };
 #define ORC_COMP_MAX 4
 typedef struct {
     int32_t disc_id;        /* ORC_DISC_THIN | SHAKURA_SUNYAEV | ELLIPTICAL | DATUM */
@@ -126,6 +128,8 @@ void orc_render_velocities(const orc_config* c, const double x[4], double a0, do
 /* ensemble_solve_tracing_problem(::EnsembleEndpointThreads), tracing.jl:151-196.
  * xs: N x 4 positions (or one position if x_stride == 0); vs: N x 4 unconstrained
  * velocities (constrain_all is applied here, constraints.jl:14-15). */
+/* jsf_algorithm (geometry/intersections.jl:58-101): segment Q1 -> Q2 against the triangle (V1, V2, V3) */
+int orc_jsf(const double V1[3], const double V2[3], const double V3[3], const double Q1[3], const double Q2[3], double* tpar);
 int orc_trace(const orc_config* c, const double* xs, int64_t x_stride, const double* vs, int64_t N,
               orc_point* out, orc_raystats* stats /* may be NULL */, int nthreads);
 

@@ -24,6 +24,7 @@ METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "ke
 DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS, DISC_DATUM = 0, 1, 2, 3, 4, 5
 DISC_ELLIPTICAL, DISC_PRECESSING_THIN = 6, 7
 DISC_COMPOSITE = 8
+DISC_MESH = 9          # MeshAccretionGeometry (geometry/meshes.jl)
 PF_AFFINE_TIME, PF_REDSHIFT, PF_STATUS, PF_R = 0, 1, 2, 3
 FILTER_NONE, FILTER_EARLY_TERM, FILTER_INTERSECTED = 0, 1, 2
 
@@ -173,6 +174,24 @@ def metric_inner_radius(metric, params):
     return inner_radius(params[0], params[1])
 
 
+def mesh_table_header(tri):
+    """bounding_box(mesh), meshes.jl:24-44: (x_min, x_max, y_min, y_max, z_min, z_max) over every vertex."""
+    pts = np.asarray(tri, dtype=np.float64).reshape(-1, 3)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    return np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]])
+
+
+def jsf_algorithm(V1, V2, V3, Q1, Q2):
+    """jsf_algorithm(V₁, V₂, V₃, Q₁, Q₂), intersections.jl:58-101 -> (hit, t)."""
+    L = lib()
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (V1, V2, V3, Q1, Q2)]
+    t = C.c_double(0.0)
+    L.orc_jsf.restype = C.c_int
+    L.orc_jsf.argtypes = [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_double)]
+    hit = L.orc_jsf(*[_dp(v) for v in a], C.byref(t))
+    return bool(hit), t.value
+
+
 def make_config(
     metric="kerr",
     params=(1.0, 0.0),
@@ -213,6 +232,13 @@ def make_config(
             c.comp[k].disc_r_in, c.comp[k].disc_r_out = one.disc_r_in, one.disc_r_out
             for i_par in range(4):          # (not `q`: that is the test particle's charge, an argument of this function)
                 c.comp[k].disc_params[i_par] = one.disc_params[i_par]
+    elif isinstance(disc, dict) and "mesh" in disc:
+        # MeshAccretionGeometry(mesh): {"mesh": triangles (n, 3, 3)}; the constructor's bounding_box (meshes.jl:11-44) in front
+        tri = np.ascontiguousarray(disc["mesh"], dtype=np.float64).reshape(-1, 3, 3)
+        tab = np.concatenate([mesh_table_header(tri), tri.ravel()])
+        c._keep = tab
+        c.disc_id = DISC_MESH
+        c.disc_table, c.disc_table_n = tab.ctypes.data, tri.shape[0]
     elif isinstance(disc, dict) and "datum" in disc:     # DatumPlane(height)
         c.disc_id = DISC_DATUM
         c.disc_params[0] = float(disc["datum"])

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../gradus.jl_amd/csrc/gr_device.hpp"
+#include "../gradus.jl_amd/csrc/gr_mesh_grid.hpp"
 
 using namespace GR_NS;
 
@@ -36,6 +37,11 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
 {
     derive_params(p);
     p.disc_table = p.cfg.disc_table;      // host pointer is directly usable here
+    static thread_local std::vector<double> mesh_table;
+    if (p.cfg.disc_id == GR_DISC_MESH) {  // ... a mesh goes through the builder the host unit uses (gr_mesh_grid.hpp)
+        gr_mesh::build_table(p.cfg.disc_table, p.cfg.disc_table_n, mesh_table);
+        p.disc_table = mesh_table.data();
+    }
     p.cfg.upper_hemisphere = (p.cfg.upper_hemisphere ? 1 : 0) | (p.cfg.count_windings ? 4 : 0);   // as stage_disc_table does
     const int disc = p.cfg.disc_id;
 #define HH_RUN(M) \
@@ -46,6 +52,7 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
          else if (disc == GR_DISC_ELLIPTICAL) run<M, GR_DISC_ELLIPTICAL>(p, p.n, tlog, hlog, cap, nlog); \
          else if (disc == GR_DISC_PRECESSING_THIN) run<M, GR_DISC_PRECESSING_THIN>(p, p.n, tlog, hlog, cap, nlog); \
          else if (disc == GR_DISC_COMPOSITE) run<M, GR_DISC_COMPOSITE>(p, p.n, tlog, hlog, cap, nlog); \
+         else if (disc == GR_DISC_MESH) run<M, GR_DISC_MESH>(p, p.n, tlog, hlog, cap, nlog); \
          else run<M, GR_DISC_NONE>(p, p.n, tlog, hlog, cap, nlog); } while (0)
     if (p.cfg.metric_id == GR_METRIC_KERR) HH_RUN(KerrMetric);
     else if (p.cfg.metric_id == GR_METRIC_KERR_NEWMAN) HH_RUN(KerrNewmanMetric);

@@ -242,7 +242,7 @@ def test_gr_config_arguments_are_in_field_order():
     expect = {"metric_id": "id", "disc_id": "did", "params": "params", "r_inner": "r_in", "r_outer": "r_out", "disc_r_in": "rin",
               "disc_r_out": "rout", "gtol": "gtol", "lambda0": "λ_domain[1]", "lambda1": "λ_domain[2]", "abstol": "abstol",
               "reltol": "reltol", "mu": "trace.μ", "maxiters": "maxiters", "upper_hemisphere": "δ", "_pad": "Int32(0)",
-              "hemi_delta": "δ", "disc_params": "dparams", "disc_table": "dtab", "disc_table_n": "length(dtab)",
+              "hemi_delta": "δ", "disc_params": "dparams", "disc_table": "dtab", "disc_table_n": "_disc_table_n(config.geometry, dtab)",
               "chart_table": "tab", "chart_table_n": "length(tab)", "chart_theta0": "θ0", "chart_theta1": "θ1", "q": "q",
               "count_windings": "windings", "_pad2": "Int32(0)", "winding_plane": "plane_inc", "comp_n": "comp_n",
               "_pad3": "Int32(0)", "comp": "comps"}
@@ -281,7 +281,8 @@ def test_metric_and_disc_ids_match_the_header():
         assert m and m.group(1) == ids[c], (jl, c)
     dwant = {"::Nothing": "GR_DISC_NONE", "d::ThinDisc": "GR_DISC_THIN", "d::ShakuraSunyaev": "GR_DISC_SHAKURA_SUNYAEV",
              "d::SampledThickDisc": "GR_DISC_TABULATED", "d::DatumPlane": "GR_DISC_DATUM", "d::EllipticalDisc": "GR_DISC_ELLIPTICAL",
-             "d::PrecessingDisc{T,<:ThinDisc}": "GR_DISC_PRECESSING_THIN"}
+             "d::PrecessingDisc{T,<:ThinDisc}": "GR_DISC_PRECESSING_THIN", "d::Gradus.CompositeGeometry": "GR_DISC_COMPOSITE",
+             "d::Gradus.MeshAccretionGeometry": "GR_DISC_MESH"}
     for jl, c in dwant.items():
         m = re.search(r"_disc\(" + re.escape(jl) + r"\)(?: where \{T\})? =\s*\(Int32\((\d+)\)", JL)
         assert m and m.group(1) == ids[c], (jl, c)
@@ -324,6 +325,11 @@ def test_reference_facts_the_binding_relies_on():
     assert re.search(r"struct PlungingInterpolation\{M,_interp_type\}\s*m::M\s*t::_interp_type\s*r::_interp_type\s*ϕ::_interp_type", orb)
     itp = src("src/interpolations.jl")
     assert re.search(r"struct NaNLinearInterpolator\{V1,V2,Y\}\s*t::V1\s*u::V2", itp)
+    # the mesh: fields read by _disc_table, and the DiscreteCallback whose condition closes over `g`
+    ms = src("src/geometry/meshes.jl")
+    assert re.search(r"struct MeshAccretionGeometry\{T\} <: AbstractAccretionGeometry\{T\}\s*mesh::Vector\{Tuple\{SVector\{3,T\},SVector\{3,T\},SVector\{3,T\}\}\}\s*"
+                     r"x_extent::Tuple\{T,T\}\s*y_extent::Tuple\{T,T\}\s*z_extent::Tuple\{T,T\}", ms)
+    assert "intersects_geometry(g, cartesian_line_element(u, integrator), integrator)" in ms
     # TracingConfiguration: the ensemble is the 9th type parameter
     cf = src("src/tracing/configuration.jl")
     params = re.search(r"struct TracingConfiguration\{(.*?)\}", cf, flags=re.S).group(1).split(",")
