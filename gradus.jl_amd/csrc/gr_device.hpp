@@ -2029,12 +2029,13 @@ struct Ray {
                 const int64_t row = ((int64_t)iz * ny + iy) * nx;
                 const uint32_t k1 = cs[row + hi[0] + 1];
                 for (uint32_t k = cs[row + lo[0]]; k < k1; ++k) {
-                    const double* T = T0 + 9 * (int64_t)k;
+                    const double* T = T0 + 3 * (int64_t)k;
                     const real V1[3] = { (real)T[0], (real)T[1], (real)T[2] };
                     const real dx = V1[0] - Q2[0], dy = V1[1] - Q2[1], dz = V1[2] - Q2[2];
                     if (dx * dx + dy * dy + dz * dz < 9.0) {
-                        const real V2[3] = { (real)T[3], (real)T[4], (real)T[5] };
-                        const real V3[3] = { (real)T[6], (real)T[7], (real)T[8] };
+                        const double* W = T0 + 3 * (int64_t)p.cfg.disc_table_n + 6 * (int64_t)k;
+                        const real V2[3] = { (real)W[0], (real)W[1], (real)W[2] };
+                        const real V3[3] = { (real)W[3], (real)W[4], (real)W[5] };
                         if (jsf_hit(V1, V2, V3, Q1, Q2)) return true;
                     }
                 }

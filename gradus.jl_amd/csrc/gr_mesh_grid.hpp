@@ -13,7 +13,8 @@
 //   [14..15] reserved
 //   [16.. ]  cell_start: nx ny nz + 1 uint32, cell (ix, iy, iz) at (iz ny + iy) nx + ix -- x runs fastest, so the three
 //            x-neighbours of a point are ONE contiguous run of triangles
-//   [off..]  the triangles sorted by cell, 9 doubles each (V1, V2, V3)
+//   [off..]  the triangles sorted by cell: first every V1 (3 n doubles -- all the distance test reads, so neighbouring
+//            candidates share cache lines), then every (V2, V3) (6 n doubles), read only by the triangles that pass it
 // Included by the host unit (gradus_mi355x.hip) and by tests/host_harness.cpp, which runs the kernel logic on the CPU.
 #pragma once
 #include <cmath>
@@ -81,7 +82,8 @@ inline void build_table(const double* src, int64_t n, std::vector<double>& out)
     std::vector<uint32_t> fill(start.begin(), start.end() - 1);
     for (int64_t k = 0; k < n; ++k) {                // stable: mesh order inside a cell
         const uint32_t slot = fill[where[(size_t)k]]++;
-        std::memcpy(out.data() + off + 9 * (int64_t)slot, tri + 9 * k, 9 * sizeof(double));
+        std::memcpy(out.data() + off + 3 * (int64_t)slot, tri + 9 * k, 3 * sizeof(double));
+        std::memcpy(out.data() + off + 3 * n + 6 * (int64_t)slot, tri + 9 * k + 3, 6 * sizeof(double));
     }
 }
 
