@@ -91,6 +91,10 @@ typedef double gr_real_t;
 #else
 #define GR_HAS_MESH 1
 #endif
+// tests due in one wave after a step up to which the wave takes them one by one, all lanes on one test (above: each lane its own)
+#ifndef GR_MESH_WAVE_MAX
+#define GR_MESH_WAVE_MAX 16
+#endif
 
 #ifdef GR_HOST_HARNESS
 // tests/host_harness.cpp compiles this header with g++ to trace single rays on the CPU next to
@@ -1929,6 +1933,11 @@ struct Ray {
     // which components the pending event belongs to
     real cprev_more[GR_COMP_MAX - 1];
     int32_t ev_mask;
+    // GR_DISC_MESH (dead in every other instantiation): the Cartesian position at the start of the step and at its end; whether
+    // the end lies inside the mesh's bounding box (a test is due); whether the user's or the chart's callback ended the ray at
+    // that step; and whether the kernel runs the due tests wave-wide after the step (mesh_phase) instead of inside it
+    real qprev[3], qnew[3];
+    int32_t mesh_need, mesh_cb_term, mesh_coop;
 #ifdef GR_HOST_HARNESS
     real dbg_e2;
     real dbg_dmax;          // per attempted step: largest |θ_stage - θ_base| (harness statistics)
@@ -1996,52 +2005,104 @@ struct Ray {
         return false;
     }
     // p.disc_table: the table gr_mesh_grid.hpp builds -- the bounding box, a uniform grid over the triangles' first vertices
-    // with cells of (just over) 3, the triangles sorted by cell
-    static GR_DEV bool mesh_hit(const Params& p, real r0, real s0, real c0, real ph0, real r1, real s1, real c1, real ph1)
+    // with cells of (just over) 3, the triangles sorted by cell (first vertices in one run, the other two in a second)
+    // in_nearby_region (meshes.jl:46-51): the step's END strictly inside the bounding box
+    static GR_DEV bool mesh_inside(const Params& p, const real Q2[3])
     {
         const double* tb = p.disc_table;
-        real Q2[3];
-        to_cartesian3(r1, s1, c1, ph1, Q2);
-        // in_nearby_region (meshes.jl:46-51): the step's END strictly inside the bounding box
-        if (!((real)tb[0] < Q2[0] && Q2[0] < (real)tb[1] && (real)tb[2] < Q2[1] && Q2[1] < (real)tb[3] && (real)tb[4] < Q2[2] && Q2[2] < (real)tb[5]))
-            return false;
-        real Q1[3];
-        to_cartesian3(r0, s0, c0, ph0, Q1);
-        // has_intersect (meshes.jl:53-64): the triangles whose FIRST vertex is within 3 of the step's end.  They sit in the
-        // point's grid cell or one of its 26 neighbours; per (y, z) neighbour the three x-cells are one run of triangles
+        return (real)tb[0] < Q2[0] && Q2[0] < (real)tb[1] && (real)tb[2] < Q2[1] && Q2[1] < (real)tb[3] && (real)tb[4] < Q2[2] && Q2[2] < (real)tb[5];
+    }
+    // the grid cells around a point: per axis the cell of the point and its two neighbours, clipped to the grid (the box may
+    // reach beyond the grid of first vertices: an empty range then)
+    static GR_DEV void mesh_cells(const double* tb, const real Q2[3], int lo[3], int hi[3])
+    {
         const real icell = (real)tb[9];
-        const int nx = (int)tb[10], ny = (int)tb[11], nz = (int)tb[12];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int dim = (int)tb[10 + a];
+            real f = GR_FLOOR((Q2[a] - (real)tb[6 + a]) * icell);
+            f = GR_FMAX((real)-2.0, GR_FMIN(f, (real)dim + (real)1.0));
+            const int i = (int)f;
+            lo[a] = i - 1 < 0 ? 0 : i - 1;
+            hi[a] = i + 1 > dim - 1 ? dim - 1 : i + 1;
+        }
+    }
+    // has_intersect (meshes.jl:53-64) for one candidate: the triangle counts if its FIRST vertex is within 3 of the step's end
+    static GR_DEV bool mesh_candidate(const Params& p, const double* T0, uint32_t k, const real Q1[3], const real Q2[3])
+    {
+        const double* T = T0 + 3 * (int64_t)k;
+        const real V1[3] = { (real)T[0], (real)T[1], (real)T[2] };
+        const real dx = V1[0] - Q2[0], dy = V1[1] - Q2[1], dz = V1[2] - Q2[2];
+        if (!(dx * dx + dy * dy + dz * dz < 9.0)) return false;
+        const double* W = T0 + 3 * (int64_t)p.cfg.disc_table_n + 6 * (int64_t)k;
+        const real V2[3] = { (real)W[0], (real)W[1], (real)W[2] };
+        const real V3[3] = { (real)W[3], (real)W[4], (real)W[5] };
+        return jsf_hit(V1, V2, V3, Q1, Q2);
+    }
+    // ONE lane walks the candidates of its own step: the point's cell and its 26 neighbours; per (y, z) neighbour the three
+    // x-cells are one run of triangles.  (The persistent and path kernels, and the lane kernel when many lanes of a wave have a
+    // test due at once.)
+    static GR_DEV bool mesh_lane_query(const Params& p, const real Q1[3], const real Q2[3])
+    {
+        const double* tb = p.disc_table;
+        const int nx = (int)tb[10], ny = (int)tb[11];
         const uint32_t* cs = reinterpret_cast<const uint32_t*>(tb + 16);
         const double* T0 = tb + (int64_t)tb[13];
         int lo[3], hi[3];
-        const int dim[3] = { nx, ny, nz };
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            real f = GR_FLOOR((Q2[a] - (real)tb[6 + a]) * icell);
-            f = GR_FMAX((real)-2.0, GR_FMIN(f, (real)dim[a] + (real)1.0));        // (the box may reach beyond the grid of first vertices)
-            const int i = (int)f;
-            lo[a] = i - 1 < 0 ? 0 : i - 1;
-            hi[a] = i + 1 > dim[a] - 1 ? dim[a] - 1 : i + 1;
-        }
+        mesh_cells(tb, Q2, lo, hi);
         if (hi[0] < lo[0]) return false;
         for (int iz = lo[2]; iz <= hi[2]; ++iz)
             for (int iy = lo[1]; iy <= hi[1]; ++iy) {
                 const int64_t row = ((int64_t)iz * ny + iy) * nx;
                 const uint32_t k1 = cs[row + hi[0] + 1];
-                for (uint32_t k = cs[row + lo[0]]; k < k1; ++k) {
-                    const double* T = T0 + 3 * (int64_t)k;
-                    const real V1[3] = { (real)T[0], (real)T[1], (real)T[2] };
-                    const real dx = V1[0] - Q2[0], dy = V1[1] - Q2[1], dz = V1[2] - Q2[2];
-                    if (dx * dx + dy * dy + dz * dz < 9.0) {
-                        const double* W = T0 + 3 * (int64_t)p.cfg.disc_table_n + 6 * (int64_t)k;
-                        const real V2[3] = { (real)W[0], (real)W[1], (real)W[2] };
-                        const real V3[3] = { (real)W[3], (real)W[4], (real)W[5] };
-                        if (jsf_hit(V1, V2, V3, Q1, Q2)) return true;
-                    }
-                }
+                for (uint32_t k = cs[row + lo[0]]; k < k1; ++k)
+                    if (mesh_candidate(p, T0, k, Q1, Q2)) return true;
             }
         return false;
     }
+#ifndef GR_HOST_HARNESS
+    // The WAVE walks the candidates of one lane's step (Q1, Q2 are the same in every lane): the up to nine runs of triangles are
+    // laid end to end and dealt to the 64 lanes, so a step with ~100 candidates costs two rounds of coalesced loads instead
+    // of a hundred dependent ones.  What the tail of a mesh launch is made of: a few rays that wind round the hole inside the
+    // bounding box, alone in their waves (DESIGN_measurements.md §M15).
+    static GR_DEV bool mesh_wave_query(const Params& p, const real Q1[3], const real Q2[3], int lane)
+    {
+        const double* tb = p.disc_table;
+        const int nx = (int)tb[10], ny = (int)tb[11];
+        const uint32_t* cs = reinterpret_cast<const uint32_t*>(tb + 16);
+        const double* T0 = tb + (int64_t)tb[13];
+        int lo[3], hi[3];
+        mesh_cells(tb, Q2, lo, hi);
+        if (hi[0] < lo[0]) return false;
+        uint32_t first[9], upto[10];
+        upto[0] = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int iz = lo[2] + q / 3, iy = lo[1] + q % 3;
+            uint32_t k0 = 0, k1 = 0;
+            if (iz <= hi[2] && iy <= hi[1]) {
+                const int64_t row = ((int64_t)iz * ny + iy) * nx;
+                k0 = cs[row + lo[0]];
+                k1 = cs[row + hi[0] + 1];
+            }
+            first[q] = k0;
+            upto[q + 1] = upto[q] + (k1 - k0);
+        }
+        for (uint32_t base = 0; base < upto[9]; base += 64) {
+            const uint32_t j = base + (uint32_t)lane;
+            bool h = false;
+            if (j < upto[9]) {
+                uint32_t k = first[0] + j;
+#pragma unroll
+                for (int q = 1; q < 9; ++q)
+                    if (j >= upto[q]) k = first[q] + (j - upto[q]);
+                h = mesh_candidate(p, T0, k, Q1, Q2);
+            }
+            if (__ballot(h)) return true;
+        }
+        return false;
+    }
+#endif
 #endif
 
     // distance_to_disc(::DatumPlane), datum-plane.jl:6-10 ; distance_to_disc(::ThinDisc), thin-disc.jl:20-26 ; distance_to_disc(::AbstractThickAccretionDisc),
@@ -2365,6 +2426,14 @@ struct Ray {
         }
         cprev = kContinuous ? disc_cond4(p, x[1], s, c, x[3]) : 1.0;
         ev_mask = 0;
+#if GR_HAS_MESH
+        if constexpr (DISC == GR_DISC_MESH) {
+            to_cartesian3(x[1], s, c, x[3], qprev);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) qnew[i] = qprev[i];
+            mesh_need = 0; mesh_cb_term = 0; mesh_coop = 0;
+        }
+#endif
         if constexpr (DISC == GR_DISC_COMPOSITE) {
 #pragma unroll
             for (int k = 0; k < GR_COMP_MAX; ++k)
@@ -2777,10 +2846,19 @@ struct Ray {
             bool term = false;
 #if GR_HAS_MESH
             if constexpr (DISC == GR_DISC_MESH) {
-                if (mesh_hit(p, x[1], sth, cth, x[3], xn[1], sn, cn, xn[3])) { status = GR_STATUS_INTERSECTED_WITH_GEOMETRY; term = true; }
+                to_cartesian3(xn[1], sn, cn, xn[3], qnew);
+                mesh_need = mesh_inside(p, qnew) ? 1 : 0;
+                if (!mesh_coop) {
+                    if (mesh_need && mesh_lane_query(p, qprev, qnew)) { status = GR_STATUS_INTERSECTED_WITH_GEOMETRY; term = true; }
+                    mesh_need = 0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) qprev[i] = qnew[i];
+                }
             }
 #endif
-            term |= discrete_cb(p, xn[1], xn[2], cn, status, flags);
+            const bool cb_term = discrete_cb(p, xn[1], xn[2], cn, status, flags);
+            term |= cb_term;
+            if constexpr (DISC == GR_DISC_MESH) mesh_cb_term = cb_term ? 1 : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[i] = xn[i]; v[i] = vn[i]; A[0][i] = A[6][i]; }
             sth = sn; cth = cn;
@@ -2792,6 +2870,7 @@ struct Ray {
             // 1/qmin, so the step size would stay finite and the ray would be rejected ~25 times down to
             // dt < dtmin: test for it here (rejected steps only, so the accepted path pays nothing)
             nrej++;
+            if constexpr (DISC == GR_DISC_MESH) mesh_need = 0;
             if (!(e2 == e2)) {
 #if GR_NORM_F32_ON
                 // The single-precision norm also turns NaN when a trial state is astronomically far off (tolerance 1e-3 next to
@@ -2818,6 +2897,50 @@ struct Ray {
 #undef GR_PARK
 #undef GR_UNPARK
     }
+
+#if GR_HAS_MESH && !defined(GR_HOST_HARNESS)
+    // GR_DISC_MESH in the one-ray-per-lane kernel: ALL 64 lanes of the wave come here after every step (finished lanes too: they
+    // are the helpers).  A few tests due: the wave takes them one after the other, 64 candidates at a time (mesh_wave_query);
+    // many due at once: every lane walks its own candidates, in parallel (mesh_lane_query).  The outcome is the inline test's:
+    // a hit ends the ray with IntersectedWithGeometry unless a later callback of the set ended it at the same step.
+    GR_DEV bool mesh_phase(const Params& p, bool live, bool fin)
+    {
+        const bool need = live && mesh_need;
+        unsigned long long due = __ballot(need);
+        bool hit = false;
+        if (due) {
+            // q tests due, each over c candidates: lane by lane in parallel costs ~c dependent rounds, the wave on one test after
+            // the other ~q (c / 64 + a few) rounds.  Measured on a ring slab of 960 / 3840 triangles at 1024², by wave up to
+            // q = 0 / 2 / 8 / 16 / 32 / 64: 11.4 / 10.1 / 9.4 / 9.1 / 10.7 / 17.7 ms and 25.0 / 22.4 / 18.2 / 15.7 / 14.4 / 24.7 ms
+            // (a rule that also counts the candidates first costs more than it finds: 9.9 and 16.7-18.0 ms)
+            const bool by_wave = __popcll(due) <= GR_MESH_WAVE_MAX;
+            if (!by_wave) {
+                if (need) hit = mesh_lane_query(p, qprev, qnew);
+            } else {
+                const int lane = (int)(threadIdx.x & 63);
+                do {
+                    const int src = __ffsll((long long)due) - 1;
+                    due &= due - 1;
+                    real Q1[3], Q2[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { Q1[i] = __shfl(qprev[i], src, 64); Q2[i] = __shfl(qnew[i], src, 64); }
+                    const bool h = mesh_wave_query(p, Q1, Q2, lane);
+                    if (lane == src) hit = h;
+                } while (due);
+            }
+        }
+        if (live) {
+            mesh_need = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) qprev[i] = qnew[i];
+            if (hit) {
+                if (!mesh_cb_term) status = GR_STATUS_INTERSECTED_WITH_GEOMETRY;
+                fin = true;
+            }
+        }
+        return fin;
+    }
+#endif
 
     // dense-output polynomial coefficients of component `comp` (0..3 position, 4..7 velocity):
     // y(Θ) = y0 + h Σ_m C[m] Θ^(m+1)

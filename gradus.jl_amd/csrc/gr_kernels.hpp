@@ -242,6 +242,36 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
     const int64_t gid = ((int64_t)chunk * blockDim.x + threadIdx.x) >> LANES_PER_RAY_LOG2;
     LaneStats<Metric, DISC> ls;
     const LdsView lds = lds_prologue<ColdSel<Metric>::kBytesPerThread>(p);
+#if GR_HAS_MESH
+    if constexpr (DISC == GR_DISC_MESH) {
+        // A mesh: the wave stays together until its last ray has ended -- after every step the tests that are due are run by the
+        // whole wave (Ray::mesh_phase), finished lanes helping.  Otherwise the tail of the launch is a few rays that wind round
+        // the hole inside the bounding box, each walking ~100 candidate triangles per step alone (25.2 -> ms for 3840 triangles
+        // at 1024², DESIGN_measurements.md §M15)
+        Ray<Metric, DISC> ray;
+        const typename ColdSel<Metric>::type cs = cold_store_of<ColdSel<Metric>>(p);
+        bool live = gid < p.n;
+        if (live) {
+            ray.init(m, p, tile_swizzle(cold_of(p), gid));
+            ray.mesh_coop = 1;
+        }
+        while (__any(live)) {
+            bool fin = true;
+            if (live) fin = ray.step(m, p, cs);
+            fin = ray.mesh_phase(p, live, fin);
+            if (fin) live = false;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (gid < p.n) {
+            GR_PARAMS_AFTER_LOOP(p, pl, zoff)
+            ray.finalize(m, pl, lds, cs);
+            ls.add(ray);
+#ifdef GR_WAVE_TIMELINE
+            tl_steps = ray.nacc + ray.nrej;
+#endif
+        }
+    } else
+#endif
     if (gid < p.n) {
         Ray<Metric, DISC> ray;
         const typename ColdSel<Metric>::type cs = cold_store_of<ColdSel<Metric>>(p);

@@ -7,6 +7,7 @@ PROF_CMD="scripts/sibling_workloads.py <which>" PROF_KERNEL=<substring of the ke
     dual      BumblebeeMetric(a=0.25, l=0.5) 1024², ThinDisc, shadow -- a TRUE dual-number metric          k_trace_lane<GenericMetricT<3>,1>
     dual2     MorrisThorneWormhole(b=1) 1024², ThinDisc, shadow (hand-fused since round 4)                k_trace_lane<GenericMetricT<2>,1>
     dual6     DilatonAxion(a=0.5, β=0.3, b=1) 1024², ThinDisc, shadow -- the heaviest dual-number metric k_trace_lane<GenericMetricT<6>,1>
+    mesh      Kerr 1024², the bench observer, MeshAccretionGeometry: a ring slab of 3840 triangles            k_trace_lane<KerrFamily<false>,8>
     dual8 / dual9 / dual10   KerrDarkMatter(a=0.5, 2, 20, 10) / KerrRefractive(a=0.5, n=1.1, 20) / NoZMetric(a=0.5, ϵ=0.5), ThinDisc(6, 50), shadow
     c5        BASELINE config 5 line profile, 4096² polar-plane rays, fp64 tol 1e-9                  k_trace_lane<KerrFamily<false>,1> (tiled rays)
     c5p       the same through the persistent kernel                                                  k_trace_persistent<...>
@@ -70,6 +71,21 @@ if which in ("c4", "generic", "dual", "dual6", "dual2", "dual8", "dual9", "dual1
                                           alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf, ensemble=ens, stats=True)
         ms.append(st["kernel_ms"])
     rays = S * S
+elif which == "mesh":
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from test_mesh_geometry import slab
+
+    m = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(75), 0.0])
+    d = G.MeshAccretionGeometry(slab(2.0, 50.0, 10, 96, 1.0))
+    pf = G.ConstPointFunctions.affine_time() @ G.ConstPointFunctions.filter_intersected()
+    S = int(os.environ.get("SIB_SIZE", "1024"))
+    for _ in range(reps):
+        _, _, img, st = G.rendergeodesics(m, x, d, 2000.0, image_width=S, image_height=S, alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf,
+                                          ensemble=ens, stats=True)
+        ms.append(st["kernel_ms"])
+    rays = S * S
+    extra = {"triangles": len(d), "pixels_hit": int(np.isfinite(img).sum())}
 elif which in ("c5", "c5p", "c5f32"):
     m = G.KerrMetric(1.0, 0.998)
     u = np.array([0.0, 1000.0, math.radians(60), 0.0])

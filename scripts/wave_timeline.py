@@ -37,9 +37,15 @@ n = S * S
 if order == "plane":
     from gradus_jl_amd import device as gdev
 
-    pcfg = G.render_configuration(m, x, G.ThinDisc(m.isco(), 50.0), 2000.0, image_width=S, image_height=S, alpha_lims=(-60.0, 60.0),
+    geom = G.ThinDisc(m.isco(), 50.0)
+    if os.environ.get("WT_MESH"):          # the slab of scripts/sibling_workloads.py mesh: WT_MESH = triangles per ring
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_mesh_geometry import slab
+
+        geom = G.MeshAccretionGeometry(slab(2.0, 50.0, 10, int(os.environ["WT_MESH"]), 1.0))
+    pcfg = G.render_configuration(m, x, geom, 2000.0, image_width=S, image_height=S, alpha_lims=(-60.0, 60.0),
                                   beta_lims=(-35.0, 35.0), ensemble=ens)
-    ppf = G.ConstPointFunctions.redshift(m, x) @ G.ConstPointFunctions.filter_intersected()
+    ppf = (G.ConstPointFunctions.affine_time() if os.environ.get("WT_MESH") else G.ConstPointFunctions.redshift(m, x)) @ G.ConstPointFunctions.filter_intersected()
     img = torch.empty(n, dtype=torch.float64, device=dev)
 
     def launch():
