@@ -103,5 +103,15 @@ print("the waves that end last (start, end, steps of longest ray):", [(round(flo
 per_step = life * 1e3 / np.maximum(steps, 1)
 print(f"µs per step of a wave's longest ray: median {np.median(per_step):.2f} p10 {np.percentile(per_step, 10):.2f} p90 {np.percentile(per_step, 90):.2f}; "
       f"for the 1 % longest waves {np.median(per_step[np.argsort(life)[-len(life) // 100:]]):.2f}")
+# idle time of the hardware wave slots between two waves (HW_ID: wave_id [3:0], simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13])
+slot = ((hw >> 32) << 16) | (hw & 0xF) | (hw & 0x30) | (hw & 0xF00) | (hw & 0x1000) | (hw & 0xE000)
+order_ = np.lexsort((t0, slot))
+s_sorted, st_s, en_s = slot[order_], st[order_], en[order_]
+same = s_sorted[1:] == s_sorted[:-1]
+gaps = (st_s[1:] - en_s[:-1])[same] * 1e3          # µs
+body = en_s[:-1][same] < 0.9 * en.max()
+print(f"wave slots seen: {np.unique(slot).size}; gap between two waves on one slot, µs (before the last 10 % of the launch): median {np.median(gaps[body]):.1f} "
+      f"p90 {np.percentile(gaps[body], 90):.1f} p99 {np.percentile(gaps[body], 99):.1f} mean {gaps[body].mean():.1f}; slot-time idle in gaps: "
+      f"{100.0 * gaps[body].sum() / (np.unique(slot).size * 0.9 * en.max() * 1e3):.1f} %")
 print(json.dumps({"launch_ms": ms, "waves": int(t.shape[0]), "lifetime_ms": {"mean": float(life.mean()), "p99": float(np.percentile(life, 99)), "max": float(life.max())},
                   "steps_longest": {"median": float(np.median(steps)), "max": int(steps.max())}, "last_start_ms": float(st.max()), "resident_per_slice": res}))
