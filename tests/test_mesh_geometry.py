@@ -239,6 +239,38 @@ def test_host_kernel_logic_equals_oracle_on_mesh_scenes(G, oracle, scene, metric
     _compare(oracle, name, params, mesh, v, got, ref)
 
 
+def _low_lid():
+    """A ring whose upper face lies just above the equatorial plane (z = 0.3) over a deep box (down to z = -2): a step of
+    the size the integrator takes there comes in through the face and ends below the plane."""
+    return np.concatenate([annulus(2.5, 9.0, 5, 24, z=0.3, up=True), annulus(2.5, 9.0, 5, 24, z=-2.0, up=False)])
+
+
+def test_a_later_callback_of_the_set_overrides_the_mesh(G, oracle):
+    """CallbackSet order: the geometry's DiscreteCallback, the user's, the chart's (callbacks.jl:19-38 with bootstrap.jl:11-21);
+    every callback whose condition holds applies its affect!, so where a step both enters a front face and drops below
+    domain_upper_hemisphere's δ the ray ends there as OutOfDomain, not as IntersectedWithGeometry."""
+    m = G.KerrMetric(1.0, 0.9)
+    v = _rays(G, m, 32)
+    mesh = _low_lid()
+    cfg = G.tracing_configuration(m, X_OBS, v, G.MeshAccretionGeometry(mesh), (0.0, 2000.0), callback=G.domain_upper_hemisphere(0.35),
+                                  ensemble=G.EnsembleMI355X.__new__(G.EnsembleMI355X))
+    got = Hh.trace_endpoints(G, cfg)
+    ocfg = oracle.make_config("kerr", (1.0, 0.9), disc={"mesh": mesh}, lambda_max=2000.0, upper_hemisphere=True, hemi_delta=0.35)
+    ref = oracle.trace(ocfg, X_OBS, v)
+    plain = _orc(oracle, "kerr", (1.0, 0.9), mesh, v)
+    # rays the mesh alone ends below the plane z = δ (here just above the lid: a step that comes in through the lid starts
+    # above δ and ends below it) are OutOfDomain with the hemisphere callback in the set -- at the same step
+    z = plain["x"][:, 1] * np.cos(plain["x"][:, 2])
+    both = (plain["status"] == 2) & (z < 0.35)
+    assert both.sum() > 20
+    # (most of them were below the plane earlier and end there; some end AT the step of the hit: both conditions held)
+    assert (ref["status"][both] == 0).all() and (ref["lambda_max"][both] <= plain["lambda_max"][both]).all()
+    assert (both & (ref["lambda_max"] == plain["lambda_max"])).sum() >= 3
+    assert (got["status"] != ref["status"]).sum() <= 4
+    same = got["status"] == ref["status"]
+    assert (got["status"][both & same] == 0).all()
+
+
 def test_mesh_constructor_and_abi_table(G):
     mesh = box((1.0, -2.0, 3.0), 2.0)
     g = G.MeshAccretionGeometry(mesh)
@@ -290,6 +322,23 @@ def test_device_mesh_far_away_changes_nothing_and_image_path_agrees(G, ens):
     img2 = G.apply(pf, cache)
     assert np.isfinite(img).sum() > 100
     assert np.array_equal(np.isnan(img), np.isnan(img2)) and np.array_equal(img[np.isfinite(img)], img2[np.isfinite(img2)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_device_later_callback_overrides_the_mesh(G, oracle, ens, kernel):
+    ens.set("kernel", kernel)
+    m = G.KerrMetric(1.0, 0.9)
+    v = _rays(G, m, 48)
+    mesh = _low_lid()
+    got = G.tracegeodesics(m, X_OBS, v, G.MeshAccretionGeometry(mesh), (0.0, 2000.0), ensemble=ens, callback=G.domain_upper_hemisphere(0.35))
+    ref = oracle.trace(oracle.make_config("kerr", (1.0, 0.9), disc={"mesh": mesh}, lambda_max=2000.0, upper_hemisphere=True, hemi_delta=0.35), X_OBS, v)
+    plain = _orc(oracle, "kerr", (1.0, 0.9), mesh, v)
+    both = (plain["status"] == 2) & (plain["x"][:, 1] * np.cos(plain["x"][:, 2]) < 0.35)
+    assert both.sum() > 50 and (ref["status"][both] == 0).all() and (both & (ref["lambda_max"] == plain["lambda_max"])).sum() >= 10
+    assert (got["status"] != ref["status"]).sum() <= max(2, got["status"].size // 200)
+    same = got["status"] == ref["status"]
+    assert (got["status"][both & same] == 0).all()
 
 
 @pytest.mark.gpu
