@@ -965,13 +965,16 @@ struct GenericMetricT {
     static constexpr bool kColdRare = (ID == GR_METRIC_BUMBLEBEE) && kLaneWavesPerSimd >= 3;
     static constexpr int kParkStages = (!kSlimFused && kLaneWavesPerSimd >= 3) ? GR_PARK_DEFAULT : 0;
     static constexpr bool kHasForce = false;
-    // rhs() below: hand-derived for Johannsen-Psaltis (round 3) and for Bumblebee and Morris-Thorne (round 4) -- the other
-    // five dual-number metrics take eval() + the generic contraction
-    static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS || ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE);
+    // rhs() below: hand-derived for Johannsen-Psaltis (round 3), for Bumblebee, Morris-Thorne, Kerr-dark-matter and Kerr-refractive
+    // (round 4; the last two as Kerr plus the terms of their r-dependent parameter) -- the other three dual-number metrics (flat
+    // space, dilaton-axion, NoZ) take eval() + the generic contraction on typed duals
+    static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS || ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE
+                                       || ID == GR_METRIC_KERR_DARK_MATTER || ID == GR_METRIC_KERR_REFRACTIVE);
     int32_t id;
     real P[6];
     real ka2, ktM, keps;      // Johannsen-Psaltis rhs(): a², 2M, ϵ3 M³ -- uniform, formed once
     real kik;                 // Bumblebee rhs(): 1/(1 + l)
+    real kin0;                // Kerr-refractive rhs(): 1/n
     GR_DEV void load(const gr_config& c)
     {
         id = ID >= 0 ? ID : c.metric_id;
@@ -979,6 +982,7 @@ struct GenericMetricT {
         for (int i = 0; i < 6; ++i) P[i] = c.params[i];
         ka2 = uni(P[1] * P[1]); ktM = uni(2.0 * P[0]); keps = uni(P[2] * P[0] * P[0] * P[0]);
         kik = (ID == GR_METRIC_BUMBLEBEE) ? uni(rcp_full(1.0 + P[2])) : (real)0.0;
+        kin0 = (ID == GR_METRIC_KERR_REFRACTIVE) ? uni(rcp_full(P[2])) : (real)0.0;
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
     template <bool A, bool B> static GR_DEV DualP<A, B> inv_(DualP<A, B> x) { return dinv(x); }
@@ -1244,6 +1248,59 @@ struct GenericMetricT {
     //   a^θ = -2 v_r v_θ / r + ½ (r² S2 v_ϕ² - 2 (K S2 / r) v_t v_ϕ)/r².
     // Two reciprocals: 1/(r (r - 2M)) shared by 1/r and 1/(r - 2M); 1/(D' s²) shared by 1/D' and 1/(s² D').
     // All three equal eval() + the generic contraction to rounding (tests/test_kernel_logic_host.py).
+    // The fused Kerr right-hand side (KerrFamily<false>::rhs, which see) with the mass M given per lane and, for the
+    // enclosed-mass metric, the mass gradient dM = M'(r) (its terms: at the Kerr-dark-matter branch of rhs() below).  Leaves
+    // the pieces its callers build their own terms from.
+    struct KerrMid { real iSig, iDel, iDs, Del, w, gtp, B; };
+    GR_DEV void kerr_core(real M, real dM, real r, real s, real c, real vt, real vr, real vh, real vp,
+                          real& at, real& ar, real& ah, real& ap, KerrMid& k) const
+    {
+        const real a = P[1];
+        const real a2 = ka2, tM = 2.0 * M;
+        const real s2 = s * s, sc = s * c;
+        const real ra2 = GR_FMA(r, r, a2);
+        const real Sig = GR_FMA(-a2, s2, ra2);
+        const real Del = GR_FMA(-tM, r, ra2);
+        const real Ds2 = Del * s2;
+        const real Pr = rcp_rhs(Sig * Ds2);
+        const real iSig = Pr * Ds2, iDs = Pr * Sig, iDel = iDs * s2;
+        const real tr = 2.0 * r;
+        const real w = (tM * r) * iSig;
+        const real wiS = w * iSig;
+        const real hw_r = GR_FMA(-r, wiS, M * iSig);
+        const real mSig_t = (2.0 * a2) * sc;
+        const real w_t = wiS * mSig_t;
+        const real q = a * s2;
+        const real U = GR_FMA(-q, vp, vt);
+        const real U2 = U * U;
+        const real vr2 = vr * vr, vh2 = vh * vh, vp2 = vp * vp, vrvh = vr * vh;
+        const real wd = GR_FMA(2.0 * hw_r, vr, w_t * vh);
+        const real s2d = (2.0 * sc) * vh;
+        const real aw = a * w;
+        const real z1 = aw * s2d;
+        const real gtp = -(q * w);
+        const real B = GR_FMA(-a, gtp, ra2);
+        const real gtpd = -GR_FMA(q, wd, z1);
+        real Tt = GR_FMA(wd, U, -(z1 * vp));
+        real Tp = GR_FMA(gtpd, U, GR_FMA(s2d, B, (tr * s2) * vr) * vp);
+        const real vr2iD = vr2 * iDel;
+        const real in = GR_FMA(hw_r, U2, r * GR_FMA(s2, vp2, vh2));
+        ar = GR_FMA(iSig, GR_FMA(Del, in, GR_FMA(mSig_t, vrvh, -(r * vr2))), (r - M) * vr2iD);
+        if (dM != 0.0) {
+            const real dTt = (dM * (tr * iSig)) * (U * vr);
+            Tt += dTt;
+            Tp = GR_FMA(-q, dTt, Tp);
+            ar = GR_FMA(-(dM * r), GR_FMA(-(Del * iSig), iSig * U2, vr2iD), ar);
+        }
+        at = iDs * GR_FMA(B * s2, Tt, -(gtp * Tp));
+        ap = -(iDs * GR_FMA(gtp, Tt, GR_FMA(-w, Tp, Tp)));
+        const real W1n = U + vt;
+        real X = GR_FMA(-(aw * vp), W1n, B * vp2);
+        X = GR_FMA(a2, GR_FMA(wiS, U2, vh2 - vr2iD), X);
+        ah = iSig * GR_FMA(sc, X, -(tr * vrvh));
+        k.iSig = iSig; k.iDel = iDel; k.iDs = iDs; k.Del = Del; k.w = w; k.gtp = gtp; k.B = B;
+    }
+
     GR_DEV void rhs(real r, real s, real c, real vt, real vr, real vh, real vp,
                     real& at, real& ar, real& ah, real& ap) const
     {
@@ -1258,6 +1315,61 @@ struct GenericMetricT {
             ar = l * GR_FMA(s, vp2, vh * vh);
             ah = GR_FMA(-(tl * iw), vr * vh, (0.5 * c) * vp2);
             ap = -(GR_FMA(tl * iw, vr, (c * is) * vh) * vp);
+            return;
+        } else if constexpr (ID == GR_METRIC_KERR_DARK_MATTER) {
+            // Kerr with the enclosed mass M(r) (kerr-dark-matter.jl:6-49): every component depends on r through M as well, so
+            // ∂_r g = ∂_r g|_M + M'(r) ∂_M g, and the right-hand side is Kerr's at M = M(r) (kerr_core: the fused form of
+            // KerrFamily::rhs with the mass per lane) plus what M' ∂_M g contributes.  With e = 2r/Σ: ∂_M (g_tt, g_tϕ, g_ϕϕ, g_rr) =
+            // (e, -a s² e, a² s⁴ e, 2rΣ/Δ²), so  δT_t = M' e U v^r,  δT_ϕ = -a s² δT_t,  δD_r = M'(e U² + (2rΣ/Δ²) v_r²)  and
+            //   δa^t = δT_t (B/Δ - a² s² w/Δ),   δa^ϕ = δT_t a/Δ,   δa^r = -M' r (v_r²/Δ - Δ U²/Σ²),   δa^θ = 0
+            // (δT joins the linear forms inside kerr_core, before the inverse block).  Outside the shell (M' = 0) it IS Kerr.
+            const real Mbh = P[0], Mdm = P[2], dR = P[3], rs = P[4];
+            real M = Mbh, dM = 0.0;
+            if (r >= rs + dR) {
+                M = Mbh + Mdm;
+            } else if (r >= rs) {
+                const real idR = rcp_full(dR);
+                const real xr = (r - rs) * idR;
+                M = GR_FMA(Mdm, (3.0 - 2.0 * xr) * (xr * xr), Mbh);
+                dM = (6.0 * Mdm * idR) * (xr * (1.0 - xr));
+            }
+            KerrMid k;
+            kerr_core(M, dM, r, s, c, vt, vr, vh, vp, at, ar, ah, ap, k);
+            return;
+        } else if constexpr (ID == GR_METRIC_KERR_REFRACTIVE) {
+            // Kerr with g_tt / n², g_tϕ / n inside the corona (kerr-refractive-ad.jl:8-33), n(r) = n0 + (1 - n0) t(r), t the smooth
+            // step of utils.jl:158-168.  The inverse block is (n² g^tt, n g^tϕ, g^ϕϕ), and with ṽ^t = v^t / n every Kerr form is
+            // Kerr's at (ṽ^t, v^r, v^θ, v^ϕ): g̃_tt (v^t)² = g_tt (ṽ^t)², T̃_t = T_t/n - (ṅ/n²) L, T̃_ϕ = T_ϕ - (ṅ/n) g_tϕ ṽ^t,
+            // L = 2 g_tt ṽ^t + g_tϕ v^ϕ, D̃_r = D_r - 2 (n'/n)(g_tt (ṽ^t)² + g_tϕ ṽ^t v^ϕ).  So
+            //   a^t = n a^t_K + ṅ (g^tt L + g^tϕ g_tϕ ṽ^t),   a^ϕ = a^ϕ_K + (ṅ/n)(g^tϕ L + g^ϕϕ g_tϕ ṽ^t),
+            //   a^r = a^r_K - g^rr (n'/n)(g_tt (ṽ^t)² + g_tϕ ṽ^t v^ϕ),   a^θ = a^θ_K,       ṅ = n' v^r.
+            // n' lives in the 2.5-wide band round the corona radius; outside it the metric is Kerr at a rescaled v^t.
+            const real M = P[0], n0 = P[2], rc = P[3];
+            real n = n0, dn = 0.0, in = kin0;
+            if (r <= rc - 1.25) {
+                n = 1.0; in = 1.0;
+            } else if (r <= rc + 1.25) {
+                const real z = 4e3 * (r - rc);
+                const real t = 0.5 - 0.3183098861837907 * GR_ATAN(z);
+                const real tp = -(0.3183098861837907 * 4e3) * rcp_full(GR_FMA(z, z, 1.0));
+                n = GR_FMA(1.0 - n0, t, n0);
+                dn = (1.0 - n0) * tp;
+                in = rcp_full(n);
+            }
+            const real wt = vt * in;                        // ṽ^t
+            KerrMid k;
+            kerr_core(M, 0.0, r, s, c, wt, vr, vh, vp, at, ar, ah, ap, k);
+            at = n * at;
+            if (dn != 0.0) {
+                const real gtt = k.w - 1.0, gtp = k.gtp;
+                const real gitt = -(k.B * k.iDel), gitp = gtp * k.iDs, gipp = (1.0 - k.w) * k.iDs;
+                const real Lf = GR_FMA(2.0 * gtt, wt, gtp * vp);
+                const real gw = gtp * wt;
+                const real nd = dn * vr, ndn = nd * in;
+                at = GR_FMA(nd, GR_FMA(gitt, Lf, gitp * gw), at);
+                ap = GR_FMA(ndn, GR_FMA(gitp, Lf, gipp * gw), ap);
+                ar = GR_FMA(-((k.Del * k.iSig) * (dn * in)), wt * GR_FMA(gtt, wt, gtp * vp), ar);
+            }
             return;
         } else if constexpr (ID == GR_METRIC_BUMBLEBEE) {
             const real tM = ktM, K = ktM * P[1];

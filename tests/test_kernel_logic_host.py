@@ -531,11 +531,13 @@ def test_fused_johannsen_psaltis_rhs_equals_generic_contraction(G, oracle):
     assert np.median(errs_fo) < 5e-15 and max(errs_fo) < 5e-12, (np.median(errs_fo), max(errs_fo))
 
 
-@pytest.mark.parametrize("name", ["bumblebee", "morris-thorne"])
+@pytest.mark.parametrize("name", ["bumblebee", "morris-thorne", "kerr-dark-matter", "kerr-refractive"])
 def test_fused_bumblebee_and_morris_thorne_rhs_equal_generic_contraction(G, oracle, name):
     """GenericMetricT<BUMBLEBEE>::rhs and GenericMetricT<MORRIS_THORNE>::rhs (round 4: hand-derived, gr_device.hpp) against the
     dual-number eval() + the generic contraction of the same functor and against the oracle's dual-number geodesic_equation
-    (src/metrics/bumblebee-ad.jl:6-21, morris-thorne-ad.jl:4-15 through auto-diff.jl:115-141,206-226)."""
+    (src/metrics/bumblebee-ad.jl:6-21, morris-thorne-ad.jl:4-15 through auto-diff.jl:115-141,206-226).  Kerr-dark-matter
+    (kerr-dark-matter.jl:6-49: Kerr at the enclosed mass M(r) plus the mass gradient's own terms): inside, across and outside
+    the shell."""
     import ctypes as C
 
     rng = np.random.default_rng(17)
@@ -546,6 +548,21 @@ def test_fused_bumblebee_and_morris_thorne_rhs_equal_generic_contraction(G, orac
             params = (rng.uniform(0.5, 1.5), rng.uniform(-0.29, 0.29), rng.uniform(-0.5, 2.0))
             m = G.BumblebeeMetric(*params)
             r = 1.05 * m.inner_radius() + 10.0 ** rng.uniform(-1, 3)
+        elif name == "kerr-dark-matter":
+            M_ = rng.uniform(0.5, 1.5)
+            params = (M_, M_ * rng.uniform(-0.9, 0.9), rng.uniform(0.0, 3.0), rng.uniform(5.0, 30.0), rng.uniform(5.0, 20.0))
+            m = G.KerrDarkMatter(*params)
+            # a third of the points inside the shell [rₛ, rₛ + Δr], where M'(r) != 0
+            r = (params[4] + rng.uniform(0.0, 1.0) * params[3]) if rng.random() < 0.34 else 3.0 * params[0] + 10.0 ** rng.uniform(-1, 3)
+        elif name == "kerr-refractive":
+            M_ = rng.uniform(0.5, 1.5)
+            params = (M_, M_ * rng.uniform(-0.9, 0.9), rng.uniform(0.8, 1.5), rng.uniform(8.0, 30.0))
+            m = G.KerrRefractive(*params)
+            # a third of the points inside the 2.5-wide band round the corona radius where n'(r) != 0 (most of them in the
+            # part a few 1e-4 wide where the atan step actually moves), a third inside the corona, a third outside
+            u_ = rng.random()
+            r = (params[3] + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-5.5, 0.09)) if u_ < 0.34 else (
+                rng.uniform(3.0 * M_, params[3] - 1.3) if u_ < 0.67 else params[3] + 1.3 + 10.0 ** rng.uniform(-1, 3))
         else:
             params = (rng.uniform(0.3, 3.0),)
             m = G.MorrisThorneWormhole(*params)
