@@ -959,6 +959,8 @@ struct GenericMetricT {
     // 142-168 with, no scratch: scripts/kernel_probe.sh "GenericMetricT<id>")
     // Bumblebee and Morris-Thorne with their fused right-hand sides need 167 registers (Bumblebee: with the event sampling's
     // registers parked in LDS like Kerr's, kColdRare): three waves per SIMD (GR_FUSED23_LANE_WAVES=2: the two-wave shape, A/B)
+    // (Kerr-dark-matter and Kerr-refractive, fused later in round 4, need 193: at three waves they spill 80-96 bytes and run 6.3 /
+    // 8.6 ms against 5.6 / 7.8 at 1024², 19.9 / 26.4 against 20.2 / 26.2 at 2048² -- two waves)
     static constexpr bool kSlimFused = (ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE);
     static constexpr int kLaneWavesPerSimd = kSlimFused ? GR_FUSED23_LANE_WAVES
                                              : (ID == GR_METRIC_JOHANNSEN_PSALTIS) ? GR_JP_LANE_WAVES : GR_GENERIC_LANE_WAVES;
