@@ -968,10 +968,10 @@ struct GenericMetricT {
     static constexpr int kParkStages = (!kSlimFused && kLaneWavesPerSimd >= 3) ? GR_PARK_DEFAULT : 0;
     static constexpr bool kHasForce = false;
     // rhs() below: hand-derived for Johannsen-Psaltis (round 3), for Bumblebee, Morris-Thorne, Kerr-dark-matter and Kerr-refractive
-    // (round 4; the last two as Kerr plus the terms of their r-dependent parameter) -- the other three dual-number metrics (flat
-    // space, dilaton-axion, NoZ) take eval() + the generic contraction on typed duals
+    // (round 4; the last two as Kerr plus the terms of their r-dependent parameter) and flat space -- the other two dual-number
+    // metrics (dilaton-axion, NoZ) take eval() + the generic contraction on typed duals
     static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS || ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE
-                                       || ID == GR_METRIC_KERR_DARK_MATTER || ID == GR_METRIC_KERR_REFRACTIVE);
+                                       || ID == GR_METRIC_KERR_DARK_MATTER || ID == GR_METRIC_KERR_REFRACTIVE || ID == GR_METRIC_SPHERICAL);
     int32_t id;
     real P[6];
     real ka2, ktM, keps;      // Johannsen-Psaltis rhs(): a², 2M, ϵ3 M³ -- uniform, formed once
@@ -1317,6 +1317,18 @@ struct GenericMetricT {
             ar = l * GR_FMA(s, vp2, vh * vh);
             ah = GR_FMA(-(tl * iw), vr * vh, (0.5 * c) * vp2);
             ap = -(GR_FMA(tl * iw, vr, (c * is) * vh) * vp);
+            return;
+        } else if constexpr (ID == GR_METRIC_SPHERICAL) {
+            // flat space in spherical coordinates (minkowski.jl:4-13): g = diag(-1, 1, r², r² s²), so
+            //   a^t = 0,  a^r = r (v_θ² + s² v_ϕ²),  a^θ = -2 v_r v_θ / r + s c v_ϕ²,  a^ϕ = -2 (v_r / r + (c/s) v_θ) v_ϕ.
+            // One reciprocal, 1/(r s), shared by 1/r and 1/s.
+            const real R = rcp_rhs(r * s);
+            const real ir = R * s, is = R * r;
+            const real vp2 = vp * vp;
+            at = 0.0;
+            ar = r * GR_FMA(s * s, vp2, vh * vh);
+            ah = GR_FMA(-(2.0 * ir), vr * vh, (s * c) * vp2);
+            ap = -(2.0 * GR_FMA(ir, vr, (c * is) * vh) * vp);
             return;
         } else if constexpr (ID == GR_METRIC_KERR_DARK_MATTER) {
             // Kerr with the enclosed mass M(r) (kerr-dark-matter.jl:6-49): every component depends on r through M as well, so
