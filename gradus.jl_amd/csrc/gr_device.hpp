@@ -968,15 +968,17 @@ struct GenericMetricT {
     static constexpr int kParkStages = (!kSlimFused && kLaneWavesPerSimd >= 3) ? GR_PARK_DEFAULT : 0;
     static constexpr bool kHasForce = false;
     // rhs() below: hand-derived for Johannsen-Psaltis (round 3), for Bumblebee, Morris-Thorne, Kerr-dark-matter and Kerr-refractive
-    // (round 4; the last two as Kerr plus the terms of their r-dependent parameter) and flat space -- the other two dual-number
-    // metrics (dilaton-axion, NoZ) take eval() + the generic contraction on typed duals
+    // (round 4; the last two as Kerr plus the terms of their r-dependent parameter), flat space and dilaton-axion -- NoZ alone
+    // takes eval() + the generic contraction, on typed duals
     static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS || ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE
-                                       || ID == GR_METRIC_KERR_DARK_MATTER || ID == GR_METRIC_KERR_REFRACTIVE || ID == GR_METRIC_SPHERICAL);
+                                       || ID == GR_METRIC_KERR_DARK_MATTER || ID == GR_METRIC_KERR_REFRACTIVE || ID == GR_METRIC_SPHERICAL
+                                       || ID == GR_METRIC_DILATON_AXION);
     int32_t id;
     real P[6];
     real ka2, ktM, keps;      // Johannsen-Psaltis rhs(): a², 2M, ϵ3 M³ -- uniform, formed once
     real kik;                 // Bumblebee rhs(): 1/(1 + l)
     real kin0;                // Kerr-refractive rhs(): 1/n
+    real kd_bab, kd_N0, kd_c1, kd_c2, kd_tk2a;      // dilaton-axion rhs(): uniform combinations of (M, a, β, b), see there
     GR_DEV void load(const gr_config& c)
     {
         id = ID >= 0 ? ID : c.metric_id;
@@ -985,6 +987,18 @@ struct GenericMetricT {
         ka2 = uni(P[1] * P[1]); ktM = uni(2.0 * P[0]); keps = uni(P[2] * P[0] * P[0] * P[0]);
         kik = (ID == GR_METRIC_BUMBLEBEE) ? uni(rcp_full(1.0 + P[2])) : (real)0.0;
         kin0 = (ID == GR_METRIC_KERR_REFRACTIVE) ? uni(rcp_full(P[2])) : (real)0.0;
+        kd_bab = kd_N0 = kd_c1 = kd_c2 = kd_tk2a = 0.0;
+        if constexpr (ID == GR_METRIC_DILATON_AXION) {
+            const real M = P[0], a = P[1], be = P[2], b = P[3];
+            const bool z = (be == 0.0);
+            const real bb = z ? 0.0 : be * rcp_full(b), ba = z ? 0.0 : be * rcp_full(a), bab = z ? 0.0 : be * rcp_full(a * b);
+            const real k1 = M * (M + 2.0 * b) * bb * bb, k2 = M * M * bb;
+            kd_bab = uni(bab);
+            kd_N0 = uni(ba * ba - bab * bab);
+            kd_c1 = uni(a * a - be * be - k1);
+            kd_c2 = uni(a * a - be * be + k2 * bb);
+            kd_tk2a = uni(2.0 * k2 * a);
+        }
     }
     static GR_DEV real inv_(real x) { return rcp_full(x); }
     template <bool A, bool B> static GR_DEV DualP<A, B> inv_(DualP<A, B> x) { return dinv(x); }
@@ -1329,6 +1343,70 @@ struct GenericMetricT {
             ar = r * GR_FMA(s * s, vp2, vh * vh);
             ah = GR_FMA(-(2.0 * ir), vr * vh, (s * c) * vp2);
             ap = -(2.0 * GR_FMA(ir, vr, (c * is) * vh) * vp);
+            return;
+        } else if constexpr (ID == GR_METRIC_DILATON_AXION) {
+            // Dilaton-axion (dilaton-axion-ad.jl:8-46).  With Δh(r), del(r) = r² - 2br + a², W(θ) = 1 + (β/(ab) (2c - β/(ab)) + (β/a)²)/s²
+            // and Σh(r, θ) the components are g_tt = -P/Σh, g_tϕ = -Q/Σh, g_ϕϕ = Φ/Σh, g_rr = Σh/Δh, g_θθ = Σh with
+            //   P = Δh - a² s²,   Q = a s² (del - Δh W),   Φ = s² (del² - Δh a² W² s²),
+            // and the t-ϕ block has the determinant -Δh s² K²/Σh², K = del - a² s² W (a perfect square, as for Kerr where W = 1).  So with
+            // J = 1/(Δh s² K²), H_t = -(Ṗ v^t + Q̇ v^ϕ), H_ϕ = Φ̇ v^ϕ - Q̇ v^t (dots: along (v^r, v^θ)) and p_t, p_ϕ dropping out
+            // (g^tμ p_μ = v^t):
+            //   a^t = J (Φ H_t + Q H_ϕ) + (Σ̇h/Σh) v^t,     a^ϕ = J (Q H_t - P H_ϕ) + (Σ̇h/Σh) v^ϕ,
+            //   a^r = -(1/Σh)[½Σh_r v_r² + Σh_θ v_r v_θ - ½ Σh Δh_r v_r²/Δh] + ½ (Δh/Σh²)(B_r - Σh_r B/Σh) + ½ Σh_r Δh v_θ²/Σh,
+            //   a^θ = -(1/Σh)[Σh_r v_r v_θ + ½ Σh_θ (v_θ² - v_r²/Δh) - ½ (B_θ - Σh_θ B/Σh)/Σh],
+            // B = -P v_t² - 2Q v_t v_ϕ + Φ v_ϕ² and B_r, B_θ the same form on the partials.  Two reciprocals (1/s² for W; 1/(Σh Δh s² K²)
+            // shared by 1/Σh, 1/Δh and J) where the dual-number form takes four.  Equal to eval() + the generic contraction to rounding
+            // (tests/test_kernel_logic_host.py).
+            const real a = P[1], b = P[3];
+            const real a2 = ka2;
+            const real s2 = s * s, S2 = 2.0 * (s * c);
+            const real is2 = rcp_rhs(s2);
+            const real Wm1 = GR_FMA(2.0 * kd_bab, c, kd_N0) * is2;          // W - 1
+            const real W = 1.0 + Wm1;
+            const real W_h = -(GR_FMA(2.0 * kd_bab, s, Wm1 * S2) * is2);    // ∂_θ W
+            const real r2 = r * r;
+            const real rb = GR_FMA(-2.0 * b, r, r2);                        // r² - 2br
+            const real del = rb + a2;
+            const real Dh = GR_FMA(-ktM, r, rb) + kd_c1;                    // Δh
+            const real Sh = GR_FMA(-a2, s2, rb) + GR_FMA(-kd_tk2a, c, kd_c2);   // Σh
+            const real rp = 2.0 * (r - b);                                  // del' = ∂_r Σh
+            const real Dh_r = rp - ktM;
+            const real Sh_h = GR_FMA(kd_tk2a, s, -(a2 * S2));               // ∂_θ Σh
+            const real aW = a * W;
+            const real G = (aW * aW) * s2;                                  // a² W² s²
+            const real E = GR_FMA(-Dh, W, del);                             // del - Δh W
+            const real K = GR_FMA(-(a2 * s2), W, del);
+            const real Pq = GR_FMA(-a2, s2, Dh);
+            const real as2 = a * s2;
+            const real Q = as2 * E;
+            const real F = GR_FMA(-Dh, G, del * del);
+            const real Phi = s2 * F;
+            const real P_h = -(a2 * S2);
+            const real Q_r = as2 * GR_FMA(-Dh_r, W, rp);
+            const real Q_h = a * GR_FMA(S2, E, -(s2 * (Dh * W_h)));
+            const real Phi_r = s2 * GR_FMA(2.0 * del, rp, -(Dh_r * G));
+            const real G_h = a2 * (W * GR_FMA(2.0 * W_h, s2, W * S2));      // ∂_θ (a² W² s²)
+            const real Phi_h = GR_FMA(S2, F, -(s2 * (Dh * G_h)));
+            const real K2 = K * K;
+            const real DsK = (Dh * s2) * K2;
+            const real R = rcp_rhs(Sh * DsK);
+            const real iSh = R * DsK, J = R * Sh, iDh = J * (s2 * K2);
+            const real Pd = GR_FMA(Dh_r, vr, P_h * vh), Qd = GR_FMA(Q_r, vr, Q_h * vh), Phd = GR_FMA(Phi_r, vr, Phi_h * vh);
+            const real Shd = GR_FMA(rp, vr, Sh_h * vh);
+            const real Ht = -GR_FMA(Pd, vt, Qd * vp);
+            const real Hp = GR_FMA(Phd, vp, -(Qd * vt));
+            const real sl = Shd * iSh;
+            at = GR_FMA(J, GR_FMA(Phi, Ht, Q * Hp), sl * vt);
+            ap = GR_FMA(J, GR_FMA(Q, Ht, -(Pq * Hp)), sl * vp);
+            const real vt2 = vt * vt, vtp2 = 2.0 * (vt * vp), vp2 = vp * vp, vr2 = vr * vr, vh2 = vh * vh, vrvh = vr * vh;
+            const real B0 = GR_FMA(Phi, vp2, -GR_FMA(Pq, vt2, Q * vtp2));
+            const real Br = GR_FMA(Phi_r, vp2, -GR_FMA(Dh_r, vt2, Q_r * vtp2));
+            const real Bh = GR_FMA(Phi_h, vp2, -GR_FMA(P_h, vt2, Q_h * vtp2));
+            const real B0i = B0 * iSh;
+            const real vr2iD = vr2 * iDh;
+            ar = iSh * (GR_FMA(0.5 * (Dh * iSh), GR_FMA(-rp, B0i, Br), (0.5 * rp) * (Dh * vh2))
+                        - GR_FMA(0.5 * rp, vr2, GR_FMA(Sh_h, vrvh, -((0.5 * Sh) * (Dh_r * vr2iD)))));
+            ah = -(iSh * (GR_FMA(rp, vrvh, (0.5 * Sh_h) * (vh2 - vr2iD)) - (0.5 * iSh) * GR_FMA(-Sh_h, B0i, Bh)));
             return;
         } else if constexpr (ID == GR_METRIC_KERR_DARK_MATTER) {
             // Kerr with the enclosed mass M(r) (kerr-dark-matter.jl:6-49): every component depends on r through M as well, so

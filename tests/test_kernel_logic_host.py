@@ -531,7 +531,7 @@ def test_fused_johannsen_psaltis_rhs_equals_generic_contraction(G, oracle):
     assert np.median(errs_fo) < 5e-15 and max(errs_fo) < 5e-12, (np.median(errs_fo), max(errs_fo))
 
 
-@pytest.mark.parametrize("name", ["bumblebee", "morris-thorne", "kerr-dark-matter", "kerr-refractive", "spherical"])
+@pytest.mark.parametrize("name", ["bumblebee", "morris-thorne", "kerr-dark-matter", "kerr-refractive", "spherical", "dilaton-axion"])
 def test_fused_bumblebee_and_morris_thorne_rhs_equal_generic_contraction(G, oracle, name):
     """GenericMetricT<BUMBLEBEE>::rhs and GenericMetricT<MORRIS_THORNE>::rhs (round 4: hand-derived, gr_device.hpp) against the
     dual-number eval() + the generic contraction of the same functor and against the oracle's dual-number geodesic_equation
@@ -554,6 +554,10 @@ def test_fused_bumblebee_and_morris_thorne_rhs_equal_generic_contraction(G, orac
             m = G.KerrDarkMatter(*params)
             # a third of the points inside the shell [rₛ, rₛ + Δr], where M'(r) != 0
             r = (params[4] + rng.uniform(0.0, 1.0) * params[3]) if rng.random() < 0.34 else 3.0 * params[0] + 10.0 ** rng.uniform(-1, 3)
+        elif name == "dilaton-axion":
+            params = (rng.uniform(0.5, 1.5), rng.uniform(0.05, 0.9) * rng.choice([-1, 1]), rng.choice([0.0, rng.uniform(-0.5, 0.5)]), rng.uniform(0.2, 1.5))
+            m = G.DilatonAxion(*params)
+            r = 1.1 * m.inner_radius() + 10.0 ** rng.uniform(-1, 3)
         elif name == "spherical":
             params = ()
             m = G.SphericalMetric()
