@@ -952,6 +952,14 @@ struct JohannsenMetric {
 #ifndef GR_FUSED23_LANE_WAVES
 #define GR_FUSED23_LANE_WAVES 3
 #endif
+// The fused dilaton-axion form shares one reciprocal of Σh Δh s² K² between 1/Σh, 1/Δh and the inverse t-ϕ block: in single precision
+// that costs rays near the horizon (the fp32 soak flags 1089 rays instead of 875 with it, profiles/r4z_soak32_2600_fp32_fused_dilaton_axion.txt) -- the fp32
+// kernels keep the dual-number form for this metric, as they keep the inverse components formed first for Kerr
+#ifdef GR_REAL_IS_FLOAT
+#define GR_DA_FUSED false
+#else
+#define GR_DA_FUSED true
+#endif
 template <int ID>
 struct GenericMetricT {
     static constexpr int kMinWavesPerSimd = GR_GENERIC_MIN_WAVES;
@@ -972,7 +980,7 @@ struct GenericMetricT {
     // takes eval() + the generic contraction, on typed duals
     static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS || ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE
                                        || ID == GR_METRIC_KERR_DARK_MATTER || ID == GR_METRIC_KERR_REFRACTIVE || ID == GR_METRIC_SPHERICAL
-                                       || ID == GR_METRIC_DILATON_AXION);
+                                       || (ID == GR_METRIC_DILATON_AXION && GR_DA_FUSED));
     int32_t id;
     real P[6];
     real ka2, ktM, keps;      // Johannsen-Psaltis rhs(): a², 2M, ϵ3 M³ -- uniform, formed once
