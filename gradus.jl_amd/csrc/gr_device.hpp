@@ -976,17 +976,19 @@ struct GenericMetricT {
     static constexpr int kParkStages = (!kSlimFused && kLaneWavesPerSimd >= 3) ? GR_PARK_DEFAULT : 0;
     static constexpr bool kHasForce = false;
     // rhs() below: hand-derived for Johannsen-Psaltis (round 3), for Bumblebee, Morris-Thorne, Kerr-dark-matter and Kerr-refractive
-    // (round 4; the last two as Kerr plus the terms of their r-dependent parameter), flat space and dilaton-axion -- NoZ alone
-    // takes eval() + the generic contraction, on typed duals
+    // (round 4; the last two as Kerr plus the terms of their r-dependent parameter), flat space, dilaton-axion and NoZ: every metric
+    // of the catalogue.  eval() + the generic contraction on typed duals remains as the definition the fused forms are tested
+    // against (tests/test_kernel_logic_host.py), as the fp32 kernels' form for dilaton-axion and NoZ, and under GR_NO_FUSED_RHS
     static constexpr bool kFusedRhs = (ID == GR_METRIC_JOHANNSEN_PSALTIS || ID == GR_METRIC_BUMBLEBEE || ID == GR_METRIC_MORRIS_THORNE
                                        || ID == GR_METRIC_KERR_DARK_MATTER || ID == GR_METRIC_KERR_REFRACTIVE || ID == GR_METRIC_SPHERICAL
-                                       || (ID == GR_METRIC_DILATON_AXION && GR_DA_FUSED));
+                                       || (ID == GR_METRIC_DILATON_AXION && GR_DA_FUSED) || (ID == GR_METRIC_NOZ && GR_DA_FUSED));
     int32_t id;
     real P[6];
     real ka2, ktM, keps;      // Johannsen-Psaltis rhs(): a², 2M, ϵ3 M³ -- uniform, formed once
     real kik;                 // Bumblebee rhs(): 1/(1 + l)
     real kin0;                // Kerr-refractive rhs(): 1/n
     real kd_bab, kd_N0, kd_c1, kd_c2, kd_tk2a;      // dilaton-axion rhs(): uniform combinations of (M, a, β, b), see there
+    real kn_eMa;              // NoZ rhs(): ϵ M a
     GR_DEV void load(const gr_config& c)
     {
         id = ID >= 0 ? ID : c.metric_id;
@@ -995,6 +997,7 @@ struct GenericMetricT {
         ka2 = uni(P[1] * P[1]); ktM = uni(2.0 * P[0]); keps = uni(P[2] * P[0] * P[0] * P[0]);
         kik = (ID == GR_METRIC_BUMBLEBEE) ? uni(rcp_full(1.0 + P[2])) : (real)0.0;
         kin0 = (ID == GR_METRIC_KERR_REFRACTIVE) ? uni(rcp_full(P[2])) : (real)0.0;
+        kn_eMa = (ID == GR_METRIC_NOZ) ? uni(P[2] * P[0] * P[1]) : (real)0.0;
         kd_bab = kd_N0 = kd_c1 = kd_c2 = kd_tk2a = 0.0;
         if constexpr (ID == GR_METRIC_DILATON_AXION) {
             const real M = P[0], a = P[1], be = P[2], b = P[3];
@@ -1415,6 +1418,76 @@ struct GenericMetricT {
             ar = iSh * (GR_FMA(0.5 * (Dh * iSh), GR_FMA(-rp, B0i, Br), (0.5 * rp) * (Dh * vh2))
                         - GR_FMA(0.5 * rp, vr2, GR_FMA(Sh_h, vrvh, -((0.5 * Sh) * (Dh_r * vr2iD)))));
             ah = -(iSh * (GR_FMA(rp, vrvh, (0.5 * Sh_h) * (vh2 - vr2iD)) - (0.5 * iSh) * GR_FMA(-Sh_h, B0i, Bh)));
+            return;
+        } else if constexpr (ID == GR_METRIC_NOZ && GR_DA_FUSED) {
+            // NoZ (noz-metric.jl:7-47; y = cosθ, η = ϵ M a y, S = r² + a² y², Se = S + η, D = S² + (S - 2Mr) η): g_tt = h_tt/D,
+            // g_tϕ = h_tϕ/D, g_ϕϕ = h_ϕϕ/D with h_tt = 2Mr S - D, h_tϕ = -a 2Mr s² Se, h_ϕϕ = s² Se big; g_rr = Se/Δ, g_θθ = Se.  The t-ϕ
+            // block has the determinant -s² Δ Se²/D (Δ = r² - 2Mr + a², Kerr's), so g^tt = -big/(Δ Se), g^tϕ = -a 2Mr/(Δ Se),
+            // g^ϕϕ = -h_tt/(s² Δ Se²), and with H_t = ḣ_tt v^t + ḣ_tϕ v^ϕ, H_ϕ = ḣ_tϕ v^t + ḣ_ϕϕ v^ϕ (p_t, p_ϕ drop out: g^tμ p_μ = v^t):
+            //   a^t = (big H_t + a 2Mr H_ϕ)/(D Δ Se) + (Ḋ/D) v^t,     a^ϕ = (a 2Mr H_t + h_tt H_ϕ/(s² Se))/(D Δ Se) + (Ḋ/D) v^ϕ,
+            //   a^r = -(Δ/Se)[½ 2r v_r²/Δ + Se_θ v_r v_θ/Δ - ½ Se Δ_r v_r²/Δ² - ½ (B_r - D_r B/D)/D - ½ 2r v_θ²],
+            //   a^θ = -(1/Se)[2r v_r v_θ + ½ Se_θ (v_θ² - v_r²/Δ) - ½ (B_θ - D_θ B/D)/D],      B = h_tt v_t² + 2 h_tϕ v_t v_ϕ + h_ϕϕ v_ϕ².
+            // One reciprocal (of D Δ Se s²) where the dual-number form takes four.  No reflection symmetry: the θ partials are
+            // -s times the y partials, odd and even powers of y both present.
+            const real a = P[1];
+            const real a2 = ka2, tM = ktM, kE = kn_eMa;
+            const real y = c, s2 = s * s;
+            const real eps = kE * y;
+            const real r2 = r * r;
+            const real a2y = a2 * y;
+            const real a2y2 = a2y * y;
+            const real S = r2 + a2y2;
+            const real tMr = tM * r;
+            const real Se = S + eps;
+            const real SmT = S - tMr;
+            const real D = GR_FMA(S, S, SmT * eps);
+            const real Del = GR_FMA(-tM, r, r2) + a2;
+            const real tr = 2.0 * r;
+            const real S_y = 2.0 * a2y;
+            const real Se_y = S_y + kE;
+            const real D_r = GR_FMA(2.0 * tr, S, (tr - tM) * eps);
+            const real D_y = GR_FMA(S_y, 2.0 * S + eps, SmT * kE);
+            const real q1 = a2 + a2y2 + eps, q2 = a2 - a2y2 - eps;
+            const real a4 = a2 * a2;
+            const real big = GR_FMA(r2, r2 + q1, GR_FMA(a4, y * y, GR_FMA(a2, eps, tMr * q2)));
+            const real big_r = GR_FMA(tr, 2.0 * r2 + q1, tM * q2);
+            const real big_y = GR_FMA(2.0 * a4, y, GR_FMA(r2 - tMr, Se_y, a2 * kE));
+            const real htt = GR_FMA(tMr, S, -D);
+            const real htt_r = GR_FMA(tM, S, GR_FMA(tMr, tr, -D_r));
+            const real htt_y = GR_FMA(tMr, S_y, -D_y);
+            const real atM = a * tMr;
+            const real htp = -(atM * (s2 * Se));
+            const real htp_r = -((a * s2) * GR_FMA(tM, Se, tMr * tr));
+            const real htp_y = -(atM * GR_FMA(-2.0 * y, Se, s2 * Se_y));
+            const real Sb = Se * big;
+            const real hpp = s2 * Sb;
+            const real hpp_r = s2 * GR_FMA(tr, big, Se * big_r);
+            const real hpp_y = GR_FMA(-2.0 * y, Sb, s2 * GR_FMA(Se_y, big, Se * big_y));
+            const real DlS = Del * Se;
+            const real R = rcp_rhs((D * DlS) * s2);
+            const real J1 = R * s2;                      // 1/(D Δ Se)
+            const real iD = R * (DlS * s2);
+            const real is2Se = R * (D * Del);            // 1/(s² Se)
+            const real iSe = is2Se * s2;
+            const real iDel = R * ((D * Se) * s2);
+            const real yd = -(s * vh);                   // ẏ
+            const real Dd = GR_FMA(D_r, vr, D_y * yd);
+            const real httd = GR_FMA(htt_r, vr, htt_y * yd), htpd = GR_FMA(htp_r, vr, htp_y * yd), hppd = GR_FMA(hpp_r, vr, hpp_y * yd);
+            const real Ht = GR_FMA(httd, vt, htpd * vp), Hp = GR_FMA(htpd, vt, hppd * vp);
+            const real dl = Dd * iD;
+            at = GR_FMA(J1, GR_FMA(big, Ht, atM * Hp), dl * vt);
+            ap = GR_FMA(J1, GR_FMA(atM, Ht, (htt * is2Se) * Hp), dl * vp);
+            const real vt2 = vt * vt, vtp2 = 2.0 * (vt * vp), vp2 = vp * vp, vr2 = vr * vr, vh2 = vh * vh, vrvh = vr * vh;
+            const real B0 = GR_FMA(htt, vt2, GR_FMA(htp, vtp2, hpp * vp2));
+            const real Br = GR_FMA(htt_r, vt2, GR_FMA(htp_r, vtp2, hpp_r * vp2));
+            const real By = GR_FMA(htt_y, vt2, GR_FMA(htp_y, vtp2, hpp_y * vp2));
+            const real B0i = B0 * iD;
+            const real Se_h = -(s * Se_y);               // ∂_θ Se
+            const real vr2iD = vr2 * iDel;
+            const real Del_r = tr - tM;
+            ar = -((Del * iSe) * (GR_FMA(0.5 * tr, vr2iD - vh2, GR_FMA(Se_h * iDel, vrvh, -((0.5 * Se) * (Del_r * iDel)) * vr2iD))
+                                  - (0.5 * iD) * GR_FMA(-D_r, B0i, Br)));
+            ah = -(iSe * (GR_FMA(tr, vrvh, (0.5 * Se_h) * (vh2 - vr2iD)) + (0.5 * (s * iD)) * GR_FMA(-D_y, B0i, By)));
             return;
         } else if constexpr (ID == GR_METRIC_KERR_DARK_MATTER) {
             // Kerr with the enclosed mass M(r) (kerr-dark-matter.jl:6-49): every component depends on r through M as well, so

@@ -18,6 +18,7 @@ PROF_CMD="scripts/sibling_workloads.py dual2" PROF_KERNEL="k_trace_lane<gr::Gene
 PROF_CMD="scripts/sibling_workloads.py dual6" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<6>" bash scripts/profile_pmc.sh ${T}_dilatonaxion
 PROF_CMD="scripts/sibling_workloads.py dual8" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<8>" bash scripts/profile_pmc.sh ${T}_kerrdarkmatter
 PROF_CMD="scripts/sibling_workloads.py dual9" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<9>" bash scripts/profile_pmc.sh ${T}_kerrrefractive
+PROF_CMD="scripts/sibling_workloads.py dual10" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<10>" bash scripts/profile_pmc.sh ${T}_noz
 PROF_CMD="scripts/sibling_workloads.py mesh" PROF_KERNEL="k_trace_lane<gr::KerrFamily<false>, 8>" bash scripts/profile_pmc.sh ${T}_mesh
 # drop the bulky raw traces, keep summaries
 for d in gpurun_out/prof_${T}_*; do rm -rf $d/trace $d/pmcA $d/pmcB $d/pmcC $d/pmcD; done

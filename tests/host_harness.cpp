@@ -157,6 +157,10 @@ int hh_rhs_both(const gr_config* cfg, double r, double th, const double* v, doub
         GenericMetricT<GR_METRIC_DILATON_AXION> m; m.load(*cfg);
         m.rhs(r, s, c, v[0], v[1], v[2], v[3], fused[0], fused[1], fused[2], fused[3]);
         geodesic_rhs_generic(m, r, s, c, v[0], v[1], v[2], v[3], generic[0], generic[1], generic[2], generic[3]);
+    } else if (cfg->metric_id == GR_METRIC_NOZ) {
+        GenericMetricT<GR_METRIC_NOZ> m; m.load(*cfg);
+        m.rhs(r, s, c, v[0], v[1], v[2], v[3], fused[0], fused[1], fused[2], fused[3]);
+        geodesic_rhs_generic(m, r, s, c, v[0], v[1], v[2], v[3], generic[0], generic[1], generic[2], generic[3]);
     } else if (cfg->metric_id == GR_METRIC_SPHERICAL) {
         GenericMetricT<GR_METRIC_SPHERICAL> m; m.load(*cfg);
         m.rhs(r, s, c, v[0], v[1], v[2], v[3], fused[0], fused[1], fused[2], fused[3]);

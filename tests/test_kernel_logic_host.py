@@ -531,7 +531,7 @@ def test_fused_johannsen_psaltis_rhs_equals_generic_contraction(G, oracle):
     assert np.median(errs_fo) < 5e-15 and max(errs_fo) < 5e-12, (np.median(errs_fo), max(errs_fo))
 
 
-@pytest.mark.parametrize("name", ["bumblebee", "morris-thorne", "kerr-dark-matter", "kerr-refractive", "spherical", "dilaton-axion"])
+@pytest.mark.parametrize("name", ["bumblebee", "morris-thorne", "kerr-dark-matter", "kerr-refractive", "spherical", "dilaton-axion", "noz"])
 def test_fused_bumblebee_and_morris_thorne_rhs_equal_generic_contraction(G, oracle, name):
     """GenericMetricT<BUMBLEBEE>::rhs and GenericMetricT<MORRIS_THORNE>::rhs (round 4: hand-derived, gr_device.hpp) against the
     dual-number eval() + the generic contraction of the same functor and against the oracle's dual-number geodesic_equation
@@ -558,6 +558,11 @@ def test_fused_bumblebee_and_morris_thorne_rhs_equal_generic_contraction(G, orac
             params = (rng.uniform(0.5, 1.5), rng.uniform(0.05, 0.9) * rng.choice([-1, 1]), rng.choice([0.0, rng.uniform(-0.5, 0.5)]), rng.uniform(0.2, 1.5))
             m = G.DilatonAxion(*params)
             r = 1.1 * m.inner_radius() + 10.0 ** rng.uniform(-1, 3)
+        elif name == "noz":
+            M_ = rng.uniform(0.5, 1.5)
+            params = (M_, M_ * rng.uniform(-0.9, 0.9), rng.uniform(-0.5, 0.5))
+            m = G.NoZMetric(*params)
+            r = 1.2 * m.inner_radius() + 10.0 ** rng.uniform(-1, 3)
         elif name == "spherical":
             params = ()
             m = G.SphericalMetric()
