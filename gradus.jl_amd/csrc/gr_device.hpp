@@ -954,7 +954,8 @@ struct JohannsenMetric {
 #endif
 // The fused dilaton-axion form shares one reciprocal of Σh Δh s² K² between 1/Σh, 1/Δh and the inverse t-ϕ block: in single precision
 // that costs rays near the horizon (the fp32 soak flags 1089 rays instead of 875 with it, profiles/r4z_soak32_2600_fp32_fused_dilaton_axion.txt) -- the fp32
-// kernels keep the dual-number form for this metric, as they keep the inverse components formed first for Kerr
+// kernels keep the dual-number form for this metric, as they keep the inverse components formed first for Kerr -- and for NoZ, whose
+// fused form is built the same way (one reciprocal of D Δ Se s²) and was not tried in single precision
 #ifdef GR_REAL_IS_FLOAT
 #define GR_DA_FUSED false
 #else
