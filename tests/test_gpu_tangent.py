@@ -86,12 +86,18 @@ def test_device_tangents_equal_the_host_build(G, ens):
     np.testing.assert_allclose(same[hit, 1], pts["x"][hit, 1], rtol=1e-8)
 
 
-@pytest.mark.parametrize("name", ["kerr", "johannsen", "kerr-newman", "johannsen-psaltis"])
+@pytest.mark.parametrize("name", ["kerr", "johannsen", "kerr-newman", "johannsen-psaltis", "bumblebee", "dilaton-axion"])
 def test_device_tangents_equal_central_differences(G, ens, name):
-    """Per metric family (fused Kerr RHS, fused Johannsen RHS, generic dual-number functor -- here dual numbers of dual
-    numbers): the tangents against central differences of the fp64 device path at tolerance 1e-12."""
+    """Per metric family (the hand-fused right-hand sides evaluated on value + tangent scalars: Kerr, Johannsen, the Kerr core with
+    an r-dependent mass / index, the closed-determinant forms): the tangents against central differences of the fp64 device path
+    at tolerance 1e-12."""
     m = {"kerr": G.KerrMetric(1.0, 0.9), "johannsen": G.JohannsenMetric(1.0, 0.7, 1.0, 0.0, 0.0, 0.5),
-         "kerr-newman": G.KerrNewmanMetric(1.0, 0.6, 0.5), "johannsen-psaltis": G.JohannsenPsaltisMetric(1.0, 0.6, 1.0)}[name]
+         "kerr-newman": G.KerrNewmanMetric(1.0, 0.6, 0.5), "johannsen-psaltis": G.JohannsenPsaltisMetric(1.0, 0.6, 1.0),
+         "bumblebee": G.BumblebeeMetric(1.0, 0.2, 0.3), "dilaton-axion": G.DilatonAxion(1.0, 0.5, 0.2, 0.8)}[name]
+    # (Kerr-dark-matter and Kerr-refractive are not in the list: central differences through the kinks of the enclosed mass and
+    # through the 1e-4-wide index step are no reference at this bound -- 6.1e-5 of the scale for Kerr-refractive with its fused
+    # right-hand side, 5.1e-5 with the dual-number one, against the 5e-5 asked here; their fused forms are pinned at the level
+    # of the right-hand side, tests/test_kernel_logic_host.py)
     x = np.array([0.0, 1000.0, math.radians(55), 0.0])
     rng = np.random.default_rng(11)
     al, be = rng.uniform(-10, 10, 64), rng.uniform(3, 12, 64) * rng.choice([-1, 1], 64)
