@@ -34,7 +34,15 @@ inline int64_t cell_of(double x, double origin, double icell, int64_t n)
     return f >= (double)n ? n - 1 : (int64_t)f;
 }
 
-// src: 6 extents + 9 n doubles (gr_config.disc_table); out: the table above
+// every vertex finite?  (an infinite one would make the grid's cell search below run for ever; the extents may be infinite)
+inline bool vertices_finite(const double* src, int64_t n)
+{
+    for (int64_t i = 6; i < 6 + 9 * n; ++i)
+        if (!std::isfinite(src[i])) return false;
+    return true;
+}
+
+// src: 6 extents + 9 n doubles (gr_config.disc_table), vertices finite; out: the table above
 inline void build_table(const double* src, int64_t n, std::vector<double>& out)
 {
     const double* tri = src + 6;

@@ -265,6 +265,7 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
         const int64_t n = p.cfg.disc_table_n;
         const uint64_t fp = gr_mesh::fingerprint(p.cfg.disc_table, n);
         if (ctx->mesh_n != n || ctx->mesh_fp != fp || !ctx->d_mesh) {
+            if (!gr_mesh::vertices_finite(p.cfg.disc_table, n)) return fail(GR_ERR_INVALID_ARGUMENT, "the mesh has a vertex that is not finite");
             gr_mesh::build_table(p.cfg.disc_table, n, ctx->mesh_host);
             const size_t mb = sizeof(double) * ctx->mesh_host.size();
             ctx->mesh_n = -1;

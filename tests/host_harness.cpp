@@ -39,6 +39,7 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
     p.disc_table = p.cfg.disc_table;      // host pointer is directly usable here
     static thread_local std::vector<double> mesh_table;
     if (p.cfg.disc_id == GR_DISC_MESH) {  // ... a mesh goes through the builder the host unit uses (gr_mesh_grid.hpp)
+        if (!gr_mesh::vertices_finite(p.cfg.disc_table, p.cfg.disc_table_n)) return;
         gr_mesh::build_table(p.cfg.disc_table, p.cfg.disc_table_n, mesh_table);
         p.disc_table = mesh_table.data();
     }

@@ -349,6 +349,10 @@ def test_mesh_is_refused_where_it_is_not_built(G, ens):
     e32 = G.EnsembleMI355X(0, precision=32)
     with pytest.raises(G.GradusMI355XError, match="fp64"):
         G.tracegeodesics(m, X_OBS, v, d, (0.0, 2000.0), ensemble=e32)
+    bad = SCENES["cube beside the hole"]().copy()
+    bad[3, 1, 2] = np.inf
+    with pytest.raises(G.GradusMI355XError, match="not finite"):
+        G.tracegeodesics(m, X_OBS, v, G.MeshAccretionGeometry(bad, x_extent=(-1, 1), y_extent=(-1, 1), z_extent=(-1, 1)), (0.0, 2000.0), ensemble=ens)
     # a valid call on the same context afterwards
     out = G.tracegeodesics(m, X_OBS, v, d, (0.0, 2000.0), ensemble=ens)
     assert out["status"].size == 64
