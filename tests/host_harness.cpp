@@ -225,4 +225,41 @@ int64_t hh_step_log(const gr_config* cfg, const gr_plane* plane, int64_t i, gr_p
     dispatch(p, tlog, hlog, cap, &n);
     return n;
 }
+
+// The grid of GR_DISC_MESH against the reference's loop, for one point: how many triangles have their first vertex within 3 of
+// `q` (the whole list walked, meshes.jl:53-64), how many of those the grid walk of the kernels reaches (gr_mesh_grid.hpp +
+// Ray::mesh_cells: must be all of them), and how many triangles the grid walk visits in all.  table: 6 extents + 9 n doubles.
+int hh_mesh_candidates(const double* table, int64_t n, const double* q, int64_t* out3)
+{
+    if (!gr_mesh::vertices_finite(table, n)) return -1;
+    std::vector<double> tb;
+    gr_mesh::build_table(table, n, tb);
+    typedef Ray<KerrMetric, GR_DISC_MESH> R;
+    const real Q2[3] = { q[0], q[1], q[2] };
+    int lo[3], hi[3];
+    R::mesh_cells(tb.data(), Q2, lo, hi);
+    const int nx = (int)tb[10], ny = (int)tb[11];
+    const uint32_t* cs = reinterpret_cast<const uint32_t*>(tb.data() + 16);
+    const double* T0 = tb.data() + (int64_t)tb[13];
+    int64_t brute = 0, visited = 0, reached = 0;
+    std::vector<char> seen((size_t)n, 0);           // by sorted slot
+    if (hi[0] >= lo[0])
+        for (int iz = lo[2]; iz <= hi[2]; ++iz)
+            for (int iy = lo[1]; iy <= hi[1]; ++iy) {
+                const int64_t row = ((int64_t)iz * ny + iy) * nx;
+                for (uint32_t k = cs[row + lo[0]]; k < cs[row + hi[0] + 1]; ++k) { seen[k] = 1; ++visited; }
+            }
+    // every triangle of the caller's list within 3 must be among the visited slots: match by its vertices (slot order differs)
+    for (int64_t t = 0; t < n; ++t) {
+        const double* V = table + 6 + 9 * t;
+        const double dx = V[0] - q[0], dy = V[1] - q[1], dz = V[2] - q[2];
+        if (!(dx * dx + dy * dy + dz * dz < 9.0)) continue;
+        ++brute;
+        for (int64_t k = 0; k < n; ++k)
+            if (seen[(size_t)k] && std::memcmp(T0 + 3 * k, V, 3 * sizeof(double)) == 0
+                && std::memcmp(T0 + 3 * n + 6 * k, V + 3, 6 * sizeof(double)) == 0) { ++reached; break; }
+    }
+    out3[0] = brute; out3[1] = reached; out3[2] = visited;
+    return 0;
+}
 }

@@ -271,6 +271,35 @@ def test_a_later_callback_of_the_set_overrides_the_mesh(G, oracle):
     assert (got["status"][both & same] == 0).all()
 
 
+def test_grid_walk_reaches_every_triangle_the_reference_would_test(G):
+    """gr_mesh_grid.hpp + Ray::mesh_cells against the reference's loop over the whole list (meshes.jl:53-64), point by point:
+    every triangle whose first vertex is within 3 of the point is among those the grid walk visits -- for compact meshes
+    (cells of 3), for one stretched to 10^4 per axis (coarser cells) and for points outside the grid of first vertices; and the
+    walk visits a small part of a large mesh."""
+    import ctypes as C
+
+    L = Hh.lib()
+    rng = np.random.default_rng(8)
+    total = 0
+    for mesh, spread in ((shards(1500, 14.0, 20.0, 1), 16.0), (shards(1200, 20.0, 5000.0, 2), 22.0), (slab(2.0, 50.0, 10, 96, 1.0), 52.0),
+                         (box((3.0, -2.0, 1.0), 4.0), 6.0)):
+        g = G.MeshAccretionGeometry(mesh)
+        out = (C.c_int64 * 3)()
+        visited = []
+        for _ in range(300):
+            q = rng.uniform(-spread, spread, 3)
+            if rng.random() < 0.5:                   # half of the points next to a first vertex
+                q = mesh[rng.integers(len(mesh)), 0] + rng.normal(size=3) * 1.5
+            qa = np.ascontiguousarray(q, dtype=np.float64)
+            assert L.hh_mesh_candidates(g.table.ctypes.data_as(C.c_void_p), C.c_int64(len(g)), qa.ctypes.data_as(C.c_void_p), out) == 0
+            assert out[1] == out[0], (q, out[0], out[1])
+            total += out[0]
+            visited.append(out[2])
+        if len(mesh) == 1502:                        # the compact cloud: cells of 3 (the stretched one walks cells of ~100)
+            assert np.mean(visited) < 0.2 * len(mesh)
+    assert total > 3000
+
+
 def test_mesh_constructor_and_abi_table(G):
     mesh = box((1.0, -2.0, 3.0), 2.0)
     g = G.MeshAccretionGeometry(mesh)
