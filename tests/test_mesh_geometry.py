@@ -371,6 +371,25 @@ def test_device_later_callback_overrides_the_mesh(G, oracle, ens, kernel):
 
 
 @pytest.mark.gpu
+def test_saved_paths_end_at_the_mesh_hit(G, ens):
+    """gr_trace_paths (save_on = true) against a mesh: the path kernel runs the same DiscreteCallback -- the stored path ends at
+    the end point the end-point kernels report, and every earlier row is a step of the mesh-less path."""
+    m = G.KerrMetric(1.0, 0.9)
+    v = _rays(G, m, 12)
+    d = G.MeshAccretionGeometry(SCENES["ring slab"]())
+    pts = G.tracegeodesics(m, X_OBS, v, d, (0.0, 2000.0), ensemble=ens)
+    paths = G.tracegeodesic_paths(m, X_OBS, v, d, (0.0, 2000.0), ensemble=ens)
+    free = G.tracegeodesic_paths(m, X_OBS, v, (0.0, 2000.0), ensemble=ens)
+    hits = np.flatnonzero(pts["status"] == 2)
+    assert hits.size > 10
+    for j in hits:
+        p, f = paths[j], free[j]
+        assert p.point["status"] == 2 and p.λ[-1] == pts["lambda_max"][j] and np.array_equal(p.x[-1], pts["x"][j])
+        k = p.λ.size
+        assert k < f.λ.size and np.array_equal(p.λ, f.λ[:k]) and np.array_equal(p.x, f.x[:k])
+
+
+@pytest.mark.gpu
 def test_mesh_is_refused_where_it_is_not_built(G, ens):
     m = G.KerrMetric(1.0, 0.9)
     v = _rays(G, m, 8)
