@@ -19,7 +19,7 @@ from .geometry import (CompositeGeometry, DatumPlane, EllipticalDisc, MeshAccret
 from .polish_doughnut import PolishDoughnut
 from .lineprofiles import BinningMethod, PowerLawEmissivity, TransferFunctionMethod, bucket_simple, lineprofile
 from .metrics import (BumblebeeMetric, DilatonAxion, JohannsenMetric, JohannsenPsaltisMetric, KerrDarkMatter, KerrMetric,
-                      KerrNewmanMetric, KerrRefractive, MorrisThorneWormhole, NoZMetric, SphericalMetric, inner_radius, isco)
+                      KerrNewmanMetric, KerrRefractive, MorrisThorneWormhole, NoZMetric, SphericalMetric, TabulatedMetric, inner_radius, isco)
 from .orthonormalization import lnrbasis, lnrbasis_matrix, lnrframe, lnrframe_matrix
 from .planes import (CartesianPlane, GeometricGrid, InverseGrid, LinearGrid, PolarPlane, image_plane,
                      impact_parameters, trajectory_count, unnormalized_areas)

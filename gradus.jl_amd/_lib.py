@@ -26,6 +26,7 @@ def kernel_source_sha16() -> str:
     h = hashlib.sha256()
     root = os.path.dirname(_HERE)
     for rel in ("gradus.jl_amd/csrc/gr_device.hpp", "gradus.jl_amd/csrc/gr_kernels.hpp", "gradus.jl_amd/csrc/gr_tangent.hpp",
+                "gradus.jl_amd/csrc/gr_tabmetric.hpp", "gradus.jl_amd/csrc/metric_table.hip",
                 "gradus.jl_amd/csrc/kernels_tu.hip",
                 "gradus.jl_amd/csrc/gradus_mi355x.hip",
                 "include/gradus_mi355x.h"):
@@ -38,7 +39,7 @@ def kernel_source_sha16() -> str:
 
 
 GR_OK = 0
-ABI_VERSION = 6      # GR_ABI_VERSION of include/gradus_mi355x.h this module mirrors (checked in load() and tests/test_host_api.py)
+ABI_VERSION = 7      # GR_ABI_VERSION of include/gradus_mi355x.h this module mirrors (checked in load() and tests/test_host_api.py)
 ERROR_NAMES = {
     -1: "GR_ERR_INVALID_ARGUMENT",
     -2: "GR_ERR_UNSUPPORTED",
@@ -95,6 +96,29 @@ class gr_config(C.Structure):
         ("comp_n", C.c_int32),
         ("_pad3", C.c_int32),
         ("comp", gr_disc_component * GR_COMP_MAX),
+        ("metric_table", C.c_void_p),      # GR_METRIC_TABULATED (ABI 7): the table gr_metric_table_fit wrote, host pointer
+        ("metric_table_n", C.c_int64),
+    ]
+
+
+class gr_metric_grid(C.Structure):
+    """Patch grid of a tabulated metric (include/gradus_mi355x.h, "tabulated metrics")."""
+
+    _fields_ = [
+        ("r0", C.c_double),
+        ("r_min", C.c_double),
+        ("r_max", C.c_double),
+        ("e_min", C.c_int32),
+        ("n_oct", C.c_int32),
+        ("m_r", C.c_int32),
+        ("n_theta", C.c_int32),
+        ("degree", C.c_int32),
+        ("fit_nodes", C.c_int32),
+        ("pole_factor", C.c_int32),
+        ("reserved", C.c_int32),
+        ("n_r_nodes", C.c_int64),
+        ("n_theta_nodes", C.c_int64),
+        ("table_doubles", C.c_int64),
     ]
 
 
@@ -245,6 +269,10 @@ EXPORTS = [
     "gr_ray_tangent_multi",
     "gr_redshift_radius_multi",
     "gr_lineprofile_multi",
+    "gr_metric_grid_plan",
+    "gr_metric_grid_nodes",
+    "gr_metric_table_fit",
+    "gr_metric_table_eval",
 ]
 
 _lib = None
@@ -303,6 +331,11 @@ def load():
     L.gr_ray_tangent_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, vp, vp]
     L.gr_redshift_radius_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, C.c_double, C.c_double, vp, vp]
     L.gr_lineprofile_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, bnp, vp, vp]
+    gdp, dp = C.POINTER(gr_metric_grid), C.POINTER(C.c_double)
+    L.gr_metric_grid_plan.argtypes = [C.c_double, C.c_double, C.c_double, i32, i32, gdp]
+    L.gr_metric_grid_nodes.argtypes = [gdp, vp, vp]
+    L.gr_metric_table_fit.argtypes = [gdp, vp, vp, dp]
+    L.gr_metric_table_eval.argtypes = [vp, i64, C.c_double, C.c_double, dp, dp, dp]
     for name in EXPORTS:
         if name not in ("gr_last_error",):
             getattr(L, name).restype = i32

@@ -129,6 +129,8 @@ typedef double gr_real_t;
 #define GR_RCPF(x) __builtin_amdgcn_rcpf(x)      // v_rcp_f32
 #endif
 
+#include "gr_tabmetric.hpp"
+
 namespace GR_NS {
 
 typedef gr_real_t real;
@@ -1661,21 +1663,12 @@ struct GenericMetricT {
 };
 typedef GenericMetricT<-1> GenericMetric;      // run-time switch over the catalogue
 
-// metric id -> functor type (the ids of include/gradus_mi355x.h)
-template <int ID> struct MetricOf { typedef GenericMetricT<ID> type; };
-template <> struct MetricOf<GR_METRIC_KERR> { typedef KerrFamily<false> type; };
-template <> struct MetricOf<GR_METRIC_KERR_NEWMAN> { typedef KerrFamily<true> type; };
-template <> struct MetricOf<GR_METRIC_JOHANNSEN> { typedef JohannsenMetric type; };
-
-// geodesic_equation (auto-diff.jl:213-226) with the sparse contraction of SURVEY App. B.1 at a
-// point given by r and (sinθ, cosθ).  The factors 2 and -½ of the reference's form cancel:
+// geodesic_equation (auto-diff.jl:213-226) with the sparse contraction of SURVEY App. B.1 from the components' Jacobian and
+// inverse.  The factors 2 and -½ of the reference's form cancel:
 //   a^t = -(g^tt T_t + g^tϕ T_ϕ), a^r = -g^rr (ġ_rr v^r - ½ D_r), ... with T_t = ġ_tt v^t + ġ_tϕ v^ϕ.
-template <class Metric>
-GR_DEV void geodesic_rhs_generic(const Metric& m, real r, real s, real c, real vt, real vr, real vh, real vp,
-                                 real& at, real& ar, real& ah, real& ap)
+GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[5], real vt, real vr, real vh, real vp,
+                              real& at, real& ar, real& ah, real& ap)
 {
-    real g[5], j1[5], j2[5], gi[5];
-    m.eval(r, s, c, g, j1, j2, gi);
     real gd[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) gd[k] = GR_FMA(j1[k], vr, j2[k] * vh);
@@ -1690,7 +1683,374 @@ GR_DEV void geodesic_rhs_generic(const Metric& m, real r, real s, real c, real v
     ar = -(gi[1] * Tr);
     ah = -(gi[2] * Th);
     ap = -GR_FMA(gi[4], Tt, gi[3] * Tp);
+}
+
+// ---------------------------------------------------------------------------------------
+// GR_METRIC_TABULATED: a user-defined metric from the piecewise-polynomial table of gr_tabmetric.hpp -- the AbstractMetric plugin
+// interface (metric_components(m, (r, θ)), src/metrics/kerr-metric.jl:62-70) on the device.
+//
+// Memory system.  A patch is 1440 bytes of coefficients and a right-hand side reads all of it for 340 FMAs: 4.2 bytes per FMA.
+// Per-LANE fetches of that volume are bound by the LDS / L1 return paths (128 / 64 bytes per clock and CU against 64 FP64 FMAs
+// per clock: 720 / 1440 clocks of the memory pipe against 415 of the vector ALU per wave and right-hand side).  But the 64 rays
+// of a wave are an 8 x 8 pixel tile: they sit in ONE patch in 58 % of the wave-steps of the 2048² bench plane and in <= 2 in
+// 91 % (oracle/ trace of 40 tiles, m_r = 8, n_theta = 32; mean 1.7).  So the coefficients go through the SCALAR path: the wave
+// takes the patch of its first unfinished lane (v_readfirstlane), s_load's its coefficients -- one fetch per WAVE, served by the
+// scalar data cache and L2 -- and every lane in that patch evaluates with the coefficients as SGPR operands of its FMAs (no
+// vector register, no LDS or L1 traffic); lanes in other patches wait for the next round ("waterfall").  Cost = rounds x 415
+// vector instructions, nothing else.
+// ---------------------------------------------------------------------------------------
+#if !defined(GR_REAL_IS_FLOAT) && !defined(GR_REAL_IS_TAN2)
+#define GR_HAS_TABULATED 1
+#ifndef GR_TAB_PATH
+#define GR_TAB_PATH 1       // 1 = LDS patch cache, 0 = scalar waterfall (see TabulatedMetric::poly)
+#endif
+#ifndef GR_TAB_SLOTS
+#define GR_TAB_SLOTS 6
+#endif
+#ifndef GR_TAB_LANE_WAVES
+#define GR_TAB_LANE_WAVES 2
+#endif
+#ifndef GR_TAB_PARK
+#define GR_TAB_PARK 0       // stage accelerations parked in LDS (ParkA); measured equal at two waves per SIMD (profiles/r5e_tab_ab.log)
+#endif
+#ifndef GR_TAB_LOOKAHEAD
+#define GR_TAB_LOOKAHEAD 16     // coefficients the LDS reads of an evaluation run ahead of its arithmetic (LdsCoef)
+#endif
+// The wave's patch cache in LDS: [ kTabSlots tags | round-robin counter | pad to 64 bytes | kTabSlots slots of kTabSlotBytes ].
+// 1488 = 5 x 256 + 208: slot k starts 208 k bytes (mod 256) into the 64 banks -- distinct 16-byte columns for k < 8, so the lanes
+// of one ds_read group that sit in different slots do not collide; 1472 of the 1488 bytes are the patch as it lies in memory.
+constexpr int kTabSlots = GR_TAB_SLOTS;
+constexpr int kTabCopyDepth = 8;        // loads a lane keeps in flight while it copies a patch into LDS
+constexpr int kTabHeadBytes = 64;
+constexpr int kTabSlotBytes = 1488;
+constexpr size_t kTabLdsBytesPerWave = kTabHeadBytes + (size_t)kTabSlots * kTabSlotBytes;
+static_assert(kTabSlots >= 1 && kTabSlots <= 8 && gr_tab::kPatchDoubles * 8 <= kTabSlotBytes, "patch cache geometry");
+typedef double double2_t __attribute__((ext_vector_type(2)));
+struct TabulatedMetric {
+    static constexpr int kMinWavesPerSimd = 2;
+    static constexpr int kLaneWavesPerSimd = GR_TAB_LANE_WAVES;
+    static constexpr int kParkStages = GR_TAB_PARK;      // stage accelerations parked in LDS while a right-hand side runs (ParkA)
+    static constexpr bool kHasForce = false;
+    static constexpr bool kFusedRhs = false;
+    static constexpr bool kByTheta = true;      // evaluated at (r, θ) -- the integrator hands θ over next to sin θ, cos θ
+    gr_tab::GridK gk;
+    int32_t pole_factor;
+    const double* patches;                      // device: first patch of the table (behind its header)
+#ifndef GR_HOST_HARNESS
+    // gr_tab::eval_patch's operations with the coefficient operand k in a scalar register pair (the three-address VOP3 forms:
+    // left to itself the compiler picks the two-address v_fmac_f64 and first copies every coefficient into vector registers,
+    // two v_mov_b32 per coefficient -- 280 of an evaluation's 624 vector instructions)
+    struct Ops {
+        static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+        static GR_DEV double fmak(double a, double b, double k) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k)); return r; }
+        static GR_DEV double add(double a, double b) { return a + b; }
+        static GR_DEV double mulk(double a, double k) { double r; asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
+        static GR_DEV double addk(double a, double k) { double r; asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
+        static GR_DEV void row_done(int, int, double&, double&, double&) {}
+    };
+#endif
+    // the host unit copies the table's header into cfg.params and the device pointer of the table into cfg.metric_table
+    // The host unit lays the grid out in cfg.params the way the kernels use it (stage_metric_table): doubles as doubles, the
+    // integers packed into the BITS of params[6] and params[7] -- a double -> int conversion would be a vector instruction whose
+    // (uniform) result then sits in vector registers for the whole step loop; kernel arguments arrive in scalar registers and
+    // bit fields of them stay there.
+    GR_DEV void load(const gr_config& c)
+    {
+        gk.r0 = c.params[0];
+        gk.xmin = c.params[1];
+        gk.mr = c.params[2];
+        gk.nth_over_pi = c.params[3];
+        const unsigned long long b6 = __builtin_bit_cast(unsigned long long, c.params[6]), b7 = __builtin_bit_cast(unsigned long long, c.params[7]);
+        gk.e_min = (int32_t)(uint32_t)(b6 & 0xffffffffull);
+        gk.e_max = (int32_t)(uint32_t)(b6 >> 32);
+        gk.m_r = (int32_t)(b7 & 0xffffull);
+        gk.n_theta = (int32_t)((b7 >> 16) & 0xffffull);
+        pole_factor = (int32_t)((b7 >> 32) & 1ull);
+        patches = c.metric_table + gr_tab::kHeaderDoubles;
+    }
+    // ---- where the coefficients come from ----
+    // (a) cold code (initial conditions, point functions, the path and apply kernels): every lane loads its own patch from
+    //     global memory.
+    // (b) the step loop, GR_TAB_PATH 1 [default]: an LDS PATCH CACHE per wave (TabLds, below): kTabSlots patches of 1440 bytes;
+    //     a lane reads its coefficients from the slot that holds its patch -- lanes in one slot read one address (a broadcast:
+    //     256 bytes per clock and CU for ds_read_b64 / b128 on CDNA4, MI355X_MICROARCH.md §LDS), lanes in different slots
+    //     different bank groups (the slot stride is 5 x 256 + 208 bytes: up to 8 slots without a bank conflict).  The cost of
+    //     an evaluation does not depend on how many patches the wave straddles.  A patch that is not resident is fetched by
+    //     the whole wave (92 x 16 bytes: two coalesced global loads per lane) into the next slot, round robin; the lanes that
+    //     hit evaluate first, so every slot may be replaced.
+    // (c) GR_TAB_PATH 0: the SCALAR path measured first (profiles/r5a_tabkerr_*): the wave takes the patch of its first
+    //     unfinished lane, s_load's its coefficients and evaluates with them as SGPR operands, round after round ("waterfall").
+    //     No LDS, no vector registers for coefficients -- and 135 ms for 1024² rays where the fused Kerr kernel takes 5.1:
+    //     the scalar data cache keeps nothing between two evaluations of a wave (20 of a patch's 23 lines miss on EVERY
+    //     evaluation: 5.1e8 misses per launch), each evaluation is a handful of dependent L2 round trips, VALU issue 0.16.
+#ifndef GR_HOST_HARNESS
+    // The coefficient stream of one evaluation out of an LDS slot: 90 ds_read_b128 (the pairs the recurrences consume in
+    // order).  Reads run GR_TAB_LOOKAHEAD coefficients ahead of the arithmetic: when a row of a component has been folded in,
+    // the pairs up to that distance beyond it are requested, so a read's LDS latency lies behind the FMAs of the rows before
+    // it and only the look-ahead (2 registers per coefficient) is held in registers.  Left to the scheduler all 90 reads go to
+    // the top of the evaluation (360 registers: 1.3 KB of scratch per lane) -- scheduling barriers do not hold the pure
+    // arithmetic in place, a DATA dependence does: the address of the next reads passes through an empty asm that also takes
+    // the accumulator of the row just finished.
+    // The loads are volatile so that they stay 16-byte reads (the optimiser otherwise narrows them to the doubles used and the
+    // back end pairs those as ds_read2_b64: half the LDS bandwidth).
+    struct LdsCoef {
+        typedef const double2_t __attribute__((address_space(3))) lds_cdouble2;
+        static constexpr int kAll = gr_tab::kComps * gr_tab::kCoefs;       // 180 coefficients = 90 pairs
+        mutable lds_cdouble2* sl;
+        mutable double2_t buf[kAll / 2];
+        // coefficients consumed once row `row` of component `comp` is done, and the pairs requested by then
+        static constexpr int consumed(int comp, int row) { return gr_tab::kCoefs * comp + gr_tab::row_offset(row) + (gr_tab::kDegree - row + 1); }
+        static constexpr int pairs_by(int coefs) { return (coefs + GR_TAB_LOOKAHEAD > kAll ? kAll : coefs + GR_TAB_LOOKAHEAD + 1) / 2; }
+        GR_DEV void issue(int from_pair, int to_pair) const
+        {
+#pragma unroll
+            for (int j = from_pair; j < to_pair; ++j) buf[j] = *(volatile lds_cdouble2*)(sl + j);
+        }
+        GR_DEV void start() const { issue(0, pairs_by(0)); }
+        GR_DEV double operator()(int kk) const { return buf[kk >> 1][kk & 1]; }
+        // the five operations of gr_tab::eval_patch on vector registers, and the hook that keeps the stream ahead
+        static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+        static GR_DEV double fmak(double a, double b, double k) { return __builtin_fma(a, b, k); }
+        static GR_DEV double add(double a, double b) { return a + b; }
+        static GR_DEV double mulk(double a, double k) { return a * k; }
+        static GR_DEV double addk(double a, double k) { return a + k; }
+        GR_DEV void row_done(int comp, int row, double& acc, double& acc_u, double& acc_v) const
+        {
+            // (rows kDegree and kDegree - 1 of a component are folded together before the first call for it)
+            const int before = (row == gr_tab::kDegree - 2) ? (comp == 0 ? 0 : consumed(comp - 1, 0)) : consumed(comp, row + 1);
+            const int from = pairs_by(before), to = pairs_by(consumed(comp, row));
+            if (to <= from) return;
+            unsigned a = (unsigned)(unsigned long long)sl;      // (a 32-bit LDS address)
+            // (all three accumulators: a chain left out is deferred by the scheduler to the end of the evaluation, with every
+            // intermediate of the value chain it reads kept alive -- spilled -- until then)
+            asm volatile("" : "+v"(a), "+v"(acc), "+v"(acc_u), "+v"(acc_v));
+            sl = (lds_cdouble2*)(unsigned long long)a;
+            issue(from, to);
+        }
+    };
+#endif
+    template <class Ld, class Ops_>
+    GR_DEV void horner(const Ld& ld, const Ops_& ops, double u, double v, double su, double sv, real s, real c, real g[5], real gr[5], real gt[5]) const
+    {
+        real P[5], Pu[5], Pv[5];
+        gr_tab::eval_patch<real>(ld, ops, u, v, P, Pu, Pv);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            g[k] = P[k];
+            gr[k] = Pu[k] * su;
+            gt[k] = Pv[k] * sv;
+        }
+        if (pole_factor) gr_tab::pole_factor_apply<real>(s * s, 2.0 * (s * c), g, gr, gt);
+    }
+    // components and Jacobian at (r, θ); s, c = sin θ, cos θ of the same θ (the axis factor of g_ϕϕ and g_tϕ)
+    GR_DEV void poly(real r, real th, real s, real c, real g[5], real gr[5], real gt[5]) const
+    {
+        int patch;
+        double u, v, su, sv;
+        gr_tab::locate(gk, r, th, patch, u, v, su, sv);
+        const double* pc = patches + (int64_t)patch * gr_tab::kPatchDoubles;
+        horner([pc](int k) { return pc[k]; }, gr_tab::HostOps{}, u, v, su, sv, s, c, g, gr, gt);
+    }
+    // the right-hand side of the geodesic equation from the table's components: inverse and contraction
+    GR_DEV void finish_rhs(const real g[5], const real gr[5], const real gt[5], real vt, real vr, real vh, real vp,
+                           real& at, real& ar, real& ah, real& ap) const
+    {
+        real gi[5];
+        inverse_generic(g, gi);
+        geodesic_contract(gr, gt, gi, vt, vr, vh, vp, at, ar, ah, ap);
+    }
+    // ... inside the step loop: through the wave's patch cache (cs.tab, TabLds) or the scalar waterfall.  The loops below enclose
+    // the WHOLE right-hand side: four accelerations are carried round them, not fifteen components.
+    template <class Cold_>
+    GR_DEV void rhs_th(const Cold_& cs, real r, real th, real s, real c, real vt, real vr, real vh, real vp,
+                       real& at, real& ar, real& ah, real& ap) const
+    {
+#ifdef GR_HOST_HARNESS
+        real g[5], gr[5], gt[5];
+        poly(r, th, s, c, g, gr, gt);
+        finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
+#else
+        if constexpr (!Cold_::kTabLds) {
+            real g[5], gr[5], gt[5];
+            poly(r, th, s, c, g, gr, gt);
+            finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
+        } else {
+            int patch;
+            double u, v, su, sv;
+            gr_tab::locate(gk, r, th, patch, u, v, su, sv);
+#if GR_TAB_PATH == 0
+            for (;;) {
+                const int sp = __builtin_amdgcn_readfirstlane(patch);
+                if (patch == sp) {
+                    // the patch's address from scalar values only, in the constant address space: every coefficient load is an s_load
+                    typedef const double __attribute__((address_space(4))) cdouble4;
+                    const unsigned long long a64 = (unsigned long long)patches + (unsigned long long)(unsigned)sp * (gr_tab::kPatchDoubles * 8ull);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(a64 & 0xffffffffull));
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a64 >> 32));
+                    cdouble4* pc = (cdouble4*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+                    real g[5], gr[5], gt[5];
+                    horner([pc](int k) { return pc[k]; }, Ops{}, u, v, su, sv, s, c, g, gr, gt);
+                    finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
+                    break;
+                }
+            }
+#else
+            typedef int __attribute__((address_space(3))) lds_int;
+            typedef volatile int __attribute__((address_space(3))) lds_vint;
+            lds_vint* tags = (lds_vint*)cs.tab;
+            // Lanes are threads to the compiler: it orders ONE lane's memory operations, not one lane's reads against another
+            // lane's writes.  Every hand-over between lanes below (a patch copied by some lanes and read by others, a slot read by
+            // some lanes and replaced for others) is therefore fenced at wave scope, and the tags are read as volatile.
+#define GR_TAB_WAVE_SYNC()                                        \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
+            bool done = false;
+            at = ar = ah = ap = 0.0;
+            for (;;) {      // wave-uniform: every lane that called goes round together (one round unless the wave straddles more patches than slots)
+                // -- phase 1: a slot for every lane that still has to evaluate
+                int slot = -1;
+                if (!done) {
+#pragma unroll
+                    for (int k = 0; k < kTabSlots; ++k) slot = (tags[k] == patch) ? k : slot;
+                }
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(!done && slot < 0);
+#ifdef GR_TAB_DEBUG_NOMISS      // (register-pressure experiments only: wrong results)
+                todo = 0ull; slot = slot < 0 ? 0 : slot;
+#endif
+                if (todo != 0ull) {
+                    // slots that lanes of THIS round read must stay; the others are replaced round robin.  All lanes copy.
+                    unsigned used = 0;
+#pragma unroll
+                    for (int k = 0; k < kTabSlots; ++k) used |= __builtin_amdgcn_ballot_w64(!done && slot == k) != 0ull ? (1u << k) : 0u;
+                    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                    const int n_act = __builtin_popcountll(act);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+                    int rr = tags[kTabSlots];
+                    for (int tries = 0; tries < kTabSlots && todo != 0ull; ++tries) {
+                        const int sidx = rr;
+                        rr = rr + 1 >= kTabSlots ? 0 : rr + 1;
+                        if (used & (1u << sidx)) continue;
+                        const int first = (int)__builtin_ctzll(todo);
+                        const int pp = __builtin_amdgcn_readlane(patch, first);
+                        const double2_t* src = (const double2_t*)(patches + (int64_t)pp * gr_tab::kPatchDoubles);
+                        typedef double2_t __attribute__((address_space(3))) lds_double2;
+                        lds_double2* dst = (lds_double2*)(cs.tab + kTabHeadBytes + sidx * kTabSlotBytes);
+                        // 92 pieces of 16 bytes, piece q by the active lane of rank q mod n_act -- kTabCopyDepth loads in flight
+                        // per lane before the first store: in the tail of a wave (a few lanes left, each fetching dozens of
+                        // pieces) a copy is a few memory round trips, not one per piece (92 serial round trips per miss with one
+                        // lane left: 40 ms of tail on every launch, profiles/r5e_tab_ab.log)
+                        for (int q0 = rank; q0 < gr_tab::kPatchDoubles / 2; q0 += kTabCopyDepth * n_act) {
+                            double2_t piece[kTabCopyDepth];
+#pragma unroll
+                            for (int jj = 0; jj < kTabCopyDepth; ++jj) {
+                                const int q = q0 + jj * n_act;
+                                if (q < gr_tab::kPatchDoubles / 2) piece[jj] = src[q];
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < kTabCopyDepth; ++jj) {
+                                const int q = q0 + jj * n_act;
+                                if (q < gr_tab::kPatchDoubles / 2) dst[q] = piece[jj];
+                            }
+                        }
+                        tags[sidx] = pp;
+                        used |= 1u << sidx;
+                        if (!done && patch == pp) slot = sidx;
+                        todo = __builtin_amdgcn_ballot_w64(!done && slot < 0);
+                    }
+                    tags[kTabSlots] = rr;
+                    GR_TAB_WAVE_SYNC();
+                }
+                // -- phase 2: the lanes that have a slot evaluate
+                if (!done && slot >= 0) {
+                    LdsCoef lc;
+                    lc.sl = (LdsCoef::lds_cdouble2*)(cs.tab + kTabHeadBytes + slot * kTabSlotBytes);
+                    lc.start();
+                    real g[5], gr[5], gt[5];
+                    horner(lc, lc, u, v, su, sv, s, c, g, gr, gt);
+                    finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
+                    done = true;
+                }
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+                GR_TAB_WAVE_SYNC();      // the slots just read may be replaced in the next round
+            }
+#undef GR_TAB_WAVE_SYNC
+#endif
+        }
+#endif
+    }
+    GR_DEV void eval_th(real r, real th, real s, real c, real g[5], real gr[5], real gt[5], real gi[5]) const
+    {
+        poly(r, th, s, c, g, gr, gt);
+        inverse_generic(g, gi);
+    }
+    GR_DEV void comps_th(real r, real th, real s, real c, real g[5]) const
+    {
+        real gr[5], gt[5];
+        poly(r, th, s, c, g, gr, gt);
+    }
+};
+#else
+#define GR_HAS_TABULATED 0
+#endif
+
+// metric id -> functor type (the ids of include/gradus_mi355x.h)
+template <int ID> struct MetricOf { typedef GenericMetricT<ID> type; };
+template <> struct MetricOf<GR_METRIC_KERR> { typedef KerrFamily<false> type; };
+template <> struct MetricOf<GR_METRIC_KERR_NEWMAN> { typedef KerrFamily<true> type; };
+template <> struct MetricOf<GR_METRIC_JOHANNSEN> { typedef JohannsenMetric type; };
+#if GR_HAS_TABULATED
+template <> struct MetricOf<GR_METRIC_TABULATED> { typedef TabulatedMetric type; };
+#endif
+
+// does a metric want (r, θ) instead of (r, sin θ, cos θ)?  (TabulatedMetric)
+template <class Metric, class = void>
+struct ByThetaOf { static constexpr bool value = false; };
+template <class Metric>
+struct ByThetaOf<Metric, decltype((void)Metric::kByTheta)> { static constexpr bool value = Metric::kByTheta; };
+
+// components / components + Jacobian + inverse at a point whose θ AND sin θ, cos θ the caller has
+template <class Metric>
+GR_DEV void metric_comps(const Metric& m, real r, real th, real s, real c, real g[5])
+{
+    if constexpr (ByThetaOf<Metric>::value) m.comps_th(r, th, s, c, g);
+    else m.comps(r, s, c, g);
+}
+template <class Metric>
+GR_DEV void metric_eval(const Metric& m, real r, real th, real s, real c, real g[5], real j1[5], real j2[5], real gi[5])
+{
+    if constexpr (ByThetaOf<Metric>::value) m.eval_th(r, th, s, c, g, j1, j2, gi);
+    else m.eval(r, s, c, g, j1, j2, gi);
+}
+
+// ... at a point given by r and (sinθ, cosθ)
+template <class Metric>
+GR_DEV void geodesic_rhs_generic(const Metric& m, real r, real s, real c, real vt, real vr, real vh, real vp,
+                                 real& at, real& ar, real& ah, real& ap)
+{
+    real g[5], j1[5], j2[5], gi[5];
+    m.eval(r, s, c, g, j1, j2, gi);
+    geodesic_contract(j1, j2, gi, vt, vr, vh, vp, at, ar, ah, ap);
     if constexpr (Metric::kHasForce) m.add_force(r, s, c, gi, vt, vr, vh, vp, at, ar, ah, ap);
+}
+
+// ... at a point given by r and θ, for the metrics that are evaluated there (ByThetaOf)
+template <class Metric>
+GR_DEV void geodesic_rhs_th(const Metric& m, real r, real th, real s, real c, real vt, real vr, real vh, real vp,
+                            real& at, real& ar, real& ah, real& ap)
+{
+    real g[5], j1[5], j2[5], gi[5];
+    m.eval_th(r, th, s, c, g, j1, j2, gi);
+    geodesic_contract(j1, j2, gi, vt, vr, vh, vp, at, ar, ah, ap);
+}
+// ... inside the step loop: `cs` carries the wave's LDS storage (the metric's patch cache, TabLds)
+template <class Metric, class Cold_>
+GR_DEV void geodesic_rhs_th(const Metric& m, const Cold_& cs, real r, real th, real s, real c, real vt, real vr, real vh, real vp,
+                            real& at, real& ar, real& ah, real& ap)
+{
+    m.rhs_th(cs, r, th, s, c, vt, vr, vh, vp, at, ar, ah, ap);
 }
 
 // the right-hand side the integrator calls: the metric's own fused form where it has one
@@ -1712,7 +2072,8 @@ GR_DEV void geodesic_rhs(const Metric& m, real r, real th, real vt, real vr, rea
                          real& at, real& ar, real& ah, real& ap, real& s, real& c)
 {
     sincos_fast(th, s, c);
-    geodesic_rhs_sc(m, r, s, c, vt, vr, vh, vp, at, ar, ah, ap);
+    if constexpr (ByThetaOf<Metric>::value) geodesic_rhs_th(m, r, th, s, c, vt, vr, vh, vp, at, ar, ah, ap);
+    else geodesic_rhs_sc(m, r, s, c, vt, vr, vh, vp, at, ar, ah, ap);
 }
 
 // constrain_time, auto-diff.jl:161-179
@@ -1937,7 +2298,7 @@ struct Params {
     int32_t lds_points;       // one-ray-per-lane kernel, end-point output: 1 = a wave's 152-B records leave through LDS as whole
                               // runs (POINT_UNITS doubles + one address slot per lane behind the other LDS regions)
     int32_t xcd_spread;       // one-ray-per-lane kernel on rays in CALLER order: 1 = workgroup b traces chunk xcd_chunk(b) of the
-    int32_t reserved0;        // rays instead of chunk b (gr_kernels.hpp)
+    int32_t lds_tab_off;      // rays instead of chunk b (gr_kernels.hpp) | byte offset of the tabulated metric's patch caches in the workgroup's LDS
 };
 
 // the derived fields of Params, from cfg (host side; one place for the library and the two host harnesses)
@@ -2058,7 +2419,7 @@ template <class Metric>
 GR_DEV void circular_fourvelocity(const Metric& m, real rho, real& vt, real& vp)
 {
     real g[5], j1[5], j2[5], gi[5];
-    m.eval(rho, 1.0, 0.0, g, j1, j2, gi);
+    metric_eval(m, rho, (real)1.5707963267948966, (real)1.0, (real)0.0, g, j1, j2, gi);
     const real Dl = sqrt_fast(j1[4] * j1[4] - j1[0] * j1[3]);
     const real Om = -(j1[4] - Dl) * rcp_full(j1[3]);
     const real A = -(Om * gi[0] - gi[4]);
@@ -2111,11 +2472,11 @@ GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const 
     }
     // _redshift_dotproduct: E_obs / E_disc with v_obs = (1,0,0,0)
     real g[5];
-    m.comps(x[1], s, c, g);
+    metric_comps(m, x[1], x[2], s, c, g);
     const real E_disc = (g[0] * v[0] + g[4] * v[3]) * dt_ + g[1] * v[1] * dr_ + (g[4] * v[0] + g[3] * v[3]) * dp_;
     real s0, c0, g0[5];
     sincos_fast(x0[2], s0, c0);
-    m.comps(x0[1], s0, c0, g0);
+    metric_comps(m, x0[1], x0[2], s0, c0, g0);
     const real E_obs = g0[0] * v0[0] + g0[4] * v0[3];
     return E_obs * rcp_full(E_disc);
 }
@@ -2137,9 +2498,11 @@ struct NoColdStore {
     static constexpr bool kOn = false;
     static constexpr bool kHead = false;
     static constexpr int kParkA = 0;
+    static constexpr bool kTabLds = false;      // (a tabulated metric's patch cache: TabLds below)
 };
 template <bool HEAD>
 struct LdsColdStoreT {
+    static constexpr bool kTabLds = false;
     static constexpr bool kOn = true;       // parked around the event sampling (the rarely taken branch)
     static constexpr bool kHead = HEAD;     // ... and across the whole hot region of every step
     static constexpr int kParkA = 0;        // (stage accelerations: ParkA below)
@@ -2188,6 +2551,17 @@ struct ParkA : Base {
         asm volatile("" ::: "memory");      // no forwarding of a parked value to its reload, no reload hoisted above a right-hand side
 #endif
     }
+};
+
+// GR_METRIC_TABULATED: the wave's patch cache rides along with the other per-wave LDS storage of the step loop
+template <class Base>
+struct TabLds : Base {
+    static constexpr bool kTabLds = true;
+#ifdef GR_HOST_HARNESS
+    char* tab;
+#else
+    char __attribute__((address_space(3)))* tab;      // this wave's region (kTabLdsBytesPerWave bytes)
+#endif
 };
 
 // ---------------------------------------------------------------------------------------
@@ -2682,7 +3056,7 @@ struct Ray {
         initial_conditions(p, jl, x0, v0);
         real s, c, g[5];
         sincos_fast(x0[2], s, c);
-        m.comps(x0[1], s, c, g);
+        metric_comps(m, x0[1], x0[2], s, c, g);
         v0[0] = constrain_time(g, v0[1], v0[2], v0[3], p.cfg.mu);
     }
 
@@ -2866,6 +3240,9 @@ struct Ray {
         sincos_rot_stage(rotk, x[2], sth, cth, ts, s, c);                                             \
         GR_DBG_BIT((GR_FABS(ts - x[2]) <= SINCOS_ROT_MAX) ? 0 : (1 << S));                                    \
         GR_DBG_DMAX(GR_FABS(ts - x[2]));                                                              \
+        if constexpr (ByThetaOf<Metric>::value)                                                       \
+            geodesic_rhs_th(m, cs, rs, ts, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
+        else                                                                                          \
         geodesic_rhs_sc(m, rs, s, c, vs[0], vs[1], vs[2], vs[3], A[S][0], A[S][1], A[S][2], A[S][3]); \
         GR_PIN4(A[S]);                                                                                \
         GR_PARK(S)                                                                                    \
@@ -2908,7 +3285,8 @@ struct Ray {
         GR_DBG_DMAX(GR_FABS(xn[2] - x[2]));
         if (resync) sincos_fast(xn[2], sn, cn);
         else sincos_rot(rotk, x[2], sth, cth, xn[2], sn, cn);
-        geodesic_rhs_sc(m, xn[1], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);
+        if constexpr (ByThetaOf<Metric>::value) geodesic_rhs_th(m, cs, xn[1], xn[2], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);
+        else geodesic_rhs_sc(m, xn[1], sn, cn, vn[0], vn[1], vn[2], vn[3], A[6][0], A[6][1], A[6][2], A[6][3]);
         GR_PIN4(A[6]);
 #else
         accel(m, xn[1], xn[2], vn, A[6], sn, cn);

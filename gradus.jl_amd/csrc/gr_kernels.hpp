@@ -88,10 +88,18 @@ struct ColdSel {
 #else
     static constexpr int kPark = LANE_KERNEL ? ParkStagesOf<Metric>::value : 0;
 #endif
-    typedef typename std::conditional<(kPark > 0), ParkA<base, kPark>, base>::type type;
+    typedef typename std::conditional<(kPark > 0), ParkA<base, kPark>, base>::type type0;
+    // a tabulated metric's patch cache (TabLds): kTabLdsBytesPerWave bytes per wave behind every other LDS region
+    static constexpr bool kTab = ByThetaOf<Metric>::value && GR_HAS_TABULATED;
+    typedef typename std::conditional<kTab, TabLds<type0>, type0>::type type;
     static constexpr size_t kColdBytes = base::kOn ? sizeof(double) * COLD_SLOTS : 0;
     static constexpr size_t kParkBytes = sizeof(real) * 4 * (size_t)kPark;
     static constexpr size_t kBytesPerThread = kColdBytes + kParkBytes;
+#if GR_HAS_TABULATED
+    static constexpr size_t kTabBytesPerWave = kTab ? kTabLdsBytesPerWave : 0;
+#else
+    static constexpr size_t kTabBytesPerWave = 0;
+#endif
 };
 // wave w of the workgroup owns bytes [w * 64 * kBytesPerThread, (w + 1) * 64 * kBytesPerThread) of the region behind the
 // histogram and the plunging table: its cold slots first (64 lanes x COLD_SLOTS doubles), then its parked accelerations
@@ -106,6 +114,19 @@ __device__ __forceinline__ typename Sel::type cold_store_of(const Params& p)
         if constexpr (Store::kOn) st.lane = reinterpret_cast<double*>(region) + l;
         if constexpr (Store::kParkA > 0) st.park = reinterpret_cast<real*>(region + 64 * Sel::kColdBytes) + l;
     }
+#if GR_HAS_TABULATED
+    if constexpr (Store::kTabLds) {
+        // the patch cache of wave w: p.lds_tab_off bytes into the workgroup's LDS (launch_tmpl), empty to begin with
+        typedef char __attribute__((address_space(3))) lds_char;
+        typedef int __attribute__((address_space(3))) lds_int;
+        const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        st.tab = (lds_char*)((lds_char*)gr_lds + p.lds_tab_off + (size_t)w * kTabLdsBytesPerWave);
+        if (l <= kTabSlots) ((lds_int*)st.tab)[l] = l < kTabSlots ? -1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#endif
     return st;
 }
 
@@ -448,8 +469,14 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
     const size_t cold_b = (k.kernel == 0 ? ColdSel<Metric, true>::kBytesPerThread : ColdSel<Metric, false>::kBytesPerThread) * (size_t)block;
     const size_t point_b = p.lds_points ? kPointLdsBytesPerThread * (size_t)block : 0;
     // one-wave workgroups: the end-point records reuse the cold lane storage (lds_prologue)
-    const size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows)
-                       + (block == 64 ? (cold_b > point_b ? cold_b : point_b) : cold_b + point_b);
+    size_t lds = sizeof(double) * ((size_t)p.lds_bins + 4 * (size_t)p.lds_plunge_rows)
+                 + (block == 64 ? (cold_b > point_b ? cold_b : point_b) : cold_b + point_b);
+    {   // a tabulated metric's patch caches, one per wave, behind everything else (16-byte aligned)
+        const size_t tab_w = k.kernel == 0 ? ColdSel<Metric, true>::kTabBytesPerWave : ColdSel<Metric, false>::kTabBytesPerWave;
+        lds = (lds + 15) & ~(size_t)15;
+        p.lds_tab_off = (int32_t)lds;
+        lds += tab_w * (size_t)((block + 63) / 64);
+    }
 #ifdef GR_LANE_ONLY
     {
 #else

@@ -41,7 +41,11 @@ using namespace gr;
 GR_DECLARE_METRIC(0) GR_DECLARE_METRIC(1) GR_DECLARE_METRIC(2) GR_DECLARE_METRIC(3) GR_DECLARE_METRIC(4) GR_DECLARE_METRIC(5)
 GR_DECLARE_METRIC(6) GR_DECLARE_METRIC(7) GR_DECLARE_METRIC(8) GR_DECLARE_METRIC(9) GR_DECLARE_METRIC(10)
 #undef GR_DECLARE_METRIC
-static_assert(GR_METRIC_NOZ == 10, "one kernel object per metric id 0..10: extend the tables below with the catalogue");
+// GR_METRIC_TABULATED (11): the fp64 kernels only
+hipError_t gr64_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
+hipError_t gr64_launch_path_m11(const void*, double*, int64_t, unsigned long long*, hipStream_t);
+hipError_t gr64_launch_apply_m11(const void*, const gr_point*, double, double*, hipStream_t);
+static_assert(GR_METRIC_NOZ == 10 && GR_METRIC_TABULATED == 11, "one kernel object per metric id 0..11: extend the tables below with the catalogue");
 
 namespace {
 struct LaunchKnobs {
@@ -54,13 +58,13 @@ struct LaunchKnobs {
 typedef hipError_t (*trace_fn)(int, int, int, int, unsigned long long*, const void*, hipStream_t);
 typedef hipError_t (*path_fn)(const void*, double*, int64_t, unsigned long long*, hipStream_t);
 typedef hipError_t (*apply_fn)(const void*, const gr_point*, double, double*, hipStream_t);
-#define GR_ROW(F) { F##0, F##1, F##2, F##3, F##4, F##5, F##6, F##7, F##8, F##9, F##10 }
-const trace_fn kTrace64[11] = GR_ROW(gr64_launch_trace_m);
-const trace_fn kTrace32[11] = GR_ROW(gr32_launch_trace_m);
-const trace_fn kTraceTan[11] = GR_ROW(grt_launch_trace_m);      // value + ∂/∂α + ∂/∂β (out_mode 5): one lane per ray
-const trace_fn kTraceTan1[11] = GR_ROW(grt1_launch_trace_m);    // the same with a PAIR of lanes per ray (kernels_tu.hip)
-const path_fn kPath64[11] = GR_ROW(gr64_launch_path_m);
-const apply_fn kApply64[11] = GR_ROW(gr64_launch_apply_m);
+#define GR_ROW(F, LAST) { F##0, F##1, F##2, F##3, F##4, F##5, F##6, F##7, F##8, F##9, F##10, LAST }
+const trace_fn kTrace64[12] = GR_ROW(gr64_launch_trace_m, gr64_launch_trace_m11);
+const trace_fn kTrace32[12] = GR_ROW(gr32_launch_trace_m, nullptr);
+const trace_fn kTraceTan[12] = GR_ROW(grt_launch_trace_m, nullptr);      // value + ∂/∂α + ∂/∂β (out_mode 5): one lane per ray
+const trace_fn kTraceTan1[12] = GR_ROW(grt1_launch_trace_m, nullptr);    // the same with a PAIR of lanes per ray (kernels_tu.hip)
+const path_fn kPath64[12] = GR_ROW(gr64_launch_path_m, gr64_launch_path_m11);
+const apply_fn kApply64[12] = GR_ROW(gr64_launch_apply_m, gr64_launch_apply_m11);
 #undef GR_ROW
 }  // namespace
 
@@ -74,6 +78,12 @@ int32_t fail(int32_t code, const std::string& msg)
     g_last_error = msg;
     return code;
 }
+
+}  // namespace
+// for the library's other host units (metric_table.hip)
+int32_t gr_set_last_error(int32_t code, const char* msg) { return fail(code, msg); }
+int32_t gr_metric_table_check(const double* table, int64_t table_n);      // metric_table.hip
+namespace {
 
 #define GR_HIP(call)                                                                              \
     do {                                                                                          \
@@ -102,6 +112,9 @@ struct gr_ctx {
     uint64_t mesh_fp = 0;
     int64_t mesh_n = -1;
     std::vector<double> mesh_host;
+    double* d_metric_table = nullptr;      // GR_METRIC_TABULATED: device copy of the caller's table, kept while its build id stays
+    size_t metric_table_bytes = 0;
+    double metric_table_id = 0.0;
     double* d_chart_table = nullptr;       // device copy of a PoloidalShapeChart table
     size_t chart_table_bytes = 0;
     Cold* d_cold = nullptr;                // ring of per-launch cold blocks
@@ -189,8 +202,12 @@ int32_t tables_release(gr_ctx* ctx, hipStream_t stream)
 int32_t validate_cfg(const gr_config* cfg)
 {
     if (!cfg) return fail(GR_ERR_INVALID_ARGUMENT, "config is null");
-    if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_NOZ)
+    if (cfg->metric_id < GR_METRIC_KERR || cfg->metric_id > GR_METRIC_TABULATED)
         return fail(GR_ERR_UNSUPPORTED, "unknown metric_id " + std::to_string(cfg->metric_id));
+    if (cfg->metric_id == GR_METRIC_TABULATED) {
+        const int32_t trc = gr_metric_table_check(cfg->metric_table, cfg->metric_table_n);
+        if (trc != GR_OK) return trc;
+    }
     if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_MESH)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
     if (cfg->disc_id == GR_DISC_COMPOSITE) {
@@ -242,8 +259,47 @@ int32_t validate_plane(const gr_plane* pl, const gr_range* rg)
 // device copies of the tabulated chart and disc profile (cfg.chart_table / cfg.disc_table are host
 // pointers); records "PoloidalShapeChart active" in bit 1 and "count windings" in bit 2 of the private copy of
 // cfg.upper_hemisphere
+// GR_METRIC_TABULATED: the device copy of the caller's table (uploaded when its build id changes), its header into cfg.params
+// and its device address into the private copy of cfg.metric_table -- what TabulatedMetric::load reads
+int32_t stage_metric_table(gr_ctx* ctx, Params& p, hipStream_t stream)
+{
+    if (p.cfg.metric_id != GR_METRIC_TABULATED) return GR_OK;
+    const double* t = p.cfg.metric_table;
+    const size_t bytes = sizeof(double) * (size_t)p.cfg.metric_table_n;
+    const double id = t[gr_tab::H_BUILD_ID];
+    if (!ctx->d_metric_table || ctx->metric_table_id != id || ctx->metric_table_bytes < bytes) {
+        const int32_t arc = tables_acquire(ctx, stream);
+        if (arc != GR_OK) return arc;
+        ctx->metric_table_id = 0.0;
+        const int32_t rc = ensure((void**)&ctx->d_metric_table, &ctx->metric_table_bytes, bytes);
+        if (rc != GR_OK) return rc;
+        GR_HIP(hipMemcpyAsync(ctx->d_metric_table, t, bytes, hipMemcpyHostToDevice, stream));
+        GR_HIP(hipStreamSynchronize(stream));      // the caller's table may be pageable and gone after the call; once per table
+        ctx->metric_table_id = id;
+    }
+    {
+        // the grid in the form TabulatedMetric::load reads it (gr_device.hpp): doubles as doubles, integers as bit fields
+        const gr_tab::GridK gk = gr_tab::make_gridk(t[gr_tab::H_R0], (int)t[gr_tab::H_EMIN], (int)t[gr_tab::H_NOCT], (int)t[gr_tab::H_MR], (int)t[gr_tab::H_NTHETA]);
+        p.cfg.params[0] = gk.r0;
+        p.cfg.params[1] = gk.xmin;
+        p.cfg.params[2] = gk.mr;
+        p.cfg.params[3] = gk.nth_over_pi;
+        p.cfg.params[4] = p.cfg.params[5] = 0.0;
+        const unsigned long long b6 = (unsigned long long)(uint32_t)gk.e_min | ((unsigned long long)(uint32_t)gk.e_max << 32);
+        const unsigned long long b7 = (unsigned long long)gk.m_r | ((unsigned long long)gk.n_theta << 16) | ((t[gr_tab::H_POLE_FACTOR] != 0.0 ? 1ull : 0ull) << 32);
+        std::memcpy(&p.cfg.params[6], &b6, 8);
+        std::memcpy(&p.cfg.params[7], &b7, 8);
+    }
+    p.cfg.metric_table = ctx->d_metric_table;
+    return GR_OK;
+}
+
 int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 {
+    {
+        const int32_t mrc = stage_metric_table(ctx, p, stream);
+        if (mrc != GR_OK) return mrc;
+    }
     p.chart_table = nullptr;
     p.cfg.upper_hemisphere = p.cfg.upper_hemisphere ? 1 : 0;
     if (p.cfg.chart_table_n > 1 || p.cfg.disc_id == GR_DISC_TABULATED || p.cfg.disc_id == GR_DISC_MESH) {
@@ -405,6 +461,8 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     p.refill_threshold = (int32_t)ctx->refill_threshold;
     // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
     const bool tangent = cold.out_mode == 5;
+    if (p.cfg.metric_id == GR_METRIC_TABULATED && (tangent || ctx->precision == 32))
+        return fail(GR_ERR_UNSUPPORTED, "a tabulated metric is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
     if (p.cfg.disc_id == GR_DISC_MESH && (tangent || ctx->precision == 32))
         return fail(GR_ERR_UNSUPPORTED, "a mesh geometry is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
     const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold);
@@ -440,7 +498,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     const hipError_t le = fn(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
     if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
     if (stream == ctx->stream) GR_HIP(hipEventRecord(ctx->ev_k, stream));      // host variants: where the kernel ends
-    if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0) {
+    if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0 || p.cfg.metric_id == GR_METRIC_TABULATED) {
         const int32_t trc = tables_release(ctx, stream);
         if (trc != GR_OK) return trc;
     }
@@ -600,6 +658,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_disc_table) (void)hipFree(c->d_disc_table);
     if (c->d_mesh) (void)hipFree(c->d_mesh);
     if (c->d_chart_table) (void)hipFree(c->d_chart_table);
+    if (c->d_metric_table) (void)hipFree(c->d_metric_table);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
@@ -962,13 +1021,14 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
     p.n = n;
     if ((rc = stage_pf(ctx, cfg, pf, cd.pf, stream)) != GR_OK) return rc;
     if (n == 0) return GR_OK;
+    if ((rc = stage_metric_table(ctx, p, stream)) != GR_OK) return rc;
     Cold* slot = ctx->d_cold + ctx->cold_next;
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cd, sizeof(Cold), hipMemcpyHostToDevice, stream));
     p.cold = slot;
     GR_HIP(kApply64[cfg->metric_id](&p, d_points, max_time, d_out, stream));
     GR_HIP(hipGetLastError());
-    if (cd.pf.n_plunge > 0 && (rc = tables_release(ctx, stream)) != GR_OK) return rc;
+    if ((cd.pf.n_plunge > 0 || cfg->metric_id == GR_METRIC_TABULATED) && (rc = tables_release(ctx, stream)) != GR_OK) return rc;
     return GR_OK;
 }
 
@@ -1018,7 +1078,7 @@ int32_t gr_trace_paths(gr_ctx* ctx, const gr_config* cfg, const double* x, int64
     p.cold = slot;
     GR_HIP(kPath64[cfg->metric_id](&p, d_path, cap, d_n, ctx->stream));
     GR_HIP(hipGetLastError());
-    if ((p.disc_table || p.chart_table) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;
+    if ((p.disc_table || p.chart_table || cfg->metric_id == GR_METRIC_TABULATED) && (rc = tables_release(ctx, ctx->stream)) != GR_OK) return rc;
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters are copied as int64");
     if (!is_pinned(path, path_bytes)) prefault_output(path, path_bytes, ctx->hugepages != 0);          // while the kernel runs (the path buffer of 16 384 geodesics is 600 MB)
     GR_HIP(hipMemcpyAsync(n_rows, d_n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -9,6 +9,7 @@ src/metrics/kerr-metric-first-order.jl:297-337 (Z1, Z2, isco).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 
@@ -18,6 +19,7 @@ GR_METRIC_KERR, GR_METRIC_JOHANNSEN = 0, 1
 GR_METRIC_MORRIS_THORNE, GR_METRIC_BUMBLEBEE, GR_METRIC_KERR_NEWMAN, GR_METRIC_JOHANNSEN_PSALTIS = 2, 3, 4, 5
 GR_METRIC_DILATON_AXION = 6
 GR_METRIC_SPHERICAL, GR_METRIC_KERR_DARK_MATTER, GR_METRIC_KERR_REFRACTIVE, GR_METRIC_NOZ = 7, 8, 9, 10
+GR_METRIC_TABULATED = 11
 
 
 class AbstractMetric:
@@ -463,6 +465,140 @@ class NoZMetric(AbstractStaticAxisSymmetric):
 
     def isco(self):
         raise NotImplementedError("NoZMetric: circular orbits leave the equatorial plane (noz-metric.jl:68-120)")
+
+
+class TabulatedMetric(AbstractStaticAxisSymmetric):
+    """ANY static, axis-symmetric metric on the device: the reference's plugin contract -- a struct `<: AbstractStaticAxisSymmetric`
+    and one method `metric_components(m, (r, θ))` (src/Gradus.jl:78-86, src/metrics/kerr-metric.jl:62-70; ForwardDiff supplies the
+    Jacobian, src/tracing/method-implementations/auto-diff.jl:206-211) -- carried across the C ABI as samples.
+
+    `source` is an `AbstractMetric` of this package (traced through the table instead of its own kernels) or any callable
+    `f(r, θ) -> (g_tt, g_rr, g_θθ, g_ϕϕ, g_tϕ)`; it is called with numpy arrays where it accepts them, point by point otherwise.
+    The library names the sample nodes, fits piecewise polynomials of total degree 7 (GR_METRIC_TABULATED, ABI 7) and reports
+    its own error estimates; (m_r, n_theta) are doubled until the estimates are below `tol` (value) and `dtol` (derivatives).
+
+    `inner_radius` (the event horizon: the chart's inner radius is 1.01 of it, charts.jl:9-23) and `isco` default to the
+    source's; a bare callable must bring `inner_radius`, and its ISCO is found on the table's own derivatives.
+    """
+
+    metric_id = GR_METRIC_TABULATED
+
+    def __init__(self, source, *, inner_radius=None, isco=None, r_min=None, r_max=12000.0, r0=None, m_r=8, n_theta=32,
+                 tol=2e-11, dtol=1e-8, max_refinements=3, closest_approach=1.01, pole_factor=True):
+        from . import _lib
+
+        self.source = source
+        self._f = source.metric_components if isinstance(source, AbstractMetric) else source
+        if inner_radius is None:
+            if not isinstance(source, AbstractMetric):
+                raise ValueError("a callable metric needs `inner_radius` (the event horizon radius)")
+            inner_radius = source.inner_radius()
+        self._inner_radius = float(inner_radius)
+        self._isco = isco
+        # radial octaves count from a point just inside the horizon; the table starts at the chart's inner radius
+        self.r0 = float(r0) if r0 is not None else self._inner_radius * (1.0 - 1e-3) if self._inner_radius > 0 else -1.0
+        self.r_min = float(r_min) if r_min is not None else max(self._inner_radius * closest_approach * (1.0 - 1e-3), self.r0 + 1e-3)
+        self.r_max = float(r_max)
+        L = _lib.load()
+        for _ in range(max_refinements + 1):
+            grid = _lib.gr_metric_grid()
+            _lib.check(L.gr_metric_grid_plan(self.r_min, self.r_max, self.r0, int(m_r), int(n_theta), grid))
+            grid.pole_factor = 1 if pole_factor else 0      # g_ϕϕ, g_tϕ stored without the sin²θ they share on the axis
+            rn, tn = np.empty(grid.n_r_nodes), np.empty(grid.n_theta_nodes)
+            _lib.check(L.gr_metric_grid_nodes(grid, rn.ctypes.data, tn.ctypes.data))
+            samples = self._sample(rn, tn)
+            table = np.empty(grid.table_doubles)
+            err = (ctypes.c_double * 3)()
+            _lib.check(L.gr_metric_table_fit(grid, samples.ctypes.data, table.ctypes.data, err))
+            self.grid, self.table, self.errors = grid, table, tuple(err)
+            if err[0] <= tol and err[1] <= dtol and err[2] <= dtol:
+                break
+            # refine the direction(s) whose derivative estimate is worse
+            if err[1] > dtol or err[0] > tol:
+                m_r *= 2
+            if err[2] > dtol or err[0] > tol:
+                n_theta *= 2
+        self.m_r, self.n_theta = int(self.grid.m_r), int(self.grid.n_theta)
+
+    def _sample(self, rn, tn):
+        """metric_components on the tensor grid of nodes -> array [n_r, n_θ, 5]."""
+        R, T = np.meshgrid(rn, tn, indexing="ij")
+        try:
+            g = self._f(R, T)
+            out = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), R.shape) for c in g], axis=-1)
+        except (TypeError, ValueError):
+            out = np.empty(R.shape + (5,))
+            for a in range(R.shape[0]):
+                for b in range(R.shape[1]):
+                    out[a, b] = self._f(float(R[a, b]), float(T[a, b]))
+        return np.ascontiguousarray(out, dtype=np.float64)
+
+    def abi_params(self):
+        return []
+
+    def metric_components(self, r, theta):
+        return tuple(self._f(r, theta))
+
+    def _components(self, r, s, c):
+        """(r may be a special_radii.Jet: the generic ISCO / plunging set-up differentiates through here)"""
+        if isinstance(self.source, AbstractMetric) and hasattr(self.source, "_components"):
+            return self.source._components(r, s, c)
+        return self._table_components(r, math.atan2(s, c))
+
+    def table_jacobian(self, r, theta):
+        """(g, ∂r g, ∂θ g) from the table, by the arithmetic of the kernels (gr_metric_table_eval)."""
+        import ctypes as C
+
+        from . import _lib
+
+        g, dr, dth = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
+        _lib.check(_lib.load().gr_metric_table_eval(self.table.ctypes.data, self.table.size, float(r), float(theta), g, dr, dth))
+        return np.array(g), np.array(dr), np.array(dth)
+
+    def _table_components(self, r, theta):
+        """The five components from the table with `r` a float or a Jet (value, d/dr, d²/dr²): the patch polynomial is
+        evaluated in the number type of r, so its exact derivatives come along."""
+        from .special_radii import Jet
+
+        rv = r.v if isinstance(r, Jet) else r
+        t = self.table
+        r0, e_min, n_oct, m_r, n_th = t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6])
+        w = abs(((theta + math.pi) % (2.0 * math.pi)) - math.pi)
+        y = w * n_th / math.pi
+        it = min(int(y), n_th - 1)
+        v = 2.0 * (y - it) - 1.0
+        x = max(float(np.max(rv)) - r0, 2.0 ** e_min) if np.ndim(rv) else max(rv - r0, 2.0 ** e_min)
+        e = min(int(math.floor(math.log2(x))), e_min + n_oct - 1)
+        j = min(int((x / 2.0 ** e - 1.0) * m_r), m_r - 1)
+        # u as a function of r (the Jet carries du/dr = 2 m_r 2^-e)
+        u = ((r - r0) * (1.0 / 2.0 ** e) - 1.0) * float(m_r) * 2.0 - (2.0 * j + 1.0)
+        p = 7
+        base = 16 + ((e - e_min) * m_r + j) * n_th * 184 + it * 184
+        out = []
+        for k in range(5):
+            cb = base + k * 36
+            acc = None
+            for i in range(p, -1, -1):                   # rows i = p .. 0 are stored in this order
+                n = p - i
+                off = cb + n * (n + 1) // 2
+                q = t[off]
+                for tt in range(1, n + 1):
+                    q = q * v + t[off + tt]
+                acc = q if acc is None else acc * u + q
+            out.append(acc * (math.sin(theta) ** 2) if (k >= 3 and t[14] != 0.0) else acc)
+        return tuple(out)
+
+    def inner_radius(self):
+        return self._inner_radius
+
+    def isco(self):
+        if self._isco is not None:
+            return float(self._isco)
+        if isinstance(self.source, AbstractMetric):
+            return self.source.isco()
+        from .special_radii import generic_isco
+
+        return generic_isco(self)
 
 
 def kerr_isco(M, a):

@@ -298,6 +298,9 @@ class TracingConfiguration:
         c.metric_id = m.metric_id
         for i, p in enumerate(m.abi_params()):
             c.params[i] = float(p)
+        if hasattr(m, "table"):
+            # GR_METRIC_TABULATED: the fitted table of a user-defined metric (metrics.TabulatedMetric keeps it alive)
+            c.metric_table, c.metric_table_n = m.table.ctypes.data, m.table.size
         if isinstance(self.chart, PoloidalShapeChart):
             ch = self.chart
             c.r_inner, c.r_outer = float(np.nanmin(ch.table)), float(ch.outer_radius)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GR_ABI_VERSION 6
+#define GR_ABI_VERSION 7
 
 typedef enum {
     GR_OK = 0,
@@ -67,7 +67,15 @@ enum {
     GR_METRIC_SPHERICAL = 7,           /* SphericalMetric() (flat space) src/metrics/minkowski.jl:1-15; no params */
     GR_METRIC_KERR_DARK_MATTER = 8,    /* KerrDarkMatter(M, a, M_dark_matter, Δr, rₛ) src/metrics/kerr-dark-matter.jl:6-70 */
     GR_METRIC_KERR_REFRACTIVE = 9,     /* KerrRefractive(M, a, n, corona_radius) src/metrics/kerr-refractive-ad.jl:8-58 */
-    GR_METRIC_NOZ = 10                 /* NoZMetric(M, a, ϵ) src/metrics/noz-metric.jl:7-66 */
+    GR_METRIC_NOZ = 10,                /* NoZMetric(M, a, ϵ) src/metrics/noz-metric.jl:7-66 */
+    /* ABI 7 -- ANY AbstractStaticAxisSymmetric metric: the reference's plugin contract is a struct and ONE method,
+     * metric_components(m, (r, θ)) -> (g_tt, g_rr, g_θθ, g_ϕϕ, g_tϕ) (src/Gradus.jl:78-86, src/metrics/kerr-metric.jl:62-70);
+     * ForwardDiff supplies the Jacobian (src/tracing/method-implementations/auto-diff.jl:206-211).  A closure cannot cross this
+     * ABI, so the caller samples its metric_components on the nodes gr_metric_grid_nodes() names, gr_metric_table_fit() turns
+     * the samples into piecewise polynomials (total degree 7 on patches geometric in r - r0 and uniform in θ), and the kernels
+     * evaluate the five components and their (∂r, ∂θ) derivatives from that table (gr_config.metric_table; params unused).
+     * See "tabulated metrics" below.  fp64 kernels only ("precision" 32 and the tangent entry points: GR_ERR_UNSUPPORTED). */
+    GR_METRIC_TABULATED = 11
 };
 
 /* accretion geometry
@@ -159,6 +167,11 @@ typedef struct gr_config {
     int32_t comp_n;           /* GR_DISC_COMPOSITE: number of components (2..GR_COMP_MAX), else 0    */
     int32_t _pad3;
     gr_disc_component comp[GR_COMP_MAX];
+    /* ABI 7, GR_METRIC_TABULATED: the table gr_metric_table_fit() wrote (HOST pointer in every entry point; the library keeps a
+     * device copy per context, keyed by the table's build id, so a table is uploaded once) and its length in doubles.
+     * NULL / 0 for every other metric. */
+    const double* metric_table;
+    int64_t metric_table_n;
 } gr_config;
 
 /* GeodesicPoint{Float64,Nothing} -- src/solution-processing.jl:15-32.  152 bytes, same
@@ -494,6 +507,46 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
                                       double* d_out, void* hip_stream);
 int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,
                                const gr_point* points, int64_t n, double max_time, double* out);
+
+/* ---- tabulated metrics (ABI 7, GR_METRIC_TABULATED): the AbstractMetric plugin interface on the device ----
+ * Host-only functions (no context, no device): plan a grid, learn its nodes, fit, check.
+ *
+ *   gr_metric_grid g;  gr_metric_grid_plan(r_min, r_max, r0, m_r, n_theta, &g);
+ *   gr_metric_grid_nodes(&g, r_nodes, theta_nodes);                 // g.n_r_nodes radii, g.n_theta_nodes angles
+ *   samples[(a * g.n_theta_nodes + b) * 5 + k] = metric_components(m, (r_nodes[a], theta_nodes[b]))[k];   // the caller's metric
+ *   gr_metric_table_fit(&g, samples, table, err);                   // table: g.table_doubles doubles
+ *   cfg.metric_id = GR_METRIC_TABULATED; cfg.metric_table = table; cfg.metric_table_n = g.table_doubles;
+ *
+ * Radial patches are the m_r equal parts of every octave [2^e, 2^(e+1)) of r - r0 between r_min and r_max: choose r0 at (or just
+ * inside) the event horizon -- inner_radius(m) -- and r_min = the chart's inner radius, so that the patches shrink geometrically
+ * towards the pole of g_rr; r_max = the chart's outer radius.  Polar patches: n_theta equal parts of [0, π]; the components are
+ * taken to be even about both poles (θ outside [0, π] is folded).  err[0..2] receive the fit's own estimates of the largest
+ * truncation error of a component, of its ∂/∂ln(r - r0) and of its ∂/∂θ, each relative to the component's magnitude on the
+ * patch: refine (m_r, n_theta) until they are below what the integration tolerance needs. */
+typedef struct gr_metric_grid {
+    double r0;                /* origin of the radial octaves                                               */
+    double r_min, r_max;      /* radii the table covers (patch edges are rounded outwards)                   */
+    int32_t e_min, n_oct;     /* octaves 2^e_min .. 2^(e_min + n_oct) of r - r0                              */
+    int32_t m_r, n_theta;     /* patches per octave, patches over [0, π]                                     */
+    int32_t degree, fit_nodes; /* total degree of a patch polynomial (7), Chebyshev nodes per patch and direction (12) */
+    int32_t pole_factor;      /* 1 [set by gr_metric_grid_plan]: g_ϕϕ and g_tϕ are stored divided by sin²θ -- both vanish like
+                                 sin²θ on the axis of any regular axis-symmetric metric, and a polynomial with an ABSOLUTE error
+                                 would leave g^ϕϕ = 1/g_ϕϕ with an unbounded RELATIVE one for rays that graze the axis; the
+                                 kernels multiply the factor (and its derivative) back.  0: stored as sampled -- for a metric
+                                 whose g_ϕϕ does not vanish like sin²θ (the reference's MorrisThorneWormhole, ∝ sin θ)      */
+    int32_t reserved;
+    int64_t n_r_nodes;        /* n_oct * m_r * fit_nodes                                                     */
+    int64_t n_theta_nodes;    /* n_theta * fit_nodes                                                         */
+    int64_t table_doubles;    /* length of the table gr_metric_table_fit writes                              */
+} gr_metric_grid;
+int32_t gr_metric_grid_plan(double r_min, double r_max, double r0, int32_t m_r, int32_t n_theta, gr_metric_grid* grid);
+int32_t gr_metric_grid_nodes(const gr_metric_grid* grid, double* r_nodes, double* theta_nodes);
+int32_t gr_metric_table_fit(const gr_metric_grid* grid, const double* samples /* n_r_nodes x n_theta_nodes x 5 */,
+                            double* table /* table_doubles */, double err[3]);
+/* the table's value at one point, by the arithmetic the kernels use: (g, ∂r g, ∂θ g) of the five components -- for checking a
+ * table against the caller's own Jacobian (Julia: Gradus.metric_jacobian) before tracing with it */
+int32_t gr_metric_table_eval(const double* table, int64_t table_n, double r, double theta, double g[5], double dr[5],
+                             double dth[5]);
 
 /* ---- ONE host thread, SEVERAL devices, ray sets (see gr_render_multi for the shape every *_multi call has) ---- */
 /* Ray sets with one output row per ray (gr_rayset_endpoints, gr_ray_summary, gr_ray_tangent, gr_redshift_radius): contiguous

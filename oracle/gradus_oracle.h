@@ -41,7 +41,8 @@ enum {
 
 enum { ORC_METRIC_KERR = 0, ORC_METRIC_JOHANNSEN = 1, ORC_METRIC_MORRIS_THORNE = 2, ORC_METRIC_BUMBLEBEE = 3,
        ORC_METRIC_KERR_NEWMAN = 4, ORC_METRIC_JOHANNSEN_PSALTIS = 5, ORC_METRIC_DILATON_AXION = 6,
-       ORC_METRIC_SPHERICAL = 7, ORC_METRIC_KERR_DARK_MATTER = 8, ORC_METRIC_KERR_REFRACTIVE = 9, ORC_METRIC_NOZ = 10 };
+       ORC_METRIC_SPHERICAL = 7, ORC_METRIC_KERR_DARK_MATTER = 8, ORC_METRIC_KERR_REFRACTIVE = 9, ORC_METRIC_NOZ = 10,
+       ORC_METRIC_TEST_BUMP = 100 /* a stand-in for a user-defined metric (metrics_tmpl.h): tests of the tabulated-metric path */ };
 /* TABULATED mirrors the product's sampled ThickDisc; TORUS is the closure `_thick_disc` of the
  * reference's own smoke test (test/smoke-tests/rendergeodesics.jl:7-14) restated exactly, used to
  * pin the thick-disc golden value. */
@@ -163,6 +164,8 @@ int64_t orc_plunging_table(const orc_config* c, double r_isco, double* r, double
 
 int64_t orc_trace_steps(const orc_config* c, const double x[4], const double v[4], orc_point* out,
                         double* t, double* r, int64_t cap);
+int64_t orc_trace_steps_rth(const orc_config* c, const double x[4], const double v[4], orc_point* out,
+                            double* t, double* r, double* th, int64_t cap);
 
 int orc_max_threads(void);
 

@@ -274,3 +274,17 @@ static void FN(noz_components)(const double* p, NUM r, NUM th, NUM g[5])
     g[3] = N_DIV(N_MUL(N_MUL(omy2, Se), big), D);
     g[4] = N_NEG(N_DIV(N_MUL(N_SCALE(a, tMr), N_MUL(omy2, Se)), D));
 }
+
+/* NOT a metric of the reference: a stand-in for a USER-DEFINED AbstractStaticAxisSymmetric metric (the plugin contract of
+ * src/Gradus.jl:78-86 -- "define metric_components(m, rθ)" -- exercised by tests of GR_METRIC_TABULATED).  Kerr with
+ * g_tt scaled by 1 + ϵ sin²θ / (1 + ((r - r_b) / w)²): smooth, asymptotically Kerr, in no catalogue.  The oracle pushes it
+ * through the same dual numbers as every other metric, i.e. what the reference would do with it.  p = M, a, ϵ, r_b, w */
+static void FN(test_bump_components)(const double* p, NUM r, NUM th, NUM g[5])
+{
+    FN(kerr_components)(p, r, th, g);
+    const double e = p[2], rb = p[3], w = p[4];
+    NUM s = N_SIN(th);
+    NUM x = N_SCALE(1.0 / w, N_SUB(r, N_CONST(rb)));
+    NUM bump = N_DIV(N_SCALE(e, N_MUL(s, s)), N_ADD(N_CONST(1.0), N_MUL(x, x)));
+    g[0] = N_MUL(g[0], N_ADD(N_CONST(1.0), bump));
+}

@@ -20,7 +20,8 @@ OUT_OF_DOMAIN, WITHIN_INNER_BOUNDARY, INTERSECTED_WITH_GEOMETRY, NO_STATUS = 0, 
 METRIC_KERR, METRIC_JOHANNSEN = 0, 1
 METRIC_IDS = {"kerr": 0, "johannsen": 1, "morris-thorne": 2, "bumblebee": 3, "kerr-newman": 4,
               "johannsen-psaltis": 5, "dilaton-axion": 6, "spherical": 7, "kerr-dark-matter": 8,
-              "kerr-refractive": 9, "noz": 10}
+              "kerr-refractive": 9, "noz": 10,
+              "test-bump": 100}      # a stand-in for a user-defined metric (metrics_tmpl.h): Kerr with a smooth bump in g_tt
 DISC_NONE, DISC_THIN, DISC_SHAKURA_SUNYAEV, DISC_TABULATED, DISC_TORUS, DISC_DATUM = 0, 1, 2, 3, 4, 5
 DISC_ELLIPTICAL, DISC_PRECESSING_THIN = 6, 7
 DISC_COMPOSITE = 8
@@ -146,6 +147,8 @@ def lib():
         L.orc_max_threads.restype = C.c_int
         L.orc_trace_steps.argtypes = [cp, dp, dp, C.c_void_p, dp, dp, C.c_int64]
         L.orc_trace_steps.restype = C.c_int64
+        L.orc_trace_steps_rth.argtypes = [cp, dp, dp, C.c_void_p, dp, dp, dp, C.c_int64]
+        L.orc_trace_steps_rth.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -431,6 +434,16 @@ def trace_steps(cfg, x, v, cap=100000):
     t, r = np.zeros(cap), np.zeros(cap)
     n = lib().orc_trace_steps(C.byref(cfg), _dp(x), _dp(v), out.ctypes.data, _dp(t), _dp(r), cap)
     return out[0], t[:n], r[:n]
+
+
+def trace_steps_rth(cfg, x, v, cap=100000):
+    """(point, t[], r[], θ[]) of every accepted step of one ray: where a ray spends its steps in the (r, θ) plane."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.zeros(1, dtype=POINT_DTYPE)
+    t, r, th = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    n = lib().orc_trace_steps_rth(C.byref(cfg), _dp(x), _dp(v), out.ctypes.data, _dp(t), _dp(r), _dp(th), cap)
+    return out[0], t[:n], r[:n], th[:n]
 
 
 def circular_energy(cfg, r):

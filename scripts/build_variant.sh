@@ -17,7 +17,7 @@ sys.path.insert(0, root)
 tmp = tempfile.mkdtemp()
 src = os.path.join(tmp, "a", "b", "csrc")          # the sources include "../../include/gradus_mi355x.h" relative to csrc
 os.makedirs(src); os.makedirs(os.path.join(tmp, "a", "include"))
-names = ["gr_device.hpp", "gr_kernels.hpp", "gr_tangent.hpp", "gr_mesh_grid.hpp", "gradus_mi355x.hip", "kernels_tu.hip"]
+names = ["gr_device.hpp", "gr_kernels.hpp", "gr_tangent.hpp", "gr_mesh_grid.hpp", "gr_tabmetric.hpp", "gradus_mi355x.hip", "kernels_tu.hip", "metric_table.hip"]
 if rev == "WORK":
     for f in names:
         shutil.copy(os.path.join(root, "gradus.jl_amd", "csrc", f), src)

@@ -9,6 +9,7 @@ PROF_CMD="scripts/sibling_workloads.py <which>" PROF_KERNEL=<substring of the ke
     dual6     DilatonAxion(a=0.5, β=0.3, b=1) 1024², ThinDisc, shadow -- the heaviest dual-number metric k_trace_lane<GenericMetricT<6>,1>
     mesh      Kerr 1024², the bench observer, MeshAccretionGeometry: a ring slab of 3840 triangles            k_trace_lane<KerrFamily<false>,8>
     dual8 / dual9 / dual10   KerrDarkMatter(a=0.5, 2, 20, 10) / KerrRefractive(a=0.5, n=1.1, 20) / NoZMetric(a=0.5, ϵ=0.5), ThinDisc(6, 50), shadow
+    tabkerr / tabc4   GR_METRIC_TABULATED: KerrMetric(a=0.998) resp. the C4 Johannsen metric through a table, ThinDisc(isco, 50), redshift   k_trace_lane<TabulatedMetric,1>
     c5        BASELINE config 5 line profile, 4096² polar-plane rays, fp64 tol 1e-9                  k_trace_lane<KerrFamily<false>,1> (tiled rays)
     c5p       the same through the persistent kernel                                                  k_trace_persistent<...>
     c5f32     config 5 with the fp32 kernels at tol 1e-5                                              gr32::k_trace_*
@@ -37,8 +38,16 @@ ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
 ms = []
 extra = {}
 
-if which in ("c4", "generic", "dual", "dual6", "dual2", "dual8", "dual9", "dual10"):
-    if which == "dual2":
+if which in ("c4", "generic", "dual", "dual6", "dual2", "dual8", "dual9", "dual10", "tabkerr", "tabc4"):
+    if which in ("tabkerr", "tabc4"):
+        # GR_METRIC_TABULATED: the bench metric / the C4 metric through a piecewise-polynomial table (TAB_GRID = "m_r,n_theta")
+        base = G.KerrMetric(1.0, 0.998) if which == "tabkerr" else G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0)
+        m_r, n_theta = (int(t) for t in os.environ.get("TAB_GRID", "8,32").split(","))
+        m = G.TabulatedMetric(base, m_r=m_r, n_theta=n_theta, max_refinements=0)
+        x = np.array([0.0, 1000.0, math.radians(75 if which == "tabkerr" else 70), 0.0])
+        pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
+        extra = {"grid": [m_r, n_theta], "table_mb": m.table.nbytes / 1e6}
+    elif which == "dual2":
         m = G.MorrisThorneWormhole(1.0)
         x = np.array([0.0, 1000.0, math.radians(70), 0.0])
         pf = G.ConstPointFunctions.shadow()

@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libhost_harness.so")
 SRC = [os.path.join(HERE, "host_harness.cpp"), os.path.join(ROOT, "gradus.jl_amd", "csrc", "gr_device.hpp"),
-       os.path.join(ROOT, "gradus.jl_amd", "csrc", "gr_mesh_grid.hpp"), os.path.join(ROOT, "include", "gradus_mi355x.h")]
+       os.path.join(ROOT, "gradus.jl_amd", "csrc", "gr_mesh_grid.hpp"), os.path.join(ROOT, "include", "gradus_mi355x.h"),
+       os.path.join(ROOT, "gradus.jl_amd", "csrc", "gr_tabmetric.hpp")]
 
 
 def build():

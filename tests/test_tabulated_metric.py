@@ -1,0 +1,323 @@
+"""GR_METRIC_TABULATED: a user-defined AbstractStaticAxisSymmetric metric on the device.
+
+The reference's plugin contract is one method, metric_components(m, (r, θ)) (src/metrics/kerr-metric.jl:62-70), with ForwardDiff
+for the Jacobian (auto-diff.jl:206-211).  Here the host samples that method, gr_metric_table_fit turns the samples into piecewise
+polynomials and the kernels evaluate components and derivatives from the table.  Checked:
+
+  CPU  the table against the oracle's dual-number Jacobian (Kerr, Johannsen, a metric of no catalogue), the fold in θ, the
+       error paths of the four host-only entry points, and the device functor compiled for the host (tests/host_harness.cpp)
+       against the oracle ray by ray;
+  GPU  tabulated-Kerr on C2 and tabulated-Johannsen on C4, every pixel, against the fused kernels AND the oracle at the bar of
+       tests/test_gpu_baseline_configs.py; the metric of no catalogue against the oracle running the same function through its
+       dual numbers.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import harness as Hh
+
+X_FAR = np.array([0.0, 1000.0, math.radians(75), 0.0])
+BUMP = (1.0, 0.9, 0.08, 6.0, 2.0)       # M, a, ϵ, r_b, w of oracle/metrics_tmpl.h test_bump_components
+
+
+def bump_components(r, th, p=BUMP):
+    """The same function as the oracle's stand-in for a user-defined metric, as a numpy callable: Kerr with
+    g_tt scaled by 1 + ϵ sin²θ / (1 + ((r - r_b)/w)²)."""
+    M, a, e, rb, w = p
+    s2 = np.sin(th) ** 2
+    c2 = 1.0 - s2
+    Sig = r * r + a * a * c2
+    tt = -(1.0 - 2.0 * M * r / Sig)
+    rr = Sig / (r * r + a * a - 2.0 * M * r)
+    pp = s2 * (r * r + a * a + 2.0 * M * r * a * a * s2 / Sig)
+    tp = -2.0 * M * r * a * s2 / Sig
+    x = (r - rb) / w
+    return (tt * (1.0 + e * s2 / (1.0 + x * x)), rr, Sig, pp, tp)
+
+
+def _oracle_cfg(O, name, params):
+    return O.make_config(name, params)
+
+
+def _jacobian_errors(O, tm, cfg, rng, n=400):
+    """Largest errors of the table's (g, ∂r g, ∂θ g) against the oracle's dual numbers at random points of the table's range.
+    Each error is taken point by point relative to the component's size THERE -- with floors where a component passes through
+    zero without the geodesic equation caring: g_tt on the ergosurface (against 0.1), g_ϕϕ at the poles (against 1e-3 g_θθ),
+    g_tϕ (against 1e-2 of the block it couples) -- and the radial derivative per unit of ln(r - r0), as the fit quotes it."""
+    rs = tm.r_min * (tm.r_max / tm.r_min) ** rng.uniform(0, 1, n)
+    ths = rng.uniform(0.0, math.pi, n)
+    A, B = [], []
+    for r, th in zip(rs, ths):
+        A.append(np.concatenate(tm.table_jacobian(r, th)))
+        B.append(np.concatenate(O.metric_jacobian(cfg, r, th)))
+    A, B = np.array(A), np.array(B)
+    sc = np.abs(B[:, :5]).copy()
+    sc[:, 0] = np.maximum(sc[:, 0], 0.1)
+    sc[:, 3] = np.maximum(sc[:, 3], 1e-3 * sc[:, 2])
+    sc[:, 4] = np.maximum(sc[:, 4], 1e-2 * np.sqrt(sc[:, 0] * sc[:, 3]))
+    ev = float(np.max(np.abs(A[:, :5] - B[:, :5]) / sc))
+    edr = float(np.max(np.abs(A[:, 5:10] - B[:, 5:10]) * (rs - tm.r0)[:, None] / sc))
+    edt = float(np.max(np.abs(A[:, 10:] - B[:, 10:]) / sc))
+    return ev, edr, edt
+
+
+@pytest.fixture(scope="module")
+def tab_kerr(G):
+    return G.TabulatedMetric(G.KerrMetric(1.0, 0.998))
+
+
+@pytest.fixture(scope="module")
+def tab_johannsen(G):
+    return G.TabulatedMetric(G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0))
+
+
+@pytest.fixture(scope="module")
+def tab_bump(G, oracle):
+    cfg = oracle.make_config("test-bump", BUMP)
+    return G.TabulatedMetric(bump_components, inner_radius=1.0 + math.sqrt(1.0 - 0.81), isco=oracle.isco(cfg))
+
+
+def test_table_matches_dual_number_jacobian_kerr(G, oracle, tab_kerr):
+    assert tab_kerr.m_r == 8 and tab_kerr.n_theta == 32          # the default grid suffices: no refinement
+    assert tab_kerr.errors[0] < 2e-11 and tab_kerr.errors[1] < 1e-8 and tab_kerr.errors[2] < 1e-8
+    cfg = oracle.make_config("kerr", (1.0, 0.998))
+    ev, edr, edt = _jacobian_errors(oracle, tab_kerr, cfg, np.random.default_rng(5))
+    assert ev < 1e-11 and edr < 3e-9 and edt < 3e-9, (ev, edr, edt)
+
+
+def test_table_matches_dual_number_jacobian_johannsen(G, oracle, tab_johannsen):
+    cfg = oracle.make_config("johannsen", (1.0, 0.7, 2.0, 0.0, 0.0, 1.0))
+    ev, edr, edt = _jacobian_errors(oracle, tab_johannsen, cfg, np.random.default_rng(6))
+    assert ev < 1e-11 and edr < 3e-9 and edt < 3e-9, (ev, edr, edt)
+
+
+def test_table_matches_dual_number_jacobian_user_metric(G, oracle, tab_bump):
+    cfg = oracle.make_config("test-bump", BUMP)
+    ev, edr, edt = _jacobian_errors(oracle, tab_bump, cfg, np.random.default_rng(7))
+    assert ev < 1e-11 and edr < 3e-9 and edt < 3e-9, (ev, edr, edt)
+
+
+def test_error_estimates_are_not_optimistic(G, oracle):
+    """The fit's own estimates (what a caller refines against) bound the measured errors on a deliberately coarse grid."""
+    tm = G.TabulatedMetric(G.KerrMetric(1.0, 0.998), m_r=2, n_theta=8, max_refinements=0)
+    assert tm.m_r == 2 and tm.n_theta == 8
+    cfg = oracle.make_config("kerr", (1.0, 0.998))
+    ev, edr, edt = _jacobian_errors(oracle, tm, cfg, np.random.default_rng(8))
+    assert tm.errors[0] > 1e-9                    # coarse on purpose
+    assert ev < 3 * tm.errors[0] and edr < 3 * tm.errors[1] and edt < 3 * tm.errors[2], (ev, edr, edt, tm.errors)
+
+
+def test_refinement_stops_at_tolerance(G):
+    tm = G.TabulatedMetric(G.KerrMetric(1.0, 0.5), m_r=2, n_theta=4, max_refinements=4)
+    assert tm.errors[0] <= 2e-11 and tm.errors[1] <= 1e-8 and tm.errors[2] <= 1e-8
+    assert tm.m_r > 2 and tm.n_theta > 4
+
+
+def test_theta_fold(tab_kerr):
+    r, th = 3.7, 0.83
+    g, dr, dt = tab_kerr.table_jacobian(r, th)
+    for th2, sign in ((-th, -1.0), (th + 2 * math.pi, 1.0), (2 * math.pi - th, -1.0), (th - 4 * math.pi, 1.0)):
+        g2, dr2, dt2 = tab_kerr.table_jacobian(r, th2)
+        np.testing.assert_allclose(g2, g, rtol=1e-13)
+        np.testing.assert_allclose(dr2, dr, rtol=1e-12)
+        np.testing.assert_allclose(dt2, sign * dt, rtol=1e-11, atol=1e-13)
+    # across the pole: θ = π + δ is θ = π - δ
+    g3, _, dt3 = tab_kerr.table_jacobian(r, math.pi + 0.01)
+    g4, _, dt4 = tab_kerr.table_jacobian(r, math.pi - 0.01)
+    np.testing.assert_allclose(g3, g4, rtol=1e-13)
+    np.testing.assert_allclose(dt3, -dt4, rtol=1e-11)
+
+
+def test_outside_the_radial_range_takes_the_nearest_patch(tab_kerr):
+    g, dr, dt = tab_kerr.table_jacobian(tab_kerr.r0 - 1.0, 1.0)      # inside the origin of the octaves: clamped, finite
+    assert np.all(np.isfinite(g)) and np.all(np.isfinite(dr))
+    g, dr, dt = tab_kerr.table_jacobian(float("nan"), 1.0)
+    assert np.all(np.isfinite(g))
+
+
+def test_host_entry_points_reject_bad_input(G):
+    L = G._lib
+    lib = L.load()
+    grid = L.gr_metric_grid()
+    assert lib.gr_metric_grid_plan(2.0, 1.0, 0.5, 8, 32, grid) == -1            # r_max < r_min
+    assert lib.gr_metric_grid_plan(1.0, 10.0, 1.5, 8, 32, grid) == -1           # r0 >= r_min
+    assert lib.gr_metric_grid_plan(1.0, 10.0, 0.5, 0, 32, grid) == -1
+    assert lib.gr_metric_grid_plan(1.0, 10.0, 0.5, 8, 0, grid) == -1
+    assert lib.gr_metric_grid_plan(1.0, 10.0, 0.5, 2, 2, None) == -1
+    assert lib.gr_metric_grid_plan(1.0, 10.0, 0.5, 2, 2, grid) == 0
+    assert grid.pole_factor == 1
+    grid.pole_factor = 0                      # the samples below are constants: nothing vanishes on the axis
+    assert grid.degree == 7 and grid.n_r_nodes == grid.n_oct * 2 * grid.fit_nodes and grid.n_theta_nodes == 2 * grid.fit_nodes
+    rn, tn = np.empty(grid.n_r_nodes), np.empty(grid.n_theta_nodes)
+    assert lib.gr_metric_grid_nodes(grid, rn.ctypes.data, tn.ctypes.data) == 0
+    assert rn.min() > 1.0 - 0.5 and np.all(np.diff(np.sort(tn)) > 0) and tn.min() > 0 and tn.max() < math.pi
+    samples = np.ones((grid.n_r_nodes, grid.n_theta_nodes, 5))
+    table = np.empty(grid.table_doubles)
+    err = (C.c_double * 3)()
+    samples[3, 4, 2] = np.inf
+    assert lib.gr_metric_table_fit(grid, samples.ctypes.data, table.ctypes.data, err) == -1
+    assert b"finite" in lib.gr_last_error()
+    samples[3, 4, 2] = 1.0
+    bad = L.gr_metric_grid.from_buffer_copy(grid)
+    bad.n_r_nodes += 1
+    assert lib.gr_metric_table_fit(bad, samples.ctypes.data, table.ctypes.data, err) == -1
+    assert lib.gr_metric_table_fit(grid, samples.ctypes.data, table.ctypes.data, err) == 0
+    assert err[0] < 1e-14                     # a constant is fitted exactly
+    g, dr, dt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
+    assert lib.gr_metric_table_eval(table.ctypes.data, table.size, 3.0, 1.0, g, dr, dt) == 0
+    np.testing.assert_allclose(np.array(g), 1.0, atol=1e-14)
+    np.testing.assert_allclose(np.array(dr), 0.0, atol=1e-13)
+    assert lib.gr_metric_table_eval(table.ctypes.data, table.size - 1, 3.0, 1.0, g, dr, dt) == -1      # wrong length
+    table[0] = 0.0
+    assert lib.gr_metric_table_eval(table.ctypes.data, table.size, 3.0, 1.0, g, dr, dt) == -1          # not a table
+
+
+def test_two_tables_have_distinct_build_ids(G):
+    a = G.TabulatedMetric(G.KerrMetric(1.0, 0.5), m_r=2, n_theta=4, max_refinements=0)
+    b = G.TabulatedMetric(G.KerrMetric(1.0, 0.6), m_r=2, n_theta=4, max_refinements=0)
+    assert a.table[8] != b.table[8]           # H_BUILD_ID: the contexts' device copies are keyed by it
+
+
+def test_scalar_callable_is_sampled_point_by_point(G):
+    def f(r, th):
+        if isinstance(r, np.ndarray):
+            raise TypeError("scalars only")
+        return G.KerrMetric(1.0, 0.3).metric_components(r, th)
+
+    tm = G.TabulatedMetric(f, inner_radius=1.0 + math.sqrt(1 - 0.09), isco=5.0, m_r=1, n_theta=2, r_max=50.0, max_refinements=0)
+    g, _, _ = tm.table_jacobian(10.0, 1.0)
+    np.testing.assert_allclose(g, f(10.0, 1.0), rtol=1e-6)
+
+
+# ---- the device functor compiled for the host (tests/host_harness.cpp) against the oracle, ray by ray ----
+
+def _compare_endpoints(got, ref, x_rtol=1e-6, max_flips=0):
+    flips = int(np.sum(got["status"] != ref["status"]))
+    assert flips <= max_flips, f"{flips} status flips"
+    # rays that end on the inner boundary are compared by status only: t and ϕ diverge towards the horizon and the end state
+    # there is ill-conditioned in every implementation (the fused Kerr kernel differs from the oracle by 2e-3 on the same rays)
+    same = (got["status"] == ref["status"]) & (ref["status"] != 1)
+    for f in ("x", "v"):
+        a, b = got[f][same], ref[f][same]
+        scale = np.maximum(np.abs(b), 1e-3 * np.max(np.abs(b), axis=1, keepdims=True))
+        assert np.max(np.abs(a - b) / scale) < x_rtol, (f, float(np.max(np.abs(a - b) / scale)))
+    assert np.max(np.abs(got["lambda_max"][same] / ref["lambda_max"][same] - 1.0)) < x_rtol
+
+
+@pytest.mark.parametrize("which", ["kerr", "johannsen", "bump"])
+def test_tabulated_endpoints_vs_oracle_kernel_logic(G, oracle, which, tab_kerr, tab_johannsen, tab_bump):
+    tm, name, params = {"kerr": (tab_kerr, "kerr", (1.0, 0.998)),
+                        "johannsen": (tab_johannsen, "johannsen", (1.0, 0.7, 2.0, 0.0, 0.0, 1.0)),
+                        "bump": (tab_bump, "test-bump", BUMP)}[which]
+    W = H = 24
+    disc = (3.0, 400.0)      # (outer rim outside the field of view: rim pixels flip between any two implementations)
+    cfg = G.render_configuration(tm, X_FAR, G.ThinDisc(*disc), 2000.0, image_width=W, image_height=H,
+                                 alpha_lims=(-60, 60), beta_lims=(-35, 35))
+    got = Hh.render_endpoints(G, cfg)
+    ocfg = oracle.make_config(name, params, disc=disc, lambda_max=2000.0)
+    assert ocfg.r_inner == pytest.approx(cfg.chart.inner_radius, rel=1e-14) and ocfg.r_outer == cfg.chart.outer_radius
+    vs = oracle.render_velocities(ocfg, X_FAR, (-60, 60), (-35, 35), W, H)
+    ref = oracle.trace(ocfg, X_FAR, vs)
+    _compare_endpoints(got, ref, max_flips=2)       # (the fused Johannsen kernel has the same two horizon-rim flips against the oracle)
+    if which != "bump":
+        # ... and against the metric's own fused right-hand side through the same integrator: the table's error alone
+        fcfg = G.render_configuration(tm.source, X_FAR, G.ThinDisc(*disc), 2000.0, image_width=W, image_height=H,
+                                      alpha_lims=(-60, 60), beta_lims=(-35, 35))
+        _compare_endpoints(got, Hh.render_endpoints(G, fcfg), x_rtol=1e-8, max_flips=0)
+
+
+# ---- on the device ----
+
+def _render_pair(G, ens, tm, base, size, disc, pf_of):
+    """(image through the table, image through the metric's own kernels) of one plane"""
+    out = []
+    for m in (tm, base):
+        a, b, img = G.rendergeodesics(m, X_FAR, disc, 2000.0, image_width=size, image_height=size, alpha_lims=(-60, 60),
+                                      beta_lims=(-35, 35), pf=pf_of(m), ensemble=ens)
+        out.append(img)
+    return out
+
+
+@pytest.mark.gpu
+def test_tabulated_kerr_equals_fused_kerr_and_oracle_on_c2(G, ens, oracle, tab_kerr):
+    """BASELINE config C2 (Kerr a = 0.998, 1024², ThinDisc, redshift) through the TABLE: every pixel against the fused Kerr
+    kernel, a strided subset against the oracle."""
+    base = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(base.isco(), 50.0)
+    pf_of = lambda m: G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    tab, fused = _render_pair(G, ens, tab_kerr, base, 1024, d, pf_of)
+    flips = int(np.sum(np.isnan(tab) != np.isnan(fused)))
+    both = ~np.isnan(tab) & ~np.isnan(fused)
+    rel = np.abs(tab[both] / fused[both] - 1.0)
+    # two integrations of the same rays with right-hand sides that differ by ~1e-10: the bar of the C2 test
+    assert flips <= 40, flips
+    assert np.quantile(rel, 0.999) < 1e-6 and np.median(rel) < 1e-8, (float(np.quantile(rel, 0.999)), float(np.median(rel)))
+    assert int(np.sum(rel > 1e-6)) <= 200, int(np.sum(rel > 1e-6))
+
+
+@pytest.mark.gpu
+def test_tabulated_johannsen_equals_fused_johannsen_on_c4(G, ens, tab_johannsen):
+    base = tab_johannsen.source
+    d = G.ThinDisc(base.isco(), 50.0)
+    pf_of = lambda m: G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    tab, fused = _render_pair(G, ens, tab_johannsen, base, 1024, d, pf_of)
+    flips = int(np.sum(np.isnan(tab) != np.isnan(fused)))
+    both = ~np.isnan(tab) & ~np.isnan(fused)
+    rel = np.abs(tab[both] / fused[both] - 1.0)
+    assert flips <= 40, flips
+    assert np.quantile(rel, 0.999) < 1e-6 and np.median(rel) < 1e-8, (float(np.quantile(rel, 0.999)), float(np.median(rel)))
+    assert int(np.sum(rel > 1e-6)) <= 200, int(np.sum(rel > 1e-6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["kerr", "johannsen", "bump"])
+def test_tabulated_endpoints_vs_oracle_on_device(G, ens, oracle, which, tab_kerr, tab_johannsen, tab_bump):
+    """End points of a 96 x 96 plane through the table on the DEVICE against the oracle's dual-number trace of the same
+    function -- for the metric of no catalogue this is the only thing it can be compared with."""
+    tm, name, params = {"kerr": (tab_kerr, "kerr", (1.0, 0.998)),
+                        "johannsen": (tab_johannsen, "johannsen", (1.0, 0.7, 2.0, 0.0, 0.0, 1.0)),
+                        "bump": (tab_bump, "test-bump", BUMP)}[which]
+    W = H = 96
+    disc = (3.0, 400.0)
+    cache = G.prerendergeodesics(tm, X_FAR, G.ThinDisc(*disc), 2000.0, image_width=W, image_height=H, alpha_lims=(-60, 60),
+                                 beta_lims=(-35, 35), ensemble=ens)
+    got = np.asarray(cache.points).T.reshape(-1)          # column-major H x W -> ray order
+    ocfg = oracle.make_config(name, params, disc=disc, lambda_max=2000.0)
+    vs = oracle.render_velocities(ocfg, X_FAR, (-60, 60), (-35, 35), W, H)
+    ref = oracle.trace(ocfg, X_FAR, vs)
+    _compare_endpoints(got, ref, max_flips=8)
+
+
+@pytest.mark.gpu
+def test_user_metric_redshift_image_vs_oracle(G, ens, oracle, tab_bump):
+    """The whole render path for a metric of no catalogue: generic ISCO, device-traced plunging table, redshift ∘ filter,
+    against the oracle doing all of that with its dual numbers."""
+    W = H = 64
+    cfgo = oracle.make_config("test-bump", BUMP)
+    isco = oracle.isco(cfgo)
+    d = G.ThinDisc(isco, 40.0)
+    pf = G.ConstPointFunctions.redshift(tab_bump, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    a, b, img = G.rendergeodesics(tab_bump, X_FAR, d, 2000.0, image_width=W, image_height=H, alpha_lims=(-50, 50),
+                                  beta_lims=(-30, 30), pf=pf, ensemble=ens)
+    ocfg = oracle.make_config("test-bump", BUMP, disc=(isco, 40.0), lambda_max=2000.0)
+    ref = oracle.rendergeodesics(ocfg, X_FAR, (-50, 50), (-30, 30), W, H, pf_id=oracle.PF_REDSHIFT,
+                                 filter_id=oracle.FILTER_INTERSECTED, r_isco=isco)
+    assert int(np.sum(np.isnan(img) != np.isnan(ref))) <= 4
+    both = ~np.isnan(img) & ~np.isnan(ref)
+    assert both.sum() > 500
+    assert np.max(np.abs(img[both] / ref[both] - 1.0)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_tabulated_metric_is_fp64_only(G, ens, tab_kerr):
+    d = G.ThinDisc(3.0, 50.0)
+    ens.set("precision", 32)
+    try:
+        with pytest.raises(G._lib.GradusMI355XError, match="fp64 kernels only"):
+            G.rendergeodesics(tab_kerr, X_FAR, d, 2000.0, image_width=16, image_height=16, alpha_lims=(-60, 60),
+                              beta_lims=(-35, 35), ensemble=ens)
+    finally:
+        ens.set("precision", 64)
