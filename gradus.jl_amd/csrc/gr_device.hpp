@@ -1713,6 +1713,9 @@ GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[
 #ifndef GR_TAB_PARK
 #define GR_TAB_PARK 0       // stage accelerations parked in LDS (ParkA); measured equal at two waves per SIMD (profiles/r5e_tab_ab.log)
 #endif
+#ifndef GR_TAB_LOOKAHEAD_GLOBAL
+#define GR_TAB_LOOKAHEAD_GLOBAL 32
+#endif
 #ifndef GR_TAB_LOOKAHEAD
 #define GR_TAB_LOOKAHEAD 16     // coefficients the LDS reads of an evaluation run ahead of its arithmetic (LdsCoef)
 #endif
@@ -1726,6 +1729,12 @@ constexpr int kTabSlotBytes = 1488;
 constexpr size_t kTabLdsBytesPerWave = kTabHeadBytes + (size_t)kTabSlots * kTabSlotBytes;
 static_assert(kTabSlots >= 1 && kTabSlots <= 8 && gr_tab::kPatchDoubles * 8 <= kTabSlotBytes, "patch cache geometry");
 typedef double double2_t __attribute__((ext_vector_type(2)));
+#ifndef GR_HOST_HARNESS
+// the right-hand side with the coefficients read per lane from global memory, NOT inlined: the step loop holds six copies of the
+// LDS-fed evaluation already (45 KB of code against a 64 KB instruction cache); this one serves lanes that found no cache slot
+__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, int pole_factor, double u, double v, double su, double sv,
+                                                             double s, double c, double vt, double vr, double vh, double vp, double* out);
+#endif
 struct TabulatedMetric {
     static constexpr int kMinWavesPerSimd = 2;
     static constexpr int kLaneWavesPerSimd = GR_TAB_LANE_WAVES;
@@ -1793,18 +1802,19 @@ struct TabulatedMetric {
     // the accumulator of the row just finished.
     // The loads are volatile so that they stay 16-byte reads (the optimiser otherwise narrows them to the doubles used and the
     // back end pairs those as ds_read2_b64: half the LDS bandwidth).
-    struct LdsCoef {
+    template <class PairPtr, class AddrInt, int LOOKAHEAD>
+    struct CoefStream {
         typedef const double2_t __attribute__((address_space(3))) lds_cdouble2;
         static constexpr int kAll = gr_tab::kComps * gr_tab::kCoefs;       // 180 coefficients = 90 pairs
-        mutable lds_cdouble2* sl;
+        mutable PairPtr sl;
         mutable double2_t buf[kAll / 2];
         // coefficients consumed once row `row` of component `comp` is done, and the pairs requested by then
         static constexpr int consumed(int comp, int row) { return gr_tab::kCoefs * comp + gr_tab::row_offset(row) + (gr_tab::kDegree - row + 1); }
-        static constexpr int pairs_by(int coefs) { return (coefs + GR_TAB_LOOKAHEAD > kAll ? kAll : coefs + GR_TAB_LOOKAHEAD + 1) / 2; }
+        static constexpr int pairs_by(int coefs) { return (coefs + LOOKAHEAD > kAll ? kAll : coefs + LOOKAHEAD + 1) / 2; }
         GR_DEV void issue(int from_pair, int to_pair) const
         {
 #pragma unroll
-            for (int j = from_pair; j < to_pair; ++j) buf[j] = *(volatile lds_cdouble2*)(sl + j);
+            for (int j = from_pair; j < to_pair; ++j) buf[j] = *(volatile typename std::remove_pointer<PairPtr>::type*)(sl + j);
         }
         GR_DEV void start() const { issue(0, pairs_by(0)); }
         GR_DEV double operator()(int kk) const { return buf[kk >> 1][kk & 1]; }
@@ -1820,14 +1830,18 @@ struct TabulatedMetric {
             const int before = (row == gr_tab::kDegree - 2) ? (comp == 0 ? 0 : consumed(comp - 1, 0)) : consumed(comp, row + 1);
             const int from = pairs_by(before), to = pairs_by(consumed(comp, row));
             if (to <= from) return;
-            unsigned a = (unsigned)(unsigned long long)sl;      // (a 32-bit LDS address)
+            AddrInt a = (AddrInt)(unsigned long long)sl;      // (a 32-bit LDS address, or a 64-bit global one)
             // (all three accumulators: a chain left out is deferred by the scheduler to the end of the evaluation, with every
             // intermediate of the value chain it reads kept alive -- spilled -- until then)
             asm volatile("" : "+v"(a), "+v"(acc), "+v"(acc_u), "+v"(acc_v));
-            sl = (lds_cdouble2*)(unsigned long long)a;
+            sl = (PairPtr)(unsigned long long)a;
             issue(from, to);
         }
     };
+    typedef CoefStream<const double2_t __attribute__((address_space(3)))*, unsigned, GR_TAB_LOOKAHEAD> LdsCoef;      // out of a cache slot
+    // ... out of the table in global memory (tab_rhs_from_global): memory latency is ten times the LDS's, and the lanes that take
+    // this path are few and often alone in their wave -- four times the look-ahead
+    typedef CoefStream<const double2_t*, unsigned long long, GR_TAB_LOOKAHEAD_GLOBAL> GlobalCoef;
 #endif
     template <class Ld, class Ops_>
     GR_DEV void horner(const Ld& ld, const Ops_& ops, double u, double v, double su, double sv, real s, real c, real g[5], real gr[5], real gt[5]) const
@@ -1907,75 +1921,72 @@ struct TabulatedMetric {
         __builtin_amdgcn_wave_barrier();                          \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
     } while (0)
-            bool done = false;
-            at = ar = ah = ap = 0.0;
-            for (;;) {      // wave-uniform: every lane that called goes round together (one round unless the wave straddles more patches than slots)
-                // -- phase 1: a slot for every lane that still has to evaluate
-                int slot = -1;
-                if (!done) {
+            // -- phase 1: a slot for every lane
+            int slot = -1;
 #pragma unroll
-                    for (int k = 0; k < kTabSlots; ++k) slot = (tags[k] == patch) ? k : slot;
-                }
-                unsigned long long todo = __builtin_amdgcn_ballot_w64(!done && slot < 0);
+            for (int k = 0; k < kTabSlots; ++k) slot = (tags[k] == patch) ? k : slot;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(slot < 0);
 #ifdef GR_TAB_DEBUG_NOMISS      // (register-pressure experiments only: wrong results)
-                todo = 0ull; slot = slot < 0 ? 0 : slot;
+            todo = 0ull; slot = slot < 0 ? 0 : slot;
 #endif
-                if (todo != 0ull) {
-                    // slots that lanes of THIS round read must stay; the others are replaced round robin.  All lanes copy.
-                    unsigned used = 0;
+            if (todo != 0ull) {
+                // slots that lanes of THIS evaluation read must stay; the others are replaced round robin.  All lanes copy.
+                unsigned used = 0;
 #pragma unroll
-                    for (int k = 0; k < kTabSlots; ++k) used |= __builtin_amdgcn_ballot_w64(!done && slot == k) != 0ull ? (1u << k) : 0u;
-                    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-                    const int n_act = __builtin_popcountll(act);
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-                    int rr = tags[kTabSlots];
-                    for (int tries = 0; tries < kTabSlots && todo != 0ull; ++tries) {
-                        const int sidx = rr;
-                        rr = rr + 1 >= kTabSlots ? 0 : rr + 1;
-                        if (used & (1u << sidx)) continue;
-                        const int first = (int)__builtin_ctzll(todo);
-                        const int pp = __builtin_amdgcn_readlane(patch, first);
-                        const double2_t* src = (const double2_t*)(patches + (int64_t)pp * gr_tab::kPatchDoubles);
-                        typedef double2_t __attribute__((address_space(3))) lds_double2;
-                        lds_double2* dst = (lds_double2*)(cs.tab + kTabHeadBytes + sidx * kTabSlotBytes);
-                        // 92 pieces of 16 bytes, piece q by the active lane of rank q mod n_act -- kTabCopyDepth loads in flight
-                        // per lane before the first store: in the tail of a wave (a few lanes left, each fetching dozens of
-                        // pieces) a copy is a few memory round trips, not one per piece (92 serial round trips per miss with one
-                        // lane left: 40 ms of tail on every launch, profiles/r5e_tab_ab.log)
-                        for (int q0 = rank; q0 < gr_tab::kPatchDoubles / 2; q0 += kTabCopyDepth * n_act) {
-                            double2_t piece[kTabCopyDepth];
+                for (int k = 0; k < kTabSlots; ++k) used |= __builtin_amdgcn_ballot_w64(slot == k) != 0ull ? (1u << k) : 0u;
+                const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                const int n_act = __builtin_popcountll(act);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+                int rr = tags[kTabSlots];
+                for (int tries = 0; tries < kTabSlots && todo != 0ull; ++tries) {
+                    const int sidx = rr;
+                    rr = rr + 1 >= kTabSlots ? 0 : rr + 1;
+                    if (used & (1u << sidx)) continue;
+                    const int first = (int)__builtin_ctzll(todo);
+                    const int pp = __builtin_amdgcn_readlane(patch, first);
+                    const double2_t* src = (const double2_t*)(patches + (int64_t)pp * gr_tab::kPatchDoubles);
+                    typedef double2_t __attribute__((address_space(3))) lds_double2;
+                    lds_double2* dst = (lds_double2*)(cs.tab + kTabHeadBytes + sidx * kTabSlotBytes);
+                    // 92 pieces of 16 bytes, piece q by the active lane of rank q mod n_act, kTabCopyDepth loads in flight per lane
+                    for (int q0 = rank; q0 < gr_tab::kPatchDoubles / 2; q0 += kTabCopyDepth * n_act) {
+                        double2_t piece[kTabCopyDepth];
 #pragma unroll
-                            for (int jj = 0; jj < kTabCopyDepth; ++jj) {
-                                const int q = q0 + jj * n_act;
-                                if (q < gr_tab::kPatchDoubles / 2) piece[jj] = src[q];
-                            }
-#pragma unroll
-                            for (int jj = 0; jj < kTabCopyDepth; ++jj) {
-                                const int q = q0 + jj * n_act;
-                                if (q < gr_tab::kPatchDoubles / 2) dst[q] = piece[jj];
-                            }
+                        for (int jj = 0; jj < kTabCopyDepth; ++jj) {
+                            const int q = q0 + jj * n_act;
+                            if (q < gr_tab::kPatchDoubles / 2) piece[jj] = src[q];
                         }
-                        tags[sidx] = pp;
-                        used |= 1u << sidx;
-                        if (!done && patch == pp) slot = sidx;
-                        todo = __builtin_amdgcn_ballot_w64(!done && slot < 0);
+#pragma unroll
+                        for (int jj = 0; jj < kTabCopyDepth; ++jj) {
+                            const int q = q0 + jj * n_act;
+                            if (q < gr_tab::kPatchDoubles / 2) dst[q] = piece[jj];
+                        }
                     }
-                    tags[kTabSlots] = rr;
-                    GR_TAB_WAVE_SYNC();
+                    tags[sidx] = pp;
+                    used |= 1u << sidx;
+                    if (patch == pp) slot = sidx;
+                    todo = __builtin_amdgcn_ballot_w64(slot < 0);
                 }
-                // -- phase 2: the lanes that have a slot evaluate
-                if (!done && slot >= 0) {
-                    LdsCoef lc;
-                    lc.sl = (LdsCoef::lds_cdouble2*)(cs.tab + kTabHeadBytes + slot * kTabSlotBytes);
-                    lc.start();
-                    real g[5], gr[5], gt[5];
-                    horner(lc, lc, u, v, su, sv, s, c, g, gr, gt);
-                    finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
-                    done = true;
-                }
-                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-                GR_TAB_WAVE_SYNC();      // the slots just read may be replaced in the next round
+                tags[kTabSlots] = rr;
+                GR_TAB_WAVE_SYNC();
             }
+            // -- phase 2: the lanes that have a slot evaluate out of LDS ...
+            if (slot >= 0) {
+                LdsCoef lc;
+                lc.sl = (LdsCoef::lds_cdouble2*)(cs.tab + kTabHeadBytes + slot * kTabSlotBytes);
+                lc.start();
+                real g[5], gr[5], gt[5];
+                horner(lc, lc, u, v, su, sv, s, c, g, gr, gt);
+                finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
+            } else {
+                // ... and a wave that straddles more patches than it has slots sends the lanes left over to global memory, each
+                // for itself, through ONE out-of-line copy of the evaluation (the shadow's edge, where neighbouring rays part: a
+                // few waves per launch; replacing slots for them instead costs ~7 patch copies per evaluation -- those waves then
+                // run 100 µs per step and set the duration of every launch, 45 ms at any image size: profiles/r5f_tab256_*)
+                double out[4];
+                tab_rhs_from_global(patches + (int64_t)patch * gr_tab::kPatchDoubles, pole_factor, u, v, su, sv, s, c, vt, vr, vh, vp, out);
+                at = out[0]; ar = out[1]; ah = out[2]; ap = out[3];
+            }
+            GR_TAB_WAVE_SYNC();      // the slots just read may be replaced by the next evaluation
 #undef GR_TAB_WAVE_SYNC
 #endif
         }
@@ -1992,6 +2003,28 @@ struct TabulatedMetric {
         poly(r, th, s, c, g, gr, gt);
     }
 };
+#ifndef GR_HOST_HARNESS
+__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, int pole_factor, double u, double v, double su, double sv,
+                                                             double s, double c, double vt, double vr, double vh, double vp, double* out)
+{
+    // (the same coefficient stream as out of LDS: a few loads ahead of the arithmetic, ~100 registers -- with all 90 loads hoisted
+    // this function needs 254 registers and saves / restores a hundred callee-saved ones around its body)
+    real P[5], Pu[5], Pv[5], g[5], gr[5], gt[5], gi[5];
+    TabulatedMetric::GlobalCoef gc;
+    gc.sl = (const double2_t*)pc;
+    gc.start();
+    gr_tab::eval_patch<real>(gc, gc, u, v, P, Pu, Pv);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        g[k] = P[k];
+        gr[k] = Pu[k] * su;
+        gt[k] = Pv[k] * sv;
+    }
+    if (pole_factor) gr_tab::pole_factor_apply<real>(s * s, 2.0 * (s * c), g, gr, gt);
+    inverse_generic(g, gi);
+    geodesic_contract(gr, gt, gi, vt, vr, vh, vp, out[0], out[1], out[2], out[3]);
+}
+#endif
 #else
 #define GR_HAS_TABULATED 0
 #endif

@@ -116,7 +116,7 @@ int32_t gr_metric_grid_nodes(const gr_metric_grid* grid, double* r_nodes, double
     return GR_OK;
 }
 
-int32_t gr_metric_table_fit(const gr_metric_grid* grid, const double* samples, double* table, double err[3])
+int32_t gr_metric_table_fit(const gr_metric_grid* grid, const double* samples, double* table, double* err)
 {
     if (!grid_ok(grid) || !samples || !table) return gr_set_last_error(GR_ERR_INVALID_ARGUMENT, "bad metric grid (use gr_metric_grid_plan) or null samples / table");
     const Cheb& cb = cheb();
@@ -252,7 +252,7 @@ int32_t gr_metric_table_check(const double* table, int64_t table_n)
     return GR_OK;
 }
 
-extern "C" int32_t gr_metric_table_eval(const double* table, int64_t table_n, double r, double theta, double g[5], double dr[5], double dth[5])
+extern "C" int32_t gr_metric_table_eval(const double* table, int64_t table_n, double r, double theta, double* g, double* dr, double* dth)
 {
     const int32_t rc = gr_metric_table_check(table, table_n);
     if (rc != GR_OK) return rc;

@@ -542,11 +542,11 @@ typedef struct gr_metric_grid {
 int32_t gr_metric_grid_plan(double r_min, double r_max, double r0, int32_t m_r, int32_t n_theta, gr_metric_grid* grid);
 int32_t gr_metric_grid_nodes(const gr_metric_grid* grid, double* r_nodes, double* theta_nodes);
 int32_t gr_metric_table_fit(const gr_metric_grid* grid, const double* samples /* n_r_nodes x n_theta_nodes x 5 */,
-                            double* table /* table_doubles */, double err[3]);
+                            double* table /* table_doubles */, double* err /* 3, may be NULL */);
 /* the table's value at one point, by the arithmetic the kernels use: (g, ∂r g, ∂θ g) of the five components -- for checking a
  * table against the caller's own Jacobian (Julia: Gradus.metric_jacobian) before tracing with it */
-int32_t gr_metric_table_eval(const double* table, int64_t table_n, double r, double theta, double g[5], double dr[5],
-                             double dth[5]);
+int32_t gr_metric_table_eval(const double* table, int64_t table_n, double r, double theta, double* g /* 5 */, double* dr /* 5 */,
+                             double* dth /* 5 */);
 
 /* ---- ONE host thread, SEVERAL devices, ray sets (see gr_render_multi for the shape every *_multi call has) ---- */
 /* Ray sets with one output row per ray (gr_rayset_endpoints, gr_ray_summary, gr_ray_tangent, gr_redshift_radius): contiguous

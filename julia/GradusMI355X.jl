@@ -34,10 +34,10 @@ using Gradus: TracingConfiguration, EnsembleProblem, GeodesicPoint, StatusCodes,
 using StaticArrays
 import SciMLBase
 
-export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, winding_numbers
+export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, winding_numbers, metric_table, selftest
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
-const ABI_VERSION = 6
+const ABI_VERSION = 7
 
 # ---------------------------------------------------------------------------------------------------------------
 # POD mirrors of include/gradus_mi355x.h (field order and types checked by tests/test_julia_binding.py)
@@ -84,6 +84,25 @@ struct GrConfig                      # == gr_config
     comp_n::Int32                    # CompositeGeometry (geometry/composite.jl): its geometries, 2..4 of them
     _pad3::Int32
     comp::NTuple{4,GrDiscComponent}
+    metric_table::Ptr{Float64}       # GR_METRIC_TABULATED (ABI 7): the table gr_metric_table_fit wrote, or C_NULL / 0
+    metric_table_n::Int64
+end
+
+struct GrMetricGrid                  # == gr_metric_grid: the patch grid of a tabulated metric
+    r0::Float64
+    r_min::Float64
+    r_max::Float64
+    e_min::Int32
+    n_oct::Int32
+    m_r::Int32
+    n_theta::Int32
+    degree::Int32
+    fit_nodes::Int32
+    pole_factor::Int32
+    reserved::Int32
+    n_r_nodes::Int64
+    n_theta_nodes::Int64
+    table_doubles::Int64
 end
 
 struct GrStats                       # == gr_stats
@@ -167,6 +186,32 @@ struct UnsupportedOnDevice <: Exception
     msg::String
 end
 
+# This file reads values OUT OF CLOSURES of Gradus.jl (the geometry callback's `gtol`, the hemisphere callback's `δ`, the trace in
+# the problem builder, the render closure's αs / βs): private layout that a refactor upstream may change without notice, and this
+# file cannot be run where it was written.  Three guards make such a change loud instead of silently wrong:
+#   * the Gradus.jl versions whose closure layouts were read are pinned (`GRADUS_TESTED`); any other version is an error unless
+#     ENV["GRADUS_MI355X_ALLOW_UNTESTED_GRADUS"] = "1" (then a warning);
+#   * every closure that is recognised must have EXACTLY the fields it had (`_expect_fields`);
+#   * `GradusMI355X.selftest()` renders a small scene on the device and with `EnsembleEndpointThreads` and compares: the first
+#     thing to run after installing or upgrading either side (INTEGRATION.md).
+const GRADUS_TESTED = (v"0.4.30", v"0.5.0")      # [first, next): read against v0.4.30
+function _check_gradus_version()
+    v = pkgversion(Gradus)
+    (!isnothing(v) && GRADUS_TESTED[1] <= v < GRADUS_TESTED[2]) && return
+    msg = "GradusMI355X was written against Gradus.jl $(GRADUS_TESTED[1]) (closure layouts of bootstrap.jl, callbacks.jl, " *
+          "geodesic-problem.jl, rendering.jl); this is $(something(v, "an unversioned checkout")). Run GradusMI355X.selftest() " *
+          "and set ENV[\"GRADUS_MI355X_ALLOW_UNTESTED_GRADUS\"] = \"1\" if it passes."
+    get(ENV, "GRADUS_MI355X_ALLOW_UNTESTED_GRADUS", "0") == "1" ? (@warn msg maxlog = 1) : error(msg)
+end
+"A closure this file reads from must have exactly the fields it had in the Gradus.jl versions of `GRADUS_TESTED`."
+function _expect_fields(f, names::Symbol...)
+    have = fieldnames(typeof(f))
+    Set(have) == Set(names) ||
+        error("GradusMI355X: the closure $(nameof(typeof(f))) has fields $have, this binding was written for $names -- " *
+              "Gradus.jl changed underneath it; see GradusMI355X.selftest()")
+    f
+end
+
 """
     EnsembleMI355X(devices = [0])
 
@@ -181,6 +226,7 @@ mutable struct EnsembleMI355X
     devices::Vector{Int32}
     ctxs::Vector{Ptr{Cvoid}}
     function EnsembleMI355X(devices = [0])
+        _check_gradus_version()
         abi = ccall((:gr_abi_version, LIB), Int32, ())
         abi == ABI_VERSION || error("GradusMI355X: libgradus_mi355x.so has ABI version $abi, this binding is written for $ABI_VERSION")
         ctxs = Ptr{Cvoid}[]
@@ -210,7 +256,62 @@ _metric(m::Gradus.SphericalMetric) = (Int32(7), (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0
 _metric(m::KerrDarkMatter) = (Int32(8), (m.M, m.a, m.M_dark_matter, m.Δr, m.rₛ, 0.0, 0.0, 0.0))
 _metric(m::KerrRefractive) = (Int32(9), (m.M, m.a, m.n, m.corona_radius, 0.0, 0.0, 0.0, 0.0))
 _metric(m::NoZMetric) = (Int32(10), (m.M, m.a, m.ϵ, 0.0, 0.0, 0.0, 0.0, 0.0))
-_metric(m) = throw(UnsupportedOnDevice("metric $(typeof(m)) has no device implementation"))
+# Any other static, axis-symmetric metric -- the reference's plugin contract: a struct `<: AbstractStaticAxisSymmetric` and ONE
+# method, `metric_components(m, rθ)` (src/Gradus.jl:78-86, src/metrics/kerr-metric.jl:62-70) -- runs on the device from a table of
+# that method's values (GR_METRIC_TABULATED, ABI 7; `metric_table` below).  Only what is not even that stays on the CPU.
+_metric(m::Gradus.AbstractStaticAxisSymmetric) = (Int32(11), (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+_metric(m) = throw(UnsupportedOnDevice("metric $(typeof(m)) is not static and axis-symmetric: no device implementation"))
+_is_tabulated(m) = _metric(m)[1] == Int32(11)
+
+const _METRIC_TABLES = Dict{Any,Vector{Float64}}()      # (metric, r_min, r_max) -> fitted table; metrics are immutable structs
+const METRIC_TABLE_TOL = (2e-11, 1e-8, 1e-8)             # the fit's own estimates a table must meet: value, ∂/∂ln(r - r0), ∂/∂θ
+
+"""
+    metric_table(m, r_inner, r_outer; m_r = 8, n_theta = 32, refinements = 3) -> Vector{Float64}
+
+The piecewise-polynomial table of `metric_components(m, (r, θ))` between the chart's radii that the kernels trace a
+user-defined metric through.  The library names the sample nodes (`gr_metric_grid_plan`, `gr_metric_grid_nodes`), this
+function evaluates `Gradus.metric_components` there -- the ONLY thing it asks of `m`, exactly the reference's contract --, the
+library fits (`gr_metric_table_fit`) and reports its error estimates; the grid is refined until they meet
+`METRIC_TABLE_TOL`.  Radial patches are geometric in `r - r0` with `r0` just inside `Gradus.inner_radius(m)`.
+Tables are cached per (metric, radii).  `gr_metric_table_eval` checks one against `Gradus.metric_jacobian` (see `selftest`).
+"""
+function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 32, refinements = 3)
+    get!(_METRIC_TABLES, (m, r_inner, r_outer)) do
+        rh = Float64(Gradus.inner_radius(m))
+        r0 = rh > 0 ? rh * (1 - 1e-3) : min(-1.0, r_inner - 1.0)
+        r_min = max(r_inner * (1 - 1e-3), r0 + 1e-3)
+        local table
+        for _ = 0:refinements
+            grid = Ref{GrMetricGrid}()
+            _check(ccall((:gr_metric_grid_plan, LIB), Int32, (Float64, Float64, Float64, Int32, Int32, Ref{GrMetricGrid}),
+                r_min, r_outer, r0, m_r, n_theta, grid))
+            g = grid[]
+            rn, tn = Vector{Float64}(undef, g.n_r_nodes), Vector{Float64}(undef, g.n_theta_nodes)
+            _check(ccall((:gr_metric_grid_nodes, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}), grid, rn, tn))
+            # samples[k, b, a] = component k at (r_a, θ_b): column-major (5, nθ, nr) is the C order [n_r][n_θ][5]
+            samples = Array{Float64,3}(undef, 5, length(tn), length(rn))
+            Threads.@threads for a in eachindex(rn)
+                for b in eachindex(tn)
+                    comps = Gradus.metric_components(m, SVector(rn[a], tn[b]))
+                    for k = 1:5
+                        samples[k, b, a] = comps[k]
+                    end
+                end
+            end
+            table = Vector{Float64}(undef, g.table_doubles)
+            err = zeros(Float64, 3)
+            _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                grid, samples, table, err))
+            all(err .<= METRIC_TABLE_TOL) && return table
+            (err[1] > METRIC_TABLE_TOL[1] || err[2] > METRIC_TABLE_TOL[2]) && (m_r *= 2)
+            (err[1] > METRIC_TABLE_TOL[1] || err[3] > METRIC_TABLE_TOL[3]) && (n_theta *= 2)
+        end
+        @warn "EnsembleMI355X: the table of $(typeof(m)) does not meet the fit tolerances after $refinements refinements; tracing with it anyway"
+        table
+    end
+end
+_metric_table(m, r_inner, r_outer) = _is_tabulated(m) ? metric_table(m, Float64(r_inner), Float64(r_outer)) : Float64[]
 
 # (disc_id, disc_r_in, disc_r_out, disc_params)
 _disc(::Nothing) = (Int32(0), 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
@@ -338,13 +439,15 @@ function _callbacks(config::TracingConfiguration)
             cbs = cond.callbacks
             ok = length(cbs) == length(config.geometry.geometry) && all(1:length(cbs)) do k
                 ck = cbs[k][1]
-                hasproperty(ck, :g) && hasproperty(ck, :gtol) && ck.g === config.geometry.geometry[k]
+                hasproperty(ck, :g) && hasproperty(ck, :gtol) && ck.g === config.geometry.geometry[k] &&
+                    !isnothing(_expect_fields(ck, :g, :gtol))
             end
             ok || throw(UnsupportedOnDevice("the composite geometry's callback does not match config.geometry"))
             gtol = Float64(cbs[1][1].gtol)
             seen_geometry = true
         elseif !seen_geometry && !isnothing(config.geometry) && hasproperty(cond, :g) && hasproperty(cond, :gtol) &&
            cond.g === config.geometry
+            _expect_fields(cond, :g, :gtol)                 # _distance_to_disc_wrapper's closure, bootstrap.jl:43-60
             gtol = Float64(cond.gtol)
             seen_geometry = true
         else
@@ -358,6 +461,7 @@ function _callbacks(config::TracingConfiguration)
             # over the mesh `g`; the device tests the same line element itself (GR_DISC_MESH)
             seen_geometry = true
         elseif occursin("_domain_upper_hemisphere_check", _closure_name(cond)) && hasproperty(cond, :δ)
+            _expect_fields(cond, :δ)                         # callbacks.jl:31-40
             δ = Float64(cond.δ)
         else
             throw(UnsupportedOnDevice("a user DiscreteCallback ($(_closure_name(cond))); only domain_upper_hemisphere runs on the device"))
@@ -394,6 +498,7 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; maxiters = 
     dtab = _disc_table(config.geometry)
     comp_n, comps = _components(config.geometry)
     gtol, δ = _callbacks(config)
+    mtab = _metric_table(config.metric, r_in, r_out)
     windings = trace isa Gradus.TraceWindings
     q = hasproperty(trace, :q) ? Float64(trace.q) : 0.0
     (q == 0.0 || config.metric isa KerrNewmanMetric) || throw(UnsupportedOnDevice("charged test particles outside Kerr-Newman"))
@@ -404,8 +509,9 @@ function _config(config::TracingConfiguration, trace::AbstractTrace; maxiters = 
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), _disc_table_n(config.geometry, dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1,
         q, windings ? Int32(1) : Int32(0), Int32(0), windings ? Float64(trace.plane_inc) : π / 2,
-        comp_n, Int32(0), comps)
-    cfg, (tab, dtab)
+        comp_n, Int32(0), comps,
+        isempty(mtab) ? Ptr{Float64}(C_NULL) : pointer(mtab), length(mtab))
+    cfg, (tab, dtab, mtab)
 end
 
 """
@@ -711,11 +817,13 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
     did, rin, rout, dparams = _disc(d)
     r_in, r_out, tab, θ0, θ1 = _chart(chart)
     dtab = _disc_table(d)
+    mtab = _metric_table(m, r_in, r_out)
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
         abstol, reltol, Float64(μ), 1_000_000, Int32(0), Int32(0), 1e-4, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), _disc_table_n(d, dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, Float64(q), Int32(0), Int32(0), π / 2,
-        _components(d)[1], Int32(0), _components(d)[2]))
+        _components(d)[1], Int32(0), _components(d)[2],
+        isempty(mtab) ? Ptr{Float64}(C_NULL) : pointer(mtab), length(mtab)))
     g = Gradus.metric(m, x)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)                       # tracing/utility.jl:32-40
     plane = Ref(GrPlane(Tuple(x), Tuple(permutedims(Mx)), Float64(αlims[1]), Float64(αlims[2]), Float64(βlims[1]),
@@ -731,13 +839,13 @@ function render_mi355x(ensemble::EnsembleMI355X, m, x::SVector{4,Float64}, d, λ
         image = _result_matrix(ensemble, image_height, image_width)
         N = image_height * image_width
         rg = Ref(GrRange(0, N, max(N, 1), 1))
-        _check(GC.@preserve tab dtab keep_pf image ccall((:gr_render, LIB), Int32,
+        _check(GC.@preserve tab dtab mtab keep_pf image ccall((:gr_render, LIB), Int32,
             (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Ref{GrRange}, Ptr{Float64}, Ptr{GrStats}),
             ensemble.ctxs[1], cfg, plane, pfs, rg, image, stats))
     else
         # several devices: the same pinned block, every device's kernel stores its columns at their place (no copies at all)
         image = _result_matrix(ensemble, image_height, image_width)
-        _check(GC.@preserve tab dtab keep_pf image ccall((:gr_render_multi, LIB), Int32,
+        _check(GC.@preserve tab dtab mtab keep_pf image ccall((:gr_render_multi, LIB), Int32,
             (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrPlane}, Ref{GrPointFunction}, Int64, Ptr{Float64}, Ptr{GrStats}),
             ensemble.ctxs, length(ensemble.ctxs), cfg, plane, pfs, 0, image, stats))
     end
@@ -762,11 +870,13 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     did, rin, rout, dparams = _disc(d)
     r_in, r_out, tab, θ0, θ1 = _chart(chart)
     dtab = _disc_table(d)
+    mtab = _metric_table(m, r_in, r_out)
     cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λ_max),
         abstol, reltol, 0.0, 1_000_000, Int32(upper_hemisphere), Int32(0), 1e-4, dparams,
         isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), _disc_table_n(d, dtab),
         isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, 0.0, Int32(0), Int32(0), π / 2,
-        _components(d)[1], Int32(0), _components(d)[2]))
+        _components(d)[1], Int32(0), _components(d)[2],
+        isempty(mtab) ? Ptr{Float64}(C_NULL) : pointer(mtab), length(mtab)))
     g = Gradus.metric(m, u)
     Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
     rs = collect(Float64, plane.grid(plane.r_min, plane.r_max, plane.Nr))             # planes.jl:110-114
@@ -792,16 +902,82 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     if length(ensemble.ctxs) > 1
         # the plane's rays dealt over the devices, one histogram per device, added by the library on the host
         mstats = Vector{GrStats}(undef, length(ensemble.ctxs))
-        _check(GC.@preserve tab dtab keep_pf rs cs sn edges er ev ccall((:gr_lineprofile_multi, LIB), Int32,
+        _check(GC.@preserve tab dtab mtab keep_pf rs cs sn edges er ev ccall((:gr_lineprofile_multi, LIB), Int32,
             (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ref{GrBinning}, Ptr{Float64}, Ptr{GrStats}),
             ensemble.ctxs, length(ensemble.ctxs), cfg, rays, pfs, binning, flux, mstats))
         return bins, flux ./ sum(flux)                                                     # line-profiles.jl:197
     end
     stats = Ref{GrStats}()
-    _check(GC.@preserve tab dtab keep_pf rs cs sn edges er ev ccall((:gr_lineprofile, LIB), Int32,
+    _check(GC.@preserve tab dtab mtab keep_pf rs cs sn edges er ev ccall((:gr_lineprofile, LIB), Int32,
         (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ref{GrBinning}, Ptr{Float64}, Ref{GrStats}),
         ensemble.ctxs[1], cfg, rays, pfs, binning, flux, stats))
     bins, flux ./ sum(flux)                                                            # line-profiles.jl:197
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# selftest: the device against the reference's own CPU ensemble, and a user-defined metric through the table
+# ---------------------------------------------------------------------------------------------------------------
+"Kerr in disguise: a metric this file has no `_metric` method for, defined the way a user defines one (kerr-metric.jl:62-72)."
+struct _SelftestMetric{T} <: Gradus.AbstractStaticAxisSymmetric{T}
+    M::T
+    a::T
+end
+Gradus.metric_components(m::_SelftestMetric, rθ) = Gradus.metric_components(KerrMetric(m.M, m.a), rθ)
+Gradus.inner_radius(m::_SelftestMetric) = Gradus.inner_radius(KerrMetric(m.M, m.a))
+
+"""
+    selftest(; device = 0, verbose = true) -> Bool
+
+Run after installing or upgrading Gradus.jl or the library.  Renders the 20 x 20 scene of the reference's smoke tests
+(test/smoke-tests/rendergeodesics.jl: observer at r = 100, θ = 85°, ThinDisc(0, 40), λ_max = 200) three ways and compares end
+points ray by ray:
+  1. `KerrMetric` on `EnsembleMI355X` against `EnsembleEndpointThreads` (status equal on all but disc-rim rays, positions to 1e-6);
+  2. the same through `rendergeodesics` with the redshift point function (the fused path against Gradus' `apply_to_image!`);
+  3. a user-defined metric (a struct with only `metric_components` and `inner_radius`) on the device -- through the table -- against
+     `KerrMetric` on the CPU, and the table against `Gradus.metric_jacobian` at a point.
+Throws with a description of the first disagreement; returns `true` otherwise.
+"""
+function selftest(; device = 0, verbose = true)
+    say(msg) = verbose && @info "GradusMI355X.selftest: $msg"
+    ens = EnsembleMI355X([device])
+    m = KerrMetric(1.0, 0.998)
+    x = SVector(0.0, 100.0, deg2rad(85), 0.0)
+    d = ThinDisc(0.0, 40.0)
+    kw = (; image_width = 20, image_height = 20, αlims = (-9.5, 9.5), βlims = (-9.5, 9.5), verbose = false)
+    function endpoints(metric, ensemble)
+        _, _, cache = Gradus.prerendergeodesics(metric, x, d, 200.0; ensemble = ensemble, kw...)
+        vec(cache.points)
+    end
+    function compare(a, b, what; flips = 4)
+        nf = count(i -> a[i].status != b[i].status, eachindex(a))
+        nf <= flips || error("selftest ($what): $nf rays differ in status")
+        for i in eachindex(a)
+            (a[i].status == b[i].status && a[i].status != StatusCodes.WithinInnerBoundary) || continue
+            err = maximum(abs.(a[i].x .- b[i].x) ./ max.(abs.(b[i].x), 1e-3 * maximum(abs.(b[i].x))))
+            err < 1e-6 || error("selftest ($what): ray $i ends at $(a[i].x), the CPU ensemble at $(b[i].x)")
+        end
+        say("$what: $(length(a)) rays agree ($nf rim flips)")
+    end
+    cpu = endpoints(m, Gradus.EnsembleEndpointThreads())
+    compare(endpoints(m, ens), cpu, "KerrMetric, end points")
+    pf = ConstPointFunctions.redshift(m, x) ∘ ConstPointFunctions.filter_intersected()
+    _, _, img_d = Gradus.rendergeodesics(m, x, d, 200.0; pf = pf, ensemble = ens, kw...)
+    _, _, img_c = Gradus.rendergeodesics(m, x, d, 200.0; pf = pf, ensemble = Gradus.EnsembleEndpointThreads(), kw...)
+    both = .!isnan.(img_d) .& .!isnan.(img_c)
+    (count(isnan.(img_d) .!= isnan.(img_c)) <= 4 && maximum(abs.(img_d[both] ./ img_c[both] .- 1)) < 1e-6) ||
+        error("selftest (fused redshift render): the images differ")
+    say("fused redshift render agrees on $(count(both)) pixels")
+    um = _SelftestMetric(1.0, 0.998)
+    chart = Gradus.chart_for_metric(um)
+    tab = metric_table(um, Float64(chart.inner_radius), Float64(chart.outer_radius))
+    g, dr, dth = zeros(5), zeros(5), zeros(5)
+    _check(ccall((:gr_metric_table_eval, LIB), Int32, (Ptr{Float64}, Int64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        tab, length(tab), 6.0, 1.2, g, dr, dth))
+    gc, jac = Gradus.metric_jacobian(m, SVector(6.0, 1.2))            # auto-diff.jl:206-211: components and their (∂r, ∂θ)
+    (maximum(abs.(g .- gc) ./ abs.(gc)) < 1e-10 && maximum(abs.(dr .- jac[:, 1])) < 1e-8 && maximum(abs.(dth .- jac[:, 2])) < 1e-8) ||
+        error("selftest (tabulated metric): the table disagrees with Gradus.metric_jacobian at (6, 1.2)")
+    compare(endpoints(um, ens), cpu, "user-defined metric through the table")
+    true
 end
 
 end # module

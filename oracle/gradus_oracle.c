@@ -148,7 +148,9 @@ static void metric_d2(const orc_config* c, double r, double th, d2 g[5])
     case ORC_METRIC_KERR_DARK_MATTER: kerr_dark_matter_components_d2(c->params, rr, tt, g); break;
     case ORC_METRIC_KERR_REFRACTIVE: kerr_refractive_components_d2(c->params, rr, tt, g); break;
     case ORC_METRIC_NOZ: noz_components_d2(c->params, rr, tt, g); break;
+#ifdef ORC_WITH_TEST_METRIC
     case ORC_METRIC_TEST_BUMP: test_bump_components_d2(c->params, rr, tt, g); break;
+#endif
     default: kerr_components_d2(c->params, rr, tt, g);
     }
 }
@@ -741,7 +743,6 @@ typedef struct {
     double *r, *vt, *vr, *vphi;
     int64_t cap, n;
     double *t;      /* optional: affine time of every saved state */
-    double *th;     /* optional: θ of every saved state */
 } save_t;
 
 static void save_state(save_t* s, const double u[8], double t)
@@ -749,7 +750,6 @@ static void save_state(save_t* s, const double u[8], double t)
     if (!s || s->n >= s->cap) return;
     s->r[s->n] = u[1]; s->vt[s->n] = u[4]; s->vr[s->n] = u[5]; s->vphi[s->n] = u[7];
     if (s->t) s->t[s->n] = t;
-    if (s->th) s->th[s->n] = u[2];
     s->n++;
 }
 
@@ -1076,7 +1076,9 @@ static void energy_jet(const orc_config* c, double r, double* E, double* dE)
     case ORC_METRIC_KERR_DARK_MATTER: kerr_dark_matter_components_j2(c->params, rr, th, g); break;
     case ORC_METRIC_KERR_REFRACTIVE: kerr_refractive_components_j2(c->params, rr, th, g); break;
     case ORC_METRIC_NOZ: noz_components_j2(c->params, rr, th, g); break;
+#ifdef ORC_WITH_TEST_METRIC
     case ORC_METRIC_TEST_BUMP: test_bump_components_j2(c->params, rr, th, g); break;
+#endif
     default: kerr_components_j2(c->params, rr, th, g);
     }
     /* first-order duals in r: metric g = (v,d); its r-derivative ∂g = (d,dd) */
@@ -1304,7 +1306,7 @@ int64_t orc_plunging_table(const orc_config* c, double r_isco, double* r, double
     const double den = -g[1];
     double u0[8] = { 0.0, r_isco - dr, M_PI / 2.0, 0.0, vtt, -sqrt(fabs(nom / den)), 0.0, vpp };
     u0[4] = orc_constrain_time(&cc, u0, u0 + 4);
-    save_t sv = { r, vt, vr, vphi, cap, 0, NULL, NULL };
+    save_t sv = { r, vt, vr, vphi, cap, 0, NULL };
     orc_point pt;
     integrate(&cc, u0, &pt, NULL, &sv);
     return sv.n;
@@ -1319,23 +1321,9 @@ int64_t orc_trace_steps(const orc_config* c, const double x[4], const double v[4
     memcpy(u0 + 4, v, 4 * sizeof(double));
     u0[4] = orc_constrain_time(c, x, v);
     double* scratch = (double*)malloc(sizeof(double) * 3 * (size_t)cap);
-    save_t sv = { r, scratch, scratch + cap, scratch + 2 * cap, cap, 0, t, NULL };
+    save_t sv = { r, scratch, scratch + cap, scratch + 2 * cap, cap, 0, t };
     integrate(c, u0, out, NULL, &sv);
     free(scratch);
     return sv.n;
 }
 
-/* the same with θ: where a ray spends its steps in the (r, θ) plane (tests of the tabulated metric's patch grid) */
-int64_t orc_trace_steps_rth(const orc_config* c, const double x[4], const double v[4], orc_point* out,
-                            double* t, double* r, double* th, int64_t cap)
-{
-    double u0[8];
-    memcpy(u0, x, 4 * sizeof(double));
-    memcpy(u0 + 4, v, 4 * sizeof(double));
-    u0[4] = orc_constrain_time(c, x, v);
-    double* scratch = (double*)malloc(sizeof(double) * 3 * (size_t)cap);
-    save_t sv = { r, scratch, scratch + cap, scratch + 2 * cap, cap, 0, t, th };
-    integrate(c, u0, out, NULL, &sv);
-    free(scratch);
-    return sv.n;
-}

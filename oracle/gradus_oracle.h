@@ -164,8 +164,6 @@ int64_t orc_plunging_table(const orc_config* c, double r_isco, double* r, double
 
 int64_t orc_trace_steps(const orc_config* c, const double x[4], const double v[4], orc_point* out,
                         double* t, double* r, int64_t cap);
-int64_t orc_trace_steps_rth(const orc_config* c, const double x[4], const double v[4], orc_point* out,
-                            double* t, double* r, double* th, int64_t cap);
 
 int orc_max_threads(void);
 

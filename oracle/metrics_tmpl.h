@@ -275,7 +275,10 @@ static void FN(noz_components)(const double* p, NUM r, NUM th, NUM g[5])
     g[4] = N_NEG(N_DIV(N_MUL(N_SCALE(a, tMr), N_MUL(omy2, Se)), D));
 }
 
-/* NOT a metric of the reference: a stand-in for a USER-DEFINED AbstractStaticAxisSymmetric metric (the plugin contract of
+#ifdef ORC_WITH_TEST_METRIC
+/* (compiled into libgradus_oracle_usermetric.so only -- oracle/Makefile `usermetric` -- so that the oracle every other test
+ * uses stays bit for bit the build its thresholds were measured with: gcc contracts FMAs differently once a switch gains a case)
+ * NOT a metric of the reference: a stand-in for a USER-DEFINED AbstractStaticAxisSymmetric metric (the plugin contract of
  * src/Gradus.jl:78-86 -- "define metric_components(m, rθ)" -- exercised by tests of GR_METRIC_TABULATED).  Kerr with
  * g_tt scaled by 1 + ϵ sin²θ / (1 + ((r - r_b) / w)²): smooth, asymptotically Kerr, in no catalogue.  The oracle pushes it
  * through the same dual numbers as every other metric, i.e. what the reference would do with it.  p = M, a, ϵ, r_b, w */
@@ -288,3 +291,4 @@ static void FN(test_bump_components)(const double* p, NUM r, NUM th, NUM g[5])
     NUM bump = N_DIV(N_SCALE(e, N_MUL(s, s)), N_ADD(N_CONST(1.0), N_MUL(x, x)));
     g[0] = N_MUL(g[0], N_ADD(N_CONST(1.0), bump));
 }
+#endif

@@ -116,6 +116,34 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_USER_LIB_PATH = os.path.join(_HERE, "libgradus_oracle_usermetric.so")
+
+
+def build_usermetric(force: bool = False) -> str:
+    """The oracle plus the stand-in for a user-defined metric ("test-bump", oracle/Makefile `usermetric`)."""
+    if force or not os.path.exists(_USER_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_USER_LIB_PATH)
+        for f in ("gradus_oracle.c", "gradus_oracle.h", "metrics_tmpl.h")
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "usermetric"])
+    return _USER_LIB_PATH
+
+
+class user_metric_library:
+    """`with oracle.user_metric_library(): ...` -- every call inside goes to libgradus_oracle_usermetric.so, the build that
+    knows the metric "test-bump"; outside, the main oracle is untouched (and bit for bit what it was before that metric existed)."""
+
+    def __enter__(self):
+        global _lib, _LIB_PATH
+        self._saved = (_lib, _LIB_PATH)
+        build_usermetric()
+        _lib, _LIB_PATH = None, _USER_LIB_PATH
+        return lib()
+
+    def __exit__(self, *exc):
+        global _lib, _LIB_PATH
+        _lib, _LIB_PATH = self._saved
+        return False
 
 
 def lib():
@@ -147,8 +175,6 @@ def lib():
         L.orc_max_threads.restype = C.c_int
         L.orc_trace_steps.argtypes = [cp, dp, dp, C.c_void_p, dp, dp, C.c_int64]
         L.orc_trace_steps.restype = C.c_int64
-        L.orc_trace_steps_rth.argtypes = [cp, dp, dp, C.c_void_p, dp, dp, dp, C.c_int64]
-        L.orc_trace_steps_rth.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -434,16 +460,6 @@ def trace_steps(cfg, x, v, cap=100000):
     t, r = np.zeros(cap), np.zeros(cap)
     n = lib().orc_trace_steps(C.byref(cfg), _dp(x), _dp(v), out.ctypes.data, _dp(t), _dp(r), cap)
     return out[0], t[:n], r[:n]
-
-
-def trace_steps_rth(cfg, x, v, cap=100000):
-    """(point, t[], r[], θ[]) of every accepted step of one ray: where a ray spends its steps in the (r, θ) plane."""
-    x = np.ascontiguousarray(x, dtype=np.float64)
-    v = np.ascontiguousarray(v, dtype=np.float64)
-    out = np.zeros(1, dtype=POINT_DTYPE)
-    t, r, th = np.zeros(cap), np.zeros(cap), np.zeros(cap)
-    n = lib().orc_trace_steps_rth(C.byref(cfg), _dp(x), _dp(v), out.ctypes.data, _dp(t), _dp(r), _dp(th), cap)
-    return out[0], t[:n], r[:n], th[:n]
 
 
 def circular_energy(cfg, r):

@@ -25,7 +25,8 @@ static const double PI = 3.141592653589793;
 
 int main()
 {
-    static_assert(sizeof(orc_config) == sizeof(gr_config), "oracle and product configs are the same POD");
+    // the product's config is the oracle's plus the two fields of a tabulated metric at its end (ABI 7: metric_table, metric_table_n)
+    static_assert(sizeof(orc_config) + sizeof(const double*) + sizeof(int64_t) == sizeof(gr_config), "oracle and product configs share their layout up to the oracle's end");
     static_assert(sizeof(orc_point) == sizeof(gr_point) && sizeof(gr_point) == 152, "GeodesicPoint is 152 bytes");
     const int W = 12, H = 12, N = W * H;
     const double x[4] = { 0.0, 100.0, 85.0 * PI / 180.0, 0.0 };
@@ -57,7 +58,8 @@ int main()
         if (orc_trace(&c, x, 0, v.data(), N, ref.data(), nullptr, 2) != 0) { std::printf("orc_trace failed\n"); return 2; }
         // the same scene through the host build of the device integrator
         gr_config g;
-        std::memcpy(&g, &c, sizeof g);
+        std::memset(&g, 0, sizeof g);
+        std::memcpy(&g, &c, sizeof c);
         g.disc_id = s.disc;      // THIN / SHAKURA_SUNYAEV / NONE share their ids between the two enums
         gr_plane pl;
         std::memset(&pl, 0, sizeof pl);
@@ -98,7 +100,8 @@ int main()
                 c.gtol = 1e-2; c.lambda0 = 0.0; c.lambda1 = 200.0; c.abstol = c.reltol = 1e-9; c.maxiters = 1000000;
                 c.hemi_delta = 1e-4; c.winding_plane = PI / 2;
                 gr_config g;
-                std::memcpy(&g, &c, sizeof g);
+                std::memset(&g, 0, sizeof g);
+                std::memcpy(&g, &c, sizeof c);
                 g.disc_id = disc; g.disc_r_in = 0.0; g.disc_r_out = disc == GR_DISC_THIN ? 40.0 : INFINITY;
                 gr_rayset rs;
                 std::memset(&rs, 0, sizeof rs);

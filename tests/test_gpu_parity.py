@@ -1953,7 +1953,7 @@ def test_c_abi_rejects_bad_input_without_touching_the_device(G, ens):
         return L.gr_render(h, C.byref(cfg_), C.byref(pl_), C.byref(pf_), C.byref(rg_), img_.ctypes.data if img_ is not None else None, None)
 
     assert call() == 0
-    for field, value, code in (("metric_id", 11, -2), ("metric_id", -1, -2), ("disc_id", 9, -2), ("disc_id", 8, -1), ("disc_id", 7, -1), ("abstol", -1.0, -1)):
+    for field, value, code in (("metric_id", 12, -2), ("metric_id", 11, -1), ("metric_id", -1, -2), ("disc_id", 9, -2), ("disc_id", 8, -1), ("disc_id", 7, -1), ("abstol", -1.0, -1)):
         bad = type(cfg).from_buffer_copy(cfg)
         setattr(bad, field, value)
         assert call(cfg_=bad) == code, field

@@ -154,7 +154,8 @@ def jl_ccalls():
 
 
 JL2C_STRUCT = {"GrConfig": "gr_config", "GrStats": "gr_stats", "GrPlane": "gr_plane", "GrPointFunction": "gr_pointfunction",
-               "GrRange": "gr_range", "GrRayset": "gr_rayset", "GrBinning": "gr_binning", "GrDiscComponent": "gr_disc_component"}
+               "GrRange": "gr_range", "GrRayset": "gr_rayset", "GrBinning": "gr_binning", "GrDiscComponent": "gr_disc_component",
+               "GrMetricGrid": "gr_metric_grid"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -245,7 +246,7 @@ def test_gr_config_arguments_are_in_field_order():
               "hemi_delta": "δ", "disc_params": "dparams", "disc_table": "dtab", "disc_table_n": "_disc_table_n(config.geometry, dtab)",
               "chart_table": "tab", "chart_table_n": "length(tab)", "chart_theta0": "θ0", "chart_theta1": "θ1", "q": "q",
               "count_windings": "windings", "_pad2": "Int32(0)", "winding_plane": "plane_inc", "comp_n": "comp_n",
-              "_pad3": "Int32(0)", "comp": "comps"}
+              "_pad3": "Int32(0)", "comp": "comps", "metric_table": "mtab", "metric_table_n": "length(mtab)"}
     assert len(args) == len(fields)
     for f, a in zip(fields, args):
         assert expect[f] in a, (f, a)
@@ -275,7 +276,9 @@ def test_metric_and_disc_ids_match_the_header():
             "BumblebeeMetric": "GR_METRIC_BUMBLEBEE", "KerrNewmanMetric": "GR_METRIC_KERR_NEWMAN",
             "JohannsenPsaltisMetric": "GR_METRIC_JOHANNSEN_PSALTIS", "DilatonAxion": "GR_METRIC_DILATON_AXION",
             "Gradus.SphericalMetric": "GR_METRIC_SPHERICAL", "KerrDarkMatter": "GR_METRIC_KERR_DARK_MATTER",
-            "KerrRefractive": "GR_METRIC_KERR_REFRACTIVE", "NoZMetric": "GR_METRIC_NOZ"}
+            "KerrRefractive": "GR_METRIC_KERR_REFRACTIVE", "NoZMetric": "GR_METRIC_NOZ",
+            # every OTHER static, axis-symmetric metric: the plugin contract (metric_components only) through a table
+            "Gradus.AbstractStaticAxisSymmetric": "GR_METRIC_TABULATED"}
     for jl, c in want.items():
         m = re.search(r"_metric\(m::" + re.escape(jl) + r"\) = \(Int32\((\d+)\)", JL)
         assert m and m.group(1) == ids[c], (jl, c)
