@@ -47,28 +47,123 @@ FLOPS_JSON = os.path.join(ROOT, "oracle", "flopcount.json")
 PROFILE_POINTER = os.path.join(ROOT, "profiles", "CURRENT")
 
 
-def profile_evidence(size, world):
-    """(summary dict, relative path) of the committed profile that belongs to this build and workload, or
-    (None, reason)."""
+def profile_index():
+    """{name: relative path} of the committed rocprofv3 summaries of THIS build: profiles/CURRENT is a small JSON index
+    ({"head": ..., "C2": ..., "C4": ..., "C5_f64": ..., "C5_f32": ..., "C2_tabulated": ..., "C4_tabulated": ...}); a bare path
+    (rounds 1-4) names the head summary only."""
+    txt = open(PROFILE_POINTER).read().strip()
+    try:
+        idx = json.loads(txt)
+        return idx if isinstance(idx, dict) else {"head": str(idx)}
+    except ValueError:
+        return {"head": txt}
+
+
+def load_summary(name, kernel_substr, rays):
+    """(summary, relative path) of the index entry `name` if it belongs to this build (kernel source hash), profiles the
+    kernel that is launched and a launch of `rays` rays; else (None, reason)."""
     from gradus_jl_amd._lib import kernel_source_sha16
 
     try:
-        rel = open(PROFILE_POINTER).read().strip()
+        rel = profile_index()[name]
         with open(os.path.join(ROOT, rel)) as f:
             summ = json.load(f)
     except Exception as e:      # noqa: BLE001
-        return None, f"no committed profile summary ({type(e).__name__}: {e})"
+        return None, f"no committed profile summary for {name} ({type(e).__name__}: {e})"
     sha = kernel_source_sha16()
     if summ.get("source_sha16") != sha:
         return None, f"{rel} was taken from kernel sources {summ.get('source_sha16')}, this tree is {sha}: re-profile"
-    if "k_trace_lane<gr::KerrFamily<false>, 1>" not in (summ.get("kernel") or ""):
-        return None, f"{rel} profiles {summ.get('kernel')}, not the bench kernel"
-    if summ.get("rays_per_launch") != size * size or world != 1:
-        return None, f"{rel} is a {summ.get('rays_per_launch')}-ray launch; this run launches {size * size // world} rays per GPU"
-    for k in ("executed_fp64_flops_per_launch", "valu_issue_per_4clk", "avg_ms"):
+    if kernel_substr not in (summ.get("kernel") or ""):
+        return None, f"{rel} profiles {summ.get('kernel')}, not {kernel_substr}"
+    if summ.get("rays_per_launch") != rays:
+        return None, f"{rel} is a {summ.get('rays_per_launch')}-ray launch; this run launches {rays}"
+    for k in ("valu_issue_per_4clk", "avg_ms"):
         if k not in summ:
             return None, f"{rel} lacks {k}"
     return summ, rel
+
+
+def profile_evidence(size, world):
+    """(summary dict, relative path) of the committed profile that belongs to this build and workload, or
+    (None, reason)."""
+    if world != 1:
+        return None, f"the committed head profile is a one-GPU launch; this run launches {size * size // world} rays per GPU"
+    summ, rel = load_summary("head", "k_trace_lane<gr::KerrFamily<false>, 1>", size * size)
+    if summ is not None and "executed_fp64_flops_per_launch" not in summ:
+        return None, f"{rel} lacks executed_fp64_flops_per_launch"
+    return summ, rel
+
+
+PEAK_FP32_VALU_TFLOPS = 157.3
+
+
+def baseline_configs(G, ens, reps=3):
+    """The other BASELINE.json configurations, each as a few launches of its own kernel next to the headline:
+    launch duration measured HERE (gr_stats.kernel_ms of the blocking call: start of the call's device work -> end of its trace
+    kernel, fastest of `reps` after one warm-up), fraction of the vector-ALU peak from the executed flops of the committed,
+    source-hash-checked rocprofv3 summary of that kernel.  ~1.5 s of GPU time in all.
+        C2            KerrMetric(a = 0.998) 1024², ThinDisc(isco, 50), redshift                       fp64 fused kernel
+        C4            JohannsenMetric(a = 0.7, α13 = 2, ϵ3 = 1) 1024², ThinDisc, interpolated redshift   fp64 fused kernel
+        C5_f64 / f32  line profile, 4096² polar-plane rays, tol 1e-9 (fp64) / 1e-5 (fp32 kernels)
+        C2_tabulated / C4_tabulated   the same two metrics as USER-DEFINED metrics: through GR_METRIC_TABULATED's table
+    """
+    out = {}
+    ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
+
+    def price(name, kernel_substr, rays, ms, f32=False):
+        rec = {"ms": ms, "rays": rays, "rays_per_s": rays / (ms * 1e-3)}
+        summ, rel = load_summary(name, kernel_substr, rays)
+        key = "executed_fp32_flops_per_launch" if f32 else "executed_fp64_flops_per_launch"
+        peak = PEAK_FP32_VALU_TFLOPS if f32 else PEAK_FP64_VALU_TFLOPS
+        if summ is not None and key in summ:
+            tf = summ[key] / (ms * 1e-3) / 1e12
+            rec["roofline"] = {"bound": "fp32-valu" if f32 else "fp64-valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                               "frac": tf / peak, "valu_issue_per_4clk": summ["valu_issue_per_4clk"],
+                               "valu_lane_utilization": summ.get("valu_lane_utilization"), "profile": rel,
+                               "profile_avg_ms": summ["avg_ms"], "profile_source_sha16": summ["source_sha16"]}
+        else:
+            rec["roofline"] = {"frac": None, "profile_error": rel if summ is None else f"{rel} lacks {key}"}
+        out[name] = rec
+
+    def render_ms(m, x, S):
+        pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
+        disc = G.ThinDisc(m.isco(), 50.0)
+        ms = []
+        for rep in range(reps + 1):
+            _, _, img, st = G.rendergeodesics(m, x, disc, 2000.0, image_width=S, image_height=S, alpha_lims=ALIMS, beta_lims=BLIMS,
+                                              pf=pf, ensemble=ens, stats=True)
+            if rep:
+                ms.append(st["kernel_ms"])
+        return min(ms)
+
+    kerr, joh = G.KerrMetric(1.0, 0.998), G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0)
+    x75, x70 = np.array([0.0, 1000.0, math.radians(75.0), 0.0]), np.array([0.0, 1000.0, math.radians(70.0), 0.0])
+    price("C2", "k_trace_lane<gr::KerrFamily<false>, 1>", 1024 * 1024, render_ms(kerr, x75, 1024))
+    price("C4", "k_trace_lane<gr::JohannsenMetric", 1024 * 1024, render_ms(joh, x70, 1024))
+    # C5: the line profile on 4096² rays (scripts/sibling_workloads.py c5 / c5f32)
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=4096, Nθ=4096, r_min=1.0, r_max=250.0)
+    bins = np.linspace(0.1, 1.5, 180)
+    for name, prec, tol, sub in (("C5_f64", 64, 1e-9, "k_trace_"), ("C5_f32", 32, 1e-5, "gr32::")):
+        ens.set("precision", prec)
+        try:
+            ms = []
+            for rep in range(reps + 1):
+                _, _, st = G.lineprofile(bins, G.PowerLawEmissivity(3), kerr, u, G.ThinDisc(kerr.isco(), 250.0), G.BinningMethod(), plane=plane,
+                                         maxrₑ=250.0, ensemble=ens, stats=True, abstol=tol, reltol=tol)
+                if rep:
+                    ms.append(st["kernel_ms"])
+        finally:
+            ens.set("precision", 64)
+        price(name, sub, 4096 * 4096, min(ms), f32=(prec == 32))
+    # the same two metrics given to the library as SAMPLES of metric_components: the AbstractMetric plugin path
+    for name, base, x in (("C2_tabulated", kerr, x75), ("C4_tabulated", joh, x70)):
+        tm = G.TabulatedMetric(base)
+        price(name, "k_trace_lane<gr::TabulatedMetric", 1024 * 1024, render_ms(tm, x, 1024))
+        out[name]["table"] = {"grid_m_r_n_theta": [tm.m_r, tm.n_theta], "mb": tm.table.nbytes / 1e6, "fit_error_estimates": list(tm.errors)}
+        ref = name.split("_")[0]
+        out[name]["slowdown_vs_fused"] = out[name]["ms"] / out[ref]["ms"]
+    return out
 
 
 def parse_args():
@@ -85,6 +180,8 @@ def parse_args():
     ap.add_argument("--block-cols", type=int, default=8)
     ap.add_argument("--tile-rows", type=int, default=None, help="pixel tile of a wave: 8 (8 x 8) or 16 (16 x 4: whole 128-B lines per store)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the third leg (the other BASELINE configurations, a few launches each: `configs` of the line)")
     ap.add_argument("--no-host-call", action="store_true",
                     help="skip the second timed leg (blocking gr_render into a host buffer, D2H included)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -437,6 +534,13 @@ def main():
         }
         if host_call is not None:
             line["host_call"] = host_call
+            line["value_blocking_call_with_d2h"] = host_call["value"]      # SURVEY §8(d)'s definition, named as such
+        line["value_device_resident"] = rays_per_s                         # == value (the contract's definition), named as such
+        if world == 1 and not args.no_configs:
+            try:
+                line["configs"] = baseline_configs(G, ens)
+            except Exception as e:      # noqa: BLE001 -- a sibling failing must not lose the measured headline
+                line["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds)

@@ -129,7 +129,7 @@ struct gr_ctx {
     int64_t kernel = 2;                    // 0 lane, 1 persistent, 2 auto (by launch depth)
     int64_t lpt_lane = 0;                  // also order tiles longest-first for the lane kernel
     int64_t block = 0;                    // 0 = auto: 64 for the one-ray-per-lane kernel, 256 for the persistent one
-    int64_t refill_threshold = 16;
+    int64_t refill_threshold = 0;          // idle lanes that trigger a refill; 0 = auto: 16 for the fp64 kernels, 32 for the fp32 ones
     int64_t waves_per_simd = 0;            // 0 = from occupancy query
     int64_t swizzle = 1;
     int64_t tile_rows = 8;                 // rows of the pixel tile of a wave: 8 (8 x 8) or 16 (16 x 4: whole 128-B lines per store)
@@ -328,6 +328,9 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
             const int32_t mrc = ensure((void**)&ctx->d_mesh, &ctx->mesh_bytes, mb);
             if (mrc != GR_OK) return mrc;
             GR_HIP(hipMemcpyAsync(ctx->d_mesh, ctx->mesh_host.data(), mb, hipMemcpyHostToDevice, stream));
+            // mesh_host is rebuilt in place by the next mesh: the copy out of it must have finished by then (the device entry
+            // points run on a caller's stream that nothing else would wait for).  Once per mesh.
+            GR_HIP(hipStreamSynchronize(stream));
             ctx->mesh_n = n;
             ctx->mesh_fp = fp;
         }
@@ -458,7 +461,8 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     ctx->cold_next = (ctx->cold_next + 1) % ctx->queue_slots;
     GR_HIP(hipMemcpyAsync(slot, &cold, sizeof(Cold), hipMemcpyHostToDevice, stream));
     p.cold = slot;
-    p.refill_threshold = (int32_t)ctx->refill_threshold;
+    // (fp32 line profile, 4096² rays: 21.2 ms at 32 against 22.3 at 16 and 24.2 at 8; fp64: 50.8 either way -- profiles/r5n_c5f32_knobs.log)
+    p.refill_threshold = (int32_t)(ctx->refill_threshold ? ctx->refill_threshold : (ctx->precision == 32 ? 32 : 16));
     // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
     const bool tangent = cold.out_mode == 5;
     if (p.cfg.metric_id == GR_METRIC_TABULATED && (tangent || ctx->precision == 32))
@@ -784,7 +788,7 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         if (value != 0 && (value < 64 || value > 256 || value % 64)) return fail(GR_ERR_INVALID_ARGUMENT, "block must be 0 (auto) or a multiple of 64 in [64, 256]");
         c->block = value;
     } else if (k == "refill_threshold") {
-        if (value < 1 || value > 64) return fail(GR_ERR_INVALID_ARGUMENT, "refill_threshold must be in [1, 64]");
+        if (value < 0 || value > 64) return fail(GR_ERR_INVALID_ARGUMENT, "refill_threshold must be in [0, 64] (0 = auto)");
         c->refill_threshold = value;
     } else if (k == "waves_per_simd") {
         if (value < 0 || value > 8) return fail(GR_ERR_INVALID_ARGUMENT, "waves_per_simd must be in [0, 8]");
@@ -2025,10 +2029,12 @@ int32_t rayset_rows_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, 
         int32_t r;
         if ((r = rayset_share(rays, n, k, share, &off)) != GR_OK) return r;
         GR_HIP(hipSetDevice(c->device));
+        // (before the rays are staged: kernel_ms / call_ms count from the start of the call's device work, input staging included,
+        // as in the single-context entry points)
+        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
         if ((r = stage_rays(c, &share, dev, 0, nullptr)) != GR_OK) return r;
         const size_t bytes = row_bytes * (size_t)share.n;
         if ((r = ensure(&c->d_scratch, &c->scratch_bytes, bytes ? bytes : 8)) != GR_OK) return r;
-        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
         if (share.n == 0) return GR_OK;
         return launch(c, &dev, c->d_scratch, stats ? (gr_stats*)c->d_stats : nullptr);
     };
@@ -2140,6 +2146,7 @@ int32_t gr_lineprofile_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cf
         if ((r = share_of(k, sh)) != GR_OK) return r;
         GR_HIP(hipSetDevice(c->device));
         void* extra = nullptr;
+        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;      // (before the staging, see rayset_rows_multi)
         if ((r = stage_rays(c, &sh, dev, sizeof(double) * (2 * nb + 2 * ne), &extra)) != GR_OK) return r;
         double* d_edges = (double*)extra;
         double* d_flux = d_edges + nb;
@@ -2153,7 +2160,6 @@ int32_t gr_lineprofile_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cf
             db.eps_r = d_er;
             db.eps_v = d_er + ne;
         }
-        if ((r = begin_host_call(c, stats ? &stats[k] : nullptr)) != GR_OK) return r;
         d_part[(size_t)k] = d_flux;
         // (a context without rays still zeroes its histogram: gr_lineprofile_device does so before it looks at n)
         return gr_lineprofile_device(c, cfg, &dev, pf, &db, d_flux, stats ? (gr_stats*)c->d_stats : nullptr, c->stream);

@@ -96,7 +96,7 @@ def render_into_image(config: TracingConfiguration, pf=None, stats=False):
         multi = ens.multi
         img = _lib.result_image(ens.ctx, n)      # >= 8 MiB: written by the kernel(s) across the link, each pixel at its place
         if multi:
-            ctxs = ens.contexts
+            ctxs = ens.contexts_for_width(pl.width)
             arr, sts = _lib.ctx_array(ctxs)
             _lib.check(_lib.load().gr_render_multi(arr, len(ctxs), C.byref(cfg), C.byref(pl), C.byref(s), 0,
                                                    img.ctypes.data, sts))

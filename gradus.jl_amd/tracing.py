@@ -219,6 +219,16 @@ class EnsembleMI355X:
     def multi(self) -> bool:
         return self.devices is not None and len(self.devices) > 1
 
+    def contexts_for_width(self, width: int):
+        """The contexts an image plane of `width` columns is dealt over: all of them when their number divides the width (the
+        library deals whole columns), else the largest leading subset that does -- 3 devices and a 1024-wide image render on 2
+        (the Julia shim guards the same way; the library itself refuses the deal)."""
+        ctxs = self.contexts
+        k = len(ctxs)
+        while k > 1 and width % k != 0:
+            k -= 1
+        return ctxs[:k]
+
     def set(self, key, value):
         self.knobs[key] = value
         if self._ctx is not None:
@@ -494,6 +504,8 @@ def ensemble_solve_tracing_problem(ensemble: EnsembleMI355X, config: TracingConf
         arr, sts = _lib.ctx_array(ctxs)
         if isinstance(config.velocity, RenderVelocity):
             pl = config.abi_plane()
+            ctxs = ensemble.contexts_for_width(pl.width)
+            arr, sts = _lib.ctx_array(ctxs)
             n = pl.width * pl.height
             out = _lib.result_points(ensemble.ctx, n)   # pinned from 64 MiB up: every device's kernel stores its records there itself
             _lib.check(L.gr_render_endpoints_multi(arr, len(ctxs), C.byref(cfg), C.byref(pl), 0, out.ctypes.data, sts))

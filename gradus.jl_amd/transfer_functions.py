@@ -151,13 +151,22 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
         (`gr_ray_tangent`), what the reference's ForwardDiff.jacobian around tracegeodesics produces."""
         rs, keep = rayset(α, β, heights)
         out = np.zeros((rs.n, 8))
-        if many:
-            _lib.check(L.gr_ray_tangent_multi(ctx_arr, n_ctx, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, ctx_stats))
-        else:
-            st, done = _logged("gr_ray_tangent", rs.n)
-            _lib.check(L.gr_ray_tangent(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data,
-                                        C.byref(st) if st is not None else None))
-            done()
+        # ONE kernel shape for every launch of this tracer (ADVICE r4): the library's default picks the lane-pair shape for small
+        # launches and one lane per ray beyond, and the two agree to rounding only (1e-11) -- a root's Newton iterate would then
+        # depend on how many other problems share its launch (or, over several devices, on the share size).  The solvers'
+        # launches are latency-bound: the pair shape, always.
+        prev = ens_.knobs.get("tangent_pairs", 2)
+        ens_.set("tangent_pairs", 1)
+        try:
+            if many:
+                _lib.check(L.gr_ray_tangent_multi(ctx_arr, n_ctx, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data, ctx_stats))
+            else:
+                st, done = _logged("gr_ray_tangent", rs.n)
+                _lib.check(L.gr_ray_tangent(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), out.ctypes.data,
+                                            C.byref(st) if st is not None else None))
+                done()
+        finally:
+            ens_.set("tangent_pairs", prev)
         return out
 
     trace.endpoints = endpoints

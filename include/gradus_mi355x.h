@@ -270,7 +270,7 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * refill, 2 = chosen per launch [default]: image planes -> one ray per lane in one-wave workgroups,
  * line profiles and caller-ordered ray arrays -> persistent); ("block", threads per workgroup,
  * 0 = auto [default]: 64 for kernel 0, 256 for kernel 1); ("refill_threshold", idle lanes that
- * trigger a refill, default 16); ("waves_per_simd"), ("swizzle"), ("lpt"), ("lpt_lane"), ("lds"),
+ * trigger a refill, 0 = auto [default]: 16 for the fp64 kernels, 32 for the fp32 ones); ("waves_per_simd"), ("swizzle"), ("lpt"), ("lpt_lane"), ("lds"),
  * ("precision", 64 | 32); ("pipeline", bands of the end-point return); ("hugepages", 1 [default] = large caller-owned
  * result buffers are madvise(MADV_HUGEPAGE)d before they are pre-faulted, 0 = the caller's mapping is left alone);
  * ("tangent_norm", 1 [default] = gr_ray_tangent's step-size controller sees values AND tangents -- DiffEqBase's norm on

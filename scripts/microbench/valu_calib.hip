@@ -54,6 +54,12 @@ STREAM_KERNEL(calib_fma_f32,
               REP8("v_fma_f32 %0, %0, %8, %9", "v_fma_f32 %1, %1, %8, %9", "v_fma_f32 %2, %2, %8, %9", "v_fma_f32 %3, %3, %8, %9",
                    "v_fma_f32 %4, %4, %8, %9", "v_fma_f32 %5, %5, %8, %9", "v_fma_f32 %6, %6, %8, %9", "v_fma_f32 %7, %7, %8, %9"),
               F_OUT, F_IN)
+// the packed form: two FP32 FMAs per lane and instruction on a register PAIR -- the only way to the 157.3 TFLOP/s FP32 vector peak
+// (round 5: what "fraction of the FP32 peak" means for a kernel of scalar v_fma_f32, DESIGN.md §5 "fp32 kernels")
+STREAM_KERNEL(calib_pk_fma_f32,
+              REP8("v_pk_fma_f32 %0, %0, %8, %9", "v_pk_fma_f32 %1, %1, %8, %9", "v_pk_fma_f32 %2, %2, %8, %9", "v_pk_fma_f32 %3, %3, %8, %9",
+                   "v_pk_fma_f32 %4, %4, %8, %9", "v_pk_fma_f32 %5, %5, %8, %9", "v_pk_fma_f32 %6, %6, %8, %9", "v_pk_fma_f32 %7, %7, %8, %9"),
+              D_OUT, D_IN)
 STREAM_KERNEL(calib_mov_b32,
               REP8("v_mov_b32 %0, %1", "v_mov_b32 %1, %2", "v_mov_b32 %2, %3", "v_mov_b32 %3, %4", "v_mov_b32 %4, %5",
                    "v_mov_b32 %5, %6", "v_mov_b32 %6, %7", "v_mov_b32 %7, %0"),
@@ -156,6 +162,7 @@ int main(int argc, char** argv)
     run("calib_add_f64", calib_add_f64, d_out, n_cu, wps, target_ms);
     run("calib_fma_f64_sgpr", calib_fma_f64_sgpr, d_out, n_cu, wps, target_ms);
     run("calib_fma_f32", calib_fma_f32, d_out, n_cu, wps, target_ms);
+    run("calib_pk_fma_f32", calib_pk_fma_f32, d_out, n_cu, wps, target_ms);
     run("calib_mov_b32", calib_mov_b32, d_out, n_cu, wps, target_ms);
     run("calib_mov_b64", calib_mov_b64, d_out, n_cu, wps, target_ms);
     run("calib_cndmask_b32", calib_cndmask_b32, d_out, n_cu, wps, target_ms);

@@ -5,6 +5,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 T=${1:-r2}
 cd $R
 bash scripts/profile_pmc.sh ${T}_head
+bash scripts/profile_pmc.sh ${T}_c2 --size 1024
+PROF_CMD="scripts/sibling_workloads.py tabkerr" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabkerr
+PROF_CMD="scripts/sibling_workloads.py tabc4" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabc4
 PROF_CMD="scripts/sibling_workloads.py c4" PROF_KERNEL="k_trace_lane<gr::JohannsenMetric" bash scripts/profile_pmc.sh ${T}_c4
 PROF_CMD="scripts/sibling_workloads.py generic" PROF_KERNEL="k_trace_lane<gr::GenericMetric" bash scripts/profile_pmc.sh ${T}_generic
 PROF_CMD="scripts/sibling_workloads.py c5" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_c5
@@ -21,4 +24,4 @@ PROF_CMD="scripts/sibling_workloads.py dual9" PROF_KERNEL="k_trace_lane<gr::Gene
 PROF_CMD="scripts/sibling_workloads.py dual10" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<10>" bash scripts/profile_pmc.sh ${T}_noz
 PROF_CMD="scripts/sibling_workloads.py mesh" PROF_KERNEL="k_trace_lane<gr::KerrFamily<false>, 8>" bash scripts/profile_pmc.sh ${T}_mesh
 # drop the bulky raw traces, keep summaries
-for d in gpurun_out/prof_${T}_*; do rm -rf $d/trace $d/pmcA $d/pmcB $d/pmcC $d/pmcD; done
+for d in gpurun_out/prof_${T}_*; do rm -rf $d/trace $d/pmcA $d/pmcB $d/pmcC $d/pmcD $d/pmcE $d/pmcF; done

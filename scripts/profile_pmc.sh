@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 WARM=${PROF_WARMUP:-2}
-if [ -n "$PROF_CMD" ]; then CMD="$PROF_CMD"; else CMD="bench.py --steps 12 --warmup $WARM --no-cpu-baseline --no-host-call $@"; fi
+if [ -n "$PROF_CMD" ]; then CMD="$PROF_CMD"; else CMD="bench.py --steps 12 --warmup $WARM --no-cpu-baseline --no-host-call --no-configs $@"; fi
 NEEDLE=${PROF_KERNEL:-k_trace}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $CMD > $OUT/bench.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcA -- python3 $CMD > /dev/null 2>&1

@@ -34,6 +34,9 @@ import gradus_jl_amd as G
 which = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ens = G.EnsembleMI355X(0)
+for kv in filter(None, os.environ.get("SIB_KNOBS", "").split(",")):      # e.g. SIB_KNOBS="kernel=0,block=256": launch knobs (gr_ctx_set)
+    k_, v_ = kv.split("=")
+    ens.set(k_, int(v_))
 ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
 ms = []
 extra = {}

@@ -298,3 +298,21 @@ def test_enqueue_phase_does_not_wait_for_a_device(G, ens, multi4, pinned):
         assert max(enq) < 0.1 * max(ker), (what, enq, ker)
         assert sum(enq) < 0.25 * max(ker), (what, enq, ker)
         assert sum(x.rays for x in sts) == n
+
+
+def test_image_width_not_divisible_by_the_number_of_devices(G, ens):
+    """three contexts and a 64-wide image -- the library deals whole columns and refuses 64 / 3; the host side takes
+    the largest leading subset of the ensemble that divides the width (here two) instead of raising, for the fused render
+    and for the end points, and the pixels / records are those of one context."""
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(m.isco(), 50.0)
+    three = G.EnsembleMI355X(devices=[0, 0, 0])
+    assert len(three.contexts_for_width(64)) == 2 and len(three.contexts_for_width(63)) == 3 and len(three.contexts_for_width(61)) == 1
+    pf = G.ConstPointFunctions.redshift(m, X_FAR) @ G.ConstPointFunctions.filter_intersected()
+    kw = dict(image_width=64, image_height=64, alpha_lims=ALIMS, beta_lims=BLIMS)
+    _, _, one = G.rendergeodesics(m, X_FAR, d, 2000.0, pf=pf, ensemble=ens, **kw)
+    _, _, many = G.rendergeodesics(m, X_FAR, d, 2000.0, pf=pf, ensemble=three, **kw)
+    assert one.tobytes() == many.tobytes()
+    _, _, c1 = G.prerendergeodesics(m, X_FAR, d, 2000.0, ensemble=ens, **kw)
+    _, _, c3 = G.prerendergeodesics(m, X_FAR, d, 2000.0, ensemble=three, **kw)
+    assert np.asarray(c1.points).tobytes() == np.asarray(c3.points).tobytes()

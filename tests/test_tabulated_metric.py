@@ -343,3 +343,30 @@ def test_tabulated_metric_is_fp64_only(G, ens, tab_kerr):
                               beta_lims=(-35, 35), ensemble=ens)
     finally:
         ens.set("precision", 64)
+
+
+@pytest.mark.gpu
+def test_tabulated_metric_through_the_persistent_kernel_and_ray_arrays(G, ens, tab_kerr):
+    """The other launch shapes: a BinningMethod line profile (persistent kernel with wave-ballot refill, four waves per
+    workgroup -- four patch caches side by side in LDS) and tracegeodesics on ray arrays in caller order, through the table
+    against the fused Kerr kernels."""
+    base = tab_kerr.source
+    u = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=256, Nθ=256, r_min=1.0, r_max=60.0)
+    bins = np.linspace(0.1, 1.5, 60)
+    prof = []
+    for m in (tab_kerr, base):
+        xs, ys = G.lineprofile(bins, G.PowerLawEmissivity(3), m, u, G.ThinDisc(base.isco(), 50.0), G.BinningMethod(), plane=plane,
+                               maxrₑ=50.0, ensemble=ens)
+        prof.append(np.asarray(ys))
+    assert np.max(np.abs(prof[0] - prof[1])) < 1e-7 * np.max(prof[1])
+    # ray arrays: 3000 rays in caller order
+    rng = np.random.default_rng(3)
+    α, β = rng.uniform(-40, 40, 3000), rng.uniform(-25, 25, 3000)
+    x = X_FAR
+    out = []
+    for m in (tab_kerr, base):
+        vs = G.map_impact_parameters(m, x, α, β)
+        pts = G.tracegeodesics(m, x, vs, G.ThinDisc(3.0, 400.0), 2000.0, ensemble=ens)
+        out.append(pts)
+    _compare_endpoints(out[0], out[1], x_rtol=1e-7, max_flips=2, max_outliers=3, r_horizon=base.inner_radius())
