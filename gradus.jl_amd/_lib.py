@@ -151,6 +151,9 @@ class gr_pointfunction(C.Structure):
         ("plunge_vt", C.POINTER(C.c_double)),
         ("plunge_vr", C.POINTER(C.c_double)),
         ("plunge_vphi", C.POINTER(C.c_double)),
+        ("has_u_src", C.c_int32),
+        ("_pad_u", C.c_int32),
+        ("u_src", C.c_double * 4),
     ]
 
 
@@ -173,6 +176,12 @@ class gr_rayset(C.Structure):
         ("sep_first", C.c_int64),
         ("sep_block", C.c_int64),
         ("sep_stride", C.c_int64),
+        ("sky_sampler", C.c_int32),
+        ("sky_both", C.c_int32),
+        ("sky_generator", C.c_int32),
+        ("sky_reserved", C.c_int32),
+        ("sky_resolution", C.c_double),
+        ("sky_i", C.c_void_p),
     ]
 
 
@@ -262,6 +271,8 @@ EXPORTS = [
     "gr_rayset_endpoints",
     "gr_apply_pointfunction_device",
     "gr_apply_pointfunction",
+    "gr_corona_trace",
+    "gr_corona_bin",
     "gr_render_endpoints_multi",
     "gr_trace_endpoints_multi",
     "gr_rayset_endpoints_multi",
@@ -323,6 +334,8 @@ def load():
     L.gr_rayset_endpoints.argtypes = [vp, cfgp, rsp, vp, stp]
     L.gr_apply_pointfunction_device.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp, vp]
     L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
+    L.gr_corona_trace.argtypes = [vp, cfgp, rsp, pfp, vp, C.POINTER(C.c_int64), stp]
+    L.gr_corona_bin.argtypes = [vp, vp, i64, vp]
     ctxa = C.POINTER(vp)
     L.gr_render_endpoints_multi.argtypes = [ctxa, i32, cfgp, plp, i64, vp, vp]
     L.gr_trace_endpoints_multi.argtypes = [ctxa, i32, cfgp, vp, i64, vp, i64, vp, vp]

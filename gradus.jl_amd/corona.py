@@ -264,9 +264,42 @@ def sample_position_direction_velocity(m, model, sampler, N):
     return xs, vs, vsrc
 
 
+def _device_corona_enabled(m, sampler):
+    """GRADUS_MI355X_DEVICE_CORONA=0 keeps the record route (tracecorona + build_radial_profile on the host's numpy)."""
+    import os
+
+    return (os.environ.get("GRADUS_MI355X_DEVICE_CORONA", "1") != "0" and isinstance(sampler, (EvenSampler, WeierstrassSampler))
+            and getattr(m, "metric_id", None) is not None)
+
+
+def _sky_route(m, model, sampler):
+    return (model.point_source or model.fixed_position) and _device_corona_enabled(m, sampler)
+
+
+def _sky_endpoints(m, model, sampler, n_samples, geometry, λs, stats=False, **kwargs):
+    """End-point records of a sky ray set (gr_rayset_endpoints): the directions are formed per lane on the device, nothing
+    per ray crosses PCIe on the way in (a caller's generator: its 8 bytes per ray)."""
+    import ctypes as C
+
+    from . import _lib
+    from .tracing import tracing_configuration
+
+    rs, keep, x, v_src = sky_rayset(m, model, sampler, n_samples)
+    config = tracing_configuration(m, x, np.zeros((1, 4)), geometry, λs, **kwargs)
+    cfg = config.abi_config()
+    out = np.zeros(rs.n, dtype=_lib.POINT_DTYPE)
+    st = _lib.gr_stats() if stats else None
+    _lib.check(_lib.load().gr_rayset_endpoints(config.ensemble.ctx.handle, C.byref(cfg), C.byref(rs), out.ctypes.data,
+                                               C.byref(st) if stats else None))
+    return (out, st, v_src) if stats else (out, v_src)
+
+
 def tracegeodesics(m, model, *args, n_samples=1024, sampler=None, **kwargs):
     """tracegeodesics(m, model::AbstractCoronaModel, [d], λ; n_samples, sampler) corona-models.jl:143-153"""
     sampler = EvenSampler(BothHemispheres(), GoldenSpiralGenerator()) if sampler is None else sampler
+    if _sky_route(m, model, sampler) and len(args) in (1, 2) and not kwargs.get("stats"):
+        geometry, λs = args if len(args) == 2 else (None, args[0])
+        return _sky_endpoints(m, model, sampler, n_samples, geometry, λs, **kwargs)[0]
     xs, vs, _ = sample_position_direction_velocity(m, model, sampler, n_samples)
     return _tracegeodesics(m, xs, vs, *args, **kwargs)
 
@@ -285,6 +318,10 @@ def tracecorona(m, g, model, *, λmax=10_000.0, n_samples=1024, sampler=None, ca
     sampler = EvenSampler(BothHemispheres(), RandomGenerator()) if sampler is None else sampler
     if callback == "default":
         callback = domain_upper_hemisphere()
+    if _sky_route(m, model, sampler):
+        gps, v_src = _sky_endpoints(m, model, sampler, n_samples, g, λmax, callback=callback, **kwargs)
+        mask = gps["status"] == StatusCodes.IntersectedWithGeometry
+        return CoronaGeodesics(m, g, model, gps[mask], np.tile(v_src, (int(mask.sum()), 1)))
     xs, vs, vsrc = sample_position_direction_velocity(m, model, sampler, n_samples)
     gps = _tracegeodesics(m, xs, vs, g, λmax, callback=callback, **kwargs)
     mask = gps["status"] == StatusCodes.IntersectedWithGeometry
@@ -444,6 +481,22 @@ def _bucket_index(values, bins):
     return np.clip(np.searchsorted(bins, values, side="right") - 1, 0, bins.size - 1)
 
 
+def _profile_from_bins(m, spec, bins, count, gsum, tsum, grouped, disc_velocity):
+    """the second half of _build_radial_profile (radial.jl:70-100): per-bin means -> emissivity."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        gs = gsum / count          # mean per bin; NaN when empty
+        ts = tsum / count
+    g_at = _nan_linear_interp(bins, gs, bins)
+    dr = np.diff(np.concatenate([[0.0], bins]))
+    xb = np.zeros((bins.size, 4))
+    xb[:, 1], xb[:, 2] = bins, math.pi / 2
+    vb = disc_velocity(xb)
+    A = dr * _proper_area(m, bins, math.pi / 2)
+    with np.errstate(all="ignore"):          # empty bins: 0 photons x (0 redshift)^-Γ = NaN, as in the reference
+        ε = source_to_disc_emissivity(m, spec, grouped, A, xb, g_at, vb)
+    return RadialDiscProfile(bins, ε, ts)
+
+
 def build_radial_profile(m, spec, points, source_velocities, *, grid=None, N=100, intensity=None, disc_velocity=None,
                          ensemble=None):
     """_build_radial_profile + the sorting wrapper (radial.jl:38-100,132-141,155-165)."""
@@ -457,19 +510,123 @@ def build_radial_profile(m, spec, points, source_velocities, *, grid=None, N=100
     idx = _bucket_index(radii, bins)
     count = np.bincount(idx, minlength=bins.size).astype(np.float64)
     g_all = energy_ratio(m, points, source_velocities, disc_velocity(points["x"]))
-    with np.errstate(invalid="ignore", divide="ignore"):
-        gs = np.bincount(idx, weights=g_all, minlength=bins.size) / count          # mean per bin; NaN when empty
-        ts = np.bincount(idx, weights=times, minlength=bins.size) / count
+    gsum = np.bincount(idx, weights=g_all, minlength=bins.size)
+    tsum = np.bincount(idx, weights=times, minlength=bins.size)
     grouped = count if intensity is None else np.bincount(idx, weights=np.asarray(intensity)[J], minlength=bins.size)
-    g_at = _nan_linear_interp(bins, gs, bins)
-    dr = np.diff(np.concatenate([[0.0], bins]))
-    xb = np.zeros((bins.size, 4))
-    xb[:, 1], xb[:, 2] = bins, math.pi / 2
-    vb = disc_velocity(xb)
-    A = dr * _proper_area(m, bins, math.pi / 2)
-    with np.errstate(all="ignore"):          # empty bins: 0 photons x (0 redshift)^-Γ = NaN, as in the reference
-        ε = source_to_disc_emissivity(m, spec, grouped, A, xb, g_at, vb)
-    return RadialDiscProfile(bins, ε, ts)
+    return _profile_from_bins(m, spec, bins, count, gsum, tsum, grouped, disc_velocity)
+
+
+# ------------------------------------------------------------------------------------------
+# corona -> disc on the device (gr_corona_trace / gr_corona_bin)
+# ------------------------------------------------------------------------------------------
+def sky_rayset(m, model, sampler, n_samples):
+    """The gr_rayset of `tracegeodesics(m, model, ...)` for a source at one position: the tetrad and the
+    Cartesian -> spherical Jacobian go in as one matrix (v = T (1, J k̂), samplers.jl:81-99) and sample number ->
+    sky angles -> k̂ happens per lane on the device (samplers.jl:30-44).  Returns (rayset, keepalive, x, v_source)."""
+    from . import _lib
+
+    if not (model.point_source or model.fixed_position):
+        raise NotImplementedError("a sky ray set describes a source at ONE position (point_source / fixed_position models)")
+    x, v = model.sample_position_velocity(m)
+    if x[1] < m.inner_radius() * 1.9:
+        raise ValueError("source position lies inside 1.9 inner radii")
+    x = np.array(x, dtype=np.float64)
+    x[2] = min(max(x[2], 1e-3), math.pi - 1e-3)             # avoid coordinate singularities, corona-models.jl:18-24
+    v = np.asarray(v, dtype=np.float64)
+    B = np.eye(4)
+    B[1:, 1:] = _cart_to_spher_jacobian(x[2], x[3])
+    Mx = tetradframe_matrix(m, x, v) @ B
+    rs = _lib.gr_rayset()
+    for q in range(4):
+        rs.x_obs[q] = x[q]
+    for q, val in enumerate(np.ascontiguousarray(Mx).ravel()):
+        rs.Mx[q] = val
+    rs.n = int(n_samples)
+    if isinstance(sampler, EvenSampler):
+        rs.sky_sampler = 1
+    elif isinstance(sampler, WeierstrassSampler):
+        rs.sky_sampler, rs.sky_resolution = 2, sampler.resolution
+    else:
+        raise NotImplementedError(f"Not implemented for {type(sampler).__name__}.")
+    rs.sky_both = 1 if isinstance(sampler.domain, BothHemispheres) else 0
+    keep = None
+    g = sampler.generator
+    if isinstance(g, GoldenSpiralGenerator):
+        rs.sky_generator = 0
+    elif isinstance(g, EvenGenerator):
+        rs.sky_generator = 1
+    else:
+        # any other generator (RandomGenerator: rand() N): its numbers cross, 8 bytes per ray
+        keep = np.ascontiguousarray(geti(sampler, np.arange(1, n_samples + 1), n_samples), dtype=np.float64)
+        rs.sky_generator, rs.sky_i = 2, keep.ctypes.data
+    return rs, keep, x, v
+
+
+_PLUNGING_TABLES = {}
+
+
+def _plunging_table(m, ensemble):
+    """interpolate_plunging_velocities(m) once per metric value: one saved geodesic, a few ms, reused by every profile."""
+    from .special_radii import interpolate_plunging_velocities
+
+    try:
+        key = (type(m).__name__, int(m.metric_id)) + tuple(float(p) for p in m.abi_params())
+        if m.metric_id == 11:
+            key += (id(m),)
+    except Exception:          # a metric without flat parameters: no reuse
+        return tuple(interpolate_plunging_velocities(m, ensemble=ensemble))
+    if key not in _PLUNGING_TABLES:
+        if len(_PLUNGING_TABLES) >= 16:
+            _PLUNGING_TABLES.pop(next(iter(_PLUNGING_TABLES)))
+        _PLUNGING_TABLES[key] = tuple(interpolate_plunging_velocities(m, ensemble=ensemble))
+    return _PLUNGING_TABLES[key]
+
+
+def device_radial_profile(m, d, model, spectrum=None, *, λmax=10_000.0, sampler=None, n_samples=1000, grid=None, N=100,
+                          callback="default", ensemble=None, stats=False, **solver_args):
+    """emissivity_profile(m, d, model, spectrum; n_samples, sampler, N, grid) (emissivity.jl:118-168) with the whole
+    per-ray half on the device: sky sampling, tracing, energy_ratio against the Keplerian / plunging disc velocity
+    (gr_corona_trace) and the radial bucketing with the per-bin sums of g and t (gr_corona_bin).  What comes back
+    over PCIe is (ρ_min, ρ_max, hits) and 3 N doubles; the N-bin tail of radial.jl:86-100 runs on the host."""
+    import ctypes as C
+
+    from . import _lib
+    from .rendering import abi_pointfunction
+    from .tracing import tracing_configuration
+
+    spectrum = PowerLawSpectrum(2.0) if spectrum is None else spectrum
+    sampler = EvenSampler(BothHemispheres(), GoldenSpiralGenerator()) if sampler is None else sampler
+    grid = GeometricGrid() if grid is None else grid
+    if callback == "default":
+        callback = domain_upper_hemisphere()
+    rs, keep, x, v_src = sky_rayset(m, model, sampler, n_samples)
+    config = tracing_configuration(m, x, np.zeros((1, 4)), d, (0.0, λmax), callback=callback, ensemble=ensemble, **solver_args)
+    ens = config.ensemble
+    # the disc velocity of _keplerian_velocity_projector (circular-orbits.jl:155-170): ALWAYS the traced plunging
+    # table inside the ISCO (the analytic Kerr plunge of the image-plane redshift is a different, if close, function)
+    plunging = _plunging_table(m, ens)
+    disc_velocity = keplerian_velocity_projector(m, plunging=plunging, ensemble=ens)
+    from .pointfunctions import GR_PF_REDSHIFT, PointFunction
+
+    rpf = PointFunction(None, device_pf=GR_PF_REDSHIFT, extra={"r_isco": m.isco(), "plunge": plunging})
+    pf, keep_pf = abi_pointfunction(rpf)
+    pf.has_u_src = 1
+    for q in range(4):
+        pf.u_src[q] = v_src[q]
+    cfg = config.abi_config()
+    L = _lib.load()
+    lim = np.zeros(2)
+    hits = C.c_int64(0)
+    st = _lib.gr_stats() if stats else None
+    _lib.check(L.gr_corona_trace(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits),
+                                 C.byref(st) if stats else None))
+    if hits.value == 0:
+        raise ValueError("no ray of the corona reached the disc")
+    bins = np.ascontiguousarray(grid(lim[0], lim[1], N), dtype=np.float64)
+    out = np.zeros((3, bins.size))
+    _lib.check(L.gr_corona_bin(ens.ctx.handle, bins.ctypes.data, bins.size, out.ctypes.data))
+    prof = _profile_from_bins(m, spectrum, bins, out[0], out[1], out[2], out[0], disc_velocity)
+    return (prof, st) if stats else prof
 
 
 def _point_source_emissivity(m, spec, source_velocity, r, δs, points, disc_velocity):
@@ -519,6 +676,9 @@ def emissivity_profile(m, d, model, spectrum=None, *, λmax=10_000.0, δmin=0.01
         gps = _tracegeodesics(m, x, vs, d, λmax, callback=callback, ensemble=ensemble, **kwargs)
         return point_source_profile_from_points(m, spectrum, v, δs, gps, disc_velocity)
     sampler = EvenSampler(BothHemispheres(), GoldenSpiralGenerator()) if sampler is None else sampler
+    if _sky_route(m, model, sampler):
+        return device_radial_profile(m, d, model, spectrum, λmax=λmax, sampler=sampler, n_samples=n_samples, grid=grid, N=N,
+                                     callback=callback, ensemble=ensemble, **kwargs)
     cg = tracecorona(m, d, model, sampler=sampler, λmax=λmax, n_samples=n_samples, ensemble=ensemble)
     return build_radial_profile(m, spectrum, cg.geodesic_points, cg.source_velocity, grid=grid, N=N,
                                 disc_velocity=disc_velocity)

@@ -2245,13 +2245,16 @@ struct PfDev {
     const double* plunge_vt;
     const double* plunge_vr;
     const double* plunge_vphi;
+    int32_t has_u_src;        // 1 = E_start is measured against u_src (energy_ratio, flux-calculations.jl:96-110) instead of (1, 0, 0, 0)
+    int32_t pad_u;
+    double u_src[4];
 };
 
 // Per-launch data that only init()/finalize() touch.  It lives in device memory behind a pointer
 // (not in the kernarg segment) and is re-read at each use, so that its ~60 scalars are not kept
 // live in SGPRs across the hot step loop.
 struct Cold {
-    int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays
+    int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays, 3 = a source's sky (gr_rayset.sky_*)
     int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs, 4 = (g, ρ, t, status), 5 = the same with ∂/∂α, ∂/∂β (tangent build only)
     int32_t swizzle;          // log2 rows of the pixel tile a wave owns: 3 = 8 x 8, 4 = 16 x 4 (0 = none)
     int32_t idx32;            // 1 = every ray / pixel index fits 31 bits: 32-bit divisions in the index maps
@@ -2299,6 +2302,10 @@ struct Cold {
     // instead of to local index j (several devices storing one plane into one page-locked host block, gr_*_multi)
     int32_t out_global;
     int32_t out_reserved;
+    // src_mode 3: rays from a source into its sky (corona-models.jl:1-33, samplers.jl:30-99)
+    int32_t sky_sampler, sky_both, sky_generator, sky_reserved;
+    double sky_resolution;
+    const double* sky_i;      // device, n (sky_generator 2) or null
 };
 
 // the error norm's scaled residuals in single precision: the fp64 device kernels only (see Ray::step)
@@ -2510,7 +2517,12 @@ GR_DEV real redshift_pf(const Metric& m, const Params& pp, const Cold& p, const 
     real s0, c0, g0[5];
     sincos_fast(x0[2], s0, c0);
     metric_comps(m, x0[1], x0[2], s0, c0, g0);
-    const real E_obs = g0[0] * v0[0] + g0[4] * v0[3];
+    real E_obs = g0[0] * v0[0] + g0[4] * v0[3];
+    if (p.pf.has_u_src) {
+        // energy_ratio (flux-calculations.jl:96-110): the photon's energy at its start in the frame of a moving source
+        const real u0 = p.pf.u_src[0], u1 = p.pf.u_src[1], u2 = p.pf.u_src[2], u3 = p.pf.u_src[3];
+        E_obs = (g0[0] * v0[0] + g0[4] * v0[3]) * u0 + g0[1] * v0[1] * u1 + g0[2] * v0[2] * u2 + (g0[4] * v0[0] + g0[3] * v0[3]) * u3;
+    }
     return E_obs * rcp_full(E_disc);
 }
 
@@ -3069,6 +3081,33 @@ struct Ray {
             const real b = be * iro, a = al * iro;
             const real pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
             const real pb[4] = { 1.0, pr, b * pr, a * pr };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x0[q] = p.plane.x_obs[q];
+                v0[q] = p.plane.Mx[q * 4 + 0] * pb[0] + p.plane.Mx[q * 4 + 1] * pb[1] + p.plane.Mx[q * 4 + 2] * pb[2]
+                        + p.plane.Mx[q * 4 + 3] * pb[3];
+            }
+        } else if (p.src_mode == 3) {
+            // sample_position_direction_velocity for a source at one position (corona-models.jl:1-33): sample number jl + 1 ->
+            // (θ, ϕ) on the source's sky (samplers.jl:30-44) -> k̂ -> v = Mx (1, k̂) (sky_angles_to_velocity, samplers.jl:81-99,
+            // with the tetrad and the Jacobian folded into Mx on the host)
+            const double n = (double)p.plane.width;
+            const double idx = (double)(jl + 1);
+            const double i = p.sky_generator == 0 ? idx : p.sky_generator == 1 ? idx / n : p.sky_i[jl];
+            double el;
+            if (p.sky_sampler == 2) {
+                const double ph = 2.0 * ::atan(::sqrt(p.sky_resolution / i));
+                const bool even = (::floor(i) == i) && (::fmod(i, 2.0) == 0.0);
+                el = (!p.sky_both || even) ? ph : 3.14159265358979323846 - ph;
+            } else {
+                const double u = i / n;
+                el = p.sky_both ? ::acos(1.0 - 2.0 * u) : ::acos(1.0 - u);
+            }
+            const double az_raw = (p.sky_generator == 0 ? 3.14159265358979323846 * (1.0 + 2.2360679774997896964) : 6.28318530717958647692) * i;
+            double az = ::fmod(az_raw, 6.28318530717958647692);
+            if (az < 0.0) az += 6.28318530717958647692;
+            const double se = ::sin(el), ce = ::cos(el), sa = ::sin(az), ca = ::cos(az);
+            const real pb[4] = { 1.0, (real)(-(se * ca)), (real)(-(se * sa)), (real)(-ce) };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 x0[q] = p.plane.x_obs[q];

@@ -112,6 +112,10 @@ struct gr_ctx {
     uint64_t mesh_fp = 0;
     int64_t mesh_n = -1;
     std::vector<double> mesh_host;
+    double* d_corona = nullptr;            // gr_corona_trace: (g, ρ, t, status) per ray, kept for gr_corona_bin
+    size_t corona_bytes = 0;
+    int64_t corona_n = -1, corona_hits = 0;
+    double corona_gmax = 0.0, corona_tmax = 0.0;
     double* d_metric_table = nullptr;      // GR_METRIC_TABULATED: device copy of the caller's table, kept while its build id stays
     size_t metric_table_bytes = 0;
     double metric_table_id = 0.0;
@@ -527,6 +531,9 @@ int32_t stage_pf(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf, 
     out.r_isco = pf->r_isco;
     out.n_plunge = 0;
     out.plunge_r = out.plunge_vt = out.plunge_vr = out.plunge_vphi = nullptr;
+    out.has_u_src = pf->has_u_src ? 1 : 0;
+    out.pad_u = 0;
+    for (int q = 0; q < 4; ++q) out.u_src[q] = pf->has_u_src ? pf->u_src[q] : (q == 0 ? 1.0 : 0.0);
     if (pf->pf_id == GR_PF_REDSHIFT && pf->n_plunge > 0) {
         if (pf->n_plunge < 2 || !pf->plunge_r || !pf->plunge_vt || !pf->plunge_vr || !pf->plunge_vphi)
             return fail(GR_ERR_INVALID_ARGUMENT, "plunging table needs >= 2 rows and four arrays");
@@ -663,6 +670,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_mesh) (void)hipFree(c->d_mesh);
     if (c->d_chart_table) (void)hipFree(c->d_chart_table);
     if (c->d_metric_table) (void)hipFree(c->d_metric_table);
+    if (c->d_corona) (void)hipFree(c->d_corona);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
@@ -1102,6 +1110,28 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
 {
     if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
     if (rays->n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (rays->sky_sampler) {
+        // rays from a source into its sky (gr_rayset.sky_*): nothing per ray crosses but, for a caller's generator, its numbers
+        if (rays->sky_sampler < 1 || rays->sky_sampler > 2 || rays->sky_generator < 0 || rays->sky_generator > 2)
+            return fail(GR_ERR_INVALID_ARGUMENT, "sky source: unknown sampler / generator");
+        if (rays->sky_generator == 2 && rays->n > 0 && !rays->sky_i) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: generator 2 needs sky_i");
+        if (rays->sky_sampler == 2 && !(rays->sky_resolution > 0.0)) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: WeierstrassSampler needs a resolution > 0");
+        if (rays->sep_r || rays->height) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: separable tables / per-ray heights do not apply");
+        std::memset(&p, 0, sizeof p);
+        std::memset(&cd, 0, sizeof cd);
+        p.cfg = *cfg;
+        p.n = rays->n;
+        cd.src_mode = 3;
+        std::memcpy(cd.plane.x_obs, rays->x_obs, sizeof cd.plane.x_obs);
+        std::memcpy(cd.plane.Mx, rays->Mx, sizeof cd.plane.Mx);
+        cd.plane.width = rays->n; cd.plane.height = 1;
+        cd.range = gr_range{ 0, rays->n, rays->n > 0 ? rays->n : 1, 1 };
+        cd.sky_sampler = rays->sky_sampler; cd.sky_both = rays->sky_both ? 1 : 0; cd.sky_generator = rays->sky_generator;
+        cd.sky_resolution = rays->sky_resolution;
+        cd.sky_i = rays->sky_generator == 2 ? rays->sky_i : nullptr;
+        cd.swizzle = 0;
+        return GR_OK;
+    }
     if (rays->sep_r) {
         if (!rays->sep_cos || !rays->sep_sin || rays->sep_nr < 1 || rays->sep_nt < 1)
             return fail(GR_ERR_INVALID_ARGUMENT, "separable ray set: tables missing or empty");
@@ -1791,6 +1821,20 @@ static int32_t stage_rays(gr_ctx* ctx, const gr_rayset* rays, gr_rayset& dev, si
 {
     if (!rays) return fail(GR_ERR_INVALID_ARGUMENT, "rayset is null");
     if (rays->n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "n must be non-negative");
+    if (rays->sky_sampler) {
+        // a source's sky: only a caller's generator has per-ray input (8 B per ray)
+        const size_t n = (rays->sky_generator == 2) ? (size_t)rays->n : 0;
+        if (n && !rays->sky_i) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: generator 2 needs sky_i");
+        int32_t rcs;
+        if ((rcs = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * n + extra_bytes + 64)) != GR_OK) return rcs;
+        double* b = (double*)ctx->d_in;
+        dev = *rays;
+        dev.alpha = dev.beta = dev.area = dev.height = nullptr;
+        dev.sky_i = n ? b : nullptr;
+        if (n) GR_HIP(hipMemcpyAsync(b, rays->sky_i, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        if (extra) *extra = (void*)(b + n);
+        return GR_OK;
+    }
     if (rays->sep_r) {
         // separable set: three small tables instead of 24 B per ray
         if (!rays->sep_cos || !rays->sep_sin || rays->sep_nr < 1 || rays->sep_nt < 1)
@@ -1893,6 +1937,198 @@ int32_t gr_ray_summary(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays,
     return end_host_call(ctx, stats);
 }
 
+// ---- corona -> disc: the reductions of emissivity_profile (src/corona/radial.jl:38-100) on the summaries gr_corona_trace keeps ----
+extern "C++" {
+namespace {
+// Over the rays that hit (finite g): min and max of ρ, max |g| and max |t| -- as ordered bit patterns (non-negative doubles: the
+// order of the bits is the order of the values) -- and their number.  red[0] = min ρ, [1] = max ρ, [2] = count, [3] = max |g|,
+// [4] = max |t|.
+__global__ void __launch_bounds__(256) k_corona_minmax(const double* __restrict__ rows, int64_t n, unsigned long long* red)
+{
+    unsigned long long lo = ~0ull, hi = 0ull, cnt = 0ull, gm = 0ull, tm = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double g = rows[4 * i], rho = rows[4 * i + 1], t = rows[4 * i + 2];
+        if (g == g) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(rho);
+            const unsigned long long bg = (unsigned long long)__double_as_longlong(fabs(g));
+            const unsigned long long bt = (unsigned long long)__double_as_longlong(fabs(t));
+            lo = b < lo ? b : lo;
+            hi = b > hi ? b : hi;
+            gm = bg > gm ? bg : gm;
+            tm = bt > tm ? bt : tm;
+            ++cnt;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64), c2 = __shfl_down(cnt, off, 64);
+        const unsigned long long g2 = __shfl_down(gm, off, 64), t2 = __shfl_down(tm, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        gm = g2 > gm ? g2 : gm;
+        tm = t2 > tm ? t2 : tm;
+        cnt += c2;
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicMin(red, lo);
+        atomicMax(red + 1, hi);
+        atomicAdd(red + 2, cnt);
+        atomicMax(red + 3, gm);
+        atomicMax(red + 4, tm);
+    }
+}
+
+// A double as two integers of a fixed-point grid whose step is a power of two chosen from the largest magnitude and the number
+// of values (CoronaScale): hi = round(v / step), lo = round((v / step - hi) 2^K).  Integer sums do not depend on the order of
+// the additions, so the per-bin sums -- and with them the whole profile -- are the same bits on every run and for every launch
+// shape, which floating-point atomics are not; the grid resolves step 2^-K, below one ulp of any value within 2^10 of the
+// largest, so the sums are also as accurate as a sorted pairwise fp64 sum.
+struct CoronaScale { double inv_step, two_k; };
+__device__ __forceinline__ void corona_split(double v, const CoronaScale& sc, long long& hi, long long& lo)
+{
+    const double s = v * sc.inv_step;             // exact: a power of two
+    hi = __double2ll_rn(s);
+    lo = __double2ll_rn((s - (double)hi) * sc.two_k);
+}
+
+// bucket(Simple(), ρ, ...) per hit: the last edge <= ρ, clamped to the first / last bin (the rule the reference's golden emissivity
+// vector pins, test/unit/emissivity.jl:27-48); per bin the count and the fixed-point sums of g and t.  acc: 5 x nb integers
+// (count, g hi, g lo, t hi, t lo).  LDS = 1: the histograms are private to the workgroup in LDS and leave as one global atomic
+// per non-empty entry; LDS = 0 (more bins than 40 KB of LDS hold): global atomics.
+template <int LDS>
+__global__ void __launch_bounds__(256) k_corona_bin(const double* __restrict__ rows, int64_t n, const double* __restrict__ edges, int nb,
+                                                    CoronaScale sg, CoronaScale st, unsigned long long* acc)
+{
+    extern __shared__ unsigned long long hist[];
+    unsigned long long* h = LDS ? hist : acc;
+    if (LDS) {
+        for (int i = threadIdx.x; i < 5 * nb; i += blockDim.x) hist[i] = 0ull;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double g = rows[4 * i], rho = rows[4 * i + 1], t = rows[4 * i + 2];
+        if (g == g) {
+            int lo = 0, hi = nb;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (edges[mid] <= rho) lo = mid + 1; else hi = mid;
+            }
+            lo = lo > 0 ? lo - 1 : 0;
+            long long gh, gl, th, tl;
+            corona_split(g, sg, gh, gl);
+            corona_split(t, st, th, tl);
+            atomicAdd(h + lo, 1ull);
+            atomicAdd(h + nb + lo, (unsigned long long)gh);
+            atomicAdd(h + 2 * nb + lo, (unsigned long long)gl);
+            atomicAdd(h + 3 * nb + lo, (unsigned long long)th);
+            atomicAdd(h + 4 * nb + lo, (unsigned long long)tl);
+        }
+    }
+    if (LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 5 * nb; i += blockDim.x)
+            if (hist[i] != 0ull) atomicAdd(acc + i, hist[i]);
+    }
+}
+
+// step = 2^(e + en - 62) with vmax < 2^e and n <= 2^en: Σ |hi| < 2^62, every hi below 2^(62 - en) <= 2^52 (exact in a double),
+// K = 62 - en: Σ |lo| < 2^61.
+struct CoronaGrid { CoronaScale sc; double step, lo_unit; };
+CoronaGrid corona_grid(double vmax, int64_t n)
+{
+    int en = 10;
+    while (en < 40 && ((int64_t)1 << en) < n) ++en;
+    int e = 0;
+    if (vmax > 0.0 && std::isfinite(vmax)) (void)std::frexp(vmax, &e);      // vmax = f 2^e, f in [0.5, 1)
+    const int k = 62 - en;
+    CoronaGrid g;
+    g.step = std::ldexp(1.0, e + en - 62);
+    g.sc.inv_step = std::ldexp(1.0, -(e + en - 62));
+    g.sc.two_k = std::ldexp(1.0, k);
+    g.lo_unit = std::ldexp(1.0, -k);
+    return g;
+}
+}  // namespace
+}  // extern "C++"
+
+int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                        double* rho_min_max, int64_t* n_hits, gr_stats* stats)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!rays || !rays->sky_sampler) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_trace traces a sky source (gr_rayset.sky_sampler != 0)");
+    if (!rho_min_max || !n_hits) return fail(GR_ERR_INVALID_ARGUMENT, "rho_min_max / n_hits is null");
+    if (cfg && cfg->disc_id == GR_DISC_NONE) return fail(GR_ERR_INVALID_ARGUMENT, "a corona illuminates accretion geometry: none given");
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    ctx->corona_n = -1;
+    gr_rayset dev;
+    if ((rc = begin_host_call(ctx, stats)) != GR_OK) return rc;
+    if ((rc = stage_rays(ctx, rays, dev, 0, nullptr)) != GR_OK) return rc;
+    const size_t bytes = sizeof(double) * 4 * (size_t)rays->n + 64;
+    if ((rc = ensure((void**)&ctx->d_corona, &ctx->corona_bytes, bytes)) != GR_OK) return rc;
+    unsigned long long* red = (unsigned long long*)(ctx->d_corona + 4 * (size_t)rays->n);
+    const unsigned long long init[5] = { ~0ull, 0ull, 0ull, 0ull, 0ull };
+    GR_HIP(hipMemcpyAsync(red, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = gr_ray_summary_device(ctx, cfg, &dev, pf, ctx->d_corona, stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    if (rays->n > 0) {
+        int64_t blocks = (rays->n + 255) / 256;
+        blocks = blocks > 2048 ? 2048 : blocks;
+        hipLaunchKernelGGL(k_corona_minmax, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_corona, rays->n, red);
+        GR_HIP(hipGetLastError());
+    }
+    unsigned long long h[5];
+    GR_HIP(hipMemcpyAsync(h, red, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = end_host_call(ctx, stats)) != GR_OK) return rc;      // (synchronises the stream)
+    *n_hits = (int64_t)h[2];
+    double v[5];
+    std::memcpy(v, h, sizeof v);
+    rho_min_max[0] = h[2] ? v[0] : NAN;
+    rho_min_max[1] = h[2] ? v[1] : NAN;
+    ctx->corona_gmax = v[3];
+    ctx->corona_tmax = v[4];
+    ctx->corona_hits = (int64_t)h[2];
+    ctx->corona_n = rays->n;
+    return GR_OK;
+}
+
+int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double* out)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (ctx->corona_n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_bin bins the rays of the context's last gr_corona_trace: there is none");
+    if (!edges || !out || n_edges < 1 || n_edges > 65536) return fail(GR_ERR_INVALID_ARGUMENT, "edges / out is null or n_edges not in 1..65536");
+    for (int64_t i = 1; i < n_edges; ++i)
+        if (!(edges[i] >= edges[i - 1])) return fail(GR_ERR_INVALID_ARGUMENT, "bin edges must ascend");
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
+    const size_t nb = (size_t)n_edges;
+    if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 6 * nb + 64)) != GR_OK) return rc;
+    double* d_edges = (double*)ctx->d_in;
+    unsigned long long* d_acc = (unsigned long long*)(d_edges + nb);
+    GR_HIP(hipMemcpyAsync(d_edges, edges, sizeof(double) * nb, hipMemcpyHostToDevice, ctx->stream));
+    GR_HIP(hipMemsetAsync(d_acc, 0, sizeof(unsigned long long) * 5 * nb, ctx->stream));
+    const CoronaGrid gg = corona_grid(ctx->corona_gmax, ctx->corona_hits), gt = corona_grid(ctx->corona_tmax, ctx->corona_hits);
+    if (ctx->corona_n > 0) {
+        int64_t blocks = (ctx->corona_n + 255) / 256;
+        blocks = blocks > 1024 ? 1024 : blocks;
+        if (nb <= 1024) {
+            hipLaunchKernelGGL(k_corona_bin<1>, dim3((unsigned)blocks), dim3(256), sizeof(unsigned long long) * 5 * nb, ctx->stream,
+                               ctx->d_corona, ctx->corona_n, d_edges, (int)nb, gg.sc, gt.sc, d_acc);
+        } else {
+            hipLaunchKernelGGL(k_corona_bin<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_corona, ctx->corona_n,
+                               d_edges, (int)nb, gg.sc, gt.sc, d_acc);
+        }
+        GR_HIP(hipGetLastError());
+    }
+    std::vector<long long> acc(5 * nb);
+    GR_HIP(hipMemcpyAsync(acc.data(), d_acc, sizeof(long long) * 5 * nb, hipMemcpyDeviceToHost, ctx->stream));
+    GR_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < nb; ++i) {
+        out[i] = (double)acc[i];
+        out[nb + i] = (double)(((long double)acc[nb + i] + (long double)acc[2 * nb + i] * (long double)gg.lo_unit) * (long double)gg.step);
+        out[2 * nb + i] = (double)(((long double)acc[3 * nb + i] + (long double)acc[4 * nb + i] * (long double)gt.lo_unit) * (long double)gt.step);
+    }
+    return GR_OK;
+}
+
 int32_t gr_ray_tangent(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
                        double* out, gr_stats* stats)
 {
@@ -1986,6 +2222,8 @@ int32_t rayset_share(const gr_rayset* rays, int32_t n, int k, gr_rayset& out, in
     if (rays->sep_r && (rays->sep_block != 0 || rays->sep_tiled))
         return fail(GR_ERR_INVALID_ARGUMENT, "*_multi: a separable ray set with one output row per ray must come whole and in ray order "
                                              "(sep_block = 0, sep_tiled = 0)");
+    if (rays->sky_sampler)
+        return fail(GR_ERR_INVALID_ARGUMENT, "*_multi: a sky source is traced by one context (its sample numbers count from ray 0)");
     int64_t off, cnt;
     contiguous_share(rays->n, n, k, &off, &cnt);
     out = *rays;

@@ -235,6 +235,13 @@ typedef struct gr_pointfunction {
     const double* plunge_vt;
     const double* plunge_vr;
     const double* plunge_vphi;
+    /* ABI 7: the four-velocity the photon's energy is measured against at its START, for GR_PF_REDSHIFT:
+     * has_u_src = 0 [every image-plane caller]: the static observer (1, 0, 0, 0) of _redshift_dotproduct (redshift.jl:192-220);
+     * has_u_src = 1: u_src -- energy_ratio(m, gp, v_src, v_disc) = (g v_init u_src) / (g v v_disc) of
+     * src/corona/flux-calculations.jl:96-110, the redshift between a moving coronal source and the disc.                    */
+    int32_t has_u_src;
+    int32_t _pad_u;
+    double u_src[4];
 } gr_pointfunction;
 
 /* aggregate counters of one call (device-side reductions) */
@@ -434,6 +441,23 @@ typedef struct gr_rayset {
      *     k = sep_first + j                                                     (sep_block = 0: a contiguous range)
      * and every k must be below sep_nr * sep_nt.  All zero and n = sep_nr * sep_nt: the whole plane. */
     int64_t sep_first, sep_block, sep_stride;
+    /* Rays FROM A SOURCE INTO ITS SKY (ABI 7): tracegeodesics(m, model::AbstractCoronaModel, ...) / tracecorona
+     * (src/corona/corona-models.jl:1-33,143-190) for a source at ONE position (lamp post, beamed point source, a ring's
+     * representative point).  sky_sampler != 0 selects it: x_obs is the source position, Mx = T · diag(1, J) with T =
+     * tetradframe(g, v_source) and J the Cartesian -> spherical Jacobian at the source (samplers.jl:81-99: v = T (E0, E0 J k̂));
+     * ray j (sample number j + 1, 1-based as in samplers.jl:30-44) leaves in the direction k̂ = -(sinθ cosϕ, sinθ sinϕ, cosθ) with
+     *   i     = j + 1 (sky_generator 0: GoldenSpiralGenerator) | (j + 1) / n (1: EvenGenerator) | sky_i[j] (2: the caller's
+     *           numbers, e.g. RandomGenerator's rand() * n)
+     *   θ     = EvenSampler (sky_sampler 1): acos(1 - i / n) lower hemisphere, acos(1 - 2 i / n) both;
+     *           WeierstrassSampler (2): 2 atan(sqrt(sky_resolution / i)), mirrored to π - θ for odd i on both hemispheres
+     *   ϕ     = mod(π (1 + √5) i, 2π) for the golden spiral, mod(2π i, 2π) otherwise.
+     * alpha / beta / area / height / sep_* are not read. */
+    int32_t sky_sampler;      /* 0 = off, 1 = EvenSampler, 2 = WeierstrassSampler */
+    int32_t sky_both;         /* 0 = LowerHemisphere, 1 = BothHemispheres */
+    int32_t sky_generator;    /* 0 = golden spiral, 1 = even, 2 = sky_i */
+    int32_t sky_reserved;
+    double sky_resolution;
+    const double* sky_i;      /* n values for sky_generator 2 (host / device pointer like alpha), else NULL */
 } gr_rayset;
 
 typedef struct gr_binning {
@@ -507,6 +531,20 @@ int32_t gr_apply_pointfunction_device(gr_ctx* ctx, const gr_config* cfg, const g
                                       double* d_out, void* hip_stream);
 int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_pointfunction* pf,
                                const gr_point* points, int64_t n, double max_time, double* out);
+
+/* ---- corona -> disc on the device (ABI 7): emissivity_profile(m, d, model; n_samples, sampler) (src/corona/emissivity.jl:118-168,
+ * src/corona/radial.jl:38-100) for a source at one position.  Two calls on ONE context, nothing else on that context in between:
+ *   gr_corona_trace  traces the rays of a sky source (gr_rayset.sky_*) against the disc and keeps (g, ρ, t, status) per ray ON THE
+ *                    DEVICE -- g = energy_ratio against pf->u_src and the disc's Keplerian / plunging velocity, ρ = r |sinθ| and
+ *                    t = coordinate time of the hit -- and returns min / max ρ over the rays that hit and their number (what
+ *                    the radial grid of radial.jl:60-66 is built from);
+ *   gr_corona_bin    bins those rays by ρ into the caller's edges (bucket(Simple()): last edge <= ρ, clamped) and returns, per
+ *                    bin, the count, Σ g and Σ t (radial.jl:70-84 takes the means).  out: 3 x n_edges doubles, n_edges <= 65536.
+ *                    The sums are accumulated as integers on a fixed-point grid finer than an ulp of the values, so they do
+ *                    not depend on the order of the additions: the same rays give the same bits on every run.             */
+int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                        double* rho_min_max /* 2 */, int64_t* n_hits, gr_stats* stats);
+int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double* out /* 3 x n_edges */);
 
 /* ---- tabulated metrics (ABI 7, GR_METRIC_TABULATED): the AbstractMetric plugin interface on the device ----
  * Host-only functions (no context, no device): plan a grid, learn its nodes, fit, check.

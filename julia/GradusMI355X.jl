@@ -34,7 +34,8 @@ using Gradus: TracingConfiguration, EnsembleProblem, GeodesicPoint, StatusCodes,
 using StaticArrays
 import SciMLBase
 
-export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, winding_numbers, metric_table, selftest
+export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, emissivity_profile_mi355x, winding_numbers, metric_table,
+    selftest
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
 const ABI_VERSION = 7
@@ -139,6 +140,9 @@ struct GrPointFunction               # == gr_pointfunction
     plunge_vt::Ptr{Float64}
     plunge_vr::Ptr{Float64}
     plunge_vphi::Ptr{Float64}
+    has_u_src::Int32                 # 1 = the photon's starting energy is measured against u_src (energy_ratio, flux-calculations.jl:96-110)
+    _pad_u::Int32
+    u_src::NTuple{4,Float64}
 end
 
 struct GrRange                       # == gr_range
@@ -166,6 +170,12 @@ struct GrRayset                      # == gr_rayset
     sep_first::Int64
     sep_block::Int64
     sep_stride::Int64
+    sky_sampler::Int32               # rays from a source into its sky: 0 = off, 1 = EvenSampler, 2 = WeierstrassSampler
+    sky_both::Int32                  # 0 = LowerHemisphere, 1 = BothHemispheres
+    sky_generator::Int32             # 0 = GoldenSpiralGenerator, 1 = EvenGenerator, 2 = sky_i (RandomGenerator's numbers)
+    sky_reserved::Int32
+    sky_resolution::Float64
+    sky_i::Ptr{Float64}
 end
 
 struct GrBinning                     # == gr_binning
@@ -579,6 +589,7 @@ Recognises `affine_time`, `redshift(m, x)` (Kerr: analytic; other metrics: `inte
 composed with `filter_early_term` / `filter_intersected` through `∘` (point-functions.jl:107-120: the composite is a
 `PointFunction` over a closure with fields `f1`, `f2`, `pf2`).  `shadow()` is `affine_time() ∘ filter_early_term()`.
 """
+const _U_STATIC = (1.0, 0.0, 0.0, 0.0)      # has_u_src = 0: every image-plane caller measures against the static observer
 function _builtin_pf(pf, m)
     pf isa PointFunction || return nothing
     f = pf.f
@@ -592,10 +603,10 @@ function _builtin_pf(pf, m)
     isnothing(b) && return nothing
     pf_id, r_isco, tab = b
     if isnothing(tab)
-        return (GrPointFunction(pf_id, filter_id, fill, r_isco, 0, C_NULL, C_NULL, C_NULL, C_NULL), nothing)
+        return (GrPointFunction(pf_id, filter_id, fill, r_isco, 0, C_NULL, C_NULL, C_NULL, C_NULL, Int32(0), Int32(0), _U_STATIC), nothing)
     end
     (GrPointFunction(pf_id, filter_id, fill, r_isco, length(tab[1]), pointer(tab[1]), pointer(tab[2]), pointer(tab[3]),
-        pointer(tab[4])), tab)
+        pointer(tab[4]), Int32(0), Int32(0), _U_STATIC), tab)
 end
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -734,7 +745,7 @@ function Gradus.ensemble_solve_tracing_problem(
         Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
         rays = Ref(GrRayset(Tuple(SVector{4,Float64}(config.position)), Tuple(permutedims(Mx)), pointer(αv), pointer(βv),
             Ptr{Float64}(C_NULL), N, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0,
-            Int32(0), Int32(0), 0, 0, 0))
+            Int32(0), Int32(0), 0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL)))
         if nctx > 1
             _check(GC.@preserve keep αv βv out ccall((:gr_rayset_endpoints_multi, LIB), Int32,
                 (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ptr{Cvoid}, Ptr{GrStats}),
@@ -885,7 +896,7 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     cs, sn = cos.(θs), sin.(θs)
     rays = Ref(GrRayset(Tuple(u), Tuple(permutedims(Mx)), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
         plane.Nr * plane.Nθ, Ptr{Float64}(C_NULL), pointer(rs), pointer(cs), pointer(sn), plane.Nr, plane.Nθ, Int32(1), Int32(0),
-        0, 0, 0))
+        0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL)))
     bpf = _builtin_pf(redshift_pf, m)
     isnothing(bpf) && error("lineprofile_mi355x: `redshift_pf` is not a redshift point function the kernels evaluate")
     gpf, keep_pf = bpf
@@ -912,6 +923,82 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
         (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ref{GrBinning}, Ptr{Float64}, Ref{GrStats}),
         ensemble.ctxs[1], cfg, rays, pfs, binning, flux, stats))
     bins, flux ./ sum(flux)                                                            # line-profiles.jl:197
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# emissivity_profile(m, d, model, spectrum; n_samples, sampler, N, grid) (src/corona/emissivity.jl:118-168) for a source at
+# one position, with the per-ray half on the device: the sky directions of samplers.jl:30-99 are formed per lane from the
+# sample number (the tetrad and the Cartesian -> spherical Jacobian cross as one 4 x 4 matrix), the rays are traced against
+# the disc, energy_ratio (flux-calculations.jl:96-110) is taken against the source's and the disc's four-velocity, and
+# bucket!(IndexBucket, Simple(), radii, bins) with the per-bin means of radial.jl:60-84 is a histogram in LDS.  Back come
+# (min ρ, max ρ, hits) and 3 N doubles; radial.jl:86-100 (N evaluations) runs here.  A maintainer wiring this in adds one
+# branch to emissivity_profile(setup, m, d, model): `ensemble isa EnsembleMI355X && return emissivity_profile_mi355x(...)`.
+# ---------------------------------------------------------------------------------------------------------------
+_sky_sampler(s::Gradus.EvenSampler) = (Int32(1), 0.0)
+_sky_sampler(s::Gradus.WeierstrassSampler) = (Int32(2), Float64(s.resolution))
+_sky_domain(::Gradus.AbstractDirectionSampler{Gradus.LowerHemisphere}) = Int32(0)
+_sky_domain(::Gradus.AbstractDirectionSampler{Gradus.BothHemispheres}) = Int32(1)
+_sky_generator(::Gradus.AbstractDirectionSampler{D,Gradus.GoldenSpiralGenerator}, N) where {D} = (Int32(0), Float64[])
+_sky_generator(::Gradus.AbstractDirectionSampler{D,Gradus.EvenGenerator}, N) where {D} = (Int32(1), Float64[])
+_sky_generator(s::Gradus.AbstractDirectionSampler, N) = (Int32(2), Float64[Gradus.geti(s, i, N) for i = 1:N])   # RandomGenerator: rand() N
+
+function emissivity_profile_mi355x(ensemble::EnsembleMI355X, m::Gradus.AbstractStaticAxisSymmetric, d, model,
+        spectrum = Gradus.PowerLawSpectrum(2); n_samples = 1000,
+        sampler = Gradus.EvenSampler(Gradus.BothHemispheres(), Gradus.GoldenSpiralGenerator()), λmax = 10_000.0,
+        grid = Gradus.GeometricGrid(), N = 100, gtol = 1e-2, abstol = 1e-9, reltol = 1e-9, chart = Gradus.chart_for_metric(m),
+        upper_hemisphere = true)
+    x, v_src = Gradus.sample_position_velocity(m, model)            # one position: LampPostModel, BeamedPointSource, a RingCorona's point
+    x[2] < Gradus.inner_radius(m) * 1.9 && error("source position lies inside 1.9 inner radii")
+    x = SVector{4,Float64}(x[1], x[2], clamp(x[3], 1e-3, π - 1e-3), x[4])                  # corona-models.jl:18-24
+    J = Gradus._cart_to_spher_jacobian(x[3], x[4])
+    B = zeros(Float64, 4, 4)
+    B[1, 1] = 1.0
+    B[2:4, 2:4] .= J
+    Mx = Matrix{Float64}(Gradus.tetradframe_matrix(m, x, v_src)) * B                        # v = T (1, J k̂), samplers.jl:81-99
+    sid, res = _sky_sampler(sampler)
+    gid, sky_i = _sky_generator(sampler, n_samples)
+    rays = Ref(GrRayset(Tuple(x), Tuple(permutedims(Mx)), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
+        n_samples, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0, Int32(0), Int32(0),
+        0, 0, 0, sid, _sky_domain(sampler), gid, Int32(0), res, isempty(sky_i) ? Ptr{Float64}(C_NULL) : pointer(sky_i)))
+    # the disc velocity of _keplerian_velocity_projector (circular-orbits.jl:155-170): Keplerian outside the ISCO, the traced
+    # plunging table inside (three NaNLinearInterpolators over the same radii, orbit-solving.jl:99-131)
+    pintrp = _expect_fields(Gradus.interpolate_plunging_velocities(m), :m, :t, :r, :ϕ)
+    ptab = (collect(Float64, pintrp.t.t), collect(Float64, pintrp.t.u), collect(Float64, pintrp.r.u), collect(Float64, pintrp.ϕ.u))
+    pfs = Ref(GrPointFunction(Int32(1), Int32(0), NaN, Float64(Gradus.isco(m)), length(ptab[1]), pointer(ptab[1]), pointer(ptab[2]),
+        pointer(ptab[3]), pointer(ptab[4]), Int32(1), Int32(0), Tuple(SVector{4,Float64}(v_src))))
+    id, params = _metric(m)
+    did, rin, rout, dparams = _disc(d)
+    r_in, r_out, tab, θ0, θ1 = _chart(chart)
+    dtab = _disc_table(d)
+    mtab = _metric_table(m, r_in, r_out)
+    cfg = Ref(GrConfig(id, did, params, r_in, r_out, rin, rout, gtol, 0.0, Float64(λmax),
+        abstol, reltol, 0.0, 1_000_000, Int32(upper_hemisphere), Int32(0), 1e-4, dparams,
+        isempty(dtab) ? Ptr{Float64}(C_NULL) : pointer(dtab), _disc_table_n(d, dtab),
+        isempty(tab) ? Ptr{Float64}(C_NULL) : pointer(tab), length(tab), θ0, θ1, 0.0, Int32(0), Int32(0), π / 2,
+        _components(d)[1], Int32(0), _components(d)[2],
+        isempty(mtab) ? Ptr{Float64}(C_NULL) : pointer(mtab), length(mtab)))
+    lim = zeros(Float64, 2)
+    hits = Ref{Int64}(0)
+    stats = Ref{GrStats}()
+    ctx = ensemble.ctxs[1]                                           # a corona is one device's work (10⁶ samples: a few ms)
+    _check(GC.@preserve tab dtab mtab ptab sky_i ccall((:gr_corona_trace, LIB), Int32,
+        (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ptr{Float64}, Ref{Int64}, Ref{GrStats}),
+        ctx, cfg, rays, pfs, lim, hits, stats))
+    hits[] > 0 || error("no ray of the corona reached the disc")
+    bins = collect(Float64, grid(lim[1], lim[2], N))                                       # radial.jl:60
+    sums = zeros(Float64, length(bins), 3)                                                 # columns: count, Σ g, Σ t
+    _check(ccall((:gr_corona_bin, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}), ctx, bins, length(bins), sums))
+    count, gs, ts = sums[:, 1], sums[:, 2] ./ sums[:, 1], sums[:, 3] ./ sums[:, 1]         # the means of radial.jl:70-84,97
+    g_interp = Gradus._make_interpolation(bins, gs)
+    disc_velocity = Gradus._keplerian_velocity_projector(m)
+    ε = similar(bins)
+    for i in eachindex(bins)                                                               # radial.jl:86-95
+        R = bins[i]
+        dr = R - (i == 1 ? 0.0 : bins[i-1])
+        xb = SVector(0.0, R, π / 2, 0.0)
+        ε[i] = Gradus.source_to_disc_emissivity(m, spectrum, count[i], dr * Gradus._proper_area(m, xb), xb, g_interp(R), disc_velocity(xb))
+    end
+    Gradus.RadialDiscProfile(bins, ts, ε)
 end
 
 # ---------------------------------------------------------------------------------------------------------------

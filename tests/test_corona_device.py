@@ -1,0 +1,214 @@
+"""Corona -> disc on the device (gr_rayset.sky_*, gr_corona_trace, gr_corona_bin) against the record route:
+`tracegeodesics(m, xs, vs, d, λ)` on host-built (x, v) arrays + numpy's reductions (corona.build_radial_profile), which is
+itself pinned to the oracle and to the reference's golden vectors in test_corona_host.py / test_gpu_parity.py.
+
+Reference: src/corona/{samplers,corona-models,emissivity,radial,flux-calculations}.jl.
+"""
+import ctypes as C
+import math
+import time
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def G(built):
+    import gradus_jl_amd as G
+
+    return G
+
+
+@pytest.fixture(scope="module")
+def ens(G):
+    return G.EnsembleMI355X(device=0)
+
+
+def _models(G):
+    kerr = G.KerrMetric(1.0, 0.998)
+    return [
+        ("lamp-post / Kerr", kerr, G.LampPostModel(h=10.0), G.ThinDisc(0.0, 500.0)),
+        ("beamed point source / Johannsen", G.JohannsenMetric(M=1.0, a=0.6, alpha13=0.5, eps3=0.3), G.BeamedPointSource(8.0, 0.3),
+         G.ThinDisc(0.0, 400.0)),
+        ("co-rotating ring / Kerr", G.KerrMetric(1.0, 0.9), G.RingCorona(G.SourceVelocities.co_rotating, 8.0, 3.0),
+         G.ThinDisc(0.0, 200.0)),
+    ]
+
+
+def _samplers(G):
+    out = []
+    for Sampler in (G.EvenSampler, G.WeierstrassSampler):
+        for gen in (G.GoldenSpiralGenerator, G.EvenGenerator, lambda: G.RandomGenerator(seed=11)):
+            for dom in (G.LowerHemisphere, G.BothHemispheres):
+                out.append(lambda Sampler=Sampler, gen=gen, dom=dom: Sampler(domain=dom(), generator=gen()))
+    return out
+
+
+# ---------------- not gpu: the host half ----------------
+def test_sky_rayset_matrix_reproduces_sky_angles_to_velocity(G):
+    """v = Mx (1, k̂) with Mx = T diag(1, J) is samplers.jl:81-99 for every source in the list."""
+    K = G.corona
+    for _, m, model, _d in _models(G):
+        s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+        rs, keep, x, v = K.sky_rayset(m, model, s, 64)
+        Mx = np.array(list(rs.Mx)).reshape(4, 4)
+        xs, vs, vsrc = K.sample_position_direction_velocity(m, model, s, 64)
+        i = K.geti(s, np.arange(1, 65), 64)
+        θ, ϕ = K.sample_angles(s, i, 64)
+        khat = -np.stack([np.sin(θ) * np.cos(ϕ), np.sin(θ) * np.sin(ϕ), np.cos(θ)], axis=-1)
+        got = np.concatenate([np.ones((64, 1)), khat], axis=1) @ Mx.T
+        np.testing.assert_allclose(got, vs, rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(np.array(list(rs.x_obs)), xs[0])
+        np.testing.assert_array_equal(v, vsrc[0])
+        assert (rs.sky_sampler, rs.sky_both, rs.sky_generator, rs.n) == (1, 1, 0, 64) and keep is None
+
+
+def test_sky_rayset_needs_a_source_at_one_position(G):
+    class Cloud(G.corona.AbstractCoronaModel):
+        def sample_position_velocity(self, m):
+            return np.array([0.0, 10.0, 0.3, 0.0]), np.array([1.0, 0.0, 0.0, 0.0])
+
+    with pytest.raises(NotImplementedError):
+        G.corona.sky_rayset(G.KerrMetric(1.0, 0.5), Cloud(), G.EvenSampler(), 8)
+    with pytest.raises(ValueError):
+        G.corona.sky_rayset(G.KerrMetric(1.0, 0.0), G.LampPostModel(h=2.5), G.EvenSampler(), 8)
+
+
+# ---------------- gpu ----------------
+@pytest.mark.gpu
+def test_sky_rays_start_as_the_host_sampler_says(G, ens):
+    """Every sampler x generator x domain: the device's (x_init, v_init) and where the rays end against the same rays
+    formed by numpy and handed over as arrays."""
+    K = G.corona
+    ens.set("kernel", 2).set("precision", 64)
+    for name, m, model, d in _models(G):
+        for mk in _samplers(G):
+            s_dev, s_host = mk(), mk()                      # two generators with the same seed
+            n = 512
+            got = K.tracegeodesics(m, model, d, (0.0, 2000.0), n_samples=n, sampler=s_dev, ensemble=ens)
+            xs, vs, _ = K.sample_position_direction_velocity(m, model, s_host, n)
+            ref = G.tracegeodesics(m, xs, vs, d, (0.0, 2000.0), ensemble=ens)
+            np.testing.assert_array_equal(got["x_init"], ref["x_init"])
+            np.testing.assert_allclose(got["v_init"], ref["v_init"], rtol=1e-14, atol=2e-14, err_msg=name)
+            same = got["status"] == ref["status"]
+            assert same.sum() >= n - 1, name
+            hit = same & (ref["status"] == G.StatusCodes.IntersectedWithGeometry)
+            np.testing.assert_allclose(got["x"][hit], ref["x"][hit], rtol=1e-9, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(got["v"][hit], ref["v"][hit], rtol=1e-8, atol=1e-9, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_device_radial_profile_equals_the_record_route(G, ens, monkeypatch):
+    """emissivity_profile with the per-ray half on the device against tracecorona + build_radial_profile on the same samples."""
+    K = G.corona
+    ens.set("kernel", 2).set("precision", 64)
+    for name, m, model, d in _models(G):
+        for mk in (lambda: G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator()),
+                   lambda: G.WeierstrassSampler(200.0, G.LowerHemisphere(), G.RandomGenerator(seed=5))):
+            kw = dict(n_samples=30_000, N=40, ensemble=ens)
+            monkeypatch.setenv("GRADUS_MI355X_DEVICE_CORONA", "1")
+            dev = G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+            monkeypatch.setenv("GRADUS_MI355X_DEVICE_CORONA", "0")
+            host = G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+            np.testing.assert_allclose(dev.radii, host.radii, rtol=1e-10, err_msg=name)
+            # The last edge of grid(extrema(radii)..., N) is the largest radius itself up to rounding, so whether that one ray
+            # counts for the last bin or the one before is decided by the last bit of ρ_max in the reference too: the two
+            # outermost bins are compared together, the others one by one.
+            inner = slice(0, -2)
+            ok = np.isfinite(host.ε[inner])
+            np.testing.assert_array_equal(np.isfinite(dev.ε[inner]), ok, err_msg=name)
+            assert ok.sum() >= 20, name
+            np.testing.assert_allclose(dev.ε[inner][ok], host.ε[inner][ok], rtol=1e-7, err_msg=name)
+            okt = np.isfinite(host.t[inner])
+            np.testing.assert_array_equal(np.isfinite(dev.t[inner]), okt, err_msg=name)
+            np.testing.assert_allclose(dev.t[inner][okt], host.t[inner][okt], rtol=1e-9, err_msg=name)
+            assert np.isfinite(dev.ε[-2:]).any() and np.isfinite(host.ε[-2:]).any()
+
+
+@pytest.mark.gpu
+def test_corona_bins_are_the_bucket_rule_and_sum_to_the_hits(G, ens):
+    """gr_corona_trace / gr_corona_bin through the C ABI: counts add up to the hits, re-binning the same trace with other
+    edges needs no new trace, edge cases of bucket(Simple()) (below the first edge / above the last)."""
+    from gradus_jl_amd import _lib
+    from gradus_jl_amd.rendering import abi_pointfunction
+    from gradus_jl_amd.pointfunctions import GR_PF_REDSHIFT, PointFunction
+    from gradus_jl_amd.tracing import tracing_configuration
+
+    K = G.corona
+    m = G.KerrMetric(1.0, 0.998)
+    model, d = G.LampPostModel(h=6.0), G.ThinDisc(0.0, 300.0)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    n = 20_000
+    rs, keep, x, v = K.sky_rayset(m, model, s, n)
+    config = tracing_configuration(m, x, np.zeros((1, 4)), d, (0.0, 5000.0), callback=G.domain_upper_hemisphere(), ensemble=ens)
+    cfg = config.abi_config()
+    L = _lib.load()
+    # a context that has not traced a corona has nothing to bin
+    fresh = G.EnsembleMI355X(device=0)
+    edges = np.linspace(1.0, 300.0, 16)
+    out = np.zeros((3, edges.size))
+    assert L.gr_corona_bin(fresh.ctx.handle, edges.ctypes.data, edges.size, out.ctypes.data) != 0
+    assert "gr_corona_trace" in _lib.load().gr_last_error().decode()
+    pf, kp = abi_pointfunction(PointFunction(None, device_pf=GR_PF_REDSHIFT, extra={"r_isco": m.isco(), "plunge": None}))
+    pf.has_u_src = 1
+    for q in range(4):
+        pf.u_src[q] = v[q]
+    lim, hits, st = np.zeros(2), C.c_int64(0), _lib.gr_stats()
+    _lib.check(L.gr_corona_trace(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits), C.byref(st)))
+    assert 0.3 * n < hits.value < 0.7 * n and 1.0 < lim[0] < 1.5 and 250.0 < lim[1] <= 300.0
+    # the same rays as records
+    gps = K.tracegeodesics(m, model, d, (0.0, 5000.0), n_samples=n, sampler=s, ensemble=ens, callback=G.domain_upper_hemisphere())
+    hit = gps["status"] == G.StatusCodes.IntersectedWithGeometry
+    rho = gps["x"][hit, 1] * np.abs(np.sin(gps["x"][hit, 2]))
+    assert hits.value == hit.sum()
+    assert lim[0] == rho.min() and lim[1] == rho.max()
+    for edges in (np.linspace(lim[0], lim[1], 32), np.array([5.0, 10.0, 20.0]), np.array([2.0])):
+        edges = np.ascontiguousarray(edges)
+        out = np.zeros((3, edges.size))
+        _lib.check(L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, out.ctypes.data))
+        idx = K._bucket_index(rho, edges)
+        np.testing.assert_array_equal(out[0], np.bincount(idx, minlength=edges.size))
+        np.testing.assert_allclose(out[2], np.bincount(idx, weights=gps["x"][hit, 0], minlength=edges.size), rtol=1e-12)
+        assert out[0].sum() == hits.value and np.all(out[1][out[0] > 0] > 0)
+        again = np.zeros_like(out)
+        _lib.check(L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, again.ctypes.data))
+        np.testing.assert_array_equal(again, out)                     # integer accumulation: the same bits every time
+    # more bins than the LDS histogram holds: global atomics, the same sums
+    edges = np.ascontiguousarray(np.geomspace(lim[0], lim[1], 3000))
+    out = np.zeros((3, edges.size))
+    _lib.check(L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, out.ctypes.data))
+    idx = K._bucket_index(rho, edges)
+    np.testing.assert_array_equal(out[0], np.bincount(idx, minlength=edges.size))
+    np.testing.assert_allclose(out[2], np.bincount(idx, weights=gps["x"][hit, 0], minlength=edges.size), rtol=1e-13)
+    # descending edges are refused
+    bad = np.array([3.0, 2.0])
+    assert L.gr_corona_bin(ens.ctx.handle, bad.ctypes.data, 2, out.ctypes.data) != 0
+    # a sky source is one context's work
+    arr, sts = _lib.ctx_array([ens.ctx, fresh.ctx])
+    rows = np.zeros((n, 4))
+    assert L.gr_ray_summary_multi(arr, 2, C.byref(cfg), C.byref(rs), C.byref(pf), rows.ctypes.data, sts) != 0
+    assert "sky source" in _lib.load().gr_last_error().decode()
+
+
+@pytest.mark.gpu
+def test_a_million_samples_stay_on_the_device(G, ens):
+    """the per-ray half of emissivity_profile at 10⁶ samples.  Timing is reported, the
+    assertion is loose: the device work of the call is tens of milliseconds, not the seconds of the record route."""
+    K = G.corona
+    ens.set("kernel", 2).set("precision", 64)
+    m = G.KerrMetric(1.0, 0.998)
+    model, d = G.LampPostModel(h=10.0), G.ThinDisc(0.0, 500.0)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    K.device_radial_profile(m, d, model, sampler=s, n_samples=10_000, N=100, ensemble=ens)        # warm: plunging table, contexts
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        prof, st = K.device_radial_profile(m, d, model, sampler=s, n_samples=1_000_000, N=100, ensemble=ens, stats=True)
+        wall = (time.perf_counter() - t0) * 1e3
+        best = (st.kernel_ms, st.call_ms, wall) if best is None or st.call_ms < best[1] else best
+    print(f"corona 1e6 samples: trace kernel {best[0]:.2f} ms, device call {best[1]:.2f} ms, wall {best[2]:.1f} ms")
+    assert np.isfinite(prof.ε).sum() >= 90 and best[1] < 100.0
+    # and it is the profile a 50x smaller run gives, to Monte-Carlo noise (ε counts photons: it scales with n_samples, as in the reference)
+    small = K.device_radial_profile(m, d, model, sampler=s, n_samples=20_000, N=100, ensemble=ens)
+    r = np.geomspace(2.0, 200.0, 12)
+    np.testing.assert_allclose(small.emissivity_at(r) * 50.0, prof.emissivity_at(r), rtol=0.25)

@@ -197,7 +197,7 @@ def test_every_ccall_matches_its_c_prototype():
     seen = {c[0] for c in calls}
     # the boundary the binding uses
     assert {"gr_abi_version", "gr_last_error", "gr_ctx_create", "gr_ctx_destroy", "gr_trace_endpoints", "gr_render_endpoints",
-            "gr_render_multi", "gr_lineprofile"} <= seen
+            "gr_render_multi", "gr_lineprofile", "gr_corona_trace", "gr_corona_bin"} <= seen
     for sym, ret, types, nvals in calls:
         assert sym in protos, sym
         want = protos[sym]
@@ -219,6 +219,8 @@ def test_every_ccall_matches_its_c_prototype():
                 assert t == "Ref{Ptr{Cvoid}}", (sym, t, w)            # gr_host_alloc's out parameter
             elif w == "voidp":
                 assert t == "Ptr{Cvoid}", (sym, t, w)
+            elif w == "i64p":
+                assert t == "Ref{Int64}", (sym, t, w)                 # gr_corona_trace's hit count
             else:
                 assert t == {"f64p": "Ptr{Float64}", "i64": "Int64", "i32": "Int32", "f64": "Float64"}[w], (sym, t, w)
 
