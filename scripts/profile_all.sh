@@ -9,12 +9,17 @@ bash scripts/profile_pmc.sh ${T}_c2 --size 1024
 PROF_CMD="scripts/sibling_workloads.py tabkerr" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabkerr
 PROF_CMD="scripts/sibling_workloads.py tabc4" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabc4
 PROF_CMD="scripts/sibling_workloads.py c4" PROF_KERNEL="k_trace_lane<gr::JohannsenMetric" bash scripts/profile_pmc.sh ${T}_c4
+# the same three at 2048² (launches deep enough that their tails do not decide): the tabulated / fused ratios of DESIGN §5c
+SIB_SIZE=2048 PROF_CMD="scripts/sibling_workloads.py tabkerr 6" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabkerr2048
+SIB_SIZE=2048 PROF_CMD="scripts/sibling_workloads.py tabc4 6" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabc42048
+SIB_SIZE=2048 PROF_CMD="scripts/sibling_workloads.py c4 6" PROF_KERNEL="k_trace_lane<gr::JohannsenMetric" bash scripts/profile_pmc.sh ${T}_c42048
 PROF_CMD="scripts/sibling_workloads.py generic" PROF_KERNEL="k_trace_lane<gr::GenericMetric" bash scripts/profile_pmc.sh ${T}_generic
 PROF_CMD="scripts/sibling_workloads.py c5" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_c5
 PROF_CMD="scripts/sibling_workloads.py c5p" PROF_KERNEL="k_trace_persistent<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_c5p
 PROF_F32=1 PROF_CMD="scripts/sibling_workloads.py c5f32" PROF_KERNEL="gr32::" bash scripts/profile_pmc.sh ${T}_c5f32
 PROF_CMD="scripts/sibling_workloads.py applypf" PROF_KERNEL="k_apply_pf" bash scripts/profile_pmc.sh ${T}_applypf
 PROF_CMD="scripts/sibling_workloads.py endpoints" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_endpoints
+PROF_CMD="scripts/sibling_workloads.py corona" PROF_KERNEL="k_trace" bash scripts/profile_pmc.sh ${T}_corona
 PROF_CMD="scripts/sibling_workloads.py tangent" PROF_KERNEL="k_trace_lane<grt::" bash scripts/profile_pmc.sh ${T}_tangent
 PROF_CMD="scripts/sibling_workloads.py dual" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<3>" bash scripts/profile_pmc.sh ${T}_bumblebee
 PROF_CMD="scripts/sibling_workloads.py dual2" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<2>" bash scripts/profile_pmc.sh ${T}_morristhorne

@@ -15,6 +15,7 @@ PROF_CMD="scripts/sibling_workloads.py <which>" PROF_KERNEL=<substring of the ke
     c5f32     config 5 with the fp32 kernels at tol 1e-5                                              gr32::k_trace_*
     applypf   apply(pf, cache) on the 2048² end points of the bench plane                             k_apply_pf
     endpoints gr_render_endpoints_device, 2048² Kerr (152-B records)                                  k_trace_lane<KerrFamily<false>,1>
+    corona    gr_corona_trace + gr_corona_bin: lamp post h = 10 over ThinDisc(0, 500), 10⁶ sky samples          k_trace_*<KerrFamily<false>,1> + k_corona_*
     tangent   gr_ray_tangent_device, 1024² Kerr rays against the datum plane (value + ∂/∂α + ∂/∂β)     grt::k_trace_lane<KerrFamily<false>,1>
 
 Prints one JSON line {"rays": rays per launch, "launches": n, ...} (bench.log of the profile run); the first 2
@@ -195,6 +196,22 @@ elif which == "tangent":
     rays = n
     o = out.view(n, 8)
     extra = {"bytes_per_ray": 16 + 64, "hit_fraction": float((o[:, 7] == 2).double().mean())}
+elif which == "corona":
+    # emissivity_profile(m, d, LampPostModel(h = 10); n_samples = 10⁶, golden-spiral EvenSampler on both hemispheres): the sky rays
+    # are formed on the device (src_mode 3), traced, reduced (gr_corona_trace) and binned (gr_corona_bin)
+    m = G.KerrMetric(1.0, 0.998)
+    d = G.ThinDisc(0.0, 500.0)
+    model = G.LampPostModel(h=10.0)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    n = int(os.environ.get("CORONA_SAMPLES", "1000000"))
+    call = []
+    for i in range(reps):
+        prof, st = G.corona.device_radial_profile(m, d, model, sampler=s, n_samples=n, N=100, ensemble=ens, stats=True)
+        ms.append(st.kernel_ms)
+        call.append(st.call_ms)
+    rays = n
+    extra = {"call_ms_median_after_warmup": float(np.median(call[2:])), "finite_bins": int(np.isfinite(prof.ε).sum()),
+             "steps_per_ray": (st.accepted_steps + st.rejected_steps) / n}
 else:
     raise SystemExit(f"unknown workload {which}")
 

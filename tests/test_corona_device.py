@@ -191,6 +191,31 @@ def test_corona_bins_are_the_bucket_rule_and_sum_to_the_hits(G, ens):
 
 
 @pytest.mark.gpu
+def test_corona_of_a_tabulated_metric_equals_the_fused_one(G, ens):
+    """A user-defined metric (GR_METRIC_TABULATED) under a corona: sky rays, energy ratio and bins through the table."""
+    K = G.corona
+    ens.set("kernel", 2).set("precision", 64)
+    kerr = G.KerrMetric(1.0, 0.9)
+    tab = G.TabulatedMetric(kerr)
+    d = G.ThinDisc(0.0, 300.0)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    for model in (G.LampPostModel(h=8.0), G.RingCorona(G.SourceVelocities.co_rotating, 6.0, 4.0)):
+        a = K.device_radial_profile(kerr, d, model, sampler=s, n_samples=20_000, N=30, ensemble=ens)
+        b = K.device_radial_profile(tab, d, model, sampler=s, n_samples=20_000, N=30, ensemble=ens)
+        np.testing.assert_allclose(b.radii, a.radii, rtol=1e-7)
+        inner = slice(0, -2)
+        ok = np.isfinite(a.ε[inner])
+        np.testing.assert_array_equal(np.isfinite(b.ε[inner]), ok)
+        # outside the ISCO the disc is Keplerian (first derivatives of the table, 1e-8); inside, its velocity is the traced plunge,
+        # which starts from a circular orbit at the ISCO where E² - V_eff cancels to ~0: the table's 1e-8 shows as ~1e-5 there
+        out = (a.radii[inner] > kerr.isco())[ok]
+        assert out.sum() >= 15 and (~out).sum() >= 2
+        np.testing.assert_allclose(b.ε[inner][ok][out], a.ε[inner][ok][out], rtol=1e-6)
+        np.testing.assert_allclose(b.ε[inner][ok][~out], a.ε[inner][ok][~out], rtol=2e-4)
+        np.testing.assert_allclose(b.t[inner][ok], a.t[inner][ok], rtol=1e-7)
+
+
+@pytest.mark.gpu
 def test_a_million_samples_stay_on_the_device(G, ens):
     """the per-ray half of emissivity_profile at 10⁶ samples.  Timing is reported, the
     assertion is loose: the device work of the call is tens of milliseconds, not the seconds of the record route."""
