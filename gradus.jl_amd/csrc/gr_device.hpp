@@ -1705,8 +1705,12 @@ GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[
 #define GR_TAB_PATH 1       // 1 = LDS patch cache, 0 = scalar waterfall (see TabulatedMetric::poly)
 #endif
 #ifndef GR_TAB_SLOTS
-#define GR_TAB_SLOTS 6
+#define GR_TAB_SLOTS 12
 #endif
+#ifndef GR_TAB_FETCH
+#define GR_TAB_FETCH 1      // missing patches a wave copies into its cache side by side; 2 and 4 measured equal (27.7 / 28.3 ms against
+#endif                      // 27.4 at 1024², profiles/r5q_tab_slots_ab.log): the slow waves are slow in the global-memory evaluation
+
 #ifndef GR_TAB_LANE_WAVES
 #define GR_TAB_LANE_WAVES 2
 #endif
@@ -1719,15 +1723,20 @@ GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[
 #ifndef GR_TAB_LOOKAHEAD
 #define GR_TAB_LOOKAHEAD 16     // coefficients the LDS reads of an evaluation run ahead of its arithmetic (LdsCoef)
 #endif
-// The wave's patch cache in LDS: [ kTabSlots tags | round-robin counter | pad to 64 bytes | kTabSlots slots of kTabSlotBytes ].
-// 1488 = 5 x 256 + 208: slot k starts 208 k bytes (mod 256) into the 64 banks -- distinct 16-byte columns for k < 8, so the lanes
+// The wave's patch cache in LDS: [ 16 ints: kTabSlots tags, -1 up to index 14, the round-robin counter at 15 | kTabSlots slots of
+// kTabSlotBytes ].  The tags are read four at a time (ds_read_b128), so a look-up costs one LDS latency whatever the number of slots.
+// 1488 = 5 x 256 + 208: slot k starts 208 k bytes (mod 256) into the 64 banks -- distinct 16-byte columns for k < 16, so the lanes
 // of one ds_read group that sit in different slots do not collide; 1472 of the 1488 bytes are the patch as it lies in memory.
 constexpr int kTabSlots = GR_TAB_SLOTS;
-constexpr int kTabCopyDepth = 8;        // loads a lane keeps in flight while it copies a patch into LDS
+constexpr int kTabTagVecs = (kTabSlots + 3) / 4;
+constexpr int kTabRR = 15;              // index of the round-robin counter among the 16 ints of the head
+constexpr int kTabFetch = GR_TAB_FETCH;
+constexpr int kTabCopyDepth = 8 / kTabFetch;        // loads per patch a lane keeps in flight while it copies (8 in flight in all)
 constexpr int kTabHeadBytes = 64;
 constexpr int kTabSlotBytes = 1488;
 constexpr size_t kTabLdsBytesPerWave = kTabHeadBytes + (size_t)kTabSlots * kTabSlotBytes;
-static_assert(kTabSlots >= 1 && kTabSlots <= 8 && gr_tab::kPatchDoubles * 8 <= kTabSlotBytes, "patch cache geometry");
+static_assert(kTabSlots >= 1 && kTabSlots <= 12 && gr_tab::kPatchDoubles * 8 <= kTabSlotBytes, "patch cache geometry");
+static_assert(kTabFetch == 1 || kTabFetch == 2 || kTabFetch == 4, "patches copied side by side");
 typedef double double2_t __attribute__((ext_vector_type(2)));
 #ifndef GR_HOST_HARNESS
 // the right-hand side with the coefficients read per lane from global memory, NOT inlined: the step loop holds six copies of the
@@ -1922,51 +1931,96 @@ struct TabulatedMetric {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
     } while (0)
             // -- phase 1: a slot for every lane
+            typedef int int4_t __attribute__((ext_vector_type(4)));
+            typedef volatile int4_t __attribute__((address_space(3))) lds_vint4;
             int slot = -1;
 #pragma unroll
-            for (int k = 0; k < kTabSlots; ++k) slot = (tags[k] == patch) ? k : slot;
+            for (int q = 0; q < kTabTagVecs; ++q) {
+                const int4_t t4 = ((lds_vint4*)cs.tab)[q];
+                if (4 * q + 0 < kTabSlots) slot = (t4.x == patch) ? 4 * q + 0 : slot;
+                if (4 * q + 1 < kTabSlots) slot = (t4.y == patch) ? 4 * q + 1 : slot;
+                if (4 * q + 2 < kTabSlots) slot = (t4.z == patch) ? 4 * q + 2 : slot;
+                if (4 * q + 3 < kTabSlots) slot = (t4.w == patch) ? 4 * q + 3 : slot;
+            }
             unsigned long long todo = __builtin_amdgcn_ballot_w64(slot < 0);
 #ifdef GR_TAB_DEBUG_NOMISS      // (register-pressure experiments only: wrong results)
             todo = 0ull; slot = slot < 0 ? 0 : slot;
 #endif
             if (todo != 0ull) {
-                // slots that lanes of THIS evaluation read must stay; the others are replaced round robin.  All lanes copy.
+                // Slots that lanes of THIS evaluation read must stay; the others are replaced round robin.  Up to kTabFetch missing
+                // patches are chosen first (scalar work) and copied side by side by all active lanes, their loads in flight together.
                 unsigned used = 0;
 #pragma unroll
                 for (int k = 0; k < kTabSlots; ++k) used |= __builtin_amdgcn_ballot_w64(slot == k) != 0ull ? (1u << k) : 0u;
                 const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
                 const int n_act = __builtin_popcountll(act);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-                int rr = tags[kTabSlots];
-                for (int tries = 0; tries < kTabSlots && todo != 0ull; ++tries) {
-                    const int sidx = rr;
-                    rr = rr + 1 >= kTabSlots ? 0 : rr + 1;
-                    if (used & (1u << sidx)) continue;
-                    const int first = (int)__builtin_ctzll(todo);
-                    const int pp = __builtin_amdgcn_readlane(patch, first);
-                    const double2_t* src = (const double2_t*)(patches + (int64_t)pp * gr_tab::kPatchDoubles);
-                    typedef double2_t __attribute__((address_space(3))) lds_double2;
-                    lds_double2* dst = (lds_double2*)(cs.tab + kTabHeadBytes + sidx * kTabSlotBytes);
-                    // 92 pieces of 16 bytes, piece q by the active lane of rank q mod n_act, kTabCopyDepth loads in flight per lane
-                    for (int q0 = rank; q0 < gr_tab::kPatchDoubles / 2; q0 += kTabCopyDepth * n_act) {
-                        double2_t piece[kTabCopyDepth];
+                int rr = tags[kTabRR];
+                typedef double2_t __attribute__((address_space(3))) lds_double2;
+                bool room = true;
+                while (todo != 0ull && room) {
+                    int pp[kTabFetch], ss[kTabFetch];
+                    int nf = 0;
 #pragma unroll
-                        for (int jj = 0; jj < kTabCopyDepth; ++jj) {
-                            const int q = q0 + jj * n_act;
-                            if (q < gr_tab::kPatchDoubles / 2) piece[jj] = src[q];
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < kTabCopyDepth; ++jj) {
-                            const int q = q0 + jj * n_act;
-                            if (q < gr_tab::kPatchDoubles / 2) dst[q] = piece[jj];
+                    for (int f = 0; f < kTabFetch; ++f) {
+                        pp[f] = -1; ss[f] = 0;
+                        if (todo != 0ull && room) {
+                            int sidx = -1;
+                            for (int tries = 0; tries < kTabSlots && sidx < 0; ++tries) {
+                                const int cand = rr;
+                                rr = rr + 1 >= kTabSlots ? 0 : rr + 1;
+                                if (!(used & (1u << cand))) sidx = cand;
+                            }
+                            if (sidx < 0) {
+                                room = false;      // every slot is read by this evaluation: the lanes left over go to global memory
+                            } else {
+                                const int first = (int)__builtin_ctzll(todo);
+                                pp[f] = __builtin_amdgcn_readlane(patch, first);
+                                ss[f] = sidx;
+                                used |= 1u << sidx;
+                                todo &= ~__builtin_amdgcn_ballot_w64(patch == pp[f]);
+                                nf = f + 1;
+                            }
                         }
                     }
-                    tags[sidx] = pp;
-                    used |= 1u << sidx;
-                    if (patch == pp) slot = sidx;
-                    todo = __builtin_amdgcn_ballot_w64(slot < 0);
+                    // 92 pieces of 16 bytes per patch, piece q by the active lane of rank q mod n_act
+                    for (int q0 = rank; q0 < gr_tab::kPatchDoubles / 2; q0 += kTabCopyDepth * n_act) {
+                        double2_t piece[kTabFetch][kTabCopyDepth];
+#pragma unroll
+                        for (int f = 0; f < kTabFetch; ++f) {
+                            if (f < nf) {
+                                const double2_t* src = (const double2_t*)(patches + (int64_t)pp[f] * gr_tab::kPatchDoubles);
+#pragma unroll
+                                for (int jj = 0; jj < kTabCopyDepth; ++jj) {
+                                    const int q = q0 + jj * n_act;
+                                    if (q < gr_tab::kPatchDoubles / 2) piece[f][jj] = src[q];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int f = 0; f < kTabFetch; ++f) {
+                            if (f < nf) {
+                                lds_double2* dst = (lds_double2*)(cs.tab + kTabHeadBytes + ss[f] * kTabSlotBytes);
+#pragma unroll
+                                for (int jj = 0; jj < kTabCopyDepth; ++jj) {
+                                    const int q = q0 + jj * n_act;
+                                    if (q < gr_tab::kPatchDoubles / 2) dst[q] = piece[f][jj];
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < kTabFetch; ++f) {
+                        if (f < nf) {
+                            tags[ss[f]] = pp[f];
+                            if (patch == pp[f]) slot = ss[f];
+                        }
+                    }
+#ifdef GR_WAVE_TIMELINE      // (debug builds: patches copied by this wave, scripts/wave_timeline.py)
+                    if (rank == 0) tags[12] = tags[12] + nf;
+#endif
                 }
-                tags[kTabSlots] = rr;
+                tags[kTabRR] = rr;
                 GR_TAB_WAVE_SYNC();
             }
             // -- phase 2: the lanes that have a slot evaluate out of LDS ...
@@ -1983,6 +2037,9 @@ struct TabulatedMetric {
                 // few waves per launch; replacing slots for them instead costs ~7 patch copies per evaluation -- those waves then
                 // run 100 µs per step and set the duration of every launch, 45 ms at any image size: profiles/r5f_tab256_*)
                 double out[4];
+#ifdef GR_WAVE_TIMELINE      // (debug builds: lane-evaluations that went to global memory)
+                __hip_atomic_fetch_add((lds_int*)cs.tab + 13, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
                 tab_rhs_from_global(patches + (int64_t)patch * gr_tab::kPatchDoubles, pole_factor, u, v, su, sv, s, c, vt, vr, vh, vp, out);
                 at = out[0]; ar = out[1]; ah = out[2]; ap = out[3];
             }
@@ -2267,7 +2324,8 @@ struct Cold {
     gr_point* points;         // device
     PfDev pf;
     // longest-first scheduling of 8x8 tiles: `tile_perm` (may be null) maps queue order -> tile;
-    // `tile_cost` (may be null) receives the step count of one representative ray per tile so
+    // `tile_cost` (may be null) receives the step count of one representative ray per tile (the lane kernel of a tabulated
+    // metric: the wave's lifetime in 160 ns units, which its step count does not predict -- gr_kernels.hpp) so
     // the host can build the permutation for the next render of the same plane
     const uint32_t* tile_perm;
     uint32_t* tile_cost;
@@ -3122,6 +3180,17 @@ struct Ray {
         }
     }
 
+    // The slot of this ray's tile in Cold::tile_cost if the ray is its tile's representative (the first row of the first
+    // column), else -1.
+    GR_DEV int64_t tile_cost_index(const Cold& cd) const
+    {
+        const int tr = cd.swizzle, tc = 6 - tr;
+        const int64_t H = cd.plane.height;
+        const int64_t col = idx_div(cd, j, H), row = j - col * H;
+        if ((col & ((1 << tc) - 1)) == 0 && (row & ((1 << tr) - 1)) == 0) return (col >> tc) * (H >> tr) + (row >> tr);
+        return -1;
+    }
+
     // constrain_all (constraints.jl:14-15): v^t from the null/mass-shell condition
     static GR_DEV void constrained_u0(const Metric& m, const Params& p, int64_t jl, real x0[4], real v0[4])
     {
@@ -3930,12 +3999,8 @@ struct Ray {
         if (flags & GR_FLAG_MASK) status = GR_STATUS_NO_STATUS;
         const Cold& cd = cold_of(p);
         if (cd.tile_cost) {
-            // representative ray of its tile: the first row of the first column
-            const int tr = cd.swizzle, tc = 6 - tr;
-            const int64_t H = cd.plane.height;
-            const int64_t col = idx_div(cd, j, H), row = j - col * H;
-            if ((col & ((1 << tc) - 1)) == 0 && (row & ((1 << tr) - 1)) == 0)
-                cd.tile_cost[(col >> tc) * (H >> tr) + (row >> tr)] = (uint32_t)(nacc + nrej);
+            const int64_t ti = tile_cost_index(cd);
+            if (ti >= 0) cd.tile_cost[ti] = (uint32_t)(nacc + nrej);
         }
         if (cd.out_mode == 1) {
             real x0[4], v0[4];

@@ -121,7 +121,12 @@ __device__ __forceinline__ typename Sel::type cold_store_of(const Params& p)
         typedef int __attribute__((address_space(3))) lds_int;
         const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
         st.tab = (lds_char*)((lds_char*)gr_lds + p.lds_tab_off + (size_t)w * kTabLdsBytesPerWave);
-        if (l <= kTabSlots) ((lds_int*)st.tab)[l] = l < kTabSlots ? -1 : 0;
+#ifdef GR_WAVE_TIMELINE      // ints 12..14 of the head count copies / global evaluations (no tag vector reads them with 12 slots)
+        static_assert(kTabSlots == 12, "the timeline build keeps its counters behind twelve tags");
+        if (l < 16) ((lds_int*)st.tab)[l] = l < 12 ? -1 : 0;
+#else
+        if (l < 16) ((lds_int*)st.tab)[l] = l < kTabRR ? -1 : 0;
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -255,6 +260,7 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
 #ifdef GR_WAVE_TIMELINE      // debug builds only (scripts/wave_timeline.py): when did this wave run, where, and how long was its longest ray
     const unsigned long long tl0 = wall_clock64();
     int tl_steps = 0;
+    unsigned long long tl_extra = 0;      // a tabulated metric: patches copied << 16 | lane-evaluations from global memory << 40
 #endif
     Metric m;
     m.load(p.cfg);
@@ -296,6 +302,8 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
     if (gid < p.n) {
         Ray<Metric, DISC> ray;
         const typename ColdSel<Metric>::type cs = cold_store_of<ColdSel<Metric>>(p);
+        unsigned long long tab_t0 = 0;
+        if constexpr (ColdSel<Metric>::kTab) tab_t0 = wall_clock64();
         ray.init(m, p, tile_swizzle(cold_of(p), gid));
         while (!ray.step(m, p, cs)) {}
         // In a one-wave workgroup finalize() lays the end-point record down in the LDS bytes other lanes of this wave use as
@@ -305,9 +313,24 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
         __builtin_amdgcn_wave_barrier();
         GR_PARAMS_AFTER_LOOP(p, pl, zoff)
         ray.finalize(m, pl, lds, cs);
+        if constexpr (ColdSel<Metric>::kTab && LANES_PER_RAY_LOG2 == 0) {
+            // A tabulated metric: what a tile costs is how long its wave lived, not how many steps its rays took -- a wave at
+            // the shadow's edge, its lanes in a dozen different patches, spends 4x the time per step of one inside a single patch
+            // (scripts/wave_timeline.py, WT_TAB=1).  The longest-first order of the next launches is learned from the clock.
+            const Cold& cdt = cold_of(pl);
+            if (cdt.tile_cost) {
+                const int64_t ti = ray.tile_cost_index(cdt);
+                const unsigned long long dt = (wall_clock64() - tab_t0) >> 4;
+                if (ti >= 0) cdt.tile_cost[ti] = (uint32_t)(dt < 1ull ? 1ull : dt > 0xffffffull ? 0xffffffull : dt);
+            }
+        }
         if (LANES_PER_RAY_LOG2 == 0 || tan_dir() == 0) ls.add(ray);      // a ray is counted once
 #ifdef GR_WAVE_TIMELINE
         tl_steps = ray.nacc + ray.nrej;
+        if constexpr (ColdSel<Metric>::kTab) {
+            typedef int __attribute__((address_space(3))) lds_int_t;
+            tl_extra = ((unsigned long long)(unsigned)((lds_int_t*)cs.tab)[12] << 16) | ((unsigned long long)(unsigned)((lds_int_t*)cs.tab)[13] << 40);
+        }
 #endif
     }
 #ifdef GR_WAVE_TIMELINE
@@ -319,7 +342,7 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             unsigned long long* o = p.queue + 4ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-            o[0] = tl0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = (unsigned long long)tl_steps;
+            o[0] = tl0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = (unsigned long long)tl_steps | tl_extra;
         }
     }
 #endif
@@ -466,6 +489,8 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
     // a kernel that parks its stage accelerations in LDS (10 KB per wave) leaves the plunging table in L2: twelve one-wave
     // workgroups per CU cannot each hold a copy as well (staged and L2-served look-ups measured equal, gradus_mi355x.hip)
     if (k.kernel == 0 && ColdSel<Metric, true>::kPark > 0) p.lds_plunge_rows = 0;
+    // (so does a tabulated metric: its LDS is the patch cache, 18 KB per wave)
+    if (ColdSel<Metric, true>::kTab) p.lds_plunge_rows = 0;
     const size_t cold_b = (k.kernel == 0 ? ColdSel<Metric, true>::kBytesPerThread : ColdSel<Metric, false>::kBytesPerThread) * (size_t)block;
     const size_t point_b = p.lds_points ? kPointLdsBytesPerThread * (size_t)block : 0;
     // one-wave workgroups: the end-point records reuse the cold lane storage (lds_prologue)
@@ -489,6 +514,11 @@ hipError_t launch_tmpl(const LaunchKnobs& k, Params& p, hipStream_t stream)
 #ifndef GR_LANE_ONLY
     else {
         int per_cu = 0;
+        if (lds > ((size_t)64 << 10)) {      // four patch caches of a tabulated metric: more dynamic LDS than a kernel may have unasked
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_persistent<Metric, DISC>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
+        }
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persistent<Metric, DISC>, block, lds);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;

@@ -386,14 +386,17 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
     cold.tile_perm = nullptr;
     cold.tile_cost = nullptr;
     const int kern = resolve_kernel(ctx, p.n, cold);
-    if (!ctx->lpt || ctx->lpt_suspend || (kern != 1 && !ctx->lpt_lane) || !cold.swizzle || cold.src_mode != 0) return GR_OK;
+    // (a tabulated metric's lane kernel orders its tiles longest-first by default: its waves' lifetimes spread 9x around their
+    // mean -- the fused kernels' 2.7x -- and the cost it learns is the wave's lifetime, not a step count)
+    const bool tab = p.cfg.metric_id == GR_METRIC_TABULATED;
+    if (!ctx->lpt || ctx->lpt_suspend || (kern != 1 && !ctx->lpt_lane && !tab) || !cold.swizzle || cold.src_mode != 0) return GR_OK;
     const int64_t tiles = p.n >> 6;
     // Measured on MI355X: longest-first pays when a launch is only a few tiles per
     // resident wave deep (the 1/8 shard of a 2048² image: 4.0 -> 3.7 ms on the rank holding the
     // α≈0 columns, whose rays take up to 430 steps) and costs 2-4 % on deep launches.  lpt = 2 forces it.
     const int64_t resident_waves = (int64_t)ctx->n_cu * 8;
     if (tiles < resident_waves) return GR_OK;
-    if (ctx->lpt == 1 && tiles >= 6 * resident_waves) return GR_OK;
+    if (ctx->lpt == 1 && tiles >= (tab ? 24 : 6) * resident_waves) return GR_OK;
     std::vector<unsigned char> key(sizeof(gr_config) + sizeof(gr_plane) + sizeof(gr_range));
     std::memcpy(key.data(), &p.cfg, sizeof(gr_config));
     std::memcpy(key.data() + sizeof(gr_config), &cold.plane, sizeof(gr_plane));

@@ -5,7 +5,7 @@ kernel writes (start, end [100 MHz clock], hardware id, steps of its longest ray
 the number of waves resident over time and where the launch's tail comes from.
     python scripts/wave_timeline.py [S=1024] [order=grid|lpt|plane]
 order = plane: the bench workload (fused image of an S x S plane, the plain fp64 lane kernel) instead of the tangent launch;
-WT_KNOBS="lpt=2,lpt_lane=1" sets context knobs first"""
+WT_KNOBS="lpt=2,lpt_lane=1" sets context knobs first; WT_TAB=1: the bench metric through a table (order = plane)"""
 import ctypes as C
 import json
 import math
@@ -29,6 +29,8 @@ for kv in filter(None, os.environ.get("WT_KNOBS", "").split(",")):
     k_, v_ = kv.split("=")
     ens.set(k_, int(v_))
 m = G.KerrMetric(1.0, 0.998)
+if os.environ.get("WT_TAB"):          # the same metric through a table (GR_METRIC_TABULATED): order = plane only
+    m = G.TabulatedMetric(m, max_refinements=0)
 x = np.array([0.0, 1000.0, math.radians(75), 0.0])
 dev = torch.device("cuda", 0)
 L = _lib.load()
@@ -88,7 +90,8 @@ L.gr_debug_set_timeline(None)
 ms = e0.elapsed_time(e1)
 t = tl.cpu().numpy().reshape(-1, 4)
 t = t[t[:, 1] != 0]
-t0, t1, hw, steps = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+t0, t1, hw, steps = t[:, 0], t[:, 1], t[:, 2], t[:, 3] & 0xFFFF
+copies, glob = (t[:, 3] >> 16) & 0xFFFFFF, (t[:, 3] >> 40) & 0xFFFFFF          # tabulated metric only
 base = t0.min()
 st, en = (t0 - base) / 1e5, (t1 - base) / 1e5          # ms (100 MHz clock)
 life = en - st
@@ -100,6 +103,14 @@ res = [(int(((st < hi) & (en > lo)).sum())) for lo, hi in zip(edges[:-1], edges[
 print("waves resident per 5 % slice of the launch:", res)
 late = np.argsort(en)[-8:]
 print("the waves that end last (start, end, steps of longest ray):", [(round(float(st[i]), 2), round(float(en[i]), 2), int(steps[i])) for i in late])
+if os.environ.get("WT_TAB"):
+    slow = np.argsort(life)[-12:]
+    print("slowest waves (lifetime ms, steps of longest ray, patches copied, lane-evaluations from global memory, copies per step):",
+          [(round(float(life[i]), 2), int(steps[i]), int(copies[i]), int(glob[i]), round(float(copies[i]) / max(int(steps[i]), 1), 1)) for i in slow])
+    print(f"all waves: copies per wave median {np.median(copies):.0f} mean {copies.mean():.0f}; per step of the longest ray median {np.median(copies / np.maximum(steps, 1)):.2f}; "
+          f"global lane-evaluations total {glob.sum()} in {int((glob > 0).sum())} waves")
+    c = np.polyfit(copies.astype(float), life * 1e3, 1)
+    print(f"lifetime ~ {c[1]:.0f} µs + {c[0]:.2f} µs per copy (least squares over all waves)")
 per_step = life * 1e3 / np.maximum(steps, 1)
 print(f"µs per step of a wave's longest ray: median {np.median(per_step):.2f} p10 {np.percentile(per_step, 10):.2f} p90 {np.percentile(per_step, 90):.2f}; "
       f"for the 1 % longest waves {np.median(per_step[np.argsort(life)[-len(life) // 100:]]):.2f}")
