@@ -1815,6 +1815,10 @@ struct TabulatedMetric {
     struct CoefStream {
         typedef const double2_t __attribute__((address_space(3))) lds_cdouble2;
         static constexpr int kAll = gr_tab::kComps * gr_tab::kCoefs;       // 180 coefficients = 90 pairs
+        // LDS reads are volatile (see above).  Global ones must NOT be: a volatile global load is a system-scope one (sc0 sc1) that
+        // no cache may serve -- every look-ahead batch of the evaluation from global memory then waits for memory itself, 7.4 µs
+        // per evaluation (scripts/wave_timeline.py); the load/store vectoriser keeps plain global loads 16 bytes wide.
+        static constexpr bool kVolatile = sizeof(AddrInt) == 4;
         mutable PairPtr sl;
         mutable double2_t buf[kAll / 2];
         // coefficients consumed once row `row` of component `comp` is done, and the pairs requested by then
@@ -1823,7 +1827,10 @@ struct TabulatedMetric {
         GR_DEV void issue(int from_pair, int to_pair) const
         {
 #pragma unroll
-            for (int j = from_pair; j < to_pair; ++j) buf[j] = *(volatile typename std::remove_pointer<PairPtr>::type*)(sl + j);
+            for (int j = from_pair; j < to_pair; ++j) {
+                if constexpr (kVolatile) buf[j] = *(volatile typename std::remove_pointer<PairPtr>::type*)(sl + j);
+                else buf[j] = sl[j];
+            }
         }
         GR_DEV void start() const { issue(0, pairs_by(0)); }
         GR_DEV double operator()(int kk) const { return buf[kk >> 1][kk & 1]; }
@@ -1850,7 +1857,9 @@ struct TabulatedMetric {
     typedef CoefStream<const double2_t __attribute__((address_space(3)))*, unsigned, GR_TAB_LOOKAHEAD> LdsCoef;      // out of a cache slot
     // ... out of the table in global memory (tab_rhs_from_global): memory latency is ten times the LDS's, and the lanes that take
     // this path are few and often alone in their wave -- four times the look-ahead
-    typedef CoefStream<const double2_t*, unsigned long long, GR_TAB_LOOKAHEAD_GLOBAL> GlobalCoef;
+    // (an address-space-1 pointer: through a generic one the loads are flat_load's, which count on the LDS counter as well and
+    // return out of order there -- every wait for one of them then waits for all of them, and the look-ahead is gone)
+    typedef CoefStream<const double2_t __attribute__((address_space(1)))*, unsigned long long, GR_TAB_LOOKAHEAD_GLOBAL> GlobalCoef;
 #endif
     template <class Ld, class Ops_>
     GR_DEV void horner(const Ld& ld, const Ops_& ops, double u, double v, double su, double sv, real s, real c, real g[5], real gr[5], real gt[5]) const
@@ -1947,6 +1956,9 @@ struct TabulatedMetric {
             todo = 0ull; slot = slot < 0 ? 0 : slot;
 #endif
             if (todo != 0ull) {
+#ifdef GR_WAVE_TIMELINE
+                const unsigned long long tl_c0 = wall_clock64();
+#endif
                 // Slots that lanes of THIS evaluation read must stay; the others are replaced round robin.  Up to kTabFetch missing
                 // patches are chosen first (scalar work) and copied side by side by all active lanes, their loads in flight together.
                 unsigned used = 0;
@@ -2022,6 +2034,9 @@ struct TabulatedMetric {
                 }
                 tags[kTabRR] = rr;
                 GR_TAB_WAVE_SYNC();
+#ifdef GR_WAVE_TIMELINE      // (debug builds: clock ticks this wave spent fetching patches)
+                if (rank == 0) tags[13] = tags[13] + (int)(wall_clock64() - tl_c0);
+#endif
             }
             // -- phase 2: the lanes that have a slot evaluate out of LDS ...
             if (slot >= 0) {
@@ -2037,10 +2052,17 @@ struct TabulatedMetric {
                 // few waves per launch; replacing slots for them instead costs ~7 patch copies per evaluation -- those waves then
                 // run 100 µs per step and set the duration of every launch, 45 ms at any image size: profiles/r5f_tab256_*)
                 double out[4];
-#ifdef GR_WAVE_TIMELINE      // (debug builds: lane-evaluations that went to global memory)
-                __hip_atomic_fetch_add((lds_int*)cs.tab + 13, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifdef GR_WAVE_TIMELINE      // (debug builds: clock ticks in the evaluation from global memory)
+                const unsigned long long tl_f0 = wall_clock64();
 #endif
                 tab_rhs_from_global(patches + (int64_t)patch * gr_tab::kPatchDoubles, pole_factor, u, v, su, sv, s, c, vt, vr, vh, vp, out);
+#ifdef GR_WAVE_TIMELINE
+                {
+                    const unsigned long long fa = __builtin_amdgcn_ballot_w64(true);
+                    if ((int)__builtin_amdgcn_mbcnt_hi((unsigned)(fa >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fa, 0u)) == 0)
+                        tags[14] = tags[14] + (int)(wall_clock64() - tl_f0);
+                }
+#endif
                 at = out[0]; ar = out[1]; ah = out[2]; ap = out[3];
             }
             GR_TAB_WAVE_SYNC();      // the slots just read may be replaced by the next evaluation
@@ -2068,7 +2090,7 @@ __device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, 
     // this function needs 254 registers and saves / restores a hundred callee-saved ones around its body)
     real P[5], Pu[5], Pv[5], g[5], gr[5], gt[5], gi[5];
     TabulatedMetric::GlobalCoef gc;
-    gc.sl = (const double2_t*)pc;
+    gc.sl = (const double2_t __attribute__((address_space(1)))*)(unsigned long long)pc;
     gc.start();
     gr_tab::eval_patch<real>(gc, gc, u, v, P, Pu, Pv);
 #pragma unroll

@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
 #ifdef GR_WAVE_TIMELINE      // debug builds only (scripts/wave_timeline.py): when did this wave run, where, and how long was its longest ray
     const unsigned long long tl0 = wall_clock64();
     int tl_steps = 0;
-    unsigned long long tl_extra = 0;      // a tabulated metric: patches copied << 16 | lane-evaluations from global memory << 40
+    unsigned long long tl_extra = 0;      // a tabulated metric: patches copied << 16 | 640 ns units spent copying << 32 | ... evaluating from global memory << 48
 #endif
     Metric m;
     m.load(p.cfg);
@@ -329,7 +329,9 @@ __global__ void __launch_bounds__(256, GR_LANE_MIN_WAVES) k_trace_lane(const Par
         tl_steps = ray.nacc + ray.nrej;
         if constexpr (ColdSel<Metric>::kTab) {
             typedef int __attribute__((address_space(3))) lds_int_t;
-            tl_extra = ((unsigned long long)(unsigned)((lds_int_t*)cs.tab)[12] << 16) | ((unsigned long long)(unsigned)((lds_int_t*)cs.tab)[13] << 40);
+            const unsigned nc = (unsigned)((lds_int_t*)cs.tab)[12], tc = (unsigned)((lds_int_t*)cs.tab)[13] >> 6, tf = (unsigned)((lds_int_t*)cs.tab)[14] >> 6;
+            tl_extra = ((unsigned long long)(nc > 0xffffu ? 0xffffu : nc) << 16) | ((unsigned long long)(tc > 0xffffu ? 0xffffu : tc) << 32)
+                       | ((unsigned long long)(tf > 0xffffu ? 0xffffu : tf) << 48);
         }
 #endif
     }

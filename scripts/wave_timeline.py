@@ -91,7 +91,8 @@ ms = e0.elapsed_time(e1)
 t = tl.cpu().numpy().reshape(-1, 4)
 t = t[t[:, 1] != 0]
 t0, t1, hw, steps = t[:, 0], t[:, 1], t[:, 2], t[:, 3] & 0xFFFF
-copies, glob = (t[:, 3] >> 16) & 0xFFFFFF, (t[:, 3] >> 40) & 0xFFFFFF          # tabulated metric only
+copies = (t[:, 3] >> 16) & 0xFFFF          # tabulated metric only: patches copied, ms spent copying, ms in the global-memory evaluation
+t_copy, t_glob = ((t[:, 3] >> 32) & 0xFFFF) * 640e-6, ((t[:, 3] >> 48) & 0xFFFF) * 640e-6
 base = t0.min()
 st, en = (t0 - base) / 1e5, (t1 - base) / 1e5          # ms (100 MHz clock)
 life = en - st
@@ -105,12 +106,10 @@ late = np.argsort(en)[-8:]
 print("the waves that end last (start, end, steps of longest ray):", [(round(float(st[i]), 2), round(float(en[i]), 2), int(steps[i])) for i in late])
 if os.environ.get("WT_TAB"):
     slow = np.argsort(life)[-12:]
-    print("slowest waves (lifetime ms, steps of longest ray, patches copied, lane-evaluations from global memory, copies per step):",
-          [(round(float(life[i]), 2), int(steps[i]), int(copies[i]), int(glob[i]), round(float(copies[i]) / max(int(steps[i]), 1), 1)) for i in slow])
-    print(f"all waves: copies per wave median {np.median(copies):.0f} mean {copies.mean():.0f}; per step of the longest ray median {np.median(copies / np.maximum(steps, 1)):.2f}; "
-          f"global lane-evaluations total {glob.sum()} in {int((glob > 0).sum())} waves")
-    c = np.polyfit(copies.astype(float), life * 1e3, 1)
-    print(f"lifetime ~ {c[1]:.0f} µs + {c[0]:.2f} µs per copy (least squares over all waves)")
+    print("slowest waves (lifetime ms, steps of longest ray, patches copied, ms copying, ms evaluating from global memory):",
+          [(round(float(life[i]), 2), int(steps[i]), int(copies[i]), round(float(t_copy[i]), 2), round(float(t_glob[i]), 2)) for i in slow])
+    print(f"all waves: copies per wave median {np.median(copies):.0f} mean {copies.mean():.0f}; µs per copy median {np.median(t_copy * 1e3 / np.maximum(copies, 1)):.2f}; "
+          f"share of wave lifetime: copying {t_copy.sum() / life.sum():.3f}, global evaluation {t_glob.sum() / life.sum():.3f} ({int((t_glob > 0).sum())} waves)")
 per_step = life * 1e3 / np.maximum(steps, 1)
 print(f"µs per step of a wave's longest ray: median {np.median(per_step):.2f} p10 {np.percentile(per_step, 10):.2f} p90 {np.percentile(per_step, 90):.2f}; "
       f"for the 1 % longest waves {np.median(per_step[np.argsort(life)[-len(life) // 100:]]):.2f}")
