@@ -121,11 +121,17 @@ __device__ __forceinline__ typename Sel::type cold_store_of(const Params& p)
         typedef int __attribute__((address_space(3))) lds_int;
         const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
         st.tab = (lds_char*)((lds_char*)gr_lds + p.lds_tab_off + (size_t)w * kTabLdsBytesPerWave);
+        // Every active lane writes all 16 ints (the same values): the last wave of a launch may have fewer lanes than the head
+        // has entries -- a ray-set launch of 5000 rays ends in a wave of 8 -- and what they left unwritten would be whatever the
+        // previous workgroup on this CU had there: a "tag" that matches by accident, a round-robin counter out of range.
+        (void)l;
 #ifdef GR_WAVE_TIMELINE      // ints 12..14 of the head count copies / global evaluations (no tag vector reads them with 12 slots)
         static_assert(kTabSlots == 12, "the timeline build keeps its counters behind twelve tags");
-        if (l < 16) ((lds_int*)st.tab)[l] = l < 12 ? -1 : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ((lds_int*)st.tab)[i] = i < 12 ? -1 : 0;
 #else
-        if (l < 16) ((lds_int*)st.tab)[l] = l < kTabRR ? -1 : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ((lds_int*)st.tab)[i] = i < kTabRR ? -1 : 0;
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

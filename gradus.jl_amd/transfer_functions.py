@@ -170,7 +170,9 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
         return out
 
     trace.endpoints = endpoints
-    trace.tangent = tangent
+    # The tangent build of the kernels exists for the catalogue metrics; a tabulated one (a user-defined metric) takes the route
+    # of every tracer without `.tangent`: safeguarded Newton on ray summaries, Jacobians by central differences.
+    trace.tangent = None if getattr(m, "metric_id", None) == 11 else tangent
     # rays are nearly free next to a launch's latency here: the solvers may trace points they might not need
     # (BRACKET_DEPTH, GOLDEN_DEPTH); tracers without this mark (the CPU tests' oracle-driven ones) get one level at a time
     trace.speculate = True

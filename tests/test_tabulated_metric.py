@@ -370,3 +370,64 @@ def test_tabulated_metric_through_the_persistent_kernel_and_ray_arrays(G, ens, t
         pts = G.tracegeodesics(m, x, vs, G.ThinDisc(3.0, 400.0), 2000.0, ensemble=ens)
         out.append(pts)
     _compare_endpoints(out[0], out[1], x_rtol=1e-7, max_flips=2, max_outliers=3, r_horizon=base.inner_radius())
+
+
+@pytest.mark.gpu
+def test_transfer_functions_of_a_tabulated_metric(G, ens, tab_kerr):
+    """Cunningham transfer functions of a user-defined metric: the tangent build of the kernels covers the catalogue, a tabulated
+    metric takes the difference-quotient route of the host solvers (safeguarded Newton on ray summaries, central-difference
+    Jacobians) -- the same route on the fused Kerr kernel is the comparison."""
+    ens.set("kernel", 2).set("precision", 64)
+    kerr = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(40), 0.0])
+    d = G.ThinDisc(0.0, float("inf"))
+    radii = [4.0, 12.0, 40.0]
+    a = G.cunningham_transfer_functions(kerr, x, d, radii, N=60, ensemble=ens, root_finder="polished")
+    b = G.cunningham_transfer_functions(tab_kerr, x, d, radii, N=60, ensemble=ens)
+    for ca, cb in zip(a, b):
+        ok = np.isfinite(ca.f)
+        assert cb.f.size == ca.f.size and ok.sum() >= ca.f.size - 2
+        np.testing.assert_array_equal(np.isfinite(cb.f), ok)
+        assert cb.gmin == pytest.approx(ca.gmin, rel=1e-7) and cb.gmax == pytest.approx(ca.gmax, rel=1e-7)
+        np.testing.assert_allclose(cb.g_star, ca.g_star, atol=1e-9)
+        # (difference-quotient Jacobians amplify the table's 1e-9 near the extrema of g, where |∂(ρ, g)/∂(α, β)| -> 0)
+        rel = np.abs(cb.f[ok] - ca.f[ok]) / np.max(np.abs(ca.f[ok]))
+        assert np.median(rel) < 2e-5 and rel.max() < 2e-2
+        sa, sb = float(np.sum((ca.f * ca.g_star)[ok]) / ca.f.size), float(np.sum((cb.f * cb.g_star)[ok]) / cb.f.size)
+        assert sb == pytest.approx(sa, rel=2e-5)
+    # and the tracer says so itself
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    chart = G.chart_for_metric(tab_kerr, 2 * x[1])
+    pf = G.ConstPointFunctions.redshift(tab_kerr, x, ensemble=ens)
+    assert device_tracer(tab_kerr, x, 2 * x[1], chart, pf, ens).tangent is None
+    assert device_tracer(kerr, x, 2 * x[1], G.chart_for_metric(kerr, 2 * x[1]), G.ConstPointFunctions.redshift(kerr, x), ens).tangent is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 8, 63, 65, 5000])
+def test_last_wave_of_a_ray_set_with_few_lanes(G, ens, tab_kerr, n):
+    """The wave's cache head in LDS is written by every active lane: a launch whose last wave has fewer lanes than the head has
+    entries (5000 rays end in a wave of 8) found stale tags there -- rays that never left the observer.  Traced after other
+    kernels have used the CU's LDS, against the fused kernel ray by ray."""
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    ens.set("kernel", 2).set("precision", 64)
+    kerr = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(40), 0.0])
+    rng = np.random.default_rng(n)
+    al, be = rng.uniform(-12, 12, n), rng.uniform(-12, 12, n)
+    got = {}
+    for name, m in (("kerr", kerr), ("tab", tab_kerr), ("kerr2", kerr), ("tab2", tab_kerr)):
+        tr = device_tracer(m, x, 2 * x[1], G.chart_for_metric(m, 2 * x[1]), G.ConstPointFunctions.redshift(m, x, ensemble=ens), ens)
+        pts, g = tr(al, be)
+        got[name] = (pts["status"].copy(), pts["x"][:, 1].copy(), g)
+    for a, b in (("tab", "kerr"), ("tab2", "kerr")):
+        np.testing.assert_array_equal(got[a][0], got[b][0])
+        hit = got[b][0] == G.StatusCodes.IntersectedWithGeometry
+        np.testing.assert_allclose(got[a][1][hit], got[b][1][hit], rtol=1e-7)
+        out = hit & (got[b][1] > kerr.isco())
+        np.testing.assert_allclose(got[a][2][out], got[b][2][out], rtol=1e-6)
+        # (inside the ISCO g rests on the traced plunge and, towards the horizon, on a cancellation in p·u: 2e-4 in 4 of 4879 rays)
+        np.testing.assert_allclose(got[a][2][hit & ~out], got[b][2][hit & ~out], rtol=1e-3)
+    np.testing.assert_array_equal(got["tab"][1], got["tab2"][1])
