@@ -484,7 +484,9 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
     metric_id = GR_METRIC_TABULATED
 
     def __init__(self, source, *, inner_radius=None, isco=None, r_min=None, r_max=12000.0, r0=None, m_r=8, n_theta=32,
-                 tol=2e-11, dtol=1e-8, max_refinements=3, closest_approach=1.01, pole_factor=True):
+                 tol=2e-11, dtol=1e-8, max_refinements=3, closest_approach=1.01, pole_factor=True, strict=True):
+        import warnings
+
         from . import _lib
 
         self.source = source
@@ -493,6 +495,15 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             if not isinstance(source, AbstractMetric):
                 raise ValueError("a callable metric needs `inner_radius` (the event horizon radius)")
             inner_radius = source.inner_radius()
+        # The table represents the metric by polynomials: a pole of g_rr INSIDE its radial range -- an `inner_radius` that lies
+        # within the outermost horizon, as the reference's formulas for the dilaton-axion and Kerr-dark-matter metrics do --
+        # cannot be fitted (estimates of order 1 .. 1000: rays near it would stall or scatter).  Direct evaluation carries such
+        # rays across the pole in one form or another; here the range starts outside the OUTERMOST sign change of g_rr instead.
+        outer = self._outermost_horizon(float(inner_radius), float(r_max))
+        if outer is not None and r_min is None and r0 is None:
+            warnings.warn(f"TabulatedMetric: g_rr changes sign at r = {outer:.6g}, outside inner_radius = {float(inner_radius):.6g}; the "
+                          "table (and the chart's inner boundary) start there", stacklevel=2)
+            inner_radius = outer
         self._inner_radius = float(inner_radius)
         self._isco = isco
         # radial octaves count from a point just inside the horizon; the table starts at the chart's inner radius
@@ -510,8 +521,14 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             table = np.empty(grid.table_doubles)
             err = (ctypes.c_double * 3)()
             _lib.check(L.gr_metric_table_fit(grid, samples.ctypes.data, table.ctypes.data, err))
+            previous = getattr(self, "errors", None)
             self.grid, self.table, self.errors = grid, table, tuple(err)
             if err[0] <= tol and err[1] <= dtol and err[2] <= dtol:
+                break
+            # a degree-7 fit gains 2^8 per halving of a smooth function's patches; one that gains less than 16 is looking at a
+            # kink or a pole, and the doublings left (4x the samples each) would not close a gap of 1000
+            miss = lambda e_: max(e_[0] / tol, e_[1] / dtol, e_[2] / dtol)
+            if previous is not None and miss(self.errors) > miss(previous) / 16.0 and miss(self.errors) > 1e3:
                 break
             # refine the direction(s) whose derivative estimate is worse
             if err[1] > dtol or err[0] > tol:
@@ -519,6 +536,41 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             if err[2] > dtol or err[0] > tol:
                 n_theta *= 2
         self.m_r, self.n_theta = int(self.grid.m_r), int(self.grid.n_theta)
+        e = self.errors
+        if e[0] > 100.0 * tol or e[1] > 100.0 * dtol or e[2] > 100.0 * dtol:
+            msg = (f"TabulatedMetric: the fit's error estimates (value {e[0]:.2g}, ∂r {e[1]:.2g}, ∂θ {e[2]:.2g}; asked {tol:.2g}, {dtol:.2g}) did not "
+                   f"come down on the grid ({self.m_r}, {self.n_theta}): the metric is not smooth on r in [{self.r_min:.6g}, {self.r_max:.6g}] -- a "
+                   "horizon inside the range (raise `inner_radius` / `r_min`), a kink in one of its functions, or NaNs")
+            if strict and not (e[0] <= 1e-7 and e[1] <= 1e-4 and e[2] <= 1e-4):
+                raise ValueError(msg + "; strict=False traces through the table as it is")
+            warnings.warn(msg, stacklevel=2)
+
+    def _outermost_horizon(self, r_in, r_max):
+        """The largest r in (r_in, r_max) where g_rr changes sign (or stops being finite) on the equator or near the axis, refined
+        by bisection; None if g_rr > 0 all the way."""
+        found = None
+        rs = r_in + np.geomspace(1e-6 * max(r_in, 1.0), max(r_max - r_in, 1.0), 400)
+        for th in (0.5 * math.pi, 0.3):
+            try:
+                grr = np.array([float(np.asarray(self._f(float(r), th)[1])) for r in rs])
+            except Exception:      # a callable that cannot be evaluated below its own horizon: nothing to look for
+                return None
+            bad = ~(np.isfinite(grr) & (grr > 0.0))
+            if not bad.any():
+                continue
+            k = int(np.nonzero(bad)[0][-1])
+            if k + 1 >= rs.size:
+                continue
+            lo, hi = rs[k], rs[k + 1]
+            for _ in range(80):
+                mid = 0.5 * (lo + hi)
+                g = float(np.asarray(self._f(mid, th)[1]))
+                if np.isfinite(g) and g > 0.0:
+                    hi = mid
+                else:
+                    lo = mid
+            found = hi if found is None else max(found, hi)
+        return found
 
     def _sample(self, rn, tn):
         """metric_components on the tensor grid of nodes -> array [n_r, n_θ, 5]."""

@@ -292,6 +292,7 @@ function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 
         r0 = rh > 0 ? rh * (1 - 1e-3) : min(-1.0, r_inner - 1.0)
         r_min = max(r_inner * (1 - 1e-3), r0 + 1e-3)
         local table
+        previous, last_err = Inf, [Inf, Inf, Inf]
         for _ = 0:refinements
             grid = Ref{GrMetricGrid}()
             _check(ccall((:gr_metric_grid_plan, LIB), Int32, (Float64, Float64, Float64, Int32, Int32, Ref{GrMetricGrid}),
@@ -314,11 +315,24 @@ function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 
             _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 grid, samples, table, err))
             all(err .<= METRIC_TABLE_TOL) && return table
+            # a degree-7 fit gains 2^8 per halving of a smooth function's patches: one that gains less than 16 is looking at a kink
+            # or a pole (a horizon inside [r_inner, r_outer], a piecewise-defined function), and more samples will not change that
+            miss = maximum(err ./ METRIC_TABLE_TOL)
+            stalled = miss > previous / 16 && miss > 1e3
+            previous = miss
+            last_err = err
+            stalled && break
             (err[1] > METRIC_TABLE_TOL[1] || err[2] > METRIC_TABLE_TOL[2]) && (m_r *= 2)
             (err[1] > METRIC_TABLE_TOL[1] || err[3] > METRIC_TABLE_TOL[3]) && (n_theta *= 2)
         end
-        @warn "EnsembleMI355X: the table of $(typeof(m)) does not meet the fit tolerances after $refinements refinements; tracing with it anyway"
-        table
+        # Good enough to trace with (value 1e-7, derivatives 1e-4)?  Then warn.  Otherwise the metric is not one a table represents:
+        # UnsupportedOnDevice sends the problem to the reference's own CPU ensemble, as for any configuration the device does not take.
+        if last_err[1] <= 1e-7 && last_err[2] <= 1e-4 && last_err[3] <= 1e-4
+            @warn "EnsembleMI355X: the table of $(typeof(m)) misses the fit tolerances (estimates $last_err, asked $METRIC_TABLE_TOL); tracing with it"
+            return table
+        end
+        throw(UnsupportedOnDevice("$(typeof(m)) is not smooth on r in [$r_min, $r_outer] (fit estimates $last_err): a horizon outside " *
+                                  "inner_radius(m), or a piecewise-defined metric function"))
     end
 end
 _metric_table(m, r_inner, r_outer) = _is_tabulated(m) ? metric_table(m, Float64(r_inner), Float64(r_outer)) : Float64[]

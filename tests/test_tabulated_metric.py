@@ -431,3 +431,30 @@ def test_last_wave_of_a_ray_set_with_few_lanes(G, ens, tab_kerr, n):
         # (inside the ISCO g rests on the traced plunge and, towards the horizon, on a cancellation in p·u: 2e-4 in 4 of 4879 rays)
         np.testing.assert_allclose(got[a][2][hit & ~out], got[b][2][hit & ~out], rtol=1e-3)
     np.testing.assert_array_equal(got["tab"][1], got["tab2"][1])
+
+
+def test_a_metric_the_table_cannot_represent_is_refused_loudly(G):
+    """A discontinuity inside the radial range (Kerr with a step in M at r = 9): the fit's own estimates do not come down, the
+    constructor says so instead of handing the kernels a table of garbage; strict=False warns and goes on."""
+    kerr_in, kerr_out = G.KerrMetric(1.0, 0.5), G.KerrMetric(1.02, 0.5)
+
+    def stepped(r, th):
+        a, b = kerr_in._components(r, np.sin(th), np.cos(th)), kerr_out._components(r, np.sin(th), np.cos(th))
+        return tuple(np.where(np.asarray(r) < 9.0, x, y) for x, y in zip(a, b))
+
+    with pytest.raises(ValueError, match="not smooth"):
+        G.TabulatedMetric(stepped, inner_radius=kerr_in.inner_radius(), isco=kerr_in.isco(), r_max=200.0)
+    with pytest.warns(UserWarning, match="not smooth"):
+        tm = G.TabulatedMetric(stepped, inner_radius=kerr_in.inner_radius(), isco=kerr_in.isco(), r_max=200.0, strict=False)
+    assert tm.errors[0] > 1e-6 and (tm.m_r, tm.n_theta) == (16, 64)      # one doubling showed no convergence: no further ones
+
+
+def test_an_inner_radius_inside_the_horizon_moves_the_table_out(G):
+    """`inner_radius` below the outermost horizon (the reference's dilaton-axion and Kerr-dark-matter formulas do that): the
+    pole of g_rr would lie inside the table; the range -- and the chart's inner boundary -- start at the sign change instead."""
+    kerr = G.KerrMetric(1.0, 0.6)
+    f = lambda r, th: kerr._components(r, np.sin(th), np.cos(th))
+    with pytest.warns(UserWarning, match="g_rr changes sign"):
+        tm = G.TabulatedMetric(f, inner_radius=0.8 * kerr.inner_radius(), isco=kerr.isco(), r_max=500.0)
+    assert tm.inner_radius() == pytest.approx(kerr.inner_radius(), rel=1e-9)
+    assert tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
