@@ -511,7 +511,8 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
         self.r_min = float(r_min) if r_min is not None else max(self._inner_radius * closest_approach * (1.0 - 1e-3), self.r0 + 1e-3)
         self.r_max = float(r_max)
         L = _lib.load()
-        for _ in range(max_refinements + 1):
+        miss = lambda e_: max(e_[0] / tol, e_[1] / dtol, e_[2] / dtol)
+        for attempt in range(max_refinements + 1):
             grid = _lib.gr_metric_grid()
             _lib.check(L.gr_metric_grid_plan(self.r_min, self.r_max, self.r0, int(m_r), int(n_theta), grid))
             grid.pole_factor = 1 if pole_factor else 0      # g_ϕϕ, g_tϕ stored without the sin²θ they share on the axis
@@ -521,13 +522,22 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             table = np.empty(grid.table_doubles)
             err = (ctypes.c_double * 3)()
             _lib.check(L.gr_metric_table_fit(grid, samples.ctypes.data, table.ctypes.data, err))
+            if attempt == 0 and pole_factor and miss(tuple(err)) > 1e4:
+                # g_ϕϕ / sin²θ is not smooth on the axis for every metric: with an axion charge (the dilaton-axion metric, β != 0)
+                # g_ϕϕ does not vanish there.  The same samples fitted with g_ϕϕ, g_tϕ as they are: kept if two orders better.
+                grid2 = _lib.gr_metric_grid()
+                _lib.check(L.gr_metric_grid_plan(self.r_min, self.r_max, self.r0, int(m_r), int(n_theta), grid2))
+                grid2.pole_factor = 0
+                table2, err2 = np.empty(grid2.table_doubles), (ctypes.c_double * 3)()
+                _lib.check(L.gr_metric_table_fit(grid2, samples.ctypes.data, table2.ctypes.data, err2))
+                if miss(tuple(err2)) < 1e-2 * miss(tuple(err)):
+                    pole_factor, grid, table, err = False, grid2, table2, err2
             previous = getattr(self, "errors", None)
             self.grid, self.table, self.errors = grid, table, tuple(err)
             if err[0] <= tol and err[1] <= dtol and err[2] <= dtol:
                 break
             # a degree-7 fit gains 2^8 per halving of a smooth function's patches; one that gains less than 16 is looking at a
             # kink or a pole, and the doublings left (4x the samples each) would not close a gap of 1000
-            miss = lambda e_: max(e_[0] / tol, e_[1] / dtol, e_[2] / dtol)
             if previous is not None and miss(self.errors) > miss(previous) / 16.0 and miss(self.errors) > 1e3:
                 break
             # refine the direction(s) whose derivative estimate is worse

@@ -35,7 +35,12 @@ fam = [          # the smooth families (a table refuses metrics with kinks or po
     ("kerr-newman", lambda: (lambda a: G.KerrNewmanMetric(1.0, a, U(0, math.sqrt(1 - a * a) * 0.95)))(U(0, 0.9))),
     ("johannsen-psaltis", lambda: G.JohannsenPsaltisMetric(1.0, U(0, 0.8), U(-0.5, 1))),
     ("bumblebee", lambda: G.BumblebeeMetric(1.0, U(0, 0.29), U(-0.5, 1))),
+    # g_ϕϕ does not vanish on the axis for β != 0: the table stores it as it is (pole_factor chosen by the fit); its inner_radius
+    # formula lies inside the outermost horizon: the table starts at the sign change of g_rr
+    ("dilaton-axion", lambda: G.DilatonAxion(1.0, U(0.1, 0.8), U(-0.3, 0.3), U(0.3, 1.5))),
 ]
+if os.environ.get("SOAK_FAMILIES"):          # e.g. SOAK_FAMILIES=dilaton-axion
+    fam = [f for f in fam if f[0] in os.environ["SOAK_FAMILIES"].split(",")]
 bad, rays_total, flips_total, worst = [], 0, 0, 0.0
 t_start = time.time()
 for case in range(n_scenes):
@@ -56,7 +61,7 @@ for case in range(n_scenes):
     if only is not None and case != only:
         continue
     x = np.array([0.0, r_obs, th, 0.0])
-    desc = f"{case}: {name} {base} r_obs={r_obs:.1f} th={math.degrees(th):.1f} {type(disc).__name__} {shape} kernel={kernel} tol={tol:.1e}"
+    desc = f"{case}: {name} {base} r_obs={r_obs:.1f} th={math.degrees(th):.1f} {disc} {shape} kernel={kernel} tol={tol:.1e}"
     try:
         tab = G.TabulatedMetric(base, r_max=max(12000.0, 3 * r_obs), max_refinements=1)
         ens.set("kernel", kernel).set("precision", 64)
@@ -97,8 +102,6 @@ for case in range(n_scenes):
     # a ray the integrator gave up on (MaxIters, dt < dtmin, NaN: a flag bit in the record's padding) where the fused kernel did not
     stuck = int(np.sum(((got["flags"] & 0xFFFF) != 0) & ((ref["flags"] & 0xFFFF) == 0) & ~lost(ref["status"])))
     rays_total += n
-    flips_total += flips
-    worst = max(worst, err)
     ill = 0
     if cmp_.any() and err >= X_RTOL * max(1.0, tol / 1e-9):
         # a ray whose end point moves as much when the FUSED kernel is asked for a tenth of the tolerance is ill-conditioned (it
@@ -111,12 +114,38 @@ for case in range(n_scenes):
         e_tab = np.max(np.abs(got["x"] - ref["x"]) / sc2, axis=1)
         e_self = np.max(np.abs(ref2["x"] - ref["x"]) / sc2, axis=1)
         bad_rays = both & (e_tab >= X_RTOL * max(1.0, tol / 1e-9)) & (e_tab > 30.0 * e_self)
+        if isinstance(disc, G.ThinDisc) and shape != "sky":
+            # a ray that meets the disc within 1e-3 of its rim in one trace and passes the rim in the other (to meet the disc
+            # elsewhere, later, with the same status) is a rim flip
+            rim = lambda r_: (np.abs(r_ / max(disc.inner_radius, 1e-9) - 1.0) < 1e-3) | (np.abs(r_ / disc.outer_radius - 1.0) < 1e-3)
+            at_rim = bad_rays & (rim(ref["x"][:, 1]) | rim(got["x"][:, 1]))
+            flips += int(at_rim.sum())
+            bad_rays &= ~at_rim
         ill = int(np.sum(cmp_ & (e_tab >= X_RTOL * max(1.0, tol / 1e-9)))) - int(bad_rays.sum())
+        if bad_rays.any():
+            # A thin disc is a slab of half-thickness gtol·r that the callbacks find by SAMPLING each step (ten points, as the
+            # reference's ContinuousCallback does): a long step across the slab at a steep angle can have every sample outside it
+            # -- in either trace, depending on where its steps happen to fall -- and the ray goes on to meet the disc elsewhere.
+            # A ray on which the table AND the fused kernel agree at a tenth of the tolerance was traced correctly by both
+            # integrands: the disagreement at `tol` is the event sampling's, and is counted with the flips.
+            kw["abstol"] = kw["reltol"] = tol * 0.1
+            got2 = run(tab)
+            kw["abstol"] = kw["reltol"] = tol
+            e_fine = np.max(np.abs(got2["x"] - ref2["x"]) / sc2, axis=1)
+            sampled = bad_rays & (got2["status"] == ref2["status"]) & (e_fine < X_RTOL * max(1.0, tol / 1e-9))
+            flips += int(sampled.sum())
+            bad_rays &= ~sampled
         err = float(e_tab[bad_rays].max()) if bad_rays.any() else 0.0
+        if os.environ.get("SOAK_VERBOSE"):
+            for i in np.nonzero(bad_rays)[0][:4]:
+                print("   ray", i, "status", ref["status"][i], "fused", ref["x"][i], "| fused at tol/10", ref2["x"][i], "| table", got["x"][i], "flags", ref["flags"][i], got["flags"][i],
+                      "lambda", ref["lambda_max"][i], got["lambda_max"][i])
     if os.environ.get("SOAK_VERBOSE") and (stuck or flips):
         for i in np.nonzero(~same | ((got["status"] == G.StatusCodes.NoStatus) & ~lost(ref["status"])))[0][:6]:
             print("   ray", i, "ref", ref["status"][i], ref["x"][i], "flags", ref["flags"][i] if "flags" in ref.dtype.names else "-",
                   "| tab", got["status"][i], got["x"][i], "flags", got["flags"][i] if "flags" in got.dtype.names else "-", "x_init", ref["x_init"][i], "v_init", ref["v_init"][i])
+    flips_total += flips
+    worst = max(worst, err)
     ok = flips <= max(1, int(MAX_FLIP_FRAC * n)) and err < X_RTOL * max(1.0, tol / 1e-9) and stuck == 0
     if ill:
         desc += f" [{ill} ill-conditioned rays set aside]"

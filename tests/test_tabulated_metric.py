@@ -458,3 +458,42 @@ def test_an_inner_radius_inside_the_horizon_moves_the_table_out(G):
         tm = G.TabulatedMetric(f, inner_radius=0.8 * kerr.inner_radius(), isco=kerr.isco(), r_max=500.0)
     assert tm.inner_radius() == pytest.approx(kerr.inner_radius(), rel=1e-9)
     assert tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
+
+
+def test_axion_charge_takes_the_raw_azimuthal_components(G):
+    """g_ϕϕ / sin²θ is not smooth on the axis of a dilaton-axion metric with β != 0 (g_ϕϕ does not vanish there): the fit with the
+    pole factor fails by orders of magnitude, the constructor keeps the raw fit of the same samples; with β = 0 nothing changes."""
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # (the inner radius moves out to the horizon: tested above)
+        tm = G.TabulatedMetric(G.DilatonAxion(1.0, 0.35, 0.16, 0.33))
+        t0 = G.TabulatedMetric(G.DilatonAxion(1.0, 0.5, 0.0, 1.0))
+    assert tm.grid.pole_factor == 0 and t0.grid.pole_factor == 1
+    assert (tm.m_r, tm.n_theta) == (8, 32) and tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8 and tm.errors[2] < 1e-8
+    g, dr, dth = tm.table_jacobian(4.0, 0.05)
+    np.testing.assert_allclose(g, tm.source.metric_components(4.0, 0.05), rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_dilaton_axion_through_the_table_equals_its_fused_kernel(G, ens):
+    """A catalogue metric with an axion charge through the table (raw azimuthal components, range starting at the horizon) against
+    its hand-fused kernel: every pixel of a small image whose rays end away from the hole."""
+    import warnings
+
+    ens.set("kernel", 2).set("precision", 64)
+    base = G.DilatonAxion(1.0, 0.35, 0.16, 0.33)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tm = G.TabulatedMetric(base)
+    x = np.array([0.0, 500.0, math.radians(60), 0.0])
+    d = G.ThinDisc(0.0, 40.0)
+    kw = dict(image_width=96, image_height=64, alpha_lims=(-25, 25), beta_lims=(-15, 15), ensemble=ens)
+    ref = G.prerendergeodesics(base, x, d, 1000.0, **kw)[2].points.ravel()
+    got = G.prerendergeodesics(tm, x, d, 1000.0, **kw)[2].points.ravel()
+    lost = lambda st: (st == G.StatusCodes.WithinInnerBoundary) | (st == G.StatusCodes.NoStatus)
+    same = (ref["status"] == got["status"]) | (lost(ref["status"]) & lost(got["status"])) | (lost(got["status"]) & (ref["x"][:, 1] < 1.03 * tm.inner_radius()))
+    assert (~same).sum() <= 2
+    cmp_ = (ref["status"] == got["status"]) & ~lost(ref["status"])
+    assert cmp_.sum() > 4000
+    np.testing.assert_allclose(got["x"][cmp_][:, 1:3], ref["x"][cmp_][:, 1:3], rtol=1e-6, atol=1e-6)
