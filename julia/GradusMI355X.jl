@@ -293,6 +293,7 @@ function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 
         r_min = max(r_inner * (1 - 1e-3), r0 + 1e-3)
         local table
         previous, last_err = Inf, [Inf, Inf, Inf]
+        raw_azimuth = nothing          # decided by the first fit: store g_ϕϕ, g_tϕ without the sin²θ factor?
         for _ = 0:refinements
             grid = Ref{GrMetricGrid}()
             _check(ccall((:gr_metric_grid_plan, LIB), Int32, (Float64, Float64, Float64, Int32, Int32, Ref{GrMetricGrid}),
@@ -314,6 +315,22 @@ function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 
             err = zeros(Float64, 3)
             _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 grid, samples, table, err))
+            if raw_azimuth === nothing && maximum(err ./ METRIC_TABLE_TOL) > 1e4
+                # g_ϕϕ / sin²θ is not smooth on the axis of every metric (an axion charge -- DilatonAxion with β != 0 -- leaves g_ϕϕ
+                # finite there): the same samples fitted with g_ϕϕ and g_tϕ as they are, kept when two orders better
+                grid2 = Ref(GrMetricGrid(g.r0, g.r_min, g.r_max, g.e_min, g.n_oct, g.m_r, g.n_theta, g.degree, g.fit_nodes, Int32(0),
+                    g.reserved, g.n_r_nodes, g.n_theta_nodes, g.table_doubles))
+                table2, err2 = Vector{Float64}(undef, g.table_doubles), zeros(Float64, 3)
+                _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                    grid2, samples, table2, err2))
+                raw_azimuth = maximum(err2 ./ METRIC_TABLE_TOL) < 1e-2 * maximum(err ./ METRIC_TABLE_TOL)
+                raw_azimuth && ((table, err) = (table2, err2))
+            elseif raw_azimuth === true
+                grid2 = Ref(GrMetricGrid(g.r0, g.r_min, g.r_max, g.e_min, g.n_oct, g.m_r, g.n_theta, g.degree, g.fit_nodes, Int32(0),
+                    g.reserved, g.n_r_nodes, g.n_theta_nodes, g.table_doubles))
+                _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                    grid2, samples, table, err))
+            end
             all(err .<= METRIC_TABLE_TOL) && return table
             # a degree-7 fit gains 2^8 per halving of a smooth function's patches: one that gains less than 16 is looking at a kink
             # or a pole (a horizon inside [r_inner, r_outer], a piecewise-defined function), and more samples will not change that
