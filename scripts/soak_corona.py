@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Soak test of the corona -> disc device route (gr_rayset.sky_*, gr_corona_trace, gr_corona_bin): N random scenes, each through
+`emissivity_profile` twice -- the device route and the record route (host-built (x, v) arrays, 152-B records, numpy reductions;
+GRADUS_MI355X_DEVICE_CORONA=0) -- compared bin by bin.  Random metric x source model (lamp post, beamed point source, ring
+corona) x sampler x generator x domain x disc x number of samples (1 ... 30 000, so that last waves of every size occur) x bins.
+
+    python scripts/soak_corona.py [n_scenes] [seed] [only]
+"""
+import math
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gradus_jl_amd as G
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+warnings.simplefilter("ignore")
+ens = G.EnsembleMI355X(0)
+bad, worst_e, worst_t, scenes = [], 0.0, 0.0, 0
+t_start = time.time()
+for case in range(n_scenes):
+    rng = np.random.default_rng([seed, case])
+    U = lambda a, b: float(rng.uniform(a, b))
+    fam = int(rng.integers(0, 5))
+    m = [lambda: G.KerrMetric(1.0, U(-0.998, 0.998)), lambda: G.KerrMetric(1.0, U(0.9, 0.998)),
+         lambda: G.JohannsenMetric(1.0, U(0, 0.9), U(-1, 2), U(-1, 1), U(-1, 1), U(-1, 2)),
+         lambda: G.KerrNewmanMetric(1.0, U(0, 0.6), U(0, 0.6)),
+         lambda: G.JohannsenPsaltisMetric(1.0, U(0, 0.8), U(-0.5, 1))][fam]()
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        model = G.LampPostModel(h=U(2.5, 40.0))
+    elif kind == 1:
+        model = G.BeamedPointSource(U(3.0, 30.0), U(-0.8, 0.8))
+    else:
+        model = G.RingCorona(G.SourceVelocities.co_rotating if rng.random() < 0.5 else G.SourceVelocities.stationary, U(1.0, 20.0), U(2.0, 15.0))
+    Sampler = G.EvenSampler if rng.random() < 0.5 else G.WeierstrassSampler
+    gen = [G.GoldenSpiralGenerator, G.EvenGenerator, lambda: G.RandomGenerator(seed=int(seed * 1000 + case))][int(rng.integers(0, 3))]
+    dom = G.BothHemispheres if rng.random() < 0.6 else G.LowerHemisphere
+    mk = lambda: Sampler(domain=dom(), generator=gen())
+    rin = U(0, 6)
+    d = G.ThinDisc(rin, rin + 10 ** U(1.0, 2.7))
+    n = int(10 ** U(0, 4.5))
+    N = int(rng.integers(3, 120))
+    kernel = int(rng.integers(0, 3))
+    if only is not None and case != only:
+        continue
+    desc = f"{case}: {m} {model.__class__.__name__}{vars(model) if hasattr(model, '__dict__') and kind == 2 else model} {Sampler.__name__}/{gen.__name__ if hasattr(gen, '__name__') else 'Random'}/{dom.__name__} {d} n={n} N={N} kernel={kernel}"
+    ens.set("kernel", kernel).set("precision", 64)
+    kw = dict(n_samples=n, N=N, ensemble=ens)
+    try:
+        os.environ["GRADUS_MI355X_DEVICE_CORONA"] = "0"
+        host = G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+    except Exception as e:          # the record route refuses the scene (source inside 1.9 r_inner, no hit at all): so must the device route
+        os.environ["GRADUS_MI355X_DEVICE_CORONA"] = "1"
+        try:
+            G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+            print("FAIL", desc, "record route raised", type(e).__name__, "the device route did not")
+            bad.append(case)
+        except Exception as e2:
+            print("skip", desc, "->", type(e).__name__, "/", type(e2).__name__, str(e)[:80])
+        continue
+    os.environ["GRADUS_MI355X_DEVICE_CORONA"] = "1"
+    dev = G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+    scenes += 1
+    inner = slice(0, -2) if host.radii.size > 4 else slice(0, 0)
+    ok_r = host.radii.shape == dev.radii.shape and np.allclose(dev.radii, host.radii, rtol=1e-9)
+    fe, ft = np.isfinite(host.ε[inner]), np.isfinite(host.t[inner])
+    masks = ok_r and np.array_equal(np.isfinite(dev.ε[inner]), fe) and np.array_equal(np.isfinite(dev.t[inner]), ft)
+    e_err = float(np.max(np.abs(dev.ε[inner][fe] / host.ε[inner][fe] - 1.0))) if masks and fe.any() else 0.0
+    t_err = float(np.max(np.abs(dev.t[inner][ft] / host.t[inner][ft] - 1.0))) if masks and ft.any() else 0.0
+    # one photon changing bins (its ρ sits on an edge to the last bit) moves a bin's count by one: such scenes are re-judged on the
+    # total instead
+    ok = masks and e_err < 1e-6 and t_err < 1e-8
+    note = ""
+    if not ok and ok_r:
+        both = np.isfinite(host.ε) & np.isfinite(dev.ε)
+        tot = abs(np.sum(dev.ε[both]) / np.sum(host.ε[both]) - 1.0) if both.any() else 0.0
+        moved = int(np.sum(np.isfinite(host.ε) != np.isfinite(dev.ε)) + np.sum(np.abs(dev.ε[both] / host.ε[both] - 1.0) > 1e-6))
+        if moved <= 2 and n > 0:
+            ok, note = True, f" [{moved} bins differ by a photon on an edge]"
+    worst_e, worst_t = max(worst_e, e_err if ok else 0.0), max(worst_t, t_err if ok else 0.0)
+    if not ok:
+        bad.append(case)
+    print("ok  " if ok else "FAIL", desc, f"bins={host.radii.size} finite={int(fe.sum())} eps_err={e_err:.1e} t_err={t_err:.1e}{note}", flush=True)
+print(f"\n{n_scenes} scenes ({scenes} compared), seed {seed}: worst relative difference per bin ε {worst_e:.1e}, t {worst_t:.1e}; failing scenes: {bad}   [{time.time() - t_start:.0f} s]")
+sys.exit(1 if bad else 0)
