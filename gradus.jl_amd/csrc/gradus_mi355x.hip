@@ -366,11 +366,15 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 //    million one-wave workgroups would turn that into 5e7 global atomics: 31 vs 21 ms at 2048² rays).
 //  * ray arrays in caller order (no tiles, neighbours may differ wildly in length): persistent with
 //    wave-ballot refill, except for launches only a few rays per resident lane deep.
-int resolve_kernel(const gr_ctx* ctx, int64_t n, const Cold& cold)
+//  * a tabulated metric: the lane kernel whatever the source of the rays.  Refilled lanes take rays from anywhere in the set, a
+//    wave's rays then sit in as many patches as it has lanes and most evaluations leave the patch cache for global memory
+//    (10⁶ sky rays of a corona: 170 ms against 84; 2²⁰ rays in random order: 179 against 138).
+int resolve_kernel(const gr_ctx* ctx, int64_t n, const Cold& cold, int metric_id = -1)
 {
     if (ctx->kernel != 2) return (int)ctx->kernel;
     if (cold.out_mode == 2) return 1;
     if (cold.src_mode == 0 && cold.swizzle) return 0;
+    if (metric_id == GR_METRIC_TABULATED) return 0;
     const int64_t resident_lanes = (int64_t)ctx->n_cu * 8 * 64;
     return n < 6 * resident_lanes ? 0 : 1;
 }
@@ -385,7 +389,7 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
     *record = false;
     cold.tile_perm = nullptr;
     cold.tile_cost = nullptr;
-    const int kern = resolve_kernel(ctx, p.n, cold);
+    const int kern = resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);
     // (a tabulated metric's lane kernel orders its tiles longest-first by default: its waves' lifetimes spread 9x around their
     // mean -- the fused kernels' 2.7x -- and the cost it learns is the wave's lifetime, not a step count)
     const bool tab = p.cfg.metric_id == GR_METRIC_TABULATED;
@@ -476,7 +480,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
         return fail(GR_ERR_UNSUPPORTED, "a tabulated metric is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
     if (p.cfg.disc_id == GR_DISC_MESH && (tangent || ctx->precision == 32))
         return fail(GR_ERR_UNSUPPORTED, "a mesh geometry is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
-    const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold);
+    const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);
     const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
     // A table is staged per workgroup: with one-wave workgroups a CU holds 8 copies, so it is staged
@@ -1453,7 +1457,7 @@ static bool plane_on_lane_kernel(gr_ctx* ctx, const gr_config* cfg, const gr_pla
     Cold cd;
     plane_params(ctx, p, cd, cfg, plane, range);
     cd.out_mode = out_mode;
-    return resolve_kernel(ctx, range->count, cd) == 0;
+    return resolve_kernel(ctx, range->count, cd, cfg->metric_id) == 0;
 }
 
 int32_t gr_render(gr_ctx* ctx, const gr_config* cfg, const gr_plane* plane, const gr_pointfunction* pf,

@@ -169,6 +169,9 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
             ens_.set("tangent_pairs", prev)
         return out
 
+    # `pf` holds raw pointers into the plunging table's arrays: they live as long as the tracer does, whoever built the point
+    # function (a caller that passes a temporary `ConstPointFunctions.redshift(...)` would otherwise leave them dangling)
+    trace._keep = (keep_pf, redshift_pf, config, cfg)
     trace.endpoints = endpoints
     # The tangent build of the kernels exists for the catalogue metrics; a tabulated one (a user-defined metric) takes the route
     # of every tracer without `.tangent`: safeguarded Newton on ray summaries, Jacobians by central differences.

@@ -200,6 +200,8 @@ elif which == "corona":
     # emissivity_profile(m, d, LampPostModel(h = 10); n_samples = 10⁶, golden-spiral EvenSampler on both hemispheres): the sky rays
     # are formed on the device (src_mode 3), traced, reduced (gr_corona_trace) and binned (gr_corona_bin)
     m = G.KerrMetric(1.0, 0.998)
+    if os.environ.get("CORONA_TAB"):          # the same metric through a table
+        m = G.TabulatedMetric(m)
     d = G.ThinDisc(0.0, 500.0)
     model = G.LampPostModel(h=10.0)
     s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
