@@ -316,3 +316,25 @@ def test_image_width_not_divisible_by_the_number_of_devices(G, ens):
     _, _, c1 = G.prerendergeodesics(m, X_FAR, d, 2000.0, ensemble=ens, **kw)
     _, _, c3 = G.prerendergeodesics(m, X_FAR, d, 2000.0, ensemble=three, **kw)
     assert np.asarray(c1.points).tobytes() == np.asarray(c3.points).tobytes()
+
+
+def test_tabulated_metric_through_a_multi_ensemble(G, ens, multi4):
+    """A user-defined metric (GR_METRIC_TABULATED) over several contexts: every context stages its own copy of the table; the
+    fused image, the end points of a ray array and a corona's sky rays equal the one-context results bit for bit."""
+    tab = G.TabulatedMetric(G.KerrMetric(1.0, 0.9))
+    d = G.ThinDisc(tab.isco(), 50.0)
+    pf = G.ConstPointFunctions.redshift(tab, X_FAR, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
+    kw = dict(image_width=128, image_height=96, alpha_lims=ALIMS, beta_lims=BLIMS, pf=pf)
+    _, _, ref = G.rendergeodesics(tab, X_FAR, d, 2000.0, ensemble=ens, **kw)
+    _, _, img = G.rendergeodesics(tab, X_FAR, d, 2000.0, ensemble=multi4, **kw)
+    assert np.isfinite(ref).sum() > 500 and img.tobytes() == ref.tobytes()
+    rng = np.random.default_rng(3)
+    vs = G.map_impact_parameters(tab, X_FAR, rng.uniform(-20, 20, 3001), rng.uniform(-12, 12, 3001))
+    a = G.tracegeodesics(tab, X_FAR, vs, d, 2000.0, ensemble=ens)
+    b = G.tracegeodesics(tab, X_FAR, vs, d, 2000.0, ensemble=multi4)
+    assert a.tobytes() == b.tobytes()
+    # a corona's sky source is one context's work: a multi ensemble uses its first context
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    p1 = G.emissivity_profile(tab, G.ThinDisc(0.0, 200.0), G.LampPostModel(h=8.0), sampler=s, n_samples=4000, N=20, ensemble=ens)
+    p4 = G.emissivity_profile(tab, G.ThinDisc(0.0, 200.0), G.LampPostModel(h=8.0), sampler=s, n_samples=4000, N=20, ensemble=multi4)
+    np.testing.assert_array_equal(p1.ε, p4.ε)
