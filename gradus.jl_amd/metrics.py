@@ -623,6 +623,40 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
         from .special_radii import Jet
 
         rv = r.v if isinstance(r, Jet) else r
+        if np.ndim(rv):
+            # an array of radii (the generic ISCO's downward scan): every radius in its own patch -- grouped, one evaluation per
+            # group on that group's slice of r
+            rv = np.asarray(rv, dtype=np.float64)
+            t_ = self.table
+            r0_, e_min_, n_oct_, m_r_ = t_[2], int(t_[3]), int(t_[4]), int(t_[5])
+            xx = np.maximum(rv - r0_, 2.0 ** e_min_)
+            ee = np.minimum(np.floor(np.log2(xx)).astype(np.int64), e_min_ + n_oct_ - 1)
+            jj = np.minimum(((xx / np.exp2(ee) - 1.0) * m_r_).astype(np.int64), m_r_ - 1)
+            key = (ee - e_min_) * m_r_ + jj
+            outs = [np.empty(rv.shape) for _ in range(5)]
+            jets = isinstance(r, Jet)
+            if jets:
+                o_d, o_dd = [np.empty(rv.shape) for _ in range(5)], [np.empty(rv.shape) for _ in range(5)]
+            pick = lambda z, sel: z[sel] if isinstance(z, np.ndarray) else z
+            for kk in np.unique(key):
+                sel = key == kk
+                # (within one patch the evaluation below is vectorised: the patch is chosen from the group's largest radius)
+                sub = Jet(rv[sel], pick(r.d, sel), pick(r.dd, sel)) if jets else rv[sel]
+                res = self._table_components_one_patch(sub, theta)
+                for c in range(5):
+                    if jets:
+                        z = Jet.lift(res[c])
+                        outs[c][sel], o_d[c][sel], o_dd[c][sel] = z.v, z.d, z.dd
+                    else:
+                        outs[c][sel] = res[c]
+            return tuple(Jet(outs[c], o_d[c], o_dd[c]) for c in range(5)) if jets else tuple(outs)
+        return self._table_components_one_patch(r, theta)
+
+    def _table_components_one_patch(self, r, theta):
+        """(r: a float, a Jet, or an array / Jet of arrays that lies within ONE radial patch)"""
+        from .special_radii import Jet
+
+        rv = r.v if isinstance(r, Jet) else r
         t = self.table
         r0, e_min, n_oct, m_r, n_th = t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6])
         w = abs(((theta + math.pi) % (2.0 * math.pi)) - math.pi)

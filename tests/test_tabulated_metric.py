@@ -497,3 +497,15 @@ def test_dilaton_axion_through_the_table_equals_its_fused_kernel(G, ens):
     cmp_ = (ref["status"] == got["status"]) & ~lost(ref["status"])
     assert cmp_.sum() > 4000
     np.testing.assert_allclose(got["x"][cmp_][:, 1:3], ref["x"][cmp_][:, 1:3], rtol=1e-6, atol=1e-6)
+
+
+def test_isco_of_a_bare_callable_comes_from_the_table(G):
+    """A callable brings no `isco`: the generic ISCO search (special-radii.jl:14-60: a downward scan of E(r) over 19 800 radii,
+    then a bracketing root find of dE/dr) runs on the table's own polynomials -- every radius of the scan in its own patch."""
+    kerr = G.KerrMetric(1.0, 0.9)
+    tm = G.TabulatedMetric(lambda r, th: kerr._components(r, np.sin(th), np.cos(th)), inner_radius=kerr.inner_radius())
+    assert tm.isco() == pytest.approx(kerr.isco(), rel=1e-8)
+    rs = np.array([1.6, 2.5, 7.0, 90.0])
+    got = tm._table_components(rs, 1.2)
+    for k in range(5):
+        np.testing.assert_allclose(got[k], [kerr.metric_components(r, 1.2)[k] for r in rs], rtol=1e-9)
