@@ -572,7 +572,7 @@ def _plunging_table(m, ensemble):
     try:
         key = (type(m).__name__, int(m.metric_id)) + tuple(float(p) for p in m.abi_params())
         if m.metric_id == 11:
-            key += (id(m),)
+            key += (float(m.table[8]),)          # the table's build id (unique per fit; an id() is reused once its object is gone)
     except Exception:          # a metric without flat parameters: no reuse
         return tuple(interpolate_plunging_velocities(m, ensemble=ensemble))
     if key not in _PLUNGING_TABLES:

@@ -605,6 +605,17 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
         """(r may be a special_radii.Jet: the generic ISCO / plunging set-up differentiates through here)"""
         if isinstance(self.source, AbstractMetric) and hasattr(self.source, "_components"):
             return self.source._components(r, s, c)
+        from .special_radii import Jet
+
+        if not isinstance(r, Jet):
+            # values only (disc kinematics of the host reductions, on arrays of points): the callable itself, for any shapes
+            th = np.arctan2(s, c)
+            try:
+                return tuple(np.asarray(x, dtype=np.float64) if np.ndim(x) else float(x) for x in self._f(r, th))
+            except (TypeError, ValueError):
+                rr, tt = np.broadcast_arrays(np.asarray(r, dtype=np.float64), np.asarray(th, dtype=np.float64))
+                out = np.array([self._f(float(a), float(b)) for a, b in zip(rr.ravel(), tt.ravel())]).reshape(rr.shape + (5,))
+                return tuple(out[..., k] for k in range(5))
         return self._table_components(r, math.atan2(s, c))
 
     def table_jacobian(self, r, theta):

@@ -33,6 +33,11 @@ for case in range(n_scenes):
          lambda: G.JohannsenMetric(1.0, U(0, 0.9), U(-1, 2), U(-1, 1), U(-1, 1), U(-1, 2)),
          lambda: G.KerrNewmanMetric(1.0, U(0, 0.6), U(0, 0.6)),
          lambda: G.JohannsenPsaltisMetric(1.0, U(0, 0.8), U(-0.5, 1))][fam]()
+    if os.environ.get("SOAK_CALLABLE"):
+        # the same metric as a user would bring it: a bare callable through a table (its ISCO and its disc kinematics come from
+        # the table / the callable), both routes on the tabulated kernels
+        base_ = m
+        m = G.TabulatedMetric(lambda r, th, b=base_: b._components(r, np.sin(th), np.cos(th)), inner_radius=base_.inner_radius(), max_refinements=1)
     kind = int(rng.integers(0, 3))
     if kind == 0:
         model = G.LampPostModel(h=U(2.5, 40.0))
@@ -88,6 +93,9 @@ for case in range(n_scenes):
     worst_e, worst_t = max(worst_e, e_err if ok else 0.0), max(worst_t, t_err if ok else 0.0)
     if not ok:
         bad.append(case)
+    if not ok and os.environ.get("SOAK_VERBOSE"):
+        np.set_printoptions(linewidth=250, precision=6)
+        print("   radii", host.radii, "\n   host ε", host.ε, "\n   dev  ε", dev.ε, "\n   host t", host.t, "\n   dev  t", dev.t, "\n   isco", m.isco())
     print("ok  " if ok else "FAIL", desc, f"bins={host.radii.size} finite={int(fe.sum())} eps_err={e_err:.1e} t_err={t_err:.1e}{note}", flush=True)
 print(f"\n{n_scenes} scenes ({scenes} compared), seed {seed}: worst relative difference per bin ε {worst_e:.1e}, t {worst_t:.1e}; failing scenes: {bad}   [{time.time() - t_start:.0f} s]")
 sys.exit(1 if bad else 0)

@@ -509,3 +509,6 @@ def test_isco_of_a_bare_callable_comes_from_the_table(G):
     got = tm._table_components(rs, 1.2)
     for k in range(5):
         np.testing.assert_allclose(got[k], [kerr.metric_components(r, 1.2)[k] for r in rs], rtol=1e-9)
+    # what the corona's disc kinematics evaluate on arrays of bin radii
+    np.testing.assert_allclose(G.corona.circular_fourvelocity(tm, rs[1:]), G.corona.circular_fourvelocity(kerr, rs[1:]), rtol=1e-7)
+    np.testing.assert_allclose(G.corona._proper_area(tm, rs, math.pi / 2), G.corona._proper_area(kerr, rs, math.pi / 2), rtol=1e-9)
