@@ -512,3 +512,27 @@ def test_isco_of_a_bare_callable_comes_from_the_table(G):
     # what the corona's disc kinematics evaluate on arrays of bin radii
     np.testing.assert_allclose(G.corona.circular_fourvelocity(tm, rs[1:]), G.corona.circular_fourvelocity(kerr, rs[1:]), rtol=1e-7)
     np.testing.assert_allclose(G.corona._proper_area(tm, rs, math.pi / 2), G.corona._proper_area(kerr, rs, math.pi / 2), rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_line_profile_of_a_tabulated_metric(G, ens, tab_kerr):
+    """lineprofile(bins, ε, m, u, d, BinningMethod()) fused on the device (C5's route: separable polar plane, LDS histogram,
+    persistent kernel) through the table against the fused Kerr kernel, for a power law and for an emissivity profile that itself
+    came from a corona traced through the table."""
+    ens.set("kernel", 2).set("precision", 64)
+    kerr = G.KerrMetric(1.0, 0.998)
+    x = np.array([0.0, 1000.0, math.radians(60), 0.0])
+    d = G.ThinDisc(0.0, 400.0)
+    bins = np.linspace(0.1, 1.5, 120)
+    plane = G.PolarPlane(G.GeometricGrid(), Nr=256, Nθ=256, r_max=60.0)
+    kw = dict(plane=plane, maxrₑ=50.0, callback=G.domain_upper_hemisphere(), ensemble=ens)
+    _, fa = G.lineprofile(bins, G.PowerLawEmissivity(3), kerr, x, d, G.BinningMethod(), **kw)
+    _, fb = G.lineprofile(bins, G.PowerLawEmissivity(3), tab_kerr, x, d, G.BinningMethod(), **kw)
+    assert fa.sum() == pytest.approx(1.0) and np.count_nonzero(fa) > 60
+    np.testing.assert_allclose(fb, fa, atol=2e-6 * fa.max())
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    pa = G.emissivity_profile(kerr, d, G.LampPostModel(h=6.0), sampler=s, n_samples=20_000, N=60, ensemble=ens)
+    pb = G.emissivity_profile(tab_kerr, d, G.LampPostModel(h=6.0), sampler=s, n_samples=20_000, N=60, ensemble=ens)
+    _, ga = G.lineprofile(bins, pa, kerr, x, d, G.BinningMethod(), **kw)
+    _, gb = G.lineprofile(bins, pb, tab_kerr, x, d, G.BinningMethod(), **kw)
+    np.testing.assert_allclose(gb, ga, atol=1e-4 * ga.max())
