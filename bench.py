@@ -106,6 +106,7 @@ def baseline_configs(G, ens, reps=3):
         C4            JohannsenMetric(a = 0.7, α13 = 2, ϵ3 = 1) 1024², ThinDisc, interpolated redshift   fp64 fused kernel
         C5_f64 / f32  line profile, 4096² polar-plane rays, tol 1e-9 (fp64) / 1e-5 (fp32 kernels)
         C2_tabulated / C4_tabulated   the same two metrics as USER-DEFINED metrics: through GR_METRIC_TABULATED's table
+        corona_1e6    the per-ray half of emissivity_profile at 10⁶ sky samples on the device (not a BASELINE configuration)
     """
     out = {}
     ALIMS, BLIMS = (-60.0, 60.0), (-35.0, 35.0)
@@ -163,6 +164,23 @@ def baseline_configs(G, ens, reps=3):
         out[name]["table"] = {"grid_m_r_n_theta": [tm.m_r, tm.n_theta], "mb": tm.table.nbytes / 1e6, "fit_error_estimates": list(tm.errors)}
         ref = name.split("_")[0]
         out[name]["slowdown_vs_fused"] = out[name]["ms"] / out[ref]["ms"]
+    # corona -> disc on the device (<= 10 ms at 10⁶ samples): emissivity_profile(m, d, LampPostModel(h = 10);
+    # n_samples = 10⁶, golden-spiral EvenSampler on both hemispheres, N = 100) -- sky rays formed, traced, reduced, binned on the GPU
+    sampler = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    disc, lamp, n_sky = G.ThinDisc(0.0, 500.0), G.LampPostModel(h=10.0), 1_000_000
+    G.corona.device_radial_profile(kerr, disc, lamp, sampler=sampler, n_samples=10_000, N=100, ensemble=ens)      # plunging table, contexts
+    best = None
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        prof, st = G.corona.device_radial_profile(kerr, disc, lamp, sampler=sampler, n_samples=n_sky, N=100, ensemble=ens, stats=True)
+        wall = (time.perf_counter() - t0) * 1e3
+        if rep and (best is None or st.call_ms < best[1]):
+            best = (st.kernel_ms, st.call_ms, wall, (st.accepted_steps + st.rejected_steps) / n_sky)
+    price("corona_1e6", "k_trace_persistent<gr::KerrFamily<false>, 1>", n_sky, best[0])
+    out["corona_1e6"].update({"device_call_ms": best[1], "python_wall_ms_incl_binning_and_host_tail": best[2], "steps_per_ray": best[3],
+                              "finite_bins": int(np.isfinite(prof.ε).sum()),
+                              "what": "emissivity_profile(KerrMetric(a = 0.998), ThinDisc(0, 500), LampPostModel(h = 10); n_samples = 10^6, N = 100): "
+                                      "ms = trace kernel, device_call_ms = staging + trace + min/max reduction + copy back"})
     return out
 
 
