@@ -2333,7 +2333,8 @@ struct PfDev {
 // (not in the kernarg segment) and is re-read at each use, so that its ~60 scalars are not kept
 // live in SGPRs across the hot step loop.
 struct Cold {
-    int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays, 3 = a source's sky (gr_rayset.sky_*)
+    int32_t src_mode;         // 0 = image plane, 1 = (x, v) arrays, 2 = impact-parameter arrays (3 = a source's sky, gr_rayset.sky_*: on the host side only --
+                              // launch_trace has a small kernel write the sky's velocities and hands the trace kernels src_mode 1)
     int32_t out_mode;         // 0 = fused point function image, 1 = endpoint records, 2 = binned line profile, 3 = (g, ρ) pairs, 4 = (g, ρ, t, status), 5 = the same with ∂/∂α, ∂/∂β (tangent build only)
     int32_t swizzle;          // log2 rows of the pixel tile a wave owns: 3 = 8 x 8, 4 = 16 x 4 (0 = none)
     int32_t idx32;            // 1 = every ray / pixel index fits 31 bits: 32-bit divisions in the index maps
@@ -3161,33 +3162,6 @@ struct Ray {
             const real b = be * iro, a = al * iro;
             const real pr = -rcp_full(sqrt_fast(1.0 + a * a + b * b));
             const real pb[4] = { 1.0, pr, b * pr, a * pr };
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                x0[q] = p.plane.x_obs[q];
-                v0[q] = p.plane.Mx[q * 4 + 0] * pb[0] + p.plane.Mx[q * 4 + 1] * pb[1] + p.plane.Mx[q * 4 + 2] * pb[2]
-                        + p.plane.Mx[q * 4 + 3] * pb[3];
-            }
-        } else if (p.src_mode == 3) {
-            // sample_position_direction_velocity for a source at one position (corona-models.jl:1-33): sample number jl + 1 ->
-            // (θ, ϕ) on the source's sky (samplers.jl:30-44) -> k̂ -> v = Mx (1, k̂) (sky_angles_to_velocity, samplers.jl:81-99,
-            // with the tetrad and the Jacobian folded into Mx on the host)
-            const double n = (double)p.plane.width;
-            const double idx = (double)(jl + 1);
-            const double i = p.sky_generator == 0 ? idx : p.sky_generator == 1 ? idx / n : p.sky_i[jl];
-            double el;
-            if (p.sky_sampler == 2) {
-                const double ph = 2.0 * ::atan(::sqrt(p.sky_resolution / i));
-                const bool even = (::floor(i) == i) && (::fmod(i, 2.0) == 0.0);
-                el = (!p.sky_both || even) ? ph : 3.14159265358979323846 - ph;
-            } else {
-                const double u = i / n;
-                el = p.sky_both ? ::acos(1.0 - 2.0 * u) : ::acos(1.0 - u);
-            }
-            const double az_raw = (p.sky_generator == 0 ? 3.14159265358979323846 * (1.0 + 2.2360679774997896964) : 6.28318530717958647692) * i;
-            double az = ::fmod(az_raw, 6.28318530717958647692);
-            if (az < 0.0) az += 6.28318530717958647692;
-            const double se = ::sin(el), ce = ::cos(el), sa = ::sin(az), ca = ::cos(az);
-            const real pb[4] = { 1.0, (real)(-(se * ca)), (real)(-(se * sa)), (real)(-ce) };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 x0[q] = p.plane.x_obs[q];

@@ -112,6 +112,8 @@ struct gr_ctx {
     uint64_t mesh_fp = 0;
     int64_t mesh_n = -1;
     std::vector<double> mesh_host;
+    double* d_sky = nullptr;               // a sky source's (x, v) arrays, written by k_sky_velocities for the trace kernels
+    size_t sky_bytes = 0;
     double* d_corona = nullptr;            // gr_corona_trace: (g, ρ, t, status) per ray, kept for gr_corona_bin
     size_t corona_bytes = 0;
     int64_t corona_n = -1, corona_hits = 0;
@@ -453,10 +455,83 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
 unsigned long long* g_debug_timeline = nullptr;
 #endif
 
+extern "C++" {
+namespace {
+// Rays from a source into its sky (gr_rayset.sky_*): sample_position_direction_velocity for a source at one position
+// (corona-models.jl:1-33).  Sample number j + 1 -> (θ, ϕ) on the source's sky (samplers.jl:30-44) -> k̂ -> v = Mx (1, k̂)
+// (sky_angles_to_velocity, samplers.jl:81-99, the tetrad and the Jacobian folded into Mx on the host).  A kernel of its own
+// that writes x (once) and v (32 B per ray) for the trace kernels to read as ray arrays: inside Ray::initial_conditions the
+// branch -- libm's double-precision sin / cos / acos / atan / fmod -- cost every persistent kernel 6 % whether taken or not
+// (C5 through the persistent kernel 58.2 -> 61.5 ms: SGPR spills in the refill path); 32 MB through HBM at 10⁶ rays cost 10 µs.
+struct SkyParams {
+    double x_obs[4], Mx[16];
+    int64_t n;
+    int32_t sampler, both, generator, reserved;
+    double resolution;
+    const double* sky_i;
+};
+__global__ void __launch_bounds__(256) k_sky_velocities(const SkyParams p, double* out)      // out: x_obs[4], then v[n][4]
+{
+    const int64_t jl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jl == 0)
+        for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
+    if (jl >= p.n) return;
+    const double n = (double)p.n;
+    const double idx = (double)(jl + 1);
+    const double i = p.generator == 0 ? idx : p.generator == 1 ? idx / n : p.sky_i[jl];
+    double el;
+    if (p.sampler == 2) {
+        const double ph = 2.0 * ::atan(::sqrt(p.resolution / i));
+        const bool even = (::floor(i) == i) && (::fmod(i, 2.0) == 0.0);
+        el = (!p.both || even) ? ph : 3.14159265358979323846 - ph;
+    } else {
+        const double u = i / n;
+        el = p.both ? ::acos(1.0 - 2.0 * u) : ::acos(1.0 - u);
+    }
+    const double az_raw = (p.generator == 0 ? 3.14159265358979323846 * (1.0 + 2.2360679774997896964) : 6.28318530717958647692) * i;
+    double az = ::fmod(az_raw, 6.28318530717958647692);
+    if (az < 0.0) az += 6.28318530717958647692;
+    const double se = ::sin(el), ce = ::cos(el), sa = ::sin(az), ca = ::cos(az);
+    const double pb[4] = { 1.0, -(se * ca), -(se * sa), -ce };
+    double* v = out + 4 + 4 * jl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = p.Mx[q * 4 + 0] * pb[0] + p.Mx[q * 4 + 1] * pb[1] + p.Mx[q * 4 + 2] * pb[2] + p.Mx[q * 4 + 3] * pb[3];
+}
+}  // namespace
+}  // extern "C++"
+
+// a sky source -> ray arrays in the context's sky buffer (ordered against earlier launches that read it like the staged tables)
+static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t stream)
+{
+    int32_t rc;
+    if ((rc = tables_acquire(ctx, stream)) != GR_OK) return rc;
+    if ((rc = ensure((void**)&ctx->d_sky, &ctx->sky_bytes, sizeof(double) * (4 + 4 * (size_t)p.n))) != GR_OK) return rc;
+    SkyParams sp;
+    std::memcpy(sp.x_obs, cold.plane.x_obs, sizeof sp.x_obs);
+    std::memcpy(sp.Mx, cold.plane.Mx, sizeof sp.Mx);
+    sp.n = p.n;
+    sp.sampler = cold.sky_sampler; sp.both = cold.sky_both; sp.generator = cold.sky_generator; sp.reserved = 0;
+    sp.resolution = cold.sky_resolution;
+    sp.sky_i = cold.sky_i;
+    hipLaunchKernelGGL(k_sky_velocities, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, sp, ctx->d_sky);
+    GR_HIP(hipGetLastError());
+    cold.src_mode = 1;
+    cold.x = ctx->d_sky;
+    cold.x_stride = 0;
+    cold.v = ctx->d_sky + 4;
+    cold.sky_i = nullptr;
+    return GR_OK;
+}
+
 int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t stream)
 {
     Cold cold = cold_in;
     cold.winding_plane = p.cfg.winding_plane;
+    const bool sky = cold.src_mode == 3;
+    if (sky && p.n > 0) {
+        const int32_t src = sky_prepare(ctx, p, cold, stream);
+        if (src != GR_OK) return src;
+    }
     bool lpt_record = false;
     if (p.n > 0) {
         const int32_t lrc = lpt_prepare(ctx, p, cold, stream, &lpt_record);
@@ -513,7 +588,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     const hipError_t le = fn(knobs.kernel, knobs.block, knobs.n_cu, knobs.waves_per_simd, knobs.queue, &p, stream);
     if (le != hipSuccess) return fail(GR_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
     if (stream == ctx->stream) GR_HIP(hipEventRecord(ctx->ev_k, stream));      // host variants: where the kernel ends
-    if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0 || p.cfg.metric_id == GR_METRIC_TABULATED) {
+    if (p.disc_table || p.chart_table || cold.pf.n_plunge > 0 || p.cfg.metric_id == GR_METRIC_TABULATED || sky) {
         const int32_t trc = tables_release(ctx, stream);
         if (trc != GR_OK) return trc;
     }
@@ -678,6 +753,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_chart_table) (void)hipFree(c->d_chart_table);
     if (c->d_metric_table) (void)hipFree(c->d_metric_table);
     if (c->d_corona) (void)hipFree(c->d_corona);
+    if (c->d_sky) (void)hipFree(c->d_sky);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
