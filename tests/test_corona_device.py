@@ -237,3 +237,34 @@ def test_a_million_samples_stay_on_the_device(G, ens):
     small = K.device_radial_profile(m, d, model, sampler=s, n_samples=20_000, N=100, ensemble=ens)
     r = np.geomspace(2.0, 200.0, 12)
     np.testing.assert_allclose(small.emissivity_at(r) * 50.0, prof.emissivity_at(r), rtol=0.25)
+
+
+@pytest.mark.gpu
+def test_corona_through_the_fp32_kernels(G, ens):
+    """`precision 32` (the kernels of the C5 tolerance sweep) under a corona: the sky rays arrive as fp64 arrays, the energy ratio
+    against a moving source is evaluated in single precision -- the profile follows the fp64 one to the tolerance asked."""
+    K = G.corona
+    m = G.KerrMetric(1.0, 0.9)
+    d = G.ThinDisc(0.0, 300.0)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    for model in (G.LampPostModel(h=8.0), G.BeamedPointSource(10.0, 0.4)):
+        ens.set("kernel", 2).set("precision", 64)
+        a = K.device_radial_profile(m, d, model, sampler=s, n_samples=40_000, N=30, ensemble=ens)
+        ens.set("precision", 32)
+        try:
+            b = K.device_radial_profile(m, d, model, sampler=s, n_samples=40_000, N=30, ensemble=ens, abstol=1e-5, reltol=1e-5)
+        finally:
+            ens.set("precision", 64)
+        # (ρ_min is the innermost hit, a ray that skims the horizon: the edges built from it move by its fp32 noise, and a few
+        # photons change bins with them)
+        np.testing.assert_allclose(b.radii, a.radii, rtol=3e-2)
+        # Compared beyond r = 16: at tolerance 1e-5 the steps near the hole are longer than the disc's slab (half-thickness gtol r)
+        # is thick, and the callback's ten samples per step miss crossings there -- in fp64 at 1e-5 exactly as in fp32, and in the
+        # reference's ContinuousCallback by the same mechanism (a third of the photons inside r = 5); not a property of the kernels
+        r = np.geomspace(16.0, 0.5 * a.radii[-1], 10)
+        np.testing.assert_allclose(b.emissivity_at(r), a.emissivity_at(r), rtol=3e-2)
+        np.testing.assert_allclose(b.coordtime_at(r), a.coordtime_at(r), rtol=1e-3)
+        ens.set("precision", 64)
+        c = K.device_radial_profile(m, d, model, sampler=s, n_samples=40_000, N=30, ensemble=ens, abstol=1e-5, reltol=1e-5)
+        ri = np.array([3.0, 4.0, 6.0])
+        np.testing.assert_allclose(b.emissivity_at(ri), c.emissivity_at(ri), rtol=0.4)       # fp32 and fp64 at the SAME tolerance lose the same share there (which photons: a matter of step placement)
