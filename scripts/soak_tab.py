@@ -141,7 +141,7 @@ for case in range(n_scenes):
             bad_rays &= ~at_rim
         ill = int(np.sum(cmp_ & (e_tab >= X_RTOL * max(1.0, tol / 1e-9)))) - int(bad_rays.sum())
         if bad_rays.any():
-            # A thin disc is a slab of half-thickness gtol·r that the callbacks find by SAMPLING each step (ten points, as the
+            # A thin disc is a slab of half-thickness gtol·r that the callbacks find by SAMPLING each step (eight points, as the
             # reference's ContinuousCallback does): a long step across the slab at a steep angle can have every sample outside it
             # -- in either trace, depending on where its steps happen to fall -- and the ray goes on to meet the disc elsewhere.
             # A ray on which the table AND the fused kernel agree at a tenth of the tolerance was traced correctly by both

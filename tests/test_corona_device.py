@@ -259,7 +259,7 @@ def test_corona_through_the_fp32_kernels(G, ens):
         # photons change bins with them)
         np.testing.assert_allclose(b.radii, a.radii, rtol=3e-2)
         # Compared beyond r = 16: at tolerance 1e-5 the steps near the hole are longer than the disc's slab (half-thickness gtol r)
-        # is thick, and the callback's ten samples per step miss crossings there -- in fp64 at 1e-5 exactly as in fp32, and in the
+        # is thick, and the callback's eight samples per step miss crossings there -- in fp64 at 1e-5 exactly as in fp32, and in the
         # reference's ContinuousCallback by the same mechanism (a third of the photons inside r = 5); not a property of the kernels
         r = np.geomspace(16.0, 0.5 * a.radii[-1], 10)
         np.testing.assert_allclose(b.emissivity_at(r), a.emissivity_at(r), rtol=3e-2)
