@@ -1052,7 +1052,8 @@ points ray by ray:
   1. `KerrMetric` on `EnsembleMI355X` against `EnsembleEndpointThreads` (status equal on all but disc-rim rays, positions to 1e-6);
   2. the same through `rendergeodesics` with the redshift point function (the fused path against Gradus' `apply_to_image!`);
   3. a user-defined metric (a struct with only `metric_components` and `inner_radius`) on the device -- through the table -- against
-     `KerrMetric` on the CPU, and the table against `Gradus.metric_jacobian` at a point.
+     `KerrMetric` on the CPU, and the table against `Gradus.metric_jacobian` at a point;
+  4. a lamp-post emissivity profile through `emissivity_profile_mi355x` against `Gradus.emissivity_profile` on the same samples.
 Throws with a description of the first disagreement; returns `true` otherwise.
 """
 function selftest(; device = 0, verbose = true)
@@ -1095,6 +1096,18 @@ function selftest(; device = 0, verbose = true)
     (maximum(abs.(g .- gc) ./ abs.(gc)) < 1e-10 && maximum(abs.(dr .- jac[:, 1])) < 1e-8 && maximum(abs.(dth .- jac[:, 2])) < 1e-8) ||
         error("selftest (tabulated metric): the table disagrees with Gradus.metric_jacobian at (6, 1.2)")
     compare(endpoints(um, ens), cpu, "user-defined metric through the table")
+    # 4. the corona route: golden-spiral sampling is deterministic, so the device's profile and Gradus' own (CPU threads, the same
+    #    samples) must agree bin by bin except where one photon sits on a bin edge
+    model, dc = LampPostModel(h = 10.0), ThinDisc(0.0, 400.0)
+    sampler = Gradus.EvenSampler(Gradus.BothHemispheres(), Gradus.GoldenSpiralGenerator())
+    p_dev = emissivity_profile_mi355x(ens, m, dc, model; n_samples = 2000, sampler = sampler, N = 20)
+    p_cpu = Gradus.emissivity_profile(m, dc, model; n_samples = 2000, sampler = sampler, N = 20)
+    inner = 1:(length(p_cpu.radii)-2)                       # (the outermost edges hang on the last bit of the largest radius)
+    okb = [i for i in inner if isfinite(p_cpu.ε[i]) && isfinite(p_dev.ε[i])]
+    (maximum(abs.(p_dev.radii ./ p_cpu.radii .- 1)) < 1e-6 && length(okb) >= 10 &&
+     count(i -> abs(p_dev.ε[i] / p_cpu.ε[i] - 1) > 1e-5, okb) <= 2) ||
+        error("selftest (corona): the device's emissivity profile differs from Gradus.emissivity_profile")
+    say("corona: emissivity profile agrees on $(length(okb)) bins")
     true
 end
 
