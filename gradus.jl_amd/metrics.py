@@ -532,6 +532,10 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
                 _lib.check(L.gr_metric_table_fit(grid2, samples.ctypes.data, table2.ctypes.data, err2))
                 if miss(tuple(err2)) < 1e-2 * miss(tuple(err)):
                     pole_factor, grid, table, err = False, grid2, table2, err2
+                    warnings.warn("TabulatedMetric: g_ϕϕ / sin²θ is not smooth on the polar axis of this metric (g_ϕϕ does not vanish there); "
+                                  "g_ϕϕ and g_tϕ are tabulated as they are.  Where g_ϕϕ passes through zero next to the axis the table's "
+                                  "absolute accuracy is no relative one: rays that graze the axis within a few milliradians end up to "
+                                  "1e-2 off in ϕ (DESIGN.md §5c)", stacklevel=2)
             previous = getattr(self, "errors", None)
             self.grid, self.table, self.errors = grid, table, tuple(err)
             if err[0] <= tol and err[1] <= dtol and err[2] <= dtol:
