@@ -447,6 +447,10 @@ def tracing_configuration(
             raise NotImplementedError(f"trace {type(trace).__name__} has no device implementation")
     if solver != "Tsit5":
         raise NotImplementedError("the device integrator is Tsit5 (configuration.jl:99)")
+    if q != 0.0 and getattr(m, "metric_id", None) == 11:
+        # the Lorentz force on a charged test particle is a term of the Kerr-Newman kernels (kerr-newman-ad.jl:66-100): a table of
+        # metric components knows nothing of the vector potential
+        raise NotImplementedError("charged test particles (q != 0) are traced by KerrNewmanMetric's own kernels, not through a TabulatedMetric")
     if save_on:
         raise ValueError("Cannot use `EnsembleMI355X` with `save_on` (cf. tracing.jl:159-161)")
     if ensemble is None:

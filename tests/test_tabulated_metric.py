@@ -536,3 +536,11 @@ def test_line_profile_of_a_tabulated_metric(G, ens, tab_kerr):
     _, ga = G.lineprofile(bins, pa, kerr, x, d, G.BinningMethod(), **kw)
     _, gb = G.lineprofile(bins, pb, tab_kerr, x, d, G.BinningMethod(), **kw)
     np.testing.assert_allclose(gb, ga, atol=1e-4 * ga.max())
+
+
+def test_charged_test_particles_are_not_traced_through_a_table(G):
+    kn = G.KerrNewmanMetric(1.0, 0.5, 0.3)
+    tm = G.TabulatedMetric(kn, m_r=4, n_theta=8, max_refinements=0, strict=False, r_max=200.0)
+    x = np.array([0.0, 100.0, 1.2, 0.0])
+    with pytest.raises(NotImplementedError, match="charged test particles"):
+        G.tracing_configuration(tm, x, np.zeros((1, 4)), None, 200.0, q=0.5, μ=1.0, ensemble=object.__new__(G.EnsembleMI355X))
