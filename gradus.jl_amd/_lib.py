@@ -39,7 +39,7 @@ def kernel_source_sha16() -> str:
 
 
 GR_OK = 0
-ABI_VERSION = 7      # GR_ABI_VERSION of include/gradus_mi355x.h this module mirrors (checked in load() and tests/test_host_api.py)
+ABI_VERSION = 8      # GR_ABI_VERSION of include/gradus_mi355x.h this module mirrors (checked in load() and tests/test_host_api.py)
 ERROR_NAMES = {
     -1: "GR_ERR_INVALID_ARGUMENT",
     -2: "GR_ERR_UNSUPPORTED",
@@ -101,6 +101,32 @@ class gr_config(C.Structure):
     ]
 
 
+GR_METRIC_MAX_SEG = 12
+
+
+class gr_metric_break(C.Structure):
+    """A radius where metric_components changes form (scale 0), or the centre of a feature that narrow (scale > 0)."""
+
+    _fields_ = [("radius", C.c_double), ("scale", C.c_double)]
+
+
+class gr_metric_segment(C.Structure):
+    _fields_ = [
+        ("r_lo", C.c_double),
+        ("r_hi", C.c_double),
+        ("anchor", C.c_double),
+        ("xmin", C.c_double),
+        ("fit_lo", C.c_double),
+        ("fit_hi", C.c_double),
+        ("e_lo", C.c_int32),
+        ("e_hi", C.c_int32),
+        ("first_row", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("dir", C.c_int32),
+        ("core", C.c_int32),
+    ]
+
+
 class gr_metric_grid(C.Structure):
     """Patch grid of a tabulated metric (include/gradus_mi355x.h, "tabulated metrics")."""
 
@@ -115,10 +141,13 @@ class gr_metric_grid(C.Structure):
         ("degree", C.c_int32),
         ("fit_nodes", C.c_int32),
         ("pole_factor", C.c_int32),
-        ("reserved", C.c_int32),
+        ("n_seg", C.c_int32),
         ("n_r_nodes", C.c_int64),
         ("n_theta_nodes", C.c_int64),
         ("table_doubles", C.c_int64),
+        ("n_rows", C.c_int32),
+        ("reserved", C.c_int32),
+        ("seg", gr_metric_segment * GR_METRIC_MAX_SEG),
     ]
 
 
@@ -281,6 +310,7 @@ EXPORTS = [
     "gr_redshift_radius_multi",
     "gr_lineprofile_multi",
     "gr_metric_grid_plan",
+    "gr_metric_grid_plan_breaks",
     "gr_metric_grid_nodes",
     "gr_metric_table_fit",
     "gr_metric_table_eval",
@@ -346,6 +376,7 @@ def load():
     L.gr_lineprofile_multi.argtypes = [ctxa, i32, cfgp, rsp, pfp, bnp, vp, vp]
     gdp, dp = C.POINTER(gr_metric_grid), C.POINTER(C.c_double)
     L.gr_metric_grid_plan.argtypes = [C.c_double, C.c_double, C.c_double, i32, i32, gdp]
+    L.gr_metric_grid_plan_breaks.argtypes = [C.c_double, C.c_double, C.c_double, i32, i32, i32, C.POINTER(gr_metric_break), gdp]
     L.gr_metric_grid_nodes.argtypes = [gdp, vp, vp]
     L.gr_metric_table_fit.argtypes = [gdp, vp, vp, dp]
     L.gr_metric_table_eval.argtypes = [vp, i64, C.c_double, C.c_double, dp, dp, dp]

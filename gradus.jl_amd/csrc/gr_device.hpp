@@ -1689,21 +1689,27 @@ GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[
 // GR_METRIC_TABULATED: a user-defined metric from the piecewise-polynomial table of gr_tabmetric.hpp -- the AbstractMetric plugin
 // interface (metric_components(m, (r, θ)), src/metrics/kerr-metric.jl:62-70) on the device.
 //
-// Memory system.  A patch is 1440 bytes of coefficients and a right-hand side reads all of it for 340 FMAs: 4.2 bytes per FMA.
-// Per-LANE fetches of that volume are bound by the LDS / L1 return paths (128 / 64 bytes per clock and CU against 64 FP64 FMAs
-// per clock: 720 / 1440 clocks of the memory pipe against 415 of the vector ALU per wave and right-hand side).  But the 64 rays
-// of a wave are an 8 x 8 pixel tile: they sit in ONE patch in 58 % of the wave-steps of the 2048² bench plane and in <= 2 in
-// 91 % (oracle/ trace of 40 tiles, m_r = 8, n_theta = 32; mean 1.7).  So the coefficients go through the SCALAR path: the wave
-// takes the patch of its first unfinished lane (v_readfirstlane), s_load's its coefficients -- one fetch per WAVE, served by the
-// scalar data cache and L2 -- and every lane in that patch evaluates with the coefficients as SGPR operands of its FMAs (no
-// vector register, no LDS or L1 traffic); lanes in other patches wait for the next round ("waterfall").  Cost = rounds x 415
-// vector instructions, nothing else.
+// Memory system.  A patch is 1440 bytes of coefficients (degree 7) and a right-hand side reads all of it for 385 FP64 operations.
+// Per-LANE fetches of that volume from L1 / L2 would be bound by the return path (64 bytes per clock and CU against 64 FP64 FMAs
+// per clock).  But the 64 rays of a wave are an 8 x 8 pixel tile: they sit in ONE patch in 58 % of the wave-steps of the 2048²
+// bench plane and in <= 2 in 91 %.  So every wave keeps a CACHE OF PATCHES IN LDS (TabLds): kTabSlots slots of one patch, tags in
+// a 64-byte head; a lane compares its patch number with the tags (read as vectors: one LDS latency per look-up), and reads its
+// coefficients from its slot with ds_read_b128 -- lanes in one slot read one address (a broadcast), lanes in different slots
+// different bank groups (the slot stride is 208 mod 256 bytes), so the cost of an evaluation does not depend on how many patches
+// the wave straddles.  The reads run GR_TAB_LOOKAHEAD coefficients ahead of the arithmetic, pinned there by a data dependence
+// (CoefStream).  A patch that is not resident is copied by all active lanes into a slot no lane of this evaluation reads; a wave
+// that straddles more patches than it has slots (the shadow's edge) sends the lanes left over to global memory through one
+// out-of-line copy of the evaluation.  The scalar path that was built first -- s_load the patch of the first unfinished lane,
+// coefficients as SGPR operands, lanes of other patches waiting their turn -- lost by 1.7x: the scalar data cache keeps nothing
+// between two evaluations of a wave (DESIGN_measurements.md §M16).
+//
+// The scalar type.  `real` is double in the fp64 kernels and a value with two tangents in the tangent flavour (gr_tangent.hpp): the
+// patch is located from VALUES, the local coordinates are lifted (du = su dr) and the same recurrences run on the lifted numbers --
+// the tangents of g and of ∂g come out of the polynomial's own second derivatives, as the reference's nested ForwardDiff does for
+// a closure (src/tracing/precision-solvers.jl:401-451).  There is no fp32 table.
 // ---------------------------------------------------------------------------------------
-#if !defined(GR_REAL_IS_FLOAT) && !defined(GR_REAL_IS_TAN2)
+#if !defined(GR_REAL_IS_FLOAT)
 #define GR_HAS_TABULATED 1
-#ifndef GR_TAB_PATH
-#define GR_TAB_PATH 1       // 1 = LDS patch cache, 0 = scalar waterfall (see TabulatedMetric::poly)
-#endif
 #ifndef GR_TAB_SLOTS
 #define GR_TAB_SLOTS 12
 #endif
@@ -1712,7 +1718,11 @@ GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[
 #endif                      // 27.4 at 1024², profiles/r5q_tab_slots_ab.log): the slow waves are slow in the global-memory evaluation
 
 #ifndef GR_TAB_LANE_WAVES
+#ifdef GR_REAL_IS_TAN2
+#define GR_TAB_LANE_WAVES 1
+#else
 #define GR_TAB_LANE_WAVES 2
+#endif
 #endif
 #ifndef GR_TAB_PARK
 #define GR_TAB_PARK 0       // stage accelerations parked in LDS (ParkA); measured equal at two waves per SIMD (profiles/r5e_tab_ab.log)
@@ -1725,51 +1735,65 @@ GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[
 #endif
 // The wave's patch cache in LDS: [ 16 ints: kTabSlots tags, -1 up to index 14, the round-robin counter at 15 | kTabSlots slots of
 // kTabSlotBytes ].  The tags are read four at a time (ds_read_b128), so a look-up costs one LDS latency whatever the number of slots.
-// 1488 = 5 x 256 + 208: slot k starts 208 k bytes (mod 256) into the 64 banks -- distinct 16-byte columns for k < 16, so the lanes
-// of one ds_read group that sit in different slots do not collide; 1472 of the 1488 bytes are the patch as it lies in memory.
+// The slot stride is 208 mod 256 bytes: slot k starts 208 k bytes (mod 256) into the 64 banks -- distinct 16-byte columns for k < 16,
+// so the lanes of one ds_read group that sit in different slots do not collide.
 constexpr int kTabSlots = GR_TAB_SLOTS;
 constexpr int kTabTagVecs = (kTabSlots + 3) / 4;
 constexpr int kTabRR = 15;              // index of the round-robin counter among the 16 ints of the head
 constexpr int kTabFetch = GR_TAB_FETCH;
 constexpr int kTabCopyDepth = 8 / kTabFetch;        // loads per patch a lane keeps in flight while it copies (8 in flight in all)
 constexpr int kTabHeadBytes = 64;
-constexpr int kTabSlotBytes = 1488;
+// (the smallest size >= a patch that is 208 mod 256: 1488 at degree 7, 1232 at 6, 976 at 5)
+constexpr int kTabSlotBytes = gr_tab::kPatchDoubles * 8 + ((208 - gr_tab::kPatchDoubles * 8 % 256) + 256) % 256;
+static_assert(kTabSlotBytes % 256 == 208 && kTabSlotBytes % 16 == 0, "slot stride");
 constexpr size_t kTabLdsBytesPerWave = kTabHeadBytes + (size_t)kTabSlots * kTabSlotBytes;
 static_assert(kTabSlots >= 1 && kTabSlots <= 12 && gr_tab::kPatchDoubles * 8 <= kTabSlotBytes, "patch cache geometry");
 static_assert(kTabFetch == 1 || kTabFetch == 2 || kTabFetch == 4, "patches copied side by side");
 typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// local coordinate -> the integrator's scalar: the tangents of u are du/dr times the tangents of r
+GR_DEV real tab_lift(double u, double su, real r)
+{
+#ifdef GR_REAL_IS_TAN2
+    gr_tan2 x(u);
+    x.a = su * r.a;
+    GR_TAN_B(x.b = su * r.b;)
+    return x;
+#else
+    (void)su; (void)r;
+    return u;
+#endif
+}
+// gr_tab::eval_patch's operations on `real`
+struct TabRealOps {
+    static GR_DEV real fma(real a, real b, real c) { return GR_FMA(a, b, c); }
+    static GR_DEV real fmak(real a, real b, double k) { return GR_FMA(a, b, k); }
+    static GR_DEV real add(real a, real b) { return a + b; }
+    static GR_DEV real mulk(real a, double k) { return a * k; }
+    static GR_DEV real addk(real a, double k) { return a + k; }
+    static GR_DEV void row_done(int, int, real&, real&, real&) {}
+};
+
 #ifndef GR_HOST_HARNESS
 // the right-hand side with the coefficients read per lane from global memory, NOT inlined: the step loop holds six copies of the
-// LDS-fed evaluation already (45 KB of code against a 64 KB instruction cache); this one serves lanes that found no cache slot
-__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, int pole_factor, double u, double v, double su, double sv,
-                                                             double s, double c, double vt, double vr, double vh, double vp, double* out);
+// LDS-fed evaluation already; this one serves lanes that found no cache slot
+__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, const double* ax, int form, real u, real v, double su, double sv,
+                                                             real s, real c, real vt, real vr, real vh, real vp, real* out);
 #endif
 struct TabulatedMetric {
-    static constexpr int kMinWavesPerSimd = 2;
+    static constexpr int kMinWavesPerSimd = GR_TAB_LANE_WAVES < 2 ? GR_TAB_LANE_WAVES : 2;
     static constexpr int kLaneWavesPerSimd = GR_TAB_LANE_WAVES;
     static constexpr int kParkStages = GR_TAB_PARK;      // stage accelerations parked in LDS while a right-hand side runs (ParkA)
     static constexpr bool kHasForce = false;
     static constexpr bool kFusedRhs = false;
     static constexpr bool kByTheta = true;      // evaluated at (r, θ) -- the integrator hands θ over next to sin θ, cos θ
     gr_tab::GridK gk;
-    int32_t pole_factor;
-    const double* patches;                      // device: first patch of the table (behind its header)
-#ifndef GR_HOST_HARNESS
-    // gr_tab::eval_patch's operations with the coefficient operand k in a scalar register pair (the three-address VOP3 forms:
-    // left to itself the compiler picks the two-address v_fmac_f64 and first copies every coefficient into vector registers,
-    // two v_mov_b32 per coefficient -- 280 of an evaluation's 624 vector instructions)
-    struct Ops {
-        static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-        static GR_DEV double fmak(double a, double b, double k) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k)); return r; }
-        static GR_DEV double add(double a, double b) { return a + b; }
-        static GR_DEV double mulk(double a, double k) { double r; asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
-        static GR_DEV double addk(double a, double k) { double r; asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r; }
-        static GR_DEV void row_done(int, int, double&, double&, double&) {}
-    };
-#endif
-    // the host unit copies the table's header into cfg.params and the device pointer of the table into cfg.metric_table
+    int32_t form;                               // gr_tab H_POLE_FACTOR: how g_ϕϕ, g_tϕ are stored (0, 1, 2)
+    const double* patches;                      // device: first patch of the table
+    const double* axis;                         //         the axis terms of form 2 (kAxisDoubles per radial row)
+    const gr_tab::SegRec* segs;                 //         the segment records
     // The host unit lays the grid out in cfg.params the way the kernels use it (stage_metric_table): doubles as doubles, the
-    // integers packed into the BITS of params[6] and params[7] -- a double -> int conversion would be a vector instruction whose
+    // integers packed into the BITS of params[5..7] -- a double -> int conversion would be a vector instruction whose
     // (uniform) result then sits in vector registers for the whole step loop; kernel arguments arrive in scalar registers and
     // bit fields of them stay there.
     GR_DEV void load(const gr_config& c)
@@ -1778,52 +1802,90 @@ struct TabulatedMetric {
         gk.xmin = c.params[1];
         gk.mr = c.params[2];
         gk.nth_over_pi = c.params[3];
-        const unsigned long long b6 = __builtin_bit_cast(unsigned long long, c.params[6]), b7 = __builtin_bit_cast(unsigned long long, c.params[7]);
+        const unsigned long long b5 = __builtin_bit_cast(unsigned long long, c.params[5]), b6 = __builtin_bit_cast(unsigned long long, c.params[6]),
+                                 b7 = __builtin_bit_cast(unsigned long long, c.params[7]);
         gk.e_min = (int32_t)(uint32_t)(b6 & 0xffffffffull);
         gk.e_max = (int32_t)(uint32_t)(b6 >> 32);
         gk.m_r = (int32_t)(b7 & 0xffffull);
         gk.n_theta = (int32_t)((b7 >> 16) & 0xffffull);
-        pole_factor = (int32_t)((b7 >> 32) & 1ull);
-        patches = c.metric_table + gr_tab::kHeaderDoubles;
+        form = (int32_t)((b7 >> 32) & 3ull);
+        gk.n_seg = (int32_t)((b7 >> 40) & 0xffull);
+        patches = c.metric_table + (long long)b5;
+        axis = c.metric_table + gr_tab::kBodyOff;
+        segs = reinterpret_cast<const gr_tab::SegRec*>(c.metric_table + gr_tab::kSegOff);
+    }
+    // ---- where a point lies ----
+    // One-segment tables (every smooth metric): segment 0 from the kernel arguments, nothing loaded.  Otherwise the segment of each
+    // lane is counted from the records' lower ends and the lanes of one segment take its record through SCALAR loads (the record
+    // of the first unfinished lane; the others wait their turn -- a wave rarely straddles a segment boundary).
+    GR_DEV void locate_any(double r, double th, int& row, int& patch, double& u, double& v, double& su, double& sv) const
+    {
+        if (gk.n_seg == 1) {
+            gr_tab::locate(gk, r, th, row, patch, u, v, su, sv);
+            return;
+        }
+#ifdef GR_HOST_HARNESS
+        gr_tab::locate_segments(gk, segs, r, th, row, patch, u, v, su, sv);
+#else
+        int it;
+        gr_tab::locate_theta(gk, th, it, v, sv);
+        typedef const gr_tab::SegRec __attribute__((address_space(4))) cseg;
+        cseg* sc = (cseg*)(unsigned long long)segs;
+        const int sg = gr_tab::segment_of(gk.n_seg, sc, r);
+        row = 0; u = 0.0; su = 0.0;
+        for (;;) {
+            const int s0 = __builtin_amdgcn_readfirstlane(sg);
+            if (sg == s0) {
+                gr_tab::locate_row(sc[s0].anchor, sc[s0].xmin, sc[s0].e_lo, sc[s0].e_hi, sc[s0].first_row, sc[s0].dir, sc[s0].core, gk.mr, gk.m_r, r, row, u, su);
+                break;
+            }
+        }
+        patch = row * gk.n_theta + it;
+#endif
+    }
+    // ---- the axis terms of form 2: K_m, ∂r K_m, K_d, ∂r K_d of g_ϕϕ and g_tϕ at this lane's radius (per-lane loads: 4 (p + 1)
+    // doubles that the lanes of a wave mostly share; only metrics whose azimuthal components do not vanish on the axis come here)
+    static GR_DEV void axis_terms(const double* ax, real u, double su, real out[8])
+    {
+#pragma unroll
+        for (int q = 0; q < gr_tab::kAxisPolys; ++q) {
+            real K, Ku;
+            gr_tab::eval_axis_poly<real>([ax](int k) { return ax[k]; }, q * (gr_tab::kDegree + 1), u, K, Ku);
+            out[2 * q] = K;
+            out[2 * q + 1] = Ku * su;
+        }
     }
     // ---- where the coefficients come from ----
     // (a) cold code (initial conditions, point functions, the path and apply kernels): every lane loads its own patch from
     //     global memory.
-    // (b) the step loop, GR_TAB_PATH 1 [default]: an LDS PATCH CACHE per wave (TabLds, below): kTabSlots patches of 1440 bytes;
-    //     a lane reads its coefficients from the slot that holds its patch -- lanes in one slot read one address (a broadcast:
-    //     256 bytes per clock and CU for ds_read_b64 / b128 on CDNA4, MI355X_MICROARCH.md §LDS), lanes in different slots
-    //     different bank groups (the slot stride is 5 x 256 + 208 bytes: up to 8 slots without a bank conflict).  The cost of
-    //     an evaluation does not depend on how many patches the wave straddles.  A patch that is not resident is fetched by
-    //     the whole wave (92 x 16 bytes: two coalesced global loads per lane) into the next slot, round robin; the lanes that
-    //     hit evaluate first, so every slot may be replaced.
-    // (c) GR_TAB_PATH 0: the SCALAR path measured first (profiles/r5a_tabkerr_*): the wave takes the patch of its first
-    //     unfinished lane, s_load's its coefficients and evaluates with them as SGPR operands, round after round ("waterfall").
-    //     No LDS, no vector registers for coefficients -- and 135 ms for 1024² rays where the fused Kerr kernel takes 5.1:
-    //     the scalar data cache keeps nothing between two evaluations of a wave (20 of a patch's 23 lines miss on EVERY
-    //     evaluation: 5.1e8 misses per launch), each evaluation is a handful of dependent L2 round trips, VALU issue 0.16.
+    // (b) the step loop: the wave's LDS patch cache (above).
 #ifndef GR_HOST_HARNESS
-    // The coefficient stream of one evaluation out of an LDS slot: 90 ds_read_b128 (the pairs the recurrences consume in
-    // order).  Reads run GR_TAB_LOOKAHEAD coefficients ahead of the arithmetic: when a row of a component has been folded in,
+    // The coefficient stream of one evaluation out of an LDS slot: ds_read_b128 of the pairs the recurrences consume in
+    // order.  Reads run GR_TAB_LOOKAHEAD coefficients ahead of the arithmetic: when a row of a component has been folded in,
     // the pairs up to that distance beyond it are requested, so a read's LDS latency lies behind the FMAs of the rows before
-    // it and only the look-ahead (2 registers per coefficient) is held in registers.  Left to the scheduler all 90 reads go to
+    // it and only the look-ahead (2 registers per coefficient) is held in registers.  Left to the scheduler all reads go to
     // the top of the evaluation (360 registers: 1.3 KB of scratch per lane) -- scheduling barriers do not hold the pure
     // arithmetic in place, a DATA dependence does: the address of the next reads passes through an empty asm that also takes
-    // the accumulator of the row just finished.
+    // the accumulators of the row just finished.
     // The loads are volatile so that they stay 16-byte reads (the optimiser otherwise narrows them to the doubles used and the
     // back end pairs those as ds_read2_b64: half the LDS bandwidth).
     template <class PairPtr, class AddrInt, int LOOKAHEAD>
     struct CoefStream {
         typedef const double2_t __attribute__((address_space(3))) lds_cdouble2;
-        static constexpr int kAll = gr_tab::kComps * gr_tab::kCoefs;       // 180 coefficients = 90 pairs
+        static constexpr int kAll = gr_tab::kComps * gr_tab::kCoefs;       // 180 coefficients = 90 pairs at degree 7
+        // (rows p and p - 1 of a component -- 3 coefficients -- and its first Horner row are consumed before the first row_done of
+        // the component, the longest row between two calls has p + 1: a shorter look-ahead would read buf[] entries never loaded)
+        static_assert(LOOKAHEAD >= gr_tab::kDegree + 1 && LOOKAHEAD % 2 == 0, "the look-ahead must cover one row of coefficients");
         // LDS reads are volatile (see above).  Global ones must NOT be: a volatile global load is a system-scope one (sc0 sc1) that
         // no cache may serve -- every look-ahead batch of the evaluation from global memory then waits for memory itself, 7.4 µs
         // per evaluation (scripts/wave_timeline.py); the load/store vectoriser keeps plain global loads 16 bytes wide.
         static constexpr bool kVolatile = sizeof(AddrInt) == 4;
+        static constexpr int kPairs = (kAll + 1) / 2;                       // (an odd count at degree 5: the last pair's second half is padding)
         mutable PairPtr sl;
-        mutable double2_t buf[kAll / 2];
+        mutable double2_t buf[kPairs];
         // coefficients consumed once row `row` of component `comp` is done, and the pairs requested by then
         static constexpr int consumed(int comp, int row) { return gr_tab::kCoefs * comp + gr_tab::row_offset(row) + (gr_tab::kDegree - row + 1); }
-        static constexpr int pairs_by(int coefs) { return (coefs + LOOKAHEAD > kAll ? kAll : coefs + LOOKAHEAD + 1) / 2; }
+        static constexpr int pairs_by(int coefs) { return coefs + LOOKAHEAD >= kAll ? kPairs : (coefs + LOOKAHEAD + 1) / 2; }
         GR_DEV void issue(int from_pair, int to_pair) const
         {
 #pragma unroll
@@ -1834,13 +1896,13 @@ struct TabulatedMetric {
         }
         GR_DEV void start() const { issue(0, pairs_by(0)); }
         GR_DEV double operator()(int kk) const { return buf[kk >> 1][kk & 1]; }
-        // the five operations of gr_tab::eval_patch on vector registers, and the hook that keeps the stream ahead
-        static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-        static GR_DEV double fmak(double a, double b, double k) { return __builtin_fma(a, b, k); }
-        static GR_DEV double add(double a, double b) { return a + b; }
-        static GR_DEV double mulk(double a, double k) { return a * k; }
-        static GR_DEV double addk(double a, double k) { return a + k; }
-        GR_DEV void row_done(int comp, int row, double& acc, double& acc_u, double& acc_v) const
+        // the five operations of gr_tab::eval_patch, and the hook that keeps the stream ahead
+        static GR_DEV real fma(real a, real b, real c) { return GR_FMA(a, b, c); }
+        static GR_DEV real fmak(real a, real b, double k) { return GR_FMA(a, b, k); }
+        static GR_DEV real add(real a, real b) { return a + b; }
+        static GR_DEV real mulk(real a, double k) { return a * k; }
+        static GR_DEV real addk(real a, double k) { return a + k; }
+        GR_DEV void row_done(int comp, int row, real& acc, real& acc_u, real& acc_v) const
         {
             // (rows kDegree and kDegree - 1 of a component are folded together before the first call for it)
             const int before = (row == gr_tab::kDegree - 2) ? (comp == 0 ? 0 : consumed(comp - 1, 0)) : consumed(comp, row + 1);
@@ -1849,20 +1911,28 @@ struct TabulatedMetric {
             AddrInt a = (AddrInt)(unsigned long long)sl;      // (a 32-bit LDS address, or a 64-bit global one)
             // (all three accumulators: a chain left out is deferred by the scheduler to the end of the evaluation, with every
             // intermediate of the value chain it reads kept alive -- spilled -- until then)
+#ifdef GR_REAL_IS_TAN2
+            asm volatile("" : "+v"(a), "+v"(acc.v), "+v"(acc_u.v), "+v"(acc_v.v), "+v"(acc.a), "+v"(acc_u.a), "+v"(acc_v.a));
+            GR_TAN_B(asm volatile("" : "+v"(a), "+v"(acc.b), "+v"(acc_u.b), "+v"(acc_v.b));)
+#else
             asm volatile("" : "+v"(a), "+v"(acc), "+v"(acc_u), "+v"(acc_v));
+#endif
             sl = (PairPtr)(unsigned long long)a;
             issue(from, to);
         }
     };
     typedef CoefStream<const double2_t __attribute__((address_space(3)))*, unsigned, GR_TAB_LOOKAHEAD> LdsCoef;      // out of a cache slot
     // ... out of the table in global memory (tab_rhs_from_global): memory latency is ten times the LDS's, and the lanes that take
-    // this path are few and often alone in their wave -- four times the look-ahead
+    // this path are few and often alone in their wave -- twice the look-ahead
     // (an address-space-1 pointer: through a generic one the loads are flat_load's, which count on the LDS counter as well and
     // return out of order there -- every wait for one of them then waits for all of them, and the look-ahead is gone)
     typedef CoefStream<const double2_t __attribute__((address_space(1)))*, unsigned long long, GR_TAB_LOOKAHEAD_GLOBAL> GlobalCoef;
 #endif
+    // components and Jacobian from a coefficient source: the polynomials, the chain rule, the axis forms
+    // (ax: this lane's row of the axis terms, read in form 2 only)
     template <class Ld, class Ops_>
-    GR_DEV void horner(const Ld& ld, const Ops_& ops, double u, double v, double su, double sv, real s, real c, real g[5], real gr[5], real gt[5]) const
+    static GR_DEV void horner(const Ld& ld, const Ops_& ops, int form, const double* ax, real u, real v, double su, double sv, real s, real c,
+                              real g[5], real gr[5], real gt[5])
     {
         real P[5], Pu[5], Pv[5];
         gr_tab::eval_patch<real>(ld, ops, u, v, P, Pu, Pv);
@@ -1872,27 +1942,35 @@ struct TabulatedMetric {
             gr[k] = Pu[k] * su;
             gt[k] = Pv[k] * sv;
         }
-        if (pole_factor) gr_tab::pole_factor_apply<real>(s * s, 2.0 * (s * c), g, gr, gt);
+        if (form != 0) {
+            gr_tab::pole_factor_apply<real>(s * s, 2.0 * (s * c), g, gr, gt);
+            if (form == 2) {
+                real at8[8];
+                axis_terms(ax, u, su, at8);
+                gr_tab::axis_terms_apply<real>(at8, s, c, g, gr, gt);
+            }
+        }
     }
     // components and Jacobian at (r, θ); s, c = sin θ, cos θ of the same θ (the axis factor of g_ϕϕ and g_tϕ)
     GR_DEV void poly(real r, real th, real s, real c, real g[5], real gr[5], real gt[5]) const
     {
-        int patch;
+        int row, patch;
         double u, v, su, sv;
-        gr_tab::locate(gk, r, th, patch, u, v, su, sv);
+        locate_any((double)r, (double)th, row, patch, u, v, su, sv);
         const double* pc = patches + (int64_t)patch * gr_tab::kPatchDoubles;
-        horner([pc](int k) { return pc[k]; }, gr_tab::HostOps{}, u, v, su, sv, s, c, g, gr, gt);
+        horner([pc](int k) { return pc[k]; }, TabRealOps{}, form, axis + (int64_t)row * gr_tab::kAxisDoubles, tab_lift(u, su, r), tab_lift(v, sv, th),
+               su, sv, s, c, g, gr, gt);
     }
     // the right-hand side of the geodesic equation from the table's components: inverse and contraction
-    GR_DEV void finish_rhs(const real g[5], const real gr[5], const real gt[5], real vt, real vr, real vh, real vp,
-                           real& at, real& ar, real& ah, real& ap) const
+    static GR_DEV void finish_rhs(const real g[5], const real gr[5], const real gt[5], real vt, real vr, real vh, real vp,
+                                  real& at, real& ar, real& ah, real& ap)
     {
         real gi[5];
         inverse_generic(g, gi);
         geodesic_contract(gr, gt, gi, vt, vr, vh, vp, at, ar, ah, ap);
     }
-    // ... inside the step loop: through the wave's patch cache (cs.tab, TabLds) or the scalar waterfall.  The loops below enclose
-    // the WHOLE right-hand side: four accelerations are carried round them, not fifteen components.
+    // ... inside the step loop: through the wave's patch cache (cs.tab, TabLds).  The branches below enclose the WHOLE right-hand
+    // side: four accelerations are carried out of them, not fifteen components.
     template <class Cold_>
     GR_DEV void rhs_th(const Cold_& cs, real r, real th, real s, real c, real vt, real vr, real vh, real vp,
                        real& at, real& ar, real& ah, real& ap) const
@@ -1907,27 +1985,9 @@ struct TabulatedMetric {
             poly(r, th, s, c, g, gr, gt);
             finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
         } else {
-            int patch;
+            int row, patch;
             double u, v, su, sv;
-            gr_tab::locate(gk, r, th, patch, u, v, su, sv);
-#if GR_TAB_PATH == 0
-            for (;;) {
-                const int sp = __builtin_amdgcn_readfirstlane(patch);
-                if (patch == sp) {
-                    // the patch's address from scalar values only, in the constant address space: every coefficient load is an s_load
-                    typedef const double __attribute__((address_space(4))) cdouble4;
-                    const unsigned long long a64 = (unsigned long long)patches + (unsigned long long)(unsigned)sp * (gr_tab::kPatchDoubles * 8ull);
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(a64 & 0xffffffffull));
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a64 >> 32));
-                    cdouble4* pc = (cdouble4*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
-                    real g[5], gr[5], gt[5];
-                    horner([pc](int k) { return pc[k]; }, Ops{}, u, v, su, sv, s, c, g, gr, gt);
-                    finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
-                    break;
-                }
-            }
-#else
-            typedef int __attribute__((address_space(3))) lds_int;
+            locate_any((double)r, (double)th, row, patch, u, v, su, sv);
             typedef volatile int __attribute__((address_space(3))) lds_vint;
             lds_vint* tags = (lds_vint*)cs.tab;
             // Lanes are threads to the compiler: it orders ONE lane's memory operations, not one lane's reads against another
@@ -1952,9 +2012,6 @@ struct TabulatedMetric {
                 if (4 * q + 3 < kTabSlots) slot = (t4.w == patch) ? 4 * q + 3 : slot;
             }
             unsigned long long todo = __builtin_amdgcn_ballot_w64(slot < 0);
-#ifdef GR_TAB_DEBUG_NOMISS      // (register-pressure experiments only: wrong results)
-            todo = 0ull; slot = slot < 0 ? 0 : slot;
-#endif
             if (todo != 0ull) {
 #ifdef GR_WAVE_TIMELINE
                 const unsigned long long tl_c0 = wall_clock64();
@@ -1995,7 +2052,7 @@ struct TabulatedMetric {
                             }
                         }
                     }
-                    // 92 pieces of 16 bytes per patch, piece q by the active lane of rank q mod n_act
+                    // a patch in pieces of 16 bytes, piece q by the active lane of rank q mod n_act
                     for (int q0 = rank; q0 < gr_tab::kPatchDoubles / 2; q0 += kTabCopyDepth * n_act) {
                         double2_t piece[kTabFetch][kTabCopyDepth];
 #pragma unroll
@@ -2038,24 +2095,26 @@ struct TabulatedMetric {
                 if (rank == 0) tags[13] = tags[13] + (int)(wall_clock64() - tl_c0);
 #endif
             }
+            const real ul = tab_lift(u, su, r), vl = tab_lift(v, sv, th);
             // -- phase 2: the lanes that have a slot evaluate out of LDS ...
             if (slot >= 0) {
                 LdsCoef lc;
-                lc.sl = (LdsCoef::lds_cdouble2*)(cs.tab + kTabHeadBytes + slot * kTabSlotBytes);
+                lc.sl = (typename LdsCoef::lds_cdouble2*)(cs.tab + kTabHeadBytes + slot * kTabSlotBytes);
                 lc.start();
                 real g[5], gr[5], gt[5];
-                horner(lc, lc, u, v, su, sv, s, c, g, gr, gt);
+                horner(lc, lc, form, axis + (int64_t)row * gr_tab::kAxisDoubles, ul, vl, su, sv, s, c, g, gr, gt);
                 finish_rhs(g, gr, gt, vt, vr, vh, vp, at, ar, ah, ap);
             } else {
                 // ... and a wave that straddles more patches than it has slots sends the lanes left over to global memory, each
                 // for itself, through ONE out-of-line copy of the evaluation (the shadow's edge, where neighbouring rays part: a
                 // few waves per launch; replacing slots for them instead costs ~7 patch copies per evaluation -- those waves then
                 // run 100 µs per step and set the duration of every launch, 45 ms at any image size: profiles/r5f_tab256_*)
-                double out[4];
+                real out[4];
 #ifdef GR_WAVE_TIMELINE      // (debug builds: clock ticks in the evaluation from global memory)
                 const unsigned long long tl_f0 = wall_clock64();
 #endif
-                tab_rhs_from_global(patches + (int64_t)patch * gr_tab::kPatchDoubles, pole_factor, u, v, su, sv, s, c, vt, vr, vh, vp, out);
+                tab_rhs_from_global(patches + (int64_t)patch * gr_tab::kPatchDoubles, axis + (int64_t)row * gr_tab::kAxisDoubles, form, ul, vl, su, sv,
+                                    s, c, vt, vr, vh, vp, out);
 #ifdef GR_WAVE_TIMELINE
                 {
                     const unsigned long long fa = __builtin_amdgcn_ballot_w64(true);
@@ -2067,7 +2126,6 @@ struct TabulatedMetric {
             }
             GR_TAB_WAVE_SYNC();      // the slots just read may be replaced by the next evaluation
 #undef GR_TAB_WAVE_SYNC
-#endif
         }
 #endif
     }
@@ -2083,25 +2141,17 @@ struct TabulatedMetric {
     }
 };
 #ifndef GR_HOST_HARNESS
-__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, int pole_factor, double u, double v, double su, double sv,
-                                                             double s, double c, double vt, double vr, double vh, double vp, double* out)
+__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, const double* ax, int form, real u, real v, double su, double sv,
+                                                             real s, real c, real vt, real vr, real vh, real vp, real* out)
 {
-    // (the same coefficient stream as out of LDS: a few loads ahead of the arithmetic, ~100 registers -- with all 90 loads hoisted
+    // (the same coefficient stream as out of LDS: a few loads ahead of the arithmetic, ~100 registers -- with all loads hoisted
     // this function needs 254 registers and saves / restores a hundred callee-saved ones around its body)
-    real P[5], Pu[5], Pv[5], g[5], gr[5], gt[5], gi[5];
+    real g[5], gr[5], gt[5];
     TabulatedMetric::GlobalCoef gc;
     gc.sl = (const double2_t __attribute__((address_space(1)))*)(unsigned long long)pc;
     gc.start();
-    gr_tab::eval_patch<real>(gc, gc, u, v, P, Pu, Pv);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        g[k] = P[k];
-        gr[k] = Pu[k] * su;
-        gt[k] = Pv[k] * sv;
-    }
-    if (pole_factor) gr_tab::pole_factor_apply<real>(s * s, 2.0 * (s * c), g, gr, gt);
-    inverse_generic(g, gi);
-    geodesic_contract(gr, gt, gi, vt, vr, vh, vp, out[0], out[1], out[2], out[3]);
+    TabulatedMetric::horner(gc, gc, form, ax, u, v, su, sv, s, c, g, gr, gt);
+    TabulatedMetric::finish_rhs(g, gr, gt, vt, vr, vh, vp, out[0], out[1], out[2], out[3]);
 }
 #endif
 #else

@@ -41,8 +41,10 @@ using namespace gr;
 GR_DECLARE_METRIC(0) GR_DECLARE_METRIC(1) GR_DECLARE_METRIC(2) GR_DECLARE_METRIC(3) GR_DECLARE_METRIC(4) GR_DECLARE_METRIC(5)
 GR_DECLARE_METRIC(6) GR_DECLARE_METRIC(7) GR_DECLARE_METRIC(8) GR_DECLARE_METRIC(9) GR_DECLARE_METRIC(10)
 #undef GR_DECLARE_METRIC
-// GR_METRIC_TABULATED (11): the fp64 kernels only
+// GR_METRIC_TABULATED (11): the fp64 kernels and the tangent flavours (no fp32 table)
 hipError_t gr64_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
+hipError_t grt_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
+hipError_t grt1_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
 hipError_t gr64_launch_path_m11(const void*, double*, int64_t, unsigned long long*, hipStream_t);
 hipError_t gr64_launch_apply_m11(const void*, const gr_point*, double, double*, hipStream_t);
 static_assert(GR_METRIC_NOZ == 10 && GR_METRIC_TABULATED == 11, "one kernel object per metric id 0..11: extend the tables below with the catalogue");
@@ -61,8 +63,8 @@ typedef hipError_t (*apply_fn)(const void*, const gr_point*, double, double*, hi
 #define GR_ROW(F, LAST) { F##0, F##1, F##2, F##3, F##4, F##5, F##6, F##7, F##8, F##9, F##10, LAST }
 const trace_fn kTrace64[12] = GR_ROW(gr64_launch_trace_m, gr64_launch_trace_m11);
 const trace_fn kTrace32[12] = GR_ROW(gr32_launch_trace_m, nullptr);
-const trace_fn kTraceTan[12] = GR_ROW(grt_launch_trace_m, nullptr);      // value + ∂/∂α + ∂/∂β (out_mode 5): one lane per ray
-const trace_fn kTraceTan1[12] = GR_ROW(grt1_launch_trace_m, nullptr);    // the same with a PAIR of lanes per ray (kernels_tu.hip)
+const trace_fn kTraceTan[12] = GR_ROW(grt_launch_trace_m, grt_launch_trace_m11);      // value + ∂/∂α + ∂/∂β (out_mode 5): one lane per ray
+const trace_fn kTraceTan1[12] = GR_ROW(grt1_launch_trace_m, grt1_launch_trace_m11);   // the same with a PAIR of lanes per ray (kernels_tu.hip)
 const path_fn kPath64[12] = GR_ROW(gr64_launch_path_m, gr64_launch_path_m11);
 const apply_fn kApply64[12] = GR_ROW(gr64_launch_apply_m, gr64_launch_apply_m11);
 #undef GR_ROW
@@ -213,6 +215,17 @@ int32_t validate_cfg(const gr_config* cfg)
     if (cfg->metric_id == GR_METRIC_TABULATED) {
         const int32_t trc = gr_metric_table_check(cfg->metric_table, cfg->metric_table_n);
         if (trc != GR_OK) return trc;
+        // The table is polynomials: outside [r_min, r_max] they extrapolate to garbage (g_tt = -3e4 at ten times r_max).  A ray
+        // lives between the chart's boundaries, so the chart has to lie inside the table (a hair of slack: the Python and Julia
+        // hosts plan r_min a part in a thousand inside the chart's inner radius).
+        const double t_min = cfg->metric_table[gr_tab::H_RMIN], t_max = cfg->metric_table[gr_tab::H_RMAX];
+        double c_in = cfg->r_inner;
+        if (cfg->chart_table_n > 1 && cfg->chart_table)
+            for (int64_t k = 0; k < cfg->chart_table_n; ++k) c_in = k == 0 ? cfg->chart_table[k] : std::fmin(c_in, cfg->chart_table[k]);
+        if (!(c_in >= t_min - 1e-9 * std::fabs(t_min) - 1e-12) || !(cfg->r_outer <= t_max + 1e-9 * std::fabs(t_max)))
+            return fail(GR_ERR_INVALID_ARGUMENT, "GR_METRIC_TABULATED: the chart [" + std::to_string(c_in) + ", " + std::to_string(cfg->r_outer)
+                                                 + "] leaves the radial range of the metric table [" + std::to_string(t_min) + ", "
+                                                 + std::to_string(t_max) + "]: fit the table on a range that contains the chart");
     }
     if (cfg->disc_id < GR_DISC_NONE || cfg->disc_id > GR_DISC_MESH)
         return fail(GR_ERR_UNSUPPORTED, "unknown disc_id " + std::to_string(cfg->disc_id));
@@ -283,19 +296,7 @@ int32_t stage_metric_table(gr_ctx* ctx, Params& p, hipStream_t stream)
         GR_HIP(hipStreamSynchronize(stream));      // the caller's table may be pageable and gone after the call; once per table
         ctx->metric_table_id = id;
     }
-    {
-        // the grid in the form TabulatedMetric::load reads it (gr_device.hpp): doubles as doubles, integers as bit fields
-        const gr_tab::GridK gk = gr_tab::make_gridk(t[gr_tab::H_R0], (int)t[gr_tab::H_EMIN], (int)t[gr_tab::H_NOCT], (int)t[gr_tab::H_MR], (int)t[gr_tab::H_NTHETA]);
-        p.cfg.params[0] = gk.r0;
-        p.cfg.params[1] = gk.xmin;
-        p.cfg.params[2] = gk.mr;
-        p.cfg.params[3] = gk.nth_over_pi;
-        p.cfg.params[4] = p.cfg.params[5] = 0.0;
-        const unsigned long long b6 = (unsigned long long)(uint32_t)gk.e_min | ((unsigned long long)(uint32_t)gk.e_max << 32);
-        const unsigned long long b7 = (unsigned long long)gk.m_r | ((unsigned long long)gk.n_theta << 16) | ((t[gr_tab::H_POLE_FACTOR] != 0.0 ? 1ull : 0ull) << 32);
-        std::memcpy(&p.cfg.params[6], &b6, 8);
-        std::memcpy(&p.cfg.params[7], &b7, 8);
-    }
+    gr_tab::stage_params(t, p.cfg.params);
     p.cfg.metric_table = ctx->d_metric_table;
     return GR_OK;
 }
@@ -403,7 +404,11 @@ int32_t lpt_prepare(gr_ctx* ctx, const Params& p, Cold& cold, hipStream_t stream
     const int64_t resident_waves = (int64_t)ctx->n_cu * 8;
     if (tiles < resident_waves) return GR_OK;
     if (ctx->lpt == 1 && tiles >= (tab ? 24 : 6) * resident_waves) return GR_OK;
-    std::vector<unsigned char> key(sizeof(gr_config) + sizeof(gr_plane) + sizeof(gr_range));
+    // (a tabulated metric: the table's build id is part of the key -- the config itself holds only a pointer, and two metrics
+    // fitted into the same buffer on the same grid would otherwise share one learned order)
+    std::vector<unsigned char> key(sizeof(gr_config) + sizeof(gr_plane) + sizeof(gr_range) + sizeof(double));
+    const double table_id = tab && p.cfg.metric_table ? p.cfg.metric_table[gr_tab::H_BUILD_ID] : 0.0;
+    std::memcpy(key.data() + sizeof(gr_config) + sizeof(gr_plane) + sizeof(gr_range), &table_id, sizeof(double));
     std::memcpy(key.data(), &p.cfg, sizeof(gr_config));
     std::memcpy(key.data() + sizeof(gr_config), &cold.plane, sizeof(gr_plane));
     std::memcpy(key.data() + sizeof(gr_config) + sizeof(gr_plane), &cold.range, sizeof(gr_range));
@@ -527,6 +532,14 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
 {
     Cold cold = cold_in;
     cold.winding_plane = p.cfg.winding_plane;
+    if (p.cfg.metric_id == GR_METRIC_TABULATED && cold_in.src_mode != 1) {
+        // (validate_cfg has compared the chart with the table's range; p.cfg.metric_table is still the caller's host table here.)
+        // The observer / source position the rays start from must lie inside the table as well.
+        const double r_obs = cold_in.plane.x_obs[1], t_min = p.cfg.metric_table[gr_tab::H_RMIN], t_max = p.cfg.metric_table[gr_tab::H_RMAX];
+        if (!(r_obs >= t_min - 1e-9 * std::fabs(t_min) - 1e-12) || !(r_obs <= t_max + 1e-9 * std::fabs(t_max)))
+            return fail(GR_ERR_INVALID_ARGUMENT, "GR_METRIC_TABULATED: the rays start at r = " + std::to_string(r_obs) + ", outside the radial range of the "
+                                                 "metric table [" + std::to_string(t_min) + ", " + std::to_string(t_max) + "]");
+    }
     const bool sky = cold.src_mode == 3;
     if (sky && p.n > 0) {
         const int32_t src = sky_prepare(ctx, p, cold, stream);
@@ -551,8 +564,8 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     p.refill_threshold = (int32_t)(ctx->refill_threshold ? ctx->refill_threshold : (ctx->precision == 32 ? 32 : 16));
     // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
     const bool tangent = cold.out_mode == 5;
-    if (p.cfg.metric_id == GR_METRIC_TABULATED && (tangent || ctx->precision == 32))
-        return fail(GR_ERR_UNSUPPORTED, "a tabulated metric is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
+    if (p.cfg.metric_id == GR_METRIC_TABULATED && ctx->precision == 32 && !tangent)
+        return fail(GR_ERR_UNSUPPORTED, "a tabulated metric is traced by the fp64 kernels only (there is no fp32 table: not with \"precision\" 32)");
     if (p.cfg.disc_id == GR_DISC_MESH && (tangent || ctx->precision == 32))
         return fail(GR_ERR_UNSUPPORTED, "a mesh geometry is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
     const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);

@@ -386,9 +386,18 @@ class KerrDarkMatter(AbstractStaticAxisSymmetric):
 
         return generic_isco(self)
 
+    def break_radii(self):
+        """Where `metric_components` changes form (TabulatedMetric `breaks`): the enclosed mass is piecewise, C¹ at rₛ and rₛ + Δr
+        (kerr-dark-matter.jl:12-20)."""
+        return [(self.rₛ, 0.0), (self.rₛ + self.Δr, 0.0)]
+
 
 def _smooth_interpolate(x, x0, δx=2.5, smoothing_offset=1e4):
-    """utils.jl:158-168"""
+    """utils.jl:158-168 (floats or arrays)"""
+    if np.ndim(x):
+        x = np.asarray(x, dtype=np.float64)
+        mid = 1.0 - (np.arctan(smoothing_offset * (x - x0) / δx) / math.pi + 0.5)
+        return np.where(x <= x0 - δx / 2, 1.0, np.where(x <= x0 + δx / 2, mid, 0.0))
     if x <= x0 - δx / 2:
         return 1.0
     if x <= x0 + δx / 2:
@@ -418,7 +427,8 @@ class KerrRefractive(AbstractStaticAxisSymmetric):
         R = 2.0 * self.M
         Sig = r * r + a * a * (c * c)
         s2 = s * s
-        t = _smooth_interpolate(float(_value(r)), self.corona_radius)
+        rv = _value(r)
+        t = _smooth_interpolate(rv if np.ndim(rv) else float(rv), self.corona_radius)
         n = t + (1.0 - t) * self.n
         return (-(1.0 - R * r / Sig) / (n * n), Sig / (r * r - R * r + a * a), Sig,
                 s2 * (r * r + a * a + (s2 * R * r * a * a) / Sig), (-(R * r * a * s2) / Sig) / n)
@@ -428,6 +438,11 @@ class KerrRefractive(AbstractStaticAxisSymmetric):
 
     def isco(self):
         return kerr_isco(self.M, self.a)                 # kerr-refractive-ad.jl:61
+
+    def break_radii(self):
+        """Where `metric_components` changes form (TabulatedMetric `breaks`): the refractive index jumps by 6e-5 at
+        corona_radius ± δx/2 and steps from n to 1 over δx / smoothing_offset at corona_radius (utils.jl:158-168)."""
+        return [(self.corona_radius - 1.25, 0.0), (self.corona_radius, 2.5e-4), (self.corona_radius + 1.25, 0.0)]
 
 
 @dataclass(frozen=True)
@@ -474,20 +489,25 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
 
     `source` is an `AbstractMetric` of this package (traced through the table instead of its own kernels) or any callable
     `f(r, θ) -> (g_tt, g_rr, g_θθ, g_ϕϕ, g_tϕ)`; it is called with numpy arrays where it accepts them, point by point otherwise.
-    The library names the sample nodes, fits piecewise polynomials of total degree 7 (GR_METRIC_TABULATED, ABI 7) and reports
-    its own error estimates; (m_r, n_theta) are doubled until the estimates are below `tol` (value) and `dtol` (derivatives).
+    The library names the sample nodes, fits piecewise polynomials (GR_METRIC_TABULATED, ABI 8) and reports its own error
+    estimates; (m_r, n_theta) are doubled until the estimates are below `tol` (value) and `dtol` (derivatives).
 
-    `inner_radius` (the event horizon: the chart's inner radius is 1.01 of it, charts.jl:9-23) and `isco` default to the
-    source's; a bare callable must bring `inner_radius`, and its ISCO is found on the table's own derivatives.
+    `breaks`: radii where the metric's functions change form -- `(radius, scale)` pairs or bare radii (scale 0: a kink or a jump
+    AT the radius; scale > 0: a smooth feature of that width centred there, resolved by patches that shrink geometrically towards it
+    from both sides).  No patch straddles a break.  A source with a `break_radii()` method (KerrDarkMatter, KerrRefractive) names
+    its own.  Radii may be negative (`r_min < 0`: a chart through a wormhole's throat, with a break at 0 of the throat's scale).
+
+    `inner_radius` (the event horizon: the chart's inner radius is 1.01 of it, charts.jl:9-23; the plunging region is traced down
+    to 1.000001 of it, orbit-solving.jl:162, which is where the table starts) and `isco` default to the source's; a bare callable
+    must bring `inner_radius`, and its ISCO is found on the table's own derivatives.  The table covers [r_min, r_max]; a chart,
+    observer or source beyond `r_max` makes it grow (`cover`), the library refuses what lies outside.
     """
 
     metric_id = GR_METRIC_TABULATED
 
     def __init__(self, source, *, inner_radius=None, isco=None, r_min=None, r_max=12000.0, r0=None, m_r=8, n_theta=32,
-                 tol=2e-11, dtol=1e-8, max_refinements=3, closest_approach=1.01, pole_factor=True, strict=True):
+                 tol=2e-11, dtol=1e-8, max_refinements=3, closest_approach=1.01, pole_factor=True, strict=True, breaks=None):
         import warnings
-
-        from . import _lib
 
         self.source = source
         self._f = source.metric_components if isinstance(source, AbstractMetric) else source
@@ -495,52 +515,113 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             if not isinstance(source, AbstractMetric):
                 raise ValueError("a callable metric needs `inner_radius` (the event horizon radius)")
             inner_radius = source.inner_radius()
+        if breaks is None and hasattr(source, "break_radii"):
+            breaks = source.break_radii()
+        self.breaks = [(float(b[0]), float(b[1])) if np.ndim(b) else (float(b), 0.0) for b in (breaks or [])]
         # The table represents the metric by polynomials: a pole of g_rr INSIDE its radial range -- an `inner_radius` that lies
         # within the outermost horizon, as the reference's formulas for the dilaton-axion and Kerr-dark-matter metrics do --
         # cannot be fitted (estimates of order 1 .. 1000: rays near it would stall or scatter).  Direct evaluation carries such
         # rays across the pole in one form or another; here the range starts outside the OUTERMOST sign change of g_rr instead.
-        outer = self._outermost_horizon(float(inner_radius), float(r_max))
+        outer = self._outermost_horizon(float(inner_radius), float(r_max)) if (r_min is None or r_min >= inner_radius) else None
         if outer is not None and r_min is None and r0 is None:
             warnings.warn(f"TabulatedMetric: g_rr changes sign at r = {outer:.6g}, outside inner_radius = {float(inner_radius):.6g}; the "
                           "table (and the chart's inner boundary) start there", stacklevel=2)
             inner_radius = outer
         self._inner_radius = float(inner_radius)
         self._isco = isco
-        # radial octaves count from a point just inside the horizon; the table starts at the chart's inner radius
-        self.r0 = float(r0) if r0 is not None else self._inner_radius * (1.0 - 1e-3) if self._inner_radius > 0 else -1.0
-        self.r_min = float(r_min) if r_min is not None else max(self._inner_radius * closest_approach * (1.0 - 1e-3), self.r0 + 1e-3)
+        # The table starts a hair inside the chart's inner radius (closest_approach = 1.01 of the horizon, charts.jl:55), and its
+        # radial octaves count from a point just inside the horizon -- the pole of g_rr, towards which the patches shrink.
+        # (The reference traces the plunging region down to 1.000001 of the horizon, orbit-solving.jl:162.  No image ray gets below
+        # the chart's 1.01, and within 1e-6 of the horizon double precision leaves g_rr itself with 1e-9 of rounding noise -- Δ is a
+        # difference of O(1) terms there: the plunge of a tabulated metric is traced as far as its table reaches,
+        # special_radii.interpolate_plunging_velocities; `closest_approach` or `cover` take the table lower if a chart needs it.)
+        rh = self._inner_radius
+        self.r_min = float(r_min) if r_min is not None else (rh * (1.0 + 0.9 * (closest_approach - 1.0)) if rh > 0 else rh)
+        self._r0_given = r0 is not None
+        self.r0 = float(r0) if r0 is not None else self._default_r0(self.r_min)
         self.r_max = float(r_max)
+        self._fit_args = dict(m_r=int(m_r), n_theta=int(n_theta), tol=float(tol), dtol=float(dtol), max_refinements=int(max_refinements),
+                              pole_factor=pole_factor, strict=bool(strict))
+        self._build()
+
+    def _default_r0(self, r_min):
+        rh = self._inner_radius
+        if rh > 0 and r_min > rh:
+            return rh - 0.1 * (r_min - rh)               # the pole of g_rr lies a tenth of the first patch's distance behind r0
+        return r_min - max(1.0, abs(r_min))              # (no horizon above r_min -- a wormhole's throat, flat space: nothing to shrink towards)
+
+    def cover(self, r_inner, r_outer):
+        """Make the table contain [r_inner, r_outer] (a chart, an observer far out): refit on a larger range when it does not --
+        polynomials do not extrapolate, and the library refuses a chart that leaves the table."""
+        lo, hi = self.r_min, self.r_max
+        if r_outer > hi * (1.0 + 1e-9):
+            hi = 2.0 * float(r_outer)
+        if r_inner < lo * (1.0 - 1e-9) - 1e-12:
+            rh = self._inner_radius
+            if rh > 0 and not r_inner > rh:
+                raise ValueError(f"TabulatedMetric: a chart that reaches r = {r_inner:.9g} crosses the horizon at {rh:.9g}")
+            lo = float(r_inner) - (1e-3 * (float(r_inner) - rh) if rh > 0 else 1e-9 * max(1.0, abs(float(r_inner))))
+        if (lo, hi) != (self.r_min, self.r_max):
+            self.r_min, self.r_max = lo, hi
+            if not self._r0_given:
+                self.r0 = self._default_r0(lo)
+            self._build()
+        return self
+
+    def _plan(self, m_r, n_theta):
+        from . import _lib
+
+        L = _lib.load()
+        grid = _lib.gr_metric_grid()
+        inside = [b for b in self.breaks if self.r_min < b[0] < self.r_max]
+        if inside:
+            arr = (_lib.gr_metric_break * len(inside))(*[_lib.gr_metric_break(b[0], b[1]) for b in inside])
+            _lib.check(L.gr_metric_grid_plan_breaks(self.r_min, self.r_max, self.r0, int(m_r), int(n_theta), len(inside), arr, grid))
+        else:
+            _lib.check(L.gr_metric_grid_plan(self.r_min, self.r_max, self.r0, int(m_r), int(n_theta), grid))
+        return grid
+
+    def _build(self):
+        import warnings
+
+        from . import _lib
+
+        a = self._fit_args
+        m_r, n_theta, tol, dtol, strict = a["m_r"], a["n_theta"], a["tol"], a["dtol"], a["strict"]
         L = _lib.load()
         miss = lambda e_: max(e_[0] / tol, e_[1] / dtol, e_[2] / dtol)
-        for attempt in range(max_refinements + 1):
-            grid = _lib.gr_metric_grid()
-            _lib.check(L.gr_metric_grid_plan(self.r_min, self.r_max, self.r0, int(m_r), int(n_theta), grid))
-            grid.pole_factor = 1 if pole_factor else 0      # g_ϕϕ, g_tϕ stored without the sin²θ they share on the axis
+        # the form g_ϕϕ and g_tϕ are stored in (gr_metric_grid.pole_factor): 1 = divided by sin²θ; tried in this order when that fails
+        forms = [1, 2, 0] if a["pole_factor"] is True else [int(a["pole_factor"])]
+        form = forms[0]
+        self.errors = None
+        for attempt in range(a["max_refinements"] + 1):
+            grid = self._plan(m_r, n_theta)
             rn, tn = np.empty(grid.n_r_nodes), np.empty(grid.n_theta_nodes)
             _lib.check(L.gr_metric_grid_nodes(grid, rn.ctypes.data, tn.ctypes.data))
             samples = self._sample(rn, tn)
-            table = np.empty(grid.table_doubles)
-            err = (ctypes.c_double * 3)()
-            _lib.check(L.gr_metric_table_fit(grid, samples.ctypes.data, table.ctypes.data, err))
-            if attempt == 0 and pole_factor and miss(tuple(err)) > 1e4:
-                # g_ϕϕ / sin²θ is not smooth on the axis for every metric: with an axion charge (the dilaton-axion metric, β != 0)
-                # g_ϕϕ does not vanish there.  The same samples fitted with g_ϕϕ, g_tϕ as they are: kept if two orders better.
-                grid2 = _lib.gr_metric_grid()
-                _lib.check(L.gr_metric_grid_plan(self.r_min, self.r_max, self.r0, int(m_r), int(n_theta), grid2))
-                grid2.pole_factor = 0
-                table2, err2 = np.empty(grid2.table_doubles), (ctypes.c_double * 3)()
-                _lib.check(L.gr_metric_table_fit(grid2, samples.ctypes.data, table2.ctypes.data, err2))
-                if miss(tuple(err2)) < 1e-2 * miss(tuple(err)):
-                    pole_factor, grid, table, err = False, grid2, table2, err2
-                    warnings.warn("TabulatedMetric: g_ϕϕ / sin²θ is not smooth on the polar axis of this metric (g_ϕϕ does not vanish there); "
-                                  "g_ϕϕ and g_tϕ are tabulated as they are.  Where g_ϕϕ passes through zero next to the axis the table's "
-                                  "absolute accuracy is no relative one: rays that graze the axis within a few milliradians end up to "
-                                  "1e-2 off in ϕ (DESIGN.md §5c)", stacklevel=2)
-            previous = getattr(self, "errors", None)
-            self.grid, self.table, self.errors = grid, table, tuple(err)
+
+            def fit(form_):
+                g = _lib.gr_metric_grid.from_buffer_copy(grid)
+                g.pole_factor = form_
+                t, e = np.empty(g.table_doubles), (ctypes.c_double * 3)()
+                _lib.check(L.gr_metric_table_fit(g, samples.ctypes.data, t.ctypes.data, e))
+                return g, t, tuple(e)
+
+            g_, table, err = fit(form)
+            if attempt == 0 and len(forms) > 1 and miss(err) > 1e4:
+                # g_ϕϕ / sin²θ is not smooth on the axis of every metric.  With an axion charge (the dilaton-axion metric, β != 0)
+                # g_ϕϕ and g_tϕ do not vanish there: form 2 takes their limits on the two poles out first, K_m(r) + K_d(r) cos θ, and
+                # divides the rest.  The reference's Morris-Thorne g_ϕϕ ∝ sin θ is smooth as it is (form 0).  Same samples.
+                for alt in forms[1:]:
+                    g2, t2, e2 = fit(alt)
+                    if miss(e2) < 1e-2 * miss(err):
+                        g_, table, err, form = g2, t2, e2, alt
+                        break
+            previous = self.errors
+            self.grid, self.table, self.errors = g_, table, err
             if err[0] <= tol and err[1] <= dtol and err[2] <= dtol:
                 break
-            # a degree-7 fit gains 2^8 per halving of a smooth function's patches; one that gains less than 16 is looking at a
+            # a fit of degree p gains 2^(p+1) per halving of a smooth function's patches; one that gains less than 16 is looking at a
             # kink or a pole, and the doublings left (4x the samples each) would not close a gap of 1000
             if previous is not None and miss(self.errors) > miss(previous) / 16.0 and miss(self.errors) > 1e3:
                 break
@@ -550,14 +631,16 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             if err[2] > dtol or err[0] > tol:
                 n_theta *= 2
         self.m_r, self.n_theta = int(self.grid.m_r), int(self.grid.n_theta)
+        self._segs = [self.grid.seg[k] for k in range(self.grid.n_seg)]
         e = self.errors
         if e[0] > 100.0 * tol or e[1] > 100.0 * dtol or e[2] > 100.0 * dtol:
             msg = (f"TabulatedMetric: the fit's error estimates (value {e[0]:.2g}, ∂r {e[1]:.2g}, ∂θ {e[2]:.2g}; asked {tol:.2g}, {dtol:.2g}) did not "
                    f"come down on the grid ({self.m_r}, {self.n_theta}): the metric is not smooth on r in [{self.r_min:.6g}, {self.r_max:.6g}] -- a "
-                   "horizon inside the range (raise `inner_radius` / `r_min`), a kink in one of its functions, or NaNs")
+                   "horizon inside the range (raise `inner_radius` / `r_min`), a kink or a jump in one of its functions (name the radius "
+                   "in `breaks`), or NaNs")
             if strict and not (e[0] <= 1e-7 and e[1] <= 1e-4 and e[2] <= 1e-4):
                 raise ValueError(msg + "; strict=False traces through the table as it is")
-            warnings.warn(msg, stacklevel=2)
+            warnings.warn(msg, stacklevel=3)
 
     def _outermost_horizon(self, r_in, r_max):
         """The largest r in (r_in, r_max) where g_rr changes sign (or stops being finite) on the equator or near the axis, refined
@@ -632,6 +715,36 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
         _lib.check(_lib.load().gr_metric_table_eval(self.table.ctypes.data, self.table.size, float(r), float(theta), g, dr, dth))
         return np.array(g), np.array(dr), np.array(dth)
 
+    def _rows_of(self, rv):
+        """Radial row of every radius of an array, and the affine map u = A r + B of that row (gr_tab::locate_row, vectorised)."""
+        rv = np.asarray(rv, dtype=np.float64)
+        m_r = self.m_r
+        sidx = np.zeros(rv.shape, dtype=np.int64)
+        for q in range(1, len(self._segs)):
+            sidx += rv >= self._segs[q].r_lo
+        row, A, B = np.empty(rv.shape, dtype=np.int64), np.empty(rv.shape), np.empty(rv.shape)
+        for q, sg in enumerate(self._segs):
+            sel = sidx == q
+            if not sel.any():
+                continue
+            d = float(sg.dir)
+            x = d * (rv[sel] - sg.anchor)
+            x = np.clip(x, 0.0, 2.0 ** (sg.e_hi + 2))
+            lin = (x < sg.xmin) if sg.core else np.zeros(x.shape, dtype=bool)
+            xx = np.where(lin, sg.xmin, np.maximum(x, sg.xmin))
+            e = np.clip(np.floor(np.log2(xx)).astype(np.int64), sg.e_lo, sg.e_hi)
+            e = np.where(lin, sg.e_lo, e)
+            sc = np.exp2(-e.astype(np.float64))
+            f = np.where(lin, x * sc + 1.0, xx * sc)
+            j = np.clip(((f - 1.0) * m_r).astype(np.int64), 0, m_r - 1)
+            octv = np.where(lin, 0, e - sg.e_lo + sg.core)
+            row[sel] = sg.first_row + octv * m_r + j
+            # u = 2 ((f - 1) m_r - j) - 1 with f = x 2^-e (+ 1 in the core), x = d (r - anchor)
+            a_ = 2.0 * m_r * sc * d
+            A[sel] = a_
+            B[sel] = -a_ * sg.anchor + np.where(lin, 0.0, -2.0 * m_r) - 2.0 * j - 1.0
+        return row, A, B
+
     def _table_components(self, r, theta):
         """The five components from the table with `r` a float or a Jet (value, d/dr, d²/dr²): the patch polynomial is
         evaluated in the number type of r, so its exact derivatives come along."""
@@ -642,12 +755,7 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             # an array of radii (the generic ISCO's downward scan): every radius in its own patch -- grouped, one evaluation per
             # group on that group's slice of r
             rv = np.asarray(rv, dtype=np.float64)
-            t_ = self.table
-            r0_, e_min_, n_oct_, m_r_ = t_[2], int(t_[3]), int(t_[4]), int(t_[5])
-            xx = np.maximum(rv - r0_, 2.0 ** e_min_)
-            ee = np.minimum(np.floor(np.log2(xx)).astype(np.int64), e_min_ + n_oct_ - 1)
-            jj = np.minimum(((xx / np.exp2(ee) - 1.0) * m_r_).astype(np.int64), m_r_ - 1)
-            key = (ee - e_min_) * m_r_ + jj
+            key, _, _ = self._rows_of(rv)
             outs = [np.empty(rv.shape) for _ in range(5)]
             jets = isinstance(r, Jet)
             if jets:
@@ -655,7 +763,6 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
             pick = lambda z, sel: z[sel] if isinstance(z, np.ndarray) else z
             for kk in np.unique(key):
                 sel = key == kk
-                # (within one patch the evaluation below is vectorised: the patch is chosen from the group's largest radius)
                 sub = Jet(rv[sel], pick(r.d, sel), pick(r.dd, sel)) if jets else rv[sel]
                 res = self._table_components_one_patch(sub, theta)
                 for c in range(5):
@@ -668,26 +775,25 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
         return self._table_components_one_patch(r, theta)
 
     def _table_components_one_patch(self, r, theta):
-        """(r: a float, a Jet, or an array / Jet of arrays that lies within ONE radial patch)"""
+        """(r: a float, a Jet, or an array / Jet of arrays that lies within ONE radial row)"""
         from .special_radii import Jet
 
         rv = r.v if isinstance(r, Jet) else r
         t = self.table
-        r0, e_min, n_oct, m_r, n_th = t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6])
+        n_th = int(t[6])
         w = abs(((theta + math.pi) % (2.0 * math.pi)) - math.pi)
         y = w * n_th / math.pi
         it = min(int(y), n_th - 1)
         v = 2.0 * (y - it) - 1.0
-        x = max(float(np.max(rv)) - r0, 2.0 ** e_min) if np.ndim(rv) else max(rv - r0, 2.0 ** e_min)
-        e = min(int(math.floor(math.log2(x))), e_min + n_oct - 1)
-        j = min(int((x / 2.0 ** e - 1.0) * m_r), m_r - 1)
-        # u as a function of r (the Jet carries du/dr = 2 m_r 2^-e)
-        u = ((r - r0) * (1.0 / 2.0 ** e) - 1.0) * float(m_r) * 2.0 - (2.0 * j + 1.0)
-        p = 7
-        base = 16 + ((e - e_min) * m_r + j) * n_th * 184 + it * 184
+        row, A, B = self._rows_of(np.atleast_1d(np.asarray(rv, dtype=np.float64))[:1])
+        row, A, B = int(row[0]), float(A[0]), float(B[0])
+        u = r * A + B                                    # (the Jet carries du/dr)
+        p, stride, form = int(t[1]), int(t[7]), int(t[14])          # H_DEGREE, H_STRIDE, H_POLE_FACTOR
+        nc = (p + 1) * (p + 2) // 2
+        base = int(t[18]) + (row * n_th + it) * stride   # H_PATCH_OFF
         out = []
         for k in range(5):
-            cb = base + k * 36
+            cb = base + k * nc
             acc = None
             for i in range(p, -1, -1):                   # rows i = p .. 0 are stored in this order
                 n = p - i
@@ -696,7 +802,16 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
                 for tt in range(1, n + 1):
                     q = q * v + t[off + tt]
                 acc = q if acc is None else acc * u + q
-            out.append(acc * (math.sin(theta) ** 2) if (k >= 3 and t[14] != 0.0) else acc)
+            if k >= 3 and form != 0:
+                acc = acc * (math.sin(theta) ** 2)
+                if form == 2:
+                    ab = int(t[17]) + row * 4 * (p + 1) + 2 * (k - 3) * (p + 1)      # H_AXIS_OFF: K_m then K_d of this component
+                    km, kd = t[ab], t[ab + p + 1]
+                    for tt in range(1, p + 1):
+                        km = km * u + t[ab + tt]
+                        kd = kd * u + t[ab + p + 1 + tt]
+                    acc = acc + km + kd * math.cos(theta)
+            out.append(acc)
         return tuple(out)
 
     def inner_radius(self):

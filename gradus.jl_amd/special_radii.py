@@ -239,7 +239,11 @@ def interpolate_plunging_velocities(m, ensemble=None, max_time=50_000.0, reltol=
     isco = m.isco()
     u = np.array([0.0, isco - δr, math.pi / 2, 0.0])
     v = plunging_fourvelocity(m, isco)
-    chart = PolarChart(m.inner_radius() * 1.000001, 12000.0)   # chart_for_metric(m; closest_approach = 1.000001)
+    inner = m.inner_radius() * 1.000001                          # chart_for_metric(m; closest_approach = 1.000001)
+    if hasattr(m, "table"):
+        # a tabulated metric: as far as its table reaches (metrics.TabulatedMetric: no ray of an image gets below the chart's 1.01)
+        inner = max(inner, m.r_min * (1.0 + 1e-9))
+    chart = PolarChart(inner, 12000.0)
     path = tracegeodesic_path(m, u, v, (0.0, max_time), μ=1.0, reltol=reltol, chart=chart, ensemble=ensemble)
     r = path.x[:, 1]
     idx = np.argsort(r, kind="stable")[1:]

@@ -309,7 +309,12 @@ class TracingConfiguration:
         for i, p in enumerate(m.abi_params()):
             c.params[i] = float(p)
         if hasattr(m, "table"):
-            # GR_METRIC_TABULATED: the fitted table of a user-defined metric (metrics.TabulatedMetric keeps it alive)
+            # GR_METRIC_TABULATED: the fitted table of a user-defined metric (metrics.TabulatedMetric keeps it alive).  The chart and
+            # the point the rays start from must lie inside it (polynomials do not extrapolate; the library refuses): it grows first.
+            ch_in = float(np.nanmin(self.chart.table)) if isinstance(self.chart, PoloidalShapeChart) else float(self.chart.inner_radius)
+            r_start = float(np.asarray(self.position, dtype=np.float64).reshape(-1, 4)[:, 1].max()) if self.position is not None else ch_in
+            r_start_lo = float(np.asarray(self.position, dtype=np.float64).reshape(-1, 4)[:, 1].min()) if self.position is not None else ch_in
+            m.cover(min(ch_in, r_start_lo), max(float(self.chart.outer_radius), r_start))
             c.metric_table, c.metric_table_n = m.table.ctypes.data, m.table.size
         if isinstance(self.chart, PoloidalShapeChart):
             ch = self.chart

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GR_ABI_VERSION 7
+#define GR_ABI_VERSION 8
 
 typedef enum {
     GR_OK = 0,
@@ -546,7 +546,7 @@ int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays
                         double* rho_min_max /* 2 */, int64_t* n_hits, gr_stats* stats);
 int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double* out /* 3 x n_edges */);
 
-/* ---- tabulated metrics (ABI 7, GR_METRIC_TABULATED): the AbstractMetric plugin interface on the device ----
+/* ---- tabulated metrics (ABI 7; segments, axis terms: ABI 8; GR_METRIC_TABULATED): the AbstractMetric plugin interface on the device ----
  * Host-only functions (no context, no device): plan a grid, learn its nodes, fit, check.
  *
  *   gr_metric_grid g;  gr_metric_grid_plan(r_min, r_max, r0, m_r, n_theta, &g);
@@ -557,27 +557,60 @@ int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double*
  *
  * Radial patches are the m_r equal parts of every octave [2^e, 2^(e+1)) of r - r0 between r_min and r_max: choose r0 at (or just
  * inside) the event horizon -- inner_radius(m) -- and r_min = the chart's inner radius, so that the patches shrink geometrically
- * towards the pole of g_rr; r_max = the chart's outer radius.  Polar patches: n_theta equal parts of [0, π]; the components are
+ * towards the pole of g_rr; r_max = the chart's outer radius (the entry points refuse a chart, an observer or a source outside
+ * [r_min, r_max]: polynomials do not extrapolate).  Polar patches: n_theta equal parts of [0, π]; the components are
  * taken to be even about both poles (θ outside [0, π] is folded).  err[0..2] receive the fit's own estimates of the largest
  * truncation error of a component, of its ∂/∂ln(r - r0) and of its ∂/∂θ, each relative to the component's magnitude on the
- * patch: refine (m_r, n_theta) until they are below what the integration tolerance needs. */
+ * patch: refine (m_r, n_theta) until they are below what the integration tolerance needs.
+ *
+ * ABI 8 -- metrics that are PIECEWISE in r (the reference's KerrDarkMatter, src/metrics/kerr-dark-matter.jl:12-20: kinks at rₛ and
+ * rₛ + Δr; KerrRefractive, kerr-refractive-ad.jl:26 with utils.jl:158-168: jumps at corona_radius ± δx/2 and an arctangent step
+ * of width δx/10⁴ between them) name their break radii: gr_metric_grid_plan_breaks starts a new radial SEGMENT at every break,
+ * anchored there (octaves of r - break, behind a core of m_r equal parts of the first octave's width), so that no patch straddles
+ * a break and the rows next to one are fitted on their own side only.  A break with scale > 0 is a feature of that width centred
+ * there: the patches shrink geometrically towards it from BOTH sides, down to that scale.  Radii may be negative (a chart through
+ * the throat of src/metrics/morris-thorne-ad.jl's wormhole: a break at 0 with scale b): a segment measures distances from its
+ * anchor.  gr_metric_grid_plan is the call without breaks: one segment, anchored at r0. */
+#define GR_METRIC_MAX_SEG 12
+typedef struct gr_metric_break {
+    double radius;            /* where metric_components changes form                                         */
+    double scale;             /* 0: a kink or a jump AT radius; > 0: a smooth feature of this width centred at radius */
+} gr_metric_break;
+typedef struct gr_metric_segment {
+    double r_lo, r_hi;        /* radii r_lo <= r < r_hi take this segment                                    */
+    double anchor;            /* x = dir (r - anchor) > 0 inside the segment                                 */
+    double xmin;              /* 2^e_lo                                                                       */
+    double fit_lo, fit_hi;    /* the metric is smooth on (fit_lo, fit_hi) ⊇ [r_lo, r_hi): no node lies outside (±inf: no limit) */
+    int32_t e_lo, e_hi;       /* octaves 2^e_lo .. 2^(e_hi + 1) of x                                          */
+    int32_t first_row, n_rows; /* radial rows (core + e_hi - e_lo + 1) m_r of the table                       */
+    int32_t dir;              /* +1 | -1                                                                      */
+    int32_t core;             /* 1: m_r equal parts of [0, 2^e_lo) come first                                 */
+} gr_metric_segment;
 typedef struct gr_metric_grid {
-    double r0;                /* origin of the radial octaves                                               */
+    double r0;                /* origin of the radial octaves of segment 0                                   */
     double r_min, r_max;      /* radii the table covers (patch edges are rounded outwards)                   */
-    int32_t e_min, n_oct;     /* octaves 2^e_min .. 2^(e_min + n_oct) of r - r0                              */
+    int32_t e_min, n_oct;     /* segment 0: octaves 2^e_min .. 2^(e_min + n_oct) of r - r0                   */
     int32_t m_r, n_theta;     /* patches per octave, patches over [0, π]                                     */
     int32_t degree, fit_nodes; /* total degree of a patch polynomial (7), Chebyshev nodes per patch and direction (12) */
-    int32_t pole_factor;      /* 1 [set by gr_metric_grid_plan]: g_ϕϕ and g_tϕ are stored divided by sin²θ -- both vanish like
-                                 sin²θ on the axis of any regular axis-symmetric metric, and a polynomial with an ABSOLUTE error
-                                 would leave g^ϕϕ = 1/g_ϕϕ with an unbounded RELATIVE one for rays that graze the axis; the
-                                 kernels multiply the factor (and its derivative) back.  0: stored as sampled -- for a metric
-                                 whose g_ϕϕ does not vanish like sin²θ (the reference's MorrisThorneWormhole, ∝ sin θ)      */
-    int32_t reserved;
-    int64_t n_r_nodes;        /* n_oct * m_r * fit_nodes                                                     */
+    int32_t pole_factor;      /* the form g_ϕϕ and g_tϕ are stored in (the caller may change it between plan and fit):
+                                 1 [set by gr_metric_grid_plan]: divided by sin²θ -- both vanish like sin²θ on the axis of a regular
+                                 axis-symmetric metric, and a polynomial with an ABSOLUTE error would leave g^ϕϕ with an unbounded
+                                 RELATIVE one for rays that graze the axis; the kernels multiply the factor (and its derivative) back.
+                                 2: g = K_m(r) + K_d(r) cos θ + sin²θ h(r, θ) -- a metric whose g_ϕϕ, g_tϕ do NOT vanish on the axis
+                                 (an axion charge: the reference's DilatonAxion with β != 0): K_m ± K_d, the limits on the two poles,
+                                 are taken from the samples nearest the poles and stored as polynomials per radial row.
+                                 0: stored as sampled (the reference's MorrisThorneWormhole, g_ϕϕ ∝ sin θ)                        */
+    int32_t n_seg;            /* radial segments (1 without breaks)                                          */
+    int64_t n_r_nodes;        /* n_rows * fit_nodes                                                          */
     int64_t n_theta_nodes;    /* n_theta * fit_nodes                                                         */
     int64_t table_doubles;    /* length of the table gr_metric_table_fit writes                              */
+    int32_t n_rows;           /* radial rows of all segments                                                 */
+    int32_t reserved;
+    gr_metric_segment seg[GR_METRIC_MAX_SEG];
 } gr_metric_grid;
 int32_t gr_metric_grid_plan(double r_min, double r_max, double r0, int32_t m_r, int32_t n_theta, gr_metric_grid* grid);
+int32_t gr_metric_grid_plan_breaks(double r_min, double r_max, double r0, int32_t m_r, int32_t n_theta, int32_t n_breaks,
+                                   const gr_metric_break* breaks /* n_breaks, any order */, gr_metric_grid* grid);
 int32_t gr_metric_grid_nodes(const gr_metric_grid* grid, double* r_nodes, double* theta_nodes);
 int32_t gr_metric_table_fit(const gr_metric_grid* grid, const double* samples /* n_r_nodes x n_theta_nodes x 5 */,
                             double* table /* table_doubles */, double* err /* 3, may be NULL */);

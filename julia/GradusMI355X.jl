@@ -38,7 +38,7 @@ export EnsembleMI355X, SampledThickDisc, render_mi355x, lineprofile_mi355x, emis
     selftest
 
 const LIB = get(ENV, "GRADUS_MI355X_LIB", "libgradus_mi355x.so")
-const ABI_VERSION = 7
+const ABI_VERSION = 8
 
 # ---------------------------------------------------------------------------------------------------------------
 # POD mirrors of include/gradus_mi355x.h (field order and types checked by tests/test_julia_binding.py)
@@ -89,6 +89,28 @@ struct GrConfig                      # == gr_config
     metric_table_n::Int64
 end
 
+struct GrMetricBreak                 # == gr_metric_break: a radius where metric_components changes form (scale 0), or a feature that narrow
+    radius::Float64
+    scale::Float64
+end
+
+struct GrMetricSegment               # == gr_metric_segment: one radial segment of a tabulated metric's grid
+    r_lo::Float64
+    r_hi::Float64
+    anchor::Float64
+    xmin::Float64
+    fit_lo::Float64
+    fit_hi::Float64
+    e_lo::Int32
+    e_hi::Int32
+    first_row::Int32
+    n_rows::Int32
+    dir::Int32
+    core::Int32
+end
+
+const METRIC_MAX_SEG = 12            # GR_METRIC_MAX_SEG
+
 struct GrMetricGrid                  # == gr_metric_grid: the patch grid of a tabulated metric
     r0::Float64
     r_min::Float64
@@ -100,10 +122,13 @@ struct GrMetricGrid                  # == gr_metric_grid: the patch grid of a ta
     degree::Int32
     fit_nodes::Int32
     pole_factor::Int32
-    reserved::Int32
+    n_seg::Int32
     n_r_nodes::Int64
     n_theta_nodes::Int64
     table_doubles::Int64
+    n_rows::Int32
+    reserved::Int32
+    seg::NTuple{12,GrMetricSegment}
 end
 
 struct GrStats                       # == gr_stats
@@ -269,7 +294,22 @@ _metric(m::NoZMetric) = (Int32(10), (m.M, m.a, m.ϵ, 0.0, 0.0, 0.0, 0.0, 0.0))
 # Any other static, axis-symmetric metric -- the reference's plugin contract: a struct `<: AbstractStaticAxisSymmetric` and ONE
 # method, `metric_components(m, rθ)` (src/Gradus.jl:78-86, src/metrics/kerr-metric.jl:62-70) -- runs on the device from a table of
 # that method's values (GR_METRIC_TABULATED, ABI 7; `metric_table` below).  Only what is not even that stays on the CPU.
-_metric(m::Gradus.AbstractStaticAxisSymmetric) = (Int32(11), (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+_metric(m::Gradus.AbstractStaticAxisSymmetric) = (Int32(11), _tabulated_params(m))
+function _tabulated_params(m)
+    # The table carries `metric_components` and nothing else.  A type that ALSO brings its own `geodesic_equation` or
+    # `metric_jacobian` (instead of the generic methods of src/tracing/method-implementations/auto-diff.jl:206-226), or an
+    # electromagnetic potential for charged particles (kerr-newman-ad.jl:63), defines dynamics the table does not hold: those
+    # stay with the reference's CPU ensemble rather than being traced as plain geodesics of the components.
+    T = typeof(m)
+    x4 = SVector{4,Float64}
+    generic_ge = which(Gradus.geodesic_equation, Tuple{Gradus.AbstractStaticAxisSymmetric,x4,x4})
+    generic_mj = which(Gradus.metric_jacobian, Tuple{Gradus.AbstractStaticAxisSymmetric,SVector{2,Float64}})
+    (which(Gradus.geodesic_equation, Tuple{T,x4,x4}) === generic_ge && which(Gradus.metric_jacobian, Tuple{T,SVector{2,Float64}}) === generic_mj) ||
+        throw(UnsupportedOnDevice("$T overrides geodesic_equation / metric_jacobian: its dynamics are not those of its metric_components alone"))
+    hasmethod(Gradus.electromagnetic_potential, Tuple{T,SVector{2,Float64}}) &&
+        throw(UnsupportedOnDevice("$T carries an electromagnetic potential: the table holds the metric only"))
+    (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+end
 _metric(m) = throw(UnsupportedOnDevice("metric $(typeof(m)) is not static and axis-symmetric: no device implementation"))
 _is_tabulated(m) = _metric(m)[1] == Int32(11)
 
@@ -277,27 +317,50 @@ const _METRIC_TABLES = Dict{Any,Vector{Float64}}()      # (metric, r_min, r_max)
 const METRIC_TABLE_TOL = (2e-11, 1e-8, 1e-8)             # the fit's own estimates a table must meet: value, ∂/∂ln(r - r0), ∂/∂θ
 
 """
-    metric_table(m, r_inner, r_outer; m_r = 8, n_theta = 32, refinements = 3) -> Vector{Float64}
+    metric_breaks(m) -> Vector{Tuple{Float64,Float64}}
+
+Radii where `metric_components(m, (r, θ))` changes form, as `(radius, scale)`: scale 0 for a kink or a jump AT the radius,
+scale > 0 for a smooth feature of that width centred there.  A table's patches never straddle a break (ABI 8,
+`gr_metric_grid_plan_breaks`); towards a break with a scale they shrink geometrically from both sides.  Extend it for a metric of
+your own that is piecewise in r:  `GradusMI355X.metric_breaks(m::MyMetric) = [(m.r_shell, 0.0)]`.
+"""
+metric_breaks(m) = Tuple{Float64,Float64}[]
+# src/metrics/kerr-dark-matter.jl:12-20: the enclosed mass is piecewise, C¹ at rₛ and rₛ + Δr
+metric_breaks(m::KerrDarkMatter) = [(Float64(m.rₛ), 0.0), (Float64(m.rₛ + m.Δr), 0.0)]
+# src/metrics/kerr-refractive-ad.jl:26 with src/utils.jl:158-168 (δx = 2.5, smoothing_offset = 1e4): jumps of 6e-5 in n at
+# corona_radius ± δx/2 and an arctangent step of width δx / 1e4 at corona_radius
+metric_breaks(m::KerrRefractive) = [(Float64(m.corona_radius) - 1.25, 0.0), (Float64(m.corona_radius), 2.5e-4), (Float64(m.corona_radius) + 1.25, 0.0)]
+
+# a copy of an (immutable) grid with another storage form for g_ϕϕ, g_tϕ
+_with_form(g::GrMetricGrid, form) = GrMetricGrid(ntuple(i -> fieldname(GrMetricGrid, i) === :pole_factor ? Int32(form) : getfield(g, i), fieldcount(GrMetricGrid))...)
+
+"""
+    metric_table(m, r_inner, r_outer; m_r = 8, n_theta = 32, refinements = 3, breaks = metric_breaks(m)) -> Vector{Float64}
 
 The piecewise-polynomial table of `metric_components(m, (r, θ))` between the chart's radii that the kernels trace a
-user-defined metric through.  The library names the sample nodes (`gr_metric_grid_plan`, `gr_metric_grid_nodes`), this
+user-defined metric through.  The library names the sample nodes (`gr_metric_grid_plan[_breaks]`, `gr_metric_grid_nodes`), this
 function evaluates `Gradus.metric_components` there -- the ONLY thing it asks of `m`, exactly the reference's contract --, the
 library fits (`gr_metric_table_fit`) and reports its error estimates; the grid is refined until they meet
-`METRIC_TABLE_TOL`.  Radial patches are geometric in `r - r0` with `r0` just inside `Gradus.inner_radius(m)`.
+`METRIC_TABLE_TOL`.  Radial patches are geometric in `r - r0` with `r0` just inside `Gradus.inner_radius(m)`, and start anew
+at every radius of `breaks`.  The azimuthal components are stored divided by sin²θ; for a metric whose g_ϕϕ, g_tϕ do not vanish
+on the axis (DilatonAxion with β != 0) their limits on the two poles are taken out first (form 2), and where neither is smooth
+(MorrisThorneWormhole: g_ϕϕ ∝ sin θ) they are stored as sampled (form 0).
 Tables are cached per (metric, radii).  `gr_metric_table_eval` checks one against `Gradus.metric_jacobian` (see `selftest`).
 """
-function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 32, refinements = 3)
+function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 32, refinements = 3, breaks = metric_breaks(m))
     get!(_METRIC_TABLES, (m, r_inner, r_outer)) do
         rh = Float64(Gradus.inner_radius(m))
-        r0 = rh > 0 ? rh * (1 - 1e-3) : min(-1.0, r_inner - 1.0)
-        r_min = max(r_inner * (1 - 1e-3), r0 + 1e-3)
+        # the table starts a hair inside the chart; its octaves count from a tenth of that distance behind the horizon
+        r_min = (rh > 0 && r_inner > rh) ? r_inner - 1e-3 * (r_inner - rh) : r_inner - 1e-9 * max(1.0, abs(r_inner))
+        r0 = (rh > 0 && r_min > rh) ? rh - 0.1 * (r_min - rh) : r_min - max(1.0, abs(r_min))
+        bs = [GrMetricBreak(Float64(b[1]), Float64(b[2])) for b in breaks if r_min < b[1] < r_outer]
         local table
         previous, last_err = Inf, [Inf, Inf, Inf]
-        raw_azimuth = nothing          # decided by the first fit: store g_ϕϕ, g_tϕ without the sin²θ factor?
+        form = nothing                 # decided by the first fit: how g_ϕϕ, g_tϕ are stored (gr_metric_grid.pole_factor)
         for _ = 0:refinements
             grid = Ref{GrMetricGrid}()
-            _check(ccall((:gr_metric_grid_plan, LIB), Int32, (Float64, Float64, Float64, Int32, Int32, Ref{GrMetricGrid}),
-                r_min, r_outer, r0, m_r, n_theta, grid))
+            _check(ccall((:gr_metric_grid_plan_breaks, LIB), Int32, (Float64, Float64, Float64, Int32, Int32, Int32, Ptr{GrMetricBreak}, Ref{GrMetricGrid}),
+                r_min, r_outer, r0, m_r, n_theta, length(bs), bs, grid))
             g = grid[]
             rn, tn = Vector{Float64}(undef, g.n_r_nodes), Vector{Float64}(undef, g.n_theta_nodes)
             _check(ccall((:gr_metric_grid_nodes, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}), grid, rn, tn))
@@ -311,25 +374,26 @@ function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 
                     end
                 end
             end
-            table = Vector{Float64}(undef, g.table_doubles)
-            err = zeros(Float64, 3)
-            _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                grid, samples, table, err))
-            if raw_azimuth === nothing && maximum(err ./ METRIC_TABLE_TOL) > 1e4
-                # g_ϕϕ / sin²θ is not smooth on the axis of every metric (an axion charge -- DilatonAxion with β != 0 -- leaves g_ϕϕ
-                # finite there): the same samples fitted with g_ϕϕ and g_tϕ as they are, kept when two orders better
-                grid2 = Ref(GrMetricGrid(g.r0, g.r_min, g.r_max, g.e_min, g.n_oct, g.m_r, g.n_theta, g.degree, g.fit_nodes, Int32(0),
-                    g.reserved, g.n_r_nodes, g.n_theta_nodes, g.table_doubles))
-                table2, err2 = Vector{Float64}(undef, g.table_doubles), zeros(Float64, 3)
+            fit(f) = begin
+                t, e = Vector{Float64}(undef, g.table_doubles), zeros(Float64, 3)
                 _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                    grid2, samples, table2, err2))
-                raw_azimuth = maximum(err2 ./ METRIC_TABLE_TOL) < 1e-2 * maximum(err ./ METRIC_TABLE_TOL)
-                raw_azimuth && ((table, err) = (table2, err2))
-            elseif raw_azimuth === true
-                grid2 = Ref(GrMetricGrid(g.r0, g.r_min, g.r_max, g.e_min, g.n_oct, g.m_r, g.n_theta, g.degree, g.fit_nodes, Int32(0),
-                    g.reserved, g.n_r_nodes, g.n_theta_nodes, g.table_doubles))
-                _check(ccall((:gr_metric_table_fit, LIB), Int32, (Ref{GrMetricGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                    grid2, samples, table, err))
+                    Ref(_with_form(g, f)), samples, t, e))
+                (t, e)
+            end
+            table, err = fit(form === nothing ? 1 : form)
+            if form === nothing
+                form = 1
+                if maximum(err ./ METRIC_TABLE_TOL) > 1e4
+                    # g_ϕϕ / sin²θ is not smooth on the axis of every metric: the same samples in the other two forms, the first that is
+                    # two orders better is kept
+                    for alt in (2, 0)
+                        t2, e2 = fit(alt)
+                        if maximum(e2 ./ METRIC_TABLE_TOL) < 1e-2 * maximum(err ./ METRIC_TABLE_TOL)
+                            table, err, form = t2, e2, alt
+                            break
+                        end
+                    end
+                end
             end
             all(err .<= METRIC_TABLE_TOL) && return table
             # a degree-7 fit gains 2^8 per halving of a smooth function's patches: one that gains less than 16 is looking at a kink
@@ -342,14 +406,15 @@ function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 
             (err[1] > METRIC_TABLE_TOL[1] || err[2] > METRIC_TABLE_TOL[2]) && (m_r *= 2)
             (err[1] > METRIC_TABLE_TOL[1] || err[3] > METRIC_TABLE_TOL[3]) && (n_theta *= 2)
         end
-        # Good enough to trace with (value 1e-7, derivatives 1e-4)?  Then warn.  Otherwise the metric is not one a table represents:
-        # UnsupportedOnDevice sends the problem to the reference's own CPU ensemble, as for any configuration the device does not take.
+        # Good enough to trace with (value 1e-7, derivatives 1e-4)?  Then warn.  Otherwise a sample was not finite or the metric has a
+        # break nobody named: UnsupportedOnDevice sends the problem to the reference's own CPU ensemble, as for any configuration the
+        # device does not take.
         if last_err[1] <= 1e-7 && last_err[2] <= 1e-4 && last_err[3] <= 1e-4
             @warn "EnsembleMI355X: the table of $(typeof(m)) misses the fit tolerances (estimates $last_err, asked $METRIC_TABLE_TOL); tracing with it"
             return table
         end
         throw(UnsupportedOnDevice("$(typeof(m)) is not smooth on r in [$r_min, $r_outer] (fit estimates $last_err): a horizon outside " *
-                                  "inner_radius(m), or a piecewise-defined metric function"))
+                                  "inner_radius(m), or a piecewise-defined metric function whose break radii GradusMI355X.metric_breaks(m) does not name"))
     end
 end
 _metric_table(m, r_inner, r_outer) = _is_tabulated(m) ? metric_table(m, Float64(r_inner), Float64(r_outer)) : Float64[]

@@ -35,6 +35,8 @@ if metrics and rev == "WORK":
     for m in metrics.split():
         if m.startswith("t"):
             keep.add(f"kernelstan_m{m[1:]}.o")
+        elif m == "11":      # GR_METRIC_TABULATED: its kernels and the host fit share gr_tabmetric.hpp (-DGR_TAB_DEGREE=...)
+            keep |= {"kernels_m11.o", "metric_table.o"}
         else:
             keep |= {f"kernels_m{m}.o", f"kernels32_m{m}.o", f"kernelstan_m{m}.o"}
     for o, _, _ in units:

@@ -45,20 +45,7 @@ static void dispatch(Params& p, double* tlog, double* hlog, int64_t cap, int64_t
     }
     p.cfg.upper_hemisphere = (p.cfg.upper_hemisphere ? 1 : 0) | (p.cfg.count_windings ? 4 : 0);   // as stage_disc_table does
     if (p.cfg.metric_id == GR_METRIC_TABULATED) {       // ... and stage_metric_table: the table's header into cfg.params (the host pointer stays)
-        const double* t = p.cfg.metric_table;
-        {
-        // the grid in the form TabulatedMetric::load reads it (gr_device.hpp): doubles as doubles, integers as bit fields
-        const gr_tab::GridK gk = gr_tab::make_gridk(t[gr_tab::H_R0], (int)t[gr_tab::H_EMIN], (int)t[gr_tab::H_NOCT], (int)t[gr_tab::H_MR], (int)t[gr_tab::H_NTHETA]);
-        p.cfg.params[0] = gk.r0;
-        p.cfg.params[1] = gk.xmin;
-        p.cfg.params[2] = gk.mr;
-        p.cfg.params[3] = gk.nth_over_pi;
-        p.cfg.params[4] = p.cfg.params[5] = 0.0;
-        const unsigned long long b6 = (unsigned long long)(uint32_t)gk.e_min | ((unsigned long long)(uint32_t)gk.e_max << 32);
-        const unsigned long long b7 = (unsigned long long)gk.m_r | ((unsigned long long)gk.n_theta << 16) | ((t[gr_tab::H_POLE_FACTOR] != 0.0 ? 1ull : 0ull) << 32);
-        std::memcpy(&p.cfg.params[6], &b6, 8);
-        std::memcpy(&p.cfg.params[7], &b7, 8);
-        }
+        gr_tab::stage_params(p.cfg.metric_table, p.cfg.params);
     }
     const int disc = p.cfg.disc_id;
 #define HH_RUN(M) \

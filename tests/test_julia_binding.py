@@ -155,7 +155,7 @@ def jl_ccalls():
 
 JL2C_STRUCT = {"GrConfig": "gr_config", "GrStats": "gr_stats", "GrPlane": "gr_plane", "GrPointFunction": "gr_pointfunction",
                "GrRange": "gr_range", "GrRayset": "gr_rayset", "GrBinning": "gr_binning", "GrDiscComponent": "gr_disc_component",
-               "GrMetricGrid": "gr_metric_grid"}
+               "GrMetricGrid": "gr_metric_grid", "GrMetricSegment": "gr_metric_segment", "GrMetricBreak": "gr_metric_break"}
 
 
 # ---------------------------------------------------------------------------------------------------------------

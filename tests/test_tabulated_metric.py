@@ -160,7 +160,8 @@ def test_host_entry_points_reject_bad_input(G):
     assert lib.gr_metric_grid_plan(1.0, 10.0, 0.5, 2, 2, grid) == 0
     assert grid.pole_factor == 1
     grid.pole_factor = 0                      # the samples below are constants: nothing vanishes on the axis
-    assert grid.degree == 7 and grid.n_r_nodes == grid.n_oct * 2 * grid.fit_nodes and grid.n_theta_nodes == 2 * grid.fit_nodes
+    assert grid.degree == 7 and grid.n_seg == 1 and grid.n_rows == grid.n_oct * 2
+    assert grid.n_r_nodes == grid.n_oct * 2 * grid.fit_nodes and grid.n_theta_nodes == 2 * grid.fit_nodes
     rn, tn = np.empty(grid.n_r_nodes), np.empty(grid.n_theta_nodes)
     assert lib.gr_metric_grid_nodes(grid, rn.ctypes.data, tn.ctypes.data) == 0
     assert rn.min() > 1.0 - 0.5 and np.all(np.diff(np.sort(tn)) > 0) and tn.min() > 0 and tn.max() < math.pi
@@ -246,6 +247,37 @@ def test_tabulated_endpoints_vs_oracle_kernel_logic(G, oracle, which, tab_kerr, 
         fcfg = G.render_configuration(tm.source, X_FAR, G.ThinDisc(*disc), 2000.0, image_width=W, image_height=H,
                                       alpha_lims=(-60, 60), beta_lims=(-35, 35))
         _compare_endpoints(got, Hh.render_endpoints(G, fcfg), x_rtol=1e-8, max_flips=0)
+
+
+@pytest.mark.parametrize("which", ["kerr-dark-matter", "kerr-refractive", "dilaton-axion"])
+def test_segments_and_axis_terms_in_the_kernel_logic(G, which):
+    """The device functor compiled for the host through tables with SEGMENTS (rays that cross the mass shell / the corona's edge on
+    their way to the disc) and with AXIS TERMS (an axion charge, a plane seen from near the axis) against the same metric's own
+    right-hand side through the same integrator: the table's error alone."""
+    import warnings
+
+    base = {"kerr-dark-matter": G.KerrDarkMatter(1.0, 0.6, 2.0, 8.0, 7.0), "kerr-refractive": G.KerrRefractive(1.0, 0.5, 1.1, 20.0),
+            "dilaton-axion": G.DilatonAxion(1.0, 0.18627144681883856, -0.2796909434574291, 1.0823340240923809)}[which]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tm = G.TabulatedMetric(base)
+    assert tm.grid.n_seg == {"kerr-dark-matter": 3, "kerr-refractive": 5, "dilaton-axion": 1}[which]
+    assert tm.grid.pole_factor == (2 if which == "dilaton-axion" else 1)
+    x = np.array([0.0, 864.3, math.radians(15.8 if which == "dilaton-axion" else 70.0), 0.0])
+    W, H = (40, 12) if which == "dilaton-axion" else (20, 20)
+    fov = 23.6 if which == "dilaton-axion" else 12.0
+    disc = G.ThinDisc(5.635412874390816, 66.84467146396622) if which == "dilaton-axion" else G.ThinDisc(3.0, 40.0)
+    kw = dict(image_width=W, image_height=H, alpha_lims=(-fov, fov), beta_lims=(-fov, fov))
+    if which != "dilaton-axion":
+        # A right-hand side with a kink (or a step) limits what tolerance 1e-9 resolves, whatever evaluates it: the fused form against
+        # ITSELF at 1e-11 moves these rays by 2e-7 ... 2e-5 (the table against the converged trace: 4e-6).  At 1e-11 both are converged.
+        kw.update(abstol=1e-11, reltol=1e-11)
+    # (the table starts at the outermost horizon, the fused form at the reference's inner_radius: the same chart for both)
+    chart = G.chart_for_metric(tm, 2000.0)
+    got = Hh.render_endpoints(G, G.render_configuration(tm, x, disc, 2000.0, chart=chart, **kw))
+    ref = Hh.render_endpoints(G, G.render_configuration(base, x, disc, 2000.0, chart=chart, **kw))
+    assert (ref["status"] == G.StatusCodes.IntersectedWithGeometry).sum() > 20
+    _compare_endpoints(got, ref, x_rtol=1e-6, max_flips=2, max_outliers=2, r_horizon=tm.inner_radius())
 
 
 # ---- on the device ----
@@ -447,6 +479,13 @@ def test_a_metric_the_table_cannot_represent_is_refused_loudly(G):
     with pytest.warns(UserWarning, match="not smooth"):
         tm = G.TabulatedMetric(stepped, inner_radius=kerr_in.inner_radius(), isco=kerr_in.isco(), r_max=200.0, strict=False)
     assert tm.errors[0] > 1e-6 and (tm.m_r, tm.n_theta) == (16, 64)      # one doubling showed no convergence: no further ones
+    # ... and the same function with its break NAMED is an ordinary table on the default grid: no patch straddles r = 9
+    tb = G.TabulatedMetric(stepped, inner_radius=kerr_in.inner_radius(), isco=kerr_in.isco(), r_max=200.0, breaks=[9.0])
+    assert (tb.m_r, tb.n_theta) == (8, 32) and tb.errors[0] < 2e-11 and tb.errors[1] < 1e-8 and tb.grid.n_seg == 2
+    for r in (8.9999999, 9.0000001, 3.0, 150.0):
+        g, dr, _ = tb.table_jacobian(r, 1.1)
+        ref = (kerr_in if r < 9.0 else kerr_out).metric_components(r, 1.1)
+        np.testing.assert_allclose(g, ref, rtol=1e-10)
 
 
 def test_an_inner_radius_inside_the_horizon_moves_the_table_out(G):
@@ -460,19 +499,127 @@ def test_an_inner_radius_inside_the_horizon_moves_the_table_out(G):
     assert tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
 
 
-def test_axion_charge_takes_the_raw_azimuthal_components(G):
-    """g_ϕϕ / sin²θ is not smooth on the axis of a dilaton-axion metric with β != 0 (g_ϕϕ does not vanish there): the fit with the
-    pole factor fails by orders of magnitude, the constructor keeps the raw fit of the same samples; with β = 0 nothing changes."""
+def test_axion_charge_takes_the_axis_form(G):
+    """g_ϕϕ and g_tϕ of a dilaton-axion metric with β != 0 do NOT vanish on the polar axis (W ∝ csc²θ, dilaton-axion-ad.jl:13-14):
+    divided by sin²θ they are singular, as sampled they pass through zero a few milliradians off the axis and a polynomial's absolute
+    error is no relative one there.  The constructor finds that out from the fit and stores them as K_m(r) + K_d(r) cos θ +
+    sin²θ h(r, θ) (gr_metric_grid.pole_factor = 2): the limits on the two poles as polynomials of their own, the rest smooth.
+    The table then follows the metric to 1e-11 of ITSELF next to the axis, on both poles; with β = 0 nothing changes."""
     import warnings
 
+    da = G.DilatonAxion(1.0, 0.35, 0.16, 0.33)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")          # (the inner radius moves out to the horizon: tested above)
-        tm = G.TabulatedMetric(G.DilatonAxion(1.0, 0.35, 0.16, 0.33))
+        tm = G.TabulatedMetric(da)
         t0 = G.TabulatedMetric(G.DilatonAxion(1.0, 0.5, 0.0, 1.0))
-    assert tm.grid.pole_factor == 0 and t0.grid.pole_factor == 1
+    assert tm.grid.pole_factor == 2 and t0.grid.pole_factor == 1
     assert (tm.m_r, tm.n_theta) == (8, 32) and tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8 and tm.errors[2] < 1e-8
-    g, dr, dth = tm.table_jacobian(4.0, 0.05)
-    np.testing.assert_allclose(g, tm.source.metric_components(4.0, 0.05), rtol=1e-9)
+    for r in (2.9, 4.0, 40.0, 900.0):
+        for th in (1e-4, 3e-3, 0.03, 0.05, 1.3, math.pi - 0.02, math.pi - 2e-3):
+            g, dr, dth = tm.table_jacobian(r, th)
+            ref = np.array(da.metric_components(r, th))
+            np.testing.assert_allclose(g, ref, rtol=2e-11)
+            # the derivatives of the azimuthal components against difference quotients of the metric
+            h = 1e-6
+            fd_r = (np.array(da.metric_components(r * (1 + h), th)) - np.array(da.metric_components(r * (1 - h), th))) / (2 * h * r)
+            np.testing.assert_allclose(dr[3:], fd_r[3:], rtol=3e-6, atol=1e-9)
+    # the two poles have different limits (the metric is not symmetric about the equator): K_d is not zero
+    gN, gS = tm.table_jacobian(4.0, 1e-5)[0], tm.table_jacobian(4.0, math.pi - 1e-5)[0]
+    assert abs(gN[3] - gS[3]) > 0.1 and abs(gN[4] - gS[4]) > 0.1
+    # a Jet through the table's own polynomials (the generic ISCO's route) includes the axis terms
+    np.testing.assert_allclose(tm._table_components(4.0, 0.01)[3], da.metric_components(4.0, 0.01)[3], rtol=1e-10)
+
+
+def _as_callable(m):
+    """a catalogue metric stripped to the plugin contract: metric_components and nothing else"""
+    return lambda r, th: m._components(r, np.sin(th), np.cos(th))
+
+
+def test_piecewise_metrics_pass_the_fit_once_their_breaks_are_named(G):
+    """KerrDarkMatter (kerr-dark-matter.jl:12-20: the enclosed mass is piecewise, kinks at rₛ and rₛ + Δr) and KerrRefractive
+    (kerr-refractive-ad.jl:26 + utils.jl:158-168: jumps of 6e-5 in n at corona_radius ± 1.25, an arctangent step 2.5e-4 wide at
+    corona_radius) as bare CALLABLES: refused without their break radii, ordinary tables on the default grid with them -- a segment
+    starts at every break, patches shrink geometrically towards the step from both sides."""
+    kdm = G.KerrDarkMatter(1.0, 0.6, 2.0, 8.0, 7.0)      # (a mass shell narrow enough that the fit sees the kinks)
+    with pytest.raises(ValueError, match="not smooth"):
+        G.TabulatedMetric(_as_callable(kdm), inner_radius=kdm.inner_radius(), isco=6.0)
+    tm = G.TabulatedMetric(_as_callable(kdm), inner_radius=kdm.inner_radius(), isco=6.0, breaks=[7.0, 15.0])
+    assert (tm.m_r, tm.n_theta) == (8, 32) and tm.grid.n_seg == 3 and tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
+    for r in (3.0, 6.999999, 7.000001, 11.0, 14.999999, 15.000001, 400.0):
+        g, dr, _ = tm.table_jacobian(r, 0.9)
+        np.testing.assert_allclose(g, kdm.metric_components(r, 0.9), rtol=1e-10)
+        h = 1e-7 * r
+        fd = (np.array(kdm.metric_components(r + h, 0.9)) - np.array(kdm.metric_components(r - h, 0.9))) / (2 * h)
+        np.testing.assert_allclose(dr, fd, rtol=2e-5, atol=1e-8)
+    # the catalogue type names its own breaks
+    assert G.TabulatedMetric(kdm).grid.n_seg == 3
+    kr = G.KerrRefractive(1.0, 0.5, 1.2, 20.0)
+    with pytest.raises(ValueError, match="not smooth"):
+        G.TabulatedMetric(_as_callable(kr), inner_radius=kr.inner_radius(), isco=kr.isco())
+    tr = G.TabulatedMetric(_as_callable(kr), inner_radius=kr.inner_radius(), isco=kr.isco(), breaks=kr.break_radii())
+    assert (tr.m_r, tr.n_theta) == (8, 32) and tr.grid.n_seg == 5 and tr.errors[0] < 2e-11 and tr.errors[1] < 1e-8
+    for r in (5.0, 18.7499, 18.7501, 19.9, 19.999, 19.99999, 20.0, 20.00001, 20.001, 20.4, 21.2499, 21.2501, 300.0):
+        g, dr, _ = tr.table_jacobian(r, 1.2)
+        np.testing.assert_allclose(g, kr.metric_components(r, 1.2), rtol=1e-10)
+    # across the arctangent step g_tt changes by a factor n² = 1.44 within 1e-3: the table resolves its slope
+    g1, d1, _ = tr.table_jacobian(20.0, 1.2)
+    fd = (kr.metric_components(20.0 + 1e-8, 1.2)[0] - kr.metric_components(20.0 - 1e-8, 1.2)[0]) / 2e-8
+    assert abs(d1[0] / fd - 1.0) < 1e-5 and abs(fd) > 100.0
+
+
+def test_breaks_are_validated_and_too_many_are_refused(G):
+    L = G._lib
+    lib = L.load()
+    grid = L.gr_metric_grid()
+    mk = lambda *bs: (L.gr_metric_break * len(bs))(*[L.gr_metric_break(r, s) for r, s in bs])
+    assert lib.gr_metric_grid_plan_breaks(2.0, 100.0, 1.9, 8, 32, 1, mk((1.5, 0.0)), grid) == -1          # outside (r_min, r_max)
+    assert lib.gr_metric_grid_plan_breaks(2.0, 100.0, 1.9, 8, 32, 2, mk((5.0, 0.0), (5.0, 0.0)), grid) == -1   # twice the same
+    assert lib.gr_metric_grid_plan_breaks(2.0, 100.0, 1.9, 8, 32, 1, mk((5.0, -1.0)), grid) == -1
+    assert lib.gr_metric_grid_plan_breaks(2.0, 100.0, 1.9, 8, 32, 1, None, grid) == -1
+    many = mk(*[(3.0 + k, 0.0) for k in range(L.GR_METRIC_MAX_SEG)])
+    assert lib.gr_metric_grid_plan_breaks(2.0, 100.0, 1.9, 8, 32, len(many), many, grid) == -1 and b"GR_METRIC_MAX_SEG" in lib.gr_last_error()
+    # any order; every break starts a segment anchored there, behind a core of m_r parts
+    assert lib.gr_metric_grid_plan_breaks(2.0, 100.0, 1.9, 8, 32, 2, mk((30.0, 0.0), (10.0, 0.0)), grid) == 0
+    assert grid.n_seg == 3 and [grid.seg[k].r_lo for k in range(3)] == [2.0, 10.0, 30.0]
+    assert grid.seg[1].anchor == 10.0 and grid.seg[1].core == 1 and grid.seg[0].core == 0 and grid.seg[0].anchor == 1.9
+    assert sum(grid.seg[k].n_rows for k in range(3)) == grid.n_rows and grid.n_r_nodes == grid.n_rows * grid.fit_nodes
+    rn, tn = np.empty(grid.n_r_nodes), np.empty(grid.n_theta_nodes)
+    assert lib.gr_metric_grid_nodes(grid, rn.ctypes.data, tn.ctypes.data) == 0
+    # no node of a segment lies beyond the break that ends it
+    for k in range(3):
+        sg = grid.seg[k]
+        nodes = rn[sg.first_row * grid.fit_nodes:(sg.first_row + sg.n_rows) * grid.fit_nodes]
+        assert nodes.min() >= sg.fit_lo and nodes.max() <= sg.fit_hi
+
+
+def test_negative_radii_through_a_wormhole_throat(G):
+    """A chart that continues through the throat of the Morris-Thorne wormhole (morris-thorne-ad.jl: l runs over both signs):
+    r_min < 0 and a break at 0 of the throat's size -- segments measure distances from their anchors, not radii."""
+    mt = G.MorrisThorneWormhole(1.0)
+    tm = G.TabulatedMetric(mt, r_min=-1000.0, r_max=1000.0, breaks=[(0.0, 1.0)])
+    assert tm.grid.pole_factor == 0 and tm.grid.n_seg == 3 and tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
+    for r in (-900.0, -256.5, -100.0, -3.0, -1e-3, 0.0, 1e-5, 0.3, 2.0, 77.0, 999.0):
+        g, dr, dth = tm.table_jacobian(r, 0.7)
+        np.testing.assert_allclose(g, mt.metric_components(r, 0.7), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(dr[2], 2.0 * r, rtol=1e-10, atol=1e-10)          # ∂r g_θθ = 2 l: changes sign in the throat
+
+
+def test_the_table_grows_to_cover_a_chart_and_nothing_is_extrapolated(G):
+    """polynomials do not extrapolate -- g_tt = -3e4 at ten times r_max.  `cover` refits on a range that
+    contains the chart; the radial clamps keep NaN and ±inf (a trial step that overflowed) inside the table."""
+    tm = G.TabulatedMetric(G.KerrMetric(1.0, 0.5), r_max=100.0)
+    assert tm.r_max == 100.0
+    tm.cover(tm.r_min, 100.0)
+    assert tm.r_max == 100.0                       # nothing to do
+    id0 = tm.table[8]
+    tm.cover(tm.r_min, 6000.0)
+    assert tm.r_max == 12000.0 and tm.table[8] != id0 and tm.table[13] == 12000.0      # H_BUILD_ID, H_RMAX
+    np.testing.assert_allclose(tm.table_jacobian(5000.0, 1.0)[0], tm.source.metric_components(5000.0, 1.0), rtol=1e-10)
+    with pytest.raises(ValueError, match="crosses the horizon"):
+        tm.cover(0.5 * tm.inner_radius(), 100.0)
+    for r in (float("inf"), float("-inf"), float("nan"), 1e300):
+        g, dr, dth = tm.table_jacobian(r, 1.0)
+        assert np.all(np.isfinite(g)) and np.all(np.isfinite(dr))
 
 
 @pytest.mark.gpu
