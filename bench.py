@@ -565,6 +565,11 @@ def main():
             except Exception as e:      # noqa: BLE001 -- the checker failing must not lose the measured line
                 line["cpu_baseline"] = {"value": None, "unit": "geodesics/s", "cores": 0, "kind": "port",
                                         "sample": f"oracle unavailable: {type(e).__name__}: {e}"}
+        if isinstance(line.get("configs"), dict) and "error" not in line["configs"]:
+            # the LAST key of the line, ~300 characters: the driver keeps the tail of stdout, and `configs` above is longer than that
+            # tail -- {name: [ms per launch, fraction of the vector-ALU peak]} of every BASELINE configuration
+            line["configs_brief"] = {k: [round(v["ms"], 3), None if v["roofline"].get("frac") is None else round(v["roofline"]["frac"], 4)]
+                                     for k, v in line["configs"].items()}
         print(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()

@@ -173,9 +173,9 @@ def device_tracer(m, x, max_time, chart, redshift_pf, ensemble, geometry=None, c
     # function (a caller that passes a temporary `ConstPointFunctions.redshift(...)` would otherwise leave them dangling)
     trace._keep = (keep_pf, redshift_pf, config, cfg)
     trace.endpoints = endpoints
-    # The tangent build of the kernels exists for the catalogue metrics; a tabulated one (a user-defined metric) takes the route
-    # of every tracer without `.tangent`: safeguarded Newton on ray summaries, Jacobians by central differences.
-    trace.tangent = None if getattr(m, "metric_id", None) == 11 else tangent
+    # (every metric has the tangent build of its kernels -- a tabulated one since ABI 8: the tangents ride through the table's own
+    # polynomials, as the reference's Duals ride through a user's metric_components)
+    trace.tangent = tangent
     # rays are nearly free next to a launch's latency here: the solvers may trace points they might not need
     # (BRACKET_DEPTH, GOLDEN_DEPTH); tracers without this mark (the CPU tests' oracle-driven ones) get one level at a time
     trace.speculate = True

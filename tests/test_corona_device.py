@@ -173,6 +173,25 @@ def test_corona_bins_are_the_bucket_rule_and_sum_to_the_hits(G, ens):
         again = np.zeros_like(out)
         _lib.check(L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, again.ctypes.data))
         np.testing.assert_array_equal(again, out)                     # integer accumulation: the same bits every time
+    # The rows of a trace live in a buffer of their own: OTHER work on the context between gr_corona_trace and gr_corona_bin -- an
+    # image, a ray set (both stage tables, use the stats block, the sky buffer and the result buffers) -- leaves them as they are ...
+    edges = np.ascontiguousarray(np.linspace(lim[0], lim[1], 32))
+    before = np.zeros((3, edges.size))
+    _lib.check(L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, before.ctypes.data))
+    xo = np.array([0.0, 1000.0, 1.2, 0.0])
+    G.rendergeodesics(m, xo, G.ThinDisc(m.isco(), 40.0), 2000.0, image_width=64, image_height=64, alpha_lims=(-30, 30), beta_lims=(-20, 20),
+                      pf=G.ConstPointFunctions.redshift(m, xo) @ G.ConstPointFunctions.filter_intersected(), ensemble=ens)
+    K.tracegeodesics(m, model, d, (0.0, 5000.0), n_samples=500, sampler=s, ensemble=ens, callback=G.domain_upper_hemisphere())
+    after = np.zeros_like(before)
+    _lib.check(L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, after.ctypes.data))
+    np.testing.assert_array_equal(after, before)
+    # ... and a gr_corona_trace that is refused leaves NO rows behind: the next gr_corona_bin fails instead of binning the previous trace's
+    bad_cfg = type(cfg).from_buffer_copy(cfg)
+    bad_cfg.abstol = -1.0
+    assert L.gr_corona_trace(ens.ctx.handle, C.byref(bad_cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits), C.byref(st)) != 0
+    assert L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, after.ctypes.data) != 0
+    assert "gr_corona_trace" in _lib.load().gr_last_error().decode()
+    _lib.check(L.gr_corona_trace(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits), C.byref(st)))
     # more bins than the LDS histogram holds: global atomics, the same sums
     edges = np.ascontiguousarray(np.geomspace(lim[0], lim[1], 3000))
     out = np.zeros((3, edges.size))

@@ -292,6 +292,15 @@ def _render_pair(G, ens, tm, base, size, disc, pf_of):
     return out
 
 
+def _oracle_strided(oracle, name, params, disc, size, stride, alims, blims, **pfkw):
+    """The oracle's redshift image of every `stride`-th pixel (both directions) of the size² plane: pixel k of a range of `size`
+    points is α0 + k Δ (rendering.jl:151-152), so the strided pixels are a plane of size / stride points from α0 to α0 + (size - stride) Δ."""
+    n = size // stride
+    cut = lambda lims: (lims[0], lims[0] + (size - stride) * (lims[1] - lims[0]) / (size - 1))
+    cfg = oracle.make_config(name, params, disc=disc, lambda_max=2000.0)
+    return oracle.rendergeodesics(cfg, X_FAR, cut(alims), cut(blims), n, n, pf_id=oracle.PF_REDSHIFT, filter_id=oracle.FILTER_INTERSECTED, **pfkw)
+
+
 @pytest.mark.gpu
 def test_tabulated_kerr_equals_fused_kerr_and_oracle_on_c2(G, ens, oracle, tab_kerr):
     """BASELINE config C2 (Kerr a = 0.998, 1024², ThinDisc, redshift) through the TABLE: every pixel against the fused Kerr
@@ -307,6 +316,14 @@ def test_tabulated_kerr_equals_fused_kerr_and_oracle_on_c2(G, ens, oracle, tab_k
     assert flips <= 40, flips
     assert np.quantile(rel, 0.999) < 1e-6 and np.median(rel) < 1e-8, (float(np.quantile(rel, 0.999)), float(np.median(rel)))
     assert int(np.sum(rel > 1e-6)) <= 200, int(np.sum(rel > 1e-6))
+    # ... and every 8th pixel in both directions against the oracle (the plane's pixel (i, j) is pixel (i / 8, j / 8) of a 128² plane
+    # whose limits are moved by half the difference of the pixel sizes: the same impact parameters)
+    ref = _oracle_strided(oracle, "kerr", (1.0, 0.998), (base.isco(), 50.0), 1024, 8, (-60, 60), (-35, 35), r_isco=base.isco())
+    sub = tab[::8, ::8]
+    both = ~np.isnan(sub) & ~np.isnan(ref)
+    assert both.sum() > 1000 and int(np.sum(np.isnan(sub) != np.isnan(ref))) <= 40
+    rel_o = np.abs(sub[both] / ref[both] - 1.0)
+    assert np.quantile(rel_o, 0.99) < 1e-6 and int(np.sum(rel_o > 1e-6)) <= 40, (float(np.quantile(rel_o, 0.99)), int(np.sum(rel_o > 1e-6)))
 
 
 @pytest.mark.gpu
@@ -366,11 +383,161 @@ def test_user_metric_redshift_image_vs_oracle(G, ens, oracle, tab_bump):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["kerr-dark-matter", "kerr-refractive"])
+def test_piecewise_metrics_through_the_table_equal_their_fused_kernels(G, ens, which):
+    """the two metrics of the catalogue that are piecewise in r, as CALLABLES with their break radii, through
+    the table against their own fused kernels on 1024² -- the C2 scene and the C2 bar.  A right-hand side with a kink or a step
+    bounds what a tolerance resolves whatever evaluates it (the fused kernel against itself at 1e-11 moves rays through the shell
+    by up to 2e-5 at 1e-9, tests above), so both are traced at 1e-11, where both are converged."""
+    ens.set("kernel", 2).set("precision", 64)
+    base = {"kerr-dark-matter": G.KerrDarkMatter(1.0, 0.6, 2.0, 8.0, 7.0), "kerr-refractive": G.KerrRefractive(1.0, 0.5, 1.1, 20.0)}[which]
+    # (circular orbits of this dark-matter shell have no ISCO -- dE/dr keeps its sign: the image is the affine time at the disc, which
+    # feels every part of the ray's path; the refractive metric keeps Kerr's ISCO, kerr-refractive-ad.jl:61, and the redshift)
+    isco = base.isco() if which == "kerr-refractive" else 6.0
+    tm = G.TabulatedMetric(_as_callable(base), inner_radius=base.inner_radius(), isco=isco, breaks=base.break_radii())
+    assert tm.grid.n_seg == (3 if which == "kerr-dark-matter" else 5) and (tm.m_r, tm.n_theta) == (8, 32)
+    d = G.ThinDisc(isco, 50.0)
+    out = []
+    for m in (tm, base):
+        pf = (G.ConstPointFunctions.redshift(m, X_FAR) if which == "kerr-refractive" else G.ConstPointFunctions.affine_time()) @ G.ConstPointFunctions.filter_intersected()
+        _, _, img = G.rendergeodesics(m, X_FAR, d, 2000.0, image_width=1024, image_height=1024, alpha_lims=(-60, 60), beta_lims=(-35, 35),
+                                      pf=pf, ensemble=ens, abstol=1e-11, reltol=1e-11, chart=G.chart_for_metric(tm, 12000.0))
+        out.append(img)
+    tab, fused = out
+    flips = int(np.sum(np.isnan(tab) != np.isnan(fused)))
+    both = ~np.isnan(tab) & ~np.isnan(fused)
+    assert both.sum() > 250_000
+    rel = np.abs(tab[both] / fused[both] - 1.0)
+    print(f"  {which}: flips {flips}, median {np.median(rel):.2e}, q999 {np.quantile(rel, 0.999):.2e}, max {rel.max():.2e}, > 1e-6: {int(np.sum(rel > 1e-6))}")
+    assert flips <= 60, flips
+    assert np.quantile(rel, 0.999) < 1e-6 and np.median(rel) < 1e-8, (float(np.quantile(rel, 0.999)), float(np.median(rel)))
+    assert int(np.sum(rel > 1e-6)) <= 200, int(np.sum(rel > 1e-6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(78, 16), (312, 64)])
+def test_axis_grazing_rays_of_an_axion_charged_metric(G, ens, size):
+    """The failing scene of round 5's soak (profiles/r5z_soak_tab_500_seed77.log:660, scene 405): a dilaton-axion metric with β != 0
+    seen from 16° -- four rays that graze the polar axis ended 1e-4 ... 3e-2 off in ϕ through a table that held g_ϕϕ as sampled
+    (an absolute 5e-12 next to its zero).  With the axis terms taken out (pole_factor 2) every ray meets the fused kernel's; the
+    same plane four times finer puts sixteen times as many rays next to the axis."""
+    import warnings
+
+    ens.set("kernel", 2).set("precision", 64)
+    base = G.DilatonAxion(1.0, 0.18627144681883856, -0.2796909434574291, 1.0823340240923809)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tm = G.TabulatedMetric(base)
+    assert tm.grid.pole_factor == 2 and not any("milliradians" in str(x.message) for x in w)
+    x = np.array([0.0, 864.3, math.radians(15.8), 0.0])
+    d = G.ThinDisc(5.635412874390816, 66.84467146396622)
+    kw = dict(image_width=size[0], image_height=size[1], alpha_lims=(-23.6, 23.6), beta_lims=(-23.6, 23.6), abstol=5.5e-10, reltol=5.5e-10,
+              ensemble=ens, chart=G.chart_for_metric(tm, 2 * 864.3))
+    ref = G.prerendergeodesics(base, x, d, 2 * 864.3, **kw)[2].points.ravel()
+    got = G.prerendergeodesics(tm, x, d, 2 * 864.3, **kw)[2].points.ravel()
+    # rays that pass within 5 mrad of the axis somewhere are what the scene is about: there are some
+    _compare_endpoints(got, ref, x_rtol=1e-6, max_flips=2, max_outliers=0, r_horizon=tm.inner_radius())
+
+
+@pytest.mark.gpu
+def test_tangents_through_the_table_equal_the_tangent_oracle_ray_by_ray(G, ens, oracle, tab_kerr):
+    """gr_ray_tangent of a TABULATED metric -- value + ∂/∂α + ∂/∂β ride through the table's own polynomials
+    (the reference pushes Duals through a user's metric_components, precision-solvers.jl:401-451) -- pinned per ray on the oracle's
+    dual-number trace of the Kerr metric, at the bar of the fused tangent kernel (tests/test_gpu_tangent.py), and against that
+    kernel itself."""
+    from gradus_jl_amd.transfer_functions import device_tracer
+
+    ens.set("kernel", 2).set("precision", 64)
+    a = 0.998
+    kerr = G.KerrMetric(1.0, a)
+    x = np.array([0.0, 100_000.0, math.radians(30), 0.0])
+    rng = np.random.default_rng(2026)
+    rr, th = rng.uniform(2.5, 14.0, 300), rng.uniform(0.0, 2 * math.pi, 300)
+    th[:4] = [math.pi / 2, math.pi / 2 + 1e-3, 3 * math.pi / 2, 0.0]         # through / next to the polar axis, and the α axis
+    al, be = rr * np.cos(th), rr * np.sin(th)
+    dev = {}
+    for name, m in (("table", tab_kerr), ("fused", kerr)):
+        chart = G.chart_for_metric(m, 2 * x[1], closest_approach=1.005)
+        pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens)
+        tr = device_tracer(m, x, 2 * x[1], chart, pf, ens)
+        assert tr.tangent is not None
+        dev[name] = tr.tangent(al, be)
+    cfg = oracle.make_config("kerr", (1.0, a), disc={"datum": 0.0}, lambda_max=2 * x[1], closest_approach=1.005, outer_radius=2 * x[1])
+    orc = oracle.ray_tangent(cfg, x, al, be, r_isco=kerr.isco(), max_time=2 * x[1], norm_with_tangents=True)
+
+    def rel(d_, o_, cols):
+        out = np.zeros(d_.shape[0])
+        for lo in cols:
+            scale = np.maximum(np.abs(o_[:, lo]), np.abs(o_[:, lo + 1]))
+            out = np.maximum(out, np.max(np.abs(d_[:, lo:lo + 2] - o_[:, lo:lo + 2]), axis=1) / scale)
+        return out
+
+    t = dev["table"]
+    assert np.array_equal(t[:, 7], orc[:, 7]) and np.array_equal(t[:, 7], dev["fused"][:, 7])
+    hit = t[:, 7] == 2
+    assert hit.sum() > 250
+    # Where a ray meets the disc INSIDE the ISCO, g is measured against the plunging flow: Kerr's closed form in the fused kernel and
+    # the oracle (redshift.jl:93-164), the traced and interpolated plunge for every other metric -- a tabulated one included
+    # (redshift.jl:246-276): 6e-5 apart on the two such rays here.  The radius and its derivatives do not know about the disc's flow.
+    outside = hit & (t[:, 1] > 1.02 * kerr.isco())
+    assert 0 < (hit & ~outside).sum() < 10
+    np.testing.assert_allclose(t[hit, 1], orc[hit, 1], rtol=1e-5)
+    np.testing.assert_allclose(t[outside, 0], orc[outside, 0], rtol=1e-5)
+    np.testing.assert_allclose(t[hit, 0], orc[hit, 0], rtol=1e-3)
+    e_orc = np.maximum(rel(t[outside], orc[outside], (2, 4)), 0.0)
+    e_fused = rel(t[outside], dev["fused"][outside], (2, 4))
+    e_rad = rel(t[hit], orc[hit], (4,))
+    print(f"  tangents through the table: vs the tangent oracle max {e_orc.max():.2e} median {np.median(e_orc):.2e} (∂ρ of all hits: {e_rad.max():.2e}); "
+          f"vs the fused tangent kernel max {e_fused.max():.2e}")
+    assert e_orc.max() < 1e-5 and np.median(e_orc) < 2e-6 and e_rad.max() < 1e-5
+    assert e_fused.max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_the_library_refuses_a_chart_or_an_observer_outside_the_table(G, ens):
+    """nothing used to compare the radii a trace visits with the table's range -- beyond it the polynomials
+    extrapolate to garbage (g_tt = -3e4 at ten times r_max) with rc = 0.  The C ABI now refuses; the Python host grows the table."""
+    ens.set("kernel", 2).set("precision", 64)
+    tm = G.TabulatedMetric(G.KerrMetric(1.0, 0.5), r_max=300.0)
+    x = np.array([0.0, 200.0, 1.2, 0.0])
+    cfg = G.render_configuration(tm, x, G.ThinDisc(3.0, 30.0), 500.0, image_width=8, image_height=8, alpha_lims=(-5, 5), beta_lims=(-5, 5),
+                                 chart=G.chart_for_metric(tm, 290.0), ensemble=ens)
+    c = cfg.abi_config()
+    assert tm.r_max == 300.0                                     # the chart fits: the table is used as it is
+    # at the C ABI: the same call with the chart's outer radius beyond the table, then with the observer beyond it
+    L = G._lib.load()
+    plane = cfg.abi_plane()
+    rg = G._lib.gr_range(0, 64, 64, 1)
+    pts = np.zeros(64, dtype=G._lib.POINT_DTYPE)
+
+    ok = L.gr_render_endpoints(ens.ctx.handle, C.byref(c), C.byref(plane), C.byref(rg), pts.ctypes.data, None)
+    assert ok == 0
+    c.r_outer = 400.0
+    assert L.gr_render_endpoints(ens.ctx.handle, C.byref(c), C.byref(plane), C.byref(rg), pts.ctypes.data, None) == -1
+    assert b"leaves the radial range" in L.gr_last_error()
+    c.r_outer = 290.0
+    c.r_inner = 0.9 * tm.r_min
+    assert L.gr_render_endpoints(ens.ctx.handle, C.byref(c), C.byref(plane), C.byref(rg), pts.ctypes.data, None) == -1
+    c.r_inner = float(cfg.chart.inner_radius)
+    plane.x_obs[1] = 350.0
+    assert L.gr_render_endpoints(ens.ctx.handle, C.byref(c), C.byref(plane), C.byref(rg), pts.ctypes.data, None) == -1
+    assert b"rays start at" in L.gr_last_error()
+    # the Python host: an observer at 7000 makes the table grow (it used to trace through extrapolated polynomials)
+    x2 = np.array([0.0, 7000.0, 1.2, 0.0])
+    a_, b_, img = G.rendergeodesics(tm, x2, G.ThinDisc(3.0, 30.0), 15000.0, image_width=16, image_height=16, alpha_lims=(-20, 20), beta_lims=(-20, 20),
+                                    ensemble=ens)
+    assert tm.r_max >= 14000.0
+    a_, b_, ref = G.rendergeodesics(tm.source, x2, G.ThinDisc(3.0, 30.0), 15000.0, image_width=16, image_height=16, alpha_lims=(-20, 20),
+                                    beta_lims=(-20, 20), ensemble=ens)
+    np.testing.assert_allclose(img, ref, rtol=1e-7)
+
+
+@pytest.mark.gpu
 def test_tabulated_metric_is_fp64_only(G, ens, tab_kerr):
     d = G.ThinDisc(3.0, 50.0)
     ens.set("precision", 32)
     try:
-        with pytest.raises(G._lib.GradusMI355XError, match="fp64 kernels only"):
+        with pytest.raises(G._lib.GradusMI355XError, match="no fp32 table"):
             G.rendergeodesics(tab_kerr, X_FAR, d, 2000.0, image_width=16, image_height=16, alpha_lims=(-60, 60),
                               beta_lims=(-35, 35), ensemble=ens)
     finally:
@@ -415,7 +582,7 @@ def test_transfer_functions_of_a_tabulated_metric(G, ens, tab_kerr):
     d = G.ThinDisc(0.0, float("inf"))
     radii = [4.0, 12.0, 40.0]
     a = G.cunningham_transfer_functions(kerr, x, d, radii, N=60, ensemble=ens, root_finder="polished")
-    b = G.cunningham_transfer_functions(tab_kerr, x, d, radii, N=60, ensemble=ens)
+    b = G.cunningham_transfer_functions(tab_kerr, x, d, radii, N=60, ensemble=ens, root_finder="polished")
     for ca, cb in zip(a, b):
         ok = np.isfinite(ca.f)
         assert cb.f.size == ca.f.size and ok.sum() >= ca.f.size - 2
@@ -432,8 +599,16 @@ def test_transfer_functions_of_a_tabulated_metric(G, ens, tab_kerr):
 
     chart = G.chart_for_metric(tab_kerr, 2 * x[1])
     pf = G.ConstPointFunctions.redshift(tab_kerr, x, ensemble=ens)
-    assert device_tracer(tab_kerr, x, 2 * x[1], chart, pf, ens).tangent is None
-    assert device_tracer(kerr, x, 2 * x[1], G.chart_for_metric(kerr, 2 * x[1]), G.ConstPointFunctions.redshift(kerr, x), ens).tangent is not None
+    assert device_tracer(tab_kerr, x, 2 * x[1], chart, pf, ens).tangent is not None
+    # ... and since ABI 8 the reference's own route (Duals through the tracer) is open to a tabulated metric: the same statistics
+    c = G.cunningham_transfer_functions(tab_kerr, x, d, radii, N=60, ensemble=ens, root_finder="reference")
+    a2 = G.cunningham_transfer_functions(kerr, x, d, radii, N=60, ensemble=ens, root_finder="reference")
+    for ca, cc in zip(a2, c):
+        ok = np.isfinite(ca.f) & np.isfinite(cc.f)
+        assert ok.sum() >= ca.f.size - 2
+        assert cc.gmin == pytest.approx(ca.gmin, rel=1e-7) and cc.gmax == pytest.approx(ca.gmax, rel=1e-7)
+        sa, sc = float(np.sum((ca.f * ca.g_star)[ok]) / ca.f.size), float(np.sum((cc.f * cc.g_star)[ok]) / cc.f.size)
+        assert sc == pytest.approx(sa, rel=2e-5)
 
 
 @pytest.mark.gpu
