@@ -144,6 +144,24 @@ typedef real creal;
 // one dead FMA per tangent member in every weighted sum of a step.
 typedef creal hreal;
 
+// PACKED single precision (fp32 build only).  The 157 TFLOP/s FP32 vector peak of CDNA4 is v_pk_fma_f32's: a scalar v_fma_f32
+// issues at the FP64 rate (one per 4 clocks and SIMD, profiles/r5_valu_calib.json).  The weighted sums of a Tsit5 step -- stage
+// arguments, new state, error estimate -- are axpys over the FOUR components of one ray with a common coefficient: components
+// (0, 1) and (2, 3) ride in the two halves of one packed instruction (the coefficient broadcast from one scalar register,
+// op_sel_hi), no second ray, no masks.  -DGR_PK_F32=0 builds the scalar sums (the A/B of profiles/r6_c5f32_packed_ab.log).
+#ifndef GR_PK_F32
+#ifdef GR_REAL_IS_FLOAT
+#define GR_PK_F32 1
+#else
+#define GR_PK_F32 0
+#endif
+#endif
+#if GR_PK_F32
+typedef float gr_f2 __attribute__((ext_vector_type(2)));
+#define GR_PK2(arr, i) (gr_f2{ (arr)[(i)], (arr)[(i) + 1] })
+#define GR_PKFMA(c, a, b) __builtin_elementwise_fma((gr_f2)(c), (a), (b))
+#endif
+
 // ---------------------------------------------------------------------------------------
 // scalar helpers
 // ---------------------------------------------------------------------------------------
@@ -3400,17 +3418,30 @@ struct Ray {
 #endif
         // stages 2..6: arguments need r, θ and the four velocities only (the RHS does not
         // depend on t or ϕ)
-#define GR_STAGE(S)                                                                                   \
-    {                                                                                                 \
-        GR_UNPARK((S) - 1)                                                                            \
-        real vs[4];                                                                                 \
-        const hreal ha = Ts::A[S][0] * hh;                                                          \
+#if GR_PK_F32
+#define GR_STAGE_VSUM(S)                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; i += 2)                                              \
+        {                                                                                             \
+            gr_f2 acc = GR_PK2(A[0], i);                                                              \
+            _Pragma("unroll") for (int q = 1; q < S; ++q) acc = GR_PKFMA(TsD::X.AR[S][q], GR_PK2(A[q], i), acc); \
+            const gr_f2 w = GR_PKFMA(ha, acc, GR_PK2(v, i));                                          \
+            vs[i] = w.x; vs[i + 1] = w.y;                                                             \
+        }
+#else
+#define GR_STAGE_VSUM(S)                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
         {                                                                                             \
             real acc = A[0][i];                                                                     \
             _Pragma("unroll") for (int q = 1; q < S; ++q) acc = GR_FMA(TsD::X.AR[S][q], A[q][i], acc); \
             vs[i] = GR_FMA(ha, acc, v[i]);                                                     \
-        }                                                                                             \
+        }
+#endif
+#define GR_STAGE(S)                                                                                   \
+    {                                                                                                 \
+        GR_UNPARK((S) - 1)                                                                            \
+        real vs[4];                                                                                 \
+        const hreal ha = Ts::A[S][0] * hh;                                                          \
+        GR_STAGE_VSUM(S)                                                                              \
         real rs = GR_FMA(TsD::X.C[S] * hh, v[1], x[1]);                                           \
         real ts = GR_FMA(TsD::X.C[S] * hh, v[2], x[2]);                                           \
         if (S > 1) {                                                                                  \
@@ -3440,11 +3471,29 @@ struct Ray {
         GR_STAGE(4)
         GR_STAGE(5)
 #undef GR_STAGE
+#undef GR_STAGE_VSUM
         // stage 7 argument = the new state.  Its right-hand side reads r, θ and the velocities; t and ϕ of the new state are
         // formed behind it (their old values are parked when the cold store is on)
         real xn[4], vn[4];
         GR_UNPARK(5)
         const hreal ha6 = Ts::A[6][0] * hh, hc6 = TsD::X.C[6] * hh, h2a6 = TsD::X.AX[6][0] * h2;
+#if GR_PK_F32
+        // (all four positions here, in pairs: t and ϕ of the new state then live across the last right-hand side -- two registers)
+        static_assert(Cold_::kParkA == 0 && !Cold_::kHead, "the packed sums keep the whole state in registers");
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            gr_f2 acc = GR_PK2(A[0], i), ax = GR_PK2(A[0], i);
+#pragma unroll
+            for (int q = 1; q < 6; ++q) acc = GR_PKFMA(TsD::X.AR[6][q], GR_PK2(A[q], i), acc);
+#pragma unroll
+            for (int q = 1; q < 5; ++q) ax = GR_PKFMA(TsD::X.AXR[6][q], GR_PK2(A[q], i), ax);
+            const gr_f2 wv = GR_PKFMA(ha6, acc, GR_PK2(v, i));
+            const gr_f2 wx = GR_PKFMA(h2a6, ax, GR_PKFMA(hc6, GR_PK2(v, i), GR_PK2(x, i)));
+            vn[i] = wv.x; vn[i + 1] = wv.y;
+            xn[i] = wx.x; xn[i + 1] = wx.y;
+        }
+#define GR_NEW_POSITION(i)
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             real acc = A[0][i];
@@ -3464,6 +3513,7 @@ struct Ray {
             GR_NEW_POSITION(0)
             GR_NEW_POSITION(3)
         }
+#endif
         // sin/cos at the new state by rotating the step's base as well (the RHS at the new state is stage 7 and the
         // base of the next step).  Rotation errors random-walk by ~1 ulp per step, so the base is re-synchronised
         // with a full evaluation every 64 accepted steps (and whenever the rotation falls back to it anyway).
@@ -3517,8 +3567,25 @@ struct Ray {
         double e2n = 0.0;
 #endif
         const hreal hbx = TsD::X.BTX[0] * hh;
+#if GR_PK_F32
+        real ev4[4], ex4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            gr_f2 ev2 = GR_PK2(A[0], i), ex2 = GR_PK2(A[0], i);
+#pragma unroll
+            for (int q = 1; q < 7; ++q) ev2 = GR_PKFMA(TsD::X.BTR[q], GR_PK2(A[q], i), ev2);
+#pragma unroll
+            for (int q = 1; q < 6; ++q) ex2 = GR_PKFMA(TsD::X.BTXR[q], GR_PK2(A[q], i), ex2);
+            ex2 = GR_PKFMA(hbx, ex2, (gr_f2)(TsD::X.SBT) * GR_PK2(v, i));
+            ev4[i] = ev2.x; ev4[i + 1] = ev2.y;
+            ex4[i] = ex2.x; ex4[i + 1] = ex2.y;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#if GR_PK_F32
+            const real ev = ev4[i], ex = ex4[i];
+#else
             real ev = A[0][i];               // ũ_v / (h b̃_0)
 #pragma unroll
             for (int q = 1; q < 7; ++q) ev = GR_FMA(TsD::X.BTR[q], A[q][i], ev);
@@ -3526,6 +3593,7 @@ struct Ray {
 #pragma unroll
             for (int q = 1; q < 6; ++q) ex = GR_FMA(TsD::X.BTXR[q], A[q][i], ex);
             ex = GR_FMA(hbx, ex, TsD::X.SBT * v[i]);
+#endif
 #ifdef GR_REAL_IS_TAN2
             if (p.tangent_norm) {
                 // The reference integrates Dual state through OrdinaryDiffEq (precision-solvers.jl:73-131,401-451) and

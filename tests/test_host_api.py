@@ -20,14 +20,15 @@ def test_library_exports_every_declared_symbol(G):
     for name in declared:
         assert hasattr(lib, name), name
     lib.gr_abi_version.restype = C.c_int32
-    assert lib.gr_abi_version() == G._lib.ABI_VERSION == 7
+    assert lib.gr_abi_version() == G._lib.ABI_VERSION == 8
 
 
 def test_struct_layouts(G):
     L = G._lib
     assert L.POINT_DTYPE.itemsize == 152            # GeodesicPoint{Float64,Nothing}
     assert C.sizeof(L.gr_config) == 8 + 64 + 8 * 10 + 8 + 8 + 8 + 32 + 16 + 32 + 8 + 16 + 8 + 4 * 56 + 16      # + comp_n, comp[4]; + metric_table, metric_table_n (ABI 7)
-    assert C.sizeof(L.gr_metric_grid) == 24 + 8 * 4 + 24
+    assert C.sizeof(L.gr_metric_segment) == 72 and C.sizeof(L.gr_metric_break) == 16          # ABI 8
+    assert C.sizeof(L.gr_metric_grid) == 24 + 8 * 4 + 24 + 8 + L.GR_METRIC_MAX_SEG * 72          # ABI 8: + n_seg, n_rows, seg[]
     assert C.sizeof(L.gr_plane) == 8 * (4 + 16 + 4) + 16 + 8
     assert C.sizeof(L.gr_range) == 32
     assert C.sizeof(L.gr_stats) == 96            # ABI 6: + enqueue_ms
