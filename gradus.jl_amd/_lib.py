@@ -211,6 +211,8 @@ class gr_rayset(C.Structure):
         ("sky_reserved", C.c_int32),
         ("sky_resolution", C.c_double),
         ("sky_i", C.c_void_p),
+        ("sky_first", C.c_int64),          # ABI 8: a share of a source's samples (the *_multi entry points set them per context)
+        ("sky_total", C.c_int64),
     ]
 
 
@@ -302,6 +304,8 @@ EXPORTS = [
     "gr_apply_pointfunction",
     "gr_corona_trace",
     "gr_corona_bin",
+    "gr_corona_trace_multi",
+    "gr_corona_bin_multi",
     "gr_render_endpoints_multi",
     "gr_trace_endpoints_multi",
     "gr_rayset_endpoints_multi",
@@ -366,6 +370,8 @@ def load():
     L.gr_apply_pointfunction.argtypes = [vp, cfgp, pfp, vp, i64, C.c_double, vp]
     L.gr_corona_trace.argtypes = [vp, cfgp, rsp, pfp, vp, C.POINTER(C.c_int64), stp]
     L.gr_corona_bin.argtypes = [vp, vp, i64, vp]
+    L.gr_corona_trace_multi.argtypes = [vp, i32, cfgp, rsp, pfp, vp, C.POINTER(C.c_int64), stp]
+    L.gr_corona_bin_multi.argtypes = [vp, i32, vp, i64, vp]
     ctxa = C.POINTER(vp)
     L.gr_render_endpoints_multi.argtypes = [ctxa, i32, cfgp, plp, i64, vp, vp]
     L.gr_trace_endpoints_multi.argtypes = [ctxa, i32, cfgp, vp, i64, vp, i64, vp, vp]

@@ -618,13 +618,26 @@ def device_radial_profile(m, d, model, spectrum=None, *, λmax=10_000.0, sampler
     lim = np.zeros(2)
     hits = C.c_int64(0)
     st = _lib.gr_stats() if stats else None
-    _lib.check(L.gr_corona_trace(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits),
-                                 C.byref(st) if stats else None))
+    many = ens.multi
+    if many:
+        # several devices: the samples shard like any ray set (gr_rayset.sky_first / sky_total, ABI 8); every context keeps and bins
+        # its own rows, the integer accumulators add up to the bits one context would give
+        ctx_arr, ctx_stats = _lib.ctx_array(ens.contexts)
+        _lib.check(L.gr_corona_trace_multi(ctx_arr, len(ens.contexts), C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits),
+                                           ctx_stats))
+        if stats:
+            st = _lib.merge_stats(ctx_stats)
+    else:
+        _lib.check(L.gr_corona_trace(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits),
+                                     C.byref(st) if stats else None))
     if hits.value == 0:
         raise ValueError("no ray of the corona reached the disc")
     bins = np.ascontiguousarray(grid(lim[0], lim[1], N), dtype=np.float64)
     out = np.zeros((3, bins.size))
-    _lib.check(L.gr_corona_bin(ens.ctx.handle, bins.ctypes.data, bins.size, out.ctypes.data))
+    if many:
+        _lib.check(L.gr_corona_bin_multi(ctx_arr, len(ens.contexts), bins.ctypes.data, bins.size, out.ctypes.data))
+    else:
+        _lib.check(L.gr_corona_bin(ens.ctx.handle, bins.ctypes.data, bins.size, out.ctypes.data))
     prof = _profile_from_bins(m, spectrum, bins, out[0], out[1], out[2], out[0], disc_velocity)
     return (prof, st) if stats else prof
 

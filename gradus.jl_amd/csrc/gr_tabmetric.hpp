@@ -47,8 +47,13 @@
 
 namespace gr_tab {
 
+// Degree 5 against degree 7, the round-5 choice, at EQUAL fit error (profiles/r6_tab_degree_ab.log; C2, 1024² rays): degree 5 on a
+// (24, 96) grid 17.8 ms, degree 6 on (12, 48) 18.9, degree 7 on (8, 32) 21.5 -- 210 operations per evaluation instead of 385, and
+// the finer grid's extra patch misses cost less than the higher degree's arithmetic.  (Degree 5 on (16, 64): 16.9 ms with the
+// image 1e-10 from the fused kernel's instead of 1e-11 -- but jumps of 1e-7 in the derivatives at patch edges, which a tolerance of
+// 1e-11 or a difference quotient of traces resolves: not the default.)
 #ifndef GR_TAB_DEGREE
-#define GR_TAB_DEGREE 7
+#define GR_TAB_DEGREE 5
 #endif
 constexpr int kDegree = GR_TAB_DEGREE;                          // total degree of a patch polynomial (a build-time choice: 5, 6 or 7)
 constexpr int kCoefs = (kDegree + 1) * (kDegree + 2) / 2;      // 36 per component at degree 7, 28 at 6, 21 at 5

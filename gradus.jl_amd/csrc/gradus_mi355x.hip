@@ -116,6 +116,7 @@ struct gr_ctx {
     std::vector<double> mesh_host;
     double* d_sky = nullptr;               // a sky source's (x, v) arrays, written by k_sky_velocities for the trace kernels
     size_t sky_bytes = 0;
+    int64_t sky_first = 0, sky_total = 0;  // the share of a sky source the launch being prepared traces (rays_params -> sky_prepare)
     double* d_corona = nullptr;            // gr_corona_trace: (g, ρ, t, status) per ray, kept for gr_corona_bin
     size_t corona_bytes = 0;
     int64_t corona_n = -1, corona_hits = 0;
@@ -471,6 +472,7 @@ namespace {
 struct SkyParams {
     double x_obs[4], Mx[16];
     int64_t n;
+    int64_t first, total;      // this launch's rays are samples first + 1 .. first + n of `total` (gr_rayset.sky_first / sky_total)
     int32_t sampler, both, generator, reserved;
     double resolution;
     const double* sky_i;
@@ -481,8 +483,8 @@ __global__ void __launch_bounds__(256) k_sky_velocities(const SkyParams p, doubl
     if (jl == 0)
         for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
     if (jl >= p.n) return;
-    const double n = (double)p.n;
-    const double idx = (double)(jl + 1);
+    const double n = (double)p.total;
+    const double idx = (double)(p.first + jl + 1);
     const double i = p.generator == 0 ? idx : p.generator == 1 ? idx / n : p.sky_i[jl];
     double el;
     if (p.sampler == 2) {
@@ -515,6 +517,8 @@ static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t strea
     std::memcpy(sp.x_obs, cold.plane.x_obs, sizeof sp.x_obs);
     std::memcpy(sp.Mx, cold.plane.Mx, sizeof sp.Mx);
     sp.n = p.n;
+    sp.first = ctx->sky_first;
+    sp.total = ctx->sky_total > 0 ? ctx->sky_total : p.n;
     sp.sampler = cold.sky_sampler; sp.both = cold.sky_both; sp.generator = cold.sky_generator; sp.reserved = 0;
     sp.resolution = cold.sky_resolution;
     sp.sky_i = cold.sky_i;
@@ -1213,6 +1217,10 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
         if (rays->sky_generator == 2 && rays->n > 0 && !rays->sky_i) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: generator 2 needs sky_i");
         if (rays->sky_sampler == 2 && !(rays->sky_resolution > 0.0)) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: WeierstrassSampler needs a resolution > 0");
         if (rays->sep_r || rays->height) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: separable tables / per-ray heights do not apply");
+        if (rays->sky_first < 0 || rays->sky_total < 0 || (rays->sky_total > 0 && rays->sky_first + rays->n > rays->sky_total))
+            return fail(GR_ERR_INVALID_ARGUMENT, "sky source: the share sky_first .. sky_first + n runs past sky_total");
+        ctx->sky_first = rays->sky_total > 0 ? rays->sky_first : 0;
+        ctx->sky_total = rays->sky_total > 0 ? rays->sky_total : rays->n;
         std::memset(&p, 0, sizeof p);
         std::memset(&cd, 0, sizeof cd);
         p.cfg = *cfg;
@@ -2143,16 +2151,16 @@ CoronaGrid corona_grid(double vmax, int64_t n)
     g.lo_unit = std::ldexp(1.0, -k);
     return g;
 }
+int32_t rayset_share(const gr_rayset* rays, int32_t n, int k, gr_rayset& out, int64_t* off_out);      // (below, with the other *_multi helpers)
 }  // namespace
 }  // extern "C++"
 
-int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
-                        double* rho_min_max, int64_t* n_hits, gr_stats* stats)
+// gr_corona_trace in two halves, so that gr_corona_trace_multi can queue every context's share before it waits for any:
+// corona_enqueue stages the rays, traces, reduces (min ρ, max ρ, hits, max |g|, max |t|) and queues the 40-byte copy into `h`;
+// corona_collect waits for the context and reads them.
+static int32_t corona_enqueue(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf, gr_stats* stats,
+                              unsigned long long* h /* 5, pinned or pageable host memory that outlives the wait */)
 {
-    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (!rays || !rays->sky_sampler) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_trace traces a sky source (gr_rayset.sky_sampler != 0)");
-    if (!rho_min_max || !n_hits) return fail(GR_ERR_INVALID_ARGUMENT, "rho_min_max / n_hits is null");
-    if (cfg && cfg->disc_id == GR_DISC_NONE) return fail(GR_ERR_INVALID_ARGUMENT, "a corona illuminates accretion geometry: none given");
     int32_t rc;
     GR_HIP(hipSetDevice(ctx->device));
     ctx->corona_n = -1;
@@ -2162,7 +2170,7 @@ int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays
     const size_t bytes = sizeof(double) * 4 * (size_t)rays->n + 64;
     if ((rc = ensure((void**)&ctx->d_corona, &ctx->corona_bytes, bytes)) != GR_OK) return rc;
     unsigned long long* red = (unsigned long long*)(ctx->d_corona + 4 * (size_t)rays->n);
-    const unsigned long long init[5] = { ~0ull, 0ull, 0ull, 0ull, 0ull };
+    static const unsigned long long init[5] = { ~0ull, 0ull, 0ull, 0ull, 0ull };
     GR_HIP(hipMemcpyAsync(red, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = gr_ray_summary_device(ctx, cfg, &dev, pf, ctx->d_corona, stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
     if (rays->n > 0) {
@@ -2171,31 +2179,92 @@ int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays
         hipLaunchKernelGGL(k_corona_minmax, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_corona, rays->n, red);
         GR_HIP(hipGetLastError());
     }
-    unsigned long long h[5];
-    GR_HIP(hipMemcpyAsync(h, red, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    GR_HIP(hipMemcpyAsync(h, red, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost, ctx->stream));
+    return GR_OK;
+}
+static int32_t corona_collect(gr_ctx* ctx, gr_stats* stats, const unsigned long long* h, int64_t n_rays, double v[5], int64_t* hits)
+{
+    int32_t rc;
+    GR_HIP(hipSetDevice(ctx->device));
     if ((rc = end_host_call(ctx, stats)) != GR_OK) return rc;      // (synchronises the stream)
-    *n_hits = (int64_t)h[2];
-    double v[5];
-    std::memcpy(v, h, sizeof v);
-    rho_min_max[0] = h[2] ? v[0] : NAN;
-    rho_min_max[1] = h[2] ? v[1] : NAN;
+    std::memcpy(v, h, sizeof(double) * 5);
+    *hits = (int64_t)h[2];
     ctx->corona_gmax = v[3];
     ctx->corona_tmax = v[4];
-    ctx->corona_hits = (int64_t)h[2];
-    ctx->corona_n = rays->n;
+    ctx->corona_hits = *hits;
+    ctx->corona_n = n_rays;
     return GR_OK;
 }
 
-int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double* out)
+int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                        double* rho_min_max, int64_t* n_hits, gr_stats* stats)
 {
     if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (ctx->corona_n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_bin bins the rays of the context's last gr_corona_trace: there is none");
-    if (!edges || !out || n_edges < 1 || n_edges > 65536) return fail(GR_ERR_INVALID_ARGUMENT, "edges / out is null or n_edges not in 1..65536");
-    for (int64_t i = 1; i < n_edges; ++i)
-        if (!(edges[i] >= edges[i - 1])) return fail(GR_ERR_INVALID_ARGUMENT, "bin edges must ascend");
+    if (!rays || !rays->sky_sampler) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_trace traces a sky source (gr_rayset.sky_sampler != 0)");
+    if (!rho_min_max || !n_hits) return fail(GR_ERR_INVALID_ARGUMENT, "rho_min_max / n_hits is null");
+    if (cfg && cfg->disc_id == GR_DISC_NONE) return fail(GR_ERR_INVALID_ARGUMENT, "a corona illuminates accretion geometry: none given");
+    int32_t rc;
+    ctx->corona_n = -1;
+    unsigned long long h[5];
+    double v[5];
+    if ((rc = corona_enqueue(ctx, cfg, rays, pf, stats, h)) != GR_OK) return rc;
+    if ((rc = corona_collect(ctx, stats, h, rays->n, v, n_hits)) != GR_OK) return rc;
+    rho_min_max[0] = *n_hits ? v[0] : NAN;
+    rho_min_max[1] = *n_hits ? v[1] : NAN;
+    return GR_OK;
+}
+
+int32_t gr_corona_trace_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                              double* rho_min_max, int64_t* n_hits, gr_stats* stats)
+{
+    int32_t rc;
+    if ((rc = validate_ctxs(ctxs, n)) != GR_OK) return rc;
+    if (n > 64) return fail(GR_ERR_INVALID_ARGUMENT, "at most 64 contexts");
+    if (!rays || !rays->sky_sampler) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_trace_multi traces a sky source (gr_rayset.sky_sampler != 0)");
+    if (!rho_min_max || !n_hits) return fail(GR_ERR_INVALID_ARGUMENT, "rho_min_max / n_hits is null");
+    if (cfg && cfg->disc_id == GR_DISC_NONE) return fail(GR_ERR_INVALID_ARGUMENT, "a corona illuminates accretion geometry: none given");
+    for (int k = 0; k < n; ++k) ctxs[k]->corona_n = -1;
+    std::vector<unsigned long long> h(5 * (size_t)n);
+    std::vector<gr_rayset> share((size_t)n);
+    // every context's share is queued before any is waited for
+    for (int k = 0; k < n; ++k) {
+        int64_t off;
+        if ((rc = rayset_share(rays, n, k, share[(size_t)k], &off)) != GR_OK) return rc;
+        const auto t0 = std::chrono::steady_clock::now();
+        if ((rc = corona_enqueue(ctxs[k], cfg, &share[(size_t)k], pf, stats ? stats + k : nullptr, h.data() + 5 * (size_t)k)) != GR_OK) return rc;
+        if (stats) stats[k].enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    double lo = INFINITY, hi = -INFINITY, gmax = 0.0, tmax = 0.0;
+    int64_t hits = 0;
+    for (int k = 0; k < n; ++k) {
+        double v[5];
+        int64_t hk;
+        const double enq = stats ? stats[k].enqueue_ms : 0.0;
+        if ((rc = corona_collect(ctxs[k], stats ? stats + k : nullptr, h.data() + 5 * (size_t)k, share[(size_t)k].n, v, &hk)) != GR_OK) return rc;
+        if (stats) stats[k].enqueue_ms = enq;
+        if (hk) { lo = std::fmin(lo, v[0]); hi = std::fmax(hi, v[1]); }
+        gmax = std::fmax(gmax, v[3]);
+        tmax = std::fmax(tmax, v[4]);
+        hits += hk;
+    }
+    // the fixed-point grid of the bins is formed from these: every context gets the values of ALL shares
+    for (int k = 0; k < n; ++k) {
+        ctxs[k]->corona_gmax = gmax;
+        ctxs[k]->corona_tmax = tmax;
+        ctxs[k]->corona_hits = hits;
+    }
+    *n_hits = hits;
+    rho_min_max[0] = hits ? lo : NAN;
+    rho_min_max[1] = hits ? hi : NAN;
+    return GR_OK;
+}
+
+// gr_corona_bin's device half: the context's rows into integer accumulators (count, Σg hi / lo, Σt hi / lo) on the grid of its
+// corona_gmax / corona_tmax / corona_hits; `acc` (5 nb, host) is filled when the stream has drained
+static int32_t corona_bin_enqueue(gr_ctx* ctx, const double* edges, size_t nb, long long* acc)
+{
     int32_t rc;
     GR_HIP(hipSetDevice(ctx->device));
-    const size_t nb = (size_t)n_edges;
     if ((rc = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * 6 * nb + 64)) != GR_OK) return rc;
     double* d_edges = (double*)ctx->d_in;
     unsigned long long* d_acc = (unsigned long long*)(d_edges + nb);
@@ -2214,14 +2283,63 @@ int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double*
         }
         GR_HIP(hipGetLastError());
     }
-    std::vector<long long> acc(5 * nb);
-    GR_HIP(hipMemcpyAsync(acc.data(), d_acc, sizeof(long long) * 5 * nb, hipMemcpyDeviceToHost, ctx->stream));
-    GR_HIP(hipStreamSynchronize(ctx->stream));
+    GR_HIP(hipMemcpyAsync(acc, d_acc, sizeof(long long) * 5 * nb, hipMemcpyDeviceToHost, ctx->stream));
+    return GR_OK;
+}
+static void corona_bins_out(const long long* acc, size_t nb, double gmax, double tmax, int64_t hits, double* out)
+{
+    const CoronaGrid gg = corona_grid(gmax, hits), gt = corona_grid(tmax, hits);
     for (size_t i = 0; i < nb; ++i) {
         out[i] = (double)acc[i];
         out[nb + i] = (double)(((long double)acc[nb + i] + (long double)acc[2 * nb + i] * (long double)gg.lo_unit) * (long double)gg.step);
         out[2 * nb + i] = (double)(((long double)acc[3 * nb + i] + (long double)acc[4 * nb + i] * (long double)gt.lo_unit) * (long double)gt.step);
     }
+}
+static int32_t corona_bin_args(const double* edges, int64_t n_edges, const double* out)
+{
+    if (!edges || !out || n_edges < 1 || n_edges > 65536) return fail(GR_ERR_INVALID_ARGUMENT, "edges / out is null or n_edges not in 1..65536");
+    for (int64_t i = 1; i < n_edges; ++i)
+        if (!(edges[i] >= edges[i - 1])) return fail(GR_ERR_INVALID_ARGUMENT, "bin edges must ascend");
+    return GR_OK;
+}
+
+int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double* out)
+{
+    if (!ctx) return fail(GR_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (ctx->corona_n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_bin bins the rays of the context's last gr_corona_trace: there is none");
+    int32_t rc;
+    if ((rc = corona_bin_args(edges, n_edges, out)) != GR_OK) return rc;
+    const size_t nb = (size_t)n_edges;
+    std::vector<long long> acc(5 * nb);
+    if ((rc = corona_bin_enqueue(ctx, edges, nb, acc.data())) != GR_OK) return rc;
+    GR_HIP(hipStreamSynchronize(ctx->stream));
+    corona_bins_out(acc.data(), nb, ctx->corona_gmax, ctx->corona_tmax, ctx->corona_hits, out);
+    return GR_OK;
+}
+
+int32_t gr_corona_bin_multi(gr_ctx* const* ctxs, int32_t n, const double* edges, int64_t n_edges, double* out)
+{
+    int32_t rc;
+    if ((rc = validate_ctxs(ctxs, n)) != GR_OK) return rc;
+    if (n > 64) return fail(GR_ERR_INVALID_ARGUMENT, "at most 64 contexts");
+    for (int k = 0; k < n; ++k) {
+        if (ctxs[k]->corona_n < 0) return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_bin_multi bins the rays of the contexts' last gr_corona_trace_multi: there is none");
+        if (ctxs[k]->corona_gmax != ctxs[0]->corona_gmax || ctxs[k]->corona_tmax != ctxs[0]->corona_tmax || ctxs[k]->corona_hits != ctxs[0]->corona_hits)
+            return fail(GR_ERR_INVALID_ARGUMENT, "gr_corona_bin_multi: the contexts do not hold the shares of ONE gr_corona_trace_multi");
+    }
+    if ((rc = corona_bin_args(edges, n_edges, out)) != GR_OK) return rc;
+    const size_t nb = (size_t)n_edges;
+    std::vector<long long> acc(5 * nb * (size_t)n);
+    for (int k = 0; k < n; ++k)
+        if ((rc = corona_bin_enqueue(ctxs[k], edges, nb, acc.data() + 5 * nb * (size_t)k)) != GR_OK) return rc;
+    for (int k = 0; k < n; ++k) {
+        GR_HIP(hipSetDevice(ctxs[k]->device));
+        GR_HIP(hipStreamSynchronize(ctxs[k]->stream));
+    }
+    // integer addition is associative: the sums of the shares are the sums one context would have formed of all rays
+    for (int k = 1; k < n; ++k)
+        for (size_t i = 0; i < 5 * nb; ++i) acc[i] += acc[5 * nb * (size_t)k + i];
+    corona_bins_out(acc.data(), nb, ctxs[0]->corona_gmax, ctxs[0]->corona_tmax, ctxs[0]->corona_hits, out);
     return GR_OK;
 }
 
@@ -2318,13 +2436,19 @@ int32_t rayset_share(const gr_rayset* rays, int32_t n, int k, gr_rayset& out, in
     if (rays->sep_r && (rays->sep_block != 0 || rays->sep_tiled))
         return fail(GR_ERR_INVALID_ARGUMENT, "*_multi: a separable ray set with one output row per ray must come whole and in ray order "
                                              "(sep_block = 0, sep_tiled = 0)");
-    if (rays->sky_sampler)
-        return fail(GR_ERR_INVALID_ARGUMENT, "*_multi: a sky source is traced by one context (its sample numbers count from ray 0)");
     int64_t off, cnt;
     contiguous_share(rays->n, n, k, &off, &cnt);
     out = *rays;
     out.n = cnt;
-    if (rays->sep_r) {
+    if (rays->sky_sampler) {
+        // a share of a source's samples: the sample numbers go on counting where the previous share stopped
+        out.sky_total = rays->sky_total > 0 ? rays->sky_total : rays->n;
+        out.sky_first = (rays->sky_total > 0 ? rays->sky_first : 0) + off;
+        if (rays->sky_generator == 2) {
+            if (rays->n > 0 && !rays->sky_i) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: generator 2 needs sky_i");
+            out.sky_i = rays->sky_i ? rays->sky_i + off : nullptr;
+        }
+    } else if (rays->sep_r) {
         out.sep_first = rays->sep_first + off;
     } else if (rays->n > 0) {
         if (!rays->alpha || !rays->beta) return fail(GR_ERR_INVALID_ARGUMENT, "alpha/beta is null");

@@ -72,9 +72,9 @@ enum {
      * metric_components(m, (r, θ)) -> (g_tt, g_rr, g_θθ, g_ϕϕ, g_tϕ) (src/Gradus.jl:78-86, src/metrics/kerr-metric.jl:62-70);
      * ForwardDiff supplies the Jacobian (src/tracing/method-implementations/auto-diff.jl:206-211).  A closure cannot cross this
      * ABI, so the caller samples its metric_components on the nodes gr_metric_grid_nodes() names, gr_metric_table_fit() turns
-     * the samples into piecewise polynomials (total degree 7 on patches geometric in r - r0 and uniform in θ), and the kernels
+     * the samples into piecewise polynomials (total degree 5 on patches geometric in r - r0 and uniform in θ), and the kernels
      * evaluate the five components and their (∂r, ∂θ) derivatives from that table (gr_config.metric_table; params unused).
-     * See "tabulated metrics" below.  fp64 kernels only ("precision" 32 and the tangent entry points: GR_ERR_UNSUPPORTED). */
+     * See "tabulated metrics" below.  fp64 kernels and the tangent entry points ("precision" 32: GR_ERR_UNSUPPORTED, there is no fp32 table). */
     GR_METRIC_TABULATED = 11
 };
 
@@ -458,6 +458,11 @@ typedef struct gr_rayset {
     int32_t sky_reserved;
     double sky_resolution;
     const double* sky_i;      /* n values for sky_generator 2 (host / device pointer like alpha), else NULL */
+    /* ABI 8 -- a SHARE of a source's samples (what the *_multi entry points hand each context; a caller that shards by hand --
+     * one process per GPU -- sets them itself): the n rays of this set are samples sky_first + 1 .. sky_first + n of sky_total in
+     * all, i.e. the `n` of the formulas above is sky_total and ray j has sample number sky_first + j + 1 (sky_i still has one
+     * entry per ray of THIS set).  sky_total = 0: the whole source (first 0, total n). */
+    int64_t sky_first, sky_total;
 } gr_rayset;
 
 typedef struct gr_binning {
@@ -545,6 +550,14 @@ int32_t gr_apply_pointfunction(gr_ctx* ctx, const gr_config* cfg, const gr_point
 int32_t gr_corona_trace(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
                         double* rho_min_max /* 2 */, int64_t* n_hits, gr_stats* stats);
 int32_t gr_corona_bin(gr_ctx* ctx, const double* edges, int64_t n_edges, double* out /* 3 x n_edges */);
+/* ABI 8 -- the same two calls over SEVERAL contexts from one host thread (see gr_render_multi for the shape every *_multi call
+ * has): context k traces a contiguous share of the source's samples (gr_rayset.sky_first / sky_total) and keeps its rows; min / max ρ
+ * and the hit count are those of all shares.  gr_corona_bin_multi bins every context's rows into the caller's edges on ONE common
+ * fixed-point grid (from the largest |g|, |t| and the hit count of all shares) and adds the integer accumulators: the result is
+ * bit for bit what one context gives for the whole source.  stats: n entries or NULL. */
+int32_t gr_corona_trace_multi(gr_ctx* const* ctxs, int32_t n, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
+                              double* rho_min_max /* 2 */, int64_t* n_hits, gr_stats* stats);
+int32_t gr_corona_bin_multi(gr_ctx* const* ctxs, int32_t n, const double* edges, int64_t n_edges, double* out /* 3 x n_edges */);
 
 /* ---- tabulated metrics (ABI 7; segments, axis terms: ABI 8; GR_METRIC_TABULATED): the AbstractMetric plugin interface on the device ----
  * Host-only functions (no context, no device): plan a grid, learn its nodes, fit, check.
@@ -591,7 +604,7 @@ typedef struct gr_metric_grid {
     double r_min, r_max;      /* radii the table covers (patch edges are rounded outwards)                   */
     int32_t e_min, n_oct;     /* segment 0: octaves 2^e_min .. 2^(e_min + n_oct) of r - r0                   */
     int32_t m_r, n_theta;     /* patches per octave, patches over [0, π]                                     */
-    int32_t degree, fit_nodes; /* total degree of a patch polynomial (7), Chebyshev nodes per patch and direction (12) */
+    int32_t degree, fit_nodes; /* total degree of a patch polynomial (5), Chebyshev nodes per patch and direction (12) */
     int32_t pole_factor;      /* the form g_ϕϕ and g_tϕ are stored in (the caller may change it between plan and fit):
                                  1 [set by gr_metric_grid_plan]: divided by sin²θ -- both vanish like sin²θ on the axis of a regular
                                  axis-symmetric metric, and a polynomial with an ABSOLUTE error would leave g^ϕϕ with an unbounded

@@ -201,6 +201,8 @@ struct GrRayset                      # == gr_rayset
     sky_reserved::Int32
     sky_resolution::Float64
     sky_i::Ptr{Float64}
+    sky_first::Int64                 # ABI 8: a share of a source's samples (0, 0 = the whole source)
+    sky_total::Int64
 end
 
 struct GrBinning                     # == gr_binning
@@ -314,7 +316,7 @@ _metric(m) = throw(UnsupportedOnDevice("metric $(typeof(m)) is not static and ax
 _is_tabulated(m) = _metric(m)[1] == Int32(11)
 
 const _METRIC_TABLES = Dict{Any,Vector{Float64}}()      # (metric, r_min, r_max) -> fitted table; metrics are immutable structs
-const METRIC_TABLE_TOL = (2e-11, 1e-8, 1e-8)             # the fit's own estimates a table must meet: value, ∂/∂ln(r - r0), ∂/∂θ
+const METRIC_TABLE_TOL = (1e-10, 1e-7, 1e-7)             # the fit's own estimates a table must meet: value, ∂/∂ln(r - r0), ∂/∂θ
 
 """
     metric_breaks(m) -> Vector{Tuple{Float64,Float64}}
@@ -335,7 +337,7 @@ metric_breaks(m::KerrRefractive) = [(Float64(m.corona_radius) - 1.25, 0.0), (Flo
 _with_form(g::GrMetricGrid, form) = GrMetricGrid(ntuple(i -> fieldname(GrMetricGrid, i) === :pole_factor ? Int32(form) : getfield(g, i), fieldcount(GrMetricGrid))...)
 
 """
-    metric_table(m, r_inner, r_outer; m_r = 8, n_theta = 32, refinements = 3, breaks = metric_breaks(m)) -> Vector{Float64}
+    metric_table(m, r_inner, r_outer; m_r = 24, n_theta = 96, refinements = 3, breaks = metric_breaks(m)) -> Vector{Float64}
 
 The piecewise-polynomial table of `metric_components(m, (r, θ))` between the chart's radii that the kernels trace a
 user-defined metric through.  The library names the sample nodes (`gr_metric_grid_plan[_breaks]`, `gr_metric_grid_nodes`), this
@@ -347,7 +349,7 @@ on the axis (DilatonAxion with β != 0) their limits on the two poles are taken 
 (MorrisThorneWormhole: g_ϕϕ ∝ sin θ) they are stored as sampled (form 0).
 Tables are cached per (metric, radii).  `gr_metric_table_eval` checks one against `Gradus.metric_jacobian` (see `selftest`).
 """
-function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 32, refinements = 3, breaks = metric_breaks(m))
+function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 24, n_theta = 96, refinements = 3, breaks = metric_breaks(m))
     get!(_METRIC_TABLES, (m, r_inner, r_outer)) do
         rh = Float64(Gradus.inner_radius(m))
         # the table starts a hair inside the chart; its octaves count from a tenth of that distance behind the horizon
@@ -396,15 +398,15 @@ function metric_table(m, r_inner::Float64, r_outer::Float64; m_r = 8, n_theta = 
                 end
             end
             all(err .<= METRIC_TABLE_TOL) && return table
-            # a degree-7 fit gains 2^8 per halving of a smooth function's patches: one that gains less than 16 is looking at a kink
-            # or a pole (a horizon inside [r_inner, r_outer], a piecewise-defined function), and more samples will not change that
+            # a degree-5 fit gains 1.5^6 = 11 when a smooth function's patches shrink by a third: one that gains less than 3 is looking at
+            # a kink or a pole (a horizon inside [r_inner, r_outer], a piecewise-defined function), and more samples will not change that
             miss = maximum(err ./ METRIC_TABLE_TOL)
-            stalled = miss > previous / 16 && miss > 1e3
+            stalled = miss > previous / 3 && miss > 1e3
             previous = miss
             last_err = err
             stalled && break
-            (err[1] > METRIC_TABLE_TOL[1] || err[2] > METRIC_TABLE_TOL[2]) && (m_r *= 2)
-            (err[1] > METRIC_TABLE_TOL[1] || err[3] > METRIC_TABLE_TOL[3]) && (n_theta *= 2)
+            (err[1] > METRIC_TABLE_TOL[1] || err[2] > METRIC_TABLE_TOL[2]) && (m_r = (3 * m_r + 1) ÷ 2)
+            (err[1] > METRIC_TABLE_TOL[1] || err[3] > METRIC_TABLE_TOL[3]) && (n_theta = (3 * n_theta + 1) ÷ 2)
         end
         # Good enough to trace with (value 1e-7, derivatives 1e-4)?  Then warn.  Otherwise a sample was not finite or the metric has a
         # break nobody named: UnsupportedOnDevice sends the problem to the reference's own CPU ensemble, as for any configuration the
@@ -841,7 +843,7 @@ function Gradus.ensemble_solve_tracing_problem(
         Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
         rays = Ref(GrRayset(Tuple(SVector{4,Float64}(config.position)), Tuple(permutedims(Mx)), pointer(αv), pointer(βv),
             Ptr{Float64}(C_NULL), N, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0,
-            Int32(0), Int32(0), 0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL)))
+            Int32(0), Int32(0), 0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL), 0, 0))
         if nctx > 1
             _check(GC.@preserve keep αv βv out ccall((:gr_rayset_endpoints_multi, LIB), Int32,
                 (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ptr{Cvoid}, Ptr{GrStats}),
@@ -992,7 +994,7 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     cs, sn = cos.(θs), sin.(θs)
     rays = Ref(GrRayset(Tuple(u), Tuple(permutedims(Mx)), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
         plane.Nr * plane.Nθ, Ptr{Float64}(C_NULL), pointer(rs), pointer(cs), pointer(sn), plane.Nr, plane.Nθ, Int32(1), Int32(0),
-        0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL)))
+        0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL), 0, 0))
     bpf = _builtin_pf(redshift_pf, m)
     isnothing(bpf) && error("lineprofile_mi355x: `redshift_pf` is not a redshift point function the kernels evaluate")
     gpf, keep_pf = bpf
@@ -1055,7 +1057,7 @@ function emissivity_profile_mi355x(ensemble::EnsembleMI355X, m::Gradus.AbstractS
     gid, sky_i = _sky_generator(sampler, n_samples)
     rays = Ref(GrRayset(Tuple(x), Tuple(permutedims(Mx)), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
         n_samples, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0, Int32(0), Int32(0),
-        0, 0, 0, sid, _sky_domain(sampler), gid, Int32(0), res, isempty(sky_i) ? Ptr{Float64}(C_NULL) : pointer(sky_i)))
+        0, 0, 0, sid, _sky_domain(sampler), gid, Int32(0), res, isempty(sky_i) ? Ptr{Float64}(C_NULL) : pointer(sky_i), 0, 0))
     # the disc velocity of _keplerian_velocity_projector (circular-orbits.jl:155-170): Keplerian outside the ISCO, the traced
     # plunging table inside (three NaNLinearInterpolators over the same radii, orbit-solving.jl:99-131)
     pintrp = _expect_fields(Gradus.interpolate_plunging_velocities(m), :m, :t, :r, :ϕ)
@@ -1076,14 +1078,26 @@ function emissivity_profile_mi355x(ensemble::EnsembleMI355X, m::Gradus.AbstractS
     lim = zeros(Float64, 2)
     hits = Ref{Int64}(0)
     stats = Ref{GrStats}()
-    ctx = ensemble.ctxs[1]                                           # a corona is one device's work (10⁶ samples: a few ms)
-    _check(GC.@preserve tab dtab mtab ptab sky_i ccall((:gr_corona_trace, LIB), Int32,
-        (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ptr{Float64}, Ref{Int64}, Ref{GrStats}),
-        ctx, cfg, rays, pfs, lim, hits, stats))
+    ctxs = ensemble.ctxs
+    nctx = length(ctxs)
+    if nctx > 1      # the samples shard like any ray set (ABI 8): every context traces and bins its share, the integer sums add up exactly
+        cstats = Vector{GrStats}(undef, nctx)
+        _check(GC.@preserve tab dtab mtab ptab sky_i ccall((:gr_corona_trace_multi, LIB), Int32,
+            (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ptr{Float64}, Ref{Int64}, Ptr{GrStats}),
+            ctxs, nctx, cfg, rays, pfs, lim, hits, cstats))
+    else
+        _check(GC.@preserve tab dtab mtab ptab sky_i ccall((:gr_corona_trace, LIB), Int32,
+            (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ptr{Float64}, Ref{Int64}, Ref{GrStats}),
+            ctxs[1], cfg, rays, pfs, lim, hits, stats))
+    end
     hits[] > 0 || error("no ray of the corona reached the disc")
     bins = collect(Float64, grid(lim[1], lim[2], N))                                       # radial.jl:60
     sums = zeros(Float64, length(bins), 3)                                                 # columns: count, Σ g, Σ t
-    _check(ccall((:gr_corona_bin, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}), ctx, bins, length(bins), sums))
+    if nctx > 1
+        _check(ccall((:gr_corona_bin_multi, LIB), Int32, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Int64, Ptr{Float64}), ctxs, nctx, bins, length(bins), sums))
+    else
+        _check(ccall((:gr_corona_bin, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}), ctxs[1], bins, length(bins), sums))
+    end
     count, gs, ts = sums[:, 1], sums[:, 2] ./ sums[:, 1], sums[:, 3] ./ sums[:, 1]         # the means of radial.jl:70-84,97
     g_interp = Gradus._make_interpolation(bins, gs)
     disc_velocity = Gradus._keplerian_velocity_projector(m)

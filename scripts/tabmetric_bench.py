@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="1024,2048")
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--grid", default="8,32")
+    ap.add_argument("--grid", default="24,96")
     ap.add_argument("--metrics", default="kerr,johannsen")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()

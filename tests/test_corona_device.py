@@ -98,6 +98,52 @@ def test_sky_rays_start_as_the_host_sampler_says(G, ens):
 
 
 @pytest.mark.gpu
+def test_corona_rows_equal_oracle_traced_rays_and_their_energy_ratio(G, ens, oracle):
+    """The (g, ρ, t, status) rows gr_corona_trace reduces -- here through gr_ray_summary, the call it is built on -- against rays the
+    ORACLE traces from the host sampler's (x, v), with energy_ratio (flux-calculations.jl:96-110) formed in numpy from the oracle's
+    end points, the source's four-velocity and the Keplerian disc velocity: nothing on the reference side of this comparison has
+    been near the device."""
+    import ctypes as C
+
+    from gradus_jl_amd import _lib
+    from gradus_jl_amd.pointfunctions import GR_PF_REDSHIFT, PointFunction
+    from gradus_jl_amd.rendering import abi_pointfunction
+    from gradus_jl_amd.tracing import tracing_configuration
+
+    K = G.corona
+    ens.set("kernel", 2).set("precision", 64)
+    a = 0.9
+    m, model, d = G.KerrMetric(1.0, a), G.LampPostModel(h=8.0), G.ThinDisc(0.0, 300.0)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    n = 3000
+    rs, keep, x, v_src = K.sky_rayset(m, model, s, n)
+    config = tracing_configuration(m, x, np.zeros((1, 4)), d, (0.0, 5000.0), callback=G.domain_upper_hemisphere(), ensemble=ens)
+    plunging = K._plunging_table(m, ens)
+    pf, kp = abi_pointfunction(PointFunction(None, device_pf=GR_PF_REDSHIFT, extra={"r_isco": m.isco(), "plunge": plunging}))
+    pf.has_u_src = 1
+    for q in range(4):
+        pf.u_src[q] = v_src[q]
+    cfg = config.abi_config()
+    rows = np.zeros((n, 4))
+    _lib.check(_lib.load().gr_ray_summary(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), rows.ctypes.data, None))
+    # the oracle on the host sampler's rays
+    xs, vs, vsrc = K.sample_position_direction_velocity(m, model, s, n)
+    ocfg = oracle.make_config("kerr", (1.0, a), disc=(0.0, 300.0), lambda_max=5000.0, upper_hemisphere=True)
+    ref = oracle.trace(ocfg, xs[0], vs)
+    st = rows[:, 3].astype(int)
+    assert int(np.sum(st != ref["status"])) <= 2
+    hit = (st == G.StatusCodes.IntersectedWithGeometry) & (ref["status"] == G.StatusCodes.IntersectedWithGeometry)
+    rho = ref["x"][:, 1] * np.abs(np.sin(ref["x"][:, 2]))
+    out = hit & (rho > 1.05 * m.isco())            # Keplerian disc: circular_fourvelocity is closed-form host code
+    assert out.sum() > 1000
+    np.testing.assert_allclose(rows[hit, 1], rho[hit], rtol=1e-6)
+    np.testing.assert_allclose(rows[hit, 2], ref["x"][hit, 0], rtol=1e-6)
+    v_disc = K.circular_fourvelocity(m, rho[out])
+    g_ref = K.energy_ratio(m, ref[out], vsrc[0], v_disc)
+    np.testing.assert_allclose(rows[out, 0], g_ref, rtol=1e-6)
+
+
+@pytest.mark.gpu
 def test_device_radial_profile_equals_the_record_route(G, ens, monkeypatch):
     """emissivity_profile with the per-ray half on the device against tracecorona + build_radial_profile on the same samples."""
     K = G.corona
@@ -202,11 +248,38 @@ def test_corona_bins_are_the_bucket_rule_and_sum_to_the_hits(G, ens):
     # descending edges are refused
     bad = np.array([3.0, 2.0])
     assert L.gr_corona_bin(ens.ctx.handle, bad.ctypes.data, 2, out.ctypes.data) != 0
-    # a sky source is one context's work
-    arr, sts = _lib.ctx_array([ens.ctx, fresh.ctx])
-    rows = np.zeros((n, 4))
-    assert L.gr_ray_summary_multi(arr, 2, C.byref(cfg), C.byref(rs), C.byref(pf), rows.ctypes.data, sts) != 0
-    assert "sky source" in _lib.load().gr_last_error().decode()
+    # A sky source shards over contexts like any ray set (ABI 8: gr_rayset.sky_first / sky_total -- the sample numbers of a share go
+    # on counting where the previous share stopped): the same rows from three contexts as from one, ...
+    third = G.EnsembleMI355X(0)
+    three = [ens.ctx, fresh.ctx, third.ctx]
+    arr, sts = _lib.ctx_array(three)
+    rows1, rows3 = np.zeros((n, 4)), np.zeros((n, 4))
+    _lib.check(L.gr_ray_summary(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), rows1.ctypes.data, None))
+    _lib.check(L.gr_ray_summary_multi(arr, 3, C.byref(cfg), C.byref(rs), C.byref(pf), rows3.ctypes.data, sts))
+    np.testing.assert_array_equal(rows3, rows1)
+    assert sum(x.rays for x in sts) == n and all(x.rays > 0 for x in sts)
+    # ... and gr_corona_trace_multi / gr_corona_bin_multi give the limits, the hit count and -- integer accumulators on ONE grid
+    # add up exactly -- the BITS of the one-context calls
+    _lib.check(L.gr_corona_trace(ens.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits), C.byref(st)))
+    one = np.zeros((3, 32))
+    edges = np.ascontiguousarray(np.linspace(lim[0], lim[1], 32))
+    _lib.check(L.gr_corona_bin(ens.ctx.handle, edges.ctypes.data, edges.size, one.ctypes.data))
+    lim3, hits3 = np.zeros(2), C.c_int64(0)
+    _lib.check(L.gr_corona_trace_multi(arr, 3, C.byref(cfg), C.byref(rs), C.byref(pf), lim3.ctypes.data, C.byref(hits3), sts))
+    assert hits3.value == hits.value and lim3[0] == lim[0] and lim3[1] == lim[1]
+    multi = np.zeros((3, 32))
+    _lib.check(L.gr_corona_bin_multi(arr, 3, edges.ctypes.data, edges.size, multi.ctypes.data))
+    np.testing.assert_array_equal(multi, one)
+    # contexts that do not hold the shares of one trace are refused
+    _lib.check(L.gr_corona_trace(third.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits), C.byref(st)))
+    assert L.gr_corona_bin_multi(arr, 3, edges.ctypes.data, edges.size, multi.ctypes.data) != 0
+    assert "ONE gr_corona_trace_multi" in _lib.load().gr_last_error().decode()
+    # the Python route: an ensemble over several contexts
+    ens3 = G.EnsembleMI355X(devices=[0, 0, 0])
+    pa = K.device_radial_profile(m, d, model, sampler=s, n_samples=n, N=40, ensemble=ens)
+    pb = K.device_radial_profile(m, d, model, sampler=s, n_samples=n, N=40, ensemble=ens3)
+    np.testing.assert_array_equal(pb.ε, pa.ε)
+    np.testing.assert_array_equal(pb.t, pa.t)
 
 
 @pytest.mark.gpu

@@ -90,24 +90,24 @@ def _oracle_lib(oracle, name):
 
 
 def test_table_matches_dual_number_jacobian_kerr(G, oracle, tab_kerr):
-    assert tab_kerr.m_r == 8 and tab_kerr.n_theta == 32          # the default grid suffices: no refinement
-    assert tab_kerr.errors[0] < 2e-11 and tab_kerr.errors[1] < 1e-8 and tab_kerr.errors[2] < 1e-8
+    assert tab_kerr.m_r == 24 and tab_kerr.n_theta == 96          # the default grid suffices: no refinement
+    assert tab_kerr.errors[0] < 1e-10 and tab_kerr.errors[1] < 1e-7 and tab_kerr.errors[2] < 1e-7
     cfg = oracle.make_config("kerr", (1.0, 0.998))
     ev, edr, edt = _jacobian_errors(oracle, tab_kerr, cfg, np.random.default_rng(5))
-    assert ev < 1e-11 and edr < 3e-9 and edt < 3e-9, (ev, edr, edt)
+    assert ev < 3e-11 and edr < 3e-8 and edt < 3e-8, (ev, edr, edt)
 
 
 def test_table_matches_dual_number_jacobian_johannsen(G, oracle, tab_johannsen):
     cfg = oracle.make_config("johannsen", (1.0, 0.7, 2.0, 0.0, 0.0, 1.0))
     ev, edr, edt = _jacobian_errors(oracle, tab_johannsen, cfg, np.random.default_rng(6))
-    assert ev < 1e-11 and edr < 3e-9 and edt < 3e-9, (ev, edr, edt)
+    assert ev < 3e-11 and edr < 3e-8 and edt < 3e-8, (ev, edr, edt)
 
 
 def test_table_matches_dual_number_jacobian_user_metric(G, oracle, tab_bump):
     cfg = oracle.make_config("test-bump", BUMP)
     with oracle.user_metric_library():
         ev, edr, edt = _jacobian_errors(oracle, tab_bump, cfg, np.random.default_rng(7))
-    assert ev < 1e-11 and edr < 3e-9 and edt < 3e-9, (ev, edr, edt)
+    assert ev < 3e-11 and edr < 3e-8 and edt < 3e-8, (ev, edr, edt)
 
 
 def test_error_estimates_are_not_optimistic(G, oracle):
@@ -116,14 +116,14 @@ def test_error_estimates_are_not_optimistic(G, oracle):
     assert tm.m_r == 2 and tm.n_theta == 8
     cfg = oracle.make_config("kerr", (1.0, 0.998))
     ev, edr, edt = _jacobian_errors(oracle, tm, cfg, np.random.default_rng(8))
-    assert tm.errors[0] > 1e-9                    # coarse on purpose
+    assert tm.errors[0] > 1e-8                    # coarse on purpose
     assert ev < 3 * tm.errors[0] and edr < 3 * tm.errors[1] and edt < 3 * tm.errors[2], (ev, edr, edt, tm.errors)
 
 
 def test_refinement_stops_at_tolerance(G):
-    tm = G.TabulatedMetric(G.KerrMetric(1.0, 0.5), m_r=2, n_theta=4, max_refinements=4)
-    assert tm.errors[0] <= 2e-11 and tm.errors[1] <= 1e-8 and tm.errors[2] <= 1e-8
-    assert tm.m_r > 2 and tm.n_theta > 4
+    tm = G.TabulatedMetric(G.KerrMetric(1.0, 0.5), m_r=4, n_theta=8, max_refinements=8)
+    assert tm.errors[0] <= 1e-10 and tm.errors[1] <= 1e-7 and tm.errors[2] <= 1e-7
+    assert tm.m_r > 4 and tm.n_theta > 8
 
 
 def test_theta_fold(tab_kerr):
@@ -160,7 +160,7 @@ def test_host_entry_points_reject_bad_input(G):
     assert lib.gr_metric_grid_plan(1.0, 10.0, 0.5, 2, 2, grid) == 0
     assert grid.pole_factor == 1
     grid.pole_factor = 0                      # the samples below are constants: nothing vanishes on the axis
-    assert grid.degree == 7 and grid.n_seg == 1 and grid.n_rows == grid.n_oct * 2
+    assert grid.degree == 5 and grid.n_seg == 1 and grid.n_rows == grid.n_oct * 2
     assert grid.n_r_nodes == grid.n_oct * 2 * grid.fit_nodes and grid.n_theta_nodes == 2 * grid.fit_nodes
     rn, tn = np.empty(grid.n_r_nodes), np.empty(grid.n_theta_nodes)
     assert lib.gr_metric_grid_nodes(grid, rn.ctypes.data, tn.ctypes.data) == 0
@@ -198,7 +198,7 @@ def test_scalar_callable_is_sampled_point_by_point(G):
             raise TypeError("scalars only")
         return G.KerrMetric(1.0, 0.3).metric_components(r, th)
 
-    tm = G.TabulatedMetric(f, inner_radius=1.0 + math.sqrt(1 - 0.09), isco=5.0, m_r=1, n_theta=2, r_max=50.0, max_refinements=0, strict=False)
+    tm = G.TabulatedMetric(f, inner_radius=1.0 + math.sqrt(1 - 0.09), isco=5.0, m_r=2, n_theta=4, r_max=50.0, max_refinements=0, strict=False)
     g, _, _ = tm.table_jacobian(10.0, 1.0)
     np.testing.assert_allclose(g, f(10.0, 1.0), rtol=1e-6)
 
@@ -246,7 +246,7 @@ def test_tabulated_endpoints_vs_oracle_kernel_logic(G, oracle, which, tab_kerr, 
         # ... and against the metric's own fused right-hand side through the same integrator: the table's error alone
         fcfg = G.render_configuration(tm.source, X_FAR, G.ThinDisc(*disc), 2000.0, image_width=W, image_height=H,
                                       alpha_lims=(-60, 60), beta_lims=(-35, 35))
-        _compare_endpoints(got, Hh.render_endpoints(G, fcfg), x_rtol=1e-8, max_flips=0)
+        _compare_endpoints(got, Hh.render_endpoints(G, fcfg), x_rtol=1e-7, max_flips=0)
 
 
 @pytest.mark.parametrize("which", ["kerr-dark-matter", "kerr-refractive", "dilaton-axion"])
@@ -395,7 +395,7 @@ def test_piecewise_metrics_through_the_table_equal_their_fused_kernels(G, ens, w
     # feels every part of the ray's path; the refractive metric keeps Kerr's ISCO, kerr-refractive-ad.jl:61, and the redshift)
     isco = base.isco() if which == "kerr-refractive" else 6.0
     tm = G.TabulatedMetric(_as_callable(base), inner_radius=base.inner_radius(), isco=isco, breaks=base.break_radii())
-    assert tm.grid.n_seg == (3 if which == "kerr-dark-matter" else 5) and (tm.m_r, tm.n_theta) == (8, 32)
+    assert tm.grid.n_seg == (3 if which == "kerr-dark-matter" else 5) and (tm.m_r, tm.n_theta) == (24, 96)
     d = G.ThinDisc(isco, 50.0)
     out = []
     for m in (tm, base):
@@ -653,14 +653,14 @@ def test_a_metric_the_table_cannot_represent_is_refused_loudly(G):
         G.TabulatedMetric(stepped, inner_radius=kerr_in.inner_radius(), isco=kerr_in.isco(), r_max=200.0)
     with pytest.warns(UserWarning, match="not smooth"):
         tm = G.TabulatedMetric(stepped, inner_radius=kerr_in.inner_radius(), isco=kerr_in.isco(), r_max=200.0, strict=False)
-    assert tm.errors[0] > 1e-6 and (tm.m_r, tm.n_theta) == (16, 64)      # one doubling showed no convergence: no further ones
+    assert tm.errors[0] > 1e-6 and (tm.m_r, tm.n_theta) == (36, 144)      # one refinement showed no convergence: no further ones
     # ... and the same function with its break NAMED is an ordinary table on the default grid: no patch straddles r = 9
     tb = G.TabulatedMetric(stepped, inner_radius=kerr_in.inner_radius(), isco=kerr_in.isco(), r_max=200.0, breaks=[9.0])
-    assert (tb.m_r, tb.n_theta) == (8, 32) and tb.errors[0] < 2e-11 and tb.errors[1] < 1e-8 and tb.grid.n_seg == 2
+    assert (tb.m_r, tb.n_theta) == (24, 96) and tb.errors[0] < 1e-10 and tb.errors[1] < 1e-7 and tb.grid.n_seg == 2
     for r in (8.9999999, 9.0000001, 3.0, 150.0):
         g, dr, _ = tb.table_jacobian(r, 1.1)
         ref = (kerr_in if r < 9.0 else kerr_out).metric_components(r, 1.1)
-        np.testing.assert_allclose(g, ref, rtol=1e-10)
+        np.testing.assert_allclose(g, ref, rtol=2e-9)
 
 
 def test_an_inner_radius_inside_the_horizon_moves_the_table_out(G):
@@ -671,7 +671,7 @@ def test_an_inner_radius_inside_the_horizon_moves_the_table_out(G):
     with pytest.warns(UserWarning, match="g_rr changes sign"):
         tm = G.TabulatedMetric(f, inner_radius=0.8 * kerr.inner_radius(), isco=kerr.isco(), r_max=500.0)
     assert tm.inner_radius() == pytest.approx(kerr.inner_radius(), rel=1e-9)
-    assert tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
+    assert tm.errors[0] < 1e-10 and tm.errors[1] < 1e-7
 
 
 def test_axion_charge_takes_the_axis_form(G):
@@ -679,7 +679,7 @@ def test_axion_charge_takes_the_axis_form(G):
     divided by sin²θ they are singular, as sampled they pass through zero a few milliradians off the axis and a polynomial's absolute
     error is no relative one there.  The constructor finds that out from the fit and stores them as K_m(r) + K_d(r) cos θ +
     sin²θ h(r, θ) (gr_metric_grid.pole_factor = 2): the limits on the two poles as polynomials of their own, the rest smooth.
-    The table then follows the metric to 1e-11 of ITSELF next to the axis, on both poles; with β = 0 nothing changes."""
+    The table then follows the metric to 1e-9 of ITSELF next to the axis, on both poles; with β = 0 nothing changes."""
     import warnings
 
     da = G.DilatonAxion(1.0, 0.35, 0.16, 0.33)
@@ -688,12 +688,12 @@ def test_axion_charge_takes_the_axis_form(G):
         tm = G.TabulatedMetric(da)
         t0 = G.TabulatedMetric(G.DilatonAxion(1.0, 0.5, 0.0, 1.0))
     assert tm.grid.pole_factor == 2 and t0.grid.pole_factor == 1
-    assert (tm.m_r, tm.n_theta) == (8, 32) and tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8 and tm.errors[2] < 1e-8
+    assert (tm.m_r, tm.n_theta) == (24, 96) and tm.errors[0] < 1e-10 and tm.errors[1] < 1e-7 and tm.errors[2] < 1e-7
     for r in (2.9, 4.0, 40.0, 900.0):
         for th in (1e-4, 3e-3, 0.03, 0.05, 1.3, math.pi - 0.02, math.pi - 2e-3):
             g, dr, dth = tm.table_jacobian(r, th)
             ref = np.array(da.metric_components(r, th))
-            np.testing.assert_allclose(g, ref, rtol=2e-11)
+            np.testing.assert_allclose(g, ref, rtol=1e-9)
             # the derivatives of the azimuthal components against difference quotients of the metric
             h = 1e-6
             fd_r = (np.array(da.metric_components(r * (1 + h), th)) - np.array(da.metric_components(r * (1 - h), th))) / (2 * h * r)
@@ -702,7 +702,7 @@ def test_axion_charge_takes_the_axis_form(G):
     gN, gS = tm.table_jacobian(4.0, 1e-5)[0], tm.table_jacobian(4.0, math.pi - 1e-5)[0]
     assert abs(gN[3] - gS[3]) > 0.1 and abs(gN[4] - gS[4]) > 0.1
     # a Jet through the table's own polynomials (the generic ISCO's route) includes the axis terms
-    np.testing.assert_allclose(tm._table_components(4.0, 0.01)[3], da.metric_components(4.0, 0.01)[3], rtol=1e-10)
+    np.testing.assert_allclose(tm._table_components(4.0, 0.01)[3], da.metric_components(4.0, 0.01)[3], rtol=1e-9)
 
 
 def _as_callable(m):
@@ -719,10 +719,10 @@ def test_piecewise_metrics_pass_the_fit_once_their_breaks_are_named(G):
     with pytest.raises(ValueError, match="not smooth"):
         G.TabulatedMetric(_as_callable(kdm), inner_radius=kdm.inner_radius(), isco=6.0)
     tm = G.TabulatedMetric(_as_callable(kdm), inner_radius=kdm.inner_radius(), isco=6.0, breaks=[7.0, 15.0])
-    assert (tm.m_r, tm.n_theta) == (8, 32) and tm.grid.n_seg == 3 and tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
+    assert (tm.m_r, tm.n_theta) == (24, 96) and tm.grid.n_seg == 3 and tm.errors[0] < 1e-10 and tm.errors[1] < 1e-7
     for r in (3.0, 6.999999, 7.000001, 11.0, 14.999999, 15.000001, 400.0):
         g, dr, _ = tm.table_jacobian(r, 0.9)
-        np.testing.assert_allclose(g, kdm.metric_components(r, 0.9), rtol=1e-10)
+        np.testing.assert_allclose(g, kdm.metric_components(r, 0.9), rtol=2e-9)
         h = 1e-7 * r
         fd = (np.array(kdm.metric_components(r + h, 0.9)) - np.array(kdm.metric_components(r - h, 0.9))) / (2 * h)
         np.testing.assert_allclose(dr, fd, rtol=2e-5, atol=1e-8)
@@ -732,10 +732,10 @@ def test_piecewise_metrics_pass_the_fit_once_their_breaks_are_named(G):
     with pytest.raises(ValueError, match="not smooth"):
         G.TabulatedMetric(_as_callable(kr), inner_radius=kr.inner_radius(), isco=kr.isco())
     tr = G.TabulatedMetric(_as_callable(kr), inner_radius=kr.inner_radius(), isco=kr.isco(), breaks=kr.break_radii())
-    assert (tr.m_r, tr.n_theta) == (8, 32) and tr.grid.n_seg == 5 and tr.errors[0] < 2e-11 and tr.errors[1] < 1e-8
+    assert (tr.m_r, tr.n_theta) == (24, 96) and tr.grid.n_seg == 5 and tr.errors[0] < 1e-10 and tr.errors[1] < 1e-7
     for r in (5.0, 18.7499, 18.7501, 19.9, 19.999, 19.99999, 20.0, 20.00001, 20.001, 20.4, 21.2499, 21.2501, 300.0):
         g, dr, _ = tr.table_jacobian(r, 1.2)
-        np.testing.assert_allclose(g, kr.metric_components(r, 1.2), rtol=1e-10)
+        np.testing.assert_allclose(g, kr.metric_components(r, 1.2), rtol=2e-9)
     # across the arctangent step g_tt changes by a factor n² = 1.44 within 1e-3: the table resolves its slope
     g1, d1, _ = tr.table_jacobian(20.0, 1.2)
     fd = (kr.metric_components(20.0 + 1e-8, 1.2)[0] - kr.metric_components(20.0 - 1e-8, 1.2)[0]) / 2e-8
@@ -772,10 +772,10 @@ def test_negative_radii_through_a_wormhole_throat(G):
     r_min < 0 and a break at 0 of the throat's size -- segments measure distances from their anchors, not radii."""
     mt = G.MorrisThorneWormhole(1.0)
     tm = G.TabulatedMetric(mt, r_min=-1000.0, r_max=1000.0, breaks=[(0.0, 1.0)])
-    assert tm.grid.pole_factor == 0 and tm.grid.n_seg == 3 and tm.errors[0] < 2e-11 and tm.errors[1] < 1e-8
+    assert tm.grid.pole_factor == 0 and tm.grid.n_seg == 3 and tm.errors[0] < 1e-10 and tm.errors[1] < 1e-7
     for r in (-900.0, -256.5, -100.0, -3.0, -1e-3, 0.0, 1e-5, 0.3, 2.0, 77.0, 999.0):
         g, dr, dth = tm.table_jacobian(r, 0.7)
-        np.testing.assert_allclose(g, mt.metric_components(r, 0.7), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(g, mt.metric_components(r, 0.7), rtol=1e-10, atol=1e-14)
         np.testing.assert_allclose(dr[2], 2.0 * r, rtol=1e-10, atol=1e-10)          # ∂r g_θθ = 2 l: changes sign in the throat
 
 
@@ -789,7 +789,7 @@ def test_the_table_grows_to_cover_a_chart_and_nothing_is_extrapolated(G):
     id0 = tm.table[8]
     tm.cover(tm.r_min, 6000.0)
     assert tm.r_max == 12000.0 and tm.table[8] != id0 and tm.table[13] == 12000.0      # H_BUILD_ID, H_RMAX
-    np.testing.assert_allclose(tm.table_jacobian(5000.0, 1.0)[0], tm.source.metric_components(5000.0, 1.0), rtol=1e-10)
+    np.testing.assert_allclose(tm.table_jacobian(5000.0, 1.0)[0], tm.source.metric_components(5000.0, 1.0), rtol=2e-9)
     with pytest.raises(ValueError, match="crosses the horizon"):
         tm.cover(0.5 * tm.inner_radius(), 100.0)
     for r in (float("inf"), float("-inf"), float("nan"), 1e300):
@@ -826,7 +826,7 @@ def test_isco_of_a_bare_callable_comes_from_the_table(G):
     then a bracketing root find of dE/dr) runs on the table's own polynomials -- every radius of the scan in its own patch."""
     kerr = G.KerrMetric(1.0, 0.9)
     tm = G.TabulatedMetric(lambda r, th: kerr._components(r, np.sin(th), np.cos(th)), inner_radius=kerr.inner_radius())
-    assert tm.isco() == pytest.approx(kerr.isco(), rel=1e-8)
+    assert tm.isco() == pytest.approx(kerr.isco(), rel=5e-7)          # (second derivatives of the table's polynomials)
     rs = np.array([1.6, 2.5, 7.0, 90.0])
     got = tm._table_components(rs, 1.2)
     for k in range(5):
