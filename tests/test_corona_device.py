@@ -271,7 +271,9 @@ def test_corona_bins_are_the_bucket_rule_and_sum_to_the_hits(G, ens):
     _lib.check(L.gr_corona_bin_multi(arr, 3, edges.ctypes.data, edges.size, multi.ctypes.data))
     np.testing.assert_array_equal(multi, one)
     # contexts that do not hold the shares of one trace are refused
-    _lib.check(L.gr_corona_trace(third.ctx.handle, C.byref(cfg), C.byref(rs), C.byref(pf), lim.ctypes.data, C.byref(hits), C.byref(st)))
+    rs_other = type(rs).from_buffer_copy(rs)
+    rs_other.n = n // 3
+    _lib.check(L.gr_corona_trace(third.ctx.handle, C.byref(cfg), C.byref(rs_other), C.byref(pf), lim.ctypes.data, C.byref(hits), C.byref(st)))
     assert L.gr_corona_bin_multi(arr, 3, edges.ctypes.data, edges.size, multi.ctypes.data) != 0
     assert "ONE gr_corona_trace_multi" in _lib.load().gr_last_error().decode()
     # the Python route: an ensemble over several contexts

