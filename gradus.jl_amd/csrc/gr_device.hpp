@@ -3581,6 +3581,25 @@ struct Ray {
             ex4[i] = ex2.x; ex4[i + 1] = ex2.y;
         }
 #endif
+#if GR_PK_F32
+        // ... and the scaled residuals of the pairs: scale = reltol max(|u0|, |u1|) + abstol, residual / scale, squares summed -- packed
+        // FMA / MUL around two scalar reciprocals
+        {
+            gr_f2 s2v = { 0.f, 0.f }, s2x = { 0.f, 0.f };
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const gr_f2 mv = { absmax(v[i], vn[i]), absmax(v[i + 1], vn[i + 1]) }, mx = { absmax(x[i], xn[i]), absmax(x[i + 1], xn[i + 1]) };
+                const gr_f2 kv = __builtin_elementwise_fma(mv, (gr_f2)(reltol), (gr_f2)(abstol));
+                const gr_f2 kx = __builtin_elementwise_fma(mx, (gr_f2)(reltol), (gr_f2)(abstol));
+                const gr_f2 av = GR_PK2(ev4, i) * gr_f2{ rcp_raw(kv.x), rcp_raw(kv.y) };
+                const gr_f2 ax = GR_PK2(ex4, i) * gr_f2{ rcp_raw(kx.x), rcp_raw(kx.y) };
+                s2v = __builtin_elementwise_fma(av, av, s2v);
+                s2x = __builtin_elementwise_fma(ax, ax, s2x);
+            }
+            e2v = s2v.x + s2v.y;
+            e2x = s2x.x + s2x.y;
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #if GR_PK_F32
@@ -3638,6 +3657,7 @@ struct Ray {
             e2x = GR_FMA(ax, ax, e2x);
 #endif
         }
+#endif
 #if GR_NORM_F32_ON
         real e2 = (real)__builtin_fmaf((float)(Ts::BT[0] * Ts::BT[0]), e2vf, e2xf);
 #else
