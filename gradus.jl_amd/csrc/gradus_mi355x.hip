@@ -117,6 +117,7 @@ struct gr_ctx {
     double* d_sky = nullptr;               // a sky source's (x, v) arrays, written by k_sky_velocities for the trace kernels
     size_t sky_bytes = 0;
     int64_t sky_first = 0, sky_total = 0;  // the share of a sky source the launch being prepared traces (rays_params -> sky_prepare)
+    bool sky_any_order = false;            // ... whose rows may come in any order (gr_corona_trace): the rays are dealt by direction
     double* d_corona = nullptr;            // gr_corona_trace: (g, ρ, t, status) per ray, kept for gr_corona_bin
     size_t corona_bytes = 0;
     int64_t corona_n = -1, corona_hits = 0;
@@ -477,16 +478,12 @@ struct SkyParams {
     double resolution;
     const double* sky_i;
 };
-__global__ void __launch_bounds__(256) k_sky_velocities(const SkyParams p, double* out)      // out: x_obs[4], then v[n][4]
+// sample jl of the launch -> its direction on the source's sky (samplers.jl:30-44) and the four-velocity v = Mx (1, k̂)
+__device__ __forceinline__ void sky_sample(const SkyParams& p, int64_t jl, double& el, double& az, double v[4])
 {
-    const int64_t jl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (jl == 0)
-        for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
-    if (jl >= p.n) return;
     const double n = (double)p.total;
     const double idx = (double)(p.first + jl + 1);
     const double i = p.generator == 0 ? idx : p.generator == 1 ? idx / n : p.sky_i[jl];
-    double el;
     if (p.sampler == 2) {
         const double ph = 2.0 * ::atan(::sqrt(p.resolution / i));
         const bool even = (::floor(i) == i) && (::fmod(i, 2.0) == 0.0);
@@ -496,13 +493,71 @@ __global__ void __launch_bounds__(256) k_sky_velocities(const SkyParams p, doubl
         el = p.both ? ::acos(1.0 - 2.0 * u) : ::acos(1.0 - u);
     }
     const double az_raw = (p.generator == 0 ? 3.14159265358979323846 * (1.0 + 2.2360679774997896964) : 6.28318530717958647692) * i;
-    double az = ::fmod(az_raw, 6.28318530717958647692);
+    az = ::fmod(az_raw, 6.28318530717958647692);
     if (az < 0.0) az += 6.28318530717958647692;
     const double se = ::sin(el), ce = ::cos(el), sa = ::sin(az), ca = ::cos(az);
     const double pb[4] = { 1.0, -(se * ca), -(se * sa), -ce };
-    double* v = out + 4 + 4 * jl;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = p.Mx[q * 4 + 0] * pb[0] + p.Mx[q * 4 + 1] * pb[1] + p.Mx[q * 4 + 2] * pb[2] + p.Mx[q * 4 + 3] * pb[3];
+}
+__global__ void __launch_bounds__(256) k_sky_velocities(const SkyParams p, double* out)      // out: x_obs[4], then v[n][4]
+{
+    const int64_t jl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jl == 0)
+        for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
+    if (jl >= p.n) return;
+    double el, az, v[4];
+    sky_sample(p, jl, el, az, v);
+    double* o = out + 4 + 4 * jl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = v[q];
+}
+// The same rays DEALT BY DIRECTION (gr_corona_trace: the order of its rows is free -- min / max and integer bins do not know it).
+// How long a ray takes depends on where it goes: of 64 CONSECUTIVE samples of a golden spiral -- one polar angle, azimuths all
+// round the sky -- the longest ray takes twice the mean (a wave of them keeps 55 % of its lanes busy, oracle step counts of the
+// lamp-post scene).  A workgroup takes kSkyChunk consecutive samples (still one polar angle to 1 %) and writes them grouped by
+// azimuth -- 64 buckets, by hemisphere and azimuth / 32 -- so that the 64 rays of a wave leave in nearly the same direction.
+constexpr int kSkyChunk = 4096;
+__global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p, double* out)
+{
+    __shared__ int cnt[64], start[64];
+    const int64_t base = (int64_t)blockIdx.x * kSkyChunk;
+    const int64_t left = p.n - base;
+    const int nloc = left < kSkyChunk ? (int)left : kSkyChunk;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
+    __syncthreads();
+    double v[kSkyChunk / 1024][4];
+    int bucket[kSkyChunk / 1024], pos[kSkyChunk / 1024];
+#pragma unroll
+    for (int k = 0; k < kSkyChunk / 1024; ++k) {
+        const int j = (int)threadIdx.x + 1024 * k;
+        bucket[k] = -1;
+        if (j < nloc) {
+            double el, az;
+            sky_sample(p, base + j, el, az, v[k]);
+            int a32 = (int)(az * (32.0 / 6.28318530717958647692));
+            a32 = a32 > 31 ? 31 : (a32 < 0 ? 0 : a32);
+            bucket[k] = (el > 1.57079632679489661923 ? 32 : 0) + a32;
+            pos[k] = atomicAdd(&cnt[bucket[k]], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int q = 0; q < 64; ++q) { start[q] = sum; sum += cnt[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSkyChunk / 1024; ++k) {
+        if (bucket[k] < 0) continue;
+        // (chunks in REVERSE order: the last samples of a sky leave upwards, away from the disc, and are the long rays -- out to
+        // the chart's edge; traced first, they do not make the tail of the launch)
+        double* o = out + 4 + 4 * ((p.n - base - nloc) + start[bucket[k]] + pos[k]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = v[k][q];
+    }
 }
 }  // namespace
 }  // extern "C++"
@@ -522,7 +577,10 @@ static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t strea
     sp.sampler = cold.sky_sampler; sp.both = cold.sky_both; sp.generator = cold.sky_generator; sp.reserved = 0;
     sp.resolution = cold.sky_resolution;
     sp.sky_i = cold.sky_i;
-    hipLaunchKernelGGL(k_sky_velocities, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, sp, ctx->d_sky);
+    if (ctx->sky_any_order && p.n >= 4 * kSkyChunk)
+        hipLaunchKernelGGL(k_sky_velocities_dealt, dim3((unsigned)((p.n + kSkyChunk - 1) / kSkyChunk)), dim3(1024), 0, stream, sp, ctx->d_sky);
+    else
+        hipLaunchKernelGGL(k_sky_velocities, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, sp, ctx->d_sky);
     GR_HIP(hipGetLastError());
     cold.src_mode = 1;
     cold.x = ctx->d_sky;
@@ -572,8 +630,13 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
         return fail(GR_ERR_UNSUPPORTED, "a tabulated metric is traced by the fp64 kernels only (there is no fp32 table: not with \"precision\" 32)");
     if (p.cfg.disc_id == GR_DISC_MESH && (tangent || ctx->precision == 32))
         return fail(GR_ERR_UNSUPPORTED, "a mesh geometry is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
-    const int kern_sel = tangent ? 0 : resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);
-    const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : resolve_block(ctx, kern_sel);
+    // A sky source whose rays were dealt by direction (sky_prepare): a wave's 64 rays leave in nearly one direction and take nearly the
+    // same number of steps (lane utilisation 0.9 against 0.5 for consecutive samples), which the persistent kernel's refill would mix
+    // again -- one ray per lane, four waves to a workgroup (10⁶ lamp-post samples: 7.2 ms against 8.4 persistent, 8.4 with one-wave
+    // workgroups; profiles/r6_corona_deal_ab.log)
+    const bool dealt = sky && ctx->sky_any_order && p.n >= 4 * kSkyChunk && !tangent;
+    const int kern_sel = tangent ? 0 : (dealt && ctx->kernel == 2) ? 0 : resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);
+    const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : (dealt && ctx->kernel == 2 && !ctx->block) ? 256 : resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
     // A table is staged per workgroup: with one-wave workgroups a CU holds 8 copies, so it is staged
     // only while those fit the 160 KB of LDS without capping the occupancy (<= 640 rows of 32 B).
@@ -2172,7 +2235,10 @@ static int32_t corona_enqueue(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     unsigned long long* red = (unsigned long long*)(ctx->d_corona + 4 * (size_t)rays->n);
     static const unsigned long long init[5] = { ~0ull, 0ull, 0ull, 0ull, 0ull };
     GR_HIP(hipMemcpyAsync(red, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = gr_ray_summary_device(ctx, cfg, &dev, pf, ctx->d_corona, stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream)) != GR_OK) return rc;
+    ctx->sky_any_order = true;      // (the rows are reduced and binned: their order is the library's to choose)
+    rc = gr_ray_summary_device(ctx, cfg, &dev, pf, ctx->d_corona, stats ? (gr_stats*)ctx->d_stats : nullptr, ctx->stream);
+    ctx->sky_any_order = false;
+    if (rc != GR_OK) return rc;
     if (rays->n > 0) {
         int64_t blocks = (rays->n + 255) / 256;
         blocks = blocks > 2048 ? 2048 : blocks;
