@@ -8,7 +8,7 @@ from . import _lib
 from ._lib import Context, GradusMI355XError, POINT_DTYPE
 from . import device, distributed
 from . import corona, reverberation, transfer_functions
-from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, EvenGenerator, EvenSampler,
+from .corona import (BeamedPointSource, BothHemispheres, CoronaGeodesics, DiscCorona, EvenGenerator, EvenSampler,
                      GoldenSpiralGenerator, LampPostModel, LowerHemisphere, PowerLawSpectrum, RadialDiscProfile, RingCorona,
                      SourceVelocities,
                      RandomGenerator, WeierstrassSampler, coordtime_at, emissivity_at, emissivity_profile,

@@ -213,6 +213,7 @@ class gr_rayset(C.Structure):
         ("sky_i", C.c_void_p),
         ("sky_first", C.c_int64),          # ABI 8: a share of a source's samples (the *_multi entry points set them per context)
         ("sky_total", C.c_int64),
+        ("sky_rows", C.c_void_p),          # ABI 8: a source without one position: 28 doubles per ray (x, Mx, lowered source velocity, g_tμ)
     ]
 
 

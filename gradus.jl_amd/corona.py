@@ -230,6 +230,28 @@ class RingCorona(AbstractCoronaModel):
         return x, np.asarray(self.vf(m, x), dtype=np.float64)
 
 
+class DiscCorona(AbstractCoronaModel):
+    """DiscCorona(vf, r, h): a disc of radius r at height h above the accretion disc (extended.jl:165-181); every sample leaves
+    from a point of its own, x = rand() r along the disc (sample_position_velocity, extended.jl:176-183).  Its emissivity goes
+    through the Monte-Carlo route (`emissivity_profile(..., sampler=...)`: tracecorona + RadialDiscProfile); the reference's
+    concentric-ring method (extended.jl:185-200, time-dependent ring profiles) is not restated.  `seed`: the generator behind rand()."""
+
+    def __init__(self, *args, r=5.0, h=5.0, vf=SourceVelocities.co_rotating, seed=None):
+        if len(args) == 3:
+            vf, r, h = args
+        elif len(args) == 2:
+            r, h = args
+        elif args:
+            raise TypeError("DiscCorona(vf, r, h) | DiscCorona(r, h) | DiscCorona(r=, h=, vf=)")
+        self.vf, self.r, self.h = vf, float(r), float(h)
+        self.rng = np.random.default_rng(seed)
+
+    def sample_position_velocity(self, m):
+        ρ = self.rng.random() * self.r
+        x = np.array([0.0, math.hypot(ρ, self.h), math.atan2(ρ, self.h), 0.0])      # (x, y) flipped: off the z axis
+        return x, np.asarray(self.vf(m, x), dtype=np.float64)
+
+
 def oblate_spheroid_to_spherical(x, h, a):
     """utils.jl:186-200: (x along the equatorial axis, height h) -> Boyer-Lindquist (r, θ)"""
     if abs(a) < 1e-8:
@@ -273,7 +295,9 @@ def _device_corona_enabled(m, sampler):
 
 
 def _sky_route(m, model, sampler):
-    return (model.point_source or model.fixed_position) and _device_corona_enabled(m, sampler)
+    """Sky rays formed on the device: a source at one position crosses the boundary as one matrix, any other as 28 doubles per
+    sample (gr_rayset.sky_rows, ABI 8)."""
+    return _device_corona_enabled(m, sampler)
 
 
 def _sky_endpoints(m, model, sampler, n_samples, geometry, λs, stats=False, **kwargs):
@@ -321,7 +345,8 @@ def tracecorona(m, g, model, *, λmax=10_000.0, n_samples=1024, sampler=None, ca
     if _sky_route(m, model, sampler):
         gps, v_src = _sky_endpoints(m, model, sampler, n_samples, g, λmax, callback=callback, **kwargs)
         mask = gps["status"] == StatusCodes.IntersectedWithGeometry
-        return CoronaGeodesics(m, g, model, gps[mask], np.tile(v_src, (int(mask.sum()), 1)))
+        # (a source of many positions: v_src holds one source velocity per sample)
+        return CoronaGeodesics(m, g, model, gps[mask], v_src[mask] if np.ndim(v_src) == 2 else np.tile(v_src, (int(mask.sum()), 1)))
     xs, vs, vsrc = sample_position_direction_velocity(m, model, sampler, n_samples)
     gps = _tracegeodesics(m, xs, vs, g, λmax, callback=callback, **kwargs)
     mask = gps["status"] == StatusCodes.IntersectedWithGeometry
@@ -525,18 +550,44 @@ def sky_rayset(m, model, sampler, n_samples):
     sky angles -> k̂ happens per lane on the device (samplers.jl:30-44).  Returns (rayset, keepalive, x, v_source)."""
     from . import _lib
 
-    if not (model.point_source or model.fixed_position):
-        raise NotImplementedError("a sky ray set describes a source at ONE position (point_source / fixed_position models)")
-    x, v = model.sample_position_velocity(m)
-    if x[1] < m.inner_radius() * 1.9:
-        raise ValueError("source position lies inside 1.9 inner radii")
-    x = np.array(x, dtype=np.float64)
-    x[2] = min(max(x[2], 1e-3), math.pi - 1e-3)             # avoid coordinate singularities, corona-models.jl:18-24
-    v = np.asarray(v, dtype=np.float64)
-    B = np.eye(4)
-    B[1:, 1:] = _cart_to_spher_jacobian(x[2], x[3])
-    Mx = tetradframe_matrix(m, x, v) @ B
+    rmin = m.inner_radius() * 1.9
+
+    def matrix_at(x, v):
+        B = np.eye(4)
+        B[1:, 1:] = _cart_to_spher_jacobian(x[2], x[3])
+        return tetradframe_matrix(m, x, v) @ B
+
     rs = _lib.gr_rayset()
+    rows = None
+    if model.point_source or model.fixed_position:
+        x, v = model.sample_position_velocity(m)
+        if x[1] < rmin:
+            raise ValueError("source position lies inside 1.9 inner radii")
+        x = np.array(x, dtype=np.float64)
+        x[2] = min(max(x[2], 1e-3), math.pi - 1e-3)             # avoid coordinate singularities, corona-models.jl:18-24
+        v = np.asarray(v, dtype=np.float64)
+        Mx = matrix_at(x, v)
+    else:
+        # A source without one position (DiscCorona; any model whose sample_position_velocity draws): every sample brings its own
+        # position, matrix and -- for the energy ratio -- its source velocity with the index lowered, and g_tμ there: 28 doubles
+        # (gr_rayset.sky_rows), in the order corona-models.jl:1-33 draws them (rejecting positions inside 1.9 inner radii).
+        rows = np.zeros((int(n_samples), 28))
+        vsrc = np.zeros((int(n_samples), 4))
+        for k in range(int(n_samples)):
+            xk, vk = model.sample_position_velocity(m)
+            while xk[1] < rmin:
+                xk, vk = model.sample_position_velocity(m)
+            xk = np.array(xk, dtype=np.float64)
+            xk[2] = min(max(xk[2], 1e-3), math.pi - 1e-3)
+            vk = np.asarray(vk, dtype=np.float64)
+            g = m.metric_components(xk[1], xk[2])
+            rows[k, 0:4] = xk
+            rows[k, 4:20] = matrix_at(xk, vk).ravel()
+            rows[k, 20:24] = (g[0] * vk[0] + g[4] * vk[3], g[1] * vk[1], g[2] * vk[2], g[3] * vk[3] + g[4] * vk[0])
+            rows[k, 24:28] = (g[0], 0.0, 0.0, g[4])
+            vsrc[k] = vk
+        x, v, Mx = rows[int(np.argmax(rows[:, 1])), 0:4].copy(), vsrc, np.eye(4)      # (x: the outermost sample, for the chart's range checks)
+        rs.sky_rows = rows.ctypes.data
     for q in range(4):
         rs.x_obs[q] = x[q]
     for q, val in enumerate(np.ascontiguousarray(Mx).ravel()):
@@ -559,7 +610,7 @@ def sky_rayset(m, model, sampler, n_samples):
         # any other generator (RandomGenerator: rand() N): its numbers cross, 8 bytes per ray
         keep = np.ascontiguousarray(geti(sampler, np.arange(1, n_samples + 1), n_samples), dtype=np.float64)
         rs.sky_generator, rs.sky_i = 2, keep.ctypes.data
-    return rs, keep, x, v
+    return rs, (None if keep is None and rows is None else (keep, rows)), x, v
 
 
 _PLUNGING_TABLES = {}
@@ -610,9 +661,11 @@ def device_radial_profile(m, d, model, spectrum=None, *, λmax=10_000.0, sampler
 
     rpf = PointFunction(None, device_pf=GR_PF_REDSHIFT, extra={"r_isco": m.isco(), "plunge": plunging})
     pf, keep_pf = abi_pointfunction(rpf)
-    pf.has_u_src = 1
-    for q in range(4):
-        pf.u_src[q] = v_src[q]
+    if np.ndim(v_src) == 1:
+        pf.has_u_src = 1
+        for q in range(4):
+            pf.u_src[q] = v_src[q]
+    # (a source of many positions: the rows of the ray set carry each sample's source velocity, pf.has_u_src stays 0)
     cfg = config.abi_config()
     L = _lib.load()
     lim = np.zeros(2)

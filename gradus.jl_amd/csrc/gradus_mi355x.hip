@@ -118,6 +118,7 @@ struct gr_ctx {
     size_t sky_bytes = 0;
     int64_t sky_first = 0, sky_total = 0;  // the share of a sky source the launch being prepared traces (rays_params -> sky_prepare)
     bool sky_any_order = false;            // ... whose rows may come in any order (gr_corona_trace): the rays are dealt by direction
+    const double* sky_rows = nullptr;      // ... and its per-sample rows (gr_rayset.sky_rows, device) or null
     double* d_corona = nullptr;            // gr_corona_trace: (g, ρ, t, status) per ray, kept for gr_corona_bin
     size_t corona_bytes = 0;
     int64_t corona_n = -1, corona_hits = 0;
@@ -474,12 +475,13 @@ struct SkyParams {
     double x_obs[4], Mx[16];
     int64_t n;
     int64_t first, total;      // this launch's rays are samples first + 1 .. first + n of `total` (gr_rayset.sky_first / sky_total)
+    const double* rows;        // gr_rayset.sky_rows (device) or null: per-sample position, matrix and lowered source velocity
     int32_t sampler, both, generator, reserved;
     double resolution;
     const double* sky_i;
 };
 // sample jl of the launch -> its direction on the source's sky (samplers.jl:30-44) and the four-velocity v = Mx (1, k̂)
-__device__ __forceinline__ void sky_sample(const SkyParams& p, int64_t jl, double& el, double& az, double v[4])
+__device__ __forceinline__ void sky_sample(const SkyParams& p, int64_t jl, double& el, double& az, double v[4], double x[4], double& f)
 {
     const double n = (double)p.total;
     const double idx = (double)(p.first + jl + 1);
@@ -497,20 +499,56 @@ __device__ __forceinline__ void sky_sample(const SkyParams& p, int64_t jl, doubl
     if (az < 0.0) az += 6.28318530717958647692;
     const double se = ::sin(el), ce = ::cos(el), sa = ::sin(az), ca = ::cos(az);
     const double pb[4] = { 1.0, -(se * ca), -(se * sa), -ce };
+    f = 1.0;
+    if (p.rows) {
+        // a sample with a position of its own: its matrix, and the factor that turns the ratio against the static observer
+        // (g_tμ v^μ) into the ratio against the source's own velocity (u_μ v^μ)
+        const double* row = p.rows + GR_SKY_ROW * jl;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = p.Mx[q * 4 + 0] * pb[0] + p.Mx[q * 4 + 1] * pb[1] + p.Mx[q * 4 + 2] * pb[2] + p.Mx[q * 4 + 3] * pb[3];
+        for (int q = 0; q < 4; ++q) {
+            x[q] = row[q];
+            v[q] = row[4 + q * 4 + 0] * pb[0] + row[4 + q * 4 + 1] * pb[1] + row[4 + q * 4 + 2] * pb[2] + row[4 + q * 4 + 3] * pb[3];
+        }
+        double eu = 0.0, et = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { eu += row[20 + q] * v[q]; et += row[24 + q] * v[q]; }
+        f = eu / et;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        x[q] = p.x_obs[q];
+        v[q] = p.Mx[q * 4 + 0] * pb[0] + p.Mx[q * 4 + 1] * pb[1] + p.Mx[q * 4 + 2] * pb[2] + p.Mx[q * 4 + 3] * pb[3];
+    }
 }
-__global__ void __launch_bounds__(256) k_sky_velocities(const SkyParams p, double* out)      // out: x_obs[4], then v[n][4]
+// out: x_obs[4], v[n][4] -- and for a source of many positions (SkyParams.rows) x[n][4] and f[n] behind them
+__device__ __forceinline__ void sky_store(const SkyParams& p, double* out, int64_t slot, const double v[4], const double x[4], double f)
+{
+    double* o = out + 4 + 4 * slot;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = v[q];
+    if (p.rows) {
+        double* ox = out + 4 + 4 * p.n + 4 * slot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ox[q] = x[q];
+        out[4 + 8 * p.n + slot] = f;
+    }
+}
+__global__ void __launch_bounds__(256) k_sky_velocities(const SkyParams p, double* out)
 {
     const int64_t jl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (jl == 0)
         for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
     if (jl >= p.n) return;
-    double el, az, v[4];
-    sky_sample(p, jl, el, az, v);
-    double* o = out + 4 + 4 * jl;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = v[q];
+    double el, az, v[4], x[4], f;
+    sky_sample(p, jl, el, az, v, x, f);
+    sky_store(p, out, jl, v, x, f);
+}
+// rows (g, ρ, t, status) of a source of many positions: g against the sample's own source velocity
+__global__ void __launch_bounds__(256) k_sky_scale_g(double* rows, const double* f, int64_t n)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) rows[4 * j] *= f[j];
 }
 // The same rays DEALT BY DIRECTION (gr_corona_trace: the order of its rows is free -- min / max and integer bins do not know it).
 // How long a ray takes depends on where it goes: of 64 CONSECUTIVE samples of a golden spiral -- one polar angle, azimuths all
@@ -528,7 +566,7 @@ __global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
     __syncthreads();
-    double v[kSkyChunk / 1024][4];
+    double v[kSkyChunk / 1024][4], x[kSkyChunk / 1024][4], f[kSkyChunk / 1024];
     int bucket[kSkyChunk / 1024], pos[kSkyChunk / 1024];
 #pragma unroll
     for (int k = 0; k < kSkyChunk / 1024; ++k) {
@@ -536,7 +574,7 @@ __global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p
         bucket[k] = -1;
         if (j < nloc) {
             double el, az;
-            sky_sample(p, base + j, el, az, v[k]);
+            sky_sample(p, base + j, el, az, v[k], x[k], f[k]);
             int a32 = (int)(az * (32.0 / 6.28318530717958647692));
             a32 = a32 > 31 ? 31 : (a32 < 0 ? 0 : a32);
             bucket[k] = (el > 1.57079632679489661923 ? 32 : 0) + a32;
@@ -554,9 +592,7 @@ __global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p
         if (bucket[k] < 0) continue;
         // (chunks in REVERSE order: the last samples of a sky leave upwards, away from the disc, and are the long rays -- out to
         // the chart's edge; traced first, they do not make the tail of the launch)
-        double* o = out + 4 + 4 * ((p.n - base - nloc) + start[bucket[k]] + pos[k]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = v[k][q];
+        sky_store(p, out, (p.n - base - nloc) + start[bucket[k]] + pos[k], v[k], x[k], f[k]);
     }
 }
 }  // namespace
@@ -567,7 +603,7 @@ static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t strea
 {
     int32_t rc;
     if ((rc = tables_acquire(ctx, stream)) != GR_OK) return rc;
-    if ((rc = ensure((void**)&ctx->d_sky, &ctx->sky_bytes, sizeof(double) * (4 + 4 * (size_t)p.n))) != GR_OK) return rc;
+    if ((rc = ensure((void**)&ctx->d_sky, &ctx->sky_bytes, sizeof(double) * (4 + (ctx->sky_rows ? 9 : 4) * (size_t)p.n))) != GR_OK) return rc;
     SkyParams sp;
     std::memcpy(sp.x_obs, cold.plane.x_obs, sizeof sp.x_obs);
     std::memcpy(sp.Mx, cold.plane.Mx, sizeof sp.Mx);
@@ -577,14 +613,15 @@ static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t strea
     sp.sampler = cold.sky_sampler; sp.both = cold.sky_both; sp.generator = cold.sky_generator; sp.reserved = 0;
     sp.resolution = cold.sky_resolution;
     sp.sky_i = cold.sky_i;
+    sp.rows = ctx->sky_rows;
     if (ctx->sky_any_order && p.n >= 4 * kSkyChunk)
         hipLaunchKernelGGL(k_sky_velocities_dealt, dim3((unsigned)((p.n + kSkyChunk - 1) / kSkyChunk)), dim3(1024), 0, stream, sp, ctx->d_sky);
     else
         hipLaunchKernelGGL(k_sky_velocities, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, sp, ctx->d_sky);
     GR_HIP(hipGetLastError());
     cold.src_mode = 1;
-    cold.x = ctx->d_sky;
-    cold.x_stride = 0;
+    cold.x = ctx->sky_rows ? ctx->d_sky + 4 + 4 * p.n : ctx->d_sky;
+    cold.x_stride = ctx->sky_rows ? 4 : 0;
     cold.v = ctx->d_sky + 4;
     cold.sky_i = nullptr;
     return GR_OK;
@@ -1284,6 +1321,7 @@ static int32_t rays_params(gr_ctx* ctx, Params& p, Cold& cd, const gr_config* cf
             return fail(GR_ERR_INVALID_ARGUMENT, "sky source: the share sky_first .. sky_first + n runs past sky_total");
         ctx->sky_first = rays->sky_total > 0 ? rays->sky_first : 0;
         ctx->sky_total = rays->sky_total > 0 ? rays->sky_total : rays->n;
+        ctx->sky_rows = rays->sky_rows;
         std::memset(&p, 0, sizeof p);
         std::memset(&cd, 0, sizeof cd);
         p.cfg = *cfg;
@@ -1409,7 +1447,16 @@ int32_t gr_ray_summary_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     cd.lp_rmax = INFINITY;
     cd.lp_pairs = d_out;
     p.stats = (unsigned long long*)d_stats;
-    return launch_trace(ctx, p, cd, stream);
+    const bool per_sample = rays->sky_sampler && rays->sky_rows;
+    if (per_sample && pf->has_u_src)
+        return fail(GR_ERR_INVALID_ARGUMENT, "a sky source with sky_rows brings a source velocity per ray: pf->has_u_src must be 0");
+    if ((rc = launch_trace(ctx, p, cd, stream)) != GR_OK) return rc;
+    if (per_sample && rays->n > 0) {
+        // g of every row against ITS sample's source velocity (the factors were formed with the rays, sky_prepare)
+        hipLaunchKernelGGL(k_sky_scale_g, dim3((unsigned)((rays->n + 255) / 256)), dim3(256), 0, stream, d_out, ctx->d_sky + 4 + 8 * rays->n, rays->n);
+        GR_HIP(hipGetLastError());
+    }
+    return GR_OK;
 }
 
 int32_t gr_ray_tangent_device(gr_ctx* ctx, const gr_config* cfg, const gr_rayset* rays, const gr_pointfunction* pf,
@@ -1992,14 +2039,18 @@ static int32_t stage_rays(gr_ctx* ctx, const gr_rayset* rays, gr_rayset& dev, si
         // a source's sky: only a caller's generator has per-ray input (8 B per ray)
         const size_t n = (rays->sky_generator == 2) ? (size_t)rays->n : 0;
         if (n && !rays->sky_i) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: generator 2 needs sky_i");
+        // ... and a source of many positions its rows (GR_SKY_ROW doubles per ray)
+        const size_t nr = rays->sky_rows ? (size_t)rays->n * GR_SKY_ROW : 0;
         int32_t rcs;
-        if ((rcs = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * n + extra_bytes + 64)) != GR_OK) return rcs;
+        if ((rcs = ensure(&ctx->d_in, &ctx->in_bytes, sizeof(double) * (n + nr) + extra_bytes + 64)) != GR_OK) return rcs;
         double* b = (double*)ctx->d_in;
         dev = *rays;
         dev.alpha = dev.beta = dev.area = dev.height = nullptr;
         dev.sky_i = n ? b : nullptr;
+        dev.sky_rows = nr ? b + n : nullptr;
         if (n) GR_HIP(hipMemcpyAsync(b, rays->sky_i, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-        if (extra) *extra = (void*)(b + n);
+        if (nr) GR_HIP(hipMemcpyAsync(b + n, rays->sky_rows, sizeof(double) * nr, hipMemcpyHostToDevice, ctx->stream));
+        if (extra) *extra = (void*)(b + n + nr);
         return GR_OK;
     }
     if (rays->sep_r) {
@@ -2514,6 +2565,7 @@ int32_t rayset_share(const gr_rayset* rays, int32_t n, int k, gr_rayset& out, in
             if (rays->n > 0 && !rays->sky_i) return fail(GR_ERR_INVALID_ARGUMENT, "sky source: generator 2 needs sky_i");
             out.sky_i = rays->sky_i ? rays->sky_i + off : nullptr;
         }
+        if (rays->sky_rows) out.sky_rows = rays->sky_rows + GR_SKY_ROW * off;
     } else if (rays->sep_r) {
         out.sep_first = rays->sep_first + off;
     } else if (rays->n > 0) {

@@ -383,6 +383,14 @@ int32_t gr_metric_table_fit(const gr_metric_grid* grid, const double* samples, d
                         A[i] = acc;
                     }
                     for (int a = 0; a < N; ++a) fmax = std::fmax(fmax, std::fabs(Km[c][a]) + std::fabs(Kd[c][a]));
+                    // (axis terms that are rounding residue of a component that does vanish there -- 1e-17 for Kerr -- are measured
+                    // against the component, not against themselves)
+                    {
+                        double gm = 0.0;
+                        for (int a = 0; a < N; ++a)
+                            for (int64_t b = 0; b < nth_nodes; b += 7) gm = std::fmax(gm, std::fabs(samples[(((int64_t)ir * N + a) * nth_nodes + b) * kComps + 3 + c]));
+                        fmax = std::fmax(fmax, 1e-9 * gm);
+                    }
                     for (int i = p + 1; i < N; ++i) { drop += std::fabs(A[i]); drop1 += std::fabs(A[i]) * i * i; }
                     if (fmax > 0.0) {
                         e_val = std::fmax(e_val, drop / fmax);

@@ -463,7 +463,18 @@ typedef struct gr_rayset {
      * all, i.e. the `n` of the formulas above is sky_total and ray j has sample number sky_first + j + 1 (sky_i still has one
      * entry per ray of THIS set).  sky_total = 0: the whole source (first 0, total n). */
     int64_t sky_first, sky_total;
+    /* ABI 8 -- a source WITHOUT one position (the reference's DiscCorona, src/corona/models/extended.jl:165-181: every sample leaves
+     * from a point of its own, sample_position_velocity per ray, corona-models.jl:1-33): GR_SKY_ROW doubles per ray,
+     *     x[4]       the sample's position
+     *     Mx[16]     its matrix T diag(1, J), row-major as above (x_obs and Mx of the set are then not read)
+     *     u_cov[4]   g_μν(x) u_src^ν, the source's four-velocity there with its index lowered
+     *     gt[4]      g_tμ(x)
+     * and the rows of gr_ray_summary / gr_corona_trace hold g = energy_ratio against THAT sample's source velocity (pf->has_u_src
+     * must be 0: the library forms (u_cov · v) / (gt · v) per ray and scales the static-observer ratio with it).  Host or device
+     * pointer like alpha; NULL: one position. */
+    const double* sky_rows;
 } gr_rayset;
+#define GR_SKY_ROW 28
 
 typedef struct gr_binning {
     double r_min, r_max;      /* minrₑ, maxrₑ: only hits with r_min <= ρ <= r_max count    */

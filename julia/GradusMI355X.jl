@@ -203,6 +203,7 @@ struct GrRayset                      # == gr_rayset
     sky_i::Ptr{Float64}
     sky_first::Int64                 # ABI 8: a share of a source's samples (0, 0 = the whole source)
     sky_total::Int64
+    sky_rows::Ptr{Float64}           # ABI 8: a source without one position: 28 doubles per ray (x, Mx, lowered source velocity, g_tμ)
 end
 
 struct GrBinning                     # == gr_binning
@@ -843,7 +844,7 @@ function Gradus.ensemble_solve_tracing_problem(
         Mx = inv(g) * hcat(Gradus.lnrbasis(g)...)
         rays = Ref(GrRayset(Tuple(SVector{4,Float64}(config.position)), Tuple(permutedims(Mx)), pointer(αv), pointer(βv),
             Ptr{Float64}(C_NULL), N, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0,
-            Int32(0), Int32(0), 0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL), 0, 0))
+            Int32(0), Int32(0), 0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL), 0, 0, Ptr{Float64}(C_NULL)))
         if nctx > 1
             _check(GC.@preserve keep αv βv out ccall((:gr_rayset_endpoints_multi, LIB), Int32,
                 (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ptr{Cvoid}, Ptr{GrStats}),
@@ -994,7 +995,7 @@ function lineprofile_mi355x(ensemble::EnsembleMI355X, bins::AbstractVector{Float
     cs, sn = cos.(θs), sin.(θs)
     rays = Ref(GrRayset(Tuple(u), Tuple(permutedims(Mx)), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
         plane.Nr * plane.Nθ, Ptr{Float64}(C_NULL), pointer(rs), pointer(cs), pointer(sn), plane.Nr, plane.Nθ, Int32(1), Int32(0),
-        0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL), 0, 0))
+        0, 0, 0, Int32(0), Int32(0), Int32(0), Int32(0), 0.0, Ptr{Float64}(C_NULL), 0, 0, Ptr{Float64}(C_NULL)))
     bpf = _builtin_pf(redshift_pf, m)
     isnothing(bpf) && error("lineprofile_mi355x: `redshift_pf` is not a redshift point function the kernels evaluate")
     gpf, keep_pf = bpf
@@ -1045,25 +1046,53 @@ function emissivity_profile_mi355x(ensemble::EnsembleMI355X, m::Gradus.AbstractS
         sampler = Gradus.EvenSampler(Gradus.BothHemispheres(), Gradus.GoldenSpiralGenerator()), λmax = 10_000.0,
         grid = Gradus.GeometricGrid(), N = 100, gtol = 1e-2, abstol = 1e-9, reltol = 1e-9, chart = Gradus.chart_for_metric(m),
         upper_hemisphere = true)
-    x, v_src = Gradus.sample_position_velocity(m, model)            # one position: LampPostModel, BeamedPointSource, a RingCorona's point
-    x[2] < Gradus.inner_radius(m) * 1.9 && error("source position lies inside 1.9 inner radii")
-    x = SVector{4,Float64}(x[1], x[2], clamp(x[3], 1e-3, π - 1e-3), x[4])                  # corona-models.jl:18-24
-    J = Gradus._cart_to_spher_jacobian(x[3], x[4])
-    B = zeros(Float64, 4, 4)
-    B[1, 1] = 1.0
-    B[2:4, 2:4] .= J
-    Mx = Matrix{Float64}(Gradus.tetradframe_matrix(m, x, v_src)) * B                        # v = T (1, J k̂), samplers.jl:81-99
+    rmin = Gradus.inner_radius(m) * 1.9
+    function matrix_at(x, v)                                                               # v = T (1, J k̂), samplers.jl:81-99
+        B = zeros(Float64, 4, 4)
+        B[1, 1] = 1.0
+        B[2:4, 2:4] .= Gradus._cart_to_spher_jacobian(x[3], x[4])
+        Matrix{Float64}(Gradus.tetradframe_matrix(m, x, v)) * B
+    end
+    one_position = model isa Union{Gradus.LampPostModel,Gradus.BeamedPointSource,Gradus.RingCorona}
+    sky_rows = Float64[]
+    if one_position
+        x, v_src = Gradus.sample_position_velocity(m, model)
+        x[2] < rmin && error("source position lies inside 1.9 inner radii")
+        x = SVector{4,Float64}(x[1], x[2], clamp(x[3], 1e-3, π - 1e-3), x[4])              # corona-models.jl:18-24
+        Mx = matrix_at(x, v_src)
+    else
+        # a source without one position (DiscCorona, extended.jl:165-183; any model whose sample_position_velocity draws): 28 doubles
+        # per sample -- position, matrix, the source velocity with its index lowered, g_tμ -- in the order corona-models.jl:1-33 draws
+        sky_rows = Vector{Float64}(undef, 28 * n_samples)
+        x = SVector{4,Float64}(0.0, 0.0, 0.0, 0.0)
+        for k = 1:n_samples
+            xk, vk = Gradus.sample_position_velocity(m, model)
+            while xk[2] < rmin
+                xk, vk = Gradus.sample_position_velocity(m, model)
+            end
+            xk = SVector{4,Float64}(xk[1], xk[2], clamp(xk[3], 1e-3, π - 1e-3), xk[4])
+            g = Gradus.metric_components(m, SVector(xk[2], xk[3]))
+            o = 28 * (k - 1)
+            sky_rows[o+1:o+4] .= xk
+            sky_rows[o+5:o+20] .= vec(permutedims(matrix_at(xk, vk)))                      # row-major
+            sky_rows[o+21:o+24] .= (g[1] * vk[1] + g[5] * vk[4], g[2] * vk[2], g[3] * vk[3], g[4] * vk[4] + g[5] * vk[1])
+            sky_rows[o+25:o+28] .= (g[1], 0.0, 0.0, g[5])
+            xk[2] > x[2] && (x = xk)
+        end
+        v_src = SVector{4,Float64}(1.0, 0.0, 0.0, 0.0)                                     # (not read: has_u_src = 0 below)
+        Mx = Float64[i == j ? 1.0 : 0.0 for i = 1:4, j = 1:4]                               # (not read either: every row brings its own)
+    end
     sid, res = _sky_sampler(sampler)
     gid, sky_i = _sky_generator(sampler, n_samples)
     rays = Ref(GrRayset(Tuple(x), Tuple(permutedims(Mx)), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
         n_samples, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), 0, 0, Int32(0), Int32(0),
-        0, 0, 0, sid, _sky_domain(sampler), gid, Int32(0), res, isempty(sky_i) ? Ptr{Float64}(C_NULL) : pointer(sky_i), 0, 0))
+        0, 0, 0, sid, _sky_domain(sampler), gid, Int32(0), res, isempty(sky_i) ? Ptr{Float64}(C_NULL) : pointer(sky_i), 0, 0, isempty(sky_rows) ? Ptr{Float64}(C_NULL) : pointer(sky_rows)))
     # the disc velocity of _keplerian_velocity_projector (circular-orbits.jl:155-170): Keplerian outside the ISCO, the traced
     # plunging table inside (three NaNLinearInterpolators over the same radii, orbit-solving.jl:99-131)
     pintrp = _expect_fields(Gradus.interpolate_plunging_velocities(m), :m, :t, :r, :ϕ)
     ptab = (collect(Float64, pintrp.t.t), collect(Float64, pintrp.t.u), collect(Float64, pintrp.r.u), collect(Float64, pintrp.ϕ.u))
     pfs = Ref(GrPointFunction(Int32(1), Int32(0), NaN, Float64(Gradus.isco(m)), length(ptab[1]), pointer(ptab[1]), pointer(ptab[2]),
-        pointer(ptab[3]), pointer(ptab[4]), Int32(1), Int32(0), Tuple(SVector{4,Float64}(v_src))))
+        pointer(ptab[3]), pointer(ptab[4]), Int32(one_position ? 1 : 0), Int32(0), Tuple(SVector{4,Float64}(v_src))))
     id, params = _metric(m)
     did, rin, rout, dparams = _disc(d)
     r_in, r_out, tab, θ0, θ1 = _chart(chart)
@@ -1082,11 +1111,11 @@ function emissivity_profile_mi355x(ensemble::EnsembleMI355X, m::Gradus.AbstractS
     nctx = length(ctxs)
     if nctx > 1      # the samples shard like any ray set (ABI 8): every context traces and bins its share, the integer sums add up exactly
         cstats = Vector{GrStats}(undef, nctx)
-        _check(GC.@preserve tab dtab mtab ptab sky_i ccall((:gr_corona_trace_multi, LIB), Int32,
+        _check(GC.@preserve tab dtab mtab ptab sky_i sky_rows ccall((:gr_corona_trace_multi, LIB), Int32,
             (Ptr{Ptr{Cvoid}}, Int32, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ptr{Float64}, Ref{Int64}, Ptr{GrStats}),
             ctxs, nctx, cfg, rays, pfs, lim, hits, cstats))
     else
-        _check(GC.@preserve tab dtab mtab ptab sky_i ccall((:gr_corona_trace, LIB), Int32,
+        _check(GC.@preserve tab dtab mtab ptab sky_i sky_rows ccall((:gr_corona_trace, LIB), Int32,
             (Ptr{Cvoid}, Ref{GrConfig}, Ref{GrRayset}, Ref{GrPointFunction}, Ptr{Float64}, Ref{Int64}, Ref{GrStats}),
             ctxs[1], cfg, rays, pfs, lim, hits, stats))
     end

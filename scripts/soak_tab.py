@@ -28,16 +28,20 @@ rng = np.random.default_rng(seed)
 U = lambda a, b: float(rng.uniform(a, b))          # (reads the scene's generator: `rng` is rebound per scene, so that a replay of one scene is that scene)
 ens = G.EnsembleMI355X(0)
 
-fam = [          # the smooth families (a table refuses metrics with kinks or poles inside its range: TabulatedMetric(strict=True))
+fam = [          # the catalogue's families -- since ABI 8 including the two that are piecewise in r (their break radii are named by the types)
     ("kerr", lambda: G.KerrMetric(1.0, U(-0.998, 0.998))),
     ("kerr", lambda: G.KerrMetric(1.0, U(0.9, 0.998))),
     ("johannsen", lambda: G.JohannsenMetric(1.0, U(0, 0.9), U(-1, 2), U(-1, 1), U(-1, 1), U(-1, 2))),
     ("kerr-newman", lambda: (lambda a: G.KerrNewmanMetric(1.0, a, U(0, math.sqrt(1 - a * a) * 0.95)))(U(0, 0.9))),
     ("johannsen-psaltis", lambda: G.JohannsenPsaltisMetric(1.0, U(0, 0.8), U(-0.5, 1))),
     ("bumblebee", lambda: G.BumblebeeMetric(1.0, U(0, 0.29), U(-0.5, 1))),
-    # g_ϕϕ does not vanish on the axis for β != 0: the table stores it as it is (pole_factor chosen by the fit); its inner_radius
-    # formula lies inside the outermost horizon: the table starts at the sign change of g_rr
+    # g_ϕϕ, g_tϕ do not vanish on the axis for β != 0: the table stores their limits on the two poles apart (pole_factor 2, chosen by
+    # the fit); its inner_radius formula lies inside the outermost horizon: the table starts at the sign change of g_rr
     ("dilaton-axion", lambda: G.DilatonAxion(1.0, U(0.1, 0.8), U(-0.3, 0.3), U(0.3, 1.5))),
+    # piecewise in r: a mass shell (kinks at rₛ and rₛ + Δr), a refractive corona (jumps at corona_radius ± 1.25, an arctangent step of
+    # width 2.5e-4 at corona_radius) -- segments of the table start at the breaks
+    ("kerr-dark-matter", lambda: G.KerrDarkMatter(1.0, U(0, 0.9), U(0, 3), U(5, 30), U(5, 20))),
+    ("kerr-refractive", lambda: G.KerrRefractive(1.0, U(0, 0.9), U(0.9, 1.3), U(10, 30))),
 ]
 if os.environ.get("SOAK_FAMILIES"):          # e.g. SOAK_FAMILIES=dilaton-axion
     fam = [f for f in fam if f[0] in os.environ["SOAK_FAMILIES"].split(",")]

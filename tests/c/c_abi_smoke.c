@@ -17,7 +17,7 @@ _Static_assert(sizeof(gr_range) == 32, "gr_range");
 _Static_assert(sizeof(gr_plane) == 8 * (4 + 16 + 4) + 16 + 8, "gr_plane");
 _Static_assert(sizeof(gr_stats) == 96, "gr_stats");
 _Static_assert(sizeof(gr_pointfunction) == 8 + 16 + 8 + 32 + 8 + 32, "gr_pointfunction (ABI 7: has_u_src, u_src)");
-_Static_assert(sizeof(gr_rayset) == 8 * (4 + 16) + 8 * 4 + 8 + 8 * 5 + 8 + 24 + 16 + 8 + 8 + 16, "gr_rayset (ABI 7: sky_*; ABI 8: sky_first, sky_total)");
+_Static_assert(sizeof(gr_rayset) == 8 * (4 + 16) + 8 * 4 + 8 + 8 * 5 + 8 + 24 + 16 + 8 + 8 + 16 + 8, "gr_rayset (ABI 7: sky_*; ABI 8: sky_first, sky_total, sky_rows)");
 _Static_assert(sizeof(gr_metric_segment) == 6 * 8 + 6 * 4, "gr_metric_segment (ABI 8)");
 _Static_assert(sizeof(gr_metric_break) == 16, "gr_metric_break (ABI 8)");
 _Static_assert(sizeof(gr_metric_grid) == 24 + 8 * 4 + 24 + 8 + GR_METRIC_MAX_SEG * sizeof(gr_metric_segment), "gr_metric_grid (ABI 8: n_seg, n_rows, seg[])");

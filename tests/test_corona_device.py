@@ -63,13 +63,31 @@ def test_sky_rayset_matrix_reproduces_sky_angles_to_velocity(G):
         assert (rs.sky_sampler, rs.sky_both, rs.sky_generator, rs.n) == (1, 1, 0, 64) and keep is None
 
 
-def test_sky_rayset_needs_a_source_at_one_position(G):
-    class Cloud(G.corona.AbstractCoronaModel):
-        def sample_position_velocity(self, m):
-            return np.array([0.0, 10.0, 0.3, 0.0]), np.array([1.0, 0.0, 0.0, 0.0])
-
-    with pytest.raises(NotImplementedError):
-        G.corona.sky_rayset(G.KerrMetric(1.0, 0.5), Cloud(), G.EvenSampler(), 8)
+def test_sky_rayset_of_a_source_without_one_position_brings_rows(G):
+    """DiscCorona (extended.jl:165-183): every sample leaves from its own point of the disc -- 28 doubles per sample cross the
+    boundary (gr_rayset.sky_rows): position, the matrix T diag(1, J) there, the source's velocity with its index lowered, g_tμ."""
+    K = G.corona
+    m = G.KerrMetric(1.0, 0.5)
+    model, twin = G.DiscCorona(G.SourceVelocities.co_rotating, 8.0, 5.0, seed=3), G.DiscCorona(G.SourceVelocities.co_rotating, 8.0, 5.0, seed=3)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    rs, keep, x, v = K.sky_rayset(m, model, s, 32)
+    rows = keep[1]
+    assert rs.sky_rows == rows.ctypes.data and rows.shape == (32, 28) and v.shape == (32, 4)
+    xs, vs, vsrc = K.sample_position_direction_velocity(m, twin, s, 32)          # the same draws, the host's way
+    np.testing.assert_array_equal(rows[:, 0:4], xs)
+    np.testing.assert_array_equal(v, vsrc)
+    assert np.ptp(xs[:, 1]) > 1.0                                                   # the samples do sit at different places
+    i = K.geti(s, np.arange(1, 33), 32)
+    θ, ϕ = K.sample_angles(s, i, 32)
+    khat = -np.stack([np.sin(θ) * np.cos(ϕ), np.sin(θ) * np.sin(ϕ), np.cos(θ)], axis=-1)
+    got = np.einsum("kij,kj->ki", rows[:, 4:20].reshape(32, 4, 4), np.concatenate([np.ones((32, 1)), khat], axis=1))
+    np.testing.assert_allclose(got, vs, rtol=0, atol=1e-13)
+    # the lowered source velocity and g_tμ: (u · v) / (g_tμ v^μ) is what turns the static observer's ratio into the source's
+    g = [m.metric_components(r, th) for r, th in xs[:, 1:3]]
+    for k in range(32):
+        e_src = K._dot(g[k], vs[k], vsrc[k])
+        assert rows[k, 20:24] @ vs[k] == pytest.approx(e_src, rel=1e-13)
+        assert rows[k, 24:28] @ vs[k] == pytest.approx(g[k][0] * vs[k, 0] + g[k][4] * vs[k, 3], rel=1e-13)
     with pytest.raises(ValueError):
         G.corona.sky_rayset(G.KerrMetric(1.0, 0.0), G.LampPostModel(h=2.5), G.EvenSampler(), 8)
 
@@ -169,6 +187,37 @@ def test_device_radial_profile_equals_the_record_route(G, ens, monkeypatch):
             np.testing.assert_array_equal(np.isfinite(dev.t[inner]), okt, err_msg=name)
             np.testing.assert_allclose(dev.t[inner][okt], host.t[inner][okt], rtol=1e-9, err_msg=name)
             assert np.isfinite(dev.ε[-2:]).any() and np.isfinite(host.ε[-2:]).any()
+
+
+@pytest.mark.gpu
+def test_disc_corona_on_the_device_equals_the_record_route(G, ens, monkeypatch):
+    """A source without one position (DiscCorona) through gr_corona_trace / gr_corona_bin -- 28 doubles per sample in, the per-sample
+    energy ratio formed on the device -- against tracecorona + build_radial_profile on records of the SAME draws (two generators
+    with one seed), and the end-point records of the sky rays against the host sampler's rays."""
+    K = G.corona
+    ens.set("kernel", 2).set("precision", 64)
+    m, d = G.KerrMetric(1.0, 0.9), G.ThinDisc(0.0, 200.0)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    mk = lambda: G.DiscCorona(G.SourceVelocities.co_rotating, 6.0, 4.0, seed=17)
+    n = 4000
+    # the rays themselves: device-formed against host-formed
+    got = K.tracegeodesics(m, mk(), d, (0.0, 3000.0), n_samples=n, sampler=s, ensemble=ens)
+    xs, vs, _ = K.sample_position_direction_velocity(m, mk(), s, n)
+    ref = G.tracegeodesics(m, xs, vs, d, (0.0, 3000.0), ensemble=ens)
+    np.testing.assert_array_equal(got["x_init"], ref["x_init"])
+    np.testing.assert_allclose(got["v_init"], ref["v_init"], rtol=1e-13, atol=1e-13)
+    assert (got["status"] == ref["status"]).sum() >= n - 2
+    # the profile
+    dev = K.emissivity_profile(m, d, mk(), n_samples=n, sampler=s, N=40, ensemble=ens)
+    monkeypatch.setenv("GRADUS_MI355X_DEVICE_CORONA", "0")
+    rec = K.emissivity_profile(m, d, mk(), n_samples=n, sampler=s, N=40, ensemble=ens)
+    monkeypatch.delenv("GRADUS_MI355X_DEVICE_CORONA")
+    np.testing.assert_allclose(dev.radii, rec.radii, rtol=1e-12)
+    ok = np.isfinite(rec.ε)
+    np.testing.assert_array_equal(np.isfinite(dev.ε), ok)
+    assert ok.sum() > 25
+    np.testing.assert_allclose(dev.ε[ok], rec.ε[ok], rtol=1e-9)
+    np.testing.assert_allclose(dev.t[ok], rec.t[ok], rtol=1e-10)
 
 
 @pytest.mark.gpu

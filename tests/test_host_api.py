@@ -33,7 +33,7 @@ def test_struct_layouts(G):
     assert C.sizeof(L.gr_range) == 32
     assert C.sizeof(L.gr_stats) == 96            # ABI 6: + enqueue_ms
     assert C.sizeof(L.gr_pointfunction) == 8 + 16 + 8 + 32 + 8 + 32          # + has_u_src, u_src (ABI 7)
-    assert C.sizeof(L.gr_rayset) == 8 * (4 + 16) + 8 * 4 + 8 + 8 * 5 + 8 + 24 + 16 + 8 + 8 + 16          # + sky_* (ABI 7), sky_first / sky_total (ABI 8)
+    assert C.sizeof(L.gr_rayset) == 8 * (4 + 16) + 8 * 4 + 8 + 8 * 5 + 8 + 24 + 16 + 8 + 8 + 16 + 8          # + sky_* (ABI 7), sky_first / sky_total / sky_rows (ABI 8)
 
 
 def test_no_device_means_loud_failure(G):
