@@ -176,7 +176,7 @@ def baseline_configs(G, ens, reps=3):
         wall = (time.perf_counter() - t0) * 1e3
         if rep and (best is None or st.call_ms < best[1]):
             best = (st.kernel_ms, st.call_ms, wall, (st.accepted_steps + st.rejected_steps) / n_sky)
-    price("corona_1e6", "k_trace_persistent<gr::KerrFamily<false>, 1>", n_sky, best[0])
+    price("corona_1e6", "k_trace_lane<gr::KerrFamily<false>, 1>", n_sky, best[0])      # (sky rays dealt by direction: the one-ray-per-lane kernel)
     out["corona_1e6"].update({"device_call_ms": best[1], "python_wall_ms_incl_binning_and_host_tail": best[2], "steps_per_ray": best[3],
                               "finite_bins": int(np.isfinite(prof.ε).sum()),
                               "what": "emissivity_profile(KerrMetric(a = 0.998), ThinDisc(0, 500), LampPostModel(h = 10); n_samples = 10^6, N = 100): "

@@ -153,6 +153,7 @@ struct gr_ctx {
     int64_t lds_points = 1;                // one-ray-per-lane kernel: a wave's end-point records leave through LDS as whole runs
     int64_t direct_host = 1;               // gr_render_endpoints into a gr_host_alloc block: the kernel stores across the link itself
     int64_t tangent_pairs = 2;             // tangent kernels: 0 = one lane per ray, 1 = a pair of lanes per ray, 2 = by launch size
+    int64_t sky_deal = 1;                  // gr_corona_trace: the sky rays of a source dealt to the waves by direction (k_sky_velocities_dealt)
     int64_t xcd_spread = 1;                // one-ray-per-lane kernel, rays in caller order: chunks dealt over the XCDs by digit sum
     int64_t tangent_norm = 1;              // tangent kernels: the tangents are part of the error norm (DiffEqBase on Dual state); 0 = values only
     // LPT state for one (config, plane, range) key
@@ -614,7 +615,7 @@ static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t strea
     sp.resolution = cold.sky_resolution;
     sp.sky_i = cold.sky_i;
     sp.rows = ctx->sky_rows;
-    if (ctx->sky_any_order && p.n >= 4 * kSkyChunk)
+    if (ctx->sky_any_order && ctx->sky_deal && p.n >= 4 * kSkyChunk)
         hipLaunchKernelGGL(k_sky_velocities_dealt, dim3((unsigned)((p.n + kSkyChunk - 1) / kSkyChunk)), dim3(1024), 0, stream, sp, ctx->d_sky);
     else
         hipLaunchKernelGGL(k_sky_velocities, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, sp, ctx->d_sky);
@@ -671,7 +672,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     // same number of steps (lane utilisation 0.9 against 0.5 for consecutive samples), which the persistent kernel's refill would mix
     // again -- one ray per lane, four waves to a workgroup (10⁶ lamp-post samples: 7.2 ms against 8.4 persistent, 8.4 with one-wave
     // workgroups; profiles/r6_corona_deal_ab.log)
-    const bool dealt = sky && ctx->sky_any_order && p.n >= 4 * kSkyChunk && !tangent;
+    const bool dealt = sky && ctx->sky_any_order && ctx->sky_deal && p.n >= 4 * kSkyChunk && !tangent;
     const int kern_sel = tangent ? 0 : (dealt && ctx->kernel == 2) ? 0 : resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);
     const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : (dealt && ctx->kernel == 2 && !ctx->block) ? 256 : resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
@@ -1028,6 +1029,8 @@ int32_t gr_ctx_set(gr_ctx* c, const char* key, int64_t value)
         c->tangent_pairs = value;
     } else if (k == "xcd_spread") {
         c->xcd_spread = value ? 1 : 0;
+    } else if (k == "sky_deal") {
+        c->sky_deal = value ? 1 : 0;
     } else if (k == "lds_points") {
         c->lds_points = value ? 1 : 0;
     } else if (k == "direct_host") {
