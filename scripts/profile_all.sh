@@ -21,6 +21,7 @@ PROF_CMD="scripts/sibling_workloads.py applypf" PROF_KERNEL="k_apply_pf" bash sc
 PROF_CMD="scripts/sibling_workloads.py endpoints" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_endpoints
 PROF_CMD="scripts/sibling_workloads.py corona" PROF_KERNEL="k_trace" bash scripts/profile_pmc.sh ${T}_corona
 PROF_CMD="scripts/sibling_workloads.py tangent" PROF_KERNEL="k_trace_lane<grt::" bash scripts/profile_pmc.sh ${T}_tangent
+PROF_CMD="scripts/sibling_workloads.py tabtangent" PROF_KERNEL="k_trace_lane<grt::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabtangent
 PROF_CMD="scripts/sibling_workloads.py dual" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<3>" bash scripts/profile_pmc.sh ${T}_bumblebee
 PROF_CMD="scripts/sibling_workloads.py dual2" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<2>" bash scripts/profile_pmc.sh ${T}_morristhorne
 PROF_CMD="scripts/sibling_workloads.py dual6" PROF_KERNEL="k_trace_lane<gr::GenericMetricT<6>" bash scripts/profile_pmc.sh ${T}_dilatonaxion

@@ -46,7 +46,7 @@ if which in ("c4", "generic", "dual", "dual6", "dual2", "dual8", "dual9", "dual1
     if which in ("tabkerr", "tabc4"):
         # GR_METRIC_TABULATED: the bench metric / the C4 metric through a piecewise-polynomial table (TAB_GRID = "m_r,n_theta")
         base = G.KerrMetric(1.0, 0.998) if which == "tabkerr" else G.JohannsenMetric(1.0, 0.7, 2.0, 0.0, 0.0, 1.0)
-        m_r, n_theta = (int(t) for t in os.environ.get("TAB_GRID", "8,32").split(","))
+        m_r, n_theta = (int(t) for t in os.environ.get("TAB_GRID", "24,96").split(","))      # (the default grid of TabulatedMetric)
         m = G.TabulatedMetric(base, m_r=m_r, n_theta=n_theta, max_refinements=0)
         x = np.array([0.0, 1000.0, math.radians(75 if which == "tabkerr" else 70), 0.0])
         pf = G.ConstPointFunctions.redshift(m, x, ensemble=ens) @ G.ConstPointFunctions.filter_intersected()
@@ -156,7 +156,7 @@ elif which in ("applypf", "endpoints"):
     ms = [a.elapsed_time(b) for a, b in ev]
     rays = n
     extra = {"bytes_per_ray": 160 if which == "applypf" else 152}
-elif which == "tangent":
+elif which in ("tangent", "tabtangent"):
     import ctypes as C
 
     import torch
@@ -166,6 +166,8 @@ elif which == "tangent":
     from gradus_jl_amd.tracing import lnr_momentum_to_global_velocity_matrix
 
     m = G.KerrMetric(1.0, 0.998)
+    if which == "tabtangent":      # value + two tangents through the table of a user-defined metric (ABI 8)
+        m = G.TabulatedMetric(m)
     x = np.array([0.0, 1000.0, math.radians(75), 0.0])
     S = 1024
     n = S * S
