@@ -1790,6 +1790,15 @@ struct TabRealOps {
     static GR_DEV real mulk(real a, double k) { return a * k; }
     static GR_DEV real addk(real a, double k) { return a + k; }
     static GR_DEV void row_done(int, int, real&, real&, real&) {}
+#ifdef GR_REAL_IS_TAN2
+    static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static GR_DEV double fmak(double a, double b, double k) { return __builtin_fma(a, b, k); }
+    static GR_DEV double add(double a, double b) { return a + b; }
+    static GR_DEV double mulk(double a, double k) { return a * k; }
+    static GR_DEV double addk(double a, double k) { return a + k; }
+    static GR_DEV double lift(double k) { return k; }
+    static GR_DEV void row_done2(int, int, double&, double&, double&, double&, double&, double&) {}
+#endif
 };
 
 #ifndef GR_HOST_HARNESS
@@ -1920,6 +1929,25 @@ struct TabulatedMetric {
         static GR_DEV real add(real a, real b) { return a + b; }
         static GR_DEV real mulk(real a, double k) { return a * k; }
         static GR_DEV real addk(real a, double k) { return a + k; }
+#ifdef GR_REAL_IS_TAN2
+        // the tangent flavour evaluates the patch on PLAIN numbers with second derivatives (gr_tab::eval_patch2) and contracts
+        static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+        static GR_DEV double fmak(double a, double b, double k) { return __builtin_fma(a, b, k); }
+        static GR_DEV double add(double a, double b) { return a + b; }
+        static GR_DEV double mulk(double a, double k) { return a * k; }
+        static GR_DEV double addk(double a, double k) { return a + k; }
+        static GR_DEV double lift(double k) { return k; }
+        GR_DEV void row_done2(int comp, int row, double& p0, double& p1, double& p2, double& p3, double& p4, double& p5) const
+        {
+            const int before = (row == gr_tab::kDegree - 2) ? (comp == 0 ? 0 : consumed(comp - 1, 0)) : consumed(comp, row + 1);
+            const int from = pairs_by(before), to = pairs_by(consumed(comp, row));
+            if (to <= from) return;
+            AddrInt a = (AddrInt)(unsigned long long)sl;
+            asm volatile("" : "+v"(a), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5));      // (all six chains: see row_done)
+            sl = (PairPtr)(unsigned long long)a;
+            issue(from, to);
+        }
+#endif
         GR_DEV void row_done(int comp, int row, real& acc, real& acc_u, real& acc_v) const
         {
             // (rows kDegree and kDegree - 1 of a component are folded together before the first call for it)
@@ -1952,6 +1980,35 @@ struct TabulatedMetric {
     static GR_DEV void horner(const Ld& ld, const Ops_& ops, int form, const double* ax, real u, real v, double su, double sv, real s, real c,
                               real g[5], real gr[5], real gt[5])
     {
+#ifdef GR_REAL_IS_TAN2
+        // Value + two tangents: the patch on plain numbers with its second derivatives, then the chain rule.  With
+        // δu = su δr, δv = sv δθ (the tangents the lifted u, v carry):
+        //   δg = Pu δu + Pv δv,   δ(∂r g) = su (Puu δu + Puv δv),   δ(∂θ g) = sv (Puv δu + Pvv δv)
+        // -- 372 operations per evaluation where the recurrences on lifted numbers took ~1050 (73.6 ms and 1.3 KB of scratch per lane
+        // for 1024² rays).
+        double P[5], Pu[5], Pv[5], Puu[5], Puv[5], Pvv[5];
+        gr_tab::eval_patch2<double>(ld, ops, u.v, v.v, P, Pu, Pv, Puu, Puv, Pvv);
+        const double dua = u.a, dva = v.a;
+        const double s2ua = 2.0 * su * dua, suva = su * dva, svua = sv * dua, s2va = 2.0 * sv * dva;      // (eval_patch2 returns ½ Puu, ½ Pvv)
+#if GR_TAN_W == 2
+        const double dub = u.b, dvb = v.b;
+        const double s2ub = 2.0 * su * dub, suvb = su * dvb, svub = sv * dub, s2vb = 2.0 * sv * dvb;
+#endif
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            g[k] = real(P[k]);
+            g[k].a = __builtin_fma(Pu[k], dua, Pv[k] * dva);
+            gr[k] = real(Pu[k] * su);
+            gr[k].a = __builtin_fma(Puu[k], s2ua, Puv[k] * suva);
+            gt[k] = real(Pv[k] * sv);
+            gt[k].a = __builtin_fma(Puv[k], svua, Pvv[k] * s2va);
+#if GR_TAN_W == 2
+            g[k].b = __builtin_fma(Pu[k], dub, Pv[k] * dvb);
+            gr[k].b = __builtin_fma(Puu[k], s2ub, Puv[k] * suvb);
+            gt[k].b = __builtin_fma(Puv[k], svub, Pvv[k] * s2vb);
+#endif
+        }
+#else
         real P[5], Pu[5], Pv[5];
         gr_tab::eval_patch<real>(ld, ops, u, v, P, Pu, Pv);
 #pragma unroll
@@ -1960,6 +2017,7 @@ struct TabulatedMetric {
             gr[k] = Pu[k] * su;
             gt[k] = Pv[k] * sv;
         }
+#endif
         if (form != 0) {
             gr_tab::pole_factor_apply<real>(s * s, 2.0 * (s * c), g, gr, gt);
             if (form == 2) {

@@ -137,6 +137,80 @@ GR_TAB_HD __attribute__((always_inline)) inline void eval_patch(const C& coef, c
     }
 }
 
+// ... and the SECOND derivatives as well: P, ∂u P, ∂v P, ½ ∂uu P, ∂uv P, ½ ∂vv P of the five components (T: a plain number).  What the
+// tangent flavour of the kernels needs: the tangents of g and of ∂g with respect to (r, θ) are contractions of these with the
+// tangents of (u, v) -- 58 operations per component at degree 5 and 14 more to contract, where the same recurrences run on
+// numbers that carry two tangents (gr_tangent.hpp) take 42 x 5.  Coefficients are consumed in the order of eval_patch; a
+// coefficient that starts a row is read twice inside its row (as c0 v and as the seed of a derivative).
+// op.lift(k) = the coefficient as a T; op.row_done2(k, i, P, Pu, Pv, Puu, Puv, Pvv) is the coefficient stream's hook.
+template <class T, class OPS, class C>
+GR_TAB_HD __attribute__((always_inline)) inline void eval_patch2(const C& coef, const OPS& op, T u, T v, T P[kComps], T Pu[kComps], T Pv[kComps],
+                                                                   T Puu_half[kComps], T Puv[kComps], T Pvv_half[kComps])
+{
+    static_assert(kDegree >= 3, "the recurrences below special-case the three highest rows");
+#pragma unroll
+    for (int k = 0; k < kComps; ++k) {
+        const int base = k * kCoefs;
+        T p_ = T(0.0), pu = T(0.0), puu = T(0.0), pv = T(0.0), puv = T(0.0), pvv = T(0.0);
+#pragma unroll
+        for (int i = kDegree; i >= 0; --i) {
+            const int d = kDegree - i, off = base + row_offset(i);      // the row's degree in v
+            // q(v), q'(v), ½ q''(v) of the row by Horner from its leading coefficient
+            T q = T(0.0), dq = T(0.0), ddq = T(0.0);
+            if (d == 0) {
+                q = op.lift(coef(off));
+            } else if (d == 1) {
+                const double c0 = coef(off);
+                q = op.addk(op.mulk(v, c0), coef(off + 1));
+                dq = op.lift(c0);
+            } else {
+                const double c0 = coef(off);
+                const T t0 = op.mulk(v, c0);                       // c0 v
+                q = op.addk(t0, coef(off + 1));                    // q_1 = c0 v + c1
+                dq = op.add(t0, q);                                // q'_2 = 2 c0 v + c1
+                q = op.fmak(q, v, coef(off + 2));                  // q_2
+                if (d == 2) {
+                    ddq = op.lift(c0);                             // ½ q''_2 = c0
+                } else {
+                    ddq = op.add(t0, dq);                          // ½ q''_3 = 3 c0 v + c1
+                    dq = op.fma(dq, v, q);                         // q'_3
+                    q = op.fmak(q, v, coef(off + 3));              // q_3
+#pragma unroll
+                    for (int t = 4; t <= d; ++t) {
+                        ddq = op.fma(ddq, v, dq);
+                        dq = op.fma(dq, v, q);
+                        q = op.fmak(q, v, coef(off + t));
+                    }
+                }
+            }
+            // the recurrences in u: (½ Puu, Pu, P) and (Puv, Pv) and ½ Pvv, the leading rows without the zeros they would multiply
+            if (d == 0) {
+                p_ = q;
+            } else if (d == 1) {
+                pu = p_;
+                p_ = op.fma(p_, u, q);
+                pv = dq;
+            } else if (d == 2) {
+                puu = pu;
+                pu = op.fma(pu, u, p_);
+                p_ = op.fma(p_, u, q);
+                puv = pv;
+                pv = op.fma(pv, u, dq);
+                pvv = ddq;
+            } else {
+                puu = op.fma(puu, u, pu);
+                pu = op.fma(pu, u, p_);
+                p_ = op.fma(p_, u, q);
+                puv = op.fma(puv, u, pv);
+                pv = op.fma(pv, u, dq);
+                pvv = op.fma(pvv, u, ddq);
+            }
+            if (d >= 2) op.row_done2(k, i, p_, pu, pv, puu, puv, pvv);
+        }
+        P[k] = p_; Pu[k] = pu; Pv[k] = pv; Puu_half[k] = puu; Puv[k] = puv; Pvv_half[k] = pvv;
+    }
+}
+
 // the operations on plain doubles (host, and the device's per-lane loads from global memory)
 struct HostOps {
     static GR_TAB_HD double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -145,6 +219,8 @@ struct HostOps {
     static GR_TAB_HD double mulk(double a, double k) { return a * k; }
     static GR_TAB_HD double addk(double a, double k) { return a + k; }
     static GR_TAB_HD void row_done(int, int, double&, double&, double&) {}
+    static GR_TAB_HD double lift(double k) { return k; }
+    static GR_TAB_HD void row_done2(int, int, double&, double&, double&, double&, double&, double&) {}
 };
 
 // K(u) and dK/du of one axis polynomial (kDegree + 1 coefficients, leading one first); T as in eval_patch
