@@ -677,7 +677,11 @@ class TabulatedMetric(AbstractStaticAxisSymmetric):
         """metric_components on the tensor grid of nodes -> array [n_r, n_θ, 5]."""
         R, T = np.meshgrid(rn, tn, indexing="ij")
         try:
-            g = self._f(R, T)
+            if isinstance(self.source, AbstractMetric) and hasattr(self.source, "_components"):
+                # (a catalogue type's metric_components takes one point -- math.sin; its formula takes arrays)
+                g = self.source._components(R, np.sin(T), np.cos(T))
+            else:
+                g = self._f(R, T)
             out = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), R.shape) for c in g], axis=-1)
         except (TypeError, ValueError):
             out = np.empty(R.shape + (5,))
