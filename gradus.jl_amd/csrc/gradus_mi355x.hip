@@ -115,6 +115,8 @@ struct gr_ctx {
     int64_t mesh_n = -1;
     std::vector<double> mesh_host;
     double* d_sky = nullptr;               // a sky source's (x, v) arrays, written by k_sky_velocities for the trace kernels
+    unsigned* d_sky_table = nullptr;       // ... dealt by cost: counts, then offsets, per (class, chunk) (k_sky_velocities_dealt)
+    size_t sky_table_bytes = 0;
     size_t sky_bytes = 0;
     int64_t sky_first = 0, sky_total = 0;  // the share of a sky source the launch being prepared traces (rays_params -> sky_prepare)
     bool sky_any_order = false;            // ... whose rows may come in any order (gr_corona_trace): the rays are dealt by direction
@@ -551,54 +553,111 @@ __global__ void __launch_bounds__(256) k_sky_scale_g(double* rows, const double*
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) rows[4 * j] *= f[j];
 }
-// The same rays DEALT BY DIRECTION (gr_corona_trace: the order of its rows is free -- min / max and integer bins do not know it).
-// How long a ray takes depends on where it goes: of 64 CONSECUTIVE samples of a golden spiral -- one polar angle, azimuths all
-// round the sky -- the longest ray takes twice the mean (a wave of them keeps 55 % of its lanes busy, oracle step counts of the
-// lamp-post scene).  A workgroup takes kSkyChunk consecutive samples (still one polar angle to 1 %) and writes them grouped by
-// azimuth -- 64 buckets, by hemisphere and azimuth / 32 -- so that the 64 rays of a wave leave in nearly the same direction.
+// The same rays DEALT BY WHAT THEY WILL COST (gr_corona_trace: the order of its rows is free -- min / max and integer bins do not
+// know it).  How many steps a ray takes is known, to a constant per polar angle of emission, BEFORE it is traced: the integrator
+// resolves the ray's passage round the polar axis of the coordinates, and along the flat-space straight line from the source the
+// azimuth sweeps Δϕ and ln sin θ runs down to the line's closest angular approach to the axis and back --
+//     steps ≈ base(polar angle of emission) + 16 Δϕ + 36 ln(sin θ₀ / sin θ_min)
+// follows the oracle's step counts of the lamp-post scene (h = 10, 0.01 rad off the axis: 53 ... 519 steps within one polar angle)
+// with a residual of 4 steps rms (scripts/corona_lanes.py, DESIGN_measurements.md §M19).  The rays are counting-sorted by that
+// number in classes of 12 steps, the most expensive class first, inside a class by chunk of kSkyChunk consecutive samples (one polar
+// angle to 1 %: one base): the 64 rays of a wave then take the same number of steps to a few per cent AND the launch starts with its
+// longest waves -- a wave of 500-step rays takes 2 ms alone whenever it starts, and consecutive samples put one into every chunk.
+// Three launches: count per (class, chunk), one-workgroup exclusive scan, scatter.
 constexpr int kSkyChunk = 4096;
-__global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p, double* out)
+constexpr int kSkyClasses = 32;
+__device__ __forceinline__ int sky_cost_class(const double x[4], const double v[4])
 {
-    __shared__ int cnt[64], start[64];
+    const double r = x[1], s = ::sin(x[2]), c = ::cos(x[2]);
+    double er = v[1], et = r * v[2], ep = r * s * v[3];
+    const double nrm = ::sqrt(er * er + et * et + ep * ep);
+    if (!(nrm > 0.0) || !(nrm < 1e300)) return 0;
+    er /= nrm; et /= nrm; ep /= nrm;
+    // the source in the x-z plane, the ray's direction in Cartesian components
+    const double Px = r * s, Pz = r * c;
+    const double dx = er * s + et * c, dy = ep, dz = er * c - et * s;
+    const double dphi = ::atan2(::fabs(dy), dx);
+    // the directions origin -> points of the line run along a great circle from P̂ to d̂ (normal n = P x d): sin θ on it has an
+    // extremum |n_z| / |n|, reached on the way iff cos θ moves towards that pole at the start and away from it at the end
+    const double Pd = Px * dx + Pz * dz;
+    const double nx = -Pz * dy, ny = Pz * dx - Px * dz, nz = Px * dy;
+    const double nn = ::sqrt(nx * nx + ny * ny + nz * nz);
+    const double a0 = dz * r * r - Pz * Pd, a1 = Pz - Pd * dz;
+    double tv = 0.0;
+    if (((a0 > 0.0 && a1 > 0.0) || (a0 < 0.0 && a1 < 0.0)) && nn > 0.0) {
+        const double s_ext = ::fabs(nz) / nn, s0 = ::fabs(s);
+        if (s_ext < s0) tv = ::log(s0 / (s_ext > 1e-12 ? s_ext : 1e-12));
+    }
+    const double cost = 16.0 * dphi + 36.0 * tv;
+    const int cls = (int)(cost * (1.0 / 12.0));
+    return cls < 0 ? 0 : cls >= kSkyClasses ? kSkyClasses - 1 : cls;      // (NaN -> 0)
+}
+// counts / offsets: [kSkyClasses - 1 - class][chunks - 1 - chunk] -- the order of the dealt array (the last samples of a sky leave
+// upwards, away from the disc, and have the larger base: first within their class)
+template <bool COUNT>
+__global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p, double* out, unsigned* table)
+{
+    __shared__ int cnt[kSkyClasses];
     const int64_t base = (int64_t)blockIdx.x * kSkyChunk;
     const int64_t left = p.n - base;
     const int nloc = left < kSkyChunk ? (int)left : kSkyChunk;
-    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (threadIdx.x < kSkyClasses) cnt[threadIdx.x] = 0;
+    if (!COUNT && blockIdx.x == 0 && threadIdx.x == 0)
         for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
     __syncthreads();
     double v[kSkyChunk / 1024][4], x[kSkyChunk / 1024][4], f[kSkyChunk / 1024];
-    int bucket[kSkyChunk / 1024], pos[kSkyChunk / 1024];
+    int cls[kSkyChunk / 1024], pos[kSkyChunk / 1024];
 #pragma unroll
     for (int k = 0; k < kSkyChunk / 1024; ++k) {
         const int j = (int)threadIdx.x + 1024 * k;
-        bucket[k] = -1;
+        cls[k] = -1;
         if (j < nloc) {
             double el, az;
             sky_sample(p, base + j, el, az, v[k], x[k], f[k]);
-            int a32 = (int)(az * (32.0 / 6.28318530717958647692));
-            a32 = a32 > 31 ? 31 : (a32 < 0 ? 0 : a32);
-            bucket[k] = (el > 1.57079632679489661923 ? 32 : 0) + a32;
-            pos[k] = atomicAdd(&cnt[bucket[k]], 1);
+            cls[k] = sky_cost_class(x[k], v[k]);
+            pos[k] = atomicAdd(&cnt[cls[k]], 1);
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int sum = 0;
-        for (int q = 0; q < 64; ++q) { start[q] = sum; sum += cnt[q]; }
+    const unsigned chunks = gridDim.x;
+    const unsigned col = chunks - 1u - blockIdx.x;
+    if (COUNT) {
+        __syncthreads();
+        if (threadIdx.x < kSkyClasses) table[(size_t)(kSkyClasses - 1 - (int)threadIdx.x) * chunks + col] = (unsigned)cnt[threadIdx.x];
+        return;
     }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < kSkyChunk / 1024; ++k) {
-        if (bucket[k] < 0) continue;
-        // (chunks in REVERSE order: the last samples of a sky leave upwards, away from the disc, and are the long rays -- out to
-        // the chart's edge; traced first, they do not make the tail of the launch)
-        sky_store(p, out, (p.n - base - nloc) + start[bucket[k]] + pos[k], v[k], x[k], f[k]);
+        if (cls[k] < 0) continue;
+        sky_store(p, out, (int64_t)table[(size_t)(kSkyClasses - 1 - cls[k]) * chunks + col] + pos[k], v[k], x[k], f[k]);
     }
+}
+// in-place exclusive scan of `n` counts by one workgroup (n = 32 x chunks: 7808 for 10⁶ samples)
+__global__ void __launch_bounds__(1024) k_sky_scan(unsigned* table, int64_t n)
+{
+    __shared__ unsigned part[1024];
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    unsigned sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += table[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - sum;
+    for (int64_t i = lo; i < hi; ++i) { const unsigned c = table[i]; table[i] = run; run += c; }
 }
 }  // namespace
 }  // extern "C++"
 
+// are the rays of this launch's sky source dealt by cost? (offsets are 32-bit)
+static bool sky_dealt(const gr_ctx* ctx, int64_t n)
+{
+    return ctx->sky_any_order && ctx->sky_deal && n >= 4 * kSkyChunk && n < ((int64_t)1 << 32);
+}
 // a sky source -> ray arrays in the context's sky buffer (ordered against earlier launches that read it like the staged tables)
 static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t stream)
 {
@@ -615,9 +674,13 @@ static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t strea
     sp.resolution = cold.sky_resolution;
     sp.sky_i = cold.sky_i;
     sp.rows = ctx->sky_rows;
-    if (ctx->sky_any_order && ctx->sky_deal && p.n >= 4 * kSkyChunk)
-        hipLaunchKernelGGL(k_sky_velocities_dealt, dim3((unsigned)((p.n + kSkyChunk - 1) / kSkyChunk)), dim3(1024), 0, stream, sp, ctx->d_sky);
-    else
+    if (sky_dealt(ctx, p.n)) {
+        const unsigned chunks = (unsigned)((p.n + kSkyChunk - 1) / kSkyChunk);
+        if ((rc = ensure((void**)&ctx->d_sky_table, &ctx->sky_table_bytes, sizeof(unsigned) * kSkyClasses * (size_t)chunks)) != GR_OK) return rc;
+        hipLaunchKernelGGL(k_sky_velocities_dealt<true>, dim3(chunks), dim3(1024), 0, stream, sp, ctx->d_sky, ctx->d_sky_table);
+        hipLaunchKernelGGL(k_sky_scan, dim3(1), dim3(1024), 0, stream, ctx->d_sky_table, (int64_t)kSkyClasses * chunks);
+        hipLaunchKernelGGL(k_sky_velocities_dealt<false>, dim3(chunks), dim3(1024), 0, stream, sp, ctx->d_sky, ctx->d_sky_table);
+    } else
         hipLaunchKernelGGL(k_sky_velocities, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, sp, ctx->d_sky);
     GR_HIP(hipGetLastError());
     cold.src_mode = 1;
@@ -672,7 +735,7 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     // same number of steps (lane utilisation 0.9 against 0.5 for consecutive samples), which the persistent kernel's refill would mix
     // again -- one ray per lane, four waves to a workgroup (10⁶ lamp-post samples: 7.2 ms against 8.4 persistent, 8.4 with one-wave
     // workgroups; profiles/r6_corona_deal_ab.log)
-    const bool dealt = sky && ctx->sky_any_order && ctx->sky_deal && p.n >= 4 * kSkyChunk && !tangent;
+    const bool dealt = sky && sky_dealt(ctx, p.n) && !tangent;
     const int kern_sel = tangent ? 0 : (dealt && ctx->kernel == 2) ? 0 : resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);
     const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : (dealt && ctx->kernel == 2 && !ctx->block) ? 256 : resolve_block(ctx, kern_sel);
     // LDS staging: the plunging table (<= 2048 rows = 64 KB) and the line-profile histogram (<= 4096 bins).
@@ -872,6 +935,7 @@ int32_t gr_ctx_destroy(gr_ctx* c)
     if (c->d_metric_table) (void)hipFree(c->d_metric_table);
     if (c->d_corona) (void)hipFree(c->d_corona);
     if (c->d_sky) (void)hipFree(c->d_sky);
+    if (c->d_sky_table) (void)hipFree(c->d_sky_table);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_perm) (void)hipFree(c->d_tile_perm);
     if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
@@ -2189,12 +2253,26 @@ __global__ void __launch_bounds__(256) k_corona_minmax(const double* __restrict_
         tm = t2 > tm ? t2 : tm;
         cnt += c2;
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        atomicMin(red, lo);
-        atomicMax(red + 1, hi);
-        atomicAdd(red + 2, cnt);
-        atomicMax(red + 3, gm);
-        atomicMax(red + 4, tm);
+    // one set of atomics per workgroup (per wave, 8192 waves on five addresses, the atomics WERE the kernel: 0.48 ms of a 9 ms call)
+    __shared__ unsigned long long part[4][5];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[w][0] = lo; part[w][1] = hi; part[w][2] = cnt; part[w][3] = gm; part[w][4] = tm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            lo = part[k][0] < lo ? part[k][0] : lo;
+            hi = part[k][1] > hi ? part[k][1] : hi;
+            cnt += part[k][2];
+            gm = part[k][3] > gm ? part[k][3] : gm;
+            tm = part[k][4] > tm ? part[k][4] : tm;
+        }
+        if (cnt) {
+            atomicMin(red, lo);
+            atomicMax(red + 1, hi);
+            atomicAdd(red + 2, cnt);
+            atomicMax(red + 3, gm);
+            atomicMax(red + 4, tm);
+        }
     }
 }
 
@@ -2295,7 +2373,7 @@ static int32_t corona_enqueue(gr_ctx* ctx, const gr_config* cfg, const gr_rayset
     if (rc != GR_OK) return rc;
     if (rays->n > 0) {
         int64_t blocks = (rays->n + 255) / 256;
-        blocks = blocks > 2048 ? 2048 : blocks;
+        blocks = blocks > 512 ? 512 : blocks;
         hipLaunchKernelGGL(k_corona_minmax, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_corona, rays->n, red);
         GR_HIP(hipGetLastError());
     }
