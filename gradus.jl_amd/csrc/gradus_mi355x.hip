@@ -119,7 +119,7 @@ struct gr_ctx {
     size_t sky_table_bytes = 0;
     size_t sky_bytes = 0;
     int64_t sky_first = 0, sky_total = 0;  // the share of a sky source the launch being prepared traces (rays_params -> sky_prepare)
-    bool sky_any_order = false;            // ... whose rows may come in any order (gr_corona_trace): the rays are dealt by direction
+    bool sky_any_order = false;            // ... whose rows may come in any order (gr_corona_trace): the rays are dealt by predicted cost
     const double* sky_rows = nullptr;      // ... and its per-sample rows (gr_rayset.sky_rows, device) or null
     double* d_corona = nullptr;            // gr_corona_trace: (g, ρ, t, status) per ray, kept for gr_corona_bin
     size_t corona_bytes = 0;
@@ -155,7 +155,7 @@ struct gr_ctx {
     int64_t lds_points = 1;                // one-ray-per-lane kernel: a wave's end-point records leave through LDS as whole runs
     int64_t direct_host = 1;               // gr_render_endpoints into a gr_host_alloc block: the kernel stores across the link itself
     int64_t tangent_pairs = 2;             // tangent kernels: 0 = one lane per ray, 1 = a pair of lanes per ray, 2 = by launch size
-    int64_t sky_deal = 1;                  // gr_corona_trace: the sky rays of a source dealt to the waves by direction (k_sky_velocities_dealt)
+    int64_t sky_deal = 1;                  // gr_corona_trace: the sky rays of a source dealt to the waves by predicted cost (k_sky_velocities_dealt)
     int64_t xcd_spread = 1;                // one-ray-per-lane kernel, rays in caller order: chunks dealt over the XCDs by digit sum
     int64_t tangent_norm = 1;              // tangent kernels: the tangents are part of the error norm (DiffEqBase on Dual state); 0 = values only
     // LPT state for one (config, plane, range) key
@@ -731,10 +731,10 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
         return fail(GR_ERR_UNSUPPORTED, "a tabulated metric is traced by the fp64 kernels only (there is no fp32 table: not with \"precision\" 32)");
     if (p.cfg.disc_id == GR_DISC_MESH && (tangent || ctx->precision == 32))
         return fail(GR_ERR_UNSUPPORTED, "a mesh geometry is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
-    // A sky source whose rays were dealt by direction (sky_prepare): a wave's 64 rays leave in nearly one direction and take nearly the
-    // same number of steps (lane utilisation 0.9 against 0.5 for consecutive samples), which the persistent kernel's refill would mix
-    // again -- one ray per lane, four waves to a workgroup (10⁶ lamp-post samples: 7.2 ms against 8.4 persistent, 8.4 with one-wave
-    // workgroups; profiles/r6_corona_deal_ab.log)
+    // A sky source whose rays were dealt by predicted cost (sky_prepare): a wave's 64 rays take nearly the same number of steps
+    // (lane utilisation 0.93 against 0.5 for consecutive samples) and the array begins with the longest, which the persistent
+    // kernel's refill would mix again -- one ray per lane, four waves to a workgroup (10⁶ lamp-post samples: 5.9 ms against 7.6
+    // persistent, 6.6 with one-wave workgroups, 8.4 in sample order; profiles/r6_corona_cost_ab.log)
     const bool dealt = sky && sky_dealt(ctx, p.n) && !tangent;
     const int kern_sel = tangent ? 0 : (dealt && ctx->kernel == 2) ? 0 : resolve_kernel(ctx, p.n, cold, p.cfg.metric_id);
     const int block_sel = tangent ? (ctx->block ? (int)ctx->block : 64) : (dealt && ctx->kernel == 2 && !ctx->block) ? 256 : resolve_block(ctx, kern_sel);

@@ -291,10 +291,11 @@ int32_t gr_ctx_destroy(gr_ctx* ctx);
  * ("xcd_spread", 1 [default] = rays in caller order on the one-ray-per-lane kernel are dealt to the 8 XCDs by the digit sum of
  * their chunk index instead of round-robin -- a periodic pattern in the rays, such as the polar-axis column of a 1024-wide grid of
  * impact parameters, otherwise lands on one or two XCDs (38 against 21 ms) --, 0 = chunk b to workgroup b);
- * ("sky_deal", 1 [default] = gr_corona_trace deals the rays of a sky source to the waves by direction -- chunks of 4096 consecutive
- * samples grouped by azimuth, upward chunks first, traced by the one-ray-per-lane kernel in 256-thread workgroups: a wave's rays then
- * take nearly the same number of steps (lane utilisation 0.9 against 0.5 for consecutive samples of a golden spiral) --, 0 = sample
- * order; same rows, min / max and bins either way);
+ * ("sky_deal", 1 [default] = gr_corona_trace deals the rays of a sky source to the waves by what they will cost -- a counting sort
+ * by a step count predicted from each ray's initial position and direction (its passage round the polar axis), the longest class
+ * first, traced by the one-ray-per-lane kernel in 256-thread workgroups: a wave's rays take nearly the same number of steps and the
+ * launch begins with its longest waves (10⁶ lamp-post samples: 5.9 against 8.4 ms in sample order) --, 0 = sample order; same
+ * min / max and bins either way);
  * ("lds_points", 1 [default] = the one-ray-per-lane kernel sends a wave's 64 end-point records through LDS as runs of
  * consecutive addresses, 0 = every lane stores its own 152 bytes; same bytes either way); ("direct_host", 1 [default] =
  * gr_render_endpoints into a gr_host_alloc block lets the kernel store across the link itself -- no staging buffer, no

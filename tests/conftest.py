@@ -47,7 +47,7 @@ def G(built):
 
 # library defaults of every launch knob (gradus_mi355x.hip, struct gr_ctx)
 KNOB_DEFAULTS = {"kernel": 2, "block": 0, "refill_threshold": 0, "waves_per_simd": 0, "swizzle": 1, "lpt_lane": 0,
-                 "lds": 1, "precision": 64, "lpt": 1, "pipeline": 4, "tangent_pairs": 2, "xcd_spread": 1}
+                 "lds": 1, "precision": 64, "lpt": 1, "pipeline": 4, "tangent_pairs": 2, "xcd_spread": 1, "sky_deal": 1}
 
 
 @pytest.fixture(scope="session")

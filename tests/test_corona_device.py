@@ -221,6 +221,28 @@ def test_disc_corona_on_the_device_equals_the_record_route(G, ens, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_rays_dealt_by_cost_are_a_permutation_of_the_samples(G, ens):
+    """gr_corona_trace deals its sky rays to the waves by what they will cost (counting sort over (class, chunk), k_sky_velocities_dealt):
+    every sample exactly once, whatever the order -- the integer bins of the dealt launch are the BITS of the launch in sample order
+    (knob sky_deal = 0), for a source at one position and for one with a position per sample, at a sample count that is not a
+    multiple of the chunk."""
+    K = G.corona
+    ens.set("kernel", 2).set("precision", 64)
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+    m, d = G.KerrMetric(1.0, 0.9), G.ThinDisc(0.0, 200.0)
+    for mk in (lambda: G.LampPostModel(h=7.0), lambda: G.DiscCorona(G.SourceVelocities.co_rotating, 6.0, 4.0, seed=3)):
+        prof = {}
+        for deal in (1, 0):
+            ens.set("sky_deal", deal)
+            prof[deal] = K.device_radial_profile(m, d, mk(), sampler=s, n_samples=50_001, N=60, ensemble=ens)
+        ens.set("sky_deal", 1)
+        np.testing.assert_array_equal(prof[1].radii, prof[0].radii)
+        np.testing.assert_array_equal(prof[1].ε, prof[0].ε)
+        np.testing.assert_array_equal(prof[1].t, prof[0].t)
+        assert np.isfinite(prof[1].ε).sum() > 40
+
+
+@pytest.mark.gpu
 def test_corona_bins_are_the_bucket_rule_and_sum_to_the_hits(G, ens):
     """gr_corona_trace / gr_corona_bin through the C ABI: counts add up to the hits, re-binning the same trace with other
     edges needs no new trace, edge cases of bucket(Simple()) (below the first edge / above the last)."""
