@@ -1724,10 +1724,12 @@ GR_DEV void geodesic_contract(const real j1[5], const real j2[5], const real gi[
 // The scalar type.  `real` is double in the fp64 kernels and a value with two tangents in the tangent flavour (gr_tangent.hpp): the
 // patch is located from VALUES, the local coordinates are lifted (du = su dr) and the same recurrences run on the lifted numbers --
 // the tangents of g and of ∂g come out of the polynomial's own second derivatives, as the reference's nested ForwardDiff does for
-// a closure (src/tracing/precision-solvers.jl:401-451).  There is no fp32 table.
+// a closure (src/tracing/precision-solvers.jl:401-451).  In the fp32 kernels (`real` = float: tolerance sweeps, gr_ctx_set
+// "precision" 32) the table stays what it is -- fp64 data -- and its polynomials are evaluated in DOUBLE (tab_real): converting the
+// 105 coefficients of an evaluation would cost as many FP64-rate instructions as the 210 operations themselves; the components
+// and their Jacobian are rounded to float once and the inverse, the contraction and the whole step run in single precision.
 // ---------------------------------------------------------------------------------------
-#if !defined(GR_REAL_IS_FLOAT)
-#define GR_HAS_TABULATED 1
+#define GR_HAS_TABULATED 1      // (every flavour of the kernels: fp64, fp32, tangents)
 #ifndef GR_TAB_SLOTS
 #define GR_TAB_SLOTS 12
 #endif
@@ -1769,8 +1771,14 @@ static_assert(kTabSlots >= 1 && kTabSlots <= 12 && gr_tab::kPatchDoubles * 8 <= 
 static_assert(kTabFetch == 1 || kTabFetch == 2 || kTabFetch == 4, "patches copied side by side");
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// local coordinate -> the integrator's scalar: the tangents of u are du/dr times the tangents of r
-GR_DEV real tab_lift(double u, double su, real r)
+// the scalar the patch polynomials are evaluated in
+#ifdef GR_REAL_IS_FLOAT
+typedef double tab_real;
+#else
+typedef real tab_real;
+#endif
+// local coordinate -> that scalar: the tangents of u are du/dr times the tangents of r
+GR_DEV tab_real tab_lift(double u, double su, real r)
 {
 #ifdef GR_REAL_IS_TAN2
     gr_tan2 x(u);
@@ -1784,13 +1792,15 @@ GR_DEV real tab_lift(double u, double su, real r)
 }
 // gr_tab::eval_patch's operations on `real`
 struct TabRealOps {
+#ifndef GR_REAL_IS_FLOAT
     static GR_DEV real fma(real a, real b, real c) { return GR_FMA(a, b, c); }
     static GR_DEV real fmak(real a, real b, double k) { return GR_FMA(a, b, k); }
     static GR_DEV real add(real a, real b) { return a + b; }
     static GR_DEV real mulk(real a, double k) { return a * k; }
     static GR_DEV real addk(real a, double k) { return a + k; }
-    static GR_DEV void row_done(int, int, real&, real&, real&) {}
-#ifdef GR_REAL_IS_TAN2
+#endif
+    static GR_DEV void row_done(int, int, tab_real&, tab_real&, tab_real&) {}
+#if defined(GR_REAL_IS_TAN2) || defined(GR_REAL_IS_FLOAT)
     static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static GR_DEV double fmak(double a, double b, double k) { return __builtin_fma(a, b, k); }
     static GR_DEV double add(double a, double b) { return a + b; }
@@ -1804,7 +1814,7 @@ struct TabRealOps {
 #ifndef GR_HOST_HARNESS
 // the right-hand side with the coefficients read per lane from global memory, NOT inlined: the step loop holds six copies of the
 // LDS-fed evaluation already; this one serves lanes that found no cache slot
-__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, const double* ax, int form, real u, real v, double su, double sv,
+__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, const double* ax, int form, tab_real u, tab_real v, double su, double sv,
                                                              real s, real c, real vt, real vr, real vh, real vp, real* out);
 #endif
 struct TabulatedMetric {
@@ -1872,12 +1882,12 @@ struct TabulatedMetric {
     }
     // ---- the axis terms of form 2: K_m, ∂r K_m, K_d, ∂r K_d of g_ϕϕ and g_tϕ at this lane's radius (per-lane loads: 4 (p + 1)
     // doubles that the lanes of a wave mostly share; only metrics whose azimuthal components do not vanish on the axis come here)
-    static GR_DEV void axis_terms(const double* ax, real u, double su, real out[8])
+    static GR_DEV void axis_terms(const double* ax, tab_real u, double su, tab_real out[8])
     {
 #pragma unroll
         for (int q = 0; q < gr_tab::kAxisPolys; ++q) {
-            real K, Ku;
-            gr_tab::eval_axis_poly<real>([ax](int k) { return ax[k]; }, q * (gr_tab::kDegree + 1), u, K, Ku);
+            tab_real K, Ku;
+            gr_tab::eval_axis_poly<tab_real>([ax](int k) { return ax[k]; }, q * (gr_tab::kDegree + 1), u, K, Ku);
             out[2 * q] = K;
             out[2 * q + 1] = Ku * su;
         }
@@ -1924,19 +1934,24 @@ struct TabulatedMetric {
         GR_DEV void start() const { issue(0, pairs_by(0)); }
         GR_DEV double operator()(int kk) const { return buf[kk >> 1][kk & 1]; }
         // the five operations of gr_tab::eval_patch, and the hook that keeps the stream ahead
+#ifndef GR_REAL_IS_FLOAT
         static GR_DEV real fma(real a, real b, real c) { return GR_FMA(a, b, c); }
         static GR_DEV real fmak(real a, real b, double k) { return GR_FMA(a, b, k); }
         static GR_DEV real add(real a, real b) { return a + b; }
         static GR_DEV real mulk(real a, double k) { return a * k; }
         static GR_DEV real addk(real a, double k) { return a + k; }
-#ifdef GR_REAL_IS_TAN2
-        // the tangent flavour evaluates the patch on PLAIN numbers with second derivatives (gr_tab::eval_patch2) and contracts
+#endif
+#if defined(GR_REAL_IS_TAN2) || defined(GR_REAL_IS_FLOAT)
+        // the tangent flavour evaluates the patch on PLAIN numbers with second derivatives (gr_tab::eval_patch2) and contracts;
+        // the fp32 kernels evaluate it in double (tab_real)
         static GR_DEV double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
         static GR_DEV double fmak(double a, double b, double k) { return __builtin_fma(a, b, k); }
         static GR_DEV double add(double a, double b) { return a + b; }
         static GR_DEV double mulk(double a, double k) { return a * k; }
         static GR_DEV double addk(double a, double k) { return a + k; }
         static GR_DEV double lift(double k) { return k; }
+#endif
+#ifdef GR_REAL_IS_TAN2
         GR_DEV void row_done2(int comp, int row, double& p0, double& p1, double& p2, double& p3, double& p4, double& p5) const
         {
             const int before = (row == gr_tab::kDegree - 2) ? (comp == 0 ? 0 : consumed(comp - 1, 0)) : consumed(comp, row + 1);
@@ -1948,7 +1963,7 @@ struct TabulatedMetric {
             issue(from, to);
         }
 #endif
-        GR_DEV void row_done(int comp, int row, real& acc, real& acc_u, real& acc_v) const
+        GR_DEV void row_done(int comp, int row, tab_real& acc, tab_real& acc_u, tab_real& acc_v) const
         {
             // (rows kDegree and kDegree - 1 of a component are folded together before the first call for it)
             const int before = (row == gr_tab::kDegree - 2) ? (comp == 0 ? 0 : consumed(comp - 1, 0)) : consumed(comp, row + 1);
@@ -1977,7 +1992,7 @@ struct TabulatedMetric {
     // components and Jacobian from a coefficient source: the polynomials, the chain rule, the axis forms
     // (ax: this lane's row of the axis terms, read in form 2 only)
     template <class Ld, class Ops_>
-    static GR_DEV void horner(const Ld& ld, const Ops_& ops, int form, const double* ax, real u, real v, double su, double sv, real s, real c,
+    static GR_DEV void horner(const Ld& ld, const Ops_& ops, int form, const double* ax, tab_real u, tab_real v, double su, double sv, real s, real c,
                               real g[5], real gr[5], real gt[5])
     {
 #ifdef GR_REAL_IS_TAN2
@@ -2008,16 +2023,6 @@ struct TabulatedMetric {
             gt[k].b = __builtin_fma(Puv[k], svub, Pvv[k] * s2vb);
 #endif
         }
-#else
-        real P[5], Pu[5], Pv[5];
-        gr_tab::eval_patch<real>(ld, ops, u, v, P, Pu, Pv);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            g[k] = P[k];
-            gr[k] = Pu[k] * su;
-            gt[k] = Pv[k] * sv;
-        }
-#endif
         if (form != 0) {
             gr_tab::pole_factor_apply<real>(s * s, 2.0 * (s * c), g, gr, gt);
             if (form == 2) {
@@ -2026,6 +2031,35 @@ struct TabulatedMetric {
                 gr_tab::axis_terms_apply<real>(at8, s, c, g, gr, gt);
             }
         }
+#else
+        // (tab_real is `real` in the fp64 kernels; in the fp32 ones everything down to the last loop is double)
+        tab_real G[5], Gr[5], Gt[5];
+        {
+            tab_real P[5], Pu[5], Pv[5];
+            gr_tab::eval_patch<tab_real>(ld, ops, u, v, P, Pu, Pv);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                G[k] = P[k];
+                Gr[k] = Pu[k] * su;
+                Gt[k] = Pv[k] * sv;
+            }
+        }
+        if (form != 0) {
+            const tab_real sd = s, cd = c;
+            gr_tab::pole_factor_apply<tab_real>(sd * sd, 2.0 * (sd * cd), G, Gr, Gt);
+            if (form == 2) {
+                tab_real at8[8];
+                axis_terms(ax, u, su, at8);
+                gr_tab::axis_terms_apply<tab_real>(at8, sd, cd, G, Gr, Gt);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            g[k] = (real)G[k];
+            gr[k] = (real)Gr[k];
+            gt[k] = (real)Gt[k];
+        }
+#endif
     }
     // components and Jacobian at (r, θ); s, c = sin θ, cos θ of the same θ (the axis factor of g_ϕϕ and g_tϕ)
     GR_DEV void poly(real r, real th, real s, real c, real g[5], real gr[5], real gt[5]) const
@@ -2171,7 +2205,7 @@ struct TabulatedMetric {
                 if (rank == 0) tags[13] = tags[13] + (int)(wall_clock64() - tl_c0);
 #endif
             }
-            const real ul = tab_lift(u, su, r), vl = tab_lift(v, sv, th);
+            const tab_real ul = tab_lift(u, su, r), vl = tab_lift(v, sv, th);
             // -- phase 2: the lanes that have a slot evaluate out of LDS ...
             if (slot >= 0) {
                 LdsCoef lc;
@@ -2217,7 +2251,7 @@ struct TabulatedMetric {
     }
 };
 #ifndef GR_HOST_HARNESS
-__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, const double* ax, int form, real u, real v, double su, double sv,
+__device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, const double* ax, int form, tab_real u, tab_real v, double su, double sv,
                                                              real s, real c, real vt, real vr, real vh, real vp, real* out)
 {
     // (the same coefficient stream as out of LDS: a few loads ahead of the arithmetic, ~100 registers -- with all loads hoisted
@@ -2229,9 +2263,6 @@ __device__ __attribute__((noinline)) void tab_rhs_from_global(const double* pc, 
     TabulatedMetric::horner(gc, gc, form, ax, u, v, su, sv, s, c, g, gr, gt);
     TabulatedMetric::finish_rhs(g, gr, gt, vt, vr, vh, vp, out[0], out[1], out[2], out[3]);
 }
-#endif
-#else
-#define GR_HAS_TABULATED 0
 #endif
 
 // metric id -> functor type (the ids of include/gradus_mi355x.h)

@@ -41,8 +41,9 @@ using namespace gr;
 GR_DECLARE_METRIC(0) GR_DECLARE_METRIC(1) GR_DECLARE_METRIC(2) GR_DECLARE_METRIC(3) GR_DECLARE_METRIC(4) GR_DECLARE_METRIC(5)
 GR_DECLARE_METRIC(6) GR_DECLARE_METRIC(7) GR_DECLARE_METRIC(8) GR_DECLARE_METRIC(9) GR_DECLARE_METRIC(10)
 #undef GR_DECLARE_METRIC
-// GR_METRIC_TABULATED (11): the fp64 kernels and the tangent flavours (no fp32 table)
+// GR_METRIC_TABULATED (11): every flavour of the trace kernels (the fp32 ones evaluate the fp64 table in double, gr_device.hpp)
 hipError_t gr64_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
+hipError_t gr32_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
 hipError_t grt_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
 hipError_t grt1_launch_trace_m11(int, int, int, int, unsigned long long*, const void*, hipStream_t);
 hipError_t gr64_launch_path_m11(const void*, double*, int64_t, unsigned long long*, hipStream_t);
@@ -62,7 +63,7 @@ typedef hipError_t (*path_fn)(const void*, double*, int64_t, unsigned long long*
 typedef hipError_t (*apply_fn)(const void*, const gr_point*, double, double*, hipStream_t);
 #define GR_ROW(F, LAST) { F##0, F##1, F##2, F##3, F##4, F##5, F##6, F##7, F##8, F##9, F##10, LAST }
 const trace_fn kTrace64[12] = GR_ROW(gr64_launch_trace_m, gr64_launch_trace_m11);
-const trace_fn kTrace32[12] = GR_ROW(gr32_launch_trace_m, nullptr);
+const trace_fn kTrace32[12] = GR_ROW(gr32_launch_trace_m, gr32_launch_trace_m11);
 const trace_fn kTraceTan[12] = GR_ROW(grt_launch_trace_m, grt_launch_trace_m11);      // value + ∂/∂α + ∂/∂β (out_mode 5): one lane per ray
 const trace_fn kTraceTan1[12] = GR_ROW(grt1_launch_trace_m, grt1_launch_trace_m11);   // the same with a PAIR of lanes per ray (kernels_tu.hip)
 const path_fn kPath64[12] = GR_ROW(gr64_launch_path_m, gr64_launch_path_m11);
@@ -381,9 +382,12 @@ int32_t stage_disc_table(gr_ctx* ctx, Params& p, hipStream_t stream)
 int resolve_kernel(const gr_ctx* ctx, int64_t n, const Cold& cold, int metric_id = -1)
 {
     if (ctx->kernel != 2) return (int)ctx->kernel;
+    // a tabulated metric: one ray per lane whatever the launch -- a refilled wave's rays sit in more patches than its cache has
+    // slots (BinningMethod line profile, 4096² rays at tolerance 1e-5: 69 ms against 158 through the persistent kernel; 203 either
+    // way at 1e-9; scripts/sibling_workloads.py tabc5lo)
+    if (metric_id == GR_METRIC_TABULATED) return 0;
     if (cold.out_mode == 2) return 1;
     if (cold.src_mode == 0 && cold.swizzle) return 0;
-    if (metric_id == GR_METRIC_TABULATED) return 0;
     const int64_t resident_lanes = (int64_t)ctx->n_cu * 8 * 64;
     return n < 6 * resident_lanes ? 0 : 1;
 }
@@ -727,8 +731,6 @@ int32_t launch_trace(gr_ctx* ctx, Params& p, const Cold& cold_in, hipStream_t st
     p.refill_threshold = (int32_t)(ctx->refill_threshold ? ctx->refill_threshold : (ctx->precision == 32 ? 32 : 16));
     // the tangent objects carry the one-ray-per-lane kernel only: settle kernel and block BEFORE anything is sized by them
     const bool tangent = cold.out_mode == 5;
-    if (p.cfg.metric_id == GR_METRIC_TABULATED && ctx->precision == 32 && !tangent)
-        return fail(GR_ERR_UNSUPPORTED, "a tabulated metric is traced by the fp64 kernels only (there is no fp32 table: not with \"precision\" 32)");
     if (p.cfg.disc_id == GR_DISC_MESH && (tangent || ctx->precision == 32))
         return fail(GR_ERR_UNSUPPORTED, "a mesh geometry is traced by the fp64 kernels only (not with \"precision\" 32, not by the tangent entry points)");
     // A sky source whose rays were dealt by predicted cost (sky_prepare): a wave's 64 rays take nearly the same number of steps

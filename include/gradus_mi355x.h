@@ -74,7 +74,7 @@ enum {
      * ABI, so the caller samples its metric_components on the nodes gr_metric_grid_nodes() names, gr_metric_table_fit() turns
      * the samples into piecewise polynomials (total degree 5 on patches geometric in r - r0 and uniform in θ), and the kernels
      * evaluate the five components and their (∂r, ∂θ) derivatives from that table (gr_config.metric_table; params unused).
-     * See "tabulated metrics" below.  fp64 kernels and the tangent entry points ("precision" 32: GR_ERR_UNSUPPORTED, there is no fp32 table). */
+     * See "tabulated metrics" below.  Every flavour of the kernels ("precision" 32: the table stays fp64 and is evaluated in double, the step is fp32). */
     GR_METRIC_TABULATED = 11
 };
 

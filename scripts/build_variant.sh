@@ -36,7 +36,7 @@ if metrics and rev == "WORK":
         if m.startswith("t"):
             keep.add(f"kernelstan_m{m[1:]}.o")
         elif m == "11":      # GR_METRIC_TABULATED: its kernels and the host fit share gr_tabmetric.hpp (-DGR_TAB_DEGREE=...)
-            keep |= {"kernels_m11.o", "kernelstan_m11.o", "kernelstan1_m11.o", "metric_table.o"}
+            keep |= {"kernels_m11.o", "kernels32_m11.o", "kernelstan_m11.o", "kernelstan1_m11.o", "metric_table.o"}
         else:
             keep |= {f"kernels_m{m}.o", f"kernels32_m{m}.o", f"kernelstan_m{m}.o"}
     for o, _, _ in units:

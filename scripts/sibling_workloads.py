@@ -99,18 +99,23 @@ elif which == "mesh":
         ms.append(st["kernel_ms"])
     rays = S * S
     extra = {"triangles": len(d), "pixels_hit": int(np.isfinite(img).sum())}
-elif which in ("c5", "c5p", "c5f32"):
+elif which in ("c5", "c5p", "c5f32", "tabc5", "tabc5f32", "tabc5lo"):
+    # tabc5 / tabc5f32 / tabc5lo: config 5 on a USER metric (Kerr through the table): fp64 at 1e-9, fp32 kernels at 1e-5, fp64 kernels at 1e-5
     m = G.KerrMetric(1.0, 0.998)
+    if which.startswith("tab"):
+        m = G.TabulatedMetric(m)
     u = np.array([0.0, 1000.0, math.radians(60), 0.0])
     d = G.ThinDisc(m.isco(), 250.0)
-    N = 4096
+    N = int(os.environ.get("SIB_SIZE", "4096"))
     plane = G.PolarPlane(G.GeometricGrid(), Nr=N, Nθ=N, r_min=1.0, r_max=250.0)
     bins = np.linspace(0.1, 1.5, 180)
     tol = 1e-9
     if which == "c5p":
         ens.set("kernel", 1)
-    if which == "c5f32":
+    if which in ("c5f32", "tabc5f32"):
         ens.set("precision", 32)
+        tol = 1e-5
+    if which == "tabc5lo":
         tol = 1e-5
     for _ in range(reps):
         xs, ys, st = G.lineprofile(bins, G.PowerLawEmissivity(3), m, u, d, G.BinningMethod(), plane=plane, maxrₑ=250.0,
