@@ -17,6 +17,10 @@ PROF_CMD="scripts/sibling_workloads.py generic" PROF_KERNEL="k_trace_lane<gr::Ge
 PROF_CMD="scripts/sibling_workloads.py c5" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_c5
 PROF_CMD="scripts/sibling_workloads.py c5p" PROF_KERNEL="k_trace_persistent<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_c5p
 PROF_F32=1 PROF_CMD="scripts/sibling_workloads.py c5f32" PROF_KERNEL="gr32::" bash scripts/profile_pmc.sh ${T}_c5f32
+# BASELINE config 5 on a USER metric (Kerr through the table): fp64 kernels at 1e-9, at 1e-5, and the fp32 kernels at 1e-5
+PROF_CMD="scripts/sibling_workloads.py tabc5 5" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabc5
+PROF_CMD="scripts/sibling_workloads.py tabc5lo 5" PROF_KERNEL="k_trace_lane<gr::TabulatedMetric" bash scripts/profile_pmc.sh ${T}_tabc5lo
+PROF_F32=1 PROF_CMD="scripts/sibling_workloads.py tabc5f32 5" PROF_KERNEL="gr32::" bash scripts/profile_pmc.sh ${T}_tabc5f32
 PROF_CMD="scripts/sibling_workloads.py applypf" PROF_KERNEL="k_apply_pf" bash scripts/profile_pmc.sh ${T}_applypf
 PROF_CMD="scripts/sibling_workloads.py endpoints" PROF_KERNEL="k_trace_lane<gr::KerrFamily" bash scripts/profile_pmc.sh ${T}_endpoints
 PROF_CMD="scripts/sibling_workloads.py corona" PROF_KERNEL="k_trace" bash scripts/profile_pmc.sh ${T}_corona
