@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .orthonormalization import tetradframe
+from .orthonormalization import tetradframe, tetradframe_batch
 from .planes import GeometricGrid
 from .status import StatusCodes
 from .tracing import domain_upper_hemisphere, tracegeodesics as _tracegeodesics
@@ -107,7 +107,7 @@ def sample_angles(sampler, i, N):
 
 
 def _cart_to_spher_jacobian(θ, ϕ):
-    s, c, sp, cp = math.sin(θ), math.cos(θ), math.sin(ϕ), math.cos(ϕ)
+    s, c, sp, cp = float(np.sin(θ)), float(np.cos(θ)), float(np.sin(ϕ)), float(np.cos(ϕ))      # (numpy's: as _sky_rows_batch)
     return np.array([[s * cp, s * sp, c], [c * cp, c * sp, -s], [-sp, cp, 0.0]])
 
 
@@ -116,8 +116,20 @@ def _cart_local_direction(θ, ϕ):
     return np.stack([np.sin(θ) * np.cos(ϕ), np.sin(θ) * np.sin(ϕ), np.cos(θ) + 0.0 * ϕ], axis=-1)
 
 
+def _components_at(m, x):
+    """the five metric components at x with numpy's sin / cos (what the array routes below use: the same bits either way)"""
+    return tuple(float(q) for q in m._components(x[1], float(np.sin(x[2])), float(np.cos(x[2]))))
+
+
+def _metric_matrix(g):
+    G4 = np.zeros((4, 4))
+    G4[0, 0], G4[1, 1], G4[2, 2], G4[3, 3] = g[0], g[1], g[2], g[3]
+    G4[0, 3] = G4[3, 0] = g[4]
+    return G4
+
+
 def tetradframe_matrix(m, x, v):
-    return np.column_stack(tetradframe(m.metric(x), v))
+    return np.column_stack(tetradframe(_metric_matrix(_components_at(m, x)), v))
 
 
 def sky_angles_to_velocity(m, x, v_source, θ, ϕ, E0=1.0):
@@ -195,16 +207,36 @@ class SourceVelocities:
     @staticmethod
     def co_rotating(m, x):
         """the source co-rotates with the (Keplerian) disc below it"""
-        s = math.sin(x[2])
+        s = float(np.sin(x[2]))
         v = circular_fourvelocity(m, np.array([max(m.isco(), x[1] * s)]))[0] * s
-        g = m.metric_components(x[1], x[2])
+        g = _components_at(m, x)
         v = v / math.sqrt(abs(_dot(g, v, v)))
         return np.array([constrain_time(g, v, 1.0), v[1], v[2], v[3]])
 
     @staticmethod
     def stationary(m, x):
-        g = m.metric_components(x[1], x[2])
+        g = _components_at(m, x)
         return np.array([1.0 / math.sqrt(-g[0]), 0.0, 0.0, 0.0])
+
+    @staticmethod
+    def batch(vf, m, x):
+        """vf(m, x[k]) for every row of x (n, 4), or None for a velocity function this module does not know (a user's callable: the
+        caller then asks sample by sample)."""
+        x = np.asarray(x, dtype=np.float64)
+        s, c = np.sin(x[:, 2]), np.cos(x[:, 2])
+        g = [np.asarray(q, dtype=np.float64) + 0.0 * x[:, 1] for q in m._components(x[:, 1], s, c)]
+        out = np.zeros_like(x)
+        if vf is SourceVelocities.stationary:
+            out[:, 0] = 1.0 / np.sqrt(-g[0])
+            return out
+        if vf is SourceVelocities.co_rotating:
+            v = circular_fourvelocity(m, np.maximum(m.isco(), x[:, 1] * s)) * s[:, None]
+            v = v / np.sqrt(np.abs(_dot(g, v, v)))[:, None]
+            disc = -g[0] * g[1] * v[:, 1] ** 2 - g[0] * g[2] * v[:, 2] ** 2 - g[0] - (g[0] * g[3] - g[4] ** 2) * v[:, 3] ** 2      # constrain_time, μ = 1
+            out[:, 0] = -(g[4] * v[:, 3] + np.sqrt(disc)) / g[0]
+            out[:, 1:] = v[:, 1:]
+            return out
+        return None
 
 
 class RingCorona(AbstractCoronaModel):
@@ -248,8 +280,21 @@ class DiscCorona(AbstractCoronaModel):
 
     def sample_position_velocity(self, m):
         ρ = self.rng.random() * self.r
-        x = np.array([0.0, math.hypot(ρ, self.h), math.atan2(ρ, self.h), 0.0])      # (x, y) flipped: off the z axis
+        # (numpy's hypot / arctan2, as sample_positions: the two routes give the same bits)
+        x = np.array([0.0, float(np.hypot(ρ, self.h)), float(np.arctan2(ρ, self.h)), 0.0])      # (x, y) flipped: off the z axis
         return x, np.asarray(self.vf(m, x), dtype=np.float64)
+
+    def sample_positions(self, m, n, r_reject=0.0):
+        """The positions of the next n calls of sample_position_velocity -- the same draws in the same order, a draw inside `r_reject`
+        redrawn as corona-models.jl:1-33 does -- as an (n, 4) array."""
+        xs = np.zeros((0, 4))
+        if math.hypot(self.r, self.h) < r_reject:
+            raise ValueError("every position of the source lies inside 1.9 inner radii")
+        while xs.shape[0] < n:
+            ρ = self.rng.random(n - xs.shape[0]) * self.r
+            x = np.stack([np.zeros_like(ρ), np.hypot(ρ, self.h), np.arctan2(ρ, self.h), np.zeros_like(ρ)], axis=1)
+            xs = np.concatenate([xs, x[x[:, 1] >= r_reject]])
+        return xs
 
 
 def oblate_spheroid_to_spherical(x, h, a):
@@ -274,11 +319,22 @@ def sample_position_direction_velocity(m, model, sampler, N):
         x[2] = min(max(x[2], 1e-3), math.pi - 1e-3)             # avoid coordinate singularities :18-24
         vs = sky_angles_to_velocity(m, x, v, θ, ϕ)
         return np.tile(x, (N, 1)), vs, np.tile(v, (N, 1))
+    batch = _sky_rows_batch(m, model, int(N), rmin) if hasattr(model, "sample_positions") else None
+    if batch is not None:
+        # every sample's position and matrix at once (the rows the device route hands over): v = M (1, -k̂)
+        rows, vsrc = batch
+        hat = -_cart_local_direction(θ, ϕ)
+        pb = np.concatenate([np.ones((int(N), 1)), hat], axis=1)
+        return rows[:, 0:4].copy(), np.einsum("nij,nj->ni", rows[:, 4:20].reshape(int(N), 4, 4), pb), vsrc
     xs, vs, vsrc = np.zeros((N, 4)), np.zeros((N, 4)), np.zeros((N, 4))
     for k in range(N):
         x, v = model.sample_position_velocity(m)
+        redraws = 0
         while x[1] < rmin:
             x, v = model.sample_position_velocity(m)
+            redraws += 1
+            if redraws > 100_000:
+                raise ValueError("source positions lie inside 1.9 inner radii")
         x = np.array(x, dtype=np.float64)
         x[2] = min(max(x[2], 1e-3), math.pi - 1e-3)
         xs[k], vsrc[k] = x, v
@@ -544,6 +600,41 @@ def build_radial_profile(m, spec, points, source_velocities, *, grid=None, N=100
 # ------------------------------------------------------------------------------------------
 # corona -> disc on the device (gr_corona_trace / gr_corona_bin)
 # ------------------------------------------------------------------------------------------
+def _sky_rows_batch(m, model, n, rmin):
+    """The 28-double rows of n samples of a source without one position, all at once (a Python loop over the samples costs 0.3 ms
+    each: five minutes for 10⁶): positions from the model's own generator in the order its sample_position_velocity would draw them,
+    velocities from SourceVelocities.batch, tetrads from tetradframe_batch.  None when the model's velocity function is not one this
+    module can evaluate on arrays (the caller then loops)."""
+    state = model.rng.bit_generator.state
+    xs = model.sample_positions(m, n, rmin)
+    with np.errstate(invalid="ignore"):
+        vs = SourceVelocities.batch(model.vf, m, xs)          # (the velocity belongs to the position as drawn, the clamp comes after)
+    xs[:, 2] = np.clip(xs[:, 2], 1e-3, math.pi - 1e-3)
+    if vs is None or not np.all(np.isfinite(vs)):
+        model.rng.bit_generator.state = state      # nothing drawn
+        return None
+    s, c = np.sin(xs[:, 2]), np.cos(xs[:, 2])
+    g = [np.asarray(q, dtype=np.float64) + 0.0 * s for q in m._components(xs[:, 1], s, c)]
+    G4 = np.zeros((n, 4, 4))
+    G4[:, 0, 0], G4[:, 1, 1], G4[:, 2, 2], G4[:, 3, 3] = g[0], g[1], g[2], g[3]
+    G4[:, 0, 3] = G4[:, 3, 0] = g[4]
+    T = np.stack(tetradframe_batch(G4, vs), axis=2)            # columns: the four vectors (tetradframe_matrix)
+    sp, cp = np.sin(xs[:, 3]), np.cos(xs[:, 3])
+    B = np.zeros((n, 4, 4))
+    B[:, 0, 0] = 1.0
+    B[:, 1, 1], B[:, 1, 2], B[:, 1, 3] = s * cp, s * sp, c                    # _cart_to_spher_jacobian
+    B[:, 2, 1], B[:, 2, 2], B[:, 2, 3] = c * cp, c * sp, -s
+    B[:, 3, 1], B[:, 3, 2] = -sp, cp
+    rows = np.zeros((n, 28))
+    rows[:, 0:4] = xs
+    rows[:, 4:20] = np.einsum("nij,njk->nik", T, B).reshape(n, 16)
+    rows[:, 20] = g[0] * vs[:, 0] + g[4] * vs[:, 3]
+    rows[:, 21], rows[:, 22] = g[1] * vs[:, 1], g[2] * vs[:, 2]
+    rows[:, 23] = g[3] * vs[:, 3] + g[4] * vs[:, 0]
+    rows[:, 24], rows[:, 27] = g[0], g[4]
+    return rows, vs
+
+
 def sky_rayset(m, model, sampler, n_samples):
     """The gr_rayset of `tracegeodesics(m, model, ...)` for a source at one position: the tetrad and the
     Cartesian -> spherical Jacobian go in as one matrix (v = T (1, J k̂), samplers.jl:81-99) and sample number ->
@@ -573,14 +664,21 @@ def sky_rayset(m, model, sampler, n_samples):
         # (gr_rayset.sky_rows), in the order corona-models.jl:1-33 draws them (rejecting positions inside 1.9 inner radii).
         rows = np.zeros((int(n_samples), 28))
         vsrc = np.zeros((int(n_samples), 4))
-        for k in range(int(n_samples)):
+        batch = _sky_rows_batch(m, model, int(n_samples), rmin) if hasattr(model, "sample_positions") else None
+        if batch is not None:
+            rows, vsrc = batch
+        for k in range(int(n_samples) if batch is None else 0):
             xk, vk = model.sample_position_velocity(m)
+            redraws = 0
             while xk[1] < rmin:
                 xk, vk = model.sample_position_velocity(m)
+                redraws += 1
+                if redraws > 100_000:
+                    raise ValueError("source positions lie inside 1.9 inner radii")
             xk = np.array(xk, dtype=np.float64)
             xk[2] = min(max(xk[2], 1e-3), math.pi - 1e-3)
             vk = np.asarray(vk, dtype=np.float64)
-            g = m.metric_components(xk[1], xk[2])
+            g = _components_at(m, xk)
             rows[k, 0:4] = xk
             rows[k, 4:20] = matrix_at(xk, vk).ravel()
             rows[k, 20:24] = (g[0] * vk[0] + g[4] * vk[3], g[1] * vk[1], g[2] * vk[2], g[3] * vk[3] + g[4] * vk[0])

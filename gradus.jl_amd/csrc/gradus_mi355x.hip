@@ -568,11 +568,21 @@ __global__ void __launch_bounds__(256) k_sky_scale_g(double* rows, const double*
 // angle to 1 %: one base): the 64 rays of a wave then take the same number of steps to a few per cent AND the launch starts with its
 // longest waves -- a wave of 500-step rays takes 2 ms alone whenever it starts, and consecutive samples put one into every chunk.
 // Three launches: count per (class, chunk), one-workgroup exclusive scan, scatter.
+// A source with a position per sample (SkyParams.rows: DiscCorona) has no "one base per chunk": its base depends on where the sample
+// sits -- oracle step counts of a disc corona (r = 10, h = 5): +90 steps for positions next to the axis, -20 far from it.  Such rays
+// are sorted by (class, bucket of |sin θ| of the POSITION, chunk): eight buckets, the one next to the axis first.  Lane utilisation of
+// 64-ray waves by the oracle's counts, four chunks: 0.17 ... 0.56 in sample order, 0.21 ... 0.71 by class alone, 0.40 ... 0.83 with
+// the position bucket (DESIGN_measurements.md §M19).
 constexpr int kSkyChunk = 4096;
 constexpr int kSkyClasses = 32;
-__device__ __forceinline__ int sky_cost_class(const double x[4], const double v[4])
+constexpr int kSkyPosBuckets = 8;
+__device__ __forceinline__ int sky_cost_class(const double x[4], const double v[4], int nb, int& pos_bucket)
 {
     const double r = x[1], s = ::sin(x[2]), c = ::cos(x[2]);
+    {
+        const int b = (int)(::fabs(s) * (double)nb);
+        pos_bucket = b < 0 ? 0 : b >= nb ? nb - 1 : b;
+    }
     double er = v[1], et = r * v[2], ep = r * s * v[3];
     const double nrm = ::sqrt(er * er + et * et + ep * ep);
     if (!(nrm > 0.0) || !(nrm < 1e300)) return 0;
@@ -596,16 +606,17 @@ __device__ __forceinline__ int sky_cost_class(const double x[4], const double v[
     const int cls = (int)(cost * (1.0 / 12.0));
     return cls < 0 ? 0 : cls >= kSkyClasses ? kSkyClasses - 1 : cls;      // (NaN -> 0)
 }
-// counts / offsets: [kSkyClasses - 1 - class][chunks - 1 - chunk] -- the order of the dealt array (the last samples of a sky leave
-// upwards, away from the disc, and have the larger base: first within their class)
+// counts / offsets: [kSkyClasses - 1 - class][position bucket][chunks - 1 - chunk] -- the order of the dealt array (the last samples
+// of a sky leave upwards, away from the disc, and have the larger base: first within their class and bucket)
 template <bool COUNT>
 __global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p, double* out, unsigned* table)
 {
-    __shared__ int cnt[kSkyClasses];
+    __shared__ int cnt[kSkyClasses * kSkyPosBuckets];
+    const int nb = p.rows ? kSkyPosBuckets : 1;
     const int64_t base = (int64_t)blockIdx.x * kSkyChunk;
     const int64_t left = p.n - base;
     const int nloc = left < kSkyChunk ? (int)left : kSkyChunk;
-    if (threadIdx.x < kSkyClasses) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < kSkyClasses * kSkyPosBuckets) cnt[threadIdx.x] = 0;
     if (!COUNT && blockIdx.x == 0 && threadIdx.x == 0)
         for (int q = 0; q < 4; ++q) out[q] = p.x_obs[q];
     __syncthreads();
@@ -618,7 +629,9 @@ __global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p
         if (j < nloc) {
             double el, az;
             sky_sample(p, base + j, el, az, v[k], x[k], f[k]);
-            cls[k] = sky_cost_class(x[k], v[k]);
+            int pb;
+            const int c = sky_cost_class(x[k], v[k], nb, pb);
+            cls[k] = (kSkyClasses - 1 - c) * nb + pb;          // the cell's row in the table: expensive classes first
             pos[k] = atomicAdd(&cnt[cls[k]], 1);
         }
     }
@@ -626,13 +639,13 @@ __global__ void __launch_bounds__(1024) k_sky_velocities_dealt(const SkyParams p
     const unsigned col = chunks - 1u - blockIdx.x;
     if (COUNT) {
         __syncthreads();
-        if (threadIdx.x < kSkyClasses) table[(size_t)(kSkyClasses - 1 - (int)threadIdx.x) * chunks + col] = (unsigned)cnt[threadIdx.x];
+        if ((int)threadIdx.x < kSkyClasses * nb) table[(size_t)threadIdx.x * chunks + col] = (unsigned)cnt[threadIdx.x];
         return;
     }
 #pragma unroll
     for (int k = 0; k < kSkyChunk / 1024; ++k) {
         if (cls[k] < 0) continue;
-        sky_store(p, out, (int64_t)table[(size_t)(kSkyClasses - 1 - cls[k]) * chunks + col] + pos[k], v[k], x[k], f[k]);
+        sky_store(p, out, (int64_t)table[(size_t)cls[k] * chunks + col] + pos[k], v[k], x[k], f[k]);
     }
 }
 // in-place exclusive scan of `n` counts by one workgroup (n = 32 x chunks: 7808 for 10⁶ samples)
@@ -680,9 +693,10 @@ static int32_t sky_prepare(gr_ctx* ctx, Params& p, Cold& cold, hipStream_t strea
     sp.rows = ctx->sky_rows;
     if (sky_dealt(ctx, p.n)) {
         const unsigned chunks = (unsigned)((p.n + kSkyChunk - 1) / kSkyChunk);
-        if ((rc = ensure((void**)&ctx->d_sky_table, &ctx->sky_table_bytes, sizeof(unsigned) * kSkyClasses * (size_t)chunks)) != GR_OK) return rc;
+        const int64_t cells = (int64_t)kSkyClasses * (sp.rows ? kSkyPosBuckets : 1) * chunks;
+        if ((rc = ensure((void**)&ctx->d_sky_table, &ctx->sky_table_bytes, sizeof(unsigned) * (size_t)cells)) != GR_OK) return rc;
         hipLaunchKernelGGL(k_sky_velocities_dealt<true>, dim3(chunks), dim3(1024), 0, stream, sp, ctx->d_sky, ctx->d_sky_table);
-        hipLaunchKernelGGL(k_sky_scan, dim3(1), dim3(1024), 0, stream, ctx->d_sky_table, (int64_t)kSkyClasses * chunks);
+        hipLaunchKernelGGL(k_sky_scan, dim3(1), dim3(1024), 0, stream, ctx->d_sky_table, cells);
         hipLaunchKernelGGL(k_sky_velocities_dealt<false>, dim3(chunks), dim3(1024), 0, stream, sp, ctx->d_sky, ctx->d_sky_table);
     } else
         hipLaunchKernelGGL(k_sky_velocities, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, sp, ctx->d_sky);

@@ -10,7 +10,13 @@ import numpy as np
 
 def dotproduct(g, v1, v2):
     # dotproduct(g, v1, v2) = _fast_dot(g * v1, v2)   :3-16
-    return float(np.dot(g @ v1, v2))
+    # (sums written out in one fixed order -- the order _bdot below uses on arrays: a tetrad built sample by sample and the same
+    # tetrad built for many samples at once are then the same bits, whatever BLAS would have made of a 4 x 4 product)
+    s = 0.0
+    for i in range(4):
+        gi = g[i]
+        s = s + (((gi[0] * v1[0] + gi[1] * v1[1]) + gi[2] * v1[2]) + gi[3] * v1[3]) * v2[i]
+    return float(s)
 
 
 def propernorm(g, v):
@@ -28,11 +34,17 @@ def projectbasis(g, basis, v):
     return s
 
 
+# The reference's loop (`while sum(p) > tol`, :37-47) tests the SUM of the projection's components: once they are rounding noise
+# (±5e-16 against tol = 9e-16) the sign pattern of that noise decides whether it ends, and for some inputs it never does.  A pass
+# changes v by an ulp; sixteen are the same vector as a thousand.
+kGuard = 16
+
+
 def gramschmidt(v, basis, g, tol=4 * np.finfo(np.float64).eps):
     v = np.array(v, dtype=np.float64)
     p = projectbasis(g, basis, v)
     guard = 0
-    while p.sum() > tol and guard < 1000:
+    while ((p[0] + p[1]) + p[2]) + p[3] > tol and guard < kGuard:
         v = v - p
         p = projectbasis(g, basis, v)
         guard += 1
@@ -87,3 +99,69 @@ def lnrbasis_matrix(m, x):
 
 def lnrframe_matrix(m, x):
     return np.column_stack(lnrframe(m.metric(x)))
+
+
+# ---- the same, for MANY (g, v) at once (a corona without one position: a tetrad per sample) ----
+def _bdot(g, a, b):
+    # dotproduct per sample, in dotproduct's order of operations: g (n, 4, 4), a, b (n, 4)
+    s = 0.0
+    for i in range(4):
+        s = s + (((g[:, i, 0] * a[:, 0] + g[:, i, 1] * a[:, 1]) + g[:, i, 2] * a[:, 2]) + g[:, i, 3] * a[:, 3]) * b[:, i]
+    return s
+
+
+def _bproject(g, basis, v):
+    s = np.zeros_like(v)
+    for e in basis:
+        s = s + (_bdot(g, v, e) / _bdot(g, e, e))[:, None] * e
+    return s
+
+
+def _bgramschmidt(v, basis, g, tol=4 * np.finfo(np.float64).eps):
+    """gramschmidt() per sample: the `sum(p) > tol` loop runs for the samples that still ask for it."""
+    v = np.array(v, dtype=np.float64)
+    p = _bproject(g, basis, v)
+    psum = lambda q: ((q[:, 0] + q[:, 1]) + q[:, 2]) + q[:, 3]
+    active = psum(p) > tol
+    guard = 0
+    while active.any() and guard < kGuard:
+        idx = np.nonzero(active)[0]
+        v[idx] = v[idx] - p[idx]
+        p[idx] = _bproject(g[idx], [e[idx] for e in basis], v[idx])
+        active[idx] = psum(p[idx]) > tol
+        guard += 1
+    v = v - p
+    return v / np.sqrt(np.abs(_bdot(g, v, v)))[:, None]
+
+
+def tetradframe_batch(g, v):
+    """tetradframe(g[k], v[k]) for every k: g (n, 4, 4), v (n, 4) -> four arrays (n, 4) ordered (t, r, θ, ϕ).  Samples are grouped by
+    which components of v vanish (the branch structure of :75-103 depends on nothing else)."""
+    g, v = np.asarray(g, dtype=np.float64), np.asarray(v, dtype=np.float64)
+    n = v.shape[0]
+    v1 = v / np.sqrt(np.abs(_bdot(g, v, v)))[:, None]
+    out = [np.zeros((n, 4)) for _ in range(4)]
+    pattern = (v1 != 0)
+    for pat in np.unique(pattern, axis=0):
+        sel = np.nonzero(np.all(pattern == pat, axis=1))[0]
+        state = [bool(c) for c in pat]
+        if sum(state) == 1:
+            state = [True, False, False, True]
+        permutations = 4
+        for i in range(1, 4):
+            if state[i]:
+                permutations = i
+                break
+        gs, e1 = g[sel], v1[sel]
+        start = lambda st: np.tile(np.array(st, dtype=np.float64), (sel.size, 1))
+        e2 = _bgramschmidt(start(state), (e1,), gs)
+        state = [a or b for a, b in zip(state, _tetrad_permute(state))]
+        e3 = _bgramschmidt(start(state), (e1, e2), gs)
+        state = [a or b for a, b in zip(state, _tetrad_permute(state))]
+        e4 = _bgramschmidt(start(state), (e1, e2, e3), gs)
+        ret = (e1, e2, e3, e4)
+        for _ in range(2, permutations + 1):
+            ret = _tetrad_permute(ret)
+        for q in range(4):
+            out[q][sel] = ret[q]
+    return tuple(out)

@@ -211,6 +211,10 @@ elif which == "corona":
         m = G.TabulatedMetric(m)
     d = G.ThinDisc(0.0, 500.0)
     model = G.LampPostModel(h=10.0)
+    if os.environ.get("CORONA_MODEL") == "disc":          # a source with a position per sample (28 doubles per sample in)
+        model = G.DiscCorona(G.SourceVelocities.co_rotating, 10.0, 5.0, seed=1)
+    elif os.environ.get("CORONA_MODEL") == "ring":
+        model = G.RingCorona(G.SourceVelocities.co_rotating, 8.0, 6.0)
     s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
     n = int(os.environ.get("CORONA_SAMPLES", "1000000"))
     call = []

@@ -92,6 +92,44 @@ def test_sky_rayset_of_a_source_without_one_position_brings_rows(G):
         G.corona.sky_rayset(G.KerrMetric(1.0, 0.0), G.LampPostModel(h=2.5), G.EvenSampler(), 8)
 
 
+def test_rows_of_many_samples_at_once_equal_the_rows_sample_by_sample(G):
+    """A source without one position brings 28 doubles per sample; the host forms them for all samples at once (positions from the
+    model's generator in the order sample_position_velocity would draw them, velocities and Gram-Schmidt tetrads on arrays: 10 µs per
+    sample where the loop took 330).  Same draws, same generator state afterwards, rows equal to the last bits of the 4 x 4 products
+    -- also for the samples next to the polar axis, where the tetrad's loop (`while sum(p) > tol`) is decided by rounding."""
+    K = G.corona
+    s = G.EvenSampler(G.BothHemispheres(), G.GoldenSpiralGenerator())
+
+    class OneByOne:            # the same model without sample_positions: sky_rayset asks sample by sample
+        point_source = fixed_position = False
+
+        def __init__(self, model):
+            self.model = model
+
+        def sample_position_velocity(self, m):
+            return self.model.sample_position_velocity(m)
+
+    for m in (G.KerrMetric(1.0, 0.998), G.JohannsenMetric(1.0, 0.6, 1.0, 0.0, 0.0, 0.5)):
+        for vf in (G.SourceVelocities.co_rotating, G.SourceVelocities.stationary):
+            n = 400 if isinstance(m, G.KerrMetric) else 40
+            a, b = G.DiscCorona(vf, 10.0, 5.0, seed=17), G.DiscCorona(vf, 10.0, 5.0, seed=17)
+            rows_a = K.sky_rayset(m, a, s, n)[1][1]
+            rows_b = K.sky_rayset(m, OneByOne(b), s, n)[1][1]
+            np.testing.assert_array_equal(rows_a[:, 0:4], rows_b[:, 0:4])
+            np.testing.assert_allclose(rows_a, rows_b, rtol=1e-14, atol=1e-14 * np.abs(rows_b).max())
+            assert a.rng.bit_generator.state == b.rng.bit_generator.state
+            assert np.min(rows_a[:, 2]) < 0.05                       # samples next to the axis are among them
+    # the record route's arrays come from the same rows
+    xs, vs, vsrc = K.sample_position_direction_velocity(G.KerrMetric(1.0, 0.9), G.DiscCorona(G.SourceVelocities.co_rotating, 6.0, 4.0, seed=3), s, 300)
+    xo, vo, vso = K.sample_position_direction_velocity(G.KerrMetric(1.0, 0.9), OneByOne(G.DiscCorona(G.SourceVelocities.co_rotating, 6.0, 4.0, seed=3)), s, 300)
+    np.testing.assert_array_equal(xs, xo)
+    np.testing.assert_allclose(vs, vo, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(vsrc, vso, rtol=1e-14)
+    # a source that lies inside 1.9 inner radii altogether is refused (the loop used to redraw for ever)
+    with pytest.raises(ValueError, match="inside 1.9 inner radii"):
+        K.sky_rayset(G.JohannsenMetric(1.0, 0.6, 1.0, 0.0, 0.0, 0.5), G.DiscCorona(G.SourceVelocities.co_rotating, 3.0, 1.5, seed=1), s, 10)
+
+
 # ---------------- gpu ----------------
 @pytest.mark.gpu
 def test_sky_rays_start_as_the_host_sampler_says(G, ens):
@@ -213,8 +251,12 @@ def test_disc_corona_on_the_device_equals_the_record_route(G, ens, monkeypatch):
     rec = K.emissivity_profile(m, d, mk(), n_samples=n, sampler=s, N=40, ensemble=ens)
     monkeypatch.delenv("GRADUS_MI355X_DEVICE_CORONA")
     np.testing.assert_allclose(dev.radii, rec.radii, rtol=1e-12)
+    # (The grid's last edge IS the largest hit radius, rounded by the grid's own arithmetic: the one ray that defines it lands in
+    # the last bin or in the one before by a bit of that rounding -- the two routes' rays differ in their last bits -- so the last
+    # two bins are compared as one.)
     ok = np.isfinite(rec.ε)
-    np.testing.assert_array_equal(np.isfinite(dev.ε), ok)
+    np.testing.assert_array_equal(np.isfinite(dev.ε)[:-1], ok[:-1])
+    ok[-2:] = False
     assert ok.sum() > 25
     np.testing.assert_allclose(dev.ε[ok], rec.ε[ok], rtol=1e-9)
     np.testing.assert_allclose(dev.t[ok], rec.t[ok], rtol=1e-10)
