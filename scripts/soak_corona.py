@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test of the corona -> disc device route (gr_rayset.sky_*, gr_corona_trace, gr_corona_bin): N random scenes, each through
 `emissivity_profile` twice -- the device route and the record route (host-built (x, v) arrays, 152-B records, numpy reductions;
-GRADUS_MI355X_DEVICE_CORONA=0) -- compared bin by bin.  Random metric x source model (lamp post, beamed point source, ring
+GRADUS_MI355X_DEVICE_CORONA=0) -- compared bin by bin.  Random metric x source model (lamp post, beamed point source, ring corona, disc corona with a position per sample; ring
 corona) x sampler x generator x domain x disc x number of samples (1 ... 30 000, so that last waves of every size occur) x bins.
 
     python scripts/soak_corona.py [n_scenes] [seed] [only]
@@ -38,8 +38,15 @@ for case in range(n_scenes):
         # the table / the callable), both routes on the tabulated kernels
         base_ = m
         m = G.TabulatedMetric(lambda r, th, b=base_: b._components(r, np.sin(th), np.cos(th)), inner_radius=base_.inner_radius(), max_refinements=1)
-    kind = int(rng.integers(0, 3))
-    if kind == 0:
+    kind = int(rng.integers(0, 4 if os.environ.get("SOAK_DISC_CORONA", "1") != "0" else 3))
+    mkmodel = None
+    if kind == 3:
+        # a source with a position per sample: the two routes must see the SAME draws -- a fresh model with the scene's seed for each
+        vf_ = G.SourceVelocities.co_rotating if rng.random() < 0.5 else G.SourceVelocities.stationary
+        r_, h_ = U(1.0, 20.0), U(2.0, 15.0)
+        mkmodel = lambda: G.DiscCorona(vf_, r_, h_, seed=int(seed * 1000 + case))
+        model = mkmodel()
+    elif kind == 0:
         model = G.LampPostModel(h=U(2.5, 40.0))
     elif kind == 1:
         model = G.BeamedPointSource(U(3.0, 30.0), U(-0.8, 0.8))
@@ -56,23 +63,23 @@ for case in range(n_scenes):
     kernel = int(rng.integers(0, 3))
     if only is not None and case != only:
         continue
-    desc = f"{case}: {m} {model.__class__.__name__}{vars(model) if hasattr(model, '__dict__') and kind == 2 else model} {Sampler.__name__}/{gen.__name__ if hasattr(gen, '__name__') else 'Random'}/{dom.__name__} {d} n={n} N={N} kernel={kernel}"
+    desc = f"{case}: {m} {model.__class__.__name__}{({k_: v_ for k_, v_ in vars(model).items() if k_ != 'rng'}) if hasattr(model, '__dict__') and kind >= 2 else model} {Sampler.__name__}/{gen.__name__ if hasattr(gen, '__name__') else 'Random'}/{dom.__name__} {d} n={n} N={N} kernel={kernel}"
     ens.set("kernel", kernel).set("precision", 64)
     kw = dict(n_samples=n, N=N, ensemble=ens)
     try:
         os.environ["GRADUS_MI355X_DEVICE_CORONA"] = "0"
-        host = G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+        host = G.emissivity_profile(m, d, model if mkmodel is None else mkmodel(), sampler=mk(), **kw)
     except Exception as e:          # the record route refuses the scene (source inside 1.9 r_inner, no hit at all): so must the device route
         os.environ["GRADUS_MI355X_DEVICE_CORONA"] = "1"
         try:
-            G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+            G.emissivity_profile(m, d, model if mkmodel is None else mkmodel(), sampler=mk(), **kw)
             print("FAIL", desc, "record route raised", type(e).__name__, "the device route did not")
             bad.append(case)
         except Exception as e2:
             print("skip", desc, "->", type(e).__name__, "/", type(e2).__name__, str(e)[:80])
         continue
     os.environ["GRADUS_MI355X_DEVICE_CORONA"] = "1"
-    dev = G.emissivity_profile(m, d, model, sampler=mk(), **kw)
+    dev = G.emissivity_profile(m, d, model if mkmodel is None else mkmodel(), sampler=mk(), **kw)
     scenes += 1
     inner = slice(0, -2) if host.radii.size > 4 else slice(0, 0)
     ok_r = host.radii.shape == dev.radii.shape and np.allclose(dev.radii, host.radii, rtol=1e-9)
