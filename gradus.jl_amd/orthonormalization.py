@@ -102,18 +102,19 @@ def lnrframe_matrix(m, x):
 
 
 # ---- the same, for MANY (g, v) at once (a corona without one position: a tetrad per sample) ----
+# Inside, arrays are COMPONENT-major -- g (4, 4, n), vectors (4, n) -- so that every operand of the sums below is a contiguous vector.
 def _bdot(g, a, b):
-    # dotproduct per sample, in dotproduct's order of operations: g (n, 4, 4), a, b (n, 4)
+    # dotproduct per sample, in dotproduct's order of operations
     s = 0.0
     for i in range(4):
-        s = s + (((g[:, i, 0] * a[:, 0] + g[:, i, 1] * a[:, 1]) + g[:, i, 2] * a[:, 2]) + g[:, i, 3] * a[:, 3]) * b[:, i]
+        s = s + (((g[i][0] * a[0] + g[i][1] * a[1]) + g[i][2] * a[2]) + g[i][3] * a[3]) * b[i]
     return s
 
 
 def _bproject(g, basis, v):
     s = np.zeros_like(v)
     for e in basis:
-        s = s + (_bdot(g, v, e) / _bdot(g, e, e))[:, None] * e
+        s = s + (_bdot(g, v, e) / _bdot(g, e, e)) * e
     return s
 
 
@@ -121,30 +122,31 @@ def _bgramschmidt(v, basis, g, tol=4 * np.finfo(np.float64).eps):
     """gramschmidt() per sample: the `sum(p) > tol` loop runs for the samples that still ask for it."""
     v = np.array(v, dtype=np.float64)
     p = _bproject(g, basis, v)
-    psum = lambda q: ((q[:, 0] + q[:, 1]) + q[:, 2]) + q[:, 3]
+    psum = lambda q: ((q[0] + q[1]) + q[2]) + q[3]
     active = psum(p) > tol
     guard = 0
     while active.any() and guard < kGuard:
         idx = np.nonzero(active)[0]
-        v[idx] = v[idx] - p[idx]
-        p[idx] = _bproject(g[idx], [e[idx] for e in basis], v[idx])
-        active[idx] = psum(p[idx]) > tol
+        v[:, idx] = v[:, idx] - p[:, idx]
+        p[:, idx] = _bproject(g[:, :, idx], [e[:, idx] for e in basis], v[:, idx])
+        active[idx] = psum(p[:, idx]) > tol
         guard += 1
     v = v - p
-    return v / np.sqrt(np.abs(_bdot(g, v, v)))[:, None]
+    return v / np.sqrt(np.abs(_bdot(g, v, v)))
 
 
 def tetradframe_batch(g, v):
     """tetradframe(g[k], v[k]) for every k: g (n, 4, 4), v (n, 4) -> four arrays (n, 4) ordered (t, r, θ, ϕ).  Samples are grouped by
     which components of v vanish (the branch structure of :75-103 depends on nothing else)."""
-    g, v = np.asarray(g, dtype=np.float64), np.asarray(v, dtype=np.float64)
-    n = v.shape[0]
-    v1 = v / np.sqrt(np.abs(_bdot(g, v, v)))[:, None]
-    out = [np.zeros((n, 4)) for _ in range(4)]
-    pattern = (v1 != 0)
-    for pat in np.unique(pattern, axis=0):
-        sel = np.nonzero(np.all(pattern == pat, axis=1))[0]
-        state = [bool(c) for c in pat]
+    g = np.ascontiguousarray(np.asarray(g, dtype=np.float64).transpose(1, 2, 0))
+    v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).T)
+    n = v.shape[1]
+    v1 = v / np.sqrt(np.abs(_bdot(g, v, v)))
+    out = [np.zeros((4, n)) for _ in range(4)]
+    code = np.array([1, 2, 4, 8]) @ (v1 != 0)          # which components vanish, as one integer per sample
+    for pc in np.unique(code):
+        sel = np.nonzero(code == pc)[0]
+        state = [bool(pc & (1 << q)) for q in range(4)]
         if sum(state) == 1:
             state = [True, False, False, True]
         permutations = 4
@@ -152,8 +154,9 @@ def tetradframe_batch(g, v):
             if state[i]:
                 permutations = i
                 break
-        gs, e1 = g[sel], v1[sel]
-        start = lambda st: np.tile(np.array(st, dtype=np.float64), (sel.size, 1))
+        whole = sel.size == n
+        gs, e1 = (g, v1) if whole else (np.ascontiguousarray(g[:, :, sel]), np.ascontiguousarray(v1[:, sel]))
+        start = lambda st: np.repeat(np.array(st, dtype=np.float64)[:, None], sel.size, axis=1)
         e2 = _bgramschmidt(start(state), (e1,), gs)
         state = [a or b for a, b in zip(state, _tetrad_permute(state))]
         e3 = _bgramschmidt(start(state), (e1, e2), gs)
@@ -163,5 +166,5 @@ def tetradframe_batch(g, v):
         for _ in range(2, permutations + 1):
             ret = _tetrad_permute(ret)
         for q in range(4):
-            out[q][sel] = ret[q]
-    return tuple(out)
+            out[q][:, sel] = ret[q]
+    return tuple(np.ascontiguousarray(o.T) for o in out)
