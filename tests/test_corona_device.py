@@ -282,6 +282,12 @@ def test_rays_dealt_by_cost_are_a_permutation_of_the_samples(G, ens):
         np.testing.assert_array_equal(prof[1].ε, prof[0].ε)
         np.testing.assert_array_equal(prof[1].t, prof[0].t)
         assert np.isfinite(prof[1].ε).sum() > 40
+    # ... and every context of an ensemble deals its own share (three shares of 20 000 samples each, all of them dealt): the same bits
+    ens3 = G.EnsembleMI355X(devices=[0, 0, 0])
+    one = K.device_radial_profile(m, d, G.LampPostModel(h=7.0), sampler=s, n_samples=60_000, N=60, ensemble=ens)
+    three = K.device_radial_profile(m, d, G.LampPostModel(h=7.0), sampler=s, n_samples=60_000, N=60, ensemble=ens3)
+    np.testing.assert_array_equal(three.ε, one.ε)
+    np.testing.assert_array_equal(three.t, one.t)
 
 
 @pytest.mark.gpu
